@@ -1,0 +1,89 @@
+"""ctypes binding of libhx_mi355.so (the C ABI declared in include/hirl4ucav.h).
+
+There is NO fallback: if the HIP extension is missing or a call fails, this raises.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C hirl4ucav_amd/csrc``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libhx_mi355.so")
+
+ENV_WORDS, OBS_DIM, ACT_DIM, ROW_WORDS = 37, 13, 4, 32
+STAT_NAMES = ("episodes", "kills", "fire_success_episodes", "time_limit", "fires", "good_fires", "locked_steps", "env_steps")
+
+F_LOCKED_PREV, F_LOCKED, F_SLOT_PREV, F_SLOT, F_FIRED, F_FIRE_SUCCESS, F_EPISODE_SUCCESS, F_DONE = (1 << i for i in range(8))
+F_SCEN_SHIFT = 8
+F_SERP_POS, F_SERP_LONG, F_M_ACTIVE, F_M_GUIDED, F_SIM_SLOT = (1 << i for i in range(10, 15))
+
+_vp, _i32, _i64, _u32, _u64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_float
+
+
+class HxStepOpts(ctypes.Structure):
+    _fields_ = [("max_step", _i32), ("auto_reset", _i32), ("randomize", _i32), ("env_id0", _u32), ("seed", _u64),
+                ("episode_ctr", _vp), ("ring", _vp), ("ring_success", _vp), ("cap", _i64), ("total", _vp), ("stats", _vp)]
+
+
+class HxError(RuntimeError):
+    pass
+
+
+_SIGNATURES = {
+    "hx_env_reset": [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _u64, _u32, _vp, _vp, _vp],
+    "hx_env_step": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(HxStepOpts), _vp],
+    "hx_env_rearm": [_vp, _i64, _i64, _vp, _vp],
+    "hx_label_transitions": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises HxError with build instructions when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise HxError(f"{SO_PATH} not found: the HIP extension is not built (run __graft_entry__.build() or "
+                      f"`make -C hirl4ucav_amd/csrc`). There is no CPU fallback.")
+    # torch first: libhx_mi355.so must bind to the SAME HIP runtime (libamdhip64) torch has loaded, because
+    # device pointers and streams are shared with torch.  Loaded the other way round the process would hold two
+    # runtimes and ours would see no device.
+    import torch  # noqa: F401
+
+    L = ctypes.CDLL(SO_PATH)
+    L.hx_last_error.restype = ctypes.c_char_p
+    L.hx_version.restype = ctypes.c_int
+    for name, args in _SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def register(name, argtypes):
+    """Used by the other binding modules to add their entry points."""
+    _SIGNATURES[name] = argtypes
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+
+
+def call(name, *args):
+    L = load()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise HxError(f"{name} failed ({rc}): {L.hx_last_error().decode()}")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,107 @@
+/*
+ * hirl4ucav.h — C ABI of the MI355X-native hot path of HIRL4UCAV (libhx_mi355.so).
+ *
+ * The reference (zrc0622/HIRL4UCAV) is pure Python and has no FFI; its "operator interface" for this path is
+ * the duck-typed env / agent API.  The Python mirror of that API lives in hirl4ucav_amd/ and
+ * calls ONLY the functions below (ctypes).  Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  Every pointer is DEVICE memory owned by the caller unless it says
+ *     "host".  The library never allocates caller-visible memory and never synchronises: all work is enqueued
+ *     on `stream` (a hipStream_t passed as void*; NULL = the default stream).
+ *   - return value: 0 = ok, negative = error (HX_ERR_*); hx_last_error() returns a thread-local message.
+ *   - thread-compatible: no global mutable state besides the thread-local error string.
+ *
+ * Env state layout (struct-of-arrays, fp32 words): word w of env i is state[w * stride + i], stride >= n.
+ * HX_ENV_WORDS = 37 words = 148 B per env (SURVEY.md 8d canonical state):
+ *     0..2  ally position (x, y = altitude, z)      13..15 opponent position
+ *     3..5  ally velocity                           16..18 opponent velocity
+ *     6..9  ally attitude quaternion (w, x, y, z)   19..22 opponent quaternion
+ *    10..12 ally control levels (pitch, roll, yaw)  23..25 opponent control levels
+ *    26..28 missile position   29..31 missile velocity
+ *    32 opponent health   33 lock timer [s]   34 missile age [s]
+ *    35 flags (u32 bit-cast)   36 counters (u32: lo16 episode step, hi16 opponent-script step)
+ */
+#ifndef HIRL4UCAV_H
+#define HIRL4UCAV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HX_ENV_WORDS 37
+#define HX_OBS_DIM 13
+#define HX_ACT_DIM 4
+#define HX_ROW_WORDS 32 /* replay row: s[13] a[4] s'[13] r done */
+
+/* flags word (state word 35) */
+#define HX_F_LOCKED_PREV (1u << 0)     /* Ally_target_locked   HarfangEnv_GYM.py:227 */
+#define HX_F_LOCKED (1u << 1)          /* n_Ally_target_locked HarfangEnv_GYM.py:228 */
+#define HX_F_SLOT_PREV (1u << 2)       /* missile1_state       HarfangEnv_GYM.py:250 */
+#define HX_F_SLOT (1u << 3)            /* n_missile1_state     HarfangEnv_GYM.py:251 */
+#define HX_F_FIRED (1u << 4)           /* now_missile_state    HarfangEnv_GYM.py:150-156 */
+#define HX_F_FIRE_SUCCESS (1u << 5)    /* fire_success         HarfangEnv_GYM.py:129 */
+#define HX_F_EPISODE_SUCCESS (1u << 6) /* episode_success      HarfangEnv_GYM.py:167 */
+#define HX_F_DONE (1u << 7)            /* done                 HarfangEnv_GYM.py:163-166 */
+#define HX_F_SCEN_SHIFT 8              /* bits 8..9: 0 straight_line, 1 serpentine, 2 circular */
+#define HX_F_SERP_POS (1u << 10)
+#define HX_F_SERP_LONG (1u << 11)
+#define HX_F_M_ACTIVE (1u << 12)
+#define HX_F_M_GUIDED (1u << 13)
+#define HX_F_SIM_SLOT (1u << 14)
+
+#define HX_ERR_ARG (-1)
+#define HX_ERR_HIP (-2)
+
+/* stats[] slots accumulated by hx_env_step (uint64 each) */
+enum { HX_STAT_EPISODES = 0, HX_STAT_KILLS, HX_STAT_FIRE_SUCCESS_EPISODES, HX_STAT_TIME_LIMIT, HX_STAT_FIRES,
+       HX_STAT_GOOD_FIRES, HX_STAT_LOCKED_STEPS, HX_STAT_ENV_STEPS, HX_STAT_COUNT };
+
+const char* hx_last_error(void);
+int hx_version(void);
+
+/* Optional per-call behaviour of hx_env_step.  All pointers device memory (or NULL = feature off). */
+typedef struct HxStepOpts {
+    int32_t max_step;      /* > 0: episode time limit (train_all.py:159-183 maxStep); the step that reaches it is
+                              executed, NOT stored, and ends the episode without done (train_all.py:346-347) */
+    int32_t auto_reset;    /* 1: an env whose episode ended (done or time limit) is reset in place and obs_io gets
+                              the reset observation (vectorised counterpart of train_all.py:320-323) */
+    int32_t randomize;     /* resets use random_reset (HarfangEnv_GYM.py:51-81) instead of reset (:34-49) */
+    uint32_t env_id0;      /* global id of env 0 of this shard (Philox counter word 0 = env_id0 + i) */
+    uint64_t seed;         /* Philox key */
+    uint32_t* episode_ctr; /* [n] per-env episode counter (Philox counter word 1); required if auto_reset */
+    float* ring;           /* [cap][HX_ROW_WORDS] replay ring or NULL: fused UniformMemory.store (buffer.py:20-36) */
+    int8_t* ring_success;  /* [cap] step_success of each stored row, or NULL */
+    int64_t cap;
+    uint64_t* total;       /* transitions ever stored; slot = total % cap (buffer.py:36 position) */
+    uint64_t* stats;       /* [HX_STAT_COUNT] or NULL */
+} HxStepOpts;
+
+/* HarfangEnv.reset / random_reset (+ Serpentine/Circular variants): HarfangEnv_GYM.py:34-81,171-188,374-406,440-474.
+ * mask: NULL = all envs, else only envs with mask[i] != 0.  scenario: per-env ids (NULL = scenario_all for all).
+ * Writes the reset observation to obs[i*13..] (obs may be NULL). */
+int hx_env_reset(float* state, int64_t n, int64_t stride, const uint8_t* mask, const int32_t* scenario,
+                 int32_t scenario_all, int32_t randomize, uint64_t seed, uint32_t env_id0, uint32_t* episode_ctr,
+                 float* obs, void* stream);
+
+/* HarfangEnv.step for n envs: _apply_action -> one simulator tick -> _get_observation -> _get_reward ->
+ * _get_termination (HarfangEnv_GYM.py:83-90,101-169,193-268; scripted opponents :342-353,412-421).
+ * actions [n][4]; obs_io [n][13] in: previous observation (read only when opts->ring), out: next observation;
+ * reward [n]; done [n] (0/1); success [n] (-1/0/+1). */
+int hx_env_step(float* state, int64_t n, int64_t stride, const float* actions, float* obs_io, float* reward,
+                uint8_t* done, int8_t* success, const HxStepOpts* opts /* host, may be NULL */, void* stream);
+
+/* df.rearm_machine before a step (HarfangSerpentineInfiniteEnv.step_test, HarfangEnv_GYM.py:484-486) */
+int hx_env_rearm(float* state, int64_t n, int64_t stride, const uint8_t* mask, void* stream);
+
+/* get_reward / get_termination for expert labelling (HarfangEnv_GYM.py:299-336, train_all.py:289-306):
+ * s, ns [n][13], a [n][4] -> reward [n], success [n], done [n]. */
+int hx_label_transitions(const float* s, const float* a, const float* ns, int64_t n, float* reward, int8_t* success,
+                         uint8_t* done, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIRL4UCAV_H */

@@ -446,7 +446,8 @@ void ox_env_rearm(OxEnv* E) { E->flags |= F_SIM_SLOT; }
  *   - an episode that ended (done or time limit) is reset in place and obs_io receives the reset obs.
  * obs_io [n][13] in: previous observation, out: next observation for the policy.
  * ring [cap][32] rows (s13 a4 s'13 r done), *total = transitions ever stored (slot = total % cap).
- * stats[8] += {episodes, kills(episode_success), fire_success episodes, time-limit ends, fires, good fires, 0, 0}. */
+ * stats[8] += {episodes, kills(episode_success), fire_success episodes, time-limit ends, fires, good fires,
+ *               locked steps, env steps}. */
 void ox_env_step_batch(OxEnv* envs, int64_t n, const float* actions, float* obs_io, float* reward, uint8_t* done,
                        int8_t* success, int max_step, int auto_reset, int randomize, uint64_t seed,
                        uint32_t env_id0, uint32_t* episode_ctr, float* ring, int8_t* ring_succ, int64_t cap,
@@ -471,6 +472,8 @@ void ox_env_step_batch(OxEnv* envs, int64_t n, const float* actions, float* obs_
         if (stats) {
             if (E->flags & F_FIRED) stats[4] += 1;
             if (success[i] == 1) stats[5] += 1;
+            if (E->flags & F_LOCKED) stats[6] += 1;
+            stats[7] += 1;
         }
         if (auto_reset && (done[i] || trunc)) {
             if (stats) {

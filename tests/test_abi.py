@@ -1,0 +1,51 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/hirl4ucav.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "hirl4ucav.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_hot_path():
+    syms = declared_symbols()
+    for must in ("hx_env_step", "hx_env_reset", "hx_label_transitions", "hx_last_error"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    so = os.path.join(REPO, "hirl4ucav_amd", "libhx_mi355.so")
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+
+        g.build()
+    L = ctypes.CDLL(so)
+    missing = [s for s in declared_symbols() if not hasattr(L, s)]
+    assert not missing, missing
+    L.hx_version.restype = ctypes.c_int
+    assert L.hx_version() >= 100
+
+
+def test_argument_errors_are_reported_not_swallowed():
+    from hirl4ucav_amd import _lib
+
+    with pytest.raises(_lib.HxError, match="hx_env_step"):
+        _lib.call("hx_env_step", None, 0, 0, None, None, None, None, None, None, None)
+
+
+def test_product_does_not_import_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    bad = []
+    for root, _, files in os.walk(os.path.join(REPO, "hirl4ucav_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                if "oracle" in open(os.path.join(root, f), errors="ignore").read().replace("the scalar oracle", ""):
+                    bad.append(os.path.join(root, f))
+    assert not bad, bad
