@@ -1,0 +1,69 @@
+"""Seeded inputs shared by the HIRL golden generator, the oracle tests and the GPU parity tests.  Everything is a pure
+function of a seed (numpy Generator PCG64), so fixtures only need to carry indices, noise and outputs."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from oracle import hirl_oracle as H  # noqa: E402  (tests may use the oracle; the product never does)
+
+PARAM_SEED, DATA_SEED = 2024, 77
+N_REPLAY, N_EXPERT, N_EXPERT_ROWS = 2000, 600, 400
+
+
+def make_params(seed, h1=256, h2=512):
+    rng = np.random.default_rng(seed)
+    return {"actor": H.init_actor(rng, h1=h1, h2=h2), "critic": H.init_critic(rng, h1=h1, h2=h2),
+            "bc_actor": H.init_actor(rng, h1=h1, h2=h2)}
+
+
+def _obs(rng, n):
+    s = rng.uniform(-1, 1, (n, 13)).astype(np.float32)
+    s[:, 7] = np.where(rng.random(n) < 0.5, 1, -1)
+    s[:, 8] = np.where(rng.random(n) < 0.7, 1, -1)
+    s[:, 12] = rng.uniform(0, 0.2, n)
+    return s
+
+
+def _rows(rng, n):
+    rows = np.zeros((n, 32), np.float32)
+    rows[:, 0:13] = _obs(rng, n)
+    rows[:, 13:17] = rng.uniform(-1, 1, (n, 4))
+    rows[:, 17:30] = _obs(rng, n)
+    rows[:, 30] = rng.uniform(-9, 0, n) + np.where(rng.random(n) < 0.02, 600, 0)
+    rows[:, 31] = rng.random(n) < 0.05
+    return rows
+
+
+def make_data(seed):
+    rng = np.random.default_rng(seed)
+    d = {"replay": _rows(rng, N_REPLAY), "expert_rows": _rows(rng, N_EXPERT_ROWS), "expert_s": _obs(rng, N_EXPERT)}
+    a = rng.uniform(-1, 1, (N_EXPERT, 4)).astype(np.float32)
+    a[:, 3] = np.where(rng.random(N_EXPERT) < 0.05, 1, -1)
+    d["expert_a"] = a
+    return d
+
+
+def probe_index(size, count=128):
+    return (np.arange(count, dtype=np.int64) * 2654435761 % size).astype(np.int64)
+
+
+def checksum(tree):
+    h = hashlib.sha256()
+    for k in sorted(tree):
+        v = tree[k]
+        if isinstance(v, dict):
+            h.update(checksum(v).encode())
+        else:
+            h.update(np.ascontiguousarray(v).tobytes())
+    return h.hexdigest()
+
+
+def net_probe(flat):
+    flat = np.asarray(flat, np.float64)
+    return flat.sum(), np.abs(flat).sum(), flat[probe_index(flat.size)]
