@@ -1,0 +1,191 @@
+"""HirlEngine — device-resident state of the HIRL (TD3+BC) / TD3 agent and the host-side sequencing of the update
+stages exported by libhx_mi355.so (include/hirl4ucav.h).
+
+Mirrors what hirl.agents.HIRL.Agent keeps as attributes (HIRL.py:149-190): five networks, two Adam optimisers,
+`actorTrainable`, `update_count`, hyper-parameters — but every tensor is one flat fp32 buffer on the GPU and every
+step only enqueues kernels on the current stream.  Sharded (one process per GPU): gradients are summed with ONE
+all-reduce per phase over the flat gradient buffer (RCCL via torch.distributed), the soft-weight count with a 4-byte
+all-reduce before the actor gradients are formed.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+H1, H2 = 256, 512
+_vp, _i32, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
+
+
+class HxBatch(ctypes.Structure):
+    _fields_ = [("ring", _vp), ("expert_ring", _vp), ("idx", _vp), ("n_main", _i32), ("batch", _i32), ("bc_table", _vp),
+                ("idx_bc", _vp), ("noise", _vp)]
+
+
+class HxNets(ctypes.Structure):
+    _fields_ = [(k, _vp) for k in ("actor", "critic", "target_actor", "target_critic", "bc_actor", "grad_actor", "grad_critic",
+                                   "m_actor", "v_actor", "m_critic", "v_critic", "losses", "soft_count", "wstate", "ws")]
+
+
+class HxHyper(ctypes.Structure):
+    _fields_ = [(k, _f32) for k in ("gamma", "tau", "lr_actor", "lr_critic", "slope", "noise_clamp", "loss_lambda")] + [("use_bc", _i32)]
+
+
+_P = ctypes.POINTER
+_lib.register("hx_actor_act", [_vp, _vp, ctypes.c_int64, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _f32, _vp, _vp])
+_lib.register("hx_hirl_critic_grads", [_P(HxNets), _P(HxBatch), _P(HxHyper), _vp])
+_lib.register("hx_hirl_actor_backward", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _vp])
+_lib.register("hx_hirl_actor_wgrad", [_P(HxNets), _P(HxHyper), _i32, _i32, _i32, _f32, _f32, _vp])
+_lib.register("hx_adam", [_P(HxNets), _P(HxHyper), _i32, _i32, _f32, _i32, _f32, _f32, _i32, _vp])
+_lib.register("hx_polyak", [_P(HxNets), _P(HxHyper), _vp])
+
+# ---- flat layout <-> reference state_dict keys (hirl/agents/HIRL.py:19-146) -------------------------------------
+
+
+def _block_layout(in_dim, out_dim, names):
+    """names = (full_a, ln_a, full_b, ln_b, final) -> [(key, offset, shape)] and the exact block size"""
+    fa, la, fb, lb, fin = names
+    shapes = [(fa + ".weight", (H1, in_dim)), (fa + ".bias", (H1,)), (la + ".weight", (H1,)), (la + ".bias", (H1,)),
+              (fb + ".weight", (H2, H1)), (fb + ".bias", (H2,)), (lb + ".weight", (H2,)), (lb + ".bias", (H2,)),
+              (fin + ".weight", (out_dim, H2)), (fin + ".bias", (out_dim,))]
+    out, off = [], 0
+    for k, shp in shapes:
+        out.append((k, off, shp))
+        off += int(np.prod(shp))
+    return out, off
+
+
+ACTOR_LAYOUT, ACTOR_SIZE = _block_layout(13, 4, ("full1", "layernorm1", "full2", "layernorm2", "final"))
+_q1, _qsize = _block_layout(17, 1, ("full1", "layernorm1", "full2", "layernorm2", "final1"))
+_q2, _ = _block_layout(17, 1, ("full3", "layernorm3", "full4", "layernorm4", "final2"))
+Q_PADDED = (_qsize + 3) & ~3
+CRITIC_LAYOUT = _q1 + [(k, off + Q_PADDED, shp) for k, off, shp in _q2]
+CRITIC_SIZE = 2 * Q_PADDED
+
+
+def pack(params, layout, size, device):
+    flat = torch.zeros(size, dtype=torch.float32, device=device)
+    for k, off, shp in layout:
+        v = torch.as_tensor(np.asarray(params[k].detach().cpu() if torch.is_tensor(params[k]) else params[k]), dtype=torch.float32)
+        assert tuple(v.shape) == tuple(shp), (k, v.shape, shp)
+        flat[off:off + v.numel()] = v.reshape(-1).to(device)
+    return flat
+
+
+def unpack(flat, layout):
+    return {k: flat[off:off + int(np.prod(shp))].reshape(shp) for k, off, shp in layout}
+
+
+class HirlEngine:
+    def __init__(self, batch=128, lr_actor=1e-3, lr_critic=1e-3, tau=0.005, gamma=0.99, slope=0.0, use_bc=True,
+                 device="cuda", group=None):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.HxError("HirlEngine runs on the GPU only (no CPU path in the product)")
+        L = _lib.load()
+        assert L.hx_actor_param_count() == ACTOR_SIZE and L.hx_critic_param_count() == CRITIC_SIZE
+        L.hx_hirl_workspace_floats.restype = ctypes.c_int64
+        self.batch = int(batch)
+        z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device)  # noqa: E731
+        self.actor, self.target_actor, self.bc_actor = z(ACTOR_SIZE), z(ACTOR_SIZE), z(ACTOR_SIZE)
+        self.critic, self.target_critic = z(CRITIC_SIZE), z(CRITIC_SIZE)
+        self.grad = z(CRITIC_SIZE + ACTOR_SIZE)  # one buffer: [critic | actor]
+        self.grad_critic, self.grad_actor = self.grad[:CRITIC_SIZE], self.grad[CRITIC_SIZE:]
+        self.m_actor, self.v_actor, self.m_critic, self.v_critic = z(ACTOR_SIZE), z(ACTOR_SIZE), z(CRITIC_SIZE), z(CRITIC_SIZE)
+        self.losses, self.soft_count, self.wstate = z(8), z(1, torch.int32), z(1)
+        self.ws = z(int(L.hx_hirl_workspace_floats(self.batch)))
+        self._act_ws = None
+        self.nets = HxNets(*(t.data_ptr() for t in (self.actor, self.critic, self.target_actor, self.target_critic, self.bc_actor,
+                                                     self.grad_actor, self.grad_critic, self.m_actor, self.v_actor, self.m_critic,
+                                                     self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)))
+        self.hyper = HxHyper(gamma, tau, lr_actor, lr_critic, slope, 0.5, 10000.0, int(use_bc))  # HIRL.py:162,182
+        self.use_bc, self.slope = bool(use_bc), float(slope)
+        self.actor_trainable, self.update_count = True, 0   # HIRL.py:157,166
+        self.critic_step, self.actor_step = 0, 0
+        self.target_update_freq = 3                          # HIRL.py:183
+        self.group = group
+        self.world = torch.distributed.get_world_size(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        self.act_calls = 0
+
+    # ---- parameters ------------------------------------------------------------------------------------------
+    def load_params(self, actor, critic, bc_actor=None, hard_update_targets=True):
+        self.actor.copy_(pack(actor, ACTOR_LAYOUT, ACTOR_SIZE, self.device))
+        self.critic.copy_(pack(critic, CRITIC_LAYOUT, CRITIC_SIZE, self.device))
+        if bc_actor is not None:
+            self.bc_actor.copy_(pack(bc_actor, ACTOR_LAYOUT, ACTOR_SIZE, self.device))
+        if hard_update_targets:  # hard_update, HIRL.py:15-17,172,176
+            self.target_actor.copy_(self.actor)
+            self.target_critic.copy_(self.critic)
+
+    def state_dicts(self):
+        return {"actor": unpack(self.actor, ACTOR_LAYOUT), "critic": unpack(self.critic, CRITIC_LAYOUT),
+                "targetActor": unpack(self.target_actor, ACTOR_LAYOUT), "targetCritic": unpack(self.target_critic, CRITIC_LAYOUT),
+                "bc_actor": unpack(self.bc_actor, ACTOR_LAYOUT)}
+
+    # ---- acting ----------------------------------------------------------------------------------------------
+    def act(self, obs, noise=None, sigma=0.0, seed=0, row0=0, out=None, net=None):
+        """clamp(actor(obs) + noise, -1, 1) for obs [N, 13] on the device (chooseAction*, HIRL.py:192-212).
+        noise: None and sigma == 0 -> NoNoise; tensor [4] -> one shared draw; tensor [N, 4] -> per row; sigma > 0 and
+        noise None -> Philox N(0, sigma^2) per row and component."""
+        n = obs.shape[0]
+        if self._act_ws is None or self._act_ws.numel() < n * H2:
+            self._act_ws = torch.empty(n * H2, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        mode = 0
+        if noise is not None:
+            mode = 1 if noise.numel() == 4 else 2
+        elif sigma > 0:
+            mode = 3
+        self.act_calls += 1
+        _lib.call("hx_actor_act", (net if net is not None else self.actor).data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode,
+                  _lib.ptr(noise), float(sigma), int(seed), int(row0), self.act_calls, self.slope, self._act_ws.data_ptr(),
+                  _lib.stream_ptr())
+        return out
+
+    # ---- learning --------------------------------------------------------------------------------------------
+    def _allreduce(self, t):
+        if self.world > 1:
+            torch.distributed.all_reduce(t, group=self.group)
+
+    def learn(self, ring, idx, noise, expert_ring=None, n_main=None, bc_table=None, idx_bc=None, bc_weight_now=0.0,
+              bc_warm_up_weight=0.0):
+        """One Agent.learn (HIRL.py:221-334 / TD3.py:201-260) on the minibatch {ring[idx[r]] | expert_ring[idx[r]]}.
+        bc_weight_now: 100 = estimate the soft weight now (HIRL.py:299), None = keep the stored device value, else the
+        given weight.  Enqueues only; read results with losses_host()."""
+        B = self.batch
+        st = _lib.stream_ptr()
+        n_main = B if n_main is None else int(n_main)
+        batch = HxBatch(ring.data_ptr(), _lib.ptr(expert_ring) or ring.data_ptr(), idx.data_ptr(), n_main, B,
+                        _lib.ptr(bc_table) or ring.data_ptr(), _lib.ptr(idx_bc) or idx.data_ptr(), noise.data_ptr())
+        nets, hyper = ctypes.byref(self.nets), ctypes.byref(self.hyper)
+        gs = 1.0 / self.world
+        _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, st)
+        self._allreduce(self.grad_critic)
+        self.critic_step += 1
+        _lib.call("hx_adam", nets, hyper, 0, self.critic_step, gs, 0, 0.0, 0.0, B, st)
+        if self.actor_trainable:  # HIRL.py:291
+            if bc_weight_now is None:
+                w_kind, w_given = 2, 0.0
+            elif bc_weight_now == 100:
+                w_kind, w_given = 1, 0.0
+            else:
+                w_kind, w_given = 0, float(bc_weight_now)
+            _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, int(w_kind == 1), st)
+            if w_kind == 1:
+                self._allreduce(self.soft_count)
+            _lib.call("hx_hirl_actor_wgrad", nets, hyper, B, B * self.world, w_kind, w_given, float(bc_warm_up_weight), st)
+            self._allreduce(self.grad_actor)
+            self.actor_step += 1
+            _lib.call("hx_adam", nets, hyper, 1, self.actor_step, gs, w_kind, w_given, float(bc_warm_up_weight), B * self.world, st)
+            self.update_count += 1
+            if self.update_count % self.target_update_freq == 0:  # HIRL.py:327-330
+                _lib.call("hx_polyak", nets, hyper, st)
+        self.actor_trainable = not self.actor_trainable  # HIRL.py:332
+
+    def losses_host(self):
+        """(critic_loss, actor_loss, bc_loss, rl_loss, bc_fire_loss, bc_weight) — HIRL.py:334.  Synchronises."""
+        v = self.losses.tolist()
+        return v[0], v[1], v[2], v[3], v[4], v[5]

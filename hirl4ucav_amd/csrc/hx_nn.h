@@ -1,0 +1,122 @@
+// hx_nn.h — device building blocks of the actor/critic kernels (gfx950): parameter-block layout, wave reductions,
+// LayerNorm rows, fp32 MFMA tiles.
+//
+// Network shape is the reference's (train_all.py:190-208: hidden 256 / 512, LayerNorm after each hidden Linear):
+//   Actor  (hirl/agents/HIRL.py:105-146)  13 -> 256 -> LN -> act -> 512 -> LN -> act -> 4 -> tanh
+//   Q head (hirl/agents/HIRL.py:19-103)   17 -> 256 -> LN -> act -> 512 -> LN -> act -> 1      (Critic = 2 heads)
+// One "MLP block" = one such 3-layer net.  Parameters live in ONE flat fp32 buffer in the reference's state_dict
+// order, so an actor is 138,756 contiguous floats and a critic 2 x 138,241 = 276,482; gradients and
+// Adam moments use the same layout, which makes Adam/Polyak elementwise and the gradient all-reduce one message.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hxnn {
+
+constexpr int H1 = 256;
+constexpr int H2 = 512;
+constexpr int XP = 20;       // padded input row (13 or 17 used)
+constexpr int RT = 16;       // rows per tile (MFMA M)
+constexpr int LDA1 = H1 + 4; // LDS pitch of a [16][256] tile (+4: ds_read_b128 rows land on distinct 16-B slots)
+constexpr int LDA2 = H2 + 4;
+constexpr float LN_EPS = 1e-5f;
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// offsets (in floats) inside one MLP block, reference state_dict order:
+// full{1,3}.weight, .bias, layernorm{1,3}.weight, .bias, full{2,4}.weight, .bias, layernorm{2,4}.weight, .bias, final.weight, .bias
+struct Mlp {
+    int in, out;
+    __host__ __device__ int W1() const { return 0; }
+    __host__ __device__ int b1() const { return H1 * in; }
+    __host__ __device__ int g1() const { return b1() + H1; }
+    __host__ __device__ int be1() const { return g1() + H1; }
+    __host__ __device__ int W2() const { return be1() + H1; }
+    __host__ __device__ int b2() const { return W2() + H2 * H1; }
+    __host__ __device__ int g2() const { return b2() + H2; }
+    __host__ __device__ int be2() const { return g2() + H2; }
+    __host__ __device__ int W3() const { return be2() + H2; }
+    __host__ __device__ int b3() const { return W3() + out * H2; }
+    __host__ __device__ int size() const { return b3() + out; }
+    // blocks are laid out at multiples of 4 floats so that every row inside a block stays 16-byte aligned
+    __host__ __device__ int padded() const { return (size() + 3) & ~3; }
+};
+
+__device__ __forceinline__ float act_f(float y, float slope) { return y > 0.0f ? y : y * slope; }
+__device__ __forceinline__ float act_d(float y, float slope) { return y > 0.0f ? 1.0f : slope; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum over aligned groups of 16 lanes
+__device__ __forceinline__ float sum16(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ v4f mfma16(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// ---- fp32 MFMA tiles ----------------------------------------------------------------------------------------
+// Lane l of a wave: r = l & 15, g = l >> 4.  v_mfma_f32_16x16x4_f32 takes A[i = r][k = g], B[k = g][j = r] and
+// returns D[row = 4 g + reg][col = r].  A k-step of 16 is 4 MFMAs; MFMA j consumes k = kk + 4 g + j, the same
+// k on the A and B side, so each lane's A (and where possible B) fragment is ONE 16-byte load along k.
+
+// D[16 x 16] += A[16 x K] * Bt^T where A rows are in LDS (pitch lda) and Bt is [n][K] row-major in global memory
+// (torch Linear weight): Bt row = output column.
+template <int K>
+__device__ __forceinline__ v4f tile_a_lds_bt_global(const float* __restrict__ a_lds, int lda, const float* __restrict__ bt_row, v4f acc) {
+    const int l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+    const float* ap = a_lds + r * lda + 4 * g;
+    const float* bp = bt_row + 4 * g;  // bt_row already points at Bt[n0 + r][0]
+#pragma unroll 4
+    for (int kk = 0; kk < K; kk += 16) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + kk);
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + kk);
+        acc = mfma16(a4.x, b4.x, acc);
+        acc = mfma16(a4.y, b4.y, acc);
+        acc = mfma16(a4.z, b4.z, acc);
+        acc = mfma16(a4.w, b4.w, acc);
+    }
+    return acc;
+}
+
+// D[16 x 16] += A[16 x K] * B where A rows are in LDS and B is [K][ldb] row-major in global memory; b_col points at
+// B[0][n0 + r].
+template <int K>
+__device__ __forceinline__ v4f tile_a_lds_b_global(const float* __restrict__ a_lds, int lda, const float* __restrict__ b_col, int ldb, v4f acc) {
+    const int l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+    const float* ap = a_lds + r * lda + 4 * g;
+    const float* bp = b_col + (size_t)(4 * g) * ldb;
+#pragma unroll 2
+    for (int kk = 0; kk < K; kk += 16) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + kk);
+        const float* b = bp + (size_t)kk * ldb;
+        const float b0 = b[0], b1 = b[ldb], b2 = b[2 * ldb], b3 = b[3 * ldb];
+        acc = mfma16(a4.x, b0, acc);
+        acc = mfma16(a4.y, b1, acc);
+        acc = mfma16(a4.z, b2, acc);
+        acc = mfma16(a4.w, b3, acc);
+    }
+    return acc;
+}
+
+// two-pass LayerNorm statistics of one row spread over a wave: each lane holds PER values
+template <int PER>
+__device__ __forceinline__ void row_stats(const float (&v)[PER], int n, float& mean, float& rstd) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += v[i];
+    mean = wave_sum(s) / (float)n;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const float d = v[i] - mean;
+        q += d * d;
+    }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + LN_EPS);
+}
+
+}  // namespace hxnn

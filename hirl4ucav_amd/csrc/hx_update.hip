@@ -1,0 +1,1003 @@
+// hx_update.hip — actor/critic kernels of the HIRL (TD3+BC) / TD3 update and batched policy inference (gfx950).
+//
+// What it replaces (reference file:line):
+//   Actor.forward / Critic.forward / onlyQ1     hirl/agents/HIRL.py:55-97,126-140          (U1, U2)
+//   Agent.chooseAction*                         hirl/agents/HIRL.py:192-212                (U5)   -> hx_actor_act
+//   Agent.learn                                 hirl/agents/HIRL.py:221-334                (U7-U11) -> hx_hirl_*
+//   TD3.Agent.learn                             hirl/agents/TD3.py:201-260                 (U12)  (slope 0.01, bc off)
+//   soft_update                                 hirl/agents/HIRL.py:11-13                  (U3)   -> hx_polyak
+//   optim.Adam(lr) defaults                     hirl/agents/HIRL.py:50,123                        -> hx_adam
+//   UniformMemory.sample + minibatch assembly   hirl/utils/buffer.py:38-48, HIRL.py:223-251 (U6, U7): rows are gathered
+//                                               by index straight from the device-resident replay rings
+//
+// Structure (DESIGN.md "update kernels"): B = 128 is latency-bound (0.49 GFLOP per learn), so the ~1,770 eager ops
+// of the reference collapse into 5 launches (critic phase) + 6 (delayed actor phase).  Every launch is either
+//   fwd_l2   z2 = act(LN(x W1^T + b1)) W2^T + b2 for up to 3 independent nets; the 16-row layer-1 prologue (and, when the
+//            input action is another net's output, that net's LN2/final/tanh "head") is recomputed per workgroup,
+//            the 256->512 GEMM is tiled 16 rows x 64 columns per workgroup on fp32 MFMA (v_mfma_f32_16x16x4_f32:
+//            exact fp32, k-ordered fma chain — no bf16 rounding, parity holds at 1e-5);
+//   bwd_l2   head + loss gradient + LN2 backward in the prologue, dh1 = dz2 W2 on MFMA;
+//   wgrad    dW2 = dz2^T h1 on MFMA (64x64 tiles) + the vector/LN/layer-1 gradients, written into a flat gradient
+//            buffer with the parameter layout (one all-reduce message per phase when sharded);
+//   adam / polyak  elementwise over the flat buffers, 16 B per lane.
+#include "hx_common.h"
+#include "hx_nn.h"
+
+using namespace hxnn;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kNT = 64;  // z2 / dh1 columns per workgroup (4 waves x 16)
+
+// minibatch row r comes from main[idx[r]] if r < nb else from exp[idx[r]]; idx == nullptr: row r of `main` itself
+struct RowSrc {
+    const float* main;
+    const float* exp;
+    const int* idx;
+    int nb;
+    int pitch;  // floats per source row (32 for replay rows, 13 for a plain observation matrix)
+};
+__device__ __forceinline__ const float* src_row(const RowSrc& s, int r) {
+    if (!s.idx) return s.main + (size_t)r * s.pitch;
+    const int i = s.idx[r];
+    return (r < s.nb ? s.main : s.exp) + (size_t)i * s.pitch;
+}
+
+// per-evaluation scratch (one "slot" = one net evaluated on one batch), R rows
+struct Slot {
+    float* x;     // [R][XP]   input rows (state ++ action)
+    float* z1;    // [R][H1]
+    float* st1;   // [R][2]    mean, rstd of LN1
+    float* h1;    // [R][H1]
+    float* z2;    // [R][H2]
+    float* st2;   // [R][2]
+    float* outv;  // [R][4]    head output (tanh(o) for actors, q for critics)
+    float* dz2;   // [R][H2]
+    float* dh1;   // [R][H1]
+    float* dout;  // [R][4]    gradient wrt the head pre-activation o
+};
+
+struct Head {  // a previous net whose output is (part of) this net's input
+    const float* net;
+    Mlp m;
+    Slot ws;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// row helpers: a wave owns one row; lane holds n = (i*64 + lane)*4 + c  (i < PER4, c < 4): 16-B coalesced loads
+// ---------------------------------------------------------------------------------------------------------------
+template <int N>
+struct RowReg {
+    static constexpr int PER4 = N / 256;
+    float v[PER4 * 4];
+    __device__ __forceinline__ void load(const float* __restrict__ p) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < PER4; ++i) {
+            const float4 t = reinterpret_cast<const float4*>(p)[i * 64 + lane];
+            v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ p) const {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < PER4; ++i) reinterpret_cast<float4*>(p)[i * 64 + lane] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+    // LDS variant with a pitch that keeps 16-B alignment (pitch % 4 == 0)
+    __device__ __forceinline__ void store_lds(float* p) const { store(p); }
+};
+
+// head of an MLP block for ONE row held by a wave: LN2 stats of z2, h2 = act(LN2(z2)), o[j] = h2 . W3[j] + b3[j].
+// Leaves xhat and y (pre-activation) in registers for the backward prologue.
+template <int OUTMAX>
+__device__ __forceinline__ void head_row(const float* __restrict__ z2row, const float* __restrict__ net, const Mlp m, float slope,
+                                         RowReg<H2>& xhat, RowReg<H2>& y, float& mean, float& rstd, float (&o)[OUTMAX]) {
+    RowReg<H2> z, g, be;
+    z.load(z2row);
+    row_stats<8>(z.v, H2, mean, rstd);
+    g.load(net + m.g2());
+    be.load(net + m.be2());
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        xhat.v[i] = (z.v[i] - mean) * rstd;
+        y.v[i] = g.v[i] * xhat.v[i] + be.v[i];
+    }
+#pragma unroll
+    for (int j = 0; j < OUTMAX; ++j) {
+        float acc = 0.0f;
+        if (j < m.out) {
+            RowReg<H2> w;
+            w.load(net + m.W3() + j * H2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += act_f(y.v[i], slope) * w.v[i];
+            acc = wave_sum(acc) + net[m.b3() + j];
+        }
+        o[j] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fwd_l2
+// ---------------------------------------------------------------------------------------------------------------
+struct FwdJob {
+    const float* net;  // MLP block to evaluate
+    Mlp m;
+    RowSrc src;
+    int col0;      // state columns [col0, col0+13) of the source row (0 = s, 17 = s')
+    int act_mode;  // in == 17 only: 0 = action from source row cols 13..16, 1 = tanh(head(prev)) (+ clamped noise, clamp +-1)
+    Head prev;
+    const float* noise;  // [4] one draw shared by the whole batch (HIRL.py:265) or nullptr
+    float noise_clamp;
+    Slot ws;
+    int rows;
+    int save;  // write x, z1, st1, h1 (needed by the backward pass)
+};
+struct FwdArgs {
+    FwdJob job[3];
+    int njobs;
+    float slope;
+};
+
+__device__ __forceinline__ int tiles_of(int rows) { return (rows + RT - 1) / RT; }
+
+__global__ __launch_bounds__(kThreads) void fwd_l2_kernel(FwdArgs A) {
+    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2];
+    float* h1s = lds;
+    float* xs = lds + RT * LDA1;
+    float* sts = xs + RT * XP;
+
+    // which job / row tile / column tile
+    int b = blockIdx.x, j = 0;
+    for (; j < A.njobs; ++j) {
+        const int nb = tiles_of(A.job[j].rows) * (H2 / kNT);
+        if (b < nb) break;
+        b -= nb;
+    }
+    if (j >= A.njobs) return;
+    const FwdJob& J = A.job[j];
+    const int rt = b / (H2 / kNT), nt = b % (H2 / kNT);
+    const int r0 = rt * RT;
+    const int nrow = min(RT, J.rows - r0);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float slope = A.slope;
+    const int in = J.m.in;
+
+    // 1. input tile xs[16][XP]
+    for (int e = tid; e < RT * XP; e += kThreads) xs[e] = 0.0f;
+    __syncthreads();
+    if (tid < RT * 13) {
+        const int r = tid / 13, c = tid % 13;
+        if (r < nrow) xs[r * XP + c] = src_row(J.src, r0 + r)[J.col0 + c];
+    }
+    if (in == 17) {
+        if (J.act_mode == 0) {
+            if (tid < RT * 4) {
+                const int r = tid >> 2, c = tid & 3;
+                if (r < nrow) xs[r * XP + 13 + c] = src_row(J.src, r0 + r)[13 + c];
+            }
+        } else {
+            // head of the previous net for rows 4*wave .. 4*wave+3
+            for (int q = 0; q < 4; ++q) {
+                const int r = wave * 4 + q;
+                if (r >= nrow) break;  // wave-uniform
+                RowReg<H2> xh, y;
+                float mean, rstd, o[4];
+                head_row<4>(J.prev.ws.z2 + (size_t)(r0 + r) * H2, J.prev.net, J.prev.m, slope, xh, y, mean, rstd, o);
+                if (lane < 4) {
+                    float a = tanhf(o[lane]);  // Actor.forward's tanh, HIRL.py:140
+                    if (J.noise) {              // target smoothing, HIRL.py:264-267
+                        const float e = fminf(fmaxf(J.noise[lane], -J.noise_clamp), J.noise_clamp);
+                        a = fminf(fmaxf(a + e, -1.0f), 1.0f);
+                    }
+                    xs[r * XP + 13 + lane] = a;
+                    if (nt == 0) J.prev.ws.outv[(size_t)(r0 + r) * 4 + lane] = a;
+                }
+                if (nt == 0 && lane == 0) {
+                    J.prev.ws.st2[(size_t)(r0 + r) * 2] = mean;
+                    J.prev.ws.st2[(size_t)(r0 + r) * 2 + 1] = rstd;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // 2. z1[r][t] = b1[t] + sum_i x[r][i] W1[t][i]   (thread t = hidden unit t)
+    float z1[RT];
+    {
+        const float* W1 = J.net + J.m.W1() + tid * in;
+        const float bias = J.net[J.m.b1() + tid];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) z1[r] = bias;
+        for (int i = 0; i < in; ++i) {
+            const float w = W1[i];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) z1[r] += xs[r * XP + i] * w;
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) h1s[r * LDA1 + tid] = z1[r];
+    }
+    __syncthreads();
+    // 3. LN1 statistics: wave w owns rows 4w..4w+3
+    for (int q = 0; q < 4; ++q) {
+        const int r = wave * 4 + q;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = h1s[r * LDA1 + i * 64 + lane];
+        float mean, rstd;
+        row_stats<4>(v, H1, mean, rstd);
+        if (lane == 0) {
+            sts[r * 2] = mean;
+            sts[r * 2 + 1] = rstd;
+        }
+    }
+    __syncthreads();
+    // 4. h1 = act(LN1(z1))
+    {
+        const float g = J.net[J.m.g1() + tid], be = J.net[J.m.be1() + tid];
+        const bool save = J.save && nt == 0;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const float h = act_f(g * ((z1[r] - sts[r * 2]) * sts[r * 2 + 1]) + be, slope);
+            h1s[r * LDA1 + tid] = h;
+            if (save && r < nrow) {
+                J.ws.z1[(size_t)(r0 + r) * H1 + tid] = z1[r];
+                J.ws.h1[(size_t)(r0 + r) * H1 + tid] = h;
+            }
+        }
+        if (save) {
+            for (int e = tid; e < nrow * XP; e += kThreads) J.ws.x[(size_t)r0 * XP + e] = xs[e];
+            if (tid < nrow * 2) J.ws.st1[(size_t)r0 * 2 + tid] = sts[tid];
+        }
+    }
+    __syncthreads();
+    // 5. z2 tile: 16 rows x 16 columns per wave on fp32 MFMA, K = 256
+    {
+        const int n0 = nt * kNT + wave * 16;
+        const int r = lane & 15, g = lane >> 4;
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+        acc = tile_a_lds_bt_global<H1>(h1s, LDA1, J.net + J.m.W2() + (size_t)(n0 + r) * H1, acc);
+        const float bias = J.net[J.m.b2() + n0 + r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 4 * g + q;
+            if (row < nrow) J.ws.z2[(size_t)(r0 + row) * H2 + n0 + r] = acc[q] + bias;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// act head: actions = clamp(tanh(head(actor)) + noise, -1, 1)  (chooseAction*, HIRL.py:192-212), one wave per row
+// ---------------------------------------------------------------------------------------------------------------
+struct ActArgs {
+    const float* net;
+    Mlp m;
+    const float* z2;
+    int rows;
+    float slope;
+    float* actions;       // [rows][4]
+    const float* noise;   // nullptr, [4] (shared) or [rows][4]
+    int noise_per_row;
+    float sigma;          // > 0 and noise == nullptr: N(0, sigma^2) from Philox(seed; row, call)
+    uint64_t seed;
+    uint32_t row0, call;
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t u) { return ((float)(u >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(kThreads) void act_head_kernel(ActArgs A) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= A.rows) return;
+    RowReg<H2> xh, y;
+    float mean, rstd, o[4];
+    head_row<4>(A.z2 + (size_t)r * H2, A.net, A.m, A.slope, xh, y, mean, rstd, o);
+    if (lane < 4) {
+        float a = tanhf(o[lane]);
+        if (A.noise) {
+            a = fminf(fmaxf(a + A.noise[(A.noise_per_row ? (size_t)r * 4 : 0) + lane], -1.0f), 1.0f);
+        } else if (A.sigma > 0.0f) {
+            uint32_t u[4];
+            philox4x32_10(A.row0 + (uint32_t)r, A.call, 0x61637421u, 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
+            // Box-Muller: lanes 0,1 use (u0,u1), lanes 2,3 use (u2,u3)
+            const float ua = u01(u[lane & 2]), ub = u01(u[(lane & 2) + 1]);
+            const float rad = sqrtf(-2.0f * logf(ua)), ang = 6.28318530717958647692f * ub;
+            const float n = (lane & 1) ? rad * sinf(ang) : rad * cosf(ang);
+            a = fminf(fmaxf(a + A.sigma * n, -1.0f), 1.0f);
+        }
+        A.actions[(size_t)r * 4 + lane] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bwd_l2: head + loss gradient + LN2 backward (prologue), dh1 = dz2 W2 (MFMA)
+// ---------------------------------------------------------------------------------------------------------------
+enum { BM_CRITIC_TD = 0, BM_CRITIC_PI = 1, BM_ACTOR_PI = 2, BM_ACTOR_BC = 3 };
+
+struct BwdJob {
+    const float* net;
+    Mlp m;
+    Slot ws;
+    int rows;
+    int mode;
+    // BM_CRITIC_TD: y = r + gamma min(Q1', Q2') (1 - d)     HIRL.py:270-274
+    Head t1, t2;  // target critic heads evaluated on (s', a')
+    RowSrc src;   // minibatch rows (reward col 30, done col 31; BC target action cols 13..16)
+    float gamma;
+    // BM_CRITIC_PI: optional soft-weight count  HIRL.py:299-306
+    Head soft;  // critic Q1 evaluated on (s, bc_actor(s)); net == nullptr: off
+    // BM_ACTOR_PI: dL/da from the critic's layer-1 backward
+    Head crit;    // the critic Q1 slot evaluated on (s, pi) (its dh1, z1, st1 are read)
+    float lambda; // BM_ACTOR_BC: loss_lambda (HIRL.py:182)
+};
+struct BwdArgs {
+    BwdJob job[2];
+    int njobs;
+    float slope;
+    float inv_batch;  // 1 / B
+    float* losses;    // [8]: critic, actor, bc, rl, bc_fire, bc_weight, -, -
+    int* soft_count;
+};
+
+__global__ __launch_bounds__(kThreads) void bwd_l2_kernel(BwdArgs A) {
+    __shared__ __attribute__((aligned(16))) float dz2s[RT * LDA2];
+    __shared__ float red[4][4];
+
+    int b = blockIdx.x, j = 0;
+    for (; j < A.njobs; ++j) {
+        const int nb = tiles_of(A.job[j].rows) * (H1 / kNT);
+        if (b < nb) break;
+        b -= nb;
+    }
+    if (j >= A.njobs) return;
+    const BwdJob& J = A.job[j];
+    const int rt = b / (H1 / kNT), nt = b % (H1 / kNT);
+    const int r0 = rt * RT;
+    const int nrow = min(RT, J.rows - r0);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float slope = A.slope;
+    const bool lead = nt == 0;  // the column-tile-0 workgroup of a row tile also publishes dz2 / st2 / dout / losses
+
+    float part[4] = {0.f, 0.f, 0.f, 0.f};  // per-wave loss partials
+    int cnt = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int r = wave * 4 + q;
+        float* drow = dz2s + r * LDA2;
+        if (r >= nrow) {  // wave-uniform: padded rows contribute zeros
+            RowReg<H2> zero;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) zero.v[i] = 0.0f;
+            zero.store_lds(drow);
+            continue;
+        }
+        const size_t R = (size_t)(r0 + r);
+        RowReg<H2> xh, y;
+        float mean, rstd, o[4];
+        head_row<4>(J.ws.z2 + R * H2, J.net, J.m, slope, xh, y, mean, rstd, o);
+        float dout[4] = {0.f, 0.f, 0.f, 0.f};
+        if (J.mode == BM_CRITIC_TD) {
+            RowReg<H2> xa, ya;
+            float m1, s1, q1[1], q2[1];
+            head_row<1>(J.t1.ws.z2 + R * H2, J.t1.net, J.t1.m, slope, xa, ya, m1, s1, q1);
+            head_row<1>(J.t2.ws.z2 + R * H2, J.t2.net, J.t2.m, slope, xa, ya, m1, s1, q2);
+            const float* row = src_row(J.src, r0 + r);
+            const float target = row[30] + (J.gamma * fminf(q1[0], q2[0])) * (1.0f - row[31]);
+            const float diff = o[0] - target;
+            dout[0] = 2.0f * diff * A.inv_batch;  // d mse / dq
+            part[0] += diff * diff * A.inv_batch;
+        } else if (J.mode == BM_CRITIC_PI) {
+            dout[0] = -A.inv_batch;            // rl_loss = -mean(Q1(s, pi(s)))  HIRL.py:297
+            part[3] += -o[0] * A.inv_batch;
+            if (J.soft.net) {
+                RowReg<H2> xa, ya;
+                float m1, s1, qs[1];
+                head_row<1>(J.soft.ws.z2 + R * H2, J.soft.net, J.soft.m, slope, xa, ya, m1, s1, qs);
+                cnt += (qs[0] > o[0]) ? 1 : 0;  // (soft_Q > rl_Q)  HIRL.py:303
+            }
+        } else if (J.mode == BM_ACTOR_PI) {
+            // dL/da_j = sum_k dz1_c[k] W1c[k][13 + j], dz1_c = LN1 backward of the critic's dh1
+            const Head& C = J.crit;
+            RowReg<H1> dh, z, g, be;
+            dh.load(C.ws.dh1 + R * H1);
+            z.load(C.ws.z1 + R * H1);
+            g.load(C.net + C.m.g1());
+            be.load(C.net + C.m.be1());
+            const float cm = C.ws.st1[R * 2], cr = C.ws.st1[R * 2 + 1];
+            float xh1[4], dxh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xh1[i] = (z.v[i] - cm) * cr;
+                const float yy = g.v[i] * xh1[i] + be.v[i];
+                dxh[i] = dh.v[i] * act_d(yy, slope) * g.v[i];
+                s1 += dxh[i];
+                s2 += dxh[i] * xh1[i];
+            }
+            s1 = wave_sum(s1) * (1.0f / H1);
+            s2 = wave_sum(s2) * (1.0f / H1);
+            float da[4] = {0.f, 0.f, 0.f, 0.f};
+            // RowReg<256> maps v[c] -> hidden unit k = lane*4 + c
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = lane * 4 + c;
+                const float dz1 = cr * (dxh[c] - s1 - xh1[c] * s2);
+                const float* w = C.net + C.m.W1() + k * C.m.in + 13;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) da[jj] += dz1 * w[jj];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                da[jj] = wave_sum(da[jj]);
+                const float a = tanhf(o[jj]);
+                dout[jj] = da[jj] * (1.0f - a * a);
+            }
+        } else {  // BM_ACTOR_BC: bc_loss = lambda * mse(actor(s_bc), a_bc)  HIRL.py:310-311
+            const float* row = src_row(J.src, r0 + r);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float a = tanhf(o[jj]);
+                const float diff = a - row[13 + jj];
+                dout[jj] = (2.0f * J.lambda * 0.25f * A.inv_batch) * diff * (1.0f - a * a);
+                part[2] += J.lambda * 0.25f * A.inv_batch * diff * diff;
+                if (jj == 3) part[1] += J.lambda * A.inv_batch * diff * diff;  // bc_fire_loss (logging), HIRL.py:317-319
+            }
+        }
+        // dh2 = dout W3, through act' and LN2 backward
+        RowReg<H2> g, dx;
+        g.load(J.net + J.m.g2());
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dx.v[i] = 0.0f;
+        for (int jj = 0; jj < J.m.out; ++jj) {
+            RowReg<H2> w;
+            w.load(J.net + J.m.W3() + jj * H2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dx.v[i] += dout[jj] * w.v[i];
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            dx.v[i] = dx.v[i] * act_d(y.v[i], slope) * g.v[i];
+            s1 += dx.v[i];
+            s2 += dx.v[i] * xh.v[i];
+        }
+        s1 = wave_sum(s1) * (1.0f / H2);
+        s2 = wave_sum(s2) * (1.0f / H2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dx.v[i] = rstd * (dx.v[i] - s1 - xh.v[i] * s2);
+        dx.store_lds(drow);
+        if (lead) {
+            dx.store(J.ws.dz2 + R * H2);
+            if (lane == 0) {
+                J.ws.st2[R * 2] = mean;
+                J.ws.st2[R * 2 + 1] = rstd;
+            }
+            if (lane < 4) {
+                J.ws.dout[R * 4 + lane] = dout[lane];
+                if (J.mode != BM_ACTOR_PI) J.ws.outv[R * 4 + lane] = (J.m.out == 4) ? tanhf(o[lane]) : o[lane];
+            }
+        }
+    }
+    if (lead && lane == 0) {
+        red[wave][0] = part[0]; red[wave][1] = part[1]; red[wave][2] = part[2]; red[wave][3] = part[3];
+        if (cnt) atomicAdd(A.soft_count, cnt);
+    }
+    __syncthreads();
+    if (lead && tid == 0) {
+        const float p0 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        const float p1 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        const float p2 = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
+        const float p3 = (red[0][3] + red[1][3]) + (red[2][3] + red[3][3]);
+        if (J.mode == BM_CRITIC_TD) atomicAdd(&A.losses[0], p0);
+        if (J.mode == BM_CRITIC_PI) atomicAdd(&A.losses[3], p3);
+        if (J.mode == BM_ACTOR_BC) {
+            atomicAdd(&A.losses[2], p2);
+            atomicAdd(&A.losses[4], p1);
+        }
+    }
+    // dh1 tile: 16 rows x 16 columns per wave, K = 512; W2 is [512][256] row-major = B[k][n]
+    {
+        const int n0 = nt * kNT + wave * 16;
+        const int r = lane & 15, g = lane >> 4;
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+        acc = tile_a_lds_b_global<H2>(dz2s, LDA2, J.net + J.m.W2() + n0 + r, H1, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 4 * g + q;
+            if (row < nrow) J.ws.dh1[(size_t)(r0 + row) * H1 + n0 + r] = acc[q];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad: all parameter gradients of one MLP block from up to two slots (scaled), into the flat gradient buffer
+// ---------------------------------------------------------------------------------------------------------------
+struct WgJob {
+    const float* net;  // parameters (W3, g2, be2, g1, be1 are read)
+    float* grad;       // gradient block, same layout
+    Mlp m;
+    Slot ws[2];
+    int rows[2];
+    int nslots;
+    int wmode[2];  // per slot: 0 = scale 1, 1 = scale (1 - w), 2 = scale w
+};
+struct WgArgs {
+    WgJob job[2];
+    int njobs;
+    float slope;
+    // effective BC weight  w: 0 = given, 1 = estimate from soft_count (HIRL.py:304-306), 2 = reuse *wstate
+    int w_kind;
+    float w_given, warm, inv_batch;
+    const int* soft_count;
+    const float* wstate;
+};
+
+__device__ __forceinline__ float effective_w(int kind, float given, float warm, float inv_batch, const int* count, const float* wstate) {
+    float w = given;
+    if (kind == 1) w = (float)(*count) * inv_batch + warm;
+    if (kind == 2) w = *wstate;
+    return w > 1.0f ? 1.0f : w;  // HIRL.py:308
+}
+
+constexpr int kWgTilesPerBlock = (H2 / 64) * (H1 / 64);  // 32 dW2 tiles
+constexpr int kWgVecWgs = H2 / kThreads;                 // 2 workgroups for the 512-wide vector gradients
+constexpr int kWgPerJob = kWgTilesPerBlock + kWgVecWgs + 1;
+
+__global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
+    __shared__ __attribute__((aligned(16))) float t_dz[RT * LDA1];
+    __shared__ __attribute__((aligned(16))) float t_dy[RT * LDA1];
+    __shared__ __attribute__((aligned(16))) float t_xh[RT * LDA1];
+    __shared__ float xs[RT * XP];
+
+    const int j = blockIdx.x / kWgPerJob, b = blockIdx.x % kWgPerJob;
+    if (j >= A.njobs) return;
+    const WgJob& J = A.job[j];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float slope = A.slope;
+    const float w = effective_w(A.w_kind, A.w_given, A.warm, A.inv_batch, A.soft_count, A.wstate);
+    float scale[2];
+    for (int s = 0; s < 2; ++s) scale[s] = J.wmode[s] == 0 ? 1.0f : (J.wmode[s] == 1 ? 1.0f - w : w);
+
+    if (b < kWgTilesPerBlock) {
+        // dW2[n][k] = sum_r scale dz2[r][n] h1[r][k]: 64 x 64 tile, wave = 16 rows (n) x 64 columns (k)
+        const int n0 = (b / (H1 / 64)) * 64 + wave * 16, k0 = (b % (H1 / 64)) * 64;
+        const int r = lane & 15, g = lane >> 4;
+        v4f acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < J.nslots; ++s) {
+            const float sc = scale[s];
+            const float* dz = J.ws[s].dz2 + n0 + r;
+            const float* h1 = J.ws[s].h1 + k0 + r;
+            const int rows = J.rows[s];
+            for (int bb = 0; bb < rows; bb += 16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = bb + 4 * q + g;  // MFMA q reduces over rows bb+4q .. bb+4q+3 (one per lane group)
+                    const bool ok = row < rows;
+                    const float a = ok ? dz[(size_t)row * H2] * sc : 0.0f;
+                    const float* hp = h1 + (size_t)row * H1;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = mfma16(a, ok ? hp[t * 16] : 0.0f, acc[t]);
+                }
+            }
+        }
+        float* out = J.grad + J.m.W2();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[(size_t)(n0 + 4 * g + q) * H1 + k0 + t * 16 + r] = acc[t][q];
+        return;
+    }
+    if (b < kWgTilesPerBlock + kWgVecWgs) {
+        // column n: db2, dg2 (layernorm2.weight), dbe2, dW3[j][n]; thread 0..out-1 of the first: db3
+        const int n = (b - kWgTilesPerBlock) * kThreads + tid;
+        const float g2 = J.net[J.m.g2() + n], be2 = J.net[J.m.be2() + n];
+        float w3[4];
+        for (int jj = 0; jj < 4; ++jj) w3[jj] = jj < J.m.out ? J.net[J.m.W3() + jj * H2 + n] : 0.0f;
+        float db2 = 0.f, dg = 0.f, dbe = 0.f, dw3[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < J.nslots; ++s) {
+            const Slot& S = J.ws[s];
+            const float sc = scale[s];
+            for (int r = 0; r < J.rows[s]; ++r) {
+                const float mean = S.st2[r * 2], rstd = S.st2[r * 2 + 1];
+                const float xh = (S.z2[(size_t)r * H2 + n] - mean) * rstd;
+                const float y = g2 * xh + be2;
+                float dh2 = 0.f;
+                const float4 d4 = *reinterpret_cast<const float4*>(S.dout + (size_t)r * 4);
+                const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) dh2 += dd[jj] * w3[jj];
+                const float dy = dh2 * act_d(y, slope);
+                const float h2 = act_f(y, slope);
+                db2 += sc * S.dz2[(size_t)r * H2 + n];
+                dbe += sc * dy;
+                dg += sc * dy * xh;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) dw3[jj] += sc * dd[jj] * h2;
+            }
+        }
+        J.grad[J.m.b2() + n] = db2;
+        J.grad[J.m.g2() + n] = dg;
+        J.grad[J.m.be2() + n] = dbe;
+        for (int jj = 0; jj < J.m.out; ++jj) J.grad[J.m.W3() + jj * H2 + n] = dw3[jj];
+        if (b == kWgTilesPerBlock && tid < J.m.out) {
+            float db3 = 0.f;
+            for (int s = 0; s < J.nslots; ++s)
+                for (int r = 0; r < J.rows[s]; ++r) db3 += scale[s] * J.ws[s].dout[(size_t)r * 4 + tid];
+            J.grad[J.m.b3() + tid] = db3;
+        }
+        return;
+    }
+    // layer 1: dz1 = LN1 backward of dh1 (row-wise, wave per row), then per-column sums: thread t = hidden unit t
+    {
+        const int in = J.m.in;
+        const float g1 = J.net[J.m.g1() + tid], be1 = J.net[J.m.be1() + tid];
+        float db1 = 0.f, dg = 0.f, dbe = 0.f, dw1[17];
+#pragma unroll
+        for (int i = 0; i < 17; ++i) dw1[i] = 0.f;
+        for (int s = 0; s < J.nslots; ++s) {
+            const Slot& S = J.ws[s];
+            const float sc = scale[s];
+            for (int r0 = 0; r0 < J.rows[s]; r0 += RT) {
+                const int nrow = min(RT, J.rows[s] - r0);
+                __syncthreads();
+                for (int e = tid; e < RT * XP; e += kThreads) xs[e] = e < nrow * XP ? S.x[(size_t)r0 * XP + e] : 0.0f;
+                for (int q = 0; q < 4; ++q) {
+                    const int r = wave * 4 + q;
+                    RowReg<H1> dzr, dyr, xhr;
+                    if (r < nrow) {
+                        const size_t R = (size_t)(r0 + r);
+                        RowReg<H1> dh, z, g, be;
+                        dh.load(S.dh1 + R * H1);
+                        z.load(S.z1 + R * H1);
+                        g.load(J.net + J.m.g1());
+                        be.load(J.net + J.m.be1());
+                        const float mean = S.st1[R * 2], rstd = S.st1[R * 2 + 1];
+                        float dxh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            xhr.v[c] = (z.v[c] - mean) * rstd;
+                            const float yy = g.v[c] * xhr.v[c] + be.v[c];
+                            dyr.v[c] = dh.v[c] * act_d(yy, slope);
+                            dxh[c] = dyr.v[c] * g.v[c];
+                            s1 += dxh[c];
+                            s2 += dxh[c] * xhr.v[c];
+                        }
+                        s1 = wave_sum(s1) * (1.0f / H1);
+                        s2 = wave_sum(s2) * (1.0f / H1);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dzr.v[c] = rstd * (dxh[c] - s1 - xhr.v[c] * s2);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dzr.v[c] = dyr.v[c] = xhr.v[c] = 0.0f;
+                    }
+                    dzr.store_lds(t_dz + r * LDA1);
+                    dyr.store_lds(t_dy + r * LDA1);
+                    xhr.store_lds(t_xh + r * LDA1);
+                }
+                __syncthreads();
+#pragma unroll 4
+                for (int r = 0; r < RT; ++r) {
+                    const float dz = sc * t_dz[r * LDA1 + tid], dy = sc * t_dy[r * LDA1 + tid];
+                    db1 += dz;
+                    dbe += dy;
+                    dg += dy * t_xh[r * LDA1 + tid];
+#pragma unroll
+                    for (int i = 0; i < 17; ++i) dw1[i] += dz * xs[r * XP + i];
+                }
+            }
+        }
+        (void)g1; (void)be1;
+        J.grad[J.m.b1() + tid] = db1;
+        J.grad[J.m.g1() + tid] = dg;
+        J.grad[J.m.be1() + tid] = dbe;
+        for (int i = 0; i < in; ++i) J.grad[J.m.W1() + tid * in + i] = dw1[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults restated) and Polyak, elementwise, 16 B per lane
+// ---------------------------------------------------------------------------------------------------------------
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v;
+    int n;
+    float b1, b2, eps, step_size, bc2_sqrt, gscale;
+    // bookkeeping done by thread 0 of block 0 on actor steps: actor_loss and the stored BC weight
+    int finish_actor;
+    int w_kind; float w_given, warm, inv_batch;
+    const int* soft_count; float* wstate; float* losses; int use_bc;
+};
+
+__global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
+    if (A.finish_actor && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (A.use_bc) {
+            const float w = effective_w(A.w_kind, A.w_given, A.warm, A.inv_batch, A.soft_count, A.wstate);
+            A.losses[1] = A.losses[2] * w + A.losses[3] * (1.0f - w);  // HIRL.py:321
+            A.losses[5] = w;
+            *A.wstate = w;
+        } else {
+            A.losses[1] = A.losses[3];  // TD3.py:236
+        }
+    }
+    const int i = (blockIdx.x * kThreads + threadIdx.x) * 4;
+    if (i >= A.n) return;
+    float pv[4], gv[4], mv[4], vv[4];
+    const int cnt = min(4, A.n - i);
+    for (int c = 0; c < cnt; ++c) { pv[c] = A.p[i + c]; gv[c] = A.g[i + c] * A.gscale; mv[c] = A.m[i + c]; vv[c] = A.v[i + c]; }
+    for (int c = 0; c < cnt; ++c) {
+        mv[c] = mv[c] * A.b1 + gv[c] * (1.0f - A.b1);
+        vv[c] = vv[c] * A.b2 + (gv[c] * gv[c]) * (1.0f - A.b2);
+        const float denom = sqrtf(vv[c]) / A.bc2_sqrt + A.eps;
+        pv[c] = pv[c] - A.step_size * (mv[c] / denom);
+        A.p[i + c] = pv[c]; A.m[i + c] = mv[c]; A.v[i + c] = vv[c];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void polyak_kernel(float* target, const float* source, int n, float tau) {
+    const int i = (blockIdx.x * kThreads + threadIdx.x) * 4;
+    if (i >= n) return;
+    const int cnt = min(4, n - i);
+    for (int c = 0; c < cnt; ++c) target[i + c] = target[i + c] * (1.0f - tau) + source[i + c] * tau;  // HIRL.py:13
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+constexpr size_t kSlotFloats = XP + H1 + 2 + H1 + H2 + 2 + 4 + H2 + H1 + 4;  // per row
+
+Slot carve_slot(float* base, int rows) {
+    Slot s;
+    float* p = base;
+    s.x = p; p += (size_t)rows * XP;
+    s.z1 = p; p += (size_t)rows * H1;
+    s.st1 = p; p += (size_t)rows * 2;
+    s.h1 = p; p += (size_t)rows * H1;
+    s.z2 = p; p += (size_t)rows * H2;
+    s.st2 = p; p += (size_t)rows * 2;
+    s.outv = p; p += (size_t)rows * 4;
+    s.dz2 = p; p += (size_t)rows * H2;
+    s.dh1 = p; p += (size_t)rows * H1;
+    s.dout = p; p += (size_t)rows * 4;
+    return s;
+}
+
+enum { S_TA = 0, S_C1, S_C2, S_TC1, S_TC2, S_API, S_ABC, S_BCS, S_CPI, S_CSOFT, S_COUNT };
+
+int fwd_blocks(const FwdArgs& a) {
+    int n = 0;
+    for (int j = 0; j < a.njobs; ++j) n += ((a.job[j].rows + RT - 1) / RT) * (H2 / kNT);
+    return n;
+}
+int bwd_blocks(const BwdArgs& a) {
+    int n = 0;
+    for (int j = 0; j < a.njobs; ++j) n += ((a.job[j].rows + RT - 1) / RT) * (H1 / kNT);
+    return n;
+}
+
+const Mlp kActor{13, 4};
+const Mlp kQ{17, 1};
+
+}  // namespace
+
+extern "C" {
+
+int hx_actor_param_count(void) { return kActor.size(); }
+int hx_critic_param_count(void) { return 2 * kQ.padded(); }
+int64_t hx_hirl_workspace_floats(int32_t batch) { return (int64_t)S_COUNT * kSlotFloats * batch + 64; }
+int64_t hx_act_workspace_floats(int64_t rows) { return rows * (int64_t)H2; }
+
+/* chooseAction / chooseActionSmallNoise / chooseActionNoNoise for `rows` observations (HIRL.py:192-212):
+ * actions = clamp(actor(obs) + noise, -1, 1).  noise_mode 0: none, 1: noise[4] shared by all rows, 2: noise[rows][4],
+ * 3: N(0, sigma^2) per row and component from Philox(seed; row0 + row, call).  ws: hx_act_workspace_floats(rows). */
+int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* actions, int32_t noise_mode, const float* noise,
+                 float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* ws, void* stream) {
+    HX_REQUIRE(actor && obs && actions && ws && rows > 0, "hx_actor_act: bad arguments");
+    HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act: bad noise mode");
+    FwdArgs F{};
+    F.njobs = 1;
+    F.slope = slope;
+    FwdJob& J = F.job[0];
+    J.net = actor; J.m = kActor;
+    J.src = RowSrc{obs, nullptr, nullptr, 0, 13};
+    J.col0 = 0; J.act_mode = 0; J.noise = nullptr; J.rows = (int)rows; J.save = 0;
+    J.ws = Slot{}; J.ws.z2 = ws;
+    hipLaunchKernelGGL(fwd_l2_kernel, dim3(fwd_blocks(F)), dim3(kThreads), 0, (hipStream_t)stream, F);
+    ActArgs H{actor, kActor, ws, (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
+              noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, seed, row0, call};
+    hipLaunchKernelGGL(act_head_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, H);
+    HX_CHECK_LAUNCH("hx_actor_act");
+    return 0;
+}
+
+static void make_slots(const HxNets* N, int B, Slot* s) {
+    for (int i = 0; i < S_COUNT; ++i) s[i] = carve_slot(N->ws + (size_t)i * kSlotFloats * B, B);
+}
+
+/* Stage 1 (every call): TD target, critic forward, critic gradients -> grad_critic, losses[0].  HIRL.py:259-286 */
+int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, void* stream) {
+    HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_critic_grads: batch must be a positive multiple of 16");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = Bt->batch;
+    Slot s[S_COUNT];
+    make_slots(N, B, s);
+    const RowSrc src{Bt->ring, Bt->expert_ring, Bt->idx, Bt->n_main, 32};
+    HX_CHECK_HIP(hipMemsetAsync(N->losses, 0, sizeof(float), st));
+    const float* tc1 = N->target_critic;
+    const float* tc2 = N->target_critic + kQ.padded();
+    {   // launch A: targetActor(s'), critic Q1/Q2 (s, a)
+        FwdArgs F{};
+        F.njobs = 3; F.slope = Hy->slope;
+        F.job[0] = FwdJob{N->target_actor, kActor, src, 17, 0, Head{}, nullptr, 0.f, s[S_TA], B, 0};
+        F.job[1] = FwdJob{N->critic, kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C1], B, 1};
+        F.job[2] = FwdJob{N->critic + kQ.padded(), kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C2], B, 1};
+        hipLaunchKernelGGL(fwd_l2_kernel, dim3(fwd_blocks(F)), dim3(kThreads), 0, st, F);
+    }
+    {   // launch B: targetCritic Q1/Q2 (s', clamp(targetActor(s') + clamp(noise)))
+        FwdArgs F{};
+        F.njobs = 2; F.slope = Hy->slope;
+        const Head prev{N->target_actor, kActor, s[S_TA]};
+        F.job[0] = FwdJob{tc1, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC1], B, 0};
+        F.job[1] = FwdJob{tc2, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC2], B, 0};
+        hipLaunchKernelGGL(fwd_l2_kernel, dim3(fwd_blocks(F)), dim3(kThreads), 0, st, F);
+    }
+    {   // launch C: y, loss, dq, LN2 backward, dh1 for both heads
+        BwdArgs G{};
+        G.njobs = 2; G.slope = Hy->slope; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = N->soft_count;
+        for (int h = 0; h < 2; ++h) {
+            BwdJob& J = G.job[h];
+            J = BwdJob{};
+            J.net = N->critic + h * kQ.padded(); J.m = kQ; J.ws = s[S_C1 + h]; J.rows = B; J.mode = BM_CRITIC_TD;
+            J.t1 = Head{tc1, kQ, s[S_TC1]}; J.t2 = Head{tc2, kQ, s[S_TC2]}; J.src = src; J.gamma = Hy->gamma;
+        }
+        hipLaunchKernelGGL(bwd_l2_kernel, dim3(bwd_blocks(G)), dim3(kThreads), 0, st, G);
+    }
+    {   // launch D: all critic parameter gradients
+        WgArgs W{};
+        W.njobs = 2; W.slope = Hy->slope; W.w_kind = 0; W.w_given = 0.f; W.inv_batch = 1.0f / B;
+        W.soft_count = N->soft_count; W.wstate = N->wstate;
+        for (int h = 0; h < 2; ++h) {
+            WgJob& J = W.job[h];
+            J = WgJob{};
+            J.net = N->critic + h * kQ.padded(); J.grad = N->grad_critic + h * kQ.padded(); J.m = kQ;
+            J.ws[0] = s[S_C1 + h]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
+        }
+        hipLaunchKernelGGL(wgrad_kernel, dim3(W.njobs * kWgPerJob), dim3(kThreads), 0, st, W);
+    }
+    HX_CHECK_LAUNCH("hx_hirl_critic_grads");
+    return 0;
+}
+
+/* Adam step over a flat buffer (torch.optim.Adam defaults; step = 1-based step count; grad is multiplied by
+ * grad_scale first — 1/world_size after a SUM all-reduce).  which: 0 critic, 1 actor (also finishes actor_loss /
+ * bc_weight bookkeeping: w_kind 0 given, 1 estimate from soft_count, 2 reuse stored). */
+int hx_adam(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t step, float grad_scale, int32_t w_kind, float w_given,
+            float warm, int32_t batch, void* stream) {
+    HX_REQUIRE(N && Hy && step >= 1 && (which == 0 || which == 1), "hx_adam: bad arguments");
+    const double b1 = 0.9, b2 = 0.999;
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    AdamArgs A{};
+    A.n = which == 0 ? 2 * kQ.padded() : kActor.size();
+    A.p = which == 0 ? N->critic : N->actor;
+    A.g = which == 0 ? N->grad_critic : N->grad_actor;
+    A.m = which == 0 ? N->m_critic : N->m_actor;
+    A.v = which == 0 ? N->v_critic : N->v_actor;
+    A.b1 = (float)b1; A.b2 = (float)b2; A.eps = 1e-8f;
+    A.step_size = (float)((which == 0 ? Hy->lr_critic : Hy->lr_actor) / bc1);
+    A.bc2_sqrt = (float)sqrt(bc2);
+    A.gscale = grad_scale;
+    A.finish_actor = which == 1;
+    A.w_kind = w_kind; A.w_given = w_given; A.warm = warm; A.inv_batch = 1.0f / (batch > 0 ? batch : 1);
+    A.soft_count = N->soft_count; A.wstate = N->wstate; A.losses = N->losses; A.use_bc = Hy->use_bc;
+    hipLaunchKernelGGL(adam_kernel, dim3((A.n / 4 + kThreads) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, A);
+    HX_CHECK_LAUNCH("hx_adam");
+    return 0;
+}
+
+/* Stage 2a (delayed actor step, HIRL.py:291-319): actor / bc_actor forward, Q1 with the UPDATED critic, the soft
+ * count, backward down to dz2/dh1 of the actor.  Leaves soft_count and losses[2..4] ready; no parameter gradient yet. */
+int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t estimate_soft, void* stream) {
+    HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_actor_backward: batch must be a positive multiple of 16");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = Bt->batch;
+    Slot s[S_COUNT];
+    make_slots(N, B, s);
+    const RowSrc src{Bt->ring, Bt->expert_ring, Bt->idx, Bt->n_main, 32};
+    const RowSrc bcsrc{Bt->bc_table, Bt->bc_table, Bt->idx_bc, B, 32};
+    const bool bc = Hy->use_bc != 0, soft = bc && estimate_soft;
+    HX_CHECK_HIP(hipMemsetAsync(N->losses + 1, 0, 4 * sizeof(float), st));
+    HX_CHECK_HIP(hipMemsetAsync(N->soft_count, 0, sizeof(int), st));
+    {   // launch F: actor(s), actor(s_bc), bc_actor(s)
+        FwdArgs F{};
+        F.slope = Hy->slope;
+        int n = 0;
+        F.job[n++] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1};
+        if (bc) F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1};
+        if (soft) F.job[n++] = FwdJob{N->bc_actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0};
+        F.njobs = n;
+        hipLaunchKernelGGL(fwd_l2_kernel, dim3(fwd_blocks(F)), dim3(kThreads), 0, st, F);
+    }
+    {   // launch G: Q1(s, pi(s)) and Q1(s, bc_actor(s)) with the updated critic
+        FwdArgs F{};
+        F.slope = Hy->slope;
+        int n = 0;
+        F.job[n++] = FwdJob{N->critic, kQ, src, 0, 1, Head{N->actor, kActor, s[S_API]}, nullptr, 0.f, s[S_CPI], B, 1};
+        if (soft) F.job[n++] = FwdJob{N->critic, kQ, src, 0, 1, Head{N->bc_actor, kActor, s[S_BCS]}, nullptr, 0.f, s[S_CSOFT], B, 0};
+        F.njobs = n;
+        hipLaunchKernelGGL(fwd_l2_kernel, dim3(fwd_blocks(F)), dim3(kThreads), 0, st, F);
+    }
+    {   // launch H: rl_loss, soft count, critic backward down to dh1 (gradient wrt the action comes next)
+        BwdArgs G{};
+        G.njobs = 1; G.slope = Hy->slope; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = N->soft_count;
+        BwdJob& J = G.job[0];
+        J = BwdJob{};
+        J.net = N->critic; J.m = kQ; J.ws = s[S_CPI]; J.rows = B; J.mode = BM_CRITIC_PI;
+        if (soft) J.soft = Head{N->critic, kQ, s[S_CSOFT]};
+        hipLaunchKernelGGL(bwd_l2_kernel, dim3(bwd_blocks(G)), dim3(kThreads), 0, st, G);
+    }
+    {   // launch I: actor backward for the RL batch (through tanh and the critic's input gradient) and the BC batch
+        BwdArgs G{};
+        G.slope = Hy->slope; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = N->soft_count;
+        int n = 0;
+        {
+            BwdJob& J = G.job[n++];
+            J = BwdJob{};
+            J.net = N->actor; J.m = kActor; J.ws = s[S_API]; J.rows = B; J.mode = BM_ACTOR_PI;
+            J.crit = Head{N->critic, kQ, s[S_CPI]};
+        }
+        if (bc) {
+            BwdJob& J = G.job[n++];
+            J = BwdJob{};
+            J.net = N->actor; J.m = kActor; J.ws = s[S_ABC]; J.rows = B; J.mode = BM_ACTOR_BC;
+            J.src = bcsrc; J.lambda = Hy->loss_lambda;
+        }
+        G.njobs = n;
+        hipLaunchKernelGGL(bwd_l2_kernel, dim3(bwd_blocks(G)), dim3(kThreads), 0, st, G);
+    }
+    HX_CHECK_LAUNCH("hx_hirl_actor_backward");
+    return 0;
+}
+
+/* Stage 2b: actor parameter gradients grad_actor = w * dL_bc + (1 - w) * dL_rl (HIRL.py:321-324).
+ * w_kind 0: w_given (linear / fixed schedule, train_all.py:328-333); 1: soft estimate soft_count / batch + warm
+ * (HIRL.py:304-306; soft_count may have been all-reduced and `batch` is then the global batch); 2: stored weight. */
+int hx_hirl_actor_wgrad(const HxNets* N, const HxHyper* Hy, int32_t batch, int32_t count_batch, int32_t w_kind, float w_given,
+                        float warm, void* stream) {
+    HX_REQUIRE(N && Hy && batch > 0 && count_batch > 0, "hx_hirl_actor_wgrad: bad arguments");
+    Slot s[S_COUNT];
+    make_slots(N, batch, s);
+    const bool bc = Hy->use_bc != 0;
+    WgArgs W{};
+    W.njobs = 1; W.slope = Hy->slope; W.w_kind = bc ? w_kind : 0; W.w_given = bc ? w_given : 0.0f; W.warm = warm;
+    W.inv_batch = 1.0f / count_batch; W.soft_count = N->soft_count; W.wstate = N->wstate;
+    WgJob& J = W.job[0];
+    J = WgJob{};
+    J.net = N->actor; J.grad = N->grad_actor; J.m = kActor;
+    J.ws[0] = s[S_API]; J.rows[0] = batch; J.wmode[0] = 1;
+    J.nslots = 1;
+    if (bc) { J.ws[1] = s[S_ABC]; J.rows[1] = batch; J.wmode[1] = 2; J.nslots = 2; }
+    hipLaunchKernelGGL(wgrad_kernel, dim3(kWgPerJob), dim3(kThreads), 0, (hipStream_t)stream, W);
+    HX_CHECK_LAUNCH("hx_hirl_actor_wgrad");
+    return 0;
+}
+
+/* soft_update of both targets (HIRL.py:327-330) */
+int hx_polyak(const HxNets* N, const HxHyper* Hy, void* stream) {
+    HX_REQUIRE(N && Hy, "hx_polyak: bad arguments");
+    const int nc = 2 * kQ.padded(), na = kActor.size();
+    hipLaunchKernelGGL(polyak_kernel, dim3((nc / 4 + kThreads) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, N->target_critic, N->critic, nc, Hy->tau);
+    hipLaunchKernelGGL(polyak_kernel, dim3((na / 4 + kThreads) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, N->target_actor, N->actor, na, Hy->tau);
+    HX_CHECK_LAUNCH("hx_polyak");
+    return 0;
+}
+
+}  // extern "C"

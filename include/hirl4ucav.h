@@ -101,6 +101,80 @@ int hx_env_rearm(float* state, int64_t n, int64_t stride, const uint8_t* mask, v
 int hx_label_transitions(const float* s, const float* a, const float* ns, int64_t n, float* reward, int8_t* success,
                          uint8_t* done, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Actor / critic side.  Parameters, gradients and Adam moments are FLAT fp32 buffers in the reference's
+ * state_dict order (hirl/agents/HIRL.py:19-146): an MLP block is
+ *   full{1|3}.weight [256][in], .bias [256], layernorm{1|3}.weight [256], .bias [256], full{2|4}.weight [512][256],
+ *   .bias [512], layernorm{2|4}.weight [512], .bias [512], final{|1|2}.weight [out][512], .bias [out]
+ * Actor = one block (in 13, out 4) = 138,756 floats; Critic = two blocks (in 17, out 1), each padded from 138,241
+ * to 138,244 floats so that the second head stays 16-byte aligned (hx_critic_param_count() = 276,488).
+ * ------------------------------------------------------------------------------------------------------------ */
+int hx_actor_param_count(void);
+int hx_critic_param_count(void);
+int64_t hx_hirl_workspace_floats(int32_t batch);
+int64_t hx_act_workspace_floats(int64_t rows);
+
+/* Agent.chooseAction / chooseActionSmallNoise / chooseActionNoNoise for `rows` observations at once
+ * (hirl/agents/HIRL.py:192-212): actions = clamp(actor(obs) + noise, -1, 1).
+ * noise_mode 0: none (NoNoise); 1: noise[4] shared by all rows (the reference's one draw per call); 2: noise[rows][4];
+ * 3: N(0, sigma^2) per row and component from Philox4x32-10(key = seed; counter = (row0 + row, call)).
+ * slope: 0 = ReLU nets (HIRL.py), 0.01 = LeakyReLU nets (TD3.py / BC.py).  ws: hx_act_workspace_floats(rows). */
+int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
+                 const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* ws,
+                 void* stream);
+
+/* Minibatch of Agent.learn (HIRL.py:223-251).  Row r is ring[idx[r]] for r < n_main, expert_ring[idx[r]] otherwise
+ * (buffer rows first, then expert rows); BC row r is bc_table[idx_bc[r]] (cols 0..12 state, 13..16 action).
+ * All tables are [*][HX_ROW_WORDS] fp32. */
+typedef struct HxBatch {
+    const float* ring;
+    const float* expert_ring;
+    const int32_t* idx;   /* [batch] */
+    int32_t n_main;
+    int32_t batch;        /* multiple of 16 */
+    const float* bc_table;
+    const int32_t* idx_bc; /* [batch] */
+    const float* noise;   /* [4] target-smoothing noise, unclamped: ONE draw for the whole batch (HIRL.py:265) */
+} HxBatch;
+
+typedef struct HxNets {
+    float* actor; float* critic; float* target_actor; float* target_critic; const float* bc_actor;
+    float* grad_actor; float* grad_critic;
+    float* m_actor; float* v_actor; float* m_critic; float* v_critic;
+    float* losses;       /* [8]: critic_loss, actor_loss, bc_loss, rl_loss, bc_fire_loss, bc_weight (HIRL.py:334) */
+    int32_t* soft_count; /* [1] count(soft_Q > rl_Q) (HIRL.py:303) — all-reduce it when the batch is sharded */
+    float* wstate;       /* [1] the BC weight in force */
+    float* ws;           /* hx_hirl_workspace_floats(batch) */
+} HxNets;
+
+typedef struct HxHyper {
+    float gamma, tau, lr_actor, lr_critic, slope, noise_clamp, loss_lambda;
+    int32_t use_bc; /* 1: HIRL (TD3+BC, HIRL.py), 0: TD3 (TD3.py:201-260) */
+} HxHyper;
+
+/* Agent.learn, split at the points where a sharded run exchanges data; single-GPU callers run the
+ * stages back to back on one stream:
+ *   hx_hirl_critic_grads    TD target + critic loss + grad_critic          HIRL.py:259-286   -> [all-reduce grad_critic]
+ *   hx_adam(which = 0)      critic.optimizer.step()                         HIRL.py:288
+ *   -- every second call (actorTrainable, HIRL.py:291,332) --
+ *   hx_hirl_actor_backward  pi, rl_Q with the updated critic, soft count,  HIRL.py:293-319   -> [all-reduce soft_count]
+ *                           BC loss, backward down to the actor's dz2/dh1
+ *   hx_hirl_actor_wgrad     grad_actor = w dL_bc + (1 - w) dL_rl            HIRL.py:321-324   -> [all-reduce grad_actor]
+ *   hx_adam(which = 1)      actor.optimizer.step(); actor_loss, bc_weight   HIRL.py:325,334
+ *   hx_polyak               every 3rd actor step (HIRL.py:327-330) */
+int hx_hirl_critic_grads(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, void* stream);
+int hx_hirl_actor_backward(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, int32_t estimate_soft,
+                           void* stream);
+/* w_kind 0: w = w_given (linear / fixed, train_all.py:328-333); 1: w = soft_count / count_batch + warm (HIRL.py:304-306);
+ * 2: the stored weight.  w is clipped to <= 1 (HIRL.py:308). */
+int hx_hirl_actor_wgrad(const HxNets* nets, const HxHyper* hyper, int32_t batch, int32_t count_batch, int32_t w_kind,
+                        float w_given, float warm, void* stream);
+/* which 0 critic / 1 actor; step = 1-based Adam step; grad is scaled by grad_scale first (1/world after a SUM). */
+int hx_adam(const HxNets* nets, const HxHyper* hyper, int32_t which, int32_t step, float grad_scale, int32_t w_kind,
+            float w_given, float warm, int32_t batch, void* stream);
+int hx_polyak(const HxNets* nets, const HxHyper* hyper, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,8 +10,9 @@ holds only: the minibatch indices the reference drew (random.sample / np.random.
 the (4,) target-smoothing noise it drew (torch.normal wrapped and recorded), the arguments passed to learn(), the
 returned tuples for K consecutive calls, and per-call probes of every network (sum, sum of |x|, 128 fixed entries).
 
-  hirl_learn_<mode>.npz   G4  hirl.agents.HIRL.Agent.learn, 10 calls = two 5-call "episodes" (the second starts on
-                              a non-actor call -> the stale soft weight of SURVEY.md quirk 2)
+  hirl_learn_<mode>.npz   G4  hirl.agents.HIRL.Agent.learn, 10 calls = three "episodes" starting at calls 0, 5, 8 (the
+                              second starts on a non-actor call -> the stale soft weight of SURVEY.md quirk 2,
+                              the third on an actor call -> a fresh estimate)
                               modes: soft_e0, soft_e64, fixed_e32, linear_e0
   td3_learn.npz           G5  agents.TD3.Agent.learn (leaky_relu nets), 8 calls
   hirl_choose_action.npz  G7  chooseAction / chooseActionSmallNoise / chooseActionNoNoise on fixed states
@@ -41,6 +42,9 @@ import hirl.agents.HIRL as ref_hirl  # noqa: E402
 import hirl.utils.buffer as ref_buf  # noqa: E402
 
 torch.set_num_threads(1)  # deterministic summation order in the reference's CPU matmuls
+
+
+EPISODE_STARTS = (0, 5, 8)  # call 5 is a non-actor call (stale weight, quirk 2), call 8 an actor call (re-estimate)
 
 
 class Recorder:
@@ -111,8 +115,8 @@ def run_hirl(mode, expert_num, schedule):
     outs, prb, w_in, warm_in = [], [], [], []
     bc_weight_now = None
     for k in range(K):
-        if k % 5 == 0:  # episode start, train_all.py:328-339
-            bc_weight_now, warm = schedule(k // 5)
+        if k in EPISODE_STARTS:  # episode start, train_all.py:328-339
+            bc_weight_now, warm = schedule(EPISODE_STARTS.index(k))
         w_in.append(bc_weight_now)
         warm_in.append(warm)
         ret = agent.learn(bc_weight_now, expert_num, warm)

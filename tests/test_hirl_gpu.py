@@ -1,0 +1,243 @@
+"""GPU parity tests of the actor/critic path (hx_actor_act, hx_hirl_*, hx_adam, hx_polyak through the C ABI) against
+the update oracle (oracle/hirl_oracle.py, itself pinned to the reference) and against the golden vectors recorded from
+the reference's own Agent.learn (tests/golden/hirl_learn_*.npz, td3_learn.npz, hirl_choose_action.npz).
+
+Tolerances (fp32 everywhere; the GPU sums in MFMA k-order, the reference in MKL/oneDNN order):
+  returned losses            rtol 2e-5 (north_star: HIRL loss parity)
+  gradients vs the oracle    |diff| <= 1e-4 |g| + 2e-5 max|g| per tensor (entries that are sums of cancelling terms
+                             carry fp32 summation-order noise relative to the tensor's scale, not to themselves)
+  parameters after k steps   atol 2e-6 + rtol 1e-5 on the probes (Adam turns last-bit gradient differences of
+                             near-zero entries into visible fractions of lr = 1e-3; bounded by the probe check)"""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import hirl_oracle as H  # noqa: E402
+from tests import _hirl_data as D  # noqa: E402
+
+MODES = ["soft_e0", "soft_e64", "fixed_e32", "linear_e0"]
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from hirl4ucav_amd.agents import engine
+
+    return engine
+
+
+def device_tables(data):
+    ring = torch.from_numpy(data["replay"]).cuda().contiguous()
+    exp = torch.from_numpy(data["expert_rows"]).cuda().contiguous()
+    bc = np.zeros((data["expert_s"].shape[0], 32), np.float32)
+    bc[:, 0:13], bc[:, 13:17] = data["expert_s"], data["expert_a"]
+    return ring, exp, torch.from_numpy(bc).cuda().contiguous()
+
+
+def flat_oracle(p, layout, size):
+    out = np.zeros(size, np.float32)
+    for k, off, shp in layout:
+        v = p[k].detach().numpy() if torch.is_tensor(p[k]) else np.asarray(p[k])
+        out[off:off + v.size] = v.ravel()
+    return out
+
+
+def check_grads(eng_mod, got_flat, oracle_grads, layout, what):
+    """Elementwise |diff| <= 1e-4 |g| + 2e-5 max|g|.  A hidden unit whose pre-activation is within fp32 rounding of zero
+    for some row is active on one side and not on the other (ReLU's derivative is discontinuous); that moves the handful
+    of entries fed by that unit (one row of W1, one entry of b1 / LayerNorm) by that row's share.  Such entries are
+    tolerated when they are < 1 % of the tensor AND the tensor's relative L2 error stays below 2e-3."""
+    got = got_flat.cpu().numpy()
+    for k, off, shp in layout:
+        g = oracle_grads[k].numpy().ravel()
+        x = got[off:off + g.size]
+        tol = 1e-4 * np.abs(g) + 2e-5 * max(np.abs(g).max(), 1e-30)
+        bad = np.abs(x - g) > tol
+        rel_l2 = np.linalg.norm(x - g) / max(np.linalg.norm(g), 1e-30)
+        ok = (not bad.any()) or (bad.mean() < 0.01 + 1.0 / g.size and rel_l2 < 2e-3)
+        assert ok, (f"{what} {k}: {bad.sum()} of {g.size} off, worst {np.abs(x - g).max():.3e} vs max|g| {np.abs(g).max():.3e}, "
+                    f"rel L2 {rel_l2:.2e}")
+
+
+def probes_of(e, eng_mod):
+    """same flattening as the golden probes: exact (unpadded) state_dict order"""
+    out = []
+    for flat, layout in ((e.actor, eng_mod.ACTOR_LAYOUT), (e.critic, eng_mod.CRITIC_LAYOUT), (e.target_actor, eng_mod.ACTOR_LAYOUT),
+                         (e.target_critic, eng_mod.CRITIC_LAYOUT)):
+        f = flat.cpu().numpy()
+        out.append(D.net_probe(np.concatenate([f[off:off + int(np.prod(shp))] for k, off, shp in layout])))
+    return out
+
+
+def test_actor_act_matches_oracle_and_reference(eng_mod, golden_dir):
+    params = D.make_params(D.PARAM_SEED)
+    e = eng_mod.HirlEngine(batch=128)
+    e.load_params(params["actor"], params["critic"], params["bc_actor"])
+    o = H.HirlOracle(params["actor"], params["critic"], params["bc_actor"])
+    rng = np.random.default_rng(0)
+    for n in (1, 5, 16, 1000):
+        obs = rng.uniform(-1, 1, (n, 13)).astype(np.float32)
+        a = e.act(torch.from_numpy(obs).cuda()).cpu().numpy()
+        np.testing.assert_allclose(a, o.choose_action(obs), rtol=1e-5, atol=1e-6)
+        shared = (rng.normal(0, 0.5, 4)).astype(np.float32)
+        a = e.act(torch.from_numpy(obs).cuda(), noise=torch.from_numpy(shared).cuda()).cpu().numpy()
+        np.testing.assert_allclose(a, o.choose_action(obs, shared), rtol=1e-5, atol=1e-6)
+        per = rng.normal(0, 0.5, (n, 4)).astype(np.float32)
+        a = e.act(torch.from_numpy(obs).cuda(), noise=torch.from_numpy(per).cuda()).cpu().numpy()
+        np.testing.assert_allclose(a, o.choose_action(obs, per), rtol=1e-5, atol=1e-6)
+    # golden: the reference's chooseAction / SmallNoise / NoNoise with its recorded noise draws
+    g = np.load(os.path.join(golden_dir, "hirl_choose_action.npz"))
+    st = torch.from_numpy(g["states"]).cuda()
+    np.testing.assert_allclose(e.act(st).cpu().numpy(), g["action_clean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(e.act(st, noise=torch.from_numpy(g["noise"]).cuda()).cpu().numpy(), g["action"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(e.act(st, noise=torch.from_numpy(g["small_noise"]).cuda()).cpu().numpy(), g["action_small"], rtol=1e-5, atol=1e-6)
+    # Philox exploration noise: deterministic per (seed, row, call), right scale, independent per row
+    obs = torch.zeros((20000, 13), device="cuda")
+    clean = e.act(obs)
+    e.act_calls = 10
+    n1 = (e.act(obs, sigma=0.1, seed=5) - clean).cpu().numpy()
+    e.act_calls = 10
+    n2 = (e.act(obs, sigma=0.1, seed=5) - clean).cpu().numpy()
+    n3 = (e.act(obs, sigma=0.1, seed=5) - clean).cpu().numpy()
+    assert np.array_equal(n1, n2) and not np.array_equal(n1, n3)
+    inner = np.abs(clean.cpu().numpy()) < 0.5  # away from the clamp
+    assert inner.any()
+    z = n1[inner] / 0.1
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03 and abs(np.corrcoef(n1[:, 0], n1[:, 1])[0, 1]) < 0.03
+
+
+def sync_oracle(o, e, E):
+    """Copy the engine's whole state (5 nets, Adam moments and step counts, alternation counters) into the oracle, so
+    that one call is compared from IDENTICAL states.  Free-running fp32 trajectories separate chaotically as soon as
+    one ReLU unit sits within rounding of zero; per-call comparison keeps the check about the kernels."""
+    sd = e.state_dicts()
+    for name, dst in (("actor", o.actor), ("critic", o.critic), ("targetActor", o.target_actor), ("targetCritic", o.target_critic)):
+        for k in dst:
+            dst[k].data.copy_(sd[name][k].cpu())
+    for opt, m, v, layout, t in ((o.opt_actor, e.m_actor, e.v_actor, E.ACTOR_LAYOUT, e.actor_step),
+                                 (o.opt_critic, e.m_critic, e.v_critic, E.CRITIC_LAYOUT, e.critic_step)):
+        mm, vv = E.unpack(m, layout), E.unpack(v, layout)
+        for k in opt.m:
+            opt.m[k].copy_(mm[k].cpu())
+            opt.v[k].copy_(vv[k].cpu())
+        opt.t = t
+    o.actor_trainable, o.update_count = e.actor_trainable, e.update_count
+
+
+def assert_losses(got, ref, what):
+    # rl_loss is a mean of O(1) Q values of both signs: absolute fp32 noise ~1e-6
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=5e-6, err_msg=what)
+
+
+def check_params(e, o, E, what):
+    """After one step from identical states: all but a vanishing fraction of entries agree to 2e-6; the rest are
+    entries whose gradient is rounding noise around zero, which Adam moves by up to 2 lr in either direction."""
+    for flat, layout, ref in ((e.actor, E.ACTOR_LAYOUT, o.actor), (e.critic, E.CRITIC_LAYOUT, o.critic),
+                              (e.target_actor, E.ACTOR_LAYOUT, o.target_actor), (e.target_critic, E.CRITIC_LAYOUT, o.target_critic)):
+        f = flat.cpu().numpy()
+        d = np.concatenate([np.abs(f[off:off + int(np.prod(shp))] - ref[k].detach().numpy().ravel()) for k, off, shp in layout])
+        assert (d > 2e-6).mean() < 2e-4 and d.max() <= 2.1e-3, f"{what}: {(d > 2e-6).sum()} entries off, max {d.max():.2e}"
+
+
+def check_probes_free_running(e, E, g, k, what):
+    """The engine's own trajectory vs the reference's recorded one (no re-sync): 128 probed entries per network.  Adam
+    normalises gradients, so fp32 summation-order noise on a near-zero gradient entry becomes a few 1e-6 of parameter
+    difference per step; >= 97 % of the probes stay within 2e-6, none may leave 5e-5, and the |x| sums agree to 2e-6."""
+    for j, (s, a, v) in enumerate(probes_of(e, E)):
+        d = np.abs(v - g["probe_val"][k][j])
+        assert (d > 2e-6).mean() <= 0.03 and d.max() < 5e-5, f"{what} net {j}: {(d > 2e-6).sum()} probes off, max {d.max():.2e}"
+        np.testing.assert_allclose(a, g["probe_abs"][k][j], rtol=2e-6, err_msg=f"{what} net {j} |sum|")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_learn_matches_oracle_and_reference(eng_mod, mode, golden_dir):
+    """10 consecutive Agent.learn calls (three "episodes": soft-weight estimate, stale weight, re-estimate; actor every
+    2nd call; Polyak at the 6th).  Free-running against the reference's recorded outputs; call by call against the
+    oracle from identical states (losses, every gradient tensor, parameters after Adam/Polyak)."""
+    g = np.load(os.path.join(golden_dir, f"hirl_learn_{mode}.npz"))
+    params, data = D.make_params(D.PARAM_SEED), D.make_data(D.DATA_SEED)
+    assert D.checksum(params) == str(g["param_checksum"]) and D.checksum(data) == str(g["data_checksum"])
+    ring, exp, bc = device_tables(data)
+    e = eng_mod.HirlEngine(batch=128)
+    e.load_params(params["actor"], params["critic"], params["bc_actor"])
+    o = H.HirlOracle(params["actor"], params["critic"], params["bc_actor"])
+    ne = int(g["expert_num"])
+    for k in range(g["out"].shape[0]):
+        idx = np.concatenate([g["idx_buf"][k], g["idx_exp"][k]]).astype(np.int32)
+        w_in = 100 if g["bc_w_in"][k] == 100 else float(g["bc_w_in"][k])
+        warm = float(g["warm_in"][k])
+        was_actor_call = e.actor_trainable
+        sync_oracle(o, e, eng_mod)
+        e.learn(ring, torch.from_numpy(idx).cuda(), torch.from_numpy(g["noise"][k]).cuda(), expert_ring=exp, n_main=128 - ne,
+                bc_table=bc, idx_bc=torch.from_numpy(g["idx_bc"][k].astype(np.int32)).cuda(), bc_weight_now=w_in, bc_warm_up_weight=warm)
+        got = e.losses_host()
+        rows = data["replay"][g["idx_buf"][k]]
+        if ne:
+            rows = np.concatenate([rows, data["expert_rows"][g["idx_exp"][k]]], 0)
+        ob = (rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31])
+        ref = o.learn(ob, (data["expert_s"][g["idx_bc"][k]], data["expert_a"][g["idx_bc"][k]]), g["noise"][k], w_in, warm)
+        assert_losses(got, ref, f"{mode} call {k} vs oracle")
+        check_grads(eng_mod, e.grad_critic, o.last_grads["critic"], eng_mod.CRITIC_LAYOUT, f"{mode} call {k} critic grad")
+        if was_actor_call:
+            check_grads(eng_mod, e.grad_actor, o.last_grads["actor"], eng_mod.ACTOR_LAYOUT, f"{mode} call {k} actor grad")
+        check_params(e, o, eng_mod, f"{mode} call {k} params")
+        # the reference's own recorded run
+        assert_losses(got, g["out"][k], f"{mode} call {k} vs reference golden")
+        check_probes_free_running(e, eng_mod, g, k, f"{mode} call {k}")
+    assert e.critic_step == 10 and e.actor_step == 5 and e.update_count == 5 and e.actor_trainable
+
+
+def test_td3_learn_matches_reference(eng_mod, golden_dir):
+    g = np.load(os.path.join(golden_dir, "td3_learn.npz"))
+    params, data = D.make_params(D.PARAM_SEED), D.make_data(D.DATA_SEED)
+    ring, exp, bc = device_tables(data)
+    e = eng_mod.HirlEngine(batch=128, slope=0.01, use_bc=False)
+    e.load_params(params["actor"], params["critic"])
+    o = H.HirlOracle(params["actor"], params["critic"], None, slope=0.01, use_bc=False)
+    for k in range(g["out"].shape[0]):
+        was_actor_call = e.actor_trainable
+        sync_oracle(o, e, eng_mod)
+        e.learn(ring, torch.from_numpy(g["idx_buf"][k].astype(np.int32)).cuda(), torch.from_numpy(g["noise"][k]).cuda())
+        got = e.losses_host()
+        rows = data["replay"][g["idx_buf"][k]]
+        ref = o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), None, g["noise"][k])
+        assert_losses(got[:2], ref[:2], f"td3 call {k} vs oracle")
+        assert_losses(got[:2], g["out"][k], f"td3 call {k} vs reference golden")
+        check_grads(eng_mod, e.grad_critic, o.last_grads["critic"], eng_mod.CRITIC_LAYOUT, f"td3 call {k} critic grad")
+        if was_actor_call:
+            check_grads(eng_mod, e.grad_actor, o.last_grads["actor"], eng_mod.ACTOR_LAYOUT, f"td3 call {k} actor grad")
+        check_params(e, o, eng_mod, f"td3 call {k} params")
+        check_probes_free_running(e, eng_mod, g, k, f"td3 call {k}")
+
+
+def test_learn_ragged_batches_and_outlier_rows(eng_mod):
+    """Batch sizes other than 128 (multiples of 16), rows carrying the +600 kill bonus (100x TD errors), soft weight
+    with warm-up: losses, gradients and stepped parameters match the oracle call by call."""
+    params, data = D.make_params(11), D.make_data(12, outliers=True)
+    ring, exp, bc = device_tables(data)
+    rng = np.random.default_rng(1)
+    for B in (16, 48, 256):
+        e = eng_mod.HirlEngine(batch=B)
+        e.load_params(params["actor"], params["critic"], params["bc_actor"])
+        o = H.HirlOracle(params["actor"], params["critic"], params["bc_actor"])
+        for k in range(4):
+            idx = rng.integers(0, D.N_REPLAY, B).astype(np.int32)
+            ibc = rng.integers(0, D.N_EXPERT, B).astype(np.int32)
+            noise = rng.normal(0, 0.2, 4).astype(np.float32)
+            was_actor_call = e.actor_trainable
+            sync_oracle(o, e, eng_mod)
+            e.learn(ring, torch.from_numpy(idx).cuda(), torch.from_numpy(noise).cuda(), bc_table=bc, idx_bc=torch.from_numpy(ibc).cuda(),
+                    bc_weight_now=100, bc_warm_up_weight=0.1)
+            rows = data["replay"][idx]
+            ref = o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]),
+                          (data["expert_s"][ibc], data["expert_a"][ibc]), noise, 100, 0.1)
+            assert_losses(e.losses_host(), ref, f"B={B} call {k}")
+            check_grads(eng_mod, e.grad_critic, o.last_grads["critic"], eng_mod.CRITIC_LAYOUT, f"B={B} critic grad call {k}")
+            if was_actor_call:
+                check_grads(eng_mod, e.grad_actor, o.last_grads["actor"], eng_mod.ACTOR_LAYOUT, f"B={B} actor grad call {k}")
+            check_params(e, o, eng_mod, f"B={B} call {k} params")

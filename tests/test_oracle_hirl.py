@@ -50,6 +50,8 @@ def test_hirl_learn_matches_reference(mode, golden_dir):
     # quirks: actor every 2nd call, targets every 3rd actor update (6th call)
     assert o.opt_critic.t == 10 and o.opt_actor.t == 5 and o.update_count == 5
     assert g["out"][5][5] == g["out"][4][5]  # stale weight on the non-actor first call of "episode 2"
+    if mode.startswith("soft"):
+        assert g["out"][8][5] != g["out"][7][5]  # "episode 3" starts on an actor call: fresh estimate
 
 
 def test_td3_learn_matches_reference(golden_dir):
