@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path end to end on N GPUs of one node (one process per GPU).
+
+One "step" = one pass of the hot path over one batch of synthetic input, per GPU:
+    act      clamp(actor(obs) + N(0, 0.1^2), -1, 1) for all envs           (chooseAction, HIRL.py:192-198)
+    env      one simulator tick + obs/reward/done for all envs, fused replay insert   (HarfangEnv.step, train_all.py:343-349)
+    sample   device-side minibatch draw                                     (buffer.py:45, HIRL.py:249,265)
+    learn    one HIRL-soft Agent.learn at B = 128 (critic every call, actor every 2nd, Polyak every 6th)   (HIRL.py:221-334)
+i.e. the reference's inner loop (train_all.py:341-361) with the single socket env replaced by `--envs` resident envs.
+The update-to-data ratio is a stated design parameter: 1 learn() of the reference's batch per vector step.
+
+Workload (BASELINE.json configs[1]): 4,096 parallel straight_line envs per GPU, HIRL-soft, fp32, synthetic random-init
+episodes (random_reset, Philox), synthetic 20,000-row expert set, seeded-init networks.  Prints ONE JSON line (rank 0).
+
+    python bench.py                       # 1 GPU, defaults finish in about a minute (incl. the bounded CPU baseline)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak, same guide
+ENV_BYTES_FUSED = 550            # algorithmic bytes per env-step with the fused replay insert
+ENV_BYTES_PLAIN = 370
+ACTOR_FLOP = 272896              # forward FLOPs per sample (2 * MAC, GEMMs only), SURVEY.md 8d
+LEARN_FLOP_PER_SAMPLE = 3810816  # HIRL-soft learn(), averaged over the actor-every-2nd alternation, SURVEY.md 8d
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=2000)
+    p.add_argument("--warmup", type=int, default=200)
+    p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    p.add_argument("--batch", type=int, default=128)
+    p.add_argument("--scenario", default="straight_line")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--sweep", action="store_true", help="also sweep the env-step kernel over 4k..4M envs per launch")
+    return p.parse_args()
+
+
+def synthetic_expert(rng, n=20000):
+    """states U(-1,1)^13 with cols 7,8 in {+-1}, col 12 in [0, 0.2]; actions U(-1,1)^3 ++ fire +-1, P(+1) = 1e-3."""
+    s = rng.uniform(-1, 1, (n, 13)).astype(np.float32)
+    s[:, 7] = np.where(rng.random(n) < 0.5, 1, -1)
+    s[:, 8] = np.where(rng.random(n) < 0.5, 1, -1)
+    s[:, 12] = rng.uniform(0, 0.2, n)
+    a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    a[:, 3] = np.where(rng.random(n) < 1e-3, 1, -1)
+    return s, a
+
+
+def init_params(rng):
+    """Seeded-init networks with the reference's bounds (HIRL.py:26-37,111-121)."""
+    import math
+
+    def U(b, shape):
+        return rng.uniform(-b, b, shape).astype(np.float32)
+
+    def block(in_dim, out_dim, names):
+        fa, la, fb, lb, fin = names
+        return {fa + ".weight": U(math.sqrt(6 / in_dim), (256, in_dim)), fa + ".bias": U(1 / math.sqrt(in_dim), (256,)),
+                la + ".weight": np.ones(256, np.float32), la + ".bias": np.zeros(256, np.float32),
+                fb + ".weight": U(math.sqrt(6 / 256), (512, 256)), fb + ".bias": U(1 / 16, (512,)),
+                lb + ".weight": np.ones(512, np.float32), lb + ".bias": np.zeros(512, np.float32),
+                fin + ".weight": U(1 / math.sqrt(512), (out_dim, 512)), fin + ".bias": U(1 / math.sqrt(512), (out_dim,))}
+
+    actor = block(13, 4, ("full1", "layernorm1", "full2", "layernorm2", "final"))
+    bc = block(13, 4, ("full1", "layernorm1", "full2", "layernorm2", "final"))
+    critic = block(17, 1, ("full1", "layernorm1", "full2", "layernorm2", "final1"))
+    critic.update(block(17, 1, ("full3", "layernorm3", "full4", "layernorm4", "final2")))
+    return actor, critic, bc
+
+
+class Loop:
+    """act -> env step (+ fused insert) -> sample -> learn, everything resident on one GPU."""
+
+    def __init__(self, args, rank, world, device):
+        from hirl4ucav_amd import _lib
+        from hirl4ucav_amd.agents.engine import HirlEngine
+        from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
+        from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+        self.lib = _lib
+        self.args, self.rank, self.world = args, rank, world
+        n = args.envs
+        self.max_step = 1900 if args.scenario == "circular" else 1500  # train_all.py:159-183
+        self.replay = DeviceReplay(max(1 << 20, 2 * n), device)
+        self.env = BatchedHarfangEnv(n, scenario=args.scenario, device=device, seed=0, max_step=self.max_step, auto_reset=True,
+                                     random_reset=True, env_id0=rank * n, replay=self.replay)
+        rng = np.random.default_rng(0)  # same networks and expert set on every rank (replicas)
+        actor, critic, bc = init_params(rng)
+        self.eng = HirlEngine(batch=args.batch, device=device)
+        self.eng.load_params(actor, critic, bc)
+        es, ea = synthetic_expert(rng)
+        # BC table rows (s, a) and the expert replay ring labelled on the GPU (train_all.py:289-306)
+        bc_rows = np.zeros((es.shape[0], 32), np.float32)
+        bc_rows[:, 0:13], bc_rows[:, 13:17] = es, ea
+        self.bc_table = torch.from_numpy(bc_rows).to(device)
+        m = es.shape[0] - 1
+        s_t, a_t, ns_t = (torch.from_numpy(x).to(device).contiguous() for x in (es[:-1], ea[:-1], es[1:]))
+        r = torch.zeros(m, device=device)
+        sc = torch.zeros(m, dtype=torch.int8, device=device)
+        dn = torch.zeros(m, dtype=torch.uint8, device=device)
+        _lib.call("hx_label_transitions", s_t.data_ptr(), a_t.data_ptr(), ns_t.data_ptr(), m, r.data_ptr(), sc.data_ptr(), dn.data_ptr(),
+                  _lib.stream_ptr())
+        self.expert = DeviceReplay(m + 10, device)
+        self.expert.store_rows(torch.cat([s_t, a_t, ns_t, r[:, None], dn.float()[:, None]], 1), sc)
+        self.expert_len, self.bc_len = m, es.shape[0]
+        self.expert_num = 0  # steady state of the 128 -> 0 decay (train_all.py:356-357)
+        self.env.reset()
+        self.t = 0
+        self.actions = torch.zeros((n, 4), device=device)
+
+    def step(self, ev=None):
+        e, env = self.eng, self.env
+        if ev:
+            ev[0].record()
+        e.act(env.obs, sigma=0.1, seed=1, row0=env.env_id0, out=self.actions)  # actionNoise 0.1, HIRL.py:160
+        if ev:
+            ev[1].record()
+        env.step(self.actions)
+        if ev:
+            ev[2].record()
+        idx, idx_bc, noise = e.sample(self.replay, self.expert_len, self.bc_len, n_main=e.batch - self.expert_num, seed=2 + self.rank)
+        # soft weight: estimated at the start of every max_step-long "episode" of vector steps, kept in between
+        # (the reference re-estimates at most once per episode)
+        w = 100 if (self.t % self.max_step == 0) else None
+        e.learn(self.replay.ring, idx, noise, expert_ring=self.expert.ring, n_main=e.batch - self.expert_num,
+                bc_table=self.bc_table, idx_bc=idx_bc, bc_weight_now=w, bc_warm_up_weight=0.0)
+        if ev:
+            ev[3].record()
+        self.t += 1
+
+
+def cpu_baseline(args, seconds):
+    """The oracle (CPU restatement) timed on this host on a BOUNDED sample of the same workload: the same loop
+    (actor forward for all envs, env step for all envs with insert, one HIRL learn at B = 128) for as many vector steps
+    as fit in about `seconds`."""
+    from oracle import hirl_oracle as H
+    from tests import _oracle as ox
+
+    n = args.envs
+    rng = np.random.default_rng(0)
+    actor, critic, bc = init_params(rng)
+    es, ea = synthetic_expert(rng)
+    o = H.HirlOracle(actor, critic, bc)
+    envs, obs = ox.reset_batch(n, 0, 1, seed=0)
+    cap = 1 << 18
+    ring = np.zeros((cap, 32), np.float32)
+    rs = np.zeros(cap, np.int8)
+    total = np.zeros(1, np.uint64)
+    epi = np.zeros(n, np.uint32)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        a = o.choose_action(obs, rng.normal(0, 0.1, (n, 4)).astype(np.float32))
+        ox.step_batch(envs, a, obs, max_step=1500, auto_reset=1, randomize=1, seed=0, episode_ctr=epi, ring=ring, ring_succ=rs, total=total)
+        m = min(int(total[0]), cap)
+        idx = rng.integers(0, m, args.batch)
+        rows = ring[idx]
+        ibc = rng.integers(0, es.shape[0], args.batch)
+        o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), (es[ibc], ea[ibc]),
+                rng.normal(0, 0.2, 4).astype(np.float32), 100 if steps == 0 else o.bc_weight, 0.0)
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds or steps >= 2000:
+            break
+    return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{steps} vector steps of {n} envs (oracle: scalar C env step on 1 thread + torch-CPU actor forward and "
+                      f"HIRL learn on {torch.get_num_threads()} threads), {dt:.1f} s",
+            "update_steps_per_s": round(steps / dt, 2)}
+
+
+def env_sweep(device):
+    from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    out = []
+    for n in (4096, 65536, 1 << 20, 1 << 22):
+        rep = DeviceReplay(max(2 * n, 1 << 20), device)
+        env = BatchedHarfangEnv(n, scenario="straight_line", device=device, seed=0, max_step=1500, replay=rep)
+        env.reset()
+        a = torch.rand(n, 4, device=device) * 2 - 1
+        for _ in range(3):
+            env.step(a)
+        iters = 30
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            env.step(a)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        out.append({"envs_per_launch": n, "us": round(us, 2), "GBps": round(ENV_BYTES_FUSED * n / us / 1e3, 1),
+                    "frac": round(ENV_BYTES_FUSED * n / us / 1e3 / HBM_PEAK_GBPS, 4)})
+        del env, rep
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+    loop = Loop(args, rank, world, device)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loop.step()
+    # per-stage HIP events (recorded on the stream the kernels are launched on = torch's current stream)
+    nev = min(args.steps, 512)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(nev)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        loop.step(evs[k] if k < nev else None)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    stage = np.array([[e[i].elapsed_time(e[i + 1]) * 1e3 for i in range(3)] for e in evs])  # us: act, env, sample+learn
+    act_us, env_us, learn_us = (float(np.median(stage[:, i])) for i in range(3))
+    n_total = args.envs * world
+    value = n_total * args.steps / dt
+    res = {
+        "metric": "env steps/sec (whole node) + HIRL update steps/sec at 4096 envs/GPU", "value": round(value, 1),
+        "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.envs} parallel {args.scenario} envs per GPU, HIRL-soft fp32, 1 learn(B={args.batch}) per vector step "
+                               f"(BASELINE.json configs[1])", "envs_per_gpu": args.envs, "batch": args.batch,
+                   "parallelism": f"dp{world}: env shards + replicated nets, RCCL all-reduce of the flat gradients"},
+        "update_steps_per_s": round(args.steps / dt, 1),
+        "stage_us": {"act(2 kernels)": round(act_us, 2), "env_step(1 kernel)": round(env_us, 2), "sample+learn(7-13 kernels)": round(learn_us, 2)},
+    }
+    # roofline of the env-step kernel (the kernel the metric counts): algorithmic bytes / live-measured launch time
+    res["roofline"] = {"kernel": "env_step_kernel<INSERT>", "bound": "hbm", "achieved": round(ENV_BYTES_FUSED * args.envs / env_us / 1e3, 1),
+                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ENV_BYTES_FUSED * args.envs / env_us / 1e3 / HBM_PEAK_GBPS, 4),
+                       "traffic": None, "bytes_per_launch": ENV_BYTES_FUSED * args.envs, "us_per_launch": round(env_us, 2)}
+    res["roofline_update"] = {"kernels": "fwd_l2/bwd_l2/wgrad/adam (one learn)", "bound": "mfma", "unit": "TFLOP/s",
+                              "achieved": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
+                              "frac": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 5),
+                              "us_per_learn": round(learn_us, 2)}
+    res["roofline_act"] = {"kernels": "fwd_l2 + act_head", "bound": "mfma", "unit": "TFLOP/s",
+                           "achieved": round(ACTOR_FLOP * args.envs / act_us / 1e6, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
+                           "frac": round(ACTOR_FLOP * args.envs / act_us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 5), "us": round(act_us, 2)}
+    res["env_stats"] = loop.env.stats_dict()
+    if rank == 0:
+        if args.sweep:
+            res["roofline_env_sweep"] = env_sweep(device)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

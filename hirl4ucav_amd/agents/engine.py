@@ -40,6 +40,7 @@ _lib.register("hx_hirl_actor_backward", [_P(HxNets), _P(HxBatch), _P(HxHyper), _
 _lib.register("hx_hirl_actor_wgrad", [_P(HxNets), _P(HxHyper), _i32, _i32, _i32, _f32, _f32, _vp])
 _lib.register("hx_adam", [_P(HxNets), _P(HxHyper), _i32, _i32, _f32, _i32, _f32, _f32, _i32, _vp])
 _lib.register("hx_polyak", [_P(HxNets), _P(HxHyper), _vp])
+_lib.register("hx_sample_batch", [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _i32, _i32, ctypes.c_uint64, ctypes.c_uint32, _f32, _vp, _vp, _vp, _vp])
 
 # ---- flat layout <-> reference state_dict keys (hirl/agents/HIRL.py:19-146) -------------------------------------
 
@@ -184,6 +185,21 @@ class HirlEngine:
             if self.update_count % self.target_update_freq == 0:  # HIRL.py:327-330
                 _lib.call("hx_polyak", nets, hyper, st)
         self.actor_trainable = not self.actor_trainable  # HIRL.py:332
+
+    def sample(self, replay, expert_len=0, bc_len=0, n_main=None, seed=0, sigma=0.2):
+        """Draw idx / idx_bc / noise for the next learn() on the device (no host sync): UniformMemory.sample
+        (buffer.py:38-48), np.random.choice (HIRL.py:249), torch.normal(0, 0.2) (HIRL.py:265)."""
+        B = self.batch
+        if not hasattr(self, "_idx"):
+            self._idx = torch.zeros(B, dtype=torch.int32, device=self.device)
+            self._idx_bc = torch.zeros(B, dtype=torch.int32, device=self.device)
+            self._noise = torch.zeros(4, dtype=torch.float32, device=self.device)
+            self.sample_calls = 0
+        self.sample_calls += 1
+        _lib.call("hx_sample_batch", replay.total.data_ptr(), replay.capacity, int(expert_len), int(bc_len), B,
+                  B if n_main is None else int(n_main), int(seed), self.sample_calls, float(sigma), self._idx.data_ptr(),
+                  self._idx_bc.data_ptr() if bc_len else None, self._noise.data_ptr(), _lib.stream_ptr())
+        return self._idx, self._idx_bc, self._noise
 
     def losses_host(self):
         """(critic_loss, actor_loss, bc_loss, rl_loss, bc_fire_loss, bc_weight) — HIRL.py:334.  Synchronises."""

@@ -750,6 +750,65 @@ __global__ __launch_bounds__(kThreads) void polyak_kernel(float* target, const f
     for (int c = 0; c < cnt; ++c) target[i + c] = target[i + c] * (1.0f - tau) + source[i + c] * tau;  // HIRL.py:13
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// minibatch sampling on the device: UniformMemory.sample (buffer.py:45 random.sample, without replacement),
+// np.random.choice(N_exp, B, replace=False) (HIRL.py:249) and the (4,) target-smoothing noise (HIRL.py:265).
+// One workgroup; Philox4x32-10 keyed by `seed`, counter (row, call, stream, round).  Duplicates inside a group are
+// redrawn for a bounded number of rounds (B << len, so a handful suffices; a leftover duplicate after the last round is
+// accepted — it is the with-replacement draw SURVEY.md quirk 13 allows).
+// ---------------------------------------------------------------------------------------------------------------
+struct SampleArgs {
+    const unsigned long long* total;  // transitions ever stored in the main ring
+    long long cap, expert_len, bc_len;
+    int batch, n_main;
+    uint64_t seed;
+    uint32_t call;
+    float sigma;
+    int* idx;
+    int* idx_bc;
+    float* noise;
+};
+
+__global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
+    __shared__ int cand[1024];
+    const int t = threadIdx.x;
+    const unsigned long long tot = *A.total;
+    const uint32_t len_main = (uint32_t)(tot < (unsigned long long)A.cap ? tot : (unsigned long long)A.cap);
+    const uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
+    for (int stream = 0; stream < 2; ++stream) {  // 0: replay / expert rows, 1: BC rows
+        const bool main_grp = t < A.n_main;
+        const uint32_t len = stream == 1 ? (uint32_t)A.bc_len : (main_grp ? len_main : (uint32_t)A.expert_len);
+        int* out = stream == 1 ? A.idx_bc : A.idx;
+        if (!out) continue;
+        int v = 0;
+        bool dup = true;
+        for (int round = 0; round < 8; ++round) {
+            if (t < A.batch && dup) {
+                uint32_t u[4];
+                philox4x32_10((uint32_t)t, A.call, (uint32_t)stream, (uint32_t)round, k0, k1, u);
+                v = len ? (int)__umulhi(u[0], len) : 0;
+            }
+            __syncthreads();
+            cand[t] = v;
+            __syncthreads();
+            dup = false;
+            if (t < A.batch) {
+                const int lo = (stream == 1 || main_grp) ? 0 : A.n_main;  // groups: [0, n_main) and [n_main, batch)
+                for (int s = lo; s < t; ++s) dup |= cand[s] == v;
+            }
+        }
+        if (t < A.batch) out[t] = v;
+    }
+    if (t < 4 && A.noise) {
+        uint32_t u[4];
+        philox4x32_10(0xFFFFFFF0u, A.call, 2u, 0u, k0, k1, u);
+        const float ua = u01(u[t & 2]), ub = u01(u[(t & 2) + 1]);
+        const float rad = sqrtf(-2.0f * logf(ua)), ang = 6.28318530717958647692f * ub;
+        A.noise[t] = A.sigma * ((t & 1) ? rad * sinf(ang) : rad * cosf(ang));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -987,6 +1046,20 @@ int hx_hirl_actor_wgrad(const HxNets* N, const HxHyper* Hy, int32_t batch, int32
     if (bc) { J.ws[1] = s[S_ABC]; J.rows[1] = batch; J.wmode[1] = 2; J.nslots = 2; }
     hipLaunchKernelGGL(wgrad_kernel, dim3(kWgPerJob), dim3(kThreads), 0, (hipStream_t)stream, W);
     HX_CHECK_LAUNCH("hx_hirl_actor_wgrad");
+    return 0;
+}
+
+
+/* Device-side minibatch draw for one learn() call: idx[batch] (rows < n_main index the main ring, whose current length
+ * min(*total, cap) is read on the device; the rest index the expert ring), idx_bc[batch] into the BC table, noise[4] =
+ * sigma * N(0, 1) (the ONE target-smoothing draw of HIRL.py:265).  Replaces random.sample (buffer.py:45) and
+ * np.random.choice(replace=False) (HIRL.py:249).  batch <= 1024. */
+int hx_sample_batch(const uint64_t* total, int64_t cap, int64_t expert_len, int64_t bc_len, int32_t batch, int32_t n_main,
+                    uint64_t seed, uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc, float* noise, void* stream) {
+    HX_REQUIRE(total && idx && batch > 0 && batch <= 1024 && n_main >= 0 && n_main <= batch && cap > 0, "hx_sample_batch: bad arguments");
+    SampleArgs A{(const unsigned long long*)total, cap, expert_len, bc_len, batch, n_main, seed, call, sigma, idx, idx_bc, noise};
+    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
+    HX_CHECK_LAUNCH("hx_sample_batch");
     return 0;
 }
 

@@ -175,6 +175,15 @@ int hx_adam(const HxNets* nets, const HxHyper* hyper, int32_t which, int32_t ste
             float w_given, float warm, int32_t batch, void* stream);
 int hx_polyak(const HxNets* nets, const HxHyper* hyper, void* stream);
 
+/* Device-side minibatch draw for one learn() call, replacing random.sample (hirl/utils/buffer.py:45, without
+ * replacement) and np.random.choice(replace=False) (HIRL.py:249): idx[batch] (rows < n_main index the main ring, whose
+ * current length min(*total, cap) is read on the device; the rest index the expert ring), idx_bc[batch] into the BC
+ * table, noise[4] = sigma * N(0,1) — the ONE target-smoothing draw of HIRL.py:265.  Philox4x32-10(seed; row, call).
+ * batch <= 1024. */
+int hx_sample_batch(const uint64_t* total, int64_t cap, int64_t expert_len, int64_t bc_len, int32_t batch,
+                    int32_t n_main, uint64_t seed, uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc,
+                    float* noise, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
