@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Vectorised counterpart of the reference training driver (hirl/train_all.py, HIRL and TD3 branches, :261-487):
+the same schedule — random exploration, expert-buffer labelling, per-step act / step / store / learn, expert_num decay,
+linear / fixed / soft BC-weight schedules, periodic validation and checkpoints — with the single socket env replaced
+by `--num_envs` GPU-resident envs per process and every per-step call replaced by a HIP launch.
+
+    python -m hirl4ucav_amd.train_all --agent HIRL --type soft --env straight_line --random --num_envs 4096
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m hirl4ucav_amd.train_all ...   (one process per GPU)
+
+What "one step" means here: the reference does one learn() per single env step (train_all.py:360-361).  With N envs a
+vector step yields N transitions; this driver keeps ONE learn() of the reference's batch size per vector step by
+default (`--updates_per_step` raises it).  That ratio is a stated design parameter, not something the reference fixes.
+"""
+import argparse
+import math
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .agents import engine as E
+from .agents.HIRL import init_actor_state_dict, init_critic_state_dict
+from .environments.batched import SCENARIOS, BatchedHarfangEnv
+from .utils.buffer import DeviceReplay
+from .utils.data_processor import read_data
+from .utils.seed import set_seed
+
+MAX_STEP = {"straight_line": 1500, "serpentine": 1500, "circular": 1900}  # train_all.py:159-183
+
+
+# ---- pure host logic (unit-tested on CPU) ----------------------------------------------------------------------------
+def bc_weight_schedule(hirl_type, episode, bc_weight, bc_warm_up=False):
+    """(bc_weight_now, bc_warm_up_weight) at the start of `episode` — train_all.py:328-339."""
+    warm = 0.0
+    if hirl_type == "linear":
+        return max(bc_weight - episode / 5000, 0), warm
+    if hirl_type == "fixed":
+        return bc_weight, warm
+    if hirl_type == "soft":
+        if bc_warm_up:
+            warm = max(0.3 - episode / 1000, 0)
+        return 100, warm
+    raise ValueError(hirl_type)
+
+
+def expert_num_after(expert_num, step, warm_up_rate=10):
+    """train_all.py:356-357: one expert row fewer whenever step % warm_up_rate == 0, down to 0."""
+    return expert_num - 1 if (step % warm_up_rate == 0 and expert_num != 0) else expert_num
+
+
+def expert_pair_indices(done):
+    """Which (i, i+1) pairs the reference turns into expert-buffer transitions (train_all.py:289-306): it walks i over the
+    expert rows and skips one extra row after a terminal pair.  done[i] = get_termination(states[i+1])."""
+    out, i, n = [], 0, len(done) + 1
+    while i + 1 < n:
+        out.append(i)
+        if done[i]:
+            i += 1
+        i += 1
+    return np.asarray(out, np.int64)
+
+
+def checkpoint_tag(arttir, success, episodes, mean_score):
+    return "Agent{}_{}_{}_".format(arttir, round(success / episodes * 100), round(mean_score))  # train_all.py:69
+
+
+# ---- device side -----------------------------------------------------------------------------------------------------
+def label_expert(states, actions, device):
+    """Expert replay rows [k, 32] + step_success from consecutive expert states, labelled on the GPU
+    (HarfangEnv.get_reward / get_termination, HarfangEnv_GYM.py:299-336)."""
+    s = torch.as_tensor(np.asarray(states[:-1], np.float32), device=device).contiguous()
+    a = torch.as_tensor(np.asarray(actions[:-1], np.float32), device=device).contiguous()
+    ns = torch.as_tensor(np.asarray(states[1:], np.float32), device=device).contiguous()
+    m = s.shape[0]
+    r = torch.zeros(m, device=device)
+    sc = torch.zeros(m, dtype=torch.int8, device=device)
+    dn = torch.zeros(m, dtype=torch.uint8, device=device)
+    _lib.call("hx_label_transitions", s.data_ptr(), a.data_ptr(), ns.data_ptr(), m, r.data_ptr(), sc.data_ptr(), dn.data_ptr(), _lib.stream_ptr())
+    keep = torch.as_tensor(expert_pair_indices(dn.cpu().numpy().astype(bool)), device=device)
+    rows = torch.cat([s, a, ns, r[:, None], dn.float()[:, None]], 1)[keep]
+    return rows, sc[keep]
+
+
+def validate(engine, scenario, episodes, max_step, if_random, seed, device):
+    """validate() of train_all.py:22-102 as ONE batch: `episodes` envs stepped with chooseActionNoNoise until done or the
+    step limit; success / fire success counted only for episodes that ended with done (train_all.py:59-64)."""
+    env = BatchedHarfangEnv(episodes, scenario=scenario, device=device, seed=seed, auto_reset=False, random_reset=if_random, collect_stats=False)
+    obs = env.reset()
+    total = torch.zeros(episodes, device=device)
+    alive = torch.ones(episodes, dtype=torch.bool, device=device)
+    for step in range(max_step):
+        a = engine.act(obs)
+        obs, r, d, s = env.step(a)
+        total += torch.where(alive, r, torch.zeros_like(r))
+        alive &= d == 0
+        if step % 64 == 63 and not bool(alive.any()):
+            break
+    flags = env.state[35].view(torch.int32)
+    done = (flags & _lib.F_DONE) != 0
+    success = int((done & ((flags & _lib.F_EPISODE_SUCCESS) != 0)).sum())
+    fire = int((done & ((flags & _lib.F_FIRE_SUCCESS) != 0)).sum())
+    scores = total.cpu().numpy()
+    return float(scores.mean()), float(scores.std()), success, fire
+
+
+def main(config):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)
+    if config.seed is not None:
+        set_seed(config.seed + rank)
+    seed = config.seed or 0
+    env_type, n = config.env, config.num_envs
+    max_step = MAX_STEP[env_type] * (8 if config.render else 1)
+    hirl = config.agent == "HIRL"
+    batch, buffer_size, warm_up_rate, checkpoint_rate = 128, config.buffer_size, 10, 25  # train_all.py:190-208
+
+    replay = DeviceReplay(buffer_size, device)
+    env = BatchedHarfangEnv(n, scenario=env_type, device=device, seed=seed, max_step=max_step, auto_reset=True,
+                            random_reset=config.random, env_id0=rank * n, replay=replay)
+    eng = E.HirlEngine(batch=batch, slope=0.0 if hirl else 0.01, use_bc=hirl, device=device)
+    torch.manual_seed(seed)  # identical initial networks on every rank
+    eng.load_params(init_actor_state_dict(), init_critic_state_dict(), init_actor_state_dict() if hirl else None)
+    expert_len = bc_len = 0
+    expert = bc_table = None
+    if hirl:
+        if config.expert_csv and os.path.exists(config.expert_csv):
+            es, ea = read_data(config.expert_csv)
+        else:  # no Drive data here (README.md:6,30): synthetic stand-in of the same shape
+            rng = np.random.default_rng(0)
+            es = rng.uniform(-1, 1, (20000, 13))
+            es[:, 7:9] = np.where(rng.random((20000, 2)) < 0.5, 1, -1)
+            es[:, 12] = rng.uniform(0, 0.2, 20000)
+            ea = rng.uniform(-1, 1, (20000, 4))
+            ea[:, 3] = np.where(rng.random(20000) < 1e-3, 1, -1)
+        rows, succ = label_expert(es, ea, device)
+        expert = DeviceReplay(rows.shape[0] + 10, device)
+        expert.store_rows(rows, succ)
+        expert_len, bc_len = rows.shape[0], es.shape[0]
+        tab = np.zeros((bc_len, 32), np.float32)
+        tab[:, 0:13], tab[:, 13:17] = es, ea
+        bc_table = torch.from_numpy(tab).to(device)
+        if config.bc_actor and os.path.exists(config.bc_actor):
+            eng.bc_actor.copy_(E.pack(torch.load(config.bc_actor, map_location="cpu"), E.ACTOR_LAYOUT, E.ACTOR_SIZE, device))
+
+    # RANDOM EXPLORATION: 20 episodes of uniform actions in the reference (train_all.py:266-282) = 20*maxStep transitions
+    obs = env.reset()
+    for _ in range(math.ceil(20 * max_step / (n * world))):
+        env.step(torch.rand((n, 4), device=device) * 2 - 1)
+
+    log_dir = os.path.join(config.result_dir, env_type, config.agent, config.model_name, time.strftime("%Y_%m_%d_%H_%M"))
+    model_dir = os.path.join(log_dir, "model")
+    if rank == 0:
+        os.makedirs(model_dir, exist_ok=True)
+    expert_num = batch if hirl else 0
+    high_score, success_rate, arttir = -math.inf, 0.0, 1
+    t0 = time.time()
+    for episode in range(config.episodes):
+        w_now, warm = bc_weight_schedule(config.type, episode, config.bc_weight) if hirl else (0.0, 0.0)
+        for step in range(max_step):
+            actions = eng.act(env.obs, sigma=0.1, seed=seed + 1, row0=env.env_id0)
+            env.step(actions)
+            if step == max_step - 1:
+                break
+            expert_num = expert_num_after(expert_num, step, warm_up_rate)
+            for _ in range(config.updates_per_step):
+                idx, idx_bc, noise = eng.sample(replay, expert_len, bc_len, n_main=batch - expert_num, seed=seed + 2 + rank)
+                eng.learn(replay.ring, idx, noise, expert_ring=expert.ring if expert else None, n_main=batch - expert_num,
+                          bc_table=bc_table, idx_bc=idx_bc if hirl else None, bc_weight_now=w_now, bc_warm_up_weight=warm)
+                w_now = None  # afterwards learn()'s own returned weight is fed back (train_all.py:361): the stored device value
+        if rank == 0:
+            c, a, b, r_, f, w = eng.losses_host()
+            st = env.stats_dict()
+            sps = (episode + 1) * max_step * n * world / (time.time() - t0)
+            print(f"Episode {episode + 1}: critic {c:.3f} actor {a:.3f} bc {b:.3f} rl {r_:.3f} bc_weight {w:.4f} | episodes {st['episodes']} "
+                  f"kills {st['kills']} fire-success {st['fire_success_episodes']} | {sps:,.0f} env steps/s", flush=True)
+        if (episode + 1) % checkpoint_rate == 0 and rank == 0:  # VALIDATION, train_all.py:400-402
+            mean, std, succ, fire = validate(eng, env_type, 50, max_step, config.random, seed + 12345, device)
+            if mean > high_score or succ / 50 >= success_rate or arttir % 5 == 0:
+                tag = checkpoint_tag(arttir, succ, 50, mean)
+                for name, flat, layout in (("Critic_", eng.critic, E.CRITIC_LAYOUT), ("Actor_", eng.actor, E.ACTOR_LAYOUT),
+                                           ("TargetCritic_", eng.target_critic, E.CRITIC_LAYOUT), ("TargetActor_", eng.target_actor, E.ACTOR_LAYOUT)):
+                    torch.save({k: v.cpu().clone() for k, v in E.unpack(flat, layout).items()}, os.path.join(model_dir, tag + name + "Harfang_GYM"))
+                high_score, success_rate = max(high_score, mean), max(success_rate, succ / 50)
+            print(f"Validation {arttir}: avg reward {mean:.2f} (std {std:.2f}) success {succ / 50:.2f} fire success {fire / 50:.2f}", flush=True)
+            arttir += 1
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def parser():
+    p = argparse.ArgumentParser()  # the reference's flags, train_all.py:489-513
+    p.add_argument("--agent", type=str, default="HIRL", choices=["HIRL", "TD3"])
+    p.add_argument("--port", type=int, default=None)
+    p.add_argument("--type", type=str, default="soft", choices=["soft", "linear", "fixed"])
+    p.add_argument("--bc_weight", type=float, default=0.5)
+    p.add_argument("--model_name", type=str, default="model")
+    p.add_argument("--load_model", action="store_true")
+    p.add_argument("--render", action="store_true")
+    p.add_argument("--plot", action="store_true")
+    p.add_argument("--seed", type=int, default=None)
+    p.add_argument("--env", type=str, default="straight_line", choices=list(SCENARIOS))
+    p.add_argument("--random", action="store_true")
+    # additions of the vectorised driver
+    p.add_argument("--num_envs", type=int, default=4096)
+    p.add_argument("--episodes", type=int, default=6000)
+    p.add_argument("--updates_per_step", type=int, default=1)
+    p.add_argument("--buffer_size", type=int, default=1 << 20)
+    p.add_argument("--expert_csv", type=str, default=None)
+    p.add_argument("--bc_actor", type=str, default=None)
+    p.add_argument("--result_dir", type=str, default="results")
+    return p
+
+
+if __name__ == "__main__":
+    main(parser().parse_args())

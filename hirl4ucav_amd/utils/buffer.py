@@ -33,3 +33,54 @@ class DeviceReplay:
         if success is not None:
             self.success[idx] = success.to(self.device, torch.int8)
         self.total += k
+
+
+# ---- reference-API façade -------------------------------------------------------------------------------------------
+import random  # noqa: E402
+from collections import namedtuple  # noqa: E402
+
+import numpy as np  # noqa: E402,F401  (the reference's drivers obtain `np`, `torch`, `device` from this module's star-export)
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")  # buffer.py:6
+
+Transition = namedtuple("Transition", ("state", "action", "next_state", "reward", "done", "step_success"))  # buffer.py:8
+
+
+class UniformMemory(DeviceReplay):
+    """hirl.utils.buffer.UniformMemory (buffer.py:11-54) over the device ring: store() appends one transition,
+    sample() draws without replacement with Python's `random` like the reference and returns the five tuples."""
+
+    def __init__(self, capacity, upsample=False):
+        if upsample:
+            raise NotImplementedError("priority upsampling is disabled in the reference (HIRL.py:184,189)")
+        super().__init__(int(capacity), device)
+        self.upsample = False
+        self._len = 0
+        self.position = 0
+
+    def store(self, state, action, next_state, reward, done, step_success=0):  # buffer.py:20-36
+        row = np.zeros(32, np.float32)
+        row[0:13], row[13:17], row[17:30] = state, action, next_state
+        row[30], row[31] = reward, float(done)
+        self.ring[self.position] = torch.from_numpy(row).to(self.device)
+        self.success[self.position] = int(step_success)
+        self.position = (self.position + 1) % self.capacity
+        self._len = min(self._len + 1, self.capacity)
+        self.total += 1
+
+    @property
+    def memory(self):  # drivers only take len() of it (train_all.py:306,308)
+        return range(self._len)
+
+    def __len__(self):
+        return self._len
+
+    def fullEnough(self, batchSize):
+        return self._len >= batchSize
+
+    def sample_indices(self, batchSize):
+        return random.sample(range(self._len), batchSize)  # buffer.py:45
+
+    def sample(self, batchSize):  # buffer.py:38-48
+        rows = self.ring[torch.as_tensor(self.sample_indices(batchSize), device=self.device)].cpu().numpy()
+        return (tuple(rows[:, 0:13]), tuple(rows[:, 13:17]), tuple(rows[:, 17:30]), tuple(rows[:, 30]), tuple(rows[:, 31]))

@@ -1,0 +1,116 @@
+"""CPU tests of the host-side logic that mirrors the reference's drivers and data formats (no GPU, no HIP calls)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hirl_oracle as H
+
+
+def test_flat_layout_follows_reference_state_dict_order():
+    from hirl4ucav_amd.agents import engine as E
+
+    assert [k for k, _, _ in E.ACTOR_LAYOUT] == list(H.ACTOR_KEYS)
+    assert [k for k, _, _ in E.CRITIC_LAYOUT] == list(H.CRITIC_KEYS)
+    assert E.ACTOR_SIZE == 138756 and E.Q_PADDED == 138244 and E.CRITIC_SIZE == 276488  # 138,241 padded to 16 B
+    rng = np.random.default_rng(0)
+    p = H.init_critic(rng)
+    flat = E.pack(p, E.CRITIC_LAYOUT, E.CRITIC_SIZE, "cpu")
+    back = E.unpack(flat, E.CRITIC_LAYOUT)
+    for k in p:
+        np.testing.assert_array_equal(back[k].numpy(), p[k])
+    assert float(flat[138241:138244].abs().sum()) == 0.0 and float(flat[-3:].abs().sum()) == 0.0  # pads stay zero
+
+
+def test_bc_weight_and_expert_num_schedules():
+    """train_all.py:328-339 and :356-357."""
+    from hirl4ucav_amd.train_all import bc_weight_schedule, checkpoint_tag, expert_num_after
+
+    assert bc_weight_schedule("linear", 0, 0.5) == (0.5, 0.0)
+    assert bc_weight_schedule("linear", 1000, 0.5) == (0.3, 0.0)
+    assert bc_weight_schedule("linear", 2500, 0.5) == (0.0, 0.0) and bc_weight_schedule("linear", 4000, 0.5) == (0, 0.0)
+    assert bc_weight_schedule("fixed", 777, 0.25) == (0.25, 0.0)
+    assert bc_weight_schedule("soft", 3, 0.5) == (100, 0.0)
+    w, warm = bc_weight_schedule("soft", 100, 0.5, bc_warm_up=True)
+    assert w == 100 and abs(warm - 0.2) < 1e-12
+    # 128 -> 0, one per 10 steps, including step 0
+    e, trace = 128, []
+    for step in range(1500):
+        e = expert_num_after(e, step)
+        trace.append(e)
+    assert trace[0] == 127 and trace[9] == 127 and trace[10] == 126 and trace[1269] == 1 and trace[1270] == 0 and trace[-1] == 0
+    assert checkpoint_tag(3, 32, 50, -412.6) == "Agent3_64_-413_"
+
+
+def test_expert_pair_indices_skip_after_done():
+    """train_all.py:289-306: after a terminal pair the walk skips one extra row."""
+    from hirl4ucav_amd.train_all import expert_pair_indices
+
+    done = np.array([0, 0, 1, 0, 0, 0, 1], bool)  # 8 states, pairs (0,1) .. (6,7)
+    np.testing.assert_array_equal(expert_pair_indices(done), [0, 1, 2, 4, 5, 6])
+    np.testing.assert_array_equal(expert_pair_indices(np.zeros(4, bool)), [0, 1, 2, 3])
+
+
+def test_expert_csv_round_trip(tmp_path):
+    """The 2-row stringified-array CSV of hirl/utils/data_processor.py:5-18."""
+    from hirl4ucav_amd.utils.data_processor import read_data, up_sample, write_data
+
+    rng = np.random.default_rng(1)
+    s, a = rng.uniform(-1, 1, (37, 13)), rng.uniform(-1, 1, (37, 4))
+    a[:, 3] = np.where(rng.random(37) < 0.2, 1, -1)
+    path = os.path.join(tmp_path, "expert_data_ai.csv")
+    write_data(s, a, path)
+    s2, a2 = read_data(path)
+    np.testing.assert_allclose(s2, s, rtol=0, atol=1e-8)  # numpy's str() keeps 8 significant digits
+    np.testing.assert_allclose(a2, a, rtol=0, atol=1e-8)
+    np.testing.assert_array_equal(up_sample(a2), np.where(a[:, 3] == 1)[0])
+
+
+def test_uniform_memory_ring_semantics():
+    """UniformMemory store/sample/fullEnough/len (buffer.py:11-54) on whatever device torch has here."""
+    import random
+
+    from hirl4ucav_amd.utils.buffer import UniformMemory
+
+    m = UniformMemory(5, False)
+    for i in range(7):
+        m.store(np.full(13, i), np.full(4, i), np.full(13, i + 0.5), float(i), i % 2 == 0, 0)
+    assert len(m) == 5 and m.fullEnough(5) and not m.fullEnough(6) and len(m.memory) == 5 and m.position == 2
+    assert sorted(m.ring[:, 30].tolist()) == [2.0, 3.0, 4.0, 5.0, 6.0]  # the two oldest were overwritten
+    random.seed(3)
+    st, ac, ns, rw, dn = m.sample(4)
+    assert len(st) == 4 and st[0].shape == (13,) and len(set(rw)) == 4  # without replacement
+    for s_, n_, r_ in zip(st, ns, rw):
+        assert s_[0] == r_ and n_[0] == r_ + 0.5
+    with pytest.raises(NotImplementedError):
+        UniformMemory(5, True)
+
+
+def test_df_shim_and_constants():
+    import hirl4ucav_amd.environments.dogfight_client as df
+    from hirl4ucav_amd.environments.constants import NormStates
+
+    assert df.connect("127.0.0.1", 50888) is None and df.disable_log() is None
+    assert df.set_renderless_mode(True) is None and df.set_client_update_mode(True) is None
+    assert NormStates["Plane_position"] == 10000 and abs(NormStates["Plane_Euler_angles"] - np.pi) < 1e-15
+
+
+def test_checkpoint_view_uses_reference_key_names(tmp_path):
+    from hirl4ucav_amd.agents import engine as E
+    from hirl4ucav_amd.agents.HIRL import _NetView, init_actor_state_dict, init_critic_state_dict
+
+    sd = init_critic_state_dict()
+    assert list(sd) != [] and set(sd) == set(H.CRITIC_KEYS) and set(init_actor_state_dict()) == set(H.ACTOR_KEYS)
+    flat = torch.zeros(E.CRITIC_SIZE)
+    v = _NetView(flat, E.CRITIC_LAYOUT, "Critic_Harfang_GYM")
+    v.load_state_dict(sd)
+    v.saveCheckpoint("Agent1_50_-3_", str(tmp_path))
+    flat2 = torch.zeros(E.CRITIC_SIZE)
+    v2 = _NetView(flat2, E.CRITIC_LAYOUT, "Critic_Harfang_GYM")
+    v2.loadCheckpoint("Agent1_50_-3_", str(tmp_path))
+    assert torch.equal(flat, flat2)
+    loaded = torch.load(os.path.join(tmp_path, "Agent1_50_-3_Critic_Harfang_GYM"))
+    assert list(loaded) == list(H.CRITIC_KEYS)  # a reference Critic.load_state_dict accepts it
+    # hidden-weight bounds of kaiming_uniform_(a=0.01, 'relu'): sqrt(6 / fan_in)
+    assert sd["full1.weight"].abs().max() <= np.sqrt(6 / 17) and sd["full2.weight"].abs().max() <= np.sqrt(6 / 256)
