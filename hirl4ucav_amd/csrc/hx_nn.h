@@ -45,16 +45,28 @@ struct Mlp {
 __device__ __forceinline__ float act_f(float y, float slope) { return y > 0.0f ? y : y * slope; }
 __device__ __forceinline__ float act_d(float y, float slope) { return y > 0.0f ? 1.0f : slope; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane sums on DPP (VALU latency) instead of ds_bpermute (LDS latency) ---------------------------------
+// The update kernels run ONE wave per SIMD (B = 128 fills < 256 CUs), so every dependent reduction is exposed; a
+// 6-step __shfl_xor tree costs ~6 LDS round trips, the DPP form 4 VALU ops + 4 v_readlane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// every lane of each aligned 16-lane row ends up with that row's sum
+__device__ __forceinline__ float sum16(float v) {
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x124>(v);  // row_ror:4
+    v = dpp_add<0x128>(v);  // row_ror:8
     return v;
 }
-// sum over aligned groups of 16 lanes
-__device__ __forceinline__ float sum16(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// full 64-lane sum, result uniform across the wave
+__device__ __forceinline__ float wave_sum(float v) {
+    v = sum16(v);
+    const int iv = __float_as_int(v);  // the builtin is typed int: pass BITS, not a value conversion
+    const float a = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), b = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), d = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+    return (a + b) + (c + d);
 }
 
 __device__ __forceinline__ v4f mfma16(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }

@@ -56,6 +56,7 @@ struct Slot {
     float* dz2;   // [R][H2]
     float* dh1;   // [R][H1]
     float* dout;  // [R][4]    gradient wrt the head pre-activation o
+    float* lnp;   // [R][4][2] LN1-backward row sums (sum dxhat, sum dxhat*xhat) over each 64-column tile of dh1
 };
 
 struct Head {  // a previous net whose output is (part of) this net's input
@@ -137,6 +138,10 @@ struct FwdArgs {
     FwdJob job[3];
     int njobs;
     float slope;
+    // accumulators cleared by this launch (consumed by LATER launches on the same stream): replaces memset nodes
+    float* zero_f;
+    int zero_nf;
+    int* zero_i;
 };
 
 __device__ __forceinline__ int tiles_of(int rows) { return (rows + RT - 1) / RT; }
@@ -155,6 +160,10 @@ __global__ __launch_bounds__(kThreads) void fwd_l2_kernel(FwdArgs A) {
         b -= nb;
     }
     if (j >= A.njobs) return;
+    if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < A.zero_nf) A.zero_f[threadIdx.x] = 0.0f;
+        if (threadIdx.x == 0 && A.zero_i) *A.zero_i = 0;
+    }
     const FwdJob& J = A.job[j];
     const int rt = b / (H2 / kNT), nt = b % (H2 / kNT);
     const int r0 = rt * RT;
@@ -414,17 +423,16 @@ __global__ __launch_bounds__(kThreads) void bwd_l2_kernel(BwdArgs A) {
             g.load(C.net + C.m.g1());
             be.load(C.net + C.m.be1());
             const float cm = C.ws.st1[R * 2], cr = C.ws.st1[R * 2 + 1];
-            float xh1[4], dxh[4], s1 = 0.f, s2 = 0.f;
+            float xh1[4], dxh[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 xh1[i] = (z.v[i] - cm) * cr;
                 const float yy = g.v[i] * xh1[i] + be.v[i];
                 dxh[i] = dh.v[i] * act_d(yy, slope) * g.v[i];
-                s1 += dxh[i];
-                s2 += dxh[i] * xh1[i];
             }
-            s1 = wave_sum(s1) * (1.0f / H1);
-            s2 = wave_sum(s2) * (1.0f / H1);
+            const float* lp = C.ws.lnp + R * 8;
+            const float s1 = ((lp[0] + lp[2]) + (lp[4] + lp[6])) * (1.0f / H1);
+            const float s2 = ((lp[1] + lp[3]) + (lp[5] + lp[7])) * (1.0f / H1);
             float da[4] = {0.f, 0.f, 0.f, 0.f};
             // RowReg<256> maps v[c] -> hidden unit k = lane*4 + c
 #pragma unroll
@@ -510,10 +518,37 @@ __global__ __launch_bounds__(kThreads) void bwd_l2_kernel(BwdArgs A) {
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
         acc = tile_a_lds_b_global<H2>(dz2s, LDA2, J.net + J.m.W2() + n0 + r, H1, acc);
+        // epilogue: store dh1 and this tile's share of the LN1-backward row sums (consumed by wgrad / the actor's
+        // backward, which then need no cross-column reduction of their own)
+        const float g1 = J.net[J.m.g1() + n0 + r], be1 = J.net[J.m.be1() + n0 + r];
+        float p1[4], p2[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = 4 * g + q;
-            if (row < nrow) J.ws.dh1[(size_t)(r0 + row) * H1 + n0 + r] = acc[q];
+            p1[q] = p2[q] = 0.0f;
+            if (row < nrow) {
+                const size_t R = (size_t)(r0 + row);
+                J.ws.dh1[R * H1 + n0 + r] = acc[q];
+                const float xh = (J.ws.z1[R * H1 + n0 + r] - J.ws.st1[R * 2]) * J.ws.st1[R * 2 + 1];
+                const float dxh = acc[q] * act_d(g1 * xh + be1, slope) * g1;
+                p1[q] = dxh;
+                p2[q] = dxh * xh;
+            }
+        }
+        __syncthreads();  // dz2s is dead: reuse its head as [4 waves][16 rows][2]
+        float* ps = dz2s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a1 = sum16(p1[q]), a2 = sum16(p2[q]);
+            if (r == 0) {
+                ps[(wave * RT + 4 * g + q) * 2] = a1;
+                ps[(wave * RT + 4 * g + q) * 2 + 1] = a2;
+            }
+        }
+        __syncthreads();
+        if (tid < nrow * 2) {
+            const float v = (ps[tid] + ps[RT * 2 + tid]) + (ps[2 * RT * 2 + tid] + ps[3 * RT * 2 + tid]);
+            J.ws.lnp[(size_t)(r0 + (tid >> 1)) * 8 + nt * 2 + (tid & 1)] = v;
         }
     }
 }
@@ -548,15 +583,17 @@ __device__ __forceinline__ float effective_w(int kind, float given, float warm, 
     return w > 1.0f ? 1.0f : w;  // HIRL.py:308
 }
 
-constexpr int kWgTilesPerBlock = (H2 / 64) * (H1 / 64);  // 32 dW2 tiles
-constexpr int kWgVecWgs = H2 / kThreads;                 // 2 workgroups for the 512-wide vector gradients
-constexpr int kWgPerJob = kWgTilesPerBlock + kWgVecWgs + 1;
+constexpr int kWgTilesPerBlock = (H2 / 64) * (H1 / 64);  // 32 dW2 tiles of 64 x 64
+constexpr int kWgVecWgs = H2 / 64;                       // 8 workgroups: 64 columns x 4 row groups, 512-wide vector gradients
+constexpr int kWgL1Wgs = H1 / 64;                        // 4 workgroups: layer-1 gradients
+constexpr int kWgPerJob = kWgTilesPerBlock + kWgVecWgs + kWgL1Wgs;
+constexpr int kWgRowChunk = 256;                         // rows whose per-row scalars are staged in LDS at a time
 
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
-    __shared__ __attribute__((aligned(16))) float t_dz[RT * LDA1];
-    __shared__ __attribute__((aligned(16))) float t_dy[RT * LDA1];
-    __shared__ __attribute__((aligned(16))) float t_xh[RT * LDA1];
-    __shared__ float xs[RT * XP];
+    __shared__ __attribute__((aligned(16))) float lds[kWgRowChunk * XP + kWgRowChunk * 8 + 4 * 64 * 20];
+    float* xs = lds;                          // [chunk][XP]   inputs (layer-1 job)
+    float* rinfo = lds + kWgRowChunk * XP;    // [chunk][8]    per-row scalars
+    float* red = rinfo + kWgRowChunk * 8;     // [4][64][20]   cross-row-group reduction
 
     const int j = blockIdx.x / kWgPerJob, b = blockIdx.x % kWgPerJob;
     if (j >= A.njobs) return;
@@ -579,16 +616,22 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
             const float* dz = J.ws[s].dz2 + n0 + r;
             const float* h1 = J.ws[s].h1 + k0 + r;
             const int rows = J.rows[s];
+#pragma unroll 2
             for (int bb = 0; bb < rows; bb += 16) {
+                float av[4], hv[4][4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = bb + 4 * q + g;  // MFMA q reduces over rows bb+4q .. bb+4q+3 (one per lane group)
                     const bool ok = row < rows;
-                    const float a = ok ? dz[(size_t)row * H2] * sc : 0.0f;
+                    av[q] = ok ? dz[(size_t)row * H2] : 0.0f;
                     const float* hp = h1 + (size_t)row * H1;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = mfma16(a, ok ? hp[t * 16] : 0.0f, acc[t]);
+                    for (int t = 0; t < 4; ++t) hv[q][t] = ok ? hp[t * 16] : 0.0f;
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = mfma16(av[q] * sc, hv[q][t], acc[t]);
             }
         }
         float* out = J.grad + J.m.W2();
@@ -598,110 +641,115 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
             for (int q = 0; q < 4; ++q) out[(size_t)(n0 + 4 * g + q) * H1 + k0 + t * 16 + r] = acc[t][q];
         return;
     }
+    const int rg = wave;  // row group: rows rg, rg + 4, ...
     if (b < kWgTilesPerBlock + kWgVecWgs) {
-        // column n: db2, dg2 (layernorm2.weight), dbe2, dW3[j][n]; thread 0..out-1 of the first: db3
-        const int n = (b - kWgTilesPerBlock) * kThreads + tid;
+        // column n: db2, dg2, dbe2, dW3[j][n] (+ db3 by the first workgroup); 64 columns x 4 row groups
+        const int vb = b - kWgTilesPerBlock;
+        const int n = vb * 64 + lane;
         const float g2 = J.net[J.m.g2() + n], be2 = J.net[J.m.be2() + n];
         float w3[4];
         for (int jj = 0; jj < 4; ++jj) w3[jj] = jj < J.m.out ? J.net[J.m.W3() + jj * H2 + n] : 0.0f;
-        float db2 = 0.f, dg = 0.f, dbe = 0.f, dw3[4] = {0.f, 0.f, 0.f, 0.f};
+        float db2 = 0.f, dg = 0.f, dbe = 0.f, dw3[4] = {0.f, 0.f, 0.f, 0.f}, db3 = 0.f;
         for (int s = 0; s < J.nslots; ++s) {
             const Slot& S = J.ws[s];
             const float sc = scale[s];
-            for (int r = 0; r < J.rows[s]; ++r) {
-                const float mean = S.st2[r * 2], rstd = S.st2[r * 2 + 1];
-                const float xh = (S.z2[(size_t)r * H2 + n] - mean) * rstd;
-                const float y = g2 * xh + be2;
-                float dh2 = 0.f;
-                const float4 d4 = *reinterpret_cast<const float4*>(S.dout + (size_t)r * 4);
-                const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+            for (int c0 = 0; c0 < J.rows[s]; c0 += kWgRowChunk) {
+                const int nr = min(kWgRowChunk, J.rows[s] - c0);
+                __syncthreads();
+                for (int e = tid; e < nr; e += kThreads) {
+                    rinfo[e * 8] = S.st2[(size_t)(c0 + e) * 2];
+                    rinfo[e * 8 + 1] = S.st2[(size_t)(c0 + e) * 2 + 1];
+                    const float4 d4 = *reinterpret_cast<const float4*>(S.dout + (size_t)(c0 + e) * 4);
+                    rinfo[e * 8 + 2] = d4.x; rinfo[e * 8 + 3] = d4.y; rinfo[e * 8 + 4] = d4.z; rinfo[e * 8 + 5] = d4.w;
+                }
+                __syncthreads();
+#pragma unroll 4
+                for (int r = rg; r < nr; r += 4) {
+                    const float* ri = rinfo + r * 8;
+                    const float xh = (S.z2[(size_t)(c0 + r) * H2 + n] - ri[0]) * ri[1];
+                    const float dz = S.dz2[(size_t)(c0 + r) * H2 + n];
+                    const float y = g2 * xh + be2;
+                    const float dh2 = (ri[2] * w3[0] + ri[3] * w3[1]) + (ri[4] * w3[2] + ri[5] * w3[3]);
+                    const float dy = dh2 * act_d(y, slope);
+                    const float h2 = act_f(y, slope);
+                    db2 += sc * dz;
+                    dbe += sc * dy;
+                    dg += sc * dy * xh;
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) dh2 += dd[jj] * w3[jj];
-                const float dy = dh2 * act_d(y, slope);
-                const float h2 = act_f(y, slope);
-                db2 += sc * S.dz2[(size_t)r * H2 + n];
-                dbe += sc * dy;
-                dg += sc * dy * xh;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) dw3[jj] += sc * dd[jj] * h2;
+                    for (int jj = 0; jj < 4; ++jj) dw3[jj] += sc * ri[2 + jj] * h2;
+                }
+                if (vb == 0 && tid < J.m.out)
+                    for (int r = 0; r < nr; ++r) db3 += sc * rinfo[r * 8 + 2 + tid];
             }
         }
-        J.grad[J.m.b2() + n] = db2;
-        J.grad[J.m.g2() + n] = dg;
-        J.grad[J.m.be2() + n] = dbe;
-        for (int jj = 0; jj < J.m.out; ++jj) J.grad[J.m.W3() + jj * H2 + n] = dw3[jj];
-        if (b == kWgTilesPerBlock && tid < J.m.out) {
-            float db3 = 0.f;
-            for (int s = 0; s < J.nslots; ++s)
-                for (int r = 0; r < J.rows[s]; ++r) db3 += scale[s] * J.ws[s].dout[(size_t)r * 4 + tid];
-            J.grad[J.m.b3() + tid] = db3;
+        float* my = red + (rg * 64 + lane) * 20;
+        my[0] = db2; my[1] = dg; my[2] = dbe; my[3] = dw3[0]; my[4] = dw3[1]; my[5] = dw3[2]; my[6] = dw3[3];
+        __syncthreads();
+        if (tid < 64) {
+            float v[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) v[i] = (red[tid * 20 + i] + red[(64 + tid) * 20 + i]) + (red[(128 + tid) * 20 + i] + red[(192 + tid) * 20 + i]);
+            J.grad[J.m.b2() + n] = v[0];
+            J.grad[J.m.g2() + n] = v[1];
+            J.grad[J.m.be2() + n] = v[2];
+            for (int jj = 0; jj < J.m.out; ++jj) J.grad[J.m.W3() + jj * H2 + n] = v[3 + jj];
         }
+        if (vb == 0 && tid < J.m.out) J.grad[J.m.b3() + tid] = db3;
         return;
     }
-    // layer 1: dz1 = LN1 backward of dh1 (row-wise, wave per row), then per-column sums: thread t = hidden unit t
+    // layer 1: hidden unit k; dz1 = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) with the row means taken from the
+    // per-tile partial sums bwd_l2 left in lnp -> no cross-column work here.  64 units x 4 row groups per workgroup.
     {
+        const int k = (b - kWgTilesPerBlock - kWgVecWgs) * 64 + lane;
         const int in = J.m.in;
-        const float g1 = J.net[J.m.g1() + tid], be1 = J.net[J.m.be1() + tid];
+        const float g1 = J.net[J.m.g1() + k], be1 = J.net[J.m.be1() + k];
         float db1 = 0.f, dg = 0.f, dbe = 0.f, dw1[17];
 #pragma unroll
         for (int i = 0; i < 17; ++i) dw1[i] = 0.f;
         for (int s = 0; s < J.nslots; ++s) {
             const Slot& S = J.ws[s];
             const float sc = scale[s];
-            for (int r0 = 0; r0 < J.rows[s]; r0 += RT) {
-                const int nrow = min(RT, J.rows[s] - r0);
+            for (int c0 = 0; c0 < J.rows[s]; c0 += kWgRowChunk) {
+                const int nr = min(kWgRowChunk, J.rows[s] - c0);
                 __syncthreads();
-                for (int e = tid; e < RT * XP; e += kThreads) xs[e] = e < nrow * XP ? S.x[(size_t)r0 * XP + e] : 0.0f;
-                for (int q = 0; q < 4; ++q) {
-                    const int r = wave * 4 + q;
-                    RowReg<H1> dzr, dyr, xhr;
-                    if (r < nrow) {
-                        const size_t R = (size_t)(r0 + r);
-                        RowReg<H1> dh, z, g, be;
-                        dh.load(S.dh1 + R * H1);
-                        z.load(S.z1 + R * H1);
-                        g.load(J.net + J.m.g1());
-                        be.load(J.net + J.m.be1());
-                        const float mean = S.st1[R * 2], rstd = S.st1[R * 2 + 1];
-                        float dxh[4], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            xhr.v[c] = (z.v[c] - mean) * rstd;
-                            const float yy = g.v[c] * xhr.v[c] + be.v[c];
-                            dyr.v[c] = dh.v[c] * act_d(yy, slope);
-                            dxh[c] = dyr.v[c] * g.v[c];
-                            s1 += dxh[c];
-                            s2 += dxh[c] * xhr.v[c];
-                        }
-                        s1 = wave_sum(s1) * (1.0f / H1);
-                        s2 = wave_sum(s2) * (1.0f / H1);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) dzr.v[c] = rstd * (dxh[c] - s1 - xhr.v[c] * s2);
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) dzr.v[c] = dyr.v[c] = xhr.v[c] = 0.0f;
-                    }
-                    dzr.store_lds(t_dz + r * LDA1);
-                    dyr.store_lds(t_dy + r * LDA1);
-                    xhr.store_lds(t_xh + r * LDA1);
+                for (int e = tid; e < nr * XP; e += kThreads) xs[e] = S.x[(size_t)c0 * XP + e];
+                for (int e = tid; e < nr; e += kThreads) {
+                    const float* lp = S.lnp + (size_t)(c0 + e) * 8;
+                    rinfo[e * 8] = S.st1[(size_t)(c0 + e) * 2];
+                    rinfo[e * 8 + 1] = S.st1[(size_t)(c0 + e) * 2 + 1];
+                    rinfo[e * 8 + 2] = ((lp[0] + lp[2]) + (lp[4] + lp[6])) * (1.0f / H1);
+                    rinfo[e * 8 + 3] = ((lp[1] + lp[3]) + (lp[5] + lp[7])) * (1.0f / H1);
                 }
                 __syncthreads();
-#pragma unroll 4
-                for (int r = 0; r < RT; ++r) {
-                    const float dz = sc * t_dz[r * LDA1 + tid], dy = sc * t_dy[r * LDA1 + tid];
+#pragma unroll 2
+                for (int r = rg; r < nr; r += 4) {
+                    const float* ri = rinfo + r * 8;
+                    const float xh = (S.z1[(size_t)(c0 + r) * H1 + k] - ri[0]) * ri[1];
+                    const float dy = S.dh1[(size_t)(c0 + r) * H1 + k] * act_d(g1 * xh + be1, slope);
+                    const float dz = sc * (ri[1] * (dy * g1 - ri[2] - xh * ri[3]));
                     db1 += dz;
-                    dbe += dy;
-                    dg += dy * t_xh[r * LDA1 + tid];
+                    dbe += sc * dy;
+                    dg += sc * dy * xh;
+                    const float* xr = xs + r * XP;
 #pragma unroll
-                    for (int i = 0; i < 17; ++i) dw1[i] += dz * xs[r * XP + i];
+                    for (int i = 0; i < 17; ++i) dw1[i] += dz * xr[i];
                 }
             }
         }
-        (void)g1; (void)be1;
-        J.grad[J.m.b1() + tid] = db1;
-        J.grad[J.m.g1() + tid] = dg;
-        J.grad[J.m.be1() + tid] = dbe;
-        for (int i = 0; i < in; ++i) J.grad[J.m.W1() + tid * in + i] = dw1[i];
+        float* my = red + (rg * 64 + lane) * 20;
+        my[0] = db1; my[1] = dg; my[2] = dbe;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) my[3 + i] = dw1[i];
+        __syncthreads();
+        if (tid < 64) {
+            float v[20];
+#pragma unroll
+            for (int i = 0; i < 20; ++i) v[i] = (red[tid * 20 + i] + red[(64 + tid) * 20 + i]) + (red[(128 + tid) * 20 + i] + red[(192 + tid) * 20 + i]);
+            J.grad[J.m.b1() + k] = v[0];
+            J.grad[J.m.g1() + k] = v[1];
+            J.grad[J.m.be1() + k] = v[2];
+            for (int i = 0; i < in; ++i) J.grad[J.m.W1() + k * in + i] = v[3 + i];
+        }
     }
 }
 
@@ -755,8 +803,8 @@ __global__ __launch_bounds__(kThreads) void polyak_kernel(float* target, const f
 // minibatch sampling on the device: UniformMemory.sample (buffer.py:45 random.sample, without replacement),
 // np.random.choice(N_exp, B, replace=False) (HIRL.py:249) and the (4,) target-smoothing noise (HIRL.py:265).
 // One workgroup; Philox4x32-10 keyed by `seed`, counter (row, call, stream, round).  Duplicates inside a group are
-// redrawn for a bounded number of rounds (B << len, so a handful suffices; a leftover duplicate after the last round is
-// accepted — it is the with-replacement draw SURVEY.md quirk 13 allows).
+// redrawn until none is left (normally one round: B << len), at most 128 rounds; a duplicate surviving that — only
+// possible when a group asks for nearly the whole table — is accepted (the with-replacement draw of SURVEY.md quirk 13).
 // ---------------------------------------------------------------------------------------------------------------
 struct SampleArgs {
     const unsigned long long* total;  // transitions ever stored in the main ring
@@ -777,28 +825,28 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
     const uint32_t len_main = (uint32_t)(tot < (unsigned long long)A.cap ? tot : (unsigned long long)A.cap);
     const uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
     for (int stream = 0; stream < 2; ++stream) {  // 0: replay / expert rows, 1: BC rows
-        const bool main_grp = t < A.n_main;
-        const uint32_t len = stream == 1 ? (uint32_t)A.bc_len : (main_grp ? len_main : (uint32_t)A.expert_len);
         int* out = stream == 1 ? A.idx_bc : A.idx;
         if (!out) continue;
+        const bool main_grp = t < A.n_main;
+        const uint32_t len = stream == 1 ? (uint32_t)A.bc_len : (main_grp ? len_main : (uint32_t)A.expert_len);
+        const int lo = (stream == 1 || main_grp) ? 0 : A.n_main;  // groups: [0, n_main) and [n_main, batch)
         int v = 0;
-        bool dup = true;
-        for (int round = 0; round < 8; ++round) {
-            if (t < A.batch && dup) {
+        bool dup = t < A.batch;
+        for (int round = 0; round < 128; ++round) {
+            if (dup) {
                 uint32_t u[4];
                 philox4x32_10((uint32_t)t, A.call, (uint32_t)stream, (uint32_t)round, k0, k1, u);
                 v = len ? (int)__umulhi(u[0], len) : 0;
             }
-            __syncthreads();
             cand[t] = v;
             __syncthreads();
             dup = false;
-            if (t < A.batch) {
-                const int lo = (stream == 1 || main_grp) ? 0 : A.n_main;  // groups: [0, n_main) and [n_main, batch)
+            if (t < A.batch)
                 for (int s = lo; s < t; ++s) dup |= cand[s] == v;
-            }
+            if (!__syncthreads_or(dup)) break;  // nobody redraws: done (the common case after the first round)
         }
         if (t < A.batch) out[t] = v;
+        __syncthreads();
     }
     if (t < 4 && A.noise) {
         uint32_t u[4];
@@ -812,7 +860,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-constexpr size_t kSlotFloats = XP + H1 + 2 + H1 + H2 + 2 + 4 + H2 + H1 + 4;  // per row
+constexpr size_t kSlotFloats = XP + H1 + 2 + H1 + H2 + 2 + 4 + H2 + H1 + 4 + 8;  // per row
 
 Slot carve_slot(float* base, int rows) {
     Slot s;
@@ -827,6 +875,7 @@ Slot carve_slot(float* base, int rows) {
     s.dz2 = p; p += (size_t)rows * H2;
     s.dh1 = p; p += (size_t)rows * H1;
     s.dout = p; p += (size_t)rows * 4;
+    s.lnp = p; p += (size_t)rows * 8;
     return s;
 }
 
@@ -890,12 +939,12 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
     Slot s[S_COUNT];
     make_slots(N, B, s);
     const RowSrc src{Bt->ring, Bt->expert_ring, Bt->idx, Bt->n_main, 32};
-    HX_CHECK_HIP(hipMemsetAsync(N->losses, 0, sizeof(float), st));
     const float* tc1 = N->target_critic;
     const float* tc2 = N->target_critic + kQ.padded();
     {   // launch A: targetActor(s'), critic Q1/Q2 (s, a)
         FwdArgs F{};
         F.njobs = 3; F.slope = Hy->slope;
+        F.zero_f = N->losses; F.zero_nf = 1;  // critic_loss accumulator
         F.job[0] = FwdJob{N->target_actor, kActor, src, 17, 0, Head{}, nullptr, 0.f, s[S_TA], B, 0};
         F.job[1] = FwdJob{N->critic, kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C1], B, 1};
         F.job[2] = FwdJob{N->critic + kQ.padded(), kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C2], B, 1};
@@ -973,11 +1022,10 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
     const RowSrc src{Bt->ring, Bt->expert_ring, Bt->idx, Bt->n_main, 32};
     const RowSrc bcsrc{Bt->bc_table, Bt->bc_table, Bt->idx_bc, B, 32};
     const bool bc = Hy->use_bc != 0, soft = bc && estimate_soft;
-    HX_CHECK_HIP(hipMemsetAsync(N->losses + 1, 0, 4 * sizeof(float), st));
-    HX_CHECK_HIP(hipMemsetAsync(N->soft_count, 0, sizeof(int), st));
     {   // launch F: actor(s), actor(s_bc), bc_actor(s)
         FwdArgs F{};
         F.slope = Hy->slope;
+        F.zero_f = N->losses + 1; F.zero_nf = 4; F.zero_i = N->soft_count;  // actor / bc / rl / bc_fire accumulators + soft count
         int n = 0;
         F.job[n++] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1};
         if (bc) F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1};
@@ -1058,7 +1106,7 @@ int hx_sample_batch(const uint64_t* total, int64_t cap, int64_t expert_len, int6
                     uint64_t seed, uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc, float* noise, void* stream) {
     HX_REQUIRE(total && idx && batch > 0 && batch <= 1024 && n_main >= 0 && n_main <= batch && cap > 0, "hx_sample_batch: bad arguments");
     SampleArgs A{(const unsigned long long*)total, cap, expert_len, bc_len, batch, n_main, seed, call, sigma, idx, idx_bc, noise};
-    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3((unsigned)((batch + 63) / 64 * 64)), 0, (hipStream_t)stream, A);
     HX_CHECK_LAUNCH("hx_sample_batch");
     return 0;
 }

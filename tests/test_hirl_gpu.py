@@ -241,3 +241,30 @@ def test_learn_ragged_batches_and_outlier_rows(eng_mod):
             if was_actor_call:
                 check_grads(eng_mod, e.grad_actor, o.last_grads["actor"], eng_mod.ACTOR_LAYOUT, f"B={B} actor grad call {k}")
             check_params(e, o, eng_mod, f"B={B} call {k} params")
+
+
+def test_device_sampler(eng_mod):
+    """hx_sample_batch: indices inside the live part of each table, no duplicates inside a group (random.sample /
+    np.random.choice(replace=False) semantics), deterministic per (seed, call), reads the ring length on the device."""
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    e = eng_mod.HirlEngine(batch=128)
+    rep = DeviceReplay(5000)
+    rep.total += 300  # only 300 rows are live
+    seen = []
+    for call in range(50):
+        idx, idx_bc, noise = e.sample(rep, expert_len=200, bc_len=150, n_main=96, seed=9)
+        i, b, z = idx.cpu().numpy(), idx_bc.cpu().numpy(), noise.cpu().numpy()
+        assert i[:96].min() >= 0 and i[:96].max() < 300 and len(set(i[:96])) == 96
+        assert i[96:].min() >= 0 and i[96:].max() < 200 and len(set(i[96:])) == 32
+        assert b.min() >= 0 and b.max() < 150 and len(set(b)) == 128  # 128 of 150 without replacement
+        seen.append((i.copy(), z.copy()))
+    assert not np.array_equal(seen[0][0], seen[1][0])
+    zs = np.stack([z for _, z in seen])
+    assert abs(zs.mean()) < 0.08 and abs(zs.std() - 0.2) < 0.05
+    e2 = eng_mod.HirlEngine(batch=128)
+    idx2, _, n2 = e2.sample(rep, expert_len=200, bc_len=150, n_main=96, seed=9)
+    assert np.array_equal(idx2.cpu().numpy(), seen[0][0]) and np.array_equal(n2.cpu().numpy(), seen[0][1])
+    rep.total += 100000  # ring wrapped: the whole capacity is live
+    idx3, _, _ = e.sample(rep, expert_len=200, bc_len=150, n_main=128, seed=9)
+    assert idx3.max().item() >= 300 and idx3.max().item() < 5000
