@@ -28,7 +28,10 @@ using namespace hxnn;
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kNT = 64;  // z2 / dh1 columns per workgroup (4 waves x 16)
+constexpr int kWide = 1024;  // fwd_l2 / bwd_l2 workgroups: 16 waves = one per row of the tile in the prologue, and
+                             // 4 column tiles x 4 K-quarters (split-K, LDS reduce) in the MFMA phase.  B = 128 runs ONE
+                             // workgroup per CU, so 4 waves per SIMD are what hides the prologue's load/reduce latency.
+constexpr int kNT = 64;  // z2 / dh1 columns per workgroup (4 column tiles x 16)
 
 // minibatch row r comes from main[idx[r]] if r < nb else from exp[idx[r]]; idx == nullptr: row r of `main` itself
 struct RowSrc {
@@ -146,16 +149,22 @@ struct FwdArgs {
 
 __device__ __forceinline__ int tiles_of(int rows) { return (rows + RT - 1) / RT; }
 
-__global__ __launch_bounds__(kThreads) void fwd_l2_kernel(FwdArgs A) {
-    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2];
+// WIDE = false: 64 columns per workgroup, split-K 4 (latency mode, B = 128: 8 column tiles per row tile keep ~190 CUs busy)
+// WIDE = true : 256 columns per workgroup, one 16-column tile per wave, full K (throughput mode, thousands of rows: the
+//               prologue is recomputed 2x per row tile instead of 8x)
+template <bool WIDE>
+__global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
+    constexpr int NTW = WIDE ? 256 : kNT;
+    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2 + 3 * 4 * 256];
     float* h1s = lds;
     float* xs = lds + RT * LDA1;
     float* sts = xs + RT * XP;
+    float* kred = sts + RT * 2;  // [3 K-quarters][4 column tiles][64 lanes][4]
 
     // which job / row tile / column tile
     int b = blockIdx.x, j = 0;
     for (; j < A.njobs; ++j) {
-        const int nb = tiles_of(A.job[j].rows) * (H2 / kNT);
+        const int nb = tiles_of(A.job[j].rows) * (H2 / NTW);
         if (b < nb) break;
         b -= nb;
     }
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void fwd_l2_kernel(FwdArgs A) {
         if (threadIdx.x == 0 && A.zero_i) *A.zero_i = 0;
     }
     const FwdJob& J = A.job[j];
-    const int rt = b / (H2 / kNT), nt = b % (H2 / kNT);
+    const int rt = b / (H2 / NTW), nt = b % (H2 / NTW);
     const int r0 = rt * RT;
     const int nrow = min(RT, J.rows - r0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void fwd_l2_kernel(FwdArgs A) {
     const int in = J.m.in;
 
     // 1. input tile xs[16][XP]
-    for (int e = tid; e < RT * XP; e += kThreads) xs[e] = 0.0f;
+    if (tid < RT * XP) xs[tid] = 0.0f;
     __syncthreads();
     if (tid < RT * 13) {
         const int r = tid / 13, c = tid % 13;
@@ -181,88 +190,86 @@ __global__ __launch_bounds__(kThreads) void fwd_l2_kernel(FwdArgs A) {
     }
     if (in == 17) {
         if (J.act_mode == 0) {
-            if (tid < RT * 4) {
-                const int r = tid >> 2, c = tid & 3;
+            if (tid >= 256 && tid < 256 + RT * 4) {
+                const int r = (tid - 256) >> 2, c = tid & 3;
                 if (r < nrow) xs[r * XP + 13 + c] = src_row(J.src, r0 + r)[13 + c];
             }
-        } else {
-            // head of the previous net for rows 4*wave .. 4*wave+3
-            for (int q = 0; q < 4; ++q) {
-                const int r = wave * 4 + q;
-                if (r >= nrow) break;  // wave-uniform
-                RowReg<H2> xh, y;
-                float mean, rstd, o[4];
-                head_row<4>(J.prev.ws.z2 + (size_t)(r0 + r) * H2, J.prev.net, J.prev.m, slope, xh, y, mean, rstd, o);
-                if (lane < 4) {
-                    float a = tanhf(o[lane]);  // Actor.forward's tanh, HIRL.py:140
-                    if (J.noise) {              // target smoothing, HIRL.py:264-267
-                        const float e = fminf(fmaxf(J.noise[lane], -J.noise_clamp), J.noise_clamp);
-                        a = fminf(fmaxf(a + e, -1.0f), 1.0f);
-                    }
-                    xs[r * XP + 13 + lane] = a;
-                    if (nt == 0) J.prev.ws.outv[(size_t)(r0 + r) * 4 + lane] = a;
+        } else if (wave < nrow) {
+            // head of the previous net: wave w owns row w
+            const int r = wave;
+            RowReg<H2> xh, y;
+            float mean, rstd, o[4];
+            head_row<4>(J.prev.ws.z2 + (size_t)(r0 + r) * H2, J.prev.net, J.prev.m, slope, xh, y, mean, rstd, o);
+            if (lane < 4) {
+                float a = tanhf(o[lane]);  // Actor.forward's tanh, HIRL.py:140
+                if (J.noise) {              // target smoothing, HIRL.py:264-267
+                    const float e = fminf(fmaxf(J.noise[lane], -J.noise_clamp), J.noise_clamp);
+                    a = fminf(fmaxf(a + e, -1.0f), 1.0f);
                 }
-                if (nt == 0 && lane == 0) {
-                    J.prev.ws.st2[(size_t)(r0 + r) * 2] = mean;
-                    J.prev.ws.st2[(size_t)(r0 + r) * 2 + 1] = rstd;
-                }
+                xs[r * XP + 13 + lane] = a;
+                if (nt == 0) J.prev.ws.outv[(size_t)(r0 + r) * 4 + lane] = a;
+            }
+            if (nt == 0 && lane == 0) {
+                J.prev.ws.st2[(size_t)(r0 + r) * 2] = mean;
+                J.prev.ws.st2[(size_t)(r0 + r) * 2 + 1] = rstd;
             }
         }
     }
     __syncthreads();
 
-    // 2. z1[r][t] = b1[t] + sum_i x[r][i] W1[t][i]   (thread t = hidden unit t)
-    float z1[RT];
+    // 2. z1[r][u] = b1[u] + sum_i x[r][i] W1[u][i]: hidden unit u = tid & 255, rows 4*(tid >> 8) .. +3
+    const int u = tid & (H1 - 1), rq = (tid >> 8) * 4;
+    float z1[4];
     {
-        const float* W1 = J.net + J.m.W1() + tid * in;
-        const float bias = J.net[J.m.b1() + tid];
+        const float* W1 = J.net + J.m.W1() + u * in;
+        const float bias = J.net[J.m.b1() + u];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) z1[r] = bias;
+        for (int r = 0; r < 4; ++r) z1[r] = bias;
         for (int i = 0; i < in; ++i) {
             const float w = W1[i];
 #pragma unroll
-            for (int r = 0; r < RT; ++r) z1[r] += xs[r * XP + i] * w;
+            for (int r = 0; r < 4; ++r) z1[r] += xs[(rq + r) * XP + i] * w;
         }
 #pragma unroll
-        for (int r = 0; r < RT; ++r) h1s[r * LDA1 + tid] = z1[r];
+        for (int r = 0; r < 4; ++r) h1s[(rq + r) * LDA1 + u] = z1[r];
     }
     __syncthreads();
-    // 3. LN1 statistics: wave w owns rows 4w..4w+3
-    for (int q = 0; q < 4; ++q) {
-        const int r = wave * 4 + q;
+    // 3. LN1 statistics: wave w owns row w
+    {
         float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = h1s[r * LDA1 + i * 64 + lane];
+        for (int i = 0; i < 4; ++i) v[i] = h1s[wave * LDA1 + i * 64 + lane];
         float mean, rstd;
         row_stats<4>(v, H1, mean, rstd);
         if (lane == 0) {
-            sts[r * 2] = mean;
-            sts[r * 2 + 1] = rstd;
+            sts[wave * 2] = mean;
+            sts[wave * 2 + 1] = rstd;
         }
     }
     __syncthreads();
     // 4. h1 = act(LN1(z1))
     {
-        const float g = J.net[J.m.g1() + tid], be = J.net[J.m.be1() + tid];
+        const float g = J.net[J.m.g1() + u], be = J.net[J.m.be1() + u];
         const bool save = J.save && nt == 0;
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const float h = act_f(g * ((z1[r] - sts[r * 2]) * sts[r * 2 + 1]) + be, slope);
-            h1s[r * LDA1 + tid] = h;
-            if (save && r < nrow) {
-                J.ws.z1[(size_t)(r0 + r) * H1 + tid] = z1[r];
-                J.ws.h1[(size_t)(r0 + r) * H1 + tid] = h;
+        for (int r = 0; r < 4; ++r) {
+            const int row = rq + r;
+            const float h = act_f(g * ((z1[r] - sts[row * 2]) * sts[row * 2 + 1]) + be, slope);
+            h1s[row * LDA1 + u] = h;
+            if (save && row < nrow) {
+                J.ws.z1[(size_t)(r0 + row) * H1 + u] = z1[r];
+                J.ws.h1[(size_t)(r0 + row) * H1 + u] = h;
             }
         }
         if (save) {
-            for (int e = tid; e < nrow * XP; e += kThreads) J.ws.x[(size_t)r0 * XP + e] = xs[e];
+            if (tid < nrow * XP) J.ws.x[(size_t)r0 * XP + tid] = xs[tid];
             if (tid < nrow * 2) J.ws.st1[(size_t)r0 * 2 + tid] = sts[tid];
         }
     }
     __syncthreads();
-    // 5. z2 tile: 16 rows x 16 columns per wave on fp32 MFMA, K = 256
-    {
-        const int n0 = nt * kNT + wave * 16;
+    // 5. z2 tile on fp32 MFMA
+    if (WIDE) {
+        const int n0 = nt * NTW + wave * 16;
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
         acc = tile_a_lds_bt_global<H1>(h1s, LDA1, J.net + J.m.W2() + (size_t)(n0 + r) * H1, acc);
@@ -271,6 +278,24 @@ __global__ __launch_bounds__(kThreads) void fwd_l2_kernel(FwdArgs A) {
         for (int q = 0; q < 4; ++q) {
             const int row = 4 * g + q;
             if (row < nrow) J.ws.z2[(size_t)(r0 + row) * H2 + n0 + r] = acc[q] + bias;
+        }
+    } else {
+        // wave = (column tile ct, K quarter kq); partial sums meet in LDS
+        const int ct = wave & 3, kq = wave >> 2;
+        const int n0 = nt * kNT + ct * 16;
+        const int r = lane & 15, g = lane >> 4;
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+        acc = tile_a_lds_bt_global<H1 / 4>(h1s + kq * (H1 / 4), LDA1, J.net + J.m.W2() + (size_t)(n0 + r) * H1 + kq * (H1 / 4), acc);
+        if (kq) *reinterpret_cast<float4*>(kred + (((kq - 1) * 4 + ct) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        __syncthreads();
+        if (kq == 0) {
+            const float bias = J.net[J.m.b2() + n0 + r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = (acc[q] + kred[((0 * 4 + ct) * 64 + lane) * 4 + q]) + (kred[((1 * 4 + ct) * 64 + lane) * 4 + q] + kred[((2 * 4 + ct) * 64 + lane) * 4 + q]);
+                const int row = 4 * g + q;
+                if (row < nrow) J.ws.z2[(size_t)(r0 + row) * H2 + n0 + r] = v + bias;
+            }
         }
     }
 }
@@ -359,9 +384,10 @@ struct BwdArgs {
     int* soft_count;
 };
 
-__global__ __launch_bounds__(kThreads) void bwd_l2_kernel(BwdArgs A) {
+__global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
     __shared__ __attribute__((aligned(16))) float dz2s[RT * LDA2];
-    __shared__ float red[4][4];
+    __shared__ __attribute__((aligned(16))) float kred[3 * 4 * 256];  // split-K partial tiles
+    __shared__ float red[16][4];
 
     int b = blockIdx.x, j = 0;
     for (; j < A.njobs; ++j) {
@@ -380,8 +406,8 @@ __global__ __launch_bounds__(kThreads) void bwd_l2_kernel(BwdArgs A) {
 
     float part[4] = {0.f, 0.f, 0.f, 0.f};  // per-wave loss partials
     int cnt = 0;
-    for (int q = 0; q < 4; ++q) {
-        const int r = wave * 4 + q;
+    for (int q = 0; q < 1; ++q) {  // wave w owns row w of the tile
+        const int r = wave;
         float* drow = dz2s + r * LDA2;
         if (r >= nrow) {  // wave-uniform: padded rows contribute zeros
             RowReg<H2> zero;
@@ -501,10 +527,10 @@ __global__ __launch_bounds__(kThreads) void bwd_l2_kernel(BwdArgs A) {
     }
     __syncthreads();
     if (lead && tid == 0) {
-        const float p0 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-        const float p1 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
-        const float p2 = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
-        const float p3 = (red[0][3] + red[1][3]) + (red[2][3] + red[3][3]);
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        for (int w = 0; w < 16; ++w) {
+            p0 += red[w][0]; p1 += red[w][1]; p2 += red[w][2]; p3 += red[w][3];
+        }
         if (J.mode == BM_CRITIC_TD) atomicAdd(&A.losses[0], p0);
         if (J.mode == BM_CRITIC_PI) atomicAdd(&A.losses[3], p3);
         if (J.mode == BM_ACTOR_BC) {
@@ -512,37 +538,38 @@ __global__ __launch_bounds__(kThreads) void bwd_l2_kernel(BwdArgs A) {
             atomicAdd(&A.losses[4], p1);
         }
     }
-    // dh1 tile: 16 rows x 16 columns per wave, K = 512; W2 is [512][256] row-major = B[k][n]
+    // dh1 tile on fp32 MFMA: wave = (column tile ct, K quarter kq), K = 512; W2 is [512][256] row-major = B[k][n]
     {
-        const int n0 = nt * kNT + wave * 16;
+        const int ct = wave & 3, kq = wave >> 2;
+        const int n0 = nt * kNT + ct * 16;
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_a_lds_b_global<H2>(dz2s, LDA2, J.net + J.m.W2() + n0 + r, H1, acc);
-        // epilogue: store dh1 and this tile's share of the LN1-backward row sums (consumed by wgrad / the actor's
-        // backward, which then need no cross-column reduction of their own)
-        const float g1 = J.net[J.m.g1() + n0 + r], be1 = J.net[J.m.be1() + n0 + r];
-        float p1[4], p2[4];
+        acc = tile_a_lds_b_global<H2 / 4>(dz2s + kq * (H2 / 4), LDA2, J.net + J.m.W2() + (size_t)(kq * (H2 / 4)) * H1 + n0 + r, H1, acc);
+        if (kq) *reinterpret_cast<float4*>(kred + (((kq - 1) * 4 + ct) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        __syncthreads();  // partial tiles visible; dz2s is dead from here on
+        float* ps = dz2s;  // reused as [4 column tiles][16 rows][2]
+        if (kq == 0) {
+            // epilogue: store dh1 and this tile's share of the LN1-backward row sums (consumed by wgrad / the actor's
+            // backward, which then need no cross-column reduction of their own)
+            const float g1 = J.net[J.m.g1() + n0 + r], be1 = J.net[J.m.be1() + n0 + r];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = 4 * g + q;
-            p1[q] = p2[q] = 0.0f;
-            if (row < nrow) {
-                const size_t R = (size_t)(r0 + row);
-                J.ws.dh1[R * H1 + n0 + r] = acc[q];
-                const float xh = (J.ws.z1[R * H1 + n0 + r] - J.ws.st1[R * 2]) * J.ws.st1[R * 2 + 1];
-                const float dxh = acc[q] * act_d(g1 * xh + be1, slope) * g1;
-                p1[q] = dxh;
-                p2[q] = dxh * xh;
-            }
-        }
-        __syncthreads();  // dz2s is dead: reuse its head as [4 waves][16 rows][2]
-        float* ps = dz2s;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float a1 = sum16(p1[q]), a2 = sum16(p2[q]);
-            if (r == 0) {
-                ps[(wave * RT + 4 * g + q) * 2] = a1;
-                ps[(wave * RT + 4 * g + q) * 2 + 1] = a2;
+            for (int q = 0; q < 4; ++q) {
+                const float v = (acc[q] + kred[((0 * 4 + ct) * 64 + lane) * 4 + q]) + (kred[((1 * 4 + ct) * 64 + lane) * 4 + q] + kred[((2 * 4 + ct) * 64 + lane) * 4 + q]);
+                const int row = 4 * g + q;
+                float p1 = 0.0f, p2 = 0.0f;
+                if (row < nrow) {
+                    const size_t R = (size_t)(r0 + row);
+                    J.ws.dh1[R * H1 + n0 + r] = v;
+                    const float xh = (J.ws.z1[R * H1 + n0 + r] - J.ws.st1[R * 2]) * J.ws.st1[R * 2 + 1];
+                    const float dxh = v * act_d(g1 * xh + be1, slope) * g1;
+                    p1 = dxh;
+                    p2 = dxh * xh;
+                }
+                const float a1 = sum16(p1), a2 = sum16(p2);
+                if (r == 0) {
+                    ps[(ct * RT + row) * 2] = a1;
+                    ps[(ct * RT + row) * 2 + 1] = a2;
+                }
             }
         }
         __syncthreads();
@@ -819,7 +846,7 @@ struct SampleArgs {
 };
 
 __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
-    __shared__ int cand[1024];
+    __shared__ __attribute__((aligned(16))) int cand[1024];
     const int t = threadIdx.x;
     const unsigned long long tot = *A.total;
     const uint32_t len_main = (uint32_t)(tot < (unsigned long long)A.cap ? tot : (unsigned long long)A.cap);
@@ -841,8 +868,16 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
             cand[t] = v;
             __syncthreads();
             dup = false;
-            if (t < A.batch)
-                for (int s = lo; s < t; ++s) dup |= cand[s] == v;
+            if (t < A.batch) {  // any earlier member of my group with the same index?  16-B LDS reads, 4 compares each
+                const int4* c4 = reinterpret_cast<const int4*>(cand);
+#pragma unroll 8
+                for (int s4 = lo >> 2; s4 <= (t >> 2); ++s4) {
+                    const int4 c = c4[s4];
+                    const int s = s4 * 4;
+                    dup |= (c.x == v && s >= lo && s < t) | (c.y == v && s + 1 >= lo && s + 1 < t) |
+                           (c.z == v && s + 2 >= lo && s + 2 < t) | (c.w == v && s + 3 >= lo && s + 3 < t);
+                }
+            }
             if (!__syncthreads_or(dup)) break;  // nobody redraws: done (the common case after the first round)
         }
         if (t < A.batch) out[t] = v;
@@ -881,10 +916,18 @@ Slot carve_slot(float* base, int rows) {
 
 enum { S_TA = 0, S_C1, S_C2, S_TC1, S_TC2, S_API, S_ABC, S_BCS, S_CPI, S_CSOFT, S_COUNT };
 
-int fwd_blocks(const FwdArgs& a) {
+int fwd_row_tiles(const FwdArgs& a) {
     int n = 0;
-    for (int j = 0; j < a.njobs; ++j) n += ((a.job[j].rows + RT - 1) / RT) * (H2 / kNT);
+    for (int j = 0; j < a.njobs; ++j) n += (a.job[j].rows + RT - 1) / RT;
     return n;
+}
+// column tiling by size: enough row tiles to fill the chip -> wide workgroups (less prologue recomputation)
+void launch_fwd(const FwdArgs& F, hipStream_t st) {
+    const int tiles = fwd_row_tiles(F);
+    if (tiles >= 128)
+        hipLaunchKernelGGL(fwd_l2_kernel<true>, dim3(tiles * (H2 / 256)), dim3(kWide), 0, st, F);
+    else
+        hipLaunchKernelGGL(fwd_l2_kernel<false>, dim3(tiles * (H2 / kNT)), dim3(kWide), 0, st, F);
 }
 int bwd_blocks(const BwdArgs& a) {
     int n = 0;
@@ -919,7 +962,7 @@ int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* acti
     J.src = RowSrc{obs, nullptr, nullptr, 0, 13};
     J.col0 = 0; J.act_mode = 0; J.noise = nullptr; J.rows = (int)rows; J.save = 0;
     J.ws = Slot{}; J.ws.z2 = ws;
-    hipLaunchKernelGGL(fwd_l2_kernel, dim3(fwd_blocks(F)), dim3(kThreads), 0, (hipStream_t)stream, F);
+    launch_fwd(F, (hipStream_t)stream);
     ActArgs H{actor, kActor, ws, (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
               noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, seed, row0, call};
     hipLaunchKernelGGL(act_head_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, H);
@@ -948,7 +991,7 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
         F.job[0] = FwdJob{N->target_actor, kActor, src, 17, 0, Head{}, nullptr, 0.f, s[S_TA], B, 0};
         F.job[1] = FwdJob{N->critic, kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C1], B, 1};
         F.job[2] = FwdJob{N->critic + kQ.padded(), kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C2], B, 1};
-        hipLaunchKernelGGL(fwd_l2_kernel, dim3(fwd_blocks(F)), dim3(kThreads), 0, st, F);
+        launch_fwd(F, st);
     }
     {   // launch B: targetCritic Q1/Q2 (s', clamp(targetActor(s') + clamp(noise)))
         FwdArgs F{};
@@ -956,7 +999,7 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
         const Head prev{N->target_actor, kActor, s[S_TA]};
         F.job[0] = FwdJob{tc1, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC1], B, 0};
         F.job[1] = FwdJob{tc2, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC2], B, 0};
-        hipLaunchKernelGGL(fwd_l2_kernel, dim3(fwd_blocks(F)), dim3(kThreads), 0, st, F);
+        launch_fwd(F, st);
     }
     {   // launch C: y, loss, dq, LN2 backward, dh1 for both heads
         BwdArgs G{};
@@ -967,7 +1010,7 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
             J.net = N->critic + h * kQ.padded(); J.m = kQ; J.ws = s[S_C1 + h]; J.rows = B; J.mode = BM_CRITIC_TD;
             J.t1 = Head{tc1, kQ, s[S_TC1]}; J.t2 = Head{tc2, kQ, s[S_TC2]}; J.src = src; J.gamma = Hy->gamma;
         }
-        hipLaunchKernelGGL(bwd_l2_kernel, dim3(bwd_blocks(G)), dim3(kThreads), 0, st, G);
+        hipLaunchKernelGGL(bwd_l2_kernel, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
     }
     {   // launch D: all critic parameter gradients
         WgArgs W{};
@@ -1031,7 +1074,7 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
         if (bc) F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1};
         if (soft) F.job[n++] = FwdJob{N->bc_actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0};
         F.njobs = n;
-        hipLaunchKernelGGL(fwd_l2_kernel, dim3(fwd_blocks(F)), dim3(kThreads), 0, st, F);
+        launch_fwd(F, st);
     }
     {   // launch G: Q1(s, pi(s)) and Q1(s, bc_actor(s)) with the updated critic
         FwdArgs F{};
@@ -1040,7 +1083,7 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
         F.job[n++] = FwdJob{N->critic, kQ, src, 0, 1, Head{N->actor, kActor, s[S_API]}, nullptr, 0.f, s[S_CPI], B, 1};
         if (soft) F.job[n++] = FwdJob{N->critic, kQ, src, 0, 1, Head{N->bc_actor, kActor, s[S_BCS]}, nullptr, 0.f, s[S_CSOFT], B, 0};
         F.njobs = n;
-        hipLaunchKernelGGL(fwd_l2_kernel, dim3(fwd_blocks(F)), dim3(kThreads), 0, st, F);
+        launch_fwd(F, st);
     }
     {   // launch H: rl_loss, soft count, critic backward down to dh1 (gradient wrt the action comes next)
         BwdArgs G{};
@@ -1049,7 +1092,7 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
         J = BwdJob{};
         J.net = N->critic; J.m = kQ; J.ws = s[S_CPI]; J.rows = B; J.mode = BM_CRITIC_PI;
         if (soft) J.soft = Head{N->critic, kQ, s[S_CSOFT]};
-        hipLaunchKernelGGL(bwd_l2_kernel, dim3(bwd_blocks(G)), dim3(kThreads), 0, st, G);
+        hipLaunchKernelGGL(bwd_l2_kernel, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
     }
     {   // launch I: actor backward for the RL batch (through tanh and the critic's input gradient) and the BC batch
         BwdArgs G{};
@@ -1068,7 +1111,7 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
             J.src = bcsrc; J.lambda = Hy->loss_lambda;
         }
         G.njobs = n;
-        hipLaunchKernelGGL(bwd_l2_kernel, dim3(bwd_blocks(G)), dim3(kThreads), 0, st, G);
+        hipLaunchKernelGGL(bwd_l2_kernel, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
     }
     HX_CHECK_LAUNCH("hx_hirl_actor_backward");
     return 0;
