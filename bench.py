@@ -132,12 +132,11 @@ class Loop:
         env.step(self.actions)
         if ev:
             ev[2].record()
-        idx, idx_bc, noise = e.sample(self.replay, self.expert_len, self.bc_len, n_main=e.batch - self.expert_num, seed=2 + self.rank)
+        e.sample(self.replay, self.expert, self.bc_table, n_main=e.batch - self.expert_num, seed=2 + self.rank)
         # soft weight: estimated at the start of every max_step-long "episode" of vector steps, kept in between
         # (the reference re-estimates at most once per episode)
         w = 100 if (self.t % self.max_step == 0) else None
-        e.learn(self.replay.ring, idx, noise, expert_ring=self.expert.ring, n_main=e.batch - self.expert_num,
-                bc_table=self.bc_table, idx_bc=idx_bc, bc_weight_now=w, bc_warm_up_weight=0.0)
+        e.learn(bc_weight_now=w, bc_warm_up_weight=0.0)
         if ev:
             ev[3].record()
         self.t += 1

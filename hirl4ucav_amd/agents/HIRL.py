@@ -148,10 +148,9 @@ class Agent:
         idx_bc = np.random.choice(self.expert_states.shape[0], B, replace=False)  # HIRL.py:249
         noise = torch.normal(mean=torch.zeros(self.actionDim), std=torch.ones(self.actionDim) * self.TD3LearningNoise)  # :265
         was_actor_call = self.eng.actor_trainable
-        self.eng.learn(self.buffer.ring, torch.as_tensor(idx, dtype=torch.int32, device=device), noise.to(device),
-                       expert_ring=self.expert_buffer.ring, n_main=n_main, bc_table=self._bc_table,
-                       idx_bc=torch.as_tensor(idx_bc.astype(np.int32), device=device), bc_weight_now=bc_weight_now,
-                       bc_warm_up_weight=bc_warm_up_weight)
+        self.eng.assemble(self.buffer.ring, torch.as_tensor(idx, dtype=torch.int32, device=device), expert_ring=self.expert_buffer.ring,
+                          n_main=n_main, bc_table=self._bc_table, idx_bc=torch.as_tensor(idx_bc.astype(np.int32), device=device))
+        self.eng.learn(noise=noise.to(device), bc_weight_now=bc_weight_now, bc_warm_up_weight=bc_warm_up_weight)
         got = self.eng.losses_host()
         if was_actor_call:
             self._last = got

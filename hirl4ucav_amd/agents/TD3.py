@@ -17,7 +17,8 @@ class Agent(_HirlAgent):
         idx = self.buffer.sample_indices(self.batchSize)
         noise = torch.normal(mean=torch.zeros(self.actionDim), std=torch.ones(self.actionDim) * self.TD3LearningNoise)
         was_actor_call = self.eng.actor_trainable
-        self.eng.learn(self.buffer.ring, torch.as_tensor(idx, dtype=torch.int32, device=device), noise.to(device))
+        self.eng.assemble(self.buffer.ring, torch.as_tensor(idx, dtype=torch.int32, device=device))
+        self.eng.learn(noise=noise.to(device))
         got = self.eng.losses_host()
         if was_actor_call:
             self._last = got

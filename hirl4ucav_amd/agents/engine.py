@@ -20,8 +20,7 @@ _vp, _i32, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
 
 
 class HxBatch(ctypes.Structure):
-    _fields_ = [("ring", _vp), ("expert_ring", _vp), ("idx", _vp), ("n_main", _i32), ("batch", _i32), ("bc_table", _vp),
-                ("idx_bc", _vp), ("noise", _vp)]
+    _fields_ = [("rows", _vp), ("bc_rows", _vp), ("batch", _i32), ("noise", _vp)]
 
 
 class HxNets(ctypes.Structure):
@@ -40,7 +39,8 @@ _lib.register("hx_hirl_actor_backward", [_P(HxNets), _P(HxBatch), _P(HxHyper), _
 _lib.register("hx_hirl_actor_wgrad", [_P(HxNets), _P(HxHyper), _i32, _i32, _i32, _f32, _f32, _vp])
 _lib.register("hx_adam", [_P(HxNets), _P(HxHyper), _i32, _i32, _f32, _i32, _f32, _f32, _i32, _vp])
 _lib.register("hx_polyak", [_P(HxNets), _P(HxHyper), _vp])
-_lib.register("hx_sample_batch", [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _i32, _i32, ctypes.c_uint64, ctypes.c_uint32, _f32, _vp, _vp, _vp, _vp])
+_lib.register("hx_sample_batch", [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _i32, _i32, _i32, ctypes.c_uint64,
+                                   ctypes.c_uint32, _f32, _vp, _vp, _vp, _vp, _vp, _vp])
 
 # ---- flat layout <-> reference state_dict keys (hirl/agents/HIRL.py:19-146) -------------------------------------
 
@@ -79,6 +79,11 @@ def unpack(flat, layout):
     return {k: flat[off:off + int(np.prod(shp))].reshape(shp) for k, off, shp in layout}
 
 
+def len_of(replay):
+    """live rows of a DeviceReplay used as a fixed table (expert ring): its capacity bound, no host sync"""
+    return 0 if replay is None else int(getattr(replay, "fixed_len", replay.capacity))
+
+
 class HirlEngine:
     def __init__(self, batch=128, lr_actor=1e-3, lr_critic=1e-3, tau=0.005, gamma=0.99, slope=0.0, use_bc=True,
                  device="cuda", group=None):
@@ -89,15 +94,25 @@ class HirlEngine:
         assert L.hx_actor_param_count() == ACTOR_SIZE and L.hx_critic_param_count() == CRITIC_SIZE
         L.hx_hirl_workspace_floats.restype = ctypes.c_int64
         self.batch = int(batch)
-        z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device)  # noqa: E731
-        self.actor, self.target_actor, self.bc_actor = z(ACTOR_SIZE), z(ACTOR_SIZE), z(ACTOR_SIZE)
-        self.critic, self.target_critic = z(CRITIC_SIZE), z(CRITIC_SIZE)
-        self.grad = z(CRITIC_SIZE + ACTOR_SIZE)  # one buffer: [critic | actor]
+        # ONE arena for everything the update kernels touch (5 nets, gradients, Adam moments, workspace, minibatch tiles):
+        # a single contiguous mapping keeps the number of distinct pages / translations a short kernel has to fetch small
+        ws_floats = int(L.hx_hirl_workspace_floats(self.batch))
+        sizes = [ACTOR_SIZE] * 3 + [CRITIC_SIZE] * 2 + [CRITIC_SIZE + ACTOR_SIZE] + [ACTOR_SIZE] * 2 + [CRITIC_SIZE] * 2 + \
+                [64, 64, 64, ws_floats, self.batch * 32, self.batch * 32, self.batch, self.batch, 64]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 63) & ~63  # 256-B aligned carve-outs
+        self.arena = torch.zeros(tot, dtype=torch.float32, device=self.device)
+        carve = [self.arena[o:o + n] for o, n in zip(offs, sizes)]
+        (self.actor, self.target_actor, self.bc_actor, self.critic, self.target_critic, self.grad, self.m_actor, self.v_actor,
+         self.m_critic, self.v_critic, self.losses, sc, self.wstate, self.ws, self.rows, self.bc_rows, ix, ixb, self._noise) = carve
         self.grad_critic, self.grad_actor = self.grad[:CRITIC_SIZE], self.grad[CRITIC_SIZE:]
-        self.m_actor, self.v_actor, self.m_critic, self.v_critic = z(ACTOR_SIZE), z(ACTOR_SIZE), z(CRITIC_SIZE), z(CRITIC_SIZE)
-        self.losses, self.soft_count, self.wstate = z(8), z(1, torch.int32), z(1)
-        self.ws = z(int(L.hx_hirl_workspace_floats(self.batch)))
+        self.soft_count, self._idx, self._idx_bc = sc.view(torch.int32), ix.view(torch.int32), ixb.view(torch.int32)
+        self.losses, self.wstate, self._noise = self.losses[:8], self.wstate[:1], self._noise[:4]
+        self.soft_count = self.soft_count[:1]
         self._act_ws = None
+        self.sample_calls = 0
         self.nets = HxNets(*(t.data_ptr() for t in (self.actor, self.critic, self.target_actor, self.target_critic, self.bc_actor,
                                                      self.grad_actor, self.grad_critic, self.m_actor, self.v_actor, self.m_critic,
                                                      self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)))
@@ -151,16 +166,36 @@ class HirlEngine:
         if self.world > 1:
             torch.distributed.all_reduce(t, group=self.group)
 
-    def learn(self, ring, idx, noise, expert_ring=None, n_main=None, bc_table=None, idx_bc=None, bc_weight_now=0.0,
-              bc_warm_up_weight=0.0):
-        """One Agent.learn (HIRL.py:221-334 / TD3.py:201-260) on the minibatch {ring[idx[r]] | expert_ring[idx[r]]}.
-        bc_weight_now: 100 = estimate the soft weight now (HIRL.py:299), None = keep the stored device value, else the
-        given weight.  Enqueues only; read results with losses_host()."""
+    def assemble(self, ring, idx, expert_ring=None, n_main=None, bc_table=None, idx_bc=None):
+        """Caller-chosen minibatch (parity tests, the N = 1 facade): gather ring[idx[r]] / expert_ring[idx[r]] and
+        bc_table[idx_bc[r]] into the compact tiles the update stages read."""
+        B = self.batch
+        n_main = B if n_main is None else int(n_main)
+        _lib.call("hx_sample_batch", None, 0, ring.data_ptr(), _lib.ptr(expert_ring), 0, _lib.ptr(bc_table), 0, B, n_main, 0, 0, 0, 0.0,
+                  idx.data_ptr(), _lib.ptr(idx_bc), None, self.rows.data_ptr(), self.bc_rows.data_ptr() if bc_table is not None else None,
+                  _lib.stream_ptr())
+
+    def sample(self, replay, expert=None, bc_table=None, n_main=None, seed=0, sigma=0.2):
+        """Draw AND gather the next minibatch on the device (no host sync): UniformMemory.sample (buffer.py:38-48), the
+        buffer/expert mix and np.random.choice of HIRL.py:223-251, torch.normal(0, 0.2) of HIRL.py:265."""
+        B = self.batch
+        self.sample_calls += 1
+        _lib.call("hx_sample_batch", replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(),
+                  expert.ring.data_ptr() if expert is not None else None, len_of(expert), _lib.ptr(bc_table),
+                  bc_table.shape[0] if bc_table is not None else 0, B, B if n_main is None else int(n_main), 1, int(seed),
+                  self.sample_calls, float(sigma), self._idx.data_ptr(), self._idx_bc.data_ptr() if bc_table is not None else None,
+                  self._noise.data_ptr(), self.rows.data_ptr(), self.bc_rows.data_ptr() if bc_table is not None else None, _lib.stream_ptr())
+        return self._idx, self._idx_bc, self._noise
+
+    def learn(self, noise=None, bc_weight_now=0.0, bc_warm_up_weight=0.0):
+        """One Agent.learn (HIRL.py:221-334 / TD3.py:201-260) on the minibatch last assembled by sample() / assemble().
+        noise: the (4,) target-smoothing draw (default: the one sample() drew).  bc_weight_now: 100 = estimate the soft
+        weight now (HIRL.py:299), None = keep the stored device value, else the given weight.  Enqueues only; read the
+        results with losses_host()."""
         B = self.batch
         st = _lib.stream_ptr()
-        n_main = B if n_main is None else int(n_main)
-        batch = HxBatch(ring.data_ptr(), _lib.ptr(expert_ring) or ring.data_ptr(), idx.data_ptr(), n_main, B,
-                        _lib.ptr(bc_table) or ring.data_ptr(), _lib.ptr(idx_bc) or idx.data_ptr(), noise.data_ptr())
+        noise = self._noise if noise is None else noise
+        batch = HxBatch(self.rows.data_ptr(), self.bc_rows.data_ptr() if self.use_bc else None, B, noise.data_ptr())
         nets, hyper = ctypes.byref(self.nets), ctypes.byref(self.hyper)
         gs = 1.0 / self.world
         _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, st)
@@ -185,21 +220,6 @@ class HirlEngine:
             if self.update_count % self.target_update_freq == 0:  # HIRL.py:327-330
                 _lib.call("hx_polyak", nets, hyper, st)
         self.actor_trainable = not self.actor_trainable  # HIRL.py:332
-
-    def sample(self, replay, expert_len=0, bc_len=0, n_main=None, seed=0, sigma=0.2):
-        """Draw idx / idx_bc / noise for the next learn() on the device (no host sync): UniformMemory.sample
-        (buffer.py:38-48), np.random.choice (HIRL.py:249), torch.normal(0, 0.2) (HIRL.py:265)."""
-        B = self.batch
-        if not hasattr(self, "_idx"):
-            self._idx = torch.zeros(B, dtype=torch.int32, device=self.device)
-            self._idx_bc = torch.zeros(B, dtype=torch.int32, device=self.device)
-            self._noise = torch.zeros(4, dtype=torch.float32, device=self.device)
-            self.sample_calls = 0
-        self.sample_calls += 1
-        _lib.call("hx_sample_batch", replay.total.data_ptr(), replay.capacity, int(expert_len), int(bc_len), B,
-                  B if n_main is None else int(n_main), int(seed), self.sample_calls, float(sigma), self._idx.data_ptr(),
-                  self._idx_bc.data_ptr() if bc_len else None, self._noise.data_ptr(), _lib.stream_ptr())
-        return self._idx, self._idx_bc, self._noise
 
     def losses_host(self):
         """(critic_loss, actor_loss, bc_loss, rl_loss, bc_fire_loss, bc_weight) — HIRL.py:334.  Synchronises."""

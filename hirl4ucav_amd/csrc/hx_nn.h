@@ -115,6 +115,58 @@ __device__ __forceinline__ v4f tile_a_lds_b_global(const float* __restrict__ a_l
     return acc;
 }
 
+
+// ---- register-resident B fragments: issued at kernel entry so that their L2/HBM latency overlaps the prologue ------
+template <int K>
+struct BtFrag {  // for tile_a_lds_bt_global's operand: K/16 float4 per lane
+    float4 v[K / 16];
+    __device__ __forceinline__ void load(const float* __restrict__ bt_row) {
+        const int g = (threadIdx.x & 63) >> 4;
+#pragma unroll
+        for (int i = 0; i < K / 16; ++i) v[i] = *reinterpret_cast<const float4*>(bt_row + 4 * g + 16 * i);
+    }
+};
+template <int K>
+__device__ __forceinline__ v4f tile_a_lds_bt_frag(const float* __restrict__ a_lds, int lda, const BtFrag<K>& f, v4f acc) {
+    const int l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+    const float* ap = a_lds + r * lda + 4 * g;
+#pragma unroll
+    for (int i = 0; i < K / 16; ++i) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * i);
+        acc = mfma16(a4.x, f.v[i].x, acc);
+        acc = mfma16(a4.y, f.v[i].y, acc);
+        acc = mfma16(a4.z, f.v[i].z, acc);
+        acc = mfma16(a4.w, f.v[i].w, acc);
+    }
+    return acc;
+}
+template <int K>
+struct BFrag {  // for tile_a_lds_b_global's operand: one dword per MFMA
+    float v[K / 4];
+    __device__ __forceinline__ void load(const float* __restrict__ b_col, int ldb) {
+        const int g = (threadIdx.x & 63) >> 4;
+        const float* bp = b_col + (size_t)(4 * g) * ldb;
+#pragma unroll
+        for (int i = 0; i < K / 16; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * i + j] = bp[(size_t)(16 * i + j) * ldb];
+    }
+};
+template <int K>
+__device__ __forceinline__ v4f tile_a_lds_b_frag(const float* __restrict__ a_lds, int lda, const BFrag<K>& f, v4f acc) {
+    const int l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+    const float* ap = a_lds + r * lda + 4 * g;
+#pragma unroll
+    for (int i = 0; i < K / 16; ++i) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * i);
+        acc = mfma16(a4.x, f.v[4 * i], acc);
+        acc = mfma16(a4.y, f.v[4 * i + 1], acc);
+        acc = mfma16(a4.z, f.v[4 * i + 2], acc);
+        acc = mfma16(a4.w, f.v[4 * i + 3], acc);
+    }
+    return acc;
+}
+
 // two-pass LayerNorm statistics of one row spread over a wave: each lane holds PER values
 template <int PER>
 __device__ __forceinline__ void row_stats(const float (&v)[PER], int n, float& mean, float& rstd) {

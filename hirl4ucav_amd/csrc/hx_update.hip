@@ -25,6 +25,19 @@
 
 using namespace hxnn;
 
+// In-kernel phase stamps for diagnosis only (make STAMPS=1): s_memrealtime ticks (10 ns) between phases of ONE
+// workgroup land in hx_dbg; the shipped build compiles them out.
+#ifdef HX_STAMPS
+__device__ float hx_dbg[64];
+#define STAMP_DECL unsigned long long TS_[10]; int tsn_ = 0
+#define STAMP() TS_[tsn_++] = __builtin_amdgcn_s_memrealtime()
+#define STAMP_FLUSH(base, cond) do { if (cond) { for (int i_ = 1; i_ < tsn_; ++i_) hx_dbg[(base) + i_] = (float)(TS_[i_] - TS_[i_ - 1]); hx_dbg[(base)] = (float)tsn_; } } while (0)
+#else
+#define STAMP_DECL
+#define STAMP()
+#define STAMP_FLUSH(base, cond)
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -155,11 +168,12 @@ __device__ __forceinline__ int tiles_of(int rows) { return (rows + RT - 1) / RT;
 template <bool WIDE>
 __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
     constexpr int NTW = WIDE ? 256 : kNT;
-    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2 + 3 * 4 * 256];
+    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2 + 3 * 4 * 256 + H1 * 17];
     float* h1s = lds;
     float* xs = lds + RT * LDA1;
     float* sts = xs + RT * XP;
-    float* kred = sts + RT * 2;  // [3 K-quarters][4 column tiles][64 lanes][4]
+    float* kred = sts + RT * 2;   // [3 K-quarters][4 column tiles][64 lanes][4]
+    float* w1s = kred + 3 * 4 * 256;  // W1 [256][in], staged with coalesced loads (a per-thread row walk is 17 scattered requests)
 
     // which job / row tile / column tile
     int b = blockIdx.x, j = 0;
@@ -180,10 +194,24 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float slope = A.slope;
     const int in = J.m.in;
+    // operands that do not depend on the prologue are requested first: their latency hides behind the gather
+    BtFrag<H1 / 4> bfrag;
+    if (!WIDE) bfrag.load(J.net + J.m.W2() + (size_t)(nt * kNT + (wave & 3) * 16 + (lane & 15)) * H1 + (wave >> 2) * (H1 / 4));
+    const int u = tid & (H1 - 1), rq = (tid >> 8) * 4;
+    STAMP_DECL;
+    STAMP();
+    {
+        const float4* W1v = reinterpret_cast<const float4*>(J.net + J.m.W1());
+        const int n4 = H1 * in / 4;  // 832 or 1088 float4
+        for (int e = tid; e < n4; e += kWide) reinterpret_cast<float4*>(w1s)[e] = W1v[e];
+    }
+    const float bias1 = J.net[J.m.b1() + u], g1v = J.net[J.m.g1() + u], be1v = J.net[J.m.be1() + u];
 
     // 1. input tile xs[16][XP]
+    STAMP();
     if (tid < RT * XP) xs[tid] = 0.0f;
     __syncthreads();
+    STAMP();
     if (tid < RT * 13) {
         const int r = tid / 13, c = tid % 13;
         if (r < nrow) xs[r * XP + c] = src_row(J.src, r0 + r)[J.col0 + c];
@@ -216,17 +244,16 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
         }
     }
     __syncthreads();
+    STAMP();
 
     // 2. z1[r][u] = b1[u] + sum_i x[r][i] W1[u][i]: hidden unit u = tid & 255, rows 4*(tid >> 8) .. +3
-    const int u = tid & (H1 - 1), rq = (tid >> 8) * 4;
     float z1[4];
     {
-        const float* W1 = J.net + J.m.W1() + u * in;
-        const float bias = J.net[J.m.b1() + u];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z1[r] = bias;
+        for (int r = 0; r < 4; ++r) z1[r] = bias1;
+        const float* wrow = w1s + u * in;  // bank (17 u + i) % 32: conflict-free
         for (int i = 0; i < in; ++i) {
-            const float w = W1[i];
+            const float w = wrow[i];
 #pragma unroll
             for (int r = 0; r < 4; ++r) z1[r] += xs[(rq + r) * XP + i] * w;
         }
@@ -234,6 +261,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
         for (int r = 0; r < 4; ++r) h1s[(rq + r) * LDA1 + u] = z1[r];
     }
     __syncthreads();
+    STAMP();
     // 3. LN1 statistics: wave w owns row w
     {
         float v[4];
@@ -247,9 +275,10 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
         }
     }
     __syncthreads();
+    STAMP();
     // 4. h1 = act(LN1(z1))
     {
-        const float g = J.net[J.m.g1() + u], be = J.net[J.m.be1() + u];
+        const float g = g1v, be = be1v;
         const bool save = J.save && nt == 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -267,6 +296,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
         }
     }
     __syncthreads();
+    STAMP();
     // 5. z2 tile on fp32 MFMA
     if (WIDE) {
         const int n0 = nt * NTW + wave * 16;
@@ -285,7 +315,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
         const int n0 = nt * kNT + ct * 16;
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_a_lds_bt_global<H1 / 4>(h1s + kq * (H1 / 4), LDA1, J.net + J.m.W2() + (size_t)(n0 + r) * H1 + kq * (H1 / 4), acc);
+        acc = tile_a_lds_bt_frag<H1 / 4>(h1s + kq * (H1 / 4), LDA1, bfrag, acc);
         if (kq) *reinterpret_cast<float4*>(kred + (((kq - 1) * 4 + ct) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         __syncthreads();
         if (kq == 0) {
@@ -297,6 +327,8 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
                 if (row < nrow) J.ws.z2[(size_t)(r0 + row) * H2 + n0 + r] = v + bias;
             }
         }
+        STAMP();
+        STAMP_FLUSH(0, blockIdx.x == 5 && tid == 0);
     }
 }
 
@@ -403,6 +435,11 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float slope = A.slope;
     const bool lead = nt == 0;  // the column-tile-0 workgroup of a row tile also publishes dz2 / st2 / dout / losses
+    // this wave's W2 fragment (column tile wave & 3, K quarter wave >> 2): requested now, consumed after the prologue
+    STAMP_DECL;
+    STAMP();
+    BFrag<H2 / 4> bfrag;
+    bfrag.load(J.net + J.m.W2() + (size_t)((wave >> 2) * (H2 / 4)) * H1 + nt * kNT + (wave & 3) * 16 + (lane & 15), H1);
 
     float part[4] = {0.f, 0.f, 0.f, 0.f};  // per-wave loss partials
     int cnt = 0;
@@ -521,6 +558,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
             }
         }
     }
+    STAMP();
     if (lead && lane == 0) {
         red[wave][0] = part[0]; red[wave][1] = part[1]; red[wave][2] = part[2]; red[wave][3] = part[3];
         if (cnt) atomicAdd(A.soft_count, cnt);
@@ -538,15 +576,17 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
             atomicAdd(&A.losses[4], p1);
         }
     }
+    STAMP();
     // dh1 tile on fp32 MFMA: wave = (column tile ct, K quarter kq), K = 512; W2 is [512][256] row-major = B[k][n]
     {
         const int ct = wave & 3, kq = wave >> 2;
         const int n0 = nt * kNT + ct * 16;
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_a_lds_b_global<H2 / 4>(dz2s + kq * (H2 / 4), LDA2, J.net + J.m.W2() + (size_t)(kq * (H2 / 4)) * H1 + n0 + r, H1, acc);
+        acc = tile_a_lds_b_frag<H2 / 4>(dz2s + kq * (H2 / 4), LDA2, bfrag, acc);
         if (kq) *reinterpret_cast<float4*>(kred + (((kq - 1) * 4 + ct) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         __syncthreads();  // partial tiles visible; dz2s is dead from here on
+        STAMP();
         float* ps = dz2s;  // reused as [4 column tiles][16 rows][2]
         if (kq == 0) {
             // epilogue: store dh1 and this tile's share of the LN1-backward row sums (consumed by wgrad / the actor's
@@ -577,6 +617,8 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
             const float v = (ps[tid] + ps[RT * 2 + tid]) + (ps[2 * RT * 2 + tid] + ps[3 * RT * 2 + tid]);
             J.ws.lnp[(size_t)(r0 + (tid >> 1)) * 8 + nt * 2 + (tid & 1)] = v;
         }
+        STAMP();
+        STAMP_FLUSH(16, blockIdx.x == 3 && tid == 0);
     }
 }
 
@@ -610,7 +652,7 @@ __device__ __forceinline__ float effective_w(int kind, float given, float warm, 
     return w > 1.0f ? 1.0f : w;  // HIRL.py:308
 }
 
-constexpr int kWgTilesPerBlock = (H2 / 64) * (H1 / 64);  // 32 dW2 tiles of 64 x 64
+constexpr int kWgTilesPerBlock = (H2 / 16) * (H1 / 64);  // 128 workgroups: 16 (n) x 64 (k) of dW2, one 16 x 16 tile per wave
 constexpr int kWgVecWgs = H2 / 64;                       // 8 workgroups: 64 columns x 4 row groups, 512-wide vector gradients
 constexpr int kWgL1Wgs = H1 / 64;                        // 4 workgroups: layer-1 gradients
 constexpr int kWgPerJob = kWgTilesPerBlock + kWgVecWgs + kWgL1Wgs;
@@ -632,40 +674,33 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
     for (int s = 0; s < 2; ++s) scale[s] = J.wmode[s] == 0 ? 1.0f : (J.wmode[s] == 1 ? 1.0f - w : w);
 
     if (b < kWgTilesPerBlock) {
-        // dW2[n][k] = sum_r scale dz2[r][n] h1[r][k]: 64 x 64 tile, wave = 16 rows (n) x 64 columns (k)
-        const int n0 = (b / (H1 / 64)) * 64 + wave * 16, k0 = (b % (H1 / 64)) * 64;
+        // dW2[n][k] = sum_r scale dz2[r][n] h1[r][k].  Wave tile 16 (n) x 16 (k); the reduction runs over the batch rows,
+        // 16 per MFMA group.  All operands of a 128-row chunk (32 + 32 dwords per lane) are requested before the first
+        // MFMA: with B = 128 the whole job is one round trip to L2 instead of one per 16 rows.
+        const int n0 = (b / (H1 / 64)) * 16, k0 = (b % (H1 / 64)) * 64 + wave * 16;
         const int r = lane & 15, g = lane >> 4;
-        v4f acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < J.nslots; ++s) {
             const float sc = scale[s];
             const float* dz = J.ws[s].dz2 + n0 + r;
             const float* h1 = J.ws[s].h1 + k0 + r;
             const int rows = J.rows[s];
-#pragma unroll 2
-            for (int bb = 0; bb < rows; bb += 16) {
-                float av[4], hv[4][4];
+            for (int c0 = 0; c0 < rows; c0 += 128) {
+                float av[32], hv[32];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = bb + 4 * q + g;  // MFMA q reduces over rows bb+4q .. bb+4q+3 (one per lane group)
+                for (int i = 0; i < 32; ++i) {
+                    const int row = c0 + 4 * i + g;  // MFMA i reduces over rows c0+4i .. c0+4i+3 (one per lane group)
                     const bool ok = row < rows;
-                    av[q] = ok ? dz[(size_t)row * H2] : 0.0f;
-                    const float* hp = h1 + (size_t)row * H1;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) hv[q][t] = ok ? hp[t * 16] : 0.0f;
+                    av[i] = ok ? dz[(size_t)row * H2] : 0.0f;
+                    hv[i] = ok ? h1[(size_t)row * H1] : 0.0f;
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = mfma16(av[q] * sc, hv[q][t], acc[t]);
+                for (int i = 0; i < 32; ++i) acc = mfma16(av[i] * sc, hv[i], acc);
             }
         }
         float* out = J.grad + J.m.W2();
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) out[(size_t)(n0 + 4 * g + q) * H1 + k0 + t * 16 + r] = acc[t][q];
+        for (int q = 0; q < 4; ++q) out[(size_t)(n0 + 4 * g + q) * H1 + k0 + r] = acc[q];
         return;
     }
     const int rg = wave;  // row group: rows rg, rg + 4, ...
@@ -690,20 +725,32 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
                     rinfo[e * 8 + 2] = d4.x; rinfo[e * 8 + 3] = d4.y; rinfo[e * 8 + 4] = d4.z; rinfo[e * 8 + 5] = d4.w;
                 }
                 __syncthreads();
-#pragma unroll 4
-                for (int r = rg; r < nr; r += 4) {
-                    const float* ri = rinfo + r * 8;
-                    const float xh = (S.z2[(size_t)(c0 + r) * H2 + n] - ri[0]) * ri[1];
-                    const float dz = S.dz2[(size_t)(c0 + r) * H2 + n];
-                    const float y = g2 * xh + be2;
-                    const float dh2 = (ri[2] * w3[0] + ri[3] * w3[1]) + (ri[4] * w3[2] + ri[5] * w3[3]);
-                    const float dy = dh2 * act_d(y, slope);
-                    const float h2 = act_f(y, slope);
-                    db2 += sc * dz;
-                    dbe += sc * dy;
-                    dg += sc * dy * xh;
+                for (int rb = rg; rb < nr; rb += 64) {  // 16 rows per thread per block, all loads in flight together
+                    float zv[16], dv[16];
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) dw3[jj] += sc * ri[2 + jj] * h2;
+                    for (int i = 0; i < 16; ++i) {
+                        const int r = rb + 4 * i;
+                        const bool ok = r < nr;
+                        zv[i] = ok ? S.z2[(size_t)(c0 + r) * H2 + n] : 0.0f;
+                        dv[i] = ok ? S.dz2[(size_t)(c0 + r) * H2 + n] : 0.0f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int r = rb + 4 * i;
+                        if (r < nr) {
+                            const float* ri = rinfo + r * 8;
+                            const float xh = (zv[i] - ri[0]) * ri[1];
+                            const float y = g2 * xh + be2;
+                            const float dh2 = (ri[2] * w3[0] + ri[3] * w3[1]) + (ri[4] * w3[2] + ri[5] * w3[3]);
+                            const float dy = dh2 * act_d(y, slope);
+                            const float h2 = act_f(y, slope);
+                            db2 += sc * dv[i];
+                            dbe += sc * dy;
+                            dg += sc * dy * xh;
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) dw3[jj] += sc * ri[2 + jj] * h2;
+                        }
+                    }
                 }
                 if (vb == 0 && tid < J.m.out)
                     for (int r = 0; r < nr; ++r) db3 += sc * rinfo[r * 8 + 2 + tid];
@@ -748,18 +795,31 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
                     rinfo[e * 8 + 3] = ((lp[1] + lp[3]) + (lp[5] + lp[7])) * (1.0f / H1);
                 }
                 __syncthreads();
-#pragma unroll 2
-                for (int r = rg; r < nr; r += 4) {
-                    const float* ri = rinfo + r * 8;
-                    const float xh = (S.z1[(size_t)(c0 + r) * H1 + k] - ri[0]) * ri[1];
-                    const float dy = S.dh1[(size_t)(c0 + r) * H1 + k] * act_d(g1 * xh + be1, slope);
-                    const float dz = sc * (ri[1] * (dy * g1 - ri[2] - xh * ri[3]));
-                    db1 += dz;
-                    dbe += sc * dy;
-                    dg += sc * dy * xh;
-                    const float* xr = xs + r * XP;
+                for (int rb = rg; rb < nr; rb += 64) {
+                    float zv[16], dv[16];
 #pragma unroll
-                    for (int i = 0; i < 17; ++i) dw1[i] += dz * xr[i];
+                    for (int i = 0; i < 16; ++i) {
+                        const int r = rb + 4 * i;
+                        const bool ok = r < nr;
+                        zv[i] = ok ? S.z1[(size_t)(c0 + r) * H1 + k] : 0.0f;
+                        dv[i] = ok ? S.dh1[(size_t)(c0 + r) * H1 + k] : 0.0f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int r = rb + 4 * i;
+                        if (r < nr) {
+                            const float* ri = rinfo + r * 8;
+                            const float xh = (zv[i] - ri[0]) * ri[1];
+                            const float dy = dv[i] * act_d(g1 * xh + be1, slope);
+                            const float dz = sc * (ri[1] * (dy * g1 - ri[2] - xh * ri[3]));
+                            db1 += dz;
+                            dbe += sc * dy;
+                            dg += sc * dy * xh;
+                            const float* xr = xs + r * XP;
+#pragma unroll
+                            for (int ii = 0; ii < 17; ++ii) dw1[ii] += dz * xr[ii];
+                        }
+                    }
                 }
             }
         }
@@ -843,52 +903,85 @@ struct SampleArgs {
     int* idx;
     int* idx_bc;
     float* noise;
+    // gather: the sampled rows are copied ONCE into compact [batch][32] tiles that every update kernel then reads with
+    // plain row addressing (no index indirection, no page-scattered loads on their critical paths)
+    const float* ring;
+    const float* expert_ring;
+    const float* bc_table;
+    float* rows;
+    float* bc_rows;
+    int do_sample;  // 0: idx / idx_bc are inputs (parity tests, the N = 1 facade), only gather
 };
 
+// 1024 threads: thread (t = tid & 127.., part) — the all-pairs duplicate check of a 128-row group is spread over 8
+// threads per row (a lone wave retires about one instruction per 8 cycles, so serial scans are what cost time here).
 __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
     __shared__ __attribute__((aligned(16))) int cand[1024];
-    const int t = threadIdx.x;
-    const unsigned long long tot = *A.total;
-    const uint32_t len_main = (uint32_t)(tot < (unsigned long long)A.cap ? tot : (unsigned long long)A.cap);
-    const uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
-    for (int stream = 0; stream < 2; ++stream) {  // 0: replay / expert rows, 1: BC rows
-        int* out = stream == 1 ? A.idx_bc : A.idx;
-        if (!out) continue;
-        const bool main_grp = t < A.n_main;
-        const uint32_t len = stream == 1 ? (uint32_t)A.bc_len : (main_grp ? len_main : (uint32_t)A.expert_len);
-        const int lo = (stream == 1 || main_grp) ? 0 : A.n_main;  // groups: [0, n_main) and [n_main, batch)
-        int v = 0;
-        bool dup = t < A.batch;
-        for (int round = 0; round < 128; ++round) {
-            if (dup) {
-                uint32_t u[4];
-                philox4x32_10((uint32_t)t, A.call, (uint32_t)stream, (uint32_t)round, k0, k1, u);
-                v = len ? (int)__umulhi(u[0], len) : 0;
-            }
-            cand[t] = v;
-            __syncthreads();
-            dup = false;
-            if (t < A.batch) {  // any earlier member of my group with the same index?  16-B LDS reads, 4 compares each
-                const int4* c4 = reinterpret_cast<const int4*>(cand);
-#pragma unroll 8
-                for (int s4 = lo >> 2; s4 <= (t >> 2); ++s4) {
-                    const int4 c = c4[s4];
-                    const int s = s4 * 4;
-                    dup |= (c.x == v && s >= lo && s < t) | (c.y == v && s + 1 >= lo && s + 1 < t) |
-                           (c.z == v && s + 2 >= lo && s + 2 < t) | (c.w == v && s + 3 >= lo && s + 3 < t);
+    __shared__ int dupf[1024];
+    const int tid = threadIdx.x;
+    const int B = A.batch;
+    const int parts = 1024 / ((B + 63) / 64 * 64) > 0 ? 1024 / ((B + 63) / 64 * 64) : 1;  // threads per row
+    const int t = tid / parts, part = tid % parts;
+    if (A.do_sample) {
+        const unsigned long long tot = *A.total;
+        const uint32_t len_main = (uint32_t)(tot < (unsigned long long)A.cap ? tot : (unsigned long long)A.cap);
+        const uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
+        for (int stream = 0; stream < 2; ++stream) {  // 0: replay / expert rows, 1: BC rows
+            int* out = stream == 1 ? A.idx_bc : A.idx;
+            if (!out) continue;
+            const bool main_grp = t < A.n_main;
+            const uint32_t len = stream == 1 ? (uint32_t)A.bc_len : (main_grp ? len_main : (uint32_t)A.expert_len);
+            const int lo = (stream == 1 || main_grp) ? 0 : A.n_main;  // groups: [0, n_main) and [n_main, batch)
+            int v = 0;
+            bool dup = t < B;
+            for (int round = 0; round < 128; ++round) {
+                if (dup) {
+                    uint32_t u[4];
+                    philox4x32_10((uint32_t)t, A.call, (uint32_t)stream, (uint32_t)round, k0, k1, u);
+                    v = len ? (int)__umulhi(u[0], len) : 0;
                 }
+                if (part == 0 && t < B) {
+                    cand[t] = v;
+                    dupf[t] = 0;
+                }
+                __syncthreads();
+                if (t < B) {  // my slice of the earlier members of my group
+                    const int span = (B + parts - 1) / parts;
+                    const int s0 = max(lo, part * span), s1 = min(t, (part + 1) * span);
+                    bool d = false;
+                    for (int s = s0; s < s1; ++s) d |= cand[s] == v;
+                    if (d) dupf[t] = 1;
+                }
+                __syncthreads();
+                dup = t < B && dupf[t] != 0;
+                if (!__syncthreads_or(dup)) break;  // nobody redraws: done (the common case after the first round)
             }
-            if (!__syncthreads_or(dup)) break;  // nobody redraws: done (the common case after the first round)
+            if (part == 0 && t < B) out[t] = v;
+            __syncthreads();
         }
-        if (t < A.batch) out[t] = v;
+        if (tid < 4 && A.noise) {
+            uint32_t u[4];
+            philox4x32_10(0xFFFFFFF0u, A.call, 2u, 0u, k0, k1, u);
+            const float ua = u01(u[tid & 2]), ub = u01(u[(tid & 2) + 1]);
+            const float rad = sqrtf(-2.0f * __logf(ua)), ang = 6.28318530717958647692f * ub;
+            A.noise[tid] = A.sigma * ((tid & 1) ? rad * __sinf(ang) : rad * __cosf(ang));
+        }
+        __threadfence_block();
         __syncthreads();
     }
-    if (t < 4 && A.noise) {
-        uint32_t u[4];
-        philox4x32_10(0xFFFFFFF0u, A.call, 2u, 0u, k0, k1, u);
-        const float ua = u01(u[t & 2]), ub = u01(u[(t & 2) + 1]);
-        const float rad = sqrtf(-2.0f * logf(ua)), ang = 6.28318530717958647692f * ub;
-        A.noise[t] = A.sigma * ((t & 1) ? rad * sinf(ang) : rad * cosf(ang));
+    // gather: 8 lanes per row, one 16-B piece each
+    if (A.rows) {
+        for (int e = tid; e < B * 8; e += 1024) {
+            const int r = e >> 3, c = e & 7;
+            const float* src = (r < A.n_main ? A.ring : A.expert_ring) + (size_t)A.idx[r] * 32;
+            reinterpret_cast<float4*>(A.rows)[e] = reinterpret_cast<const float4*>(src)[c];
+        }
+    }
+    if (A.bc_rows && A.bc_table && A.idx_bc) {
+        for (int e = tid; e < B * 8; e += 1024) {
+            const int r = e >> 3, c = e & 7;
+            reinterpret_cast<float4*>(A.bc_rows)[e] = reinterpret_cast<const float4*>(A.bc_table + (size_t)A.idx_bc[r] * 32)[c];
+        }
     }
 }
 
@@ -942,6 +1035,15 @@ const Mlp kQ{17, 1};
 
 extern "C" {
 
+/* diagnostic builds only (make STAMPS=1): copy the 64 phase-stamp floats to host memory; returns -1 otherwise */
+int hx_debug_stamps(float* host_out) {
+#ifdef HX_STAMPS
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(hx_dbg), 64 * sizeof(float)) == hipSuccess ? 0 : -2;
+#else
+    (void)host_out;
+    return -1;
+#endif
+}
 int hx_actor_param_count(void) { return kActor.size(); }
 int hx_critic_param_count(void) { return 2 * kQ.padded(); }
 int64_t hx_hirl_workspace_floats(int32_t batch) { return (int64_t)S_COUNT * kSlotFloats * batch + 64; }
@@ -981,7 +1083,7 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
     const int B = Bt->batch;
     Slot s[S_COUNT];
     make_slots(N, B, s);
-    const RowSrc src{Bt->ring, Bt->expert_ring, Bt->idx, Bt->n_main, 32};
+    const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
     const float* tc1 = N->target_critic;
     const float* tc2 = N->target_critic + kQ.padded();
     {   // launch A: targetActor(s'), critic Q1/Q2 (s, a)
@@ -1062,8 +1164,8 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
     const int B = Bt->batch;
     Slot s[S_COUNT];
     make_slots(N, B, s);
-    const RowSrc src{Bt->ring, Bt->expert_ring, Bt->idx, Bt->n_main, 32};
-    const RowSrc bcsrc{Bt->bc_table, Bt->bc_table, Bt->idx_bc, B, 32};
+    const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
+    const RowSrc bcsrc{Bt->bc_rows ? Bt->bc_rows : Bt->rows, nullptr, nullptr, 0, 32};
     const bool bc = Hy->use_bc != 0, soft = bc && estimate_soft;
     {   // launch F: actor(s), actor(s_bc), bc_actor(s)
         FwdArgs F{};
@@ -1141,15 +1243,22 @@ int hx_hirl_actor_wgrad(const HxNets* N, const HxHyper* Hy, int32_t batch, int32
 }
 
 
-/* Device-side minibatch draw for one learn() call: idx[batch] (rows < n_main index the main ring, whose current length
- * min(*total, cap) is read on the device; the rest index the expert ring), idx_bc[batch] into the BC table, noise[4] =
- * sigma * N(0, 1) (the ONE target-smoothing draw of HIRL.py:265).  Replaces random.sample (buffer.py:45) and
- * np.random.choice(replace=False) (HIRL.py:249).  batch <= 1024. */
-int hx_sample_batch(const uint64_t* total, int64_t cap, int64_t expert_len, int64_t bc_len, int32_t batch, int32_t n_main,
-                    uint64_t seed, uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc, float* noise, void* stream) {
-    HX_REQUIRE(total && idx && batch > 0 && batch <= 1024 && n_main >= 0 && n_main <= batch && cap > 0, "hx_sample_batch: bad arguments");
-    SampleArgs A{(const unsigned long long*)total, cap, expert_len, bc_len, batch, n_main, seed, call, sigma, idx, idx_bc, noise};
-    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3((unsigned)((batch + 63) / 64 * 64)), 0, (hipStream_t)stream, A);
+/* Minibatch assembly for one learn() call (replaces UniformMemory.sample buffer.py:38-48, the buffer/expert mixing and the
+ * BC draw of HIRL.py:223-251, and the noise draw HIRL.py:265).  do_sample = 1: draw idx[batch] (rows < n_main index the main
+ * ring, whose live length min(*total, cap) is read on the device; the rest the expert ring), idx_bc[batch], noise[4] =
+ * sigma N(0,1) with Philox4x32-10(seed; row, call), without replacement inside each group.  do_sample = 0: idx / idx_bc are
+ * inputs.  Either way the selected rows are then copied into the compact tiles rows[batch][32] / bc_rows[batch][32] that
+ * the update stages read. */
+int hx_sample_batch(const uint64_t* total, int64_t cap, const float* ring, const float* expert_ring, int64_t expert_len,
+                    const float* bc_table, int64_t bc_len, int32_t batch, int32_t n_main, int32_t do_sample, uint64_t seed,
+                    uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc, float* noise, float* rows, float* bc_rows,
+                    void* stream) {
+    HX_REQUIRE(idx && ring && rows && batch > 0 && batch <= 1024 && n_main >= 0 && n_main <= batch, "hx_sample_batch: bad arguments");
+    HX_REQUIRE(!do_sample || (total && cap > 0), "hx_sample_batch: sampling needs total and cap");
+    HX_REQUIRE(n_main == batch || expert_ring, "hx_sample_batch: expert rows requested without an expert ring");
+    SampleArgs A{(const unsigned long long*)total, cap, expert_len, bc_len, batch, n_main, seed, call, sigma, idx, idx_bc, noise,
+                 ring, expert_ring ? expert_ring : ring, bc_table, rows, bc_rows, do_sample};
+    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
     HX_CHECK_LAUNCH("hx_sample_batch");
     return 0;
 }

@@ -171,9 +171,8 @@ def main(config):
                 break
             expert_num = expert_num_after(expert_num, step, warm_up_rate)
             for _ in range(config.updates_per_step):
-                idx, idx_bc, noise = eng.sample(replay, expert_len, bc_len, n_main=batch - expert_num, seed=seed + 2 + rank)
-                eng.learn(replay.ring, idx, noise, expert_ring=expert.ring if expert else None, n_main=batch - expert_num,
-                          bc_table=bc_table, idx_bc=idx_bc if hirl else None, bc_weight_now=w_now, bc_warm_up_weight=warm)
+                eng.sample(replay, expert, bc_table, n_main=batch - expert_num, seed=seed + 2 + rank)
+                eng.learn(bc_weight_now=w_now, bc_warm_up_weight=warm)
                 w_now = None  # afterwards learn()'s own returned weight is fed back (train_all.py:361): the stored device value
         if rank == 0:
             c, a, b, r_, f, w = eng.losses_host()

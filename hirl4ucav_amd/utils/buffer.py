@@ -33,6 +33,7 @@ class DeviceReplay:
         if success is not None:
             self.success[idx] = success.to(self.device, torch.int8)
         self.total += k
+        self.fixed_len = min(start + k, self.capacity)  # host-known live length (tables filled once: expert ring)
 
 
 # ---- reference-API façade -------------------------------------------------------------------------------------------

@@ -110,6 +110,7 @@ int hx_label_transitions(const float* s, const float* a, const float* ns, int64_
  * Actor = one block (in 13, out 4) = 138,756 floats; Critic = two blocks (in 17, out 1), each padded from 138,241
  * to 138,244 floats so that the second head stays 16-byte aligned (hx_critic_param_count() = 276,488).
  * ------------------------------------------------------------------------------------------------------------ */
+int hx_debug_stamps(float* host_out /* host, 64 floats */); /* diagnostic builds only; -1 in the shipped build */
 int hx_actor_param_count(void);
 int hx_critic_param_count(void);
 int64_t hx_hirl_workspace_floats(int32_t batch);
@@ -124,18 +125,14 @@ int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* acti
                  const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* ws,
                  void* stream);
 
-/* Minibatch of Agent.learn (HIRL.py:223-251).  Row r is ring[idx[r]] for r < n_main, expert_ring[idx[r]] otherwise
- * (buffer rows first, then expert rows); BC row r is bc_table[idx_bc[r]] (cols 0..12 state, 13..16 action).
- * All tables are [*][HX_ROW_WORDS] fp32. */
+/* Minibatch of Agent.learn (HIRL.py:223-251), already assembled by hx_sample_batch into compact row tiles:
+ * rows[batch][HX_ROW_WORDS] = s[13] a[4] s'[13] r done (buffer rows first, then expert rows, HIRL.py:229-233);
+ * bc_rows[batch][HX_ROW_WORDS]: cols 0..12 state, 13..16 action of the BC minibatch (HIRL.py:248-251; NULL for TD3). */
 typedef struct HxBatch {
-    const float* ring;
-    const float* expert_ring;
-    const int32_t* idx;   /* [batch] */
-    int32_t n_main;
-    int32_t batch;        /* multiple of 16 */
-    const float* bc_table;
-    const int32_t* idx_bc; /* [batch] */
-    const float* noise;   /* [4] target-smoothing noise, unclamped: ONE draw for the whole batch (HIRL.py:265) */
+    const float* rows;
+    const float* bc_rows;
+    int32_t batch;      /* multiple of 16 */
+    const float* noise; /* [4] target-smoothing noise, unclamped: ONE draw for the whole batch (HIRL.py:265) */
 } HxBatch;
 
 typedef struct HxNets {
@@ -175,14 +172,17 @@ int hx_adam(const HxNets* nets, const HxHyper* hyper, int32_t which, int32_t ste
             float w_given, float warm, int32_t batch, void* stream);
 int hx_polyak(const HxNets* nets, const HxHyper* hyper, void* stream);
 
-/* Device-side minibatch draw for one learn() call, replacing random.sample (hirl/utils/buffer.py:45, without
- * replacement) and np.random.choice(replace=False) (HIRL.py:249): idx[batch] (rows < n_main index the main ring, whose
- * current length min(*total, cap) is read on the device; the rest index the expert ring), idx_bc[batch] into the BC
- * table, noise[4] = sigma * N(0,1) — the ONE target-smoothing draw of HIRL.py:265.  Philox4x32-10(seed; row, call).
+/* Minibatch assembly for one learn() call: replaces UniformMemory.sample (hirl/utils/buffer.py:38-48, random.sample without
+ * replacement), the buffer/expert mixing and np.random.choice(replace=False) of HIRL.py:223-251, and the noise draw
+ * HIRL.py:265.  do_sample = 1: draws idx[batch] (rows < n_main index `ring`, whose live length min(*total, cap) is read on
+ * the device; the rest index `expert_ring`), idx_bc[batch] into bc_table, noise[4] = sigma N(0,1); Philox4x32-10(seed; row,
+ * call).  do_sample = 0: idx / idx_bc are inputs (caller-chosen minibatch).  Either way the selected rows are copied into the
+ * compact tiles rows[batch][32] and bc_rows[batch][32] (bc_table / idx_bc / bc_rows may be NULL) that HxBatch points at.
  * batch <= 1024. */
-int hx_sample_batch(const uint64_t* total, int64_t cap, int64_t expert_len, int64_t bc_len, int32_t batch,
-                    int32_t n_main, uint64_t seed, uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc,
-                    float* noise, void* stream);
+int hx_sample_batch(const uint64_t* total, int64_t cap, const float* ring, const float* expert_ring, int64_t expert_len,
+                    const float* bc_table, int64_t bc_len, int32_t batch, int32_t n_main, int32_t do_sample, uint64_t seed,
+                    uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc, float* noise, float* rows, float* bc_rows,
+                    void* stream);
 
 #ifdef __cplusplus
 }

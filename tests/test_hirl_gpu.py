@@ -173,8 +173,9 @@ def test_learn_matches_oracle_and_reference(eng_mod, mode, golden_dir):
         warm = float(g["warm_in"][k])
         was_actor_call = e.actor_trainable
         sync_oracle(o, e, eng_mod)
-        e.learn(ring, torch.from_numpy(idx).cuda(), torch.from_numpy(g["noise"][k]).cuda(), expert_ring=exp, n_main=128 - ne,
-                bc_table=bc, idx_bc=torch.from_numpy(g["idx_bc"][k].astype(np.int32)).cuda(), bc_weight_now=w_in, bc_warm_up_weight=warm)
+        e.assemble(ring, torch.from_numpy(idx).cuda(), expert_ring=exp, n_main=128 - ne, bc_table=bc,
+                   idx_bc=torch.from_numpy(g["idx_bc"][k].astype(np.int32)).cuda())
+        e.learn(noise=torch.from_numpy(g["noise"][k]).cuda(), bc_weight_now=w_in, bc_warm_up_weight=warm)
         got = e.losses_host()
         rows = data["replay"][g["idx_buf"][k]]
         if ne:
@@ -202,7 +203,8 @@ def test_td3_learn_matches_reference(eng_mod, golden_dir):
     for k in range(g["out"].shape[0]):
         was_actor_call = e.actor_trainable
         sync_oracle(o, e, eng_mod)
-        e.learn(ring, torch.from_numpy(g["idx_buf"][k].astype(np.int32)).cuda(), torch.from_numpy(g["noise"][k]).cuda())
+        e.assemble(ring, torch.from_numpy(g["idx_buf"][k].astype(np.int32)).cuda())
+        e.learn(noise=torch.from_numpy(g["noise"][k]).cuda())
         got = e.losses_host()
         rows = data["replay"][g["idx_buf"][k]]
         ref = o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), None, g["noise"][k])
@@ -231,8 +233,8 @@ def test_learn_ragged_batches_and_outlier_rows(eng_mod):
             noise = rng.normal(0, 0.2, 4).astype(np.float32)
             was_actor_call = e.actor_trainable
             sync_oracle(o, e, eng_mod)
-            e.learn(ring, torch.from_numpy(idx).cuda(), torch.from_numpy(noise).cuda(), bc_table=bc, idx_bc=torch.from_numpy(ibc).cuda(),
-                    bc_weight_now=100, bc_warm_up_weight=0.1)
+            e.assemble(ring, torch.from_numpy(idx).cuda(), bc_table=bc, idx_bc=torch.from_numpy(ibc).cuda())
+            e.learn(noise=torch.from_numpy(noise).cuda(), bc_weight_now=100, bc_warm_up_weight=0.1)
             rows = data["replay"][idx]
             ref = o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]),
                           (data["expert_s"][ibc], data["expert_a"][ibc]), noise, 100, 0.1)
@@ -245,26 +247,36 @@ def test_learn_ragged_batches_and_outlier_rows(eng_mod):
 
 def test_device_sampler(eng_mod):
     """hx_sample_batch: indices inside the live part of each table, no duplicates inside a group (random.sample /
-    np.random.choice(replace=False) semantics), deterministic per (seed, call), reads the ring length on the device."""
+    np.random.choice(replace=False) semantics), deterministic per (seed, call), ring length read on the device, and the
+    compact row tiles hold exactly the selected rows."""
     from hirl4ucav_amd.utils.buffer import DeviceReplay
 
     e = eng_mod.HirlEngine(batch=128)
+    rng = np.random.default_rng(0)
     rep = DeviceReplay(5000)
+    rep.ring.copy_(torch.from_numpy(rng.normal(size=(5000, 32)).astype(np.float32)))
     rep.total += 300  # only 300 rows are live
+    exp = DeviceReplay(210)
+    exp.store_rows(torch.from_numpy(rng.normal(size=(200, 32)).astype(np.float32)))
+    bc = torch.from_numpy(rng.normal(size=(150, 32)).astype(np.float32)).cuda()
     seen = []
     for call in range(50):
-        idx, idx_bc, noise = e.sample(rep, expert_len=200, bc_len=150, n_main=96, seed=9)
+        idx, idx_bc, noise = e.sample(rep, exp, bc, n_main=96, seed=9)
         i, b, z = idx.cpu().numpy(), idx_bc.cpu().numpy(), noise.cpu().numpy()
         assert i[:96].min() >= 0 and i[:96].max() < 300 and len(set(i[:96])) == 96
         assert i[96:].min() >= 0 and i[96:].max() < 200 and len(set(i[96:])) == 32
         assert b.min() >= 0 and b.max() < 150 and len(set(b)) == 128  # 128 of 150 without replacement
+        rows = e.rows.reshape(128, 32).cpu().numpy()
+        np.testing.assert_array_equal(rows[:96], rep.ring.cpu().numpy()[i[:96]])
+        np.testing.assert_array_equal(rows[96:], exp.ring.cpu().numpy()[i[96:]])
+        np.testing.assert_array_equal(e.bc_rows.reshape(128, 32).cpu().numpy(), bc.cpu().numpy()[b])
         seen.append((i.copy(), z.copy()))
     assert not np.array_equal(seen[0][0], seen[1][0])
     zs = np.stack([z for _, z in seen])
     assert abs(zs.mean()) < 0.08 and abs(zs.std() - 0.2) < 0.05
     e2 = eng_mod.HirlEngine(batch=128)
-    idx2, _, n2 = e2.sample(rep, expert_len=200, bc_len=150, n_main=96, seed=9)
+    idx2, _, n2 = e2.sample(rep, exp, bc, n_main=96, seed=9)
     assert np.array_equal(idx2.cpu().numpy(), seen[0][0]) and np.array_equal(n2.cpu().numpy(), seen[0][1])
     rep.total += 100000  # ring wrapped: the whole capacity is live
-    idx3, _, _ = e.sample(rep, expert_len=200, bc_len=150, n_main=128, seed=9)
+    idx3, _, _ = e.sample(rep, exp, bc, n_main=128, seed=9)
     assert idx3.max().item() >= 300 and idx3.max().item() < 5000

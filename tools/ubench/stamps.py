@@ -1,0 +1,18 @@
+"""Phase stamps of one fwd_l2 and one bwd_l2 workgroup (diagnostic build: make -C hirl4ucav_amd/csrc clean all STAMPS=1)."""
+import sys, ctypes, numpy as np, torch
+sys.path.insert(0, ".")
+import bench as B
+from hirl4ucav_amd import _lib
+from hirl4ucav_amd.agents.engine import HxBatch
+class A: envs=4096; batch=128; scenario="straight_line"
+loop = B.Loop(A, 0, 1, torch.device("cuda", 0))
+for _ in range(20): loop.step()
+e = loop.eng
+e.sample(loop.replay, loop.expert, loop.bc_table, n_main=128, seed=2)
+batch = HxBatch(e.rows.data_ptr(), e.bc_rows.data_ptr(), 128, e._noise.data_ptr())
+L = _lib.load(); out = np.zeros(64, np.float32)
+for i in range(3):
+    _lib.call("hx_hirl_critic_grads", ctypes.byref(e.nets), ctypes.byref(batch), ctypes.byref(e.hyper), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert L.hx_debug_stamps(out.ctypes.data_as(ctypes.c_void_p)) == 0
+    print("fwd (x10ns): W1 issue %d | zero+sync %d | gather+sync %d | z1 %d | stats %d | norm %d | mfma+store %d      bwd: prologue %d | red %d | mfma %d | epilogue %d" % tuple(out[1:8].tolist() + out[17:21].tolist()))
