@@ -39,6 +39,7 @@ _lib.register("hx_hirl_actor_backward", [_P(HxNets), _P(HxBatch), _P(HxHyper), _
 _lib.register("hx_hirl_actor_wgrad", [_P(HxNets), _P(HxHyper), _i32, _i32, _i32, _f32, _f32, _vp])
 _lib.register("hx_adam", [_P(HxNets), _P(HxHyper), _i32, _i32, _f32, _i32, _f32, _f32, _i32, _vp])
 _lib.register("hx_polyak", [_P(HxNets), _P(HxHyper), _vp])
+_lib.register("hx_hirl_learn", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp])
 _lib.register("hx_sample_batch", [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _i32, _i32, _i32, ctypes.c_uint64,
                                    ctypes.c_uint32, _f32, _vp, _vp, _vp, _vp, _vp, _vp])
 
@@ -197,28 +198,35 @@ class HirlEngine:
         noise = self._noise if noise is None else noise
         batch = HxBatch(self.rows.data_ptr(), self.bc_rows.data_ptr() if self.use_bc else None, B, noise.data_ptr())
         nets, hyper = ctypes.byref(self.nets), ctypes.byref(self.hyper)
-        gs = 1.0 / self.world
-        _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, st)
-        self._allreduce(self.grad_critic)
+        if bc_weight_now is None:
+            w_kind, w_given = 2, 0.0
+        elif bc_weight_now == 100:
+            w_kind, w_given = 1, 0.0
+        else:
+            w_kind, w_given = 0, float(bc_weight_now)
+        actor_phase = self.actor_trainable  # HIRL.py:291
         self.critic_step += 1
-        _lib.call("hx_adam", nets, hyper, 0, self.critic_step, gs, 0, 0.0, 0.0, B, st)
-        if self.actor_trainable:  # HIRL.py:291
-            if bc_weight_now is None:
-                w_kind, w_given = 2, 0.0
-            elif bc_weight_now == 100:
-                w_kind, w_given = 1, 0.0
-            else:
-                w_kind, w_given = 0, float(bc_weight_now)
-            _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, int(w_kind == 1), st)
-            if w_kind == 1:
-                self._allreduce(self.soft_count)
-            _lib.call("hx_hirl_actor_wgrad", nets, hyper, B, B * self.world, w_kind, w_given, float(bc_warm_up_weight), st)
-            self._allreduce(self.grad_actor)
+        if actor_phase:
             self.actor_step += 1
-            _lib.call("hx_adam", nets, hyper, 1, self.actor_step, gs, w_kind, w_given, float(bc_warm_up_weight), B * self.world, st)
             self.update_count += 1
-            if self.update_count % self.target_update_freq == 0:  # HIRL.py:327-330
-                _lib.call("hx_polyak", nets, hyper, st)
+        do_polyak = actor_phase and self.update_count % self.target_update_freq == 0  # HIRL.py:327-330
+        if self.world == 1:
+            _lib.call("hx_hirl_learn", nets, ctypes.byref(batch), hyper, self.critic_step, int(actor_phase), self.actor_step,
+                      int(do_polyak), w_kind, w_given, float(bc_warm_up_weight), st)
+        else:  # sharded: the same stages with the three exchanges of SURVEY.md 8e in between
+            gs = 1.0 / self.world
+            _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, st)
+            self._allreduce(self.grad_critic)
+            _lib.call("hx_adam", nets, hyper, 0, self.critic_step, gs, 0, 0.0, 0.0, B, st)
+            if actor_phase:
+                _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, int(w_kind == 1), st)
+                if w_kind == 1:
+                    self._allreduce(self.soft_count)
+                _lib.call("hx_hirl_actor_wgrad", nets, hyper, B, B * self.world, w_kind, w_given, float(bc_warm_up_weight), st)
+                self._allreduce(self.grad_actor)
+                _lib.call("hx_adam", nets, hyper, 1, self.actor_step, gs, w_kind, w_given, float(bc_warm_up_weight), B * self.world, st)
+                if do_polyak:
+                    _lib.call("hx_polyak", nets, hyper, st)
         self.actor_trainable = not self.actor_trainable  # HIRL.py:332
 
     def losses_host(self):

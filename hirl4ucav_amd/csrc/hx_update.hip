@@ -387,6 +387,133 @@ __global__ __launch_bounds__(kThreads) void act_head_kernel(ActArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// act_fused: the whole policy for 16 observation rows in ONE workgroup — layer 1 + LN1 (VALU), z2 = h1 W2^T for all 512
+// columns (two 16-column MFMA tiles per wave, K = 256), then LN2 + final layer + tanh + exploration noise + clamp with one
+// wave per row straight from the LDS copy of z2.  No z2 round trip through HBM, no second launch.
+// chooseAction / chooseActionSmallNoise / chooseActionNoNoise, HIRL.py:192-212.
+// ---------------------------------------------------------------------------------------------------------------
+struct ActFusedArgs {
+    const float* net;
+    Mlp m;
+    const float* obs;  // [rows][13]
+    int rows;
+    float slope;
+    float* actions;      // [rows][4]
+    const float* noise;  // nullptr, [4] (shared) or [rows][4]
+    int noise_per_row;
+    float sigma;
+    uint64_t seed;
+    uint32_t row0, call;
+};
+
+__global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
+    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * LDA2 + RT * XP + RT * 2 + H1 * 13];
+    float* h1s = lds;
+    float* z2s = h1s + RT * LDA1;
+    float* xs = z2s + RT * LDA2;
+    float* sts = xs + RT * XP;
+    float* w1s = sts + RT * 2;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * RT;
+    const int nrow = min(RT, A.rows - r0);
+    const float* net = A.net;
+    const Mlp m = A.m;
+    const float slope = A.slope;
+    const int u = tid & (H1 - 1), rq = (tid >> 8) * 4;
+    // all independent operands first
+    float xv = 0.0f;
+    if (tid < RT * 13) {
+        const int r = tid / 13;
+        if (r < nrow) xv = A.obs[(size_t)r0 * 13 + tid];  // the 16 x 13 tile is contiguous
+    }
+    float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < H1 * 13 / 4) wv = reinterpret_cast<const float4*>(net + m.W1())[tid];
+    const float bias1 = net[m.b1() + u], g1v = net[m.g1() + u], be1v = net[m.be1() + u];
+    if (tid < H1 * 13 / 4) reinterpret_cast<float4*>(w1s)[tid] = wv;
+    if (tid < RT * XP) xs[tid] = 0.0f;
+    __syncthreads();
+    if (tid < RT * 13) xs[(tid / 13) * XP + tid % 13] = xv;
+    __syncthreads();
+    float z1[4];
+    {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z1[r] = bias1;
+        const float* wrow = w1s + u * 13;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            const float w = wrow[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z1[r] += xs[(rq + r) * XP + i] * w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1s[(rq + r) * LDA1 + u] = z1[r];
+    }
+    __syncthreads();
+    {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = h1s[wave * LDA1 + i * 64 + lane];
+        float mean, rstd;
+        row_stats<4>(v, H1, mean, rstd);
+        if (lane == 0) {
+            sts[wave * 2] = mean;
+            sts[wave * 2 + 1] = rstd;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = rq + r;
+        h1s[row * LDA1 + u] = act_f(g1v * ((z1[r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
+    }
+    __syncthreads();
+    {   // z2 tiles: columns 16*wave .. and 256 + 16*wave ..
+        const int r = lane & 15, g = lane >> 4;
+        v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* ap = h1s + r * LDA1 + 4 * g;
+        const float* b0 = net + m.W2() + (size_t)(wave * 16 + r) * H1 + 4 * g;
+        const float* b1 = b0 + (size_t)256 * H1;
+#pragma unroll 4
+        for (int kk = 0; kk < H1; kk += 16) {
+            const float4 a4 = *reinterpret_cast<const float4*>(ap + kk);
+            const float4 p4 = *reinterpret_cast<const float4*>(b0 + kk);
+            const float4 q4 = *reinterpret_cast<const float4*>(b1 + kk);
+            acc0 = mfma16(a4.x, p4.x, acc0); acc1 = mfma16(a4.x, q4.x, acc1);
+            acc0 = mfma16(a4.y, p4.y, acc0); acc1 = mfma16(a4.y, q4.y, acc1);
+            acc0 = mfma16(a4.z, p4.z, acc0); acc1 = mfma16(a4.z, q4.z, acc1);
+            acc0 = mfma16(a4.w, p4.w, acc0); acc1 = mfma16(a4.w, q4.w, acc1);
+        }
+        const float bb0 = net[m.b2() + wave * 16 + r], bb1 = net[m.b2() + 256 + wave * 16 + r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            z2s[(4 * g + q) * LDA2 + wave * 16 + r] = acc0[q] + bb0;
+            z2s[(4 * g + q) * LDA2 + 256 + wave * 16 + r] = acc1[q] + bb1;
+        }
+    }
+    __syncthreads();
+    if (wave < nrow) {  // head: wave w owns row w
+        const int r = r0 + wave;
+        RowReg<H2> xh, y;
+        float mean, rstd, o[4];
+        head_row<4>(z2s + wave * LDA2, net, m, slope, xh, y, mean, rstd, o);
+        if (lane < 4) {
+            float a = tanhf(o[lane]);
+            if (A.noise) {
+                a = fminf(fmaxf(a + A.noise[(A.noise_per_row ? (size_t)r * 4 : 0) + lane], -1.0f), 1.0f);
+            } else if (A.sigma > 0.0f) {
+                uint32_t uu[4];
+                philox4x32_10(A.row0 + (uint32_t)r, A.call, 0x61637421u, 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), uu);
+                const float ua = u01(uu[lane & 2]), ub = u01(uu[(lane & 2) + 1]);
+                const float rad = sqrtf(-2.0f * logf(ua)), ang = 6.28318530717958647692f * ub;
+                const float n = (lane & 1) ? rad * sinf(ang) : rad * cosf(ang);
+                a = fminf(fmaxf(a + A.sigma * n, -1.0f), 1.0f);
+            }
+            A.actions[(size_t)r * 4 + lane] = a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // bwd_l2: head + loss gradient + LN2 backward (prologue), dh1 = dz2 W2 (MFMA)
 // ---------------------------------------------------------------------------------------------------------------
 enum { BM_CRITIC_TD = 0, BM_CRITIC_PI = 1, BM_ACTOR_PI = 2, BM_ACTOR_BC = 3 };
@@ -1054,20 +1181,12 @@ int64_t hx_act_workspace_floats(int64_t rows) { return rows * (int64_t)H2; }
  * 3: N(0, sigma^2) per row and component from Philox(seed; row0 + row, call).  ws: hx_act_workspace_floats(rows). */
 int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* actions, int32_t noise_mode, const float* noise,
                  float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* ws, void* stream) {
-    HX_REQUIRE(actor && obs && actions && ws && rows > 0, "hx_actor_act: bad arguments");
+    HX_REQUIRE(actor && obs && actions && rows > 0, "hx_actor_act: bad arguments");
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act: bad noise mode");
-    FwdArgs F{};
-    F.njobs = 1;
-    F.slope = slope;
-    FwdJob& J = F.job[0];
-    J.net = actor; J.m = kActor;
-    J.src = RowSrc{obs, nullptr, nullptr, 0, 13};
-    J.col0 = 0; J.act_mode = 0; J.noise = nullptr; J.rows = (int)rows; J.save = 0;
-    J.ws = Slot{}; J.ws.z2 = ws;
-    launch_fwd(F, (hipStream_t)stream);
-    ActArgs H{actor, kActor, ws, (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
-              noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, seed, row0, call};
-    hipLaunchKernelGGL(act_head_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, H);
+    (void)ws;
+    ActFusedArgs H{actor, kActor, obs, (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
+                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, seed, row0, call};
+    hipLaunchKernelGGL(act_fused_kernel, dim3((unsigned)((rows + RT - 1) / RT)), dim3(kWide), 0, (hipStream_t)stream, H);
     HX_CHECK_LAUNCH("hx_actor_act");
     return 0;
 }
@@ -1271,6 +1390,22 @@ int hx_polyak(const HxNets* N, const HxHyper* Hy, void* stream) {
     hipLaunchKernelGGL(polyak_kernel, dim3((na / 4 + kThreads) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, N->target_actor, N->actor, na, Hy->tau);
     HX_CHECK_LAUNCH("hx_polyak");
     return 0;
+}
+
+/* One whole Agent.learn on a single GPU (no gradient exchange): the stages above back to back in ONE host call.
+ * actor_phase: this is an actorTrainable call (HIRL.py:291); do_polyak: its update_count hits target_update_freq
+ * (HIRL.py:327).  critic_step / actor_step: 1-based Adam step numbers of this call. */
+int hx_hirl_learn(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t critic_step, int32_t actor_phase,
+                  int32_t actor_step, int32_t do_polyak, int32_t w_kind, float w_given, float warm, void* stream) {
+    int rc = hx_hirl_critic_grads(N, Bt, Hy, stream);
+    if (rc) return rc;
+    if ((rc = hx_adam(N, Hy, 0, critic_step, 1.0f, 0, 0.0f, 0.0f, Bt->batch, stream))) return rc;
+    if (!actor_phase) return 0;
+    if ((rc = hx_hirl_actor_backward(N, Bt, Hy, w_kind == 1, stream))) return rc;
+    if ((rc = hx_hirl_actor_wgrad(N, Hy, Bt->batch, Bt->batch, w_kind, w_given, warm, stream))) return rc;
+    if ((rc = hx_adam(N, Hy, 1, actor_step, 1.0f, w_kind, w_given, warm, Bt->batch, stream))) return rc;
+    if (do_polyak) rc = hx_polyak(N, Hy, stream);
+    return rc;
 }
 
 }  // extern "C"

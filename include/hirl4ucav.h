@@ -171,6 +171,11 @@ int hx_hirl_actor_wgrad(const HxNets* nets, const HxHyper* hyper, int32_t batch,
 int hx_adam(const HxNets* nets, const HxHyper* hyper, int32_t which, int32_t step, float grad_scale, int32_t w_kind,
             float w_given, float warm, int32_t batch, void* stream);
 int hx_polyak(const HxNets* nets, const HxHyper* hyper, void* stream);
+/* The stages above back to back in one host call, for a single GPU (no gradient exchange).  actor_phase: this is an
+ * actorTrainable call (HIRL.py:291,332); do_polyak: update_count reaches a multiple of 3 in it (HIRL.py:327-330);
+ * critic_step / actor_step: 1-based Adam step numbers of this call; w_kind / w_given / warm as in hx_hirl_actor_wgrad. */
+int hx_hirl_learn(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, int32_t critic_step, int32_t actor_phase,
+                  int32_t actor_step, int32_t do_polyak, int32_t w_kind, float w_given, float warm, void* stream);
 
 /* Minibatch assembly for one learn() call: replaces UniformMemory.sample (hirl/utils/buffer.py:38-48, random.sample without
  * replacement), the buffer/expert mixing and np.random.choice(replace=False) of HIRL.py:223-251, and the noise draw
