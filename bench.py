@@ -212,14 +212,16 @@ def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        # RCCL over xGMI.  HX_BENCH_BACKEND=gloo exists only to exercise this code path where all ranks share one GPU.
+        backend = os.environ.get("HX_BENCH_BACKEND", "nccl")
+        torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
     loop = Loop(args, rank, world, device)
 
     def barrier():

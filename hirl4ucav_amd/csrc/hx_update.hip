@@ -543,10 +543,57 @@ struct BwdArgs {
     int* soft_count;
 };
 
+// LDS image of one net's head parameters: g2[512] be2[512] W3[out][512] b3[out]  (out <= 4)
+constexpr int kHpStride = 6 * H2 + 8;
+__device__ __forceinline__ int hp_float4s(const Mlp& m) { return (2 + m.out) * (H2 / 4); }
+// the float4 of the image that thread `tid` stages (g2, be2, W3 rows are contiguous in the parameter block from g2())
+__device__ __forceinline__ float4 hp_fetch(const float* __restrict__ net, const Mlp& m, int tid) {
+    return tid < hp_float4s(m) ? reinterpret_cast<const float4*>(net + m.g2())[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void hp_store(float* hp, const float* __restrict__ net, const Mlp& m, int tid, const float4& v) {
+    if (tid < hp_float4s(m)) reinterpret_cast<float4*>(hp)[tid] = v;
+    if (tid < m.out) hp[6 * H2 + tid] = net[m.b3() + tid];
+}
+// head from registers + the LDS image: LN2 stats of z, y = g2 xhat + be2, o[j] = act(y) . W3[j] + b3[j]
+template <int OUTMAX>
+__device__ __forceinline__ void head_regs(const RowReg<H2>& z, const float* hp, int out, float slope, RowReg<H2>& xhat, RowReg<H2>& y,
+                                          float& mean, float& rstd, float (&o)[OUTMAX]) {
+    RowReg<H2> g, be;
+    row_stats<8>(z.v, H2, mean, rstd);
+    g.load(hp);
+    be.load(hp + H2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        xhat.v[i] = (z.v[i] - mean) * rstd;
+        y.v[i] = g.v[i] * xhat.v[i] + be.v[i];
+    }
+#pragma unroll
+    for (int j = 0; j < OUTMAX; ++j) {
+        float acc = 0.0f;
+        if (j < out) {
+            RowReg<H2> w;
+            w.load(hp + (2 + j) * H2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += act_f(y.v[i], slope) * w.v[i];
+            acc = wave_sum(acc) + hp[6 * H2 + j];
+        }
+        o[j] = acc;
+    }
+}
+
+// GRP 0: BM_CRITIC_TD jobs, 1: BM_CRITIC_PI, 2: BM_ACTOR_PI / BM_ACTOR_BC (one instantiation per launch keeps the register
+// footprint of each below 128 at 16 waves per workgroup).
+// Latency structure (what matters at B = 128, one workgroup per CU): EVERY global load of the workgroup — the W2 fragment
+// of the MFMA phase, the z2 rows, labels, the other nets' rows, all head parameters, the epilogue's z1 — is issued at
+// entry; there is ONE wait; head parameters are shared through LDS; the rest runs out of registers and LDS.
+template <int GRP>
 __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
     __shared__ __attribute__((aligned(16))) float dz2s[RT * LDA2];
     __shared__ __attribute__((aligned(16))) float kred[3 * 4 * 256];  // split-K partial tiles
+    __shared__ __attribute__((aligned(16))) float hps[(GRP == 0 ? 3 : 1) * kHpStride];
+    __shared__ __attribute__((aligned(16))) float c1s[GRP == 2 ? H1 * 6 : 4];  // critic layer 1: g1 be1 W1[:,13..16]
     __shared__ float red[16][4];
+    __shared__ float st1s[RT * 2];  // LN1 stats of the tile's rows (epilogue)
 
     int b = blockIdx.x, j = 0;
     for (; j < A.njobs; ++j) {
@@ -562,76 +609,132 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float slope = A.slope;
     const bool lead = nt == 0;  // the column-tile-0 workgroup of a row tile also publishes dz2 / st2 / dout / losses
-    // this wave's W2 fragment (column tile wave & 3, K quarter wave >> 2): requested now, consumed after the prologue
+    const bool live = wave < nrow;  // wave w owns row w of the tile
+    const size_t R = (size_t)(r0 + (live ? wave : 0));
+    const int ct = wave & 3, kq = wave >> 2;
+    const int n0 = nt * kNT + ct * 16;
     STAMP_DECL;
     STAMP();
-    BFrag<H2 / 4> bfrag;
-    bfrag.load(J.net + J.m.W2() + (size_t)((wave >> 2) * (H2 / 4)) * H1 + nt * kNT + (wave & 3) * 16 + (lane & 15), H1);
 
-    float part[4] = {0.f, 0.f, 0.f, 0.f};  // per-wave loss partials
-    int cnt = 0;
-    for (int q = 0; q < 1; ++q) {  // wave w owns row w of the tile
-        const int r = wave;
-        float* drow = dz2s + r * LDA2;
-        if (r >= nrow) {  // wave-uniform: padded rows contribute zeros
-            RowReg<H2> zero;
+    // ---------------- issue phase ----------------
+    BFrag<H2 / 4> bfrag;
+    bfrag.load(J.net + J.m.W2() + (size_t)(kq * (H2 / 4)) * H1 + n0 + (lane & 15), H1);
+    RowReg<H2> z, za, zb;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) zero.v[i] = 0.0f;
-            zero.store_lds(drow);
-            continue;
+    for (int i = 0; i < 8; ++i) z.v[i] = za.v[i] = zb.v[i] = 0.0f;
+    float lab0 = 0.f, lab1 = 0.f, tgt[4] = {0.f, 0.f, 0.f, 0.f};
+    RowReg<H1> cdh, cz;
+    float cst0 = 0.f, cst1 = 0.f, cs1 = 0.f, cs2 = 0.f;
+    if (live) z.load(J.ws.z2 + R * H2);
+    float4 pv0 = hp_fetch(J.net, J.m, tid), pv1 = make_float4(0.f, 0.f, 0.f, 0.f), pv2 = pv1;
+    if (GRP == 0) {
+        if (live) {
+            za.load(J.t1.ws.z2 + R * H2);
+            zb.load(J.t2.ws.z2 + R * H2);
+            const float* row = src_row(J.src, r0 + wave);
+            lab0 = row[30];
+            lab1 = row[31];
         }
-        const size_t R = (size_t)(r0 + r);
+        pv1 = hp_fetch(J.t1.net, J.t1.m, tid);
+        pv2 = hp_fetch(J.t2.net, J.t2.m, tid);
+    }
+    if (GRP == 1) {
+        if (live && J.soft.net) za.load(J.soft.ws.z2 + R * H2);  // same net as J.net: shares the LDS image
+    }
+    float c1v[2] = {0.f, 0.f};
+    if (GRP == 2) {
+        if (J.mode == BM_ACTOR_PI) {
+            const Head& C = J.crit;
+            if (live) {
+                cdh.load(C.ws.dh1 + R * H1);
+                cz.load(C.ws.z1 + R * H1);
+                cst0 = C.ws.st1[R * 2];
+                cst1 = C.ws.st1[R * 2 + 1];
+                const float* lp = C.ws.lnp + R * 8;
+                cs1 = ((lp[0] + lp[2]) + (lp[4] + lp[6])) * (1.0f / H1);
+                cs2 = ((lp[1] + lp[3]) + (lp[5] + lp[7])) * (1.0f / H1);
+            }
+            // g1 | be1 (512 floats) by threads 0..511; W1[k][13..16] (1024 floats) one per thread
+            if (tid < 2 * H1) c1v[0] = C.net[C.m.g1() + tid];
+            c1v[1] = C.net[C.m.W1() + (tid >> 2) * C.m.in + 13 + (tid & 3)];
+        } else if (live) {
+            const float* row = src_row(J.src, r0 + wave);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) tgt[jj] = row[13 + jj];
+        }
+    }
+    // epilogue operands of the waves that finish the tile (kq == 0): z1, g1, be1 of their 4 rows x 1 column; LN1 stats via LDS
+    constexpr bool kEpiPrefetch = GRP != 0;  // the TD instantiation has no registers to spare: it loads these in the epilogue
+    float ez1[4] = {0.f, 0.f, 0.f, 0.f}, eg1 = 0.f, ebe1 = 0.f;
+    if (kEpiPrefetch && kq == 0) {
+        const int r = lane & 15, g = lane >> 4;
+        eg1 = J.net[J.m.g1() + n0 + r];
+        ebe1 = J.net[J.m.be1() + n0 + r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 4 * g + q;
+            if (row < nrow) ez1[q] = J.ws.z1[(size_t)(r0 + row) * H1 + n0 + r];
+        }
+    }
+    const float st1v = tid < nrow * 2 ? J.ws.st1[(size_t)r0 * 2 + tid] : (tid & 1 ? 1.0f : 0.0f);
+    // ---------------- one wait: publish the shared operands in LDS ----------------
+    if (tid < RT * 2) st1s[tid] = st1v;
+    hp_store(hps, J.net, J.m, tid, pv0);
+    if (GRP == 0) {
+        hp_store(hps + kHpStride, J.t1.net, J.t1.m, tid, pv1);
+        hp_store(hps + 2 * kHpStride, J.t2.net, J.t2.m, tid, pv2);
+    }
+    if (GRP == 2 && J.mode == BM_ACTOR_PI) {
+        if (tid < 2 * H1) c1s[tid] = c1v[0];
+        c1s[2 * H1 + tid] = c1v[1];
+    }
+    __syncthreads();
+    STAMP();
+
+    // ---------------- prologue: head, loss gradient, LN2 backward (registers + LDS only) ----------------
+    float part[4] = {0.f, 0.f, 0.f, 0.f};  // loss partials of this row
+    int cnt = 0;
+    float* drow = dz2s + wave * LDA2;
+    if (!live) {  // padded rows contribute zeros
+        RowReg<H2> zero;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) zero.v[i] = 0.0f;
+        zero.store_lds(drow);
+    } else {
         RowReg<H2> xh, y;
         float mean, rstd, o[4];
-        head_row<4>(J.ws.z2 + R * H2, J.net, J.m, slope, xh, y, mean, rstd, o);
+        head_regs<4>(z, hps, J.m.out, slope, xh, y, mean, rstd, o);
         float dout[4] = {0.f, 0.f, 0.f, 0.f};
-        if (J.mode == BM_CRITIC_TD) {
+        if (GRP == 0) {
             RowReg<H2> xa, ya;
             float m1, s1, q1[1], q2[1];
-            head_row<1>(J.t1.ws.z2 + R * H2, J.t1.net, J.t1.m, slope, xa, ya, m1, s1, q1);
-            head_row<1>(J.t2.ws.z2 + R * H2, J.t2.net, J.t2.m, slope, xa, ya, m1, s1, q2);
-            const float* row = src_row(J.src, r0 + r);
-            const float target = row[30] + (J.gamma * fminf(q1[0], q2[0])) * (1.0f - row[31]);
+            head_regs<1>(za, hps + kHpStride, 1, slope, xa, ya, m1, s1, q1);
+            head_regs<1>(zb, hps + 2 * kHpStride, 1, slope, xa, ya, m1, s1, q2);
+            const float target = lab0 + (J.gamma * fminf(q1[0], q2[0])) * (1.0f - lab1);  // HIRL.py:270-274
             const float diff = o[0] - target;
             dout[0] = 2.0f * diff * A.inv_batch;  // d mse / dq
             part[0] += diff * diff * A.inv_batch;
-        } else if (J.mode == BM_CRITIC_PI) {
+        } else if (GRP == 1) {
             dout[0] = -A.inv_batch;            // rl_loss = -mean(Q1(s, pi(s)))  HIRL.py:297
             part[3] += -o[0] * A.inv_batch;
             if (J.soft.net) {
                 RowReg<H2> xa, ya;
                 float m1, s1, qs[1];
-                head_row<1>(J.soft.ws.z2 + R * H2, J.soft.net, J.soft.m, slope, xa, ya, m1, s1, qs);
+                head_regs<1>(za, hps, 1, slope, xa, ya, m1, s1, qs);
                 cnt += (qs[0] > o[0]) ? 1 : 0;  // (soft_Q > rl_Q)  HIRL.py:303
             }
         } else if (J.mode == BM_ACTOR_PI) {
-            // dL/da_j = sum_k dz1_c[k] W1c[k][13 + j], dz1_c = LN1 backward of the critic's dh1
-            const Head& C = J.crit;
-            RowReg<H1> dh, z, g, be;
-            dh.load(C.ws.dh1 + R * H1);
-            z.load(C.ws.z1 + R * H1);
-            g.load(C.net + C.m.g1());
-            be.load(C.net + C.m.be1());
-            const float cm = C.ws.st1[R * 2], cr = C.ws.st1[R * 2 + 1];
-            float xh1[4], dxh[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xh1[i] = (z.v[i] - cm) * cr;
-                const float yy = g.v[i] * xh1[i] + be.v[i];
-                dxh[i] = dh.v[i] * act_d(yy, slope) * g.v[i];
-            }
-            const float* lp = C.ws.lnp + R * 8;
-            const float s1 = ((lp[0] + lp[2]) + (lp[4] + lp[6])) * (1.0f / H1);
-            const float s2 = ((lp[1] + lp[3]) + (lp[5] + lp[7])) * (1.0f / H1);
+            // dL/da_j = sum_k dz1_c[k] W1c[k][13 + j], dz1_c = LN1 backward of the critic's dh1 (row sums from lnp)
             float da[4] = {0.f, 0.f, 0.f, 0.f};
-            // RowReg<256> maps v[c] -> hidden unit k = lane*4 + c
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 4; ++c) {  // RowReg<256> maps v[c] -> hidden unit k = lane*4 + c
                 const int k = lane * 4 + c;
-                const float dz1 = cr * (dxh[c] - s1 - xh1[c] * s2);
-                const float* w = C.net + C.m.W1() + k * C.m.in + 13;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) da[jj] += dz1 * w[jj];
+                const float g1 = c1s[k], be1 = c1s[H1 + k];
+                const float xh1 = (cz.v[c] - cst0) * cst1;
+                const float dxh = cdh.v[c] * act_d(g1 * xh1 + be1, slope) * g1;
+                const float dz1 = cst1 * (dxh - cs1 - xh1 * cs2);
+                const float4 w4 = *reinterpret_cast<const float4*>(c1s + 2 * H1 + 4 * k);
+                da[0] += dz1 * w4.x; da[1] += dz1 * w4.y; da[2] += dz1 * w4.z; da[3] += dz1 * w4.w;
             }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -640,11 +743,10 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
                 dout[jj] = da[jj] * (1.0f - a * a);
             }
         } else {  // BM_ACTOR_BC: bc_loss = lambda * mse(actor(s_bc), a_bc)  HIRL.py:310-311
-            const float* row = src_row(J.src, r0 + r);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const float a = tanhf(o[jj]);
-                const float diff = a - row[13 + jj];
+                const float diff = a - tgt[jj];
                 dout[jj] = (2.0f * J.lambda * 0.25f * A.inv_batch) * diff * (1.0f - a * a);
                 part[2] += J.lambda * 0.25f * A.inv_batch * diff * diff;
                 if (jj == 3) part[1] += J.lambda * A.inv_batch * diff * diff;  // bc_fire_loss (logging), HIRL.py:317-319
@@ -652,12 +754,12 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
         }
         // dh2 = dout W3, through act' and LN2 backward
         RowReg<H2> g, dx;
-        g.load(J.net + J.m.g2());
+        g.load(hps);
 #pragma unroll
         for (int i = 0; i < 8; ++i) dx.v[i] = 0.0f;
         for (int jj = 0; jj < J.m.out; ++jj) {
             RowReg<H2> w;
-            w.load(J.net + J.m.W3() + jj * H2);
+            w.load(hps + (2 + jj) * H2);
 #pragma unroll
             for (int i = 0; i < 8; ++i) dx.v[i] += dout[jj] * w.v[i];
         }
@@ -685,12 +787,12 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
             }
         }
     }
-    STAMP();
     if (lead && lane == 0) {
         red[wave][0] = part[0]; red[wave][1] = part[1]; red[wave][2] = part[2]; red[wave][3] = part[3];
         if (cnt) atomicAdd(A.soft_count, cnt);
     }
     __syncthreads();
+    STAMP();
     if (lead && tid == 0) {
         float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
         for (int w = 0; w < 16; ++w) {
@@ -703,11 +805,8 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
             atomicAdd(&A.losses[4], p1);
         }
     }
-    STAMP();
-    // dh1 tile on fp32 MFMA: wave = (column tile ct, K quarter kq), K = 512; W2 is [512][256] row-major = B[k][n]
+    // ---------------- dh1 tile on fp32 MFMA: wave = (column tile ct, K quarter kq), K = 512 ----------------
     {
-        const int ct = wave & 3, kq = wave >> 2;
-        const int n0 = nt * kNT + ct * 16;
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
         acc = tile_a_lds_b_frag<H2 / 4>(dz2s + kq * (H2 / 4), LDA2, bfrag, acc);
@@ -715,20 +814,25 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
         __syncthreads();  // partial tiles visible; dz2s is dead from here on
         STAMP();
         float* ps = dz2s;  // reused as [4 column tiles][16 rows][2]
+        if (!kEpiPrefetch && kq == 0) {
+            eg1 = J.net[J.m.g1() + n0 + r];
+            ebe1 = J.net[J.m.be1() + n0 + r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (4 * g + q < nrow) ez1[q] = J.ws.z1[(size_t)(r0 + 4 * g + q) * H1 + n0 + r];
+        }
         if (kq == 0) {
             // epilogue: store dh1 and this tile's share of the LN1-backward row sums (consumed by wgrad / the actor's
             // backward, which then need no cross-column reduction of their own)
-            const float g1 = J.net[J.m.g1() + n0 + r], be1 = J.net[J.m.be1() + n0 + r];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float v = (acc[q] + kred[((0 * 4 + ct) * 64 + lane) * 4 + q]) + (kred[((1 * 4 + ct) * 64 + lane) * 4 + q] + kred[((2 * 4 + ct) * 64 + lane) * 4 + q]);
                 const int row = 4 * g + q;
                 float p1 = 0.0f, p2 = 0.0f;
                 if (row < nrow) {
-                    const size_t R = (size_t)(r0 + row);
-                    J.ws.dh1[R * H1 + n0 + r] = v;
-                    const float xh = (J.ws.z1[R * H1 + n0 + r] - J.ws.st1[R * 2]) * J.ws.st1[R * 2 + 1];
-                    const float dxh = v * act_d(g1 * xh + be1, slope) * g1;
+                    J.ws.dh1[(size_t)(r0 + row) * H1 + n0 + r] = v;
+                    const float xh = (ez1[q] - st1s[row * 2]) * st1s[row * 2 + 1];
+                    const float dxh = v * act_d(eg1 * xh + ebe1, slope) * eg1;
                     p1 = dxh;
                     p2 = dxh * xh;
                 }
@@ -796,6 +900,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
     const WgJob& J = A.job[j];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float slope = A.slope;
+    STAMP_DECL;
+    STAMP();
     const float w = effective_w(A.w_kind, A.w_given, A.warm, A.inv_batch, A.soft_count, A.wstate);
     float scale[2];
     for (int s = 0; s < 2; ++s) scale[s] = J.wmode[s] == 0 ? 1.0f : (J.wmode[s] == 1 ? 1.0f - w : w);
@@ -825,9 +931,12 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
                 for (int i = 0; i < 32; ++i) acc = mfma16(av[i] * sc, hv[i], acc);
             }
         }
+        STAMP();
         float* out = J.grad + J.m.W2();
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[(size_t)(n0 + 4 * g + q) * H1 + k0 + r] = acc[q];
+        STAMP();
+        STAMP_FLUSH(32, blockIdx.x == 0 && tid == 0);
         return;
     }
     const int rg = wave;  // row group: rows rg, rg + 4, ...
@@ -883,6 +992,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
                     for (int r = 0; r < nr; ++r) db3 += sc * rinfo[r * 8 + 2 + tid];
             }
         }
+        STAMP();
         float* my = red + (rg * 64 + lane) * 20;
         my[0] = db2; my[1] = dg; my[2] = dbe; my[3] = dw3[0]; my[4] = dw3[1]; my[5] = dw3[2]; my[6] = dw3[3];
         __syncthreads();
@@ -896,6 +1006,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
             for (int jj = 0; jj < J.m.out; ++jj) J.grad[J.m.W3() + jj * H2 + n] = v[3 + jj];
         }
         if (vb == 0 && tid < J.m.out) J.grad[J.m.b3() + tid] = db3;
+        STAMP();
+        STAMP_FLUSH(40, b == kWgTilesPerBlock && j == 0 && tid == 0);
         return;
     }
     // layer 1: hidden unit k; dz1 = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) with the row means taken from the
@@ -950,6 +1062,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
                 }
             }
         }
+        STAMP();
         float* my = red + (rg * 64 + lane) * 20;
         my[0] = db1; my[1] = dg; my[2] = dbe;
 #pragma unroll
@@ -964,6 +1077,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
             J.grad[J.m.be1() + k] = v[2];
             for (int i = 0; i < in; ++i) J.grad[J.m.W1() + k * in + i] = v[3 + i];
         }
+        STAMP();
+        STAMP_FLUSH(48, b == kWgTilesPerBlock + kWgVecWgs && j == 0 && tid == 0);
     }
 }
 
@@ -1231,7 +1346,7 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
             J.net = N->critic + h * kQ.padded(); J.m = kQ; J.ws = s[S_C1 + h]; J.rows = B; J.mode = BM_CRITIC_TD;
             J.t1 = Head{tc1, kQ, s[S_TC1]}; J.t2 = Head{tc2, kQ, s[S_TC2]}; J.src = src; J.gamma = Hy->gamma;
         }
-        hipLaunchKernelGGL(bwd_l2_kernel, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+        hipLaunchKernelGGL(bwd_l2_kernel<0>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
     }
     {   // launch D: all critic parameter gradients
         WgArgs W{};
@@ -1313,7 +1428,7 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
         J = BwdJob{};
         J.net = N->critic; J.m = kQ; J.ws = s[S_CPI]; J.rows = B; J.mode = BM_CRITIC_PI;
         if (soft) J.soft = Head{N->critic, kQ, s[S_CSOFT]};
-        hipLaunchKernelGGL(bwd_l2_kernel, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+        hipLaunchKernelGGL(bwd_l2_kernel<1>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
     }
     {   // launch I: actor backward for the RL batch (through tanh and the critic's input gradient) and the BC batch
         BwdArgs G{};
@@ -1332,7 +1447,7 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
             J.src = bcsrc; J.lambda = Hy->loss_lambda;
         }
         G.njobs = n;
-        hipLaunchKernelGGL(bwd_l2_kernel, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+        hipLaunchKernelGGL(bwd_l2_kernel<2>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
     }
     HX_CHECK_LAUNCH("hx_hirl_actor_backward");
     return 0;
