@@ -34,8 +34,8 @@ class HxHyper(ctypes.Structure):
 
 _P = ctypes.POINTER
 _lib.register("hx_actor_act", [_vp, _vp, ctypes.c_int64, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _f32, _vp, _vp])
-_lib.register("hx_hirl_critic_grads", [_P(HxNets), _P(HxBatch), _P(HxHyper), _vp])
-_lib.register("hx_hirl_actor_backward", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _vp])
+_lib.register("hx_hirl_critic_grads", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _vp])
+_lib.register("hx_hirl_actor_backward", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _vp])
 _lib.register("hx_hirl_actor_wgrad", [_P(HxNets), _P(HxHyper), _i32, _i32, _i32, _f32, _f32, _vp])
 _lib.register("hx_adam", [_P(HxNets), _P(HxHyper), _i32, _i32, _f32, _i32, _f32, _f32, _i32, _vp])
 _lib.register("hx_polyak", [_P(HxNets), _P(HxHyper), _vp])
@@ -125,6 +125,7 @@ class HirlEngine:
         self.group = group
         self.world = torch.distributed.get_world_size(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         self.act_calls = 0
+        self.staged = self.world > 1  # stage-by-stage path with the gradient exchanges; the one-call fused path otherwise
 
     # ---- parameters ------------------------------------------------------------------------------------------
     def load_params(self, actor, critic, bc_actor=None, hard_update_targets=True):
@@ -210,16 +211,16 @@ class HirlEngine:
             self.actor_step += 1
             self.update_count += 1
         do_polyak = actor_phase and self.update_count % self.target_update_freq == 0  # HIRL.py:327-330
-        if self.world == 1:
+        if not self.staged:
             _lib.call("hx_hirl_learn", nets, ctypes.byref(batch), hyper, self.critic_step, int(actor_phase), self.actor_step,
                       int(do_polyak), w_kind, w_given, float(bc_warm_up_weight), st)
         else:  # sharded: the same stages with the three exchanges of SURVEY.md 8e in between
             gs = 1.0 / self.world
-            _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, st)
+            _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, (2 if w_kind == 1 else 1) if actor_phase else 0, st)
             self._allreduce(self.grad_critic)
             _lib.call("hx_adam", nets, hyper, 0, self.critic_step, gs, 0, 0.0, 0.0, B, st)
             if actor_phase:
-                _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, int(w_kind == 1), st)
+                _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, int(w_kind == 1), 1, st)
                 if w_kind == 1:
                     self._allreduce(self.soft_count)
                 _lib.call("hx_hirl_actor_wgrad", nets, hyper, B, B * self.world, w_kind, w_given, float(bc_warm_up_weight), st)

@@ -151,7 +151,7 @@ struct FwdJob {
     int save;  // write x, z1, st1, h1 (needed by the backward pass)
 };
 struct FwdArgs {
-    FwdJob job[3];
+    FwdJob job[6];
     int njobs;
     float slope;
     // accumulators cleared by this launch (consumed by LATER launches on the same stream): replaces memset nodes
@@ -876,6 +876,13 @@ struct WgArgs {
     const float* wstate;
 };
 
+// torch.optim.Adam (defaults) on one element; explicit single-rounding intrinsics so that every caller rounds alike
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float b1, float b2, float eps, float step_size, float bc2_sqrt) {
+    m = __fmaf_rn(g, 1.0f - b1, __fmul_rn(m, b1));
+    v = __fmaf_rn(__fmul_rn(g, g), 1.0f - b2, __fmul_rn(v, b2));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
+    p = __fsub_rn(p, __fmul_rn(step_size, __fdiv_rn(m, denom)));
+}
 __device__ __forceinline__ float effective_w(int kind, float given, float warm, float inv_batch, const int* count, const float* wstate) {
     float w = given;
     if (kind == 1) w = (float)(*count) * inv_batch + warm;
@@ -1112,10 +1119,7 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
     const int cnt = min(4, A.n - i);
     for (int c = 0; c < cnt; ++c) { pv[c] = A.p[i + c]; gv[c] = A.g[i + c] * A.gscale; mv[c] = A.m[i + c]; vv[c] = A.v[i + c]; }
     for (int c = 0; c < cnt; ++c) {
-        mv[c] = mv[c] * A.b1 + gv[c] * (1.0f - A.b1);
-        vv[c] = vv[c] * A.b2 + (gv[c] * gv[c]) * (1.0f - A.b2);
-        const float denom = sqrtf(vv[c]) / A.bc2_sqrt + A.eps;
-        pv[c] = pv[c] - A.step_size * (mv[c] / denom);
+        adam_update(pv[c], mv[c], vv[c], gv[c], A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
         A.p[i + c] = pv[c]; A.m[i + c] = mv[c]; A.v[i + c] = vv[c];
     }
 }
@@ -1310,8 +1314,11 @@ static void make_slots(const HxNets* N, int B, Slot* s) {
     for (int i = 0; i < S_COUNT; ++i) s[i] = carve_slot(N->ws + (size_t)i * kSlotFloats * B, B);
 }
 
-/* Stage 1 (every call): TD target, critic forward, critic gradients -> grad_critic, losses[0].  HIRL.py:259-286 */
-int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, void* stream) {
+/* Stage 1 (every call): TD target, critic forward, critic gradients -> grad_critic, losses[0].  HIRL.py:259-286.
+ * actor_fwd: 1 = also run the delayed actor step's forward passes that do not depend on the critic update (actor(s),
+ * actor(s_bc)), 2 = plus bc_actor(s) for the soft estimate — they ride in launch A instead of a launch of their own.
+ */
+int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, void* stream) {
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_critic_grads: batch must be a positive multiple of 16");
     hipStream_t st = (hipStream_t)stream;
     const int B = Bt->batch;
@@ -1327,6 +1334,16 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
         F.job[0] = FwdJob{N->target_actor, kActor, src, 17, 0, Head{}, nullptr, 0.f, s[S_TA], B, 0};
         F.job[1] = FwdJob{N->critic, kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C1], B, 1};
         F.job[2] = FwdJob{N->critic + kQ.padded(), kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C2], B, 1};
+        if (actor_fwd) {
+            const RowSrc bcsrc{Bt->bc_rows ? Bt->bc_rows : Bt->rows, nullptr, nullptr, 0, 32};
+            const bool bc = Hy->use_bc != 0;
+            F.zero_nf = 5; F.zero_i = N->soft_count;  // + actor / bc / rl / bc_fire accumulators and the soft count
+            int n = 3;
+            F.job[n++] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1};
+            if (bc) F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1};
+            if (bc && actor_fwd == 2) F.job[n++] = FwdJob{N->bc_actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0};
+            F.njobs = n;
+        }
         launch_fwd(F, st);
     }
     {   // launch B: targetCritic Q1/Q2 (s', clamp(targetActor(s') + clamp(noise)))
@@ -1364,6 +1381,7 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
     return 0;
 }
 
+
 /* Adam step over a flat buffer (torch.optim.Adam defaults; step = 1-based step count; grad is multiplied by
  * grad_scale first — 1/world_size after a SUM all-reduce).  which: 0 critic, 1 actor (also finishes actor_loss /
  * bc_weight bookkeeping: w_kind 0 given, 1 estimate from soft_count, 2 reuse stored). */
@@ -1392,7 +1410,7 @@ int hx_adam(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t step, flo
 
 /* Stage 2a (delayed actor step, HIRL.py:291-319): actor / bc_actor forward, Q1 with the UPDATED critic, the soft
  * count, backward down to dz2/dh1 of the actor.  Leaves soft_count and losses[2..4] ready; no parameter gradient yet. */
-int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t estimate_soft, void* stream) {
+int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t estimate_soft, int32_t fwd_done, void* stream) {
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_actor_backward: batch must be a positive multiple of 16");
     hipStream_t st = (hipStream_t)stream;
     const int B = Bt->batch;
@@ -1401,7 +1419,7 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
     const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
     const RowSrc bcsrc{Bt->bc_rows ? Bt->bc_rows : Bt->rows, nullptr, nullptr, 0, 32};
     const bool bc = Hy->use_bc != 0, soft = bc && estimate_soft;
-    {   // launch F: actor(s), actor(s_bc), bc_actor(s)
+    if (!fwd_done) {   // launch F: actor(s), actor(s_bc), bc_actor(s)  (hx_hirl_critic_grads(actor_fwd) can carry them instead)
         FwdArgs F{};
         F.slope = Hy->slope;
         F.zero_f = N->losses + 1; F.zero_nf = 4; F.zero_i = N->soft_count;  // actor / bc / rl / bc_fire accumulators + soft count
@@ -1477,6 +1495,7 @@ int hx_hirl_actor_wgrad(const HxNets* N, const HxHyper* Hy, int32_t batch, int32
 }
 
 
+
 /* Minibatch assembly for one learn() call (replaces UniformMemory.sample buffer.py:38-48, the buffer/expert mixing and the
  * BC draw of HIRL.py:223-251, and the noise draw HIRL.py:265).  do_sample = 1: draw idx[batch] (rows < n_main index the main
  * ring, whose live length min(*total, cap) is read on the device; the rest the expert ring), idx_bc[batch], noise[4] =
@@ -1512,11 +1531,11 @@ int hx_polyak(const HxNets* N, const HxHyper* Hy, void* stream) {
  * (HIRL.py:327).  critic_step / actor_step: 1-based Adam step numbers of this call. */
 int hx_hirl_learn(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t critic_step, int32_t actor_phase,
                   int32_t actor_step, int32_t do_polyak, int32_t w_kind, float w_given, float warm, void* stream) {
-    int rc = hx_hirl_critic_grads(N, Bt, Hy, stream);
+    // 5 launches on a critic-only call, 10 on an actor call (the actor's critic-independent forwards ride in launch A)
+    int rc = hx_hirl_critic_grads(N, Bt, Hy, actor_phase ? (w_kind == 1 ? 2 : 1) : 0, stream);
     if (rc) return rc;
-    if ((rc = hx_adam(N, Hy, 0, critic_step, 1.0f, 0, 0.0f, 0.0f, Bt->batch, stream))) return rc;
-    if (!actor_phase) return 0;
-    if ((rc = hx_hirl_actor_backward(N, Bt, Hy, w_kind == 1, stream))) return rc;
+    if ((rc = hx_adam(N, Hy, 0, critic_step, 1.0f, 0, 0.0f, 0.0f, Bt->batch, stream)) || !actor_phase) return rc;
+    if ((rc = hx_hirl_actor_backward(N, Bt, Hy, w_kind == 1, 1, stream))) return rc;
     if ((rc = hx_hirl_actor_wgrad(N, Hy, Bt->batch, Bt->batch, w_kind, w_given, warm, stream))) return rc;
     if ((rc = hx_adam(N, Hy, 1, actor_step, 1.0f, w_kind, w_given, warm, Bt->batch, stream))) return rc;
     if (do_polyak) rc = hx_polyak(N, Hy, stream);

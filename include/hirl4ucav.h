@@ -160,9 +160,11 @@ typedef struct HxHyper {
  *   hx_hirl_actor_wgrad     grad_actor = w dL_bc + (1 - w) dL_rl            HIRL.py:321-324   -> [all-reduce grad_actor]
  *   hx_adam(which = 1)      actor.optimizer.step(); actor_loss, bc_weight   HIRL.py:325,334
  *   hx_polyak               every 3rd actor step (HIRL.py:327-330) */
-int hx_hirl_critic_grads(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, void* stream);
+/* actor_fwd: 0 = critic phase only; 1 = also run the delayed actor step's critic-independent forward passes actor(s),
+ * actor(s_bc) in the same first launch; 2 = plus bc_actor(s) for the soft estimate (then pass fwd_done = 1 below). */
+int hx_hirl_critic_grads(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, int32_t actor_fwd, void* stream);
 int hx_hirl_actor_backward(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, int32_t estimate_soft,
-                           void* stream);
+                           int32_t fwd_done, void* stream);
 /* w_kind 0: w = w_given (linear / fixed, train_all.py:328-333); 1: w = soft_count / count_batch + warm (HIRL.py:304-306);
  * 2: the stored weight.  w is clipped to <= 1 (HIRL.py:308). */
 int hx_hirl_actor_wgrad(const HxNets* nets, const HxHyper* hyper, int32_t batch, int32_t count_batch, int32_t w_kind,

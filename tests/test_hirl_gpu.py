@@ -280,3 +280,33 @@ def test_device_sampler(eng_mod):
     rep.total += 100000  # ring wrapped: the whole capacity is live
     idx3, _, _ = e.sample(rep, exp, bc, n_main=128, seed=9)
     assert idx3.max().item() >= 300 and idx3.max().item() < 5000
+
+
+def test_staged_path_equals_fused_path(eng_mod):
+    """The stage-by-stage sequence a sharded run uses (critic_grads -> [all-reduce] -> adam -> actor_backward -> [all-reduce
+    count] -> actor_wgrad -> [all-reduce] -> adam -> polyak) and the single-GPU one-call path (actor forwards folded into the
+    first launch) are the same arithmetic: identical parameters after 12 calls."""
+    params, data = D.make_params(21), D.make_data(22, outliers=True)
+    ring, exp, bc = device_tables(data)
+    rng = np.random.default_rng(5)
+    engines = []
+    for staged in (False, True):
+        e = eng_mod.HirlEngine(batch=128)
+        e.staged = staged
+        e.load_params(params["actor"], params["critic"], params["bc_actor"])
+        engines.append(e)
+    for k in range(12):
+        idx = rng.integers(0, D.N_REPLAY, 128).astype(np.int32)
+        ibc = rng.integers(0, D.N_EXPERT, 128).astype(np.int32)
+        noise = rng.normal(0, 0.2, 4).astype(np.float32)
+        w = 100 if k % 4 == 0 else (None if k % 4 < 3 else 0.3)
+        outs = []
+        for e in engines:
+            e.assemble(ring, torch.from_numpy(idx).cuda(), bc_table=bc, idx_bc=torch.from_numpy(ibc).cuda())
+            e.learn(noise=torch.from_numpy(noise).cuda(), bc_weight_now=w, bc_warm_up_weight=0.05)
+            outs.append(e.losses_host())
+        np.testing.assert_allclose(outs[0], outs[1], rtol=1e-6, atol=1e-7, err_msg=f"call {k}")
+    a, b = engines
+    for name in ("actor", "critic", "target_actor", "target_critic", "m_actor", "v_actor", "m_critic", "v_critic"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert a.update_count == 6 and b.update_count == 6

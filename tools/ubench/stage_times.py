@@ -27,11 +27,13 @@ st = _lib.stream_ptr()
 timeit("sample+gather", lambda: e.sample(loop.replay, loop.expert, loop.bc_table, n_main=128, seed=2))
 timeit("env.step (4096, insert)", lambda: env.step(loop.actions))
 timeit("act (fwd wide + head, 4096)", lambda: e.act(env.obs, sigma=0.1, seed=1, out=loop.actions))
-timeit("critic_grads (A,B,C,D)", lambda: _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, st))
+timeit("critic_grads (A,B,C,D)", lambda: _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, 0, st))
 timeit("adam critic", lambda: _lib.call("hx_adam", nets, hyper, 0, 5, 1.0, 0, 0.0, 0.0, 128, st))
-timeit("actor_backward (F,G,H,I) soft", lambda: _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, 1, st))
-timeit("actor_backward (F,G,H,I) nosoft", lambda: _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, 0, st))
+timeit("actor_backward (F,G,H,I) soft", lambda: _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, 1, 0, st))
+timeit("actor_backward (F,G,H,I) nosoft", lambda: _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, 0, 0, st))
 timeit("actor_wgrad (J)", lambda: _lib.call("hx_hirl_actor_wgrad", nets, hyper, 128, 128, 2, 0.0, 0.0, st))
 timeit("adam actor", lambda: _lib.call("hx_adam", nets, hyper, 1, 5, 1.0, 2, 0.0, 0.0, 128, st))
 timeit("polyak", lambda: _lib.call("hx_polyak", nets, hyper, st))
+timeit("hx_hirl_learn critic-only (4 k)", lambda: _lib.call("hx_hirl_learn", nets, ctypes.byref(batch), hyper, 5, 0, 5, 0, 2, 0.0, 0.0, st))
+timeit("hx_hirl_learn actor call (8 k)", lambda: _lib.call("hx_hirl_learn", nets, ctypes.byref(batch), hyper, 5, 1, 5, 0, 2, 0.0, 0.0, st))
 timeit("full loop.step()", lambda: loop.step(), n=500)

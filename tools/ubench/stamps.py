@@ -12,7 +12,7 @@ e.sample(loop.replay, loop.expert, loop.bc_table, n_main=128, seed=2)
 batch = HxBatch(e.rows.data_ptr(), e.bc_rows.data_ptr(), 128, e._noise.data_ptr())
 L = _lib.load(); out = np.zeros(64, np.float32)
 for i in range(3):
-    _lib.call("hx_hirl_critic_grads", ctypes.byref(e.nets), ctypes.byref(batch), ctypes.byref(e.hyper), _lib.stream_ptr())
+    _lib.call("hx_hirl_critic_grads", ctypes.byref(e.nets), ctypes.byref(batch), ctypes.byref(e.hyper), 0, _lib.stream_ptr())
     torch.cuda.synchronize()
     assert L.hx_debug_stamps(out.ctypes.data_as(ctypes.c_void_p)) == 0
     print("wgrad(critic) x10ns: tiles: loads+mfma %d store %d | vector: loop %d reduce+store %d | layer1: loop %d reduce+store %d" % (out[33], out[34], out[41], out[42], out[49], out[50]))
