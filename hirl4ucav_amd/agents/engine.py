@@ -39,6 +39,7 @@ _lib.register("hx_hirl_actor_backward", [_P(HxNets), _P(HxBatch), _P(HxHyper), _
 _lib.register("hx_hirl_actor_wgrad", [_P(HxNets), _P(HxHyper), _i32, _i32, _i32, _f32, _f32, _vp])
 _lib.register("hx_adam", [_P(HxNets), _P(HxHyper), _i32, _i32, _f32, _i32, _f32, _f32, _i32, _vp])
 _lib.register("hx_polyak", [_P(HxNets), _P(HxHyper), _vp])
+_lib.register("hx_bc_train_actor", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _vp])
 _lib.register("hx_hirl_learn", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp])
 _lib.register("hx_sample_batch", [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _i32, _i32, _i32, ctypes.c_uint64,
                                    ctypes.c_uint32, _f32, _vp, _vp, _vp, _vp, _vp, _vp])
@@ -229,6 +230,12 @@ class HirlEngine:
                 if do_polyak:
                     _lib.call("hx_polyak", nets, hyper, st)
         self.actor_trainable = not self.actor_trainable  # HIRL.py:332
+
+    def bc_train_actor(self):
+        """BC.Agent.train_actor (BC.py:160-185) on the BC minibatch last assembled: mse, backward, Adam on the actor."""
+        batch = HxBatch(self.rows.data_ptr(), self.bc_rows.data_ptr(), self.batch, self._noise.data_ptr())
+        self.actor_step += 1
+        _lib.call("hx_bc_train_actor", ctypes.byref(self.nets), ctypes.byref(batch), ctypes.byref(self.hyper), self.actor_step, _lib.stream_ptr())
 
     def losses_host(self):
         """(critic_loss, actor_loss, bc_loss, rl_loss, bc_fire_loss, bc_weight) — HIRL.py:334.  Synchronises."""

@@ -1387,7 +1387,7 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
  * bc_weight bookkeeping: w_kind 0 given, 1 estimate from soft_count, 2 reuse stored). */
 int hx_adam(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t step, float grad_scale, int32_t w_kind, float w_given,
             float warm, int32_t batch, void* stream) {
-    HX_REQUIRE(N && Hy && step >= 1 && (which == 0 || which == 1), "hx_adam: bad arguments");
+    HX_REQUIRE(N && Hy && step >= 1 && which >= 0 && which <= 2, "hx_adam: bad arguments");
     const double b1 = 0.9, b2 = 0.999;
     const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
     AdamArgs A{};
@@ -1400,7 +1400,7 @@ int hx_adam(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t step, flo
     A.step_size = (float)((which == 0 ? Hy->lr_critic : Hy->lr_actor) / bc1);
     A.bc2_sqrt = (float)sqrt(bc2);
     A.gscale = grad_scale;
-    A.finish_actor = which == 1;
+    A.finish_actor = which == 1;  // which == 2: the actor's Adam step alone (BC pre-training)
     A.w_kind = w_kind; A.w_given = w_given; A.warm = warm; A.inv_batch = 1.0f / (batch > 0 ? batch : 1);
     A.soft_count = N->soft_count; A.wstate = N->wstate; A.losses = N->losses; A.use_bc = Hy->use_bc;
     hipLaunchKernelGGL(adam_kernel, dim3((A.n / 4 + kThreads) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, A);
@@ -1540,6 +1540,44 @@ int hx_hirl_learn(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t
     if ((rc = hx_adam(N, Hy, 1, actor_step, 1.0f, w_kind, w_given, warm, Bt->batch, stream))) return rc;
     if (do_polyak) rc = hx_polyak(N, Hy, stream);
     return rc;
+}
+
+/* BC.Agent.train_actor (hirl/agents/BC.py:160-185): one behaviour-cloning step of the actor on the BC minibatch
+ * Bt->bc_rows — loss = mse(actor(s_bc), a_bc) (no loss_lambda here), backward, actor.optimizer.step().
+ * losses[2] receives the loss.  Hy->slope = 0.01 reproduces BC.py's LeakyReLU actor. */
+int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t step, void* stream) {
+    HX_REQUIRE(N && Bt && Hy && Bt->bc_rows && Bt->batch > 0 && Bt->batch % 16 == 0 && step >= 1, "hx_bc_train_actor: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = Bt->batch;
+    Slot s[S_COUNT];
+    make_slots(N, B, s);
+    const RowSrc bcsrc{Bt->bc_rows, nullptr, nullptr, 0, 32};
+    {
+        FwdArgs F{};
+        F.njobs = 1; F.slope = Hy->slope;
+        F.zero_f = N->losses + 1; F.zero_nf = 4;
+        F.job[0] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1};
+        launch_fwd(F, st);
+    }
+    {
+        BwdArgs G{};
+        G.njobs = 1; G.slope = Hy->slope; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = N->soft_count;
+        BwdJob& J = G.job[0];
+        J = BwdJob{};
+        J.net = N->actor; J.m = kActor; J.ws = s[S_ABC]; J.rows = B; J.mode = BM_ACTOR_BC; J.src = bcsrc; J.lambda = 1.0f;
+        hipLaunchKernelGGL(bwd_l2_kernel<2>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+    }
+    {
+        WgArgs W{};
+        W.njobs = 1; W.slope = Hy->slope; W.w_kind = 0; W.w_given = 0.f; W.inv_batch = 1.0f / B;
+        W.soft_count = N->soft_count; W.wstate = N->wstate;
+        WgJob& J = W.job[0];
+        J = WgJob{};
+        J.net = N->actor; J.grad = N->grad_actor; J.m = kActor; J.ws[0] = s[S_ABC]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
+        hipLaunchKernelGGL(wgrad_kernel, dim3(kWgPerJob), dim3(kThreads), 0, st, W);
+    }
+    HX_CHECK_LAUNCH("hx_bc_train_actor");
+    return hx_adam(N, Hy, 2, step, 1.0f, 0, 0.0f, 0.0f, B, stream);
 }
 
 }  // extern "C"

@@ -173,6 +173,10 @@ int hx_hirl_actor_wgrad(const HxNets* nets, const HxHyper* hyper, int32_t batch,
 int hx_adam(const HxNets* nets, const HxHyper* hyper, int32_t which, int32_t step, float grad_scale, int32_t w_kind,
             float w_given, float warm, int32_t batch, void* stream);
 int hx_polyak(const HxNets* nets, const HxHyper* hyper, void* stream);
+/* BC.Agent.train_actor (hirl/agents/BC.py:160-185): one behaviour-cloning step on batch->bc_rows: loss = mse(actor(s_bc),
+ * a_bc), backward, actor.optimizer.step(); losses[2] receives the loss.  hyper->slope = 0.01 gives BC.py's LeakyReLU actor.
+ * (hx_adam's which = 2 is the actor step without HIRL's actor_loss / bc_weight bookkeeping.) */
+int hx_bc_train_actor(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, int32_t step, void* stream);
 /* The stages above back to back in one host call, for a single GPU (no gradient exchange).  actor_phase: this is an
  * actorTrainable call (HIRL.py:291,332); do_polyak: update_count reaches a multiple of 3 in it (HIRL.py:327-330);
  * critic_step / actor_step: 1-based Adam step numbers of this call; w_kind / w_given / warm as in hx_hirl_actor_wgrad. */

@@ -15,6 +15,7 @@ Adam and Polyak.  PINNED: tests/test_oracle_hirl.py checks it against golden vec
     HirlOracle.choose_action <- chooseAction*             hirl/agents/HIRL.py:192-212   (U5)
     adam_step            <- torch.optim.Adam defaults (lr, betas (0.9, 0.999), eps 1e-8)  HIRL.py:50,123
     TD3 variant (leaky_relu 0.01, no BC)  <- hirl/agents/TD3.py:201-260 (U12) via slope=0.01, bc off
+    HirlOracle.bc_train_actor <- BC.Agent.train_actor  hirl/agents/BC.py:160-185
 """
 import math
 
@@ -213,6 +214,17 @@ class HirlOracle:
                 polyak(self.target_actor, self.actor, self.tau)
         self.actor_trainable = not self.actor_trainable  # HIRL.py:332
         return critic_loss.item(), self.actor_loss, self.bc_loss, self.rl_loss, self.bc_fire_loss, self.bc_weight
+
+
+def bc_train_actor(o, bc_batch):
+    """BC.Agent.train_actor (BC.py:160-185) on an oracle built with slope=0.01: mse(actor(s), a), backward, Adam."""
+    bs, ba = (torch.as_tensor(x, dtype=torch.float32) for x in bc_batch)
+    loss = F.mse_loss(actor_forward(o.actor, bs, o.slope), ba)
+    keys = list(o.actor)
+    grads = dict(zip(keys, torch.autograd.grad(loss, [o.actor[k] for k in keys])))
+    o.last_grads["actor"] = {k: g.clone() for k, g in grads.items()}
+    o.opt_actor.step(o.actor, grads)
+    return loss.item()
 
 
 # ---- flat parameter layout shared by the tests (order = the reference's state_dict order) ----------------------

@@ -15,6 +15,7 @@ returned tuples for K consecutive calls, and per-call probes of every network (s
                               the third on an actor call -> a fresh estimate)
                               modes: soft_e0, soft_e64, fixed_e32, linear_e0
   td3_learn.npz           G5  agents.TD3.Agent.learn (leaky_relu nets), 8 calls
+  bc_train.npz                agents.BC.Agent.train_actor (leaky_relu actor), 6 calls
   hirl_choose_action.npz  G7  chooseAction / chooseActionSmallNoise / chooseActionNoNoise on fixed states
 """
 import os
@@ -162,6 +163,25 @@ def run_td3():
     print("td3", [round(o[0], 3) for o in outs[:4]], [round(o[1], 3) for o in outs[:4]])
 
 
+def run_bc():
+    import agents.BC as ref_bc
+
+    params, data = D.make_params(D.PARAM_SEED), D.make_data(D.DATA_SEED)
+    agent = ref_bc.Agent(1e-3, 13, 4, 256, 512, True, "g", 128, data["expert_s"], data["expert_a"])
+    agent.actor.load_state_dict({k: torch.tensor(v) for k, v in params["actor"].items()})
+    rec = Recorder(777)
+    install(rec, ref_buf)
+    outs, prb = [], []
+    for k in range(6):
+        outs.append(float(agent.train_actor()))
+        flat = np.concatenate([v.detach().numpy().ravel() for v in agent.actor.state_dict().values()]).astype(np.float64)
+        prb.append((np.abs(flat).sum(), flat[D.probe_index(flat.size)]))
+    np.savez_compressed(os.path.join(HERE, "bc_train.npz"), idx_bc=np.asarray(rec.choices), out=np.asarray(outs, np.float64),
+                        probe_abs=np.asarray([p[0] for p in prb]), probe_val=np.asarray([p[1] for p in prb], np.float32),
+                        data_checksum=D.checksum(data), param_checksum=D.checksum(params))
+    print("bc", [round(o, 5) for o in outs])
+
+
 def run_choose_action():
     params, data = D.make_params(D.PARAM_SEED), D.make_data(D.DATA_SEED)
     agent = ref_hirl.Agent(1e-3, 1e-3, 13, 4, 256, 512, 0.005, 0.99, 1000, 128, True, "g", data["expert_s"], data["expert_a"], 0.5, True)
@@ -187,5 +207,6 @@ if __name__ == "__main__":
     run_hirl("fixed_e32", 32, lambda ep: (0.5, 0.0))
     run_hirl("linear_e0", 0, lambda ep: (max(0.5 - ep / 4.0, 0.0), 0.0))
     run_td3()
+    run_bc()
     run_choose_action()
     np.random.choice, torch.normal = _choice, _normal

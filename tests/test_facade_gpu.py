@@ -148,3 +148,22 @@ def test_vectorised_driver_runs_and_learns_something(tmp_path, capsys):
         T.MAX_STEP["straight_line"] = 1500
     out = capsys.readouterr().out
     assert "Episode 2:" in out and "env steps/s" in out and "nan" not in out.lower()
+
+
+def test_bc_agent_facade_learns_the_expert(tmp_path):
+    """agent = BCAgent(actorLR, stateDim, actionDim, h1, h2, useLayerNorm, name, batchSize, expert_states, expert_actions);
+    bc_loss = agent.train_actor()  (train_all.py:229,244-250) — the loss falls, the checkpoint loads as HIRL's bc_actor."""
+    from hirl4ucav_amd.agents.BC import Agent as BCAgent
+    from hirl4ucav_amd.agents.HIRL import Agent as HIRLAgent
+
+    rng = np.random.default_rng(0)
+    s = rng.uniform(-1, 1, (2000, 13))
+    a = np.tanh(s[:, :4] * 1.5)  # a learnable expert
+    agent = BCAgent(1e-3, 13, 4, 256, 512, True, "Harfang_GYM", 128, s, a)
+    losses = [float(agent.train_actor()) for _ in range(300)]
+    assert np.mean(losses[-20:]) < 0.25 * np.mean(losses[:5])
+    agent.saveCheckpoints("Agent1_", str(tmp_path))
+    h = HIRLAgent(1e-3, 1e-3, 13, 4, 256, 512, 0.005, 0.99, 1000, 128, True, "Harfang_GYM", s, a, 0.5, True)
+    h.load_bc_actor("Agent1_", str(tmp_path))  # train_all.py:311-312
+    np.testing.assert_array_equal(h.bc_actor.state_dict()["full2.weight"].numpy(), agent.actor.state_dict()["full2.weight"].numpy())
+    assert agent.chooseActionNoNoise(s[0]).shape == (4,)

@@ -310,3 +310,31 @@ def test_staged_path_equals_fused_path(eng_mod):
     for name in ("actor", "critic", "target_actor", "target_critic", "m_actor", "v_actor", "m_critic", "v_critic"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert a.update_count == 6 and b.update_count == 6
+
+
+def test_bc_train_actor_matches_oracle_and_reference(eng_mod, golden_dir):
+    """BC.Agent.train_actor through hx_bc_train_actor: loss, gradient and stepped actor call by call vs the oracle (from
+    identical states) and the loss / probes vs the reference's recorded run."""
+    g = np.load(os.path.join(golden_dir, "bc_train.npz"))
+    params, data = D.make_params(D.PARAM_SEED), D.make_data(D.DATA_SEED)
+    ring, exp, bc = device_tables(data)
+    e = eng_mod.HirlEngine(batch=128, slope=0.01)
+    e.load_params(params["actor"], params["critic"])
+    o = H.HirlOracle(params["actor"], params["critic"], None, slope=0.01)
+    for k in range(g["out"].shape[0]):
+        idx = g["idx_bc"][k].astype(np.int32)
+        sync_oracle(o, e, eng_mod)
+        t = torch.from_numpy(idx).cuda()
+        e.assemble(bc, t, bc_table=bc, idx_bc=t)
+        e.bc_train_actor()
+        got = e.losses_host()[2]
+        ref = H.bc_train_actor(o, (data["expert_s"][idx], data["expert_a"][idx]))
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6, err_msg=f"bc call {k} vs oracle")
+        np.testing.assert_allclose(got, g["out"][k], rtol=2e-5, atol=1e-6, err_msg=f"bc call {k} vs reference golden")
+        check_grads(eng_mod, e.grad_actor, o.last_grads["actor"], eng_mod.ACTOR_LAYOUT, f"bc call {k} actor grad")
+        f = e.actor.cpu().numpy()
+        d = np.abs(f - H.flatten(o.actor, H.ACTOR_KEYS))
+        assert (d > 2e-6).mean() < 2e-4 and d.max() <= 2.1e-3
+        s_, a_, v_ = D.net_probe(f)
+        dv = np.abs(v_ - g["probe_val"][k])
+        assert (dv > 2e-6).mean() <= 0.03 and dv.max() < 5e-5

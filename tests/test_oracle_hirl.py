@@ -86,3 +86,17 @@ def test_initialisation_bounds():
     n_actor = sum(v.size for v in p["actor"].values())
     n_critic = sum(v.size for v in p["critic"].values())
     assert (n_actor, n_critic) == (138756, 276482)
+
+
+def test_bc_train_actor_matches_reference(golden_dir):
+    """BC.Agent.train_actor (BC.py:160-185), 6 consecutive calls with the LeakyReLU actor."""
+    g = np.load(os.path.join(golden_dir, "bc_train.npz"))
+    params, data = D.make_params(D.PARAM_SEED), D.make_data(D.DATA_SEED)
+    o = H.HirlOracle(params["actor"], params["critic"], None, slope=0.01)
+    for k in range(g["out"].shape[0]):
+        idx = g["idx_bc"][k]
+        loss = H.bc_train_actor(o, (data["expert_s"][idx], data["expert_a"][idx]))
+        np.testing.assert_allclose(loss, g["out"][k], rtol=1e-5, atol=1e-6, err_msg=f"bc call {k}")
+        s, a, v = D.net_probe(H.flatten(o.actor, H.ACTOR_KEYS))
+        np.testing.assert_allclose(v, g["probe_val"][k], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(a, g["probe_abs"][k], rtol=1e-6)
