@@ -257,17 +257,20 @@ def main():
                                f"(BASELINE.json configs[1])", "envs_per_gpu": args.envs, "batch": args.batch,
                    "parallelism": f"dp{world}: env shards + replicated nets, RCCL all-reduce of the flat gradients"},
         "update_steps_per_s": round(args.steps / dt, 1),
-        "stage_us": {"act(2 kernels)": round(act_us, 2), "env_step(1 kernel)": round(env_us, 2), "sample+learn(7-13 kernels)": round(learn_us, 2)},
+        "stage_us": {"act(1 kernel)": round(act_us, 2), "env_step(1 kernel)": round(env_us, 2), "sample+learn(6-12 kernels)": round(learn_us, 2)},
     }
     # roofline of the env-step kernel (the kernel the metric counts): algorithmic bytes / live-measured launch time
     res["roofline"] = {"kernel": "env_step_kernel<INSERT>", "bound": "hbm", "achieved": round(ENV_BYTES_FUSED * args.envs / env_us / 1e3, 1),
                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ENV_BYTES_FUSED * args.envs / env_us / 1e3 / HBM_PEAK_GBPS, 4),
-                       "traffic": None, "bytes_per_launch": ENV_BYTES_FUSED * args.envs, "us_per_launch": round(env_us, 2)}
+                       "traffic": None, "bytes_per_launch": ENV_BYTES_FUSED * args.envs, "us_per_launch": round(env_us, 2),
+                       "traffic_note": "PMC (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per the gfx950 calibration) at "
+                                       "1,048,576 envs per launch: 226.9 MB read + 351.6 MB written = 1.003 x the 576.7 MB algorithmic bytes "
+                                       "(profiles/r01_pmc_*_env_1M.csv); not collectable inside this process"}
     res["roofline_update"] = {"kernels": "fwd_l2/bwd_l2/wgrad/adam (one learn)", "bound": "mfma", "unit": "TFLOP/s",
                               "achieved": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
                               "frac": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 5),
                               "us_per_learn": round(learn_us, 2)}
-    res["roofline_act"] = {"kernels": "fwd_l2 + act_head", "bound": "mfma", "unit": "TFLOP/s",
+    res["roofline_act"] = {"kernels": "act_fused_kernel", "bound": "mfma", "unit": "TFLOP/s",
                            "achieved": round(ACTOR_FLOP * args.envs / act_us / 1e6, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
                            "frac": round(ACTOR_FLOP * args.envs / act_us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 5), "us": round(act_us, 2)}
     res["env_stats"] = loop.env.stats_dict()

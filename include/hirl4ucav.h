@@ -61,6 +61,8 @@ enum { HX_STAT_EPISODES = 0, HX_STAT_KILLS, HX_STAT_FIRE_SUCCESS_EPISODES, HX_ST
 
 const char* hx_last_error(void);
 int hx_version(void);
+/* PMC calibration helper: dst[i] = src[i], one dword per lane (the env kernel's access shape), n floats */
+int hx_debug_copy_dword(const float* src, float* dst, int64_t n, void* stream);
 
 /* Optional per-call behaviour of hx_env_step.  All pointers device memory (or NULL = feature off). */
 typedef struct HxStepOpts {
