@@ -1,0 +1,167 @@
+"""SacEngine — device-resident state of the SAC agent (reference hirl/agents/SAC/agent.py, non-imitative branch) and the
+host-side sequencing of the hx_sac_* stages.  The networks are the plain Linear-ReLU stacks of the reference's (un-vendored)
+rltorch builder; they reuse the flat MLP-block layout of include/hirl4ucav.h with the LayerNorm slots pinned to (1, 0)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from . import engine as E
+
+_vp, _i32, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
+_P = ctypes.POINTER
+
+
+class HxSacNets(ctypes.Structure):
+    _fields_ = [(k, _vp) for k in ("policy", "critic", "target_critic", "grad_policy", "grad_critic", "m_policy", "v_policy", "m_critic",
+                                   "v_critic", "losses", "alpha_state", "ws")]
+
+
+class HxSacBatch(ctypes.Structure):
+    _fields_ = [("rows", _vp), ("batch", _i32), ("eps_next", _vp), ("eps_cur", _vp)]
+
+
+_lib.register("hx_sac_act", [_vp, _vp, ctypes.c_int64, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp])
+_lib.register("hx_sac_critic_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _i32, _vp])
+_lib.register("hx_sac_policy_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _vp])
+_lib.register("hx_sac_adam", [_P(HxSacNets), _P(E.HxHyper), _i32, _i32, _f32, _f32, _vp])
+
+H1, H2 = E.H1, E.H2
+SEQ_KEYS = ("0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias")  # nn.Sequential(Linear, ReLU, Linear, ReLU, Linear)
+
+
+def _block(in_dim, out_dim):
+    """offsets of W1 b1 g1 be1 W2 b2 g2 be2 W3 b3 inside one block (hx_nn.h Mlp)"""
+    o, off = {}, 0
+    for k, n in (("W1", H1 * in_dim), ("b1", H1), ("g1", H1), ("be1", H1), ("W2", H2 * H1), ("b2", H2), ("g2", H2), ("be2", H2),
+                 ("W3", out_dim * H2), ("b3", out_dim)):
+        o[k] = (off, n)
+        off += n
+    return o, (off + 3) & ~3
+
+
+POLICY_BLOCK, POLICY_SIZE = _block(13, 8)
+Q_BLOCK, Q_SIZE = _block(17, 1)
+assert Q_SIZE == E.Q_PADDED
+
+
+def pack_mlp(sd, block, size, in_dim, out_dim, device):
+    """Sequential state_dict -> flat block (LayerNorm slots = (1, 0))"""
+    flat = torch.zeros(size, dtype=torch.float32, device=device)
+    shapes = {"0.weight": (H1, in_dim), "0.bias": (H1,), "2.weight": (H2, H1), "2.bias": (H2,), "4.weight": (out_dim, H2), "4.bias": (out_dim,)}
+    for key, slot in zip(SEQ_KEYS, ("W1", "b1", "W2", "b2", "W3", "b3")):
+        v = torch.as_tensor(np.asarray(sd[key].detach().cpu() if torch.is_tensor(sd[key]) else sd[key]), dtype=torch.float32)
+        assert tuple(v.shape) == shapes[key], (key, v.shape)
+        off, n = block[slot]
+        flat[off:off + n] = v.reshape(-1).to(device)
+    for slot in ("g1", "g2"):
+        off, n = block[slot]
+        flat[off:off + n] = 1.0
+    return flat
+
+
+def unpack_mlp(flat, block, in_dim, out_dim):
+    shapes = {"W1": (H1, in_dim), "b1": (H1,), "W2": (H2, H1), "b2": (H2,), "W3": (out_dim, H2), "b3": (out_dim,)}
+    return {key: flat[block[slot][0]:block[slot][0] + block[slot][1]].reshape(shapes[slot])
+            for key, slot in zip(SEQ_KEYS, ("W1", "b1", "W2", "b2", "W3", "b3"))}
+
+
+class SacEngine:
+    def __init__(self, batch=128, lr=1e-3, gamma=0.99, tau=0.005, target_entropy=-4.0, target_update_interval=3, device="cuda", group=None):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.HxError("SacEngine runs on the GPU only (no CPU path in the product)")
+        L = _lib.load()
+        L.hx_sac_workspace_floats.restype = ctypes.c_int64
+        assert L.hx_sac_policy_param_count() == POLICY_SIZE
+        self.batch = int(batch)
+        ws = int(L.hx_sac_workspace_floats(self.batch))
+        sizes = [POLICY_SIZE, 2 * Q_SIZE, 2 * Q_SIZE, POLICY_SIZE + 2 * Q_SIZE, POLICY_SIZE, POLICY_SIZE, 2 * Q_SIZE, 2 * Q_SIZE, 64, 64, ws,
+                 self.batch * 32, self.batch * 4, self.batch * 4, self.batch, 64]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 63) & ~63
+        self.arena = torch.zeros(tot, dtype=torch.float32, device=self.device)
+        c = [self.arena[o:o + n] for o, n in zip(offs, sizes)]
+        (self.policy, self.critic, self.target_critic, self.grad, self.m_policy, self.v_policy, self.m_critic, self.v_critic, losses,
+         alpha, self.ws, self.rows, self.eps_next, self.eps_cur, ix, noise) = c
+        self.grad_critic, self.grad_policy = self.grad[:2 * Q_SIZE], self.grad[2 * Q_SIZE:]
+        self.losses, self.alpha_state, self._idx, self._noise = losses[:8], alpha[:4], ix.view(torch.int32), noise[:4]
+        self.alpha_state[3] = 1.0  # log_alpha = 0 -> alpha = 1  (agent.py:106-107)
+        self.nets = HxSacNets(*(t.data_ptr() for t in (self.policy, self.critic, self.target_critic, self.grad_policy, self.grad_critic,
+                                                        self.m_policy, self.v_policy, self.m_critic, self.v_critic, self.losses,
+                                                        self.alpha_state, self.ws)))
+        self.hyper = E.HxHyper(gamma, tau, lr, lr, 0.0, 0.5, 0.0, 0)
+        self.target_entropy, self.interval = float(target_entropy), int(target_update_interval)
+        self.learning_steps = 0
+        self.group = group
+        self.world = torch.distributed.get_world_size(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        self._act_ws, self.act_calls, self.sample_calls = None, 0, 0
+
+    def load_params(self, policy, q1, q2, hard_update_target=True):
+        self.policy.copy_(pack_mlp(policy, POLICY_BLOCK, POLICY_SIZE, 13, 8, self.device))
+        self.critic[:Q_SIZE].copy_(pack_mlp(q1, Q_BLOCK, Q_SIZE, 17, 1, self.device))
+        self.critic[Q_SIZE:].copy_(pack_mlp(q2, Q_BLOCK, Q_SIZE, 17, 1, self.device))
+        if hard_update_target:  # hard_update(critic_target, critic), agent.py:92
+            self.target_critic.copy_(self.critic)
+
+    def state_dicts(self):
+        return {"policy": unpack_mlp(self.policy, POLICY_BLOCK, 13, 8), "q1": unpack_mlp(self.critic[:Q_SIZE], Q_BLOCK, 17, 1),
+                "q2": unpack_mlp(self.critic[Q_SIZE:], Q_BLOCK, 17, 1), "q1_target": unpack_mlp(self.target_critic[:Q_SIZE], Q_BLOCK, 17, 1),
+                "q2_target": unpack_mlp(self.target_critic[Q_SIZE:], Q_BLOCK, 17, 1)}
+
+    def act(self, obs, eps=None, explore=True, seed=0, row0=0, out=None):
+        """explore (agent.py:183-188): sampled tanh-Gaussian action (eps [N, 4] given, else Philox); exploit (:191-196): tanh(mean)."""
+        n = obs.shape[0]
+        if self._act_ws is None or self._act_ws.numel() < n * H2:
+            self._act_ws = torch.empty(n * H2, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        mode = 0 if not explore else (1 if eps is not None else 2)
+        self.act_calls += 1
+        _lib.call("hx_sac_act", self.policy.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode, _lib.ptr(eps), int(seed), int(row0),
+                  self.act_calls, self._act_ws.data_ptr(), _lib.stream_ptr())
+        return out
+
+    def assemble(self, ring, idx):
+        _lib.call("hx_sample_batch", None, 0, ring.data_ptr(), None, 0, None, 0, self.batch, self.batch, 0, 0, 0, 0.0, idx.data_ptr(), None,
+                  None, self.rows.data_ptr(), None, _lib.stream_ptr())
+
+    def sample(self, replay, seed=0):
+        """memory.sample(batch_size) on the device + the two standard-normal draw sets of the learn() call."""
+        self.sample_calls += 1
+        _lib.call("hx_sample_batch", replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(), None, 0, None, 0, self.batch, self.batch,
+                  1, int(seed), self.sample_calls, 0.0, self._idx.data_ptr(), None, self._noise.data_ptr(), self.rows.data_ptr(), None,
+                  _lib.stream_ptr())
+        self.eps_next.normal_()
+        self.eps_cur.normal_()
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            torch.distributed.all_reduce(t, group=self.group)
+
+    def learn(self, eps_next=None, eps_cur=None):
+        """SacAgent.learn(False) (agent.py:276-327) on the minibatch last assembled.  Enqueues only."""
+        st = _lib.stream_ptr()
+        if eps_next is not None:
+            self.eps_next.copy_(eps_next.reshape(-1))
+            self.eps_cur.copy_(eps_cur.reshape(-1))
+        batch = HxSacBatch(self.rows.data_ptr(), self.batch, self.eps_next.data_ptr(), self.eps_cur.data_ptr())
+        nets, hyper, gs = ctypes.byref(self.nets), ctypes.byref(self.hyper), 1.0 / self.world
+        self.learning_steps += 1
+        _lib.call("hx_sac_critic_grads", nets, ctypes.byref(batch), hyper, int(self.learning_steps % self.interval == 0), st)
+        self._allreduce(self.grad_critic)
+        _lib.call("hx_sac_adam", nets, hyper, 0, self.learning_steps, gs, self.target_entropy, st)
+        _lib.call("hx_sac_policy_grads", nets, ctypes.byref(batch), hyper, st)
+        if self.world > 1:  # mean entropy and the policy-loss terms are per-shard means: average them with the gradients
+            self._allreduce(self.grad_policy)
+            self._allreduce(self.losses)
+            self.losses.mul_(gs)
+        _lib.call("hx_sac_adam", nets, hyper, 1, self.learning_steps, gs, self.target_entropy, st)
+
+    def losses_host(self):
+        """(q1_loss, q2_loss, policy_loss, entropy_loss, mean entropy, alpha)"""
+        v = self.losses.tolist()
+        return v[0], v[1], v[2], v[3], v[4], v[5]

@@ -27,6 +27,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // full{1,3}.weight, .bias, layernorm{1,3}.weight, .bias, full{2,4}.weight, .bias, layernorm{2,4}.weight, .bias, final.weight, .bias
 struct Mlp {
     int in, out;
+    int no_ln;  // 1: plain Linear-ReLU stack (SAC nets, rltorch builder): the LayerNorm slots hold (1, 0) and statistics are (0, 1)
     __host__ __device__ int W1() const { return 0; }
     __host__ __device__ int b1() const { return H1 * in; }
     __host__ __device__ int g1() const { return b1() + H1; }

@@ -45,6 +45,7 @@ constexpr int kWide = 1024;  // fwd_l2 / bwd_l2 workgroups: 16 waves = one per r
                              // 4 column tiles x 4 K-quarters (split-K, LDS reduce) in the MFMA phase.  B = 128 runs ONE
                              // workgroup per CU, so 4 waves per SIMD are what hides the prologue's load/reduce latency.
 constexpr int kNT = 64;  // z2 / dh1 columns per workgroup (4 column tiles x 16)
+constexpr int OW = 8;    // row pitch of the per-slot head output / head gradient arrays
 
 // minibatch row r comes from main[idx[r]] if r < nb else from exp[idx[r]]; idx == nullptr: row r of `main` itself
 struct RowSrc {
@@ -68,10 +69,10 @@ struct Slot {
     float* h1;    // [R][H1]
     float* z2;    // [R][H2]
     float* st2;   // [R][2]
-    float* outv;  // [R][4]    head output (tanh(o) for actors, q for critics)
+    float* outv;  // [R][8]    head output (tanh(o) for actors, q for critics); 8 = widest head (SAC policy: mean ++ log_std)
     float* dz2;   // [R][H2]
     float* dh1;   // [R][H1]
-    float* dout;  // [R][4]    gradient wrt the head pre-activation o
+    float* dout;  // [R][8]    gradient wrt the head pre-activation o
     float* lnp;   // [R][4][2] LN1-backward row sums (sum dxhat, sum dxhat*xhat) over each 64-column tile of dh1
 };
 
@@ -113,6 +114,7 @@ __device__ __forceinline__ void head_row(const float* __restrict__ z2row, const 
     RowReg<H2> z, g, be;
     z.load(z2row);
     row_stats<8>(z.v, H2, mean, rstd);
+    if (m.no_ln) { mean = 0.0f; rstd = 1.0f; }
     g.load(net + m.g2());
     be.load(net + m.be2());
 #pragma unroll
@@ -142,7 +144,8 @@ struct FwdJob {
     Mlp m;
     RowSrc src;
     int col0;      // state columns [col0, col0+13) of the source row (0 = s, 17 = s')
-    int act_mode;  // in == 17 only: 0 = action from source row cols 13..16, 1 = tanh(head(prev)) (+ clamped noise, clamp +-1)
+    int act_mode;  // in == 17 only: 0 = action from source row cols 13..16, 1 = tanh(head(prev)) (+ clamped noise, clamp +-1),
+                   // 3 = action rows [rows][4] given through `noise`
     Head prev;
     const float* noise;  // [4] one draw shared by the whole batch (HIRL.py:265) or nullptr
     float noise_clamp;
@@ -222,6 +225,11 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
                 const int r = (tid - 256) >> 2, c = tid & 3;
                 if (r < nrow) xs[r * XP + 13 + c] = src_row(J.src, r0 + r)[13 + c];
             }
+        } else if (J.act_mode == 3) {  // action rows prepared by an earlier kernel (SAC: sampled tanh-Gaussian actions)
+            if (tid >= 256 && tid < 256 + RT * 4) {
+                const int r = (tid - 256) >> 2, c = tid & 3;
+                if (r < nrow) xs[r * XP + 13 + c] = J.noise[(size_t)(r0 + r) * 4 + c];
+            }
         } else if (wave < nrow) {
             // head of the previous net: wave w owns row w
             const int r = wave;
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
                     a = fminf(fmaxf(a + e, -1.0f), 1.0f);
                 }
                 xs[r * XP + 13 + lane] = a;
-                if (nt == 0) J.prev.ws.outv[(size_t)(r0 + r) * 4 + lane] = a;
+                if (nt == 0) J.prev.ws.outv[(size_t)(r0 + r) * OW + lane] = a;
             }
             if (nt == 0 && lane == 0) {
                 J.prev.ws.st2[(size_t)(r0 + r) * 2] = mean;
@@ -269,6 +277,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
         for (int i = 0; i < 4; ++i) v[i] = h1s[wave * LDA1 + i * 64 + lane];
         float mean, rstd;
         row_stats<4>(v, H1, mean, rstd);
+        if (J.m.no_ln) { mean = 0.0f; rstd = 1.0f; }
         if (lane == 0) {
             sts[wave * 2] = mean;
             sts[wave * 2 + 1] = rstd;
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 // ---------------------------------------------------------------------------------------------------------------
 // bwd_l2: head + loss gradient + LN2 backward (prologue), dh1 = dz2 W2 (MFMA)
 // ---------------------------------------------------------------------------------------------------------------
-enum { BM_CRITIC_TD = 0, BM_CRITIC_PI = 1, BM_ACTOR_PI = 2, BM_ACTOR_BC = 3 };
+enum { BM_CRITIC_TD = 0, BM_CRITIC_PI = 1, BM_ACTOR_PI = 2, BM_ACTOR_BC = 3, BM_GIVEN = 4 };
 
 struct BwdJob {
     const float* net;
@@ -533,6 +542,10 @@ struct BwdJob {
     // BM_ACTOR_PI: dL/da from the critic's layer-1 backward
     Head crit;    // the critic Q1 slot evaluated on (s, pi) (its dh1, z1, st1 are read)
     float lambda; // BM_ACTOR_BC: loss_lambda (HIRL.py:182)
+    // SAC: per-row target bonus (entropy of the next action, scaled by *bonus_scale = alpha) and which losses[] slot a TD job feeds
+    const float* bonus;
+    const float* bonus_scale;
+    int loss_slot;
 };
 struct BwdArgs {
     BwdJob job[2];
@@ -543,23 +556,37 @@ struct BwdArgs {
     int* soft_count;
 };
 
-// LDS image of one net's head parameters: g2[512] be2[512] W3[out][512] b3[out]  (out <= 4)
-constexpr int kHpStride = 6 * H2 + 8;
-__device__ __forceinline__ int hp_float4s(const Mlp& m) { return (2 + m.out) * (H2 / 4); }
-// the float4 of the image that thread `tid` stages (g2, be2, W3 rows are contiguous in the parameter block from g2())
-__device__ __forceinline__ float4 hp_fetch(const float* __restrict__ net, const Mlp& m, int tid) {
-    return tid < hp_float4s(m) ? reinterpret_cast<const float4*>(net + m.g2())[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-__device__ __forceinline__ void hp_store(float* hp, const float* __restrict__ net, const Mlp& m, int tid, const float4& v) {
-    if (tid < hp_float4s(m)) reinterpret_cast<float4*>(hp)[tid] = v;
-    if (tid < m.out) hp[6 * H2 + tid] = net[m.b3() + tid];
-}
-// head from registers + the LDS image: LN2 stats of z, y = g2 xhat + be2, o[j] = act(y) . W3[j] + b3[j]
+// LDS image of one net's head parameters: g2[512] be2[512] W3[out][512] (padded to OUTMAX rows) b3[out]
 template <int OUTMAX>
+struct HeadImage {
+    static constexpr int kStride = (2 + OUTMAX) * H2 + 8;
+    static constexpr int kPer = ((2 + OUTMAX) * (H2 / 4) + kWide - 1) / kWide;  // float4 per thread to stage it
+    float4 v[kPer];
+    // g2, be2, W3 rows are contiguous in the parameter block from g2()
+    __device__ __forceinline__ void fetch(const float* __restrict__ net, const Mlp& m, int tid) {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int e = tid + i * kWide;
+            v[i] = e < (2 + m.out) * (H2 / 4) ? reinterpret_cast<const float4*>(net + m.g2())[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void store(float* hp, const float* __restrict__ net, const Mlp& m, int tid) const {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int e = tid + i * kWide;
+            if (e < (2 + m.out) * (H2 / 4)) reinterpret_cast<float4*>(hp)[e] = v[i];
+        }
+        if (tid < m.out) hp[(2 + OUTMAX) * H2 + tid] = net[m.b3() + tid];
+    }
+};
+// head from registers + the LDS image: LN2 stats of z, y = g2 xhat + be2, o[j] = act(y) . W3[j] + b3[j]
+// OUTMAX = how many outputs are computed, IMG = head width the LDS image was laid out for (HeadImage<IMG>)
+template <int OUTMAX, int IMG>
 __device__ __forceinline__ void head_regs(const RowReg<H2>& z, const float* hp, int out, float slope, RowReg<H2>& xhat, RowReg<H2>& y,
-                                          float& mean, float& rstd, float (&o)[OUTMAX]) {
+                                          float& mean, float& rstd, float (&o)[OUTMAX], int no_ln = 0) {
     RowReg<H2> g, be;
     row_stats<8>(z.v, H2, mean, rstd);
+    if (no_ln) { mean = 0.0f; rstd = 1.0f; }
     g.load(hp);
     be.load(hp + H2);
 #pragma unroll
@@ -575,13 +602,14 @@ __device__ __forceinline__ void head_regs(const RowReg<H2>& z, const float* hp, 
             w.load(hp + (2 + j) * H2);
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc += act_f(y.v[i], slope) * w.v[i];
-            acc = wave_sum(acc) + hp[6 * H2 + j];
+            acc = wave_sum(acc) + hp[(2 + IMG) * H2 + j];
         }
         o[j] = acc;
     }
 }
 
-// GRP 0: BM_CRITIC_TD jobs, 1: BM_CRITIC_PI, 2: BM_ACTOR_PI / BM_ACTOR_BC (one instantiation per launch keeps the register
+// GRP 0: BM_CRITIC_TD jobs, 1: BM_CRITIC_PI, 2: BM_ACTOR_PI / BM_ACTOR_BC, 3: BM_GIVEN — the head gradient was written to ws.dout
+// by an earlier kernel, heads up to 8 wide (SAC) (one instantiation per launch keeps the register
 // footprint of each below 128 at 16 waves per workgroup).
 // Latency structure (what matters at B = 128, one workgroup per CU): EVERY global load of the workgroup — the W2 fragment
 // of the MFMA phase, the z2 rows, labels, the other nets' rows, all head parameters, the epilogue's z1 — is issued at
@@ -590,6 +618,9 @@ template <int GRP>
 __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
     __shared__ __attribute__((aligned(16))) float dz2s[RT * LDA2];
     __shared__ __attribute__((aligned(16))) float kred[3 * 4 * 256];  // split-K partial tiles
+    constexpr int IMG = GRP == 3 ? 8 : 4;  // head width of this instantiation's LDS images
+    typedef HeadImage<IMG> Img;
+    constexpr int kHpStride = Img::kStride;
     __shared__ __attribute__((aligned(16))) float hps[(GRP == 0 ? 3 : 1) * kHpStride];
     __shared__ __attribute__((aligned(16))) float c1s[GRP == 2 ? H1 * 6 : 4];  // critic layer 1: g1 be1 W1[:,13..16]
     __shared__ float red[16][4];
@@ -626,7 +657,9 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
     RowReg<H1> cdh, cz;
     float cst0 = 0.f, cst1 = 0.f, cs1 = 0.f, cs2 = 0.f;
     if (live) z.load(J.ws.z2 + R * H2);
-    float4 pv0 = hp_fetch(J.net, J.m, tid), pv1 = make_float4(0.f, 0.f, 0.f, 0.f), pv2 = pv1;
+    Img pv0, pv1, pv2;
+    pv0.fetch(J.net, J.m, tid);
+    float bonus = 0.f, dgiv[GRP == 3 ? 8 : 1] = {};
     if (GRP == 0) {
         if (live) {
             za.load(J.t1.ws.z2 + R * H2);
@@ -635,8 +668,13 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
             lab0 = row[30];
             lab1 = row[31];
         }
-        pv1 = hp_fetch(J.t1.net, J.t1.m, tid);
-        pv2 = hp_fetch(J.t2.net, J.t2.m, tid);
+        pv1.fetch(J.t1.net, J.t1.m, tid);
+        pv2.fetch(J.t2.net, J.t2.m, tid);
+        if (live && J.bonus) bonus = J.bonus[R] * (*J.bonus_scale);  // SAC: + alpha * entropy(s')  SAC/agent.py:205-206
+    }
+    if (GRP == 3 && live) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) dgiv[jj] = jj < J.m.out ? J.ws.dout[R * OW + jj] : 0.0f;
     }
     if (GRP == 1) {
         if (live && J.soft.net) za.load(J.soft.ws.z2 + R * H2);  // same net as J.net: shares the LDS image
@@ -679,10 +717,10 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
     const float st1v = tid < nrow * 2 ? J.ws.st1[(size_t)r0 * 2 + tid] : (tid & 1 ? 1.0f : 0.0f);
     // ---------------- one wait: publish the shared operands in LDS ----------------
     if (tid < RT * 2) st1s[tid] = st1v;
-    hp_store(hps, J.net, J.m, tid, pv0);
+    pv0.store(hps, J.net, J.m, tid);
     if (GRP == 0) {
-        hp_store(hps + kHpStride, J.t1.net, J.t1.m, tid, pv1);
-        hp_store(hps + 2 * kHpStride, J.t2.net, J.t2.m, tid, pv2);
+        pv1.store(hps + kHpStride, J.t1.net, J.t1.m, tid);
+        pv2.store(hps + 2 * kHpStride, J.t2.net, J.t2.m, tid);
     }
     if (GRP == 2 && J.mode == BM_ACTOR_PI) {
         if (tid < 2 * H1) c1s[tid] = c1v[0];
@@ -702,15 +740,20 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
         zero.store_lds(drow);
     } else {
         RowReg<H2> xh, y;
-        float mean, rstd, o[4];
-        head_regs<4>(z, hps, J.m.out, slope, xh, y, mean, rstd, o);
-        float dout[4] = {0.f, 0.f, 0.f, 0.f};
-        if (GRP == 0) {
+        float mean, rstd, o[IMG];
+        head_regs<IMG, IMG>(z, hps, J.m.out, slope, xh, y, mean, rstd, o, J.m.no_ln);
+        float dout[IMG] = {};
+        if (GRP == 3) {  // head gradient supplied by a previous kernel (SAC: min-selected critics, sampled policy)
+#pragma unroll
+            for (int jj = 0; jj < IMG; ++jj) dout[jj] = dgiv[jj < (GRP == 3 ? 8 : 1) ? jj : 0];
+        } else if (GRP == 0) {
             RowReg<H2> xa, ya;
             float m1, s1, q1[1], q2[1];
-            head_regs<1>(za, hps + kHpStride, 1, slope, xa, ya, m1, s1, q1);
-            head_regs<1>(zb, hps + 2 * kHpStride, 1, slope, xa, ya, m1, s1, q2);
-            const float target = lab0 + (J.gamma * fminf(q1[0], q2[0])) * (1.0f - lab1);  // HIRL.py:270-274
+            head_regs<1, IMG>(za, hps + kHpStride, 1, slope, xa, ya, m1, s1, q1, J.t1.m.no_ln);
+            head_regs<1, IMG>(zb, hps + 2 * kHpStride, 1, slope, xa, ya, m1, s1, q2, J.t2.m.no_ln);
+            // HIRL.py:270-274; with `bonus` SAC's r + (1 - d) gamma (min Q' + alpha H')  SAC/agent.py:202-210
+            const float target = J.bonus ? lab0 + (1.0f - lab1) * (J.gamma * (fminf(q1[0], q2[0]) + bonus))
+                                         : lab0 + (J.gamma * fminf(q1[0], q2[0])) * (1.0f - lab1);
             const float diff = o[0] - target;
             dout[0] = 2.0f * diff * A.inv_batch;  // d mse / dq
             part[0] += diff * diff * A.inv_batch;
@@ -720,7 +763,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
             if (J.soft.net) {
                 RowReg<H2> xa, ya;
                 float m1, s1, qs[1];
-                head_regs<1>(za, hps, 1, slope, xa, ya, m1, s1, qs);
+                head_regs<1, IMG>(za, hps, 1, slope, xa, ya, m1, s1, qs, J.m.no_ln);
                 cnt += (qs[0] > o[0]) ? 1 : 0;  // (soft_Q > rl_Q)  HIRL.py:303
             }
         } else if (J.mode == BM_ACTOR_PI) {
@@ -772,6 +815,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
         }
         s1 = wave_sum(s1) * (1.0f / H2);
         s2 = wave_sum(s2) * (1.0f / H2);
+        if (J.m.no_ln) s1 = s2 = 0.0f;  // identity "norm": dz2 = dy2
 #pragma unroll
         for (int i = 0; i < 8; ++i) dx.v[i] = rstd * (dx.v[i] - s1 - xh.v[i] * s2);
         dx.store_lds(drow);
@@ -781,9 +825,9 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
                 J.ws.st2[R * 2] = mean;
                 J.ws.st2[R * 2 + 1] = rstd;
             }
-            if (lane < 4) {
-                J.ws.dout[R * 4 + lane] = dout[lane];
-                if (J.mode != BM_ACTOR_PI) J.ws.outv[R * 4 + lane] = (J.m.out == 4) ? tanhf(o[lane]) : o[lane];
+            if (GRP != 3 && lane < 4) {
+                J.ws.dout[R * OW + lane] = dout[lane < IMG ? lane : 0];
+                if (J.mode != BM_ACTOR_PI) J.ws.outv[R * OW + lane] = (J.m.out == 4) ? tanhf(o[lane < IMG ? lane : 0]) : o[lane < IMG ? lane : 0];
             }
         }
     }
@@ -798,7 +842,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
         for (int w = 0; w < 16; ++w) {
             p0 += red[w][0]; p1 += red[w][1]; p2 += red[w][2]; p3 += red[w][3];
         }
-        if (J.mode == BM_CRITIC_TD) atomicAdd(&A.losses[0], p0);
+        if (J.mode == BM_CRITIC_TD) atomicAdd(&A.losses[J.loss_slot], p0);
         if (J.mode == BM_CRITIC_PI) atomicAdd(&A.losses[3], p3);
         if (J.mode == BM_ACTOR_BC) {
             atomicAdd(&A.losses[2], p2);
@@ -833,8 +877,8 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
                     J.ws.dh1[(size_t)(r0 + row) * H1 + n0 + r] = v;
                     const float xh = (ez1[q] - st1s[row * 2]) * st1s[row * 2 + 1];
                     const float dxh = v * act_d(eg1 * xh + ebe1, slope) * eg1;
-                    p1 = dxh;
-                    p2 = dxh * xh;
+                    p1 = J.m.no_ln ? 0.0f : dxh;
+                    p2 = J.m.no_ln ? 0.0f : dxh * xh;
                 }
                 const float a1 = sum16(p1), a2 = sum16(p2);
                 if (r == 0) {
@@ -850,6 +894,146 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
         }
         STAMP();
         STAMP_FLUSH(16, blockIdx.x == 3 && tid == 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SAC (hirl/agents/SAC): small per-row kernels around the shared fwd_l2 / bwd_l2<3> / wgrad machinery.  One wave per row.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pick8(const float (&o)[8], int i) {
+    return i == 0 ? o[0] : i == 1 ? o[1] : i == 2 ? o[2] : i == 3 ? o[3] : i == 4 ? o[4] : i == 5 ? o[5] : i == 6 ? o[6] : o[7];
+}
+// GaussianPolicy.sample (SAC/model.py:69-82) from the policy's z2 rows: mean, log_std = chunk(head), clamp(log_std, -20, 2),
+// x = mean + exp(log_std) eps, a = tanh(x), entropy = -sum_j (log N(x_j) - log(1 - a_j^2 + 1e-6)).
+struct GaussArgs {
+    const float* net;
+    Mlp m;
+    const float* z2;
+    const float* eps;  // [rows][4] standard-normal draws; nullptr with mode 2 -> Philox; mode 0 ignores it
+    int rows, mode;    // 0: exploit tanh(mean) (agent.py:191-196), 1: sample with eps, 2: sample with Philox(seed; row, call)
+    float* act;        // [rows][4]
+    float* ent;        // [rows] or nullptr
+    float* aux;        // [rows][16] or nullptr: a[4], sigma*eps[4], clamp pass-through mask[4], entropy
+    uint64_t seed;
+    uint32_t row0, call;
+};
+__global__ __launch_bounds__(kThreads) void gauss_head_kernel(GaussArgs A) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= A.rows) return;
+    RowReg<H2> xh, y;
+    float mean_, rstd_, o[8];
+    head_row<8>(A.z2 + (size_t)r * H2, A.net, A.m, 0.0f, xh, y, mean_, rstd_, o);
+    const int j = lane & 3;
+    const float mu = pick8(o, j), ls_raw = pick8(o, 4 + j);
+    const float ls = fminf(fmaxf(ls_raw, -20.0f), 2.0f);  // model.py:65-66
+    const float sd = expf(ls);
+    float e = 0.0f;
+    if (A.mode == 1) e = A.eps[(size_t)r * 4 + j];
+    if (A.mode == 2) {
+        uint32_t u[4];
+        philox4x32_10(A.row0 + (uint32_t)r, A.call, 0x53414331u, 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
+        const float ua = u01(u[j & 2]), ub = u01(u[(j & 2) + 1]);
+        const float rad = sqrtf(-2.0f * logf(ua)), ang = 6.28318530717958647692f * ub;
+        e = (j & 1) ? rad * sinf(ang) : rad * cosf(ang);
+    }
+    const float se = sd * e;
+    const float a = tanhf(A.mode == 0 ? mu : mu + se);
+    // Normal(mean, std).log_prob(x) with x - mean = sd * eps, minus the tanh correction   model.py:77-78
+    const float logp = (-(se * se) / (2.0f * (sd * sd)) - ls - 0.91893853320467274f) - logf(1.0f - a * a + 1e-6f);
+    float h = lane < 4 ? -logp : 0.0f;
+    h = sum16(h);  // lanes 0..3 sit in the first 16-lane row
+    if (lane < 4) {
+        A.act[(size_t)r * 4 + j] = a;
+        if (A.aux) {
+            float* x = A.aux + (size_t)r * 16;
+            x[j] = a;
+            x[4 + j] = se;
+            x[8 + j] = (ls_raw >= -20.0f && ls_raw <= 2.0f) ? 1.0f : 0.0f;
+            if (lane == 0) x[12] = h;
+        }
+    }
+    if (lane == 0 && A.ent) A.ent[r] = h;
+}
+
+// min(Q1, Q2)(s, a~) for the policy loss (SAC/agent.py:380-383): writes each head's output gradient -w/B (w = 1 for the smaller
+// head, 1/2 each on a tie: torch.min's subgradient) and accumulates the -min(Q)/B part of the policy loss.
+struct QSelArgs {
+    const float* net1;
+    const float* net2;
+    Mlp m;
+    Slot s1, s2;
+    int rows;
+    float inv_batch;
+    float* losses;
+};
+__global__ __launch_bounds__(kThreads) void q_select_kernel(QSelArgs A) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= A.rows) return;
+    RowReg<H2> xh, y;
+    float mean_, rstd_, q1[1], q2[1];
+    head_row<1>(A.s1.z2 + (size_t)r * H2, A.net1, A.m, 0.0f, xh, y, mean_, rstd_, q1);
+    if (lane == 0) { A.s1.st2[r * 2] = mean_; A.s1.st2[r * 2 + 1] = rstd_; }
+    head_row<1>(A.s2.z2 + (size_t)r * H2, A.net2, A.m, 0.0f, xh, y, mean_, rstd_, q2);
+    if (lane == 0) {
+        A.s2.st2[r * 2] = mean_; A.s2.st2[r * 2 + 1] = rstd_;
+        const float w1 = q1[0] < q2[0] ? 1.0f : (q1[0] == q2[0] ? 0.5f : 0.0f);
+        A.s1.dout[(size_t)r * OW] = -w1 * A.inv_batch;
+        A.s2.dout[(size_t)r * OW] = -(1.0f - w1) * A.inv_batch;
+        atomicAdd(&A.losses[2], -fminf(q1[0], q2[0]) * A.inv_batch);
+    }
+}
+
+// Gradient of the policy loss mean(-min Q - alpha H) (SAC/agent.py:404-406) wrt the policy head's 8 pre-activations: the
+// critics' input gradients wrt the action (both heads; the unselected one carries zeros) chained through a = tanh(mean + sigma eps),
+// plus the entropy term.  Also accumulates -alpha H / B (policy loss) and H / B (mean entropy, for the alpha step).
+struct PDoutArgs {
+    const float* q1net;
+    const float* q2net;
+    Mlp mq;
+    Slot c1, c2, pol;
+    const float* aux;
+    const float* alpha_state;  // [4]: log_alpha, m, v, alpha
+    int rows;
+    float inv_batch;
+    float* losses;
+};
+__global__ __launch_bounds__(kThreads) void policy_dout_kernel(PDoutArgs A) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= A.rows) return;
+    float da[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int hsel = 0; hsel < 2; ++hsel) {
+        const Slot& C = hsel ? A.c2 : A.c1;
+        const float* net = hsel ? A.q2net : A.q1net;
+        RowReg<H1> dh, z;
+        dh.load(C.dh1 + (size_t)r * H1);
+        z.load(C.z1 + (size_t)r * H1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {  // hidden unit k = lane*4 + c; plain stack: dz1 = dh1 * relu'(z1)
+            const int k = lane * 4 + c;
+            const float dz1 = dh.v[c] * act_d(z.v[c], 0.0f);
+            const float* w = net + A.mq.W1() + k * A.mq.in + 13;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) da[jj] += dz1 * w[jj];
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) da[jj] = wave_sum(da[jj]);
+    const float alpha = A.alpha_state[3];
+    if (lane < 4) {
+        const float* x = A.aux + (size_t)r * 16;
+        const float a = x[lane], se = x[4 + lane], mask = x[8 + lane];
+        const float t = 1.0f - a * a;
+        const float dHdx = (-2.0f * a * t) / (t + 1e-6f);
+        const float dLdx = (lane == 0 ? da[0] : lane == 1 ? da[1] : lane == 2 ? da[2] : da[3]) * t - alpha * A.inv_batch * dHdx;
+        A.pol.dout[(size_t)r * OW + lane] = dLdx;
+        A.pol.dout[(size_t)r * OW + 4 + lane] = (dLdx * se - alpha * A.inv_batch) * mask;
+        if (lane == 0) {
+            atomicAdd(&A.losses[2], -alpha * x[12] * A.inv_batch);
+            atomicAdd(&A.losses[4], x[12] * A.inv_batch);
+        }
     }
 }
 
@@ -897,10 +1081,10 @@ constexpr int kWgPerJob = kWgTilesPerBlock + kWgVecWgs + kWgL1Wgs;
 constexpr int kWgRowChunk = 256;                         // rows whose per-row scalars are staged in LDS at a time
 
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
-    __shared__ __attribute__((aligned(16))) float lds[kWgRowChunk * XP + kWgRowChunk * 8 + 4 * 64 * 20];
+    __shared__ __attribute__((aligned(16))) float lds[kWgRowChunk * XP + kWgRowChunk * 12 + 4 * 64 * 20];
     float* xs = lds;                          // [chunk][XP]   inputs (layer-1 job)
-    float* rinfo = lds + kWgRowChunk * XP;    // [chunk][8]    per-row scalars
-    float* red = rinfo + kWgRowChunk * 8;     // [4][64][20]   cross-row-group reduction
+    float* rinfo = lds + kWgRowChunk * XP;    // [chunk][<=12] per-row scalars
+    float* red = rinfo + kWgRowChunk * 12;    // [4][64][20]   cross-row-group reduction
 
     const int j = blockIdx.x / kWgPerJob, b = blockIdx.x % kWgPerJob;
     if (j >= A.njobs) return;
@@ -949,12 +1133,14 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
     const int rg = wave;  // row group: rows rg, rg + 4, ...
     if (b < kWgTilesPerBlock + kWgVecWgs) {
         // column n: db2, dg2, dbe2, dW3[j][n] (+ db3 by the first workgroup); 64 columns x 4 row groups
+        constexpr int RP = 12;  // rinfo pitch: mean, rstd, dout[0..7], pad
         const int vb = b - kWgTilesPerBlock;
         const int n = vb * 64 + lane;
         const float g2 = J.net[J.m.g2() + n], be2 = J.net[J.m.be2() + n];
-        float w3[4];
-        for (int jj = 0; jj < 4; ++jj) w3[jj] = jj < J.m.out ? J.net[J.m.W3() + jj * H2 + n] : 0.0f;
-        float db2 = 0.f, dg = 0.f, dbe = 0.f, dw3[4] = {0.f, 0.f, 0.f, 0.f}, db3 = 0.f;
+        float w3[OW];
+#pragma unroll
+        for (int jj = 0; jj < OW; ++jj) w3[jj] = jj < J.m.out ? J.net[J.m.W3() + jj * H2 + n] : 0.0f;
+        float db2 = 0.f, dg = 0.f, dbe = 0.f, dw3[OW] = {}, db3 = 0.f;
         for (int s = 0; s < J.nslots; ++s) {
             const Slot& S = J.ws[s];
             const float sc = scale[s];
@@ -962,10 +1148,12 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
                 const int nr = min(kWgRowChunk, J.rows[s] - c0);
                 __syncthreads();
                 for (int e = tid; e < nr; e += kThreads) {
-                    rinfo[e * 8] = S.st2[(size_t)(c0 + e) * 2];
-                    rinfo[e * 8 + 1] = S.st2[(size_t)(c0 + e) * 2 + 1];
-                    const float4 d4 = *reinterpret_cast<const float4*>(S.dout + (size_t)(c0 + e) * 4);
-                    rinfo[e * 8 + 2] = d4.x; rinfo[e * 8 + 3] = d4.y; rinfo[e * 8 + 4] = d4.z; rinfo[e * 8 + 5] = d4.w;
+                    rinfo[e * RP] = S.st2[(size_t)(c0 + e) * 2];
+                    rinfo[e * RP + 1] = S.st2[(size_t)(c0 + e) * 2 + 1];
+                    const float4 d4 = *reinterpret_cast<const float4*>(S.dout + (size_t)(c0 + e) * OW);
+                    const float4 d5 = *reinterpret_cast<const float4*>(S.dout + (size_t)(c0 + e) * OW + 4);
+                    rinfo[e * RP + 2] = d4.x; rinfo[e * RP + 3] = d4.y; rinfo[e * RP + 4] = d4.z; rinfo[e * RP + 5] = d4.w;
+                    rinfo[e * RP + 6] = d5.x; rinfo[e * RP + 7] = d5.y; rinfo[e * RP + 8] = d5.z; rinfo[e * RP + 9] = d5.w;
                 }
                 __syncthreads();
                 for (int rb = rg; rb < nr; rb += 64) {  // 16 rows per thread per block, all loads in flight together
@@ -981,36 +1169,41 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
                     for (int i = 0; i < 16; ++i) {
                         const int r = rb + 4 * i;
                         if (r < nr) {
-                            const float* ri = rinfo + r * 8;
+                            const float* ri = rinfo + r * RP;
                             const float xh = (zv[i] - ri[0]) * ri[1];
                             const float y = g2 * xh + be2;
-                            const float dh2 = (ri[2] * w3[0] + ri[3] * w3[1]) + (ri[4] * w3[2] + ri[5] * w3[3]);
+                            float dh2 = (ri[2] * w3[0] + ri[3] * w3[1]) + (ri[4] * w3[2] + ri[5] * w3[3]);
+                            if (J.m.out > 4) dh2 += (ri[6] * w3[4] + ri[7] * w3[5]) + (ri[8] * w3[6] + ri[9] * w3[7]);
                             const float dy = dh2 * act_d(y, slope);
                             const float h2 = act_f(y, slope);
                             db2 += sc * dv[i];
                             dbe += sc * dy;
                             dg += sc * dy * xh;
 #pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) dw3[jj] += sc * ri[2 + jj] * h2;
+                            for (int jj = 0; jj < OW; ++jj) dw3[jj] += sc * ri[2 + jj] * h2;
                         }
                     }
                 }
                 if (vb == 0 && tid < J.m.out)
-                    for (int r = 0; r < nr; ++r) db3 += sc * rinfo[r * 8 + 2 + tid];
+                    for (int r = 0; r < nr; ++r) db3 += sc * rinfo[r * RP + 2 + tid];
             }
         }
         STAMP();
         float* my = red + (rg * 64 + lane) * 20;
-        my[0] = db2; my[1] = dg; my[2] = dbe; my[3] = dw3[0]; my[4] = dw3[1]; my[5] = dw3[2]; my[6] = dw3[3];
+        my[0] = db2; my[1] = dg; my[2] = dbe;
+#pragma unroll
+        for (int jj = 0; jj < OW; ++jj) my[3 + jj] = dw3[jj];
         __syncthreads();
         if (tid < 64) {
-            float v[7];
+            float v[3 + OW];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) v[i] = (red[tid * 20 + i] + red[(64 + tid) * 20 + i]) + (red[(128 + tid) * 20 + i] + red[(192 + tid) * 20 + i]);
+            for (int i = 0; i < 3 + OW; ++i) v[i] = (red[tid * 20 + i] + red[(64 + tid) * 20 + i]) + (red[(128 + tid) * 20 + i] + red[(192 + tid) * 20 + i]);
             J.grad[J.m.b2() + n] = v[0];
-            J.grad[J.m.g2() + n] = v[1];
-            J.grad[J.m.be2() + n] = v[2];
-            for (int jj = 0; jj < J.m.out; ++jj) J.grad[J.m.W3() + jj * H2 + n] = v[3 + jj];
+            J.grad[J.m.g2() + n] = J.m.no_ln ? 0.0f : v[1];
+            J.grad[J.m.be2() + n] = J.m.no_ln ? 0.0f : v[2];
+#pragma unroll
+            for (int jj = 0; jj < OW; ++jj)
+                if (jj < J.m.out) J.grad[J.m.W3() + jj * H2 + n] = v[3 + jj];
         }
         if (vb == 0 && tid < J.m.out) J.grad[J.m.b3() + tid] = db3;
         STAMP();
@@ -1080,8 +1273,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
 #pragma unroll
             for (int i = 0; i < 20; ++i) v[i] = (red[tid * 20 + i] + red[(64 + tid) * 20 + i]) + (red[(128 + tid) * 20 + i] + red[(192 + tid) * 20 + i]);
             J.grad[J.m.b1() + k] = v[0];
-            J.grad[J.m.g1() + k] = v[1];
-            J.grad[J.m.be1() + k] = v[2];
+            J.grad[J.m.g1() + k] = J.m.no_ln ? 0.0f : v[1];
+            J.grad[J.m.be1() + k] = J.m.no_ln ? 0.0f : v[2];
             for (int i = 0; i < in; ++i) J.grad[J.m.W1() + k * in + i] = v[3 + i];
         }
         STAMP();
@@ -1100,9 +1293,21 @@ struct AdamArgs {
     int finish_actor;
     int w_kind; float w_given, warm, inv_batch;
     const int* soft_count; float* wstate; float* losses; int use_bc;
+    // SAC policy step: also the log-alpha step (SAC/agent.py:322-325, 408-414)
+    float* alpha_state;  // [4]: log_alpha, m, v, alpha; nullptr = not a SAC policy step
+    float target_entropy, alpha_step_size;
 };
 
 __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
+    if (A.alpha_state && blockIdx.x == 0 && threadIdx.x == 0) {
+        const float mean_h = A.losses[4];
+        float la = A.alpha_state[0], m = A.alpha_state[1], v = A.alpha_state[2];
+        A.losses[3] = -(la * (A.target_entropy - mean_h));  // entropy_loss with the log_alpha BEFORE its step
+        adam_update(la, m, v, mean_h - A.target_entropy, A.b1, A.b2, A.eps, A.alpha_step_size, A.bc2_sqrt);
+        A.alpha_state[0] = la; A.alpha_state[1] = m; A.alpha_state[2] = v;
+        A.alpha_state[3] = expf(la);  // self.alpha = self.log_alpha.exp()
+        A.losses[5] = A.alpha_state[3];
+    }
     if (A.finish_actor && blockIdx.x == 0 && threadIdx.x == 0) {
         if (A.use_bc) {
             const float w = effective_w(A.w_kind, A.w_given, A.warm, A.inv_batch, A.soft_count, A.wstate);
@@ -1234,7 +1439,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-constexpr size_t kSlotFloats = XP + H1 + 2 + H1 + H2 + 2 + 4 + H2 + H1 + 4 + 8;  // per row
+constexpr size_t kSlotFloats = XP + H1 + 2 + H1 + H2 + 2 + OW + H2 + H1 + OW + 8;  // per row
 
 Slot carve_slot(float* base, int rows) {
     Slot s;
@@ -1245,10 +1450,10 @@ Slot carve_slot(float* base, int rows) {
     s.h1 = p; p += (size_t)rows * H1;
     s.z2 = p; p += (size_t)rows * H2;
     s.st2 = p; p += (size_t)rows * 2;
-    s.outv = p; p += (size_t)rows * 4;
+    s.outv = p; p += (size_t)rows * OW;
     s.dz2 = p; p += (size_t)rows * H2;
     s.dh1 = p; p += (size_t)rows * H1;
-    s.dout = p; p += (size_t)rows * 4;
+    s.dout = p; p += (size_t)rows * OW;
     s.lnp = p; p += (size_t)rows * 8;
     return s;
 }
@@ -1274,8 +1479,10 @@ int bwd_blocks(const BwdArgs& a) {
     return n;
 }
 
-const Mlp kActor{13, 4};
-const Mlp kQ{17, 1};
+const Mlp kActor{13, 4, 0};
+const Mlp kQ{17, 1, 0};
+const Mlp kPolicy{13, 8, 1};  // SAC GaussianPolicy: Linear-ReLU stack, head = mean ++ log_std (SAC/model.py:58-60)
+const Mlp kQs{17, 1, 1};      // SAC Q head (SAC/model.py:21-23)
 
 }  // namespace
 
@@ -1578,6 +1785,195 @@ int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int
     }
     HX_CHECK_LAUNCH("hx_bc_train_actor");
     return hx_adam(N, Hy, 2, step, 1.0f, 0, 0.0f, 0.0f, B, stream);
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * SAC (hirl/agents/SAC/agent.py, the non-imitative branch train_sac.py uses).
+ * Slots: 0 policy(s'), 1 policy(s), 2/3 Q1/Q2(s, a), 4/5 target Q1/Q2(s', a'), 6/7 Q1/Q2(s, a~)
+ * ------------------------------------------------------------------------------------------------------------------ */
+enum { SS_PN = 0, SS_PC, SS_Q1, SS_Q2, SS_T1, SS_T2, SS_Q1P, SS_Q2P };
+
+int hx_sac_policy_param_count(void) { return kPolicy.padded(); }
+int64_t hx_sac_workspace_floats(int32_t batch) { return hx_hirl_workspace_floats(batch) + 32 * (int64_t)batch; }
+
+struct SacAux {
+    float* act_n; float* ent_n; float* act_c; float* aux_c;
+};
+static SacAux sac_aux(const HxSacNets* N, int B) {
+    float* p = N->ws + (size_t)S_COUNT * kSlotFloats * B;
+    return SacAux{p, p + 4 * B, p + 5 * B, p + 9 * B};  // [B][4], [B], [B][4], [B][16]
+}
+static void sac_slots(const HxSacNets* N, int B, Slot* s) {
+    for (int i = 0; i < S_COUNT; ++i) s[i] = carve_slot(N->ws + (size_t)i * kSlotFloats * B, B);
+}
+
+/* SacAgent.explore / exploit (SAC/agent.py:183-196) for `rows` observations.  mode 0: exploit = tanh(mean); 1: sample with the
+ * standard-normal draws eps[rows][4]; 2: sample with Philox(seed; row0 + row, call).  ws: hx_act_workspace_floats(rows). */
+int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps, uint64_t seed,
+               uint32_t row0, uint32_t call, float* ws, void* stream) {
+    HX_REQUIRE(policy && obs && actions && ws && rows > 0 && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act: bad arguments");
+    FwdArgs F{};
+    F.njobs = 1; F.slope = 0.0f;
+    FwdJob& J = F.job[0];
+    J.net = policy; J.m = kPolicy; J.src = RowSrc{obs, nullptr, nullptr, 0, 13}; J.rows = (int)rows;
+    J.ws = Slot{}; J.ws.z2 = ws;
+    launch_fwd(F, (hipStream_t)stream);
+    GaussArgs G{policy, kPolicy, ws, eps, (int)rows, mode, actions, nullptr, nullptr, seed, row0, call};
+    hipLaunchKernelGGL(gauss_head_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, G);
+    HX_CHECK_LAUNCH("hx_sac_act");
+    return 0;
+}
+
+/* Critic half of SacAgent.learn (SAC/agent.py:278-313): [Polyak of the target critics first when polyak_first], a', H' =
+ * policy.sample(s') with eps_next, y = r + (1 - d) gamma (min Q_target(s', a') + alpha H'), q1_loss / q2_loss -> losses[0..1],
+ * grad_critic.  Also evaluates policy(s) for the policy half.  Follow with hx_sac_adam(which = 0). */
+int hx_sac_critic_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, int32_t polyak_first, void* stream) {
+    HX_REQUIRE(N && Bt && Hy && Bt->rows && Bt->eps_next && Bt->eps_cur && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_sac_critic_grads: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = Bt->batch;
+    Slot s[S_COUNT];
+    sac_slots(N, B, s);
+    const SacAux X = sac_aux(N, B);
+    const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
+    const int nq = 2 * kQs.padded();
+    if (polyak_first)  // soft_update(critic_target, critic) BEFORE the update, agent.py:278-279
+        hipLaunchKernelGGL(polyak_kernel, dim3((nq / 4 + kThreads) / kThreads), dim3(kThreads), 0, st, N->target_critic, N->critic, nq, Hy->tau);
+    const float* q1 = N->critic; const float* q2 = N->critic + kQs.padded();
+    const float* t1 = N->target_critic; const float* t2 = N->target_critic + kQs.padded();
+    {   // policy(s'), policy(s), Q1/Q2(s, a)
+        FwdArgs F{};
+        F.njobs = 4; F.slope = 0.0f;
+        F.zero_f = N->losses; F.zero_nf = 5;
+        F.job[0] = FwdJob{N->policy, kPolicy, src, 17, 0, Head{}, nullptr, 0.f, s[SS_PN], B, 0};
+        F.job[1] = FwdJob{N->policy, kPolicy, src, 0, 0, Head{}, nullptr, 0.f, s[SS_PC], B, 1};
+        F.job[2] = FwdJob{q1, kQs, src, 0, 0, Head{}, nullptr, 0.f, s[SS_Q1], B, 1};
+        F.job[3] = FwdJob{q2, kQs, src, 0, 0, Head{}, nullptr, 0.f, s[SS_Q2], B, 1};
+        launch_fwd(F, st);
+    }
+    {   // a', H' = policy.sample(s')
+        GaussArgs G{N->policy, kPolicy, s[SS_PN].z2, Bt->eps_next, B, 1, X.act_n, X.ent_n, nullptr, 0, 0, 0};
+        hipLaunchKernelGGL(gauss_head_kernel, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, st, G);
+    }
+    {   // target Q1/Q2 (s', a')
+        FwdArgs F{};
+        F.njobs = 2; F.slope = 0.0f;
+        F.job[0] = FwdJob{t1, kQs, src, 17, 3, Head{}, X.act_n, 0.f, s[SS_T1], B, 0};
+        F.job[1] = FwdJob{t2, kQs, src, 17, 3, Head{}, X.act_n, 0.f, s[SS_T2], B, 0};
+        launch_fwd(F, st);
+    }
+    {   // y, losses, dq, dh1
+        BwdArgs G{};
+        G.njobs = 2; G.slope = 0.0f; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = nullptr;
+        for (int h = 0; h < 2; ++h) {
+            BwdJob& J = G.job[h];
+            J = BwdJob{};
+            J.net = h ? q2 : q1; J.m = kQs; J.ws = s[SS_Q1 + h]; J.rows = B; J.mode = BM_CRITIC_TD;
+            J.t1 = Head{t1, kQs, s[SS_T1]}; J.t2 = Head{t2, kQs, s[SS_T2]}; J.src = src; J.gamma = Hy->gamma;
+            J.bonus = X.ent_n; J.bonus_scale = N->alpha_state + 3; J.loss_slot = h;
+        }
+        hipLaunchKernelGGL(bwd_l2_kernel<0>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+    }
+    {
+        WgArgs W{};
+        W.njobs = 2; W.slope = 0.0f; W.w_kind = 0; W.inv_batch = 1.0f / B; W.soft_count = nullptr; W.wstate = nullptr;
+        for (int h = 0; h < 2; ++h) {
+            WgJob& J = W.job[h];
+            J = WgJob{};
+            J.net = h ? q2 : q1; J.grad = N->grad_critic + h * kQs.padded(); J.m = kQs;
+            J.ws[0] = s[SS_Q1 + h]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
+        }
+        hipLaunchKernelGGL(wgrad_kernel, dim3(W.njobs * kWgPerJob), dim3(kThreads), 0, st, W);
+    }
+    HX_CHECK_LAUNCH("hx_sac_critic_grads");
+    return 0;
+}
+
+/* Policy half (SAC/agent.py:315-319, 376-406): a~, H = policy.sample(s) with eps_cur, Q1/Q2(s, a~) with the UPDATED critics,
+ * policy_loss = mean(-min Q - alpha H) -> losses[2], mean entropy -> losses[4], grad_policy.  Follow with hx_sac_adam(which = 1). */
+int hx_sac_policy_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, void* stream) {
+    HX_REQUIRE(N && Bt && Hy && Bt->rows && Bt->eps_cur && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_sac_policy_grads: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = Bt->batch;
+    Slot s[S_COUNT];
+    sac_slots(N, B, s);
+    const SacAux X = sac_aux(N, B);
+    const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
+    const float* q1 = N->critic; const float* q2 = N->critic + kQs.padded();
+    {
+        GaussArgs G{N->policy, kPolicy, s[SS_PC].z2, Bt->eps_cur, B, 1, X.act_c, nullptr, X.aux_c, 0, 0, 0};
+        hipLaunchKernelGGL(gauss_head_kernel, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, st, G);
+    }
+    {
+        FwdArgs F{};
+        F.njobs = 2; F.slope = 0.0f;
+        F.job[0] = FwdJob{q1, kQs, src, 0, 3, Head{}, X.act_c, 0.f, s[SS_Q1P], B, 1};
+        F.job[1] = FwdJob{q2, kQs, src, 0, 3, Head{}, X.act_c, 0.f, s[SS_Q2P], B, 1};
+        launch_fwd(F, st);
+    }
+    {
+        QSelArgs Q{q1, q2, kQs, s[SS_Q1P], s[SS_Q2P], B, 1.0f / B, N->losses};
+        hipLaunchKernelGGL(q_select_kernel, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, st, Q);
+    }
+    {   // both critics backward down to dh1 with the given head gradients
+        BwdArgs G{};
+        G.njobs = 2; G.slope = 0.0f; G.inv_batch = 1.0f / B; G.losses = N->losses;
+        for (int h = 0; h < 2; ++h) {
+            BwdJob& J = G.job[h];
+            J = BwdJob{};
+            J.net = h ? q2 : q1; J.m = kQs; J.ws = s[SS_Q1P + h]; J.rows = B; J.mode = BM_GIVEN;
+        }
+        hipLaunchKernelGGL(bwd_l2_kernel<3>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+    }
+    {
+        PDoutArgs P{q1, q2, kQs, s[SS_Q1P], s[SS_Q2P], s[SS_PC], X.aux_c, N->alpha_state, B, 1.0f / B, N->losses};
+        hipLaunchKernelGGL(policy_dout_kernel, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, st, P);
+    }
+    {
+        BwdArgs G{};
+        G.njobs = 1; G.slope = 0.0f; G.inv_batch = 1.0f / B; G.losses = N->losses;
+        BwdJob& J = G.job[0];
+        J = BwdJob{};
+        J.net = N->policy; J.m = kPolicy; J.ws = s[SS_PC]; J.rows = B; J.mode = BM_GIVEN;
+        hipLaunchKernelGGL(bwd_l2_kernel<3>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+    }
+    {
+        WgArgs W{};
+        W.njobs = 1; W.slope = 0.0f; W.w_kind = 0; W.inv_batch = 1.0f / B;
+        WgJob& J = W.job[0];
+        J = WgJob{};
+        J.net = N->policy; J.grad = N->grad_policy; J.m = kPolicy; J.ws[0] = s[SS_PC]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
+        hipLaunchKernelGGL(wgrad_kernel, dim3(kWgPerJob), dim3(kThreads), 0, st, W);
+    }
+    HX_CHECK_LAUNCH("hx_sac_policy_grads");
+    return 0;
+}
+
+/* Adam (torch defaults) for SAC.  which 0: q1_optim + q2_optim over the flat critic (SAC/agent.py:310-313); which 1:
+ * policy_optim, followed in the same launch by the log-alpha step of alpha_optim with the mean entropy in losses[4]
+ * (SAC/agent.py:318-325).  step: 1-based (all four optimisers step once per learn()).  grad_scale: 1/world after a SUM. */
+int hx_sac_adam(const HxSacNets* N, const HxHyper* Hy, int32_t which, int32_t step, float grad_scale, float target_entropy, void* stream) {
+    HX_REQUIRE(N && Hy && step >= 1 && (which == 0 || which == 1), "hx_sac_adam: bad arguments");
+    const double b1 = 0.9, b2 = 0.999;
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    AdamArgs A{};
+    A.n = which == 0 ? 2 * kQs.padded() : kPolicy.padded();
+    A.p = which == 0 ? N->critic : N->policy;
+    A.g = which == 0 ? N->grad_critic : N->grad_policy;
+    A.m = which == 0 ? N->m_critic : N->m_policy;
+    A.v = which == 0 ? N->v_critic : N->v_policy;
+    A.b1 = (float)b1; A.b2 = (float)b2; A.eps = 1e-8f;
+    A.step_size = (float)((which == 0 ? Hy->lr_critic : Hy->lr_actor) / bc1);
+    A.bc2_sqrt = (float)sqrt(bc2);
+    A.gscale = grad_scale;
+    A.losses = N->losses;
+    if (which == 1) {
+        A.alpha_state = N->alpha_state;
+        A.target_entropy = target_entropy;
+        A.alpha_step_size = (float)(Hy->lr_actor / bc1);
+    }
+    hipLaunchKernelGGL(adam_kernel, dim3((A.n / 4 + kThreads) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, A);
+    HX_CHECK_LAUNCH("hx_sac_adam");
+    return 0;
 }
 
 }  // extern "C"

@@ -197,6 +197,46 @@ int hx_sample_batch(const uint64_t* total, int64_t cap, const float* ring, const
                     uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc, float* noise, float* rows, float* bc_rows,
                     void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * SAC (hirl/agents/SAC, the non-imitative branch train_sac.py uses).  Networks are the plain Linear-ReLU stacks of the
+ * un-vendored rltorch builder (SAC/model.py:21,58): policy 13 -> 256 -> 512 -> 8 (mean ++ log_std), Q heads 17 -> 256 -> 512
+ * -> 1.  They use the SAME flat block layout as above; the LayerNorm slots hold (1, 0) and are never updated.
+ * hx_sac_policy_param_count() floats for the policy, hx_critic_param_count() for the twinned Q.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct HxSacNets {
+    float* policy; float* critic; float* target_critic;
+    float* grad_policy; float* grad_critic;
+    float* m_policy; float* v_policy; float* m_critic; float* v_critic;
+    float* losses;      /* [8]: q1_loss, q2_loss, policy_loss, entropy_loss, mean entropy, alpha */
+    float* alpha_state; /* [4]: log_alpha, its Adam m and v, alpha = exp(log_alpha)  (SAC/agent.py:106-108) */
+    float* ws;          /* hx_sac_workspace_floats(batch) */
+} HxSacNets;
+
+typedef struct HxSacBatch {
+    const float* rows;     /* [batch][HX_ROW_WORDS] compact minibatch (hx_sample_batch) */
+    int32_t batch;         /* multiple of 16 */
+    const float* eps_next; /* [batch][4] standard-normal draws of policy.sample(next_states) (SAC/agent.py:204) */
+    const float* eps_cur;  /* [batch][4] draws of policy.sample(states) in calc_policy_loss (SAC/agent.py:380) */
+} HxSacBatch;
+
+int hx_sac_policy_param_count(void);
+int64_t hx_sac_workspace_floats(int32_t batch);
+/* SacAgent.explore / exploit (SAC/agent.py:183-196): mode 0 exploit = tanh(mean); 1 sample with eps[rows][4]; 2 sample with
+ * Philox4x32-10(seed; row0 + row, call).  ws: hx_act_workspace_floats(rows). */
+int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps,
+               uint64_t seed, uint32_t row0, uint32_t call, float* ws, void* stream);
+/* SacAgent.learn (SAC/agent.py:276-327) in the stages a sharded run separates:
+ *   hx_sac_critic_grads   [soft_update of the target critics first on every 3rd call :278-279]; target y = r + (1-d) gamma
+ *                         (min Q_target(s', a') + alpha H') :202-210; q1_loss, q2_loss :361-374 -> losses[0..1]; grad_critic
+ *   hx_sac_adam(0)        q1_optim.step(), q2_optim.step() :310-313                                  [after all-reduce]
+ *   hx_sac_policy_grads   policy_loss = mean(-min Q(s, a~) - alpha H) with the updated critics :376-406 -> losses[2], grad_policy
+ *   hx_sac_adam(1)        policy_optim.step() :318-319, then entropy_loss and alpha_optim.step() :322-325,408-414 */
+int hx_sac_critic_grads(const HxSacNets* nets, const HxSacBatch* batch, const HxHyper* hyper, int32_t polyak_first, void* stream);
+int hx_sac_policy_grads(const HxSacNets* nets, const HxSacBatch* batch, const HxHyper* hyper, void* stream);
+int hx_sac_adam(const HxSacNets* nets, const HxHyper* hyper, int32_t which, int32_t step, float grad_scale, float target_entropy,
+                void* stream);
+
 #ifdef __cplusplus
 }
 #endif
