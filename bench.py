@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     p.add_argument("--batch", type=int, default=128)
     p.add_argument("--scenario", default="straight_line")
+    p.add_argument("--agent", default="hirl", choices=["hirl", "sac"], help="sac: BASELINE.json configs[2] (use --envs 16384 --scenario serpentine)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--sweep", action="store_true", help="also sweep the env-step kernel over 4k..4M envs per launch")
@@ -100,8 +101,22 @@ class Loop:
                                      random_reset=True, env_id0=rank * n, replay=self.replay)
         rng = np.random.default_rng(0)  # same networks and expert set on every rank (replicas)
         actor, critic, bc = init_params(rng)
-        self.eng = HirlEngine(batch=args.batch, device=device)
-        self.eng.load_params(actor, critic, bc)
+        self.sac = getattr(args, "agent", "hirl") == "sac"
+        if self.sac:
+            from hirl4ucav_amd.agents.sac_engine import SacEngine
+
+            def seq(p, names, last):
+                return {"0.weight": p[names[0] + ".weight"], "0.bias": p[names[0] + ".bias"], "2.weight": p[names[1] + ".weight"],
+                        "2.bias": p[names[1] + ".bias"], "4.weight": last[0], "4.bias": last[1]}
+
+            w8 = rng.uniform(-0.04, 0.04, (8, 512)).astype(np.float32)
+            self.eng = SacEngine(batch=args.batch, device=device)
+            self.eng.load_params(seq(actor, ("full1", "full2"), (w8, np.zeros(8, np.float32))),
+                                 seq(critic, ("full1", "full2"), (critic["final1.weight"], critic["final1.bias"])),
+                                 seq(critic, ("full3", "full4"), (critic["final2.weight"], critic["final2.bias"])))
+        else:
+            self.eng = HirlEngine(batch=args.batch, device=device)
+            self.eng.load_params(actor, critic, bc)
         es, ea = synthetic_expert(rng)
         # BC table rows (s, a) and the expert replay ring labelled on the GPU (train_all.py:289-306)
         bc_rows = np.zeros((es.shape[0], 32), np.float32)
@@ -126,12 +141,22 @@ class Loop:
         e, env = self.eng, self.env
         if ev:
             ev[0].record()
-        e.act(env.obs, sigma=0.1, seed=1, row0=env.env_id0, out=self.actions)  # actionNoise 0.1, HIRL.py:160
+        if self.sac:
+            e.act(env.obs, seed=1, row0=env.env_id0, out=self.actions)  # SacAgent.explore
+        else:
+            e.act(env.obs, sigma=0.1, seed=1, row0=env.env_id0, out=self.actions)  # actionNoise 0.1, HIRL.py:160
         if ev:
             ev[1].record()
         env.step(self.actions)
         if ev:
             ev[2].record()
+        if self.sac:  # train_sac.py:401-403
+            e.sample(self.replay, seed=2 + self.rank)
+            e.learn()
+            if ev:
+                ev[3].record()
+            self.t += 1
+            return
         e.sample(self.replay, self.expert, self.bc_table, n_main=e.batch - self.expert_num, seed=2 + self.rank)
         # soft weight: estimated at the start of every max_step-long "episode" of vector steps, kept in between
         # (the reference re-estimates at most once per episode)
@@ -253,8 +278,10 @@ def main():
         "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.envs} parallel {args.scenario} envs per GPU, HIRL-soft fp32, 1 learn(B={args.batch}) per vector step "
-                               f"(BASELINE.json configs[1])", "envs_per_gpu": args.envs, "batch": args.batch,
+        "config": {"workload": (f"{args.envs} parallel {args.scenario} envs per GPU, SAC fp32, 1 learn(B={args.batch}) per vector step "
+                                f"(BASELINE.json configs[2])" if args.agent == "sac" else
+                                f"{args.envs} parallel {args.scenario} envs per GPU, HIRL-soft fp32, 1 learn(B={args.batch}) per vector step "
+                                f"(BASELINE.json configs[1])"), "envs_per_gpu": args.envs, "batch": args.batch,
                    "parallelism": f"dp{world}: env shards + replicated nets, RCCL all-reduce of the flat gradients"},
         "update_steps_per_s": round(args.steps / dt, 1),
         "stage_us": {"act(1 kernel)": round(act_us, 2), "env_step(1 kernel)": round(env_us, 2), "sample+learn(6-12 kernels)": round(learn_us, 2)},
@@ -277,7 +304,7 @@ def main():
     if rank == 0:
         if args.sweep:
             res["roofline_env_sweep"] = env_sweep(device)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.agent == "hirl":
             res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -125,9 +125,17 @@ def main(config):
     replay = DeviceReplay(buffer_size, device)
     env = BatchedHarfangEnv(n, scenario=env_type, device=device, seed=seed, max_step=max_step, auto_reset=True,
                             random_reset=config.random, env_id0=rank * n, replay=replay)
-    eng = E.HirlEngine(batch=batch, slope=0.0 if hirl else 0.01, use_bc=hirl, device=device)
+    sac = config.agent == "SAC"
     torch.manual_seed(seed)  # identical initial networks on every rank
-    eng.load_params(init_actor_state_dict(), init_critic_state_dict(), init_actor_state_dict() if hirl else None)
+    if sac:  # train_sac.py:187-215: lr 1e-3, hidden [256, 512], batch 128, target_update_interval 3
+        from .agents import sac_engine as SE
+        from .agents.SAC.agent import _xavier_mlp
+
+        eng = SE.SacEngine(batch=batch, lr=1e-3, device=device)
+        eng.load_params(_xavier_mlp(13, 8), _xavier_mlp(17, 1), _xavier_mlp(17, 1))
+    else:
+        eng = E.HirlEngine(batch=batch, slope=0.0 if hirl else 0.01, use_bc=hirl, device=device)
+        eng.load_params(init_actor_state_dict(), init_critic_state_dict(), init_actor_state_dict() if hirl else None)
     expert_len = bc_len = 0
     expert = bc_table = None
     if hirl:
@@ -165,12 +173,16 @@ def main(config):
     for episode in range(config.episodes):
         w_now, warm = bc_weight_schedule(config.type, episode, config.bc_weight) if hirl else (0.0, 0.0)
         for step in range(max_step):
-            actions = eng.act(env.obs, sigma=0.1, seed=seed + 1, row0=env.env_id0)
+            actions = eng.act(env.obs, seed=seed + 1, row0=env.env_id0) if sac else eng.act(env.obs, sigma=0.1, seed=seed + 1, row0=env.env_id0)
             env.step(actions)
             if step == max_step - 1:
                 break
             expert_num = expert_num_after(expert_num, step, warm_up_rate)
             for _ in range(config.updates_per_step):
+                if sac:  # train_sac.py:401-403 (non-expert branch)
+                    eng.sample(replay, seed=seed + 2 + rank)
+                    eng.learn()
+                    continue
                 eng.sample(replay, expert, bc_table, n_main=batch - expert_num, seed=seed + 2 + rank)
                 eng.learn(bc_weight_now=w_now, bc_warm_up_weight=warm)
                 w_now = None  # afterwards learn()'s own returned weight is fed back (train_all.py:361): the stored device value
@@ -178,9 +190,11 @@ def main(config):
             c, a, b, r_, f, w = eng.losses_host()
             st = env.stats_dict()
             sps = (episode + 1) * max_step * n * world / (time.time() - t0)
-            print(f"Episode {episode + 1}: critic {c:.3f} actor {a:.3f} bc {b:.3f} rl {r_:.3f} bc_weight {w:.4f} | episodes {st['episodes']} "
+            names = ("q1", "q2", "policy", "entropy_loss", "alpha") if sac else ("critic", "actor", "bc", "rl", "bc_weight")
+            vals = (c, a, b, r_, w)
+            print(f"Episode {episode + 1}: " + " ".join(f"{k} {v:.4f}" for k, v in zip(names, vals)) + f" | episodes {st['episodes']} "
                   f"kills {st['kills']} fire-success {st['fire_success_episodes']} | {sps:,.0f} env steps/s", flush=True)
-        if (episode + 1) % checkpoint_rate == 0 and rank == 0:  # VALIDATION, train_all.py:400-402
+        if (episode + 1) % checkpoint_rate == 0 and rank == 0 and not sac:  # VALIDATION, train_all.py:400-402
             mean, std, succ, fire = validate(eng, env_type, 50, max_step, config.random, seed + 12345, device)
             if mean > high_score or succ / 50 >= success_rate or arttir % 5 == 0:
                 tag = checkpoint_tag(arttir, succ, 50, mean)
@@ -196,7 +210,7 @@ def main(config):
 
 def parser():
     p = argparse.ArgumentParser()  # the reference's flags, train_all.py:489-513
-    p.add_argument("--agent", type=str, default="HIRL", choices=["HIRL", "TD3"])
+    p.add_argument("--agent", type=str, default="HIRL", choices=["HIRL", "TD3", "SAC"])  # SAC: the train_sac.py path (D2)
     p.add_argument("--port", type=int, default=None)
     p.add_argument("--type", type=str, default="soft", choices=["soft", "linear", "fixed"])
     p.add_argument("--bc_weight", type=float, default=0.5)

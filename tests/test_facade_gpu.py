@@ -167,3 +167,38 @@ def test_bc_agent_facade_learns_the_expert(tmp_path):
     h.load_bc_actor("Agent1_", str(tmp_path))  # train_all.py:311-312
     np.testing.assert_array_equal(h.bc_actor.state_dict()["full2.weight"].numpy(), agent.actor.state_dict()["full2.weight"].numpy())
     assert agent.chooseActionNoNoise(s[0]).shape == (4,)
+
+
+def test_sac_agent_facade_and_driver(tmp_path, capsys):
+    """agent = SACAgent(observation_space=..., action_space=..., log_dir=..., batch_size=128, lr=1e-3, hidden_units=[256, 512],
+    memory_size=..., gamma=..., tau=...)  (train_sac.py:214-215); memory.append / explore / exploit / learn(False) / save_models;
+    then two short episodes of the vectorised driver with --agent SAC on serpentine envs."""
+    import types
+
+    from hirl4ucav_amd import train_all as T
+    from hirl4ucav_amd.agents.SAC.agent import SacAgent
+
+    box = lambda n: types.SimpleNamespace(shape=(n,), sample=lambda: np.random.uniform(-1, 1, n))  # noqa: E731
+    agent = SacAgent(observation_space=box(13), action_space=box(4), log_dir=str(tmp_path), batch_size=128, lr=1e-3, hidden_units=[256, 512],
+                     memory_size=2e5, gamma=0.99, tau=0.005)
+    data = D.make_data(3)
+    for row in data["replay"][:300]:
+        agent.memory.append(row[0:13], row[13:17], row[30], row[17:30], bool(row[31]), bool(row[31]))
+    assert len(agent.memory) == 300 and len(agent.memory) > agent.batch_size
+    s = data["replay"][0, 0:13]
+    a, b = agent.explore(s), agent.exploit(s)
+    assert a.shape == (4,) and b.shape == (4,) and np.all(np.abs(a) <= 1) and not np.allclose(a, b)
+    for _ in range(4):
+        agent.learn(False)
+    q1, q2, pl, el, ent, alpha = agent.eng.losses_host()
+    assert np.isfinite([q1, q2, pl, el, ent]).all() and 0.99 < alpha < 1.0 and agent.learning_steps == 4
+    agent.save_models("Agent1_0_-5_")
+    assert sorted(os.listdir(agent.model_dir)) == ["critic_Agent1_0_-5_.pth", "critic_target_Agent1_0_-5_.pth", "policy_Agent1_0_-5_.pth"]
+    T.MAX_STEP["serpentine"] = 30
+    try:
+        T.main(T.parser().parse_args(["--agent", "SAC", "--env", "serpentine", "--random", "--seed", "2", "--num_envs", "256", "--episodes", "2",
+                                      "--result_dir", str(tmp_path), "--buffer_size", "65536"]))
+    finally:
+        T.MAX_STEP["serpentine"] = 1500
+    out = capsys.readouterr().out
+    assert "Episode 2:" in out and "alpha" in out and "nan" not in out.lower()
