@@ -341,23 +341,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// act head: actions = clamp(tanh(head(actor)) + noise, -1, 1)  (chooseAction*, HIRL.py:192-212), one wave per row
-// ---------------------------------------------------------------------------------------------------------------
-struct ActArgs {
-    const float* net;
-    Mlp m;
-    const float* z2;
-    int rows;
-    float slope;
-    float* actions;       // [rows][4]
-    const float* noise;   // nullptr, [4] (shared) or [rows][4]
-    int noise_per_row;
-    float sigma;          // > 0 and noise == nullptr: N(0, sigma^2) from Philox(seed; row, call)
-    uint64_t seed;
-    uint32_t row0, call;
-};
-
+// ---- counter-based RNG shared by the acting / sampling kernels ------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -370,30 +354,6 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 __device__ __forceinline__ float u01(uint32_t u) { return ((float)(u >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-
-__global__ __launch_bounds__(kThreads) void act_head_kernel(ActArgs A) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + wave;
-    if (r >= A.rows) return;
-    RowReg<H2> xh, y;
-    float mean, rstd, o[4];
-    head_row<4>(A.z2 + (size_t)r * H2, A.net, A.m, A.slope, xh, y, mean, rstd, o);
-    if (lane < 4) {
-        float a = tanhf(o[lane]);
-        if (A.noise) {
-            a = fminf(fmaxf(a + A.noise[(A.noise_per_row ? (size_t)r * 4 : 0) + lane], -1.0f), 1.0f);
-        } else if (A.sigma > 0.0f) {
-            uint32_t u[4];
-            philox4x32_10(A.row0 + (uint32_t)r, A.call, 0x61637421u, 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
-            // Box-Muller: lanes 0,1 use (u0,u1), lanes 2,3 use (u2,u3)
-            const float ua = u01(u[lane & 2]), ub = u01(u[(lane & 2) + 1]);
-            const float rad = sqrtf(-2.0f * logf(ua)), ang = 6.28318530717958647692f * ub;
-            const float n = (lane & 1) ? rad * sinf(ang) : rad * cosf(ang);
-            a = fminf(fmaxf(a + A.sigma * n, -1.0f), 1.0f);
-        }
-        A.actions[(size_t)r * 4 + lane] = a;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // act_fused: the whole policy for 16 observation rows in ONE workgroup — layer 1 + LN1 (VALU), z2 = h1 W2^T for all 512
