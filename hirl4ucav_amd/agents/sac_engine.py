@@ -129,10 +129,13 @@ class SacEngine:
         _lib.call("hx_sample_batch", None, 0, ring.data_ptr(), None, 0, None, 0, self.batch, self.batch, 0, 0, 0, 0.0, idx.data_ptr(), None,
                   None, self.rows.data_ptr(), None, _lib.stream_ptr())
 
-    def sample(self, replay, seed=0):
-        """memory.sample(batch_size) on the device + the two standard-normal draw sets of the learn() call."""
+    def sample(self, replay, expert=None, n_main=None, seed=0):
+        """memory.sample(batch_size) on the device (E-SAC: batch - expert_num rows from the memory followed by expert_num rows of
+        the expert memory, SAC/agent.py:286-296, train_sac.py:401-403) + the two standard-normal draw sets of the learn() call."""
         self.sample_calls += 1
-        _lib.call("hx_sample_batch", replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(), None, 0, None, 0, self.batch, self.batch,
+        n_main = self.batch if (n_main is None or expert is None) else int(n_main)
+        _lib.call("hx_sample_batch", replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(),
+                  expert.ring.data_ptr() if expert is not None else None, E.len_of(expert), None, 0, self.batch, n_main,
                   1, int(seed), self.sample_calls, 0.0, self._idx.data_ptr(), None, self._noise.data_ptr(), self.rows.data_ptr(), None,
                   _lib.stream_ptr())
         self.eps_next.normal_()

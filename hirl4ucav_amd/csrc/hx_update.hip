@@ -389,6 +389,8 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     const Mlp m = A.m;
     const float slope = A.slope;
     const int u = tid & (H1 - 1), rq = (tid >> 8) * 4;
+    STAMP_DECL;
+    STAMP();
     // all independent operands first
     float xv = 0.0f;
     if (tid < RT * 13) {
@@ -436,6 +438,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         h1s[row * LDA1 + u] = act_f(g1v * ((z1[r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
     }
     __syncthreads();
+    STAMP();
     {   // z2 tiles: columns 16*wave .. and 256 + 16*wave ..
         const int r = lane & 15, g = lane >> 4;
         v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -460,6 +463,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         }
     }
     __syncthreads();
+    STAMP();
     if (wave < nrow) {  // head: wave w owns row w
         const int r = r0 + wave;
         RowReg<H2> xh, y;
@@ -480,6 +484,8 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             A.actions[(size_t)r * 4 + lane] = a;
         }
     }
+    STAMP();
+    STAMP_FLUSH(56, (blockIdx.x == 0 || blockIdx.x == 200) && tid == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -120,7 +120,9 @@ def main(config):
     env_type, n = config.env, config.num_envs
     max_step = MAX_STEP[env_type] * (8 if config.render else 1)
     hirl = config.agent == "HIRL"
-    batch, buffer_size, warm_up_rate, checkpoint_rate = 128, config.buffer_size, 10, 25  # train_all.py:190-208
+    esac = config.agent == "SAC" and config.type == "ESAC"
+    batch, buffer_size, checkpoint_rate = 128, config.buffer_size, 25  # train_all.py:190-208
+    warm_up_rate = 20 if config.agent == "SAC" else 10  # train_sac.py:203 / train_all.py:207
 
     replay = DeviceReplay(buffer_size, device)
     env = BatchedHarfangEnv(n, scenario=env_type, device=device, seed=seed, max_step=max_step, auto_reset=True,
@@ -138,7 +140,7 @@ def main(config):
         eng.load_params(init_actor_state_dict(), init_critic_state_dict(), init_actor_state_dict() if hirl else None)
     expert_len = bc_len = 0
     expert = bc_table = None
-    if hirl:
+    if hirl or esac:
         if config.expert_csv and os.path.exists(config.expert_csv):
             es, ea = read_data(config.expert_csv)
         else:  # no Drive data here (README.md:6,30): synthetic stand-in of the same shape
@@ -155,7 +157,7 @@ def main(config):
         tab = np.zeros((bc_len, 32), np.float32)
         tab[:, 0:13], tab[:, 13:17] = es, ea
         bc_table = torch.from_numpy(tab).to(device)
-        if config.bc_actor and os.path.exists(config.bc_actor):
+        if hirl and config.bc_actor and os.path.exists(config.bc_actor):
             eng.bc_actor.copy_(E.pack(torch.load(config.bc_actor, map_location="cpu"), E.ACTOR_LAYOUT, E.ACTOR_SIZE, device))
 
     # RANDOM EXPLORATION: 20 episodes of uniform actions in the reference (train_all.py:266-282) = 20*maxStep transitions
@@ -167,7 +169,7 @@ def main(config):
     model_dir = os.path.join(log_dir, "model")
     if rank == 0:
         os.makedirs(model_dir, exist_ok=True)
-    expert_num = batch if hirl else 0
+    expert_num = batch if (hirl or esac) else 0
     high_score, success_rate, arttir = -math.inf, 0.0, 1
     t0 = time.time()
     for episode in range(config.episodes):
@@ -179,8 +181,8 @@ def main(config):
                 break
             expert_num = expert_num_after(expert_num, step, warm_up_rate)
             for _ in range(config.updates_per_step):
-                if sac:  # train_sac.py:401-403 (non-expert branch)
-                    eng.sample(replay, seed=seed + 2 + rank)
+                if sac:  # train_sac.py:270-273 (SAC) / :401-403 (E-SAC: expert rows mixed in while expert_num > 0)
+                    eng.sample(replay, expert if esac else None, n_main=batch - expert_num, seed=seed + 2 + rank)
                     eng.learn()
                     continue
                 eng.sample(replay, expert, bc_table, n_main=batch - expert_num, seed=seed + 2 + rank)
@@ -212,7 +214,7 @@ def parser():
     p = argparse.ArgumentParser()  # the reference's flags, train_all.py:489-513
     p.add_argument("--agent", type=str, default="HIRL", choices=["HIRL", "TD3", "SAC"])  # SAC: the train_sac.py path (D2)
     p.add_argument("--port", type=int, default=None)
-    p.add_argument("--type", type=str, default="soft", choices=["soft", "linear", "fixed"])
+    p.add_argument("--type", type=str, default="soft", choices=["soft", "linear", "fixed", "SAC", "ESAC"])  # SAC / ESAC: train_sac.py:440-458
     p.add_argument("--bc_weight", type=float, default=0.5)
     p.add_argument("--model_name", type=str, default="model")
     p.add_argument("--load_model", action="store_true")

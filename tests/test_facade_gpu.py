@@ -198,6 +198,8 @@ def test_sac_agent_facade_and_driver(tmp_path, capsys):
     try:
         T.main(T.parser().parse_args(["--agent", "SAC", "--env", "serpentine", "--random", "--seed", "2", "--num_envs", "256", "--episodes", "2",
                                       "--result_dir", str(tmp_path), "--buffer_size", "65536"]))
+        T.main(T.parser().parse_args(["--agent", "SAC", "--type", "ESAC", "--env", "serpentine", "--seed", "2", "--num_envs", "256", "--episodes", "1",
+                                      "--result_dir", str(tmp_path), "--buffer_size", "65536"]))
     finally:
         T.MAX_STEP["serpentine"] = 1500
     out = capsys.readouterr().out

@@ -17,3 +17,8 @@ for i in range(3):
     assert L.hx_debug_stamps(out.ctypes.data_as(ctypes.c_void_p)) == 0
     print("wgrad(critic) x10ns: tiles: loads+mfma %d store %d | vector: loop %d reduce+store %d | layer1: loop %d reduce+store %d" % (out[33], out[34], out[41], out[42], out[49], out[50]))
     print("fwd (x10ns): W1 issue %d | zero+sync %d | gather+sync %d | z1 %d | stats %d | norm %d | mfma+store %d      bwd: issue+wait %d | prologue %d | lossred %d | mfma %d | epilogue %d" % tuple(out[1:8].tolist() + out[17:22].tolist()))
+for i in range(3):
+    e.act(loop.env.obs, sigma=0.1, seed=1, out=loop.actions)
+    torch.cuda.synchronize()
+    assert L.hx_debug_stamps(out.ctypes.data_as(ctypes.c_void_p)) == 0
+    print("act_fused x10ns (one workgroup of 256): prologue %d | mfma %d | head %d" % tuple(out[57:60].tolist()))
