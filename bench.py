@@ -47,6 +47,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--sweep", action="store_true", help="also sweep the env-step kernel over 4k..4M envs per launch")
+    p.add_argument("--actions", default="policy", choices=["policy", "uniform"],
+                   help="uniform: U(-1,1)^4 actions instead of the live actor (SURVEY.md 8d C2's second run, decoupled from the policy)")
+    p.add_argument("--staged", action="store_true",
+                   help="use the stage-by-stage update path of the sharded build on one rank too (costs of the N > 1 launch sequence)")
     return p.parse_args()
 
 
@@ -102,6 +106,7 @@ class Loop:
         rng = np.random.default_rng(0)  # same networks and expert set on every rank (replicas)
         actor, critic, bc = init_params(rng)
         self.sac = getattr(args, "agent", "hirl") == "sac"
+        self.uniform = getattr(args, "actions", "policy") == "uniform"
         if self.sac:
             from hirl4ucav_amd.agents.sac_engine import SacEngine
 
@@ -117,6 +122,8 @@ class Loop:
         else:
             self.eng = HirlEngine(batch=args.batch, device=device)
             self.eng.load_params(actor, critic, bc)
+            if getattr(args, "staged", False):
+                self.eng.staged = True
         es, ea = synthetic_expert(rng)
         # BC table rows (s, a) and the expert replay ring labelled on the GPU (train_all.py:289-306)
         bc_rows = np.zeros((es.shape[0], 32), np.float32)
@@ -141,7 +148,9 @@ class Loop:
         e, env = self.eng, self.env
         if ev:
             ev[0].record()
-        if self.sac:
+        if self.uniform:  # env.action_space.sample() for every env (train_all.py:272)
+            self.actions.uniform_(-1.0, 1.0)
+        elif self.sac:
             e.act(env.obs, seed=1, row0=env.env_id0, out=self.actions)  # SacAgent.explore
         else:
             e.act(env.obs, sigma=0.1, seed=1, row0=env.env_id0, out=self.actions)  # actionNoise 0.1, HIRL.py:160
@@ -282,6 +291,7 @@ def main():
                                 f"(BASELINE.json configs[2])" if args.agent == "sac" else
                                 f"{args.envs} parallel {args.scenario} envs per GPU, HIRL-soft fp32, 1 learn(B={args.batch}) per vector step "
                                 f"(BASELINE.json configs[1])"), "envs_per_gpu": args.envs, "batch": args.batch,
+                   "actions": args.actions, "update_path": "staged" if (args.staged or world > 1) and args.agent == "hirl" else "one-call",
                    "parallelism": f"dp{world}: env shards + replicated nets, RCCL all-reduce of the flat gradients"},
         "update_steps_per_s": round(args.steps / dt, 1),
         "stage_us": {"act(1 kernel)": round(act_us, 2), "env_step(1 kernel)": round(env_us, 2), "sample+learn(6-12 kernels)": round(learn_us, 2)},

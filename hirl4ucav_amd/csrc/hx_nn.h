@@ -96,27 +96,6 @@ __device__ __forceinline__ v4f tile_a_lds_bt_global(const float* __restrict__ a_
     return acc;
 }
 
-// D[16 x 16] += A[16 x K] * B where A rows are in LDS and B is [K][ldb] row-major in global memory; b_col points at
-// B[0][n0 + r].
-template <int K>
-__device__ __forceinline__ v4f tile_a_lds_b_global(const float* __restrict__ a_lds, int lda, const float* __restrict__ b_col, int ldb, v4f acc) {
-    const int l = threadIdx.x & 63, r = l & 15, g = l >> 4;
-    const float* ap = a_lds + r * lda + 4 * g;
-    const float* bp = b_col + (size_t)(4 * g) * ldb;
-#pragma unroll 2
-    for (int kk = 0; kk < K; kk += 16) {
-        const float4 a4 = *reinterpret_cast<const float4*>(ap + kk);
-        const float* b = bp + (size_t)kk * ldb;
-        const float b0 = b[0], b1 = b[ldb], b2 = b[2 * ldb], b3 = b[3 * ldb];
-        acc = mfma16(a4.x, b0, acc);
-        acc = mfma16(a4.y, b1, acc);
-        acc = mfma16(a4.z, b2, acc);
-        acc = mfma16(a4.w, b3, acc);
-    }
-    return acc;
-}
-
-
 // ---- register-resident B fragments: issued at kernel entry so that their L2/HBM latency overlaps the prologue ------
 template <int K>
 struct BtFrag {  // for tile_a_lds_bt_global's operand: K/16 float4 per lane
@@ -142,7 +121,7 @@ __device__ __forceinline__ v4f tile_a_lds_bt_frag(const float* __restrict__ a_ld
     return acc;
 }
 template <int K>
-struct BFrag {  // for tile_a_lds_b_global's operand: one dword per MFMA
+struct BFrag {  // B is [K][ldb] row-major in global memory, b_col points at B[0][n0 + r]: one dword per MFMA
     float v[K / 4];
     __device__ __forceinline__ void load(const float* __restrict__ b_col, int ldb) {
         const int g = (threadIdx.x & 63) >> 4;

@@ -39,14 +39,6 @@ def device_tables(data):
     return ring, exp, torch.from_numpy(bc).cuda().contiguous()
 
 
-def flat_oracle(p, layout, size):
-    out = np.zeros(size, np.float32)
-    for k, off, shp in layout:
-        v = p[k].detach().numpy() if torch.is_tensor(p[k]) else np.asarray(p[k])
-        out[off:off + v.size] = v.ravel()
-    return out
-
-
 def check_grads(eng_mod, got_flat, oracle_grads, layout, what):
     """Elementwise |diff| <= 1e-4 |g| + 2e-5 max|g|.  A hidden unit whose pre-activation is within fp32 rounding of zero
     for some row is active on one side and not on the other (ReLU's derivative is discontinuous); that moves the handful
