@@ -129,9 +129,4 @@ class SacAgent:
                 self.writer.add_scalar(k, v, self.eng.learning_steps)
 
     def save_models(self, ajan):  # agent.py:440-444
-        sd = self.eng.state_dicts()
-        torch.save({k: v.cpu().clone() for k, v in sd["policy"].items()}, os.path.join(self.model_dir, f"policy_{ajan}.pth"))
-        torch.save({"Q1": {k: v.cpu().clone() for k, v in sd["q1"].items()}, "Q2": {k: v.cpu().clone() for k, v in sd["q2"].items()}},
-                   os.path.join(self.model_dir, f"critic_{ajan}.pth"))
-        torch.save({"Q1": {k: v.cpu().clone() for k, v in sd["q1_target"].items()}, "Q2": {k: v.cpu().clone() for k, v in sd["q2_target"].items()}},
-                   os.path.join(self.model_dir, f"critic_target_{ajan}.pth"))
+        self.eng.save_models(self.model_dir, ajan)

@@ -2,6 +2,7 @@
 host-side sequencing of the hx_sac_* stages.  The networks are the plain Linear-ReLU stacks of the reference's (un-vendored)
 rltorch builder; they reuse the flat MLP-block layout of include/hirl4ucav.h with the LayerNorm slots pinned to (1, 0)."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -111,6 +112,26 @@ class SacEngine:
         return {"policy": unpack_mlp(self.policy, POLICY_BLOCK, 13, 8), "q1": unpack_mlp(self.critic[:Q_SIZE], Q_BLOCK, 17, 1),
                 "q2": unpack_mlp(self.critic[Q_SIZE:], Q_BLOCK, 17, 1), "q1_target": unpack_mlp(self.target_critic[:Q_SIZE], Q_BLOCK, 17, 1),
                 "q2_target": unpack_mlp(self.target_critic[Q_SIZE:], Q_BLOCK, 17, 1)}
+
+    def model_files(self):
+        """What SacAgent.save_models writes (SAC/agent.py:440-444): the state_dicts of GaussianPolicy, TwinnedQNetwork and its
+        target with the reference's key names (SAC/model.py:21,35-38,58: `policy.N.*`, `Q1.Q.N.*`, `Q2.Q.N.*`)."""
+        sd = self.state_dicts()
+        cpu = lambda d, pre: {pre + k: v.cpu().clone() for k, v in d.items()}
+        return {"policy": cpu(sd["policy"], "policy."),
+                "critic": {**cpu(sd["q1"], "Q1.Q."), **cpu(sd["q2"], "Q2.Q.")},
+                "critic_target": {**cpu(sd["q1_target"], "Q1.Q."), **cpu(sd["q2_target"], "Q2.Q.")}}
+
+    def save_models(self, model_dir, tag):
+        for name, sd in self.model_files().items():
+            torch.save(sd, os.path.join(model_dir, f"{name}_{tag}.pth"))
+
+    def load_models(self, model_dir, tag):
+        strip = lambda d, pre: {k[len(pre):]: v for k, v in d.items() if k.startswith(pre)}
+        f = {name: torch.load(os.path.join(model_dir, f"{name}_{tag}.pth"), map_location="cpu") for name in ("policy", "critic", "critic_target")}
+        self.load_params(strip(f["policy"], "policy."), strip(f["critic"], "Q1.Q."), strip(f["critic"], "Q2.Q."), hard_update_target=False)
+        self.target_critic[:Q_SIZE].copy_(pack_mlp(strip(f["critic_target"], "Q1.Q."), Q_BLOCK, Q_SIZE, 17, 1, self.device))
+        self.target_critic[Q_SIZE:].copy_(pack_mlp(strip(f["critic_target"], "Q2.Q."), Q_BLOCK, Q_SIZE, 17, 1, self.device))
 
     def act(self, obs, eps=None, explore=True, seed=0, row0=0, out=None):
         """explore (agent.py:183-188): sampled tanh-Gaussian action (eps [N, 4] given, else Philox); exploit (:191-196): tanh(mean)."""

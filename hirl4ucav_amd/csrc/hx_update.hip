@@ -953,7 +953,7 @@ __global__ __launch_bounds__(kThreads) void q_select_kernel(QSelArgs A) {
 
 // Gradient of the policy loss mean(-min Q - alpha H) (SAC/agent.py:404-406) wrt the policy head's 8 pre-activations: the
 // critics' input gradients wrt the action (both heads; the unselected one carries zeros) chained through a = tanh(mean + sigma eps),
-// plus the entropy term.  Also accumulates -alpha H / B (policy loss) and H / B (mean entropy, for the alpha step).
+// plus the entropy term.  Also accumulates -alpha H / B (policy loss) and stores mean H (for the alpha step).
 struct PDoutArgs {
     const float* q1net;
     const float* q2net;
@@ -996,10 +996,15 @@ __global__ __launch_bounds__(kThreads) void policy_dout_kernel(PDoutArgs A) {
         const float dLdx = (lane == 0 ? da[0] : lane == 1 ? da[1] : lane == 2 ? da[2] : da[3]) * t - alpha * A.inv_batch * dHdx;
         A.pol.dout[(size_t)r * OW + lane] = dLdx;
         A.pol.dout[(size_t)r * OW + 4 + lane] = (dLdx * se - alpha * A.inv_batch) * mask;
-        if (lane == 0) {
-            atomicAdd(&A.losses[2], -alpha * x[12] * A.inv_batch);
-            atomicAdd(&A.losses[4], x[12] * A.inv_batch);
-        }
+        if (lane == 0) atomicAdd(&A.losses[2], -alpha * x[12] * A.inv_batch);  // logged only
+    }
+    // The mean entropy feeds the log-alpha step, so it must not depend on arrival order: the per-row entropies were written by
+    // the head kernel before this launch, one wave adds them in a fixed order.
+    if (blockIdx.x == 0 && wave == 0) {
+        float s = 0.0f;
+        for (int rr = lane; rr < A.rows; rr += 64) s += A.aux[(size_t)rr * 16 + 12];
+        s = wave_sum(s);
+        if (lane == 0) A.losses[4] = s * A.inv_batch;
     }
 }
 

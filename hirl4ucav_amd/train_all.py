@@ -23,6 +23,7 @@ from . import _lib
 from .agents import engine as E
 from .agents.HIRL import init_actor_state_dict, init_critic_state_dict
 from .environments.batched import SCENARIOS, BatchedHarfangEnv
+from .utils import checkpoint as CK
 from .utils.buffer import DeviceReplay
 from .utils.data_processor import read_data
 from .utils.seed import set_seed
@@ -83,15 +84,16 @@ def label_expert(states, actions, device):
     return rows, sc[keep]
 
 
-def validate(engine, scenario, episodes, max_step, if_random, seed, device):
-    """validate() of train_all.py:22-102 as ONE batch: `episodes` envs stepped with chooseActionNoNoise until done or the
-    step limit; success / fire success counted only for episodes that ended with done (train_all.py:59-64)."""
+def validate(engine, scenario, episodes, max_step, if_random, seed, device, sac=False):
+    """validate() of train_all.py:22-102 (train_sac.py:24-68 for SAC) as ONE batch: `episodes` envs stepped with
+    chooseActionNoNoise / exploit until done or the step limit; success / fire success counted only for episodes that ended
+    with done (train_all.py:59-64)."""
     env = BatchedHarfangEnv(episodes, scenario=scenario, device=device, seed=seed, auto_reset=False, random_reset=if_random, collect_stats=False)
     obs = env.reset()
     total = torch.zeros(episodes, device=device)
     alive = torch.ones(episodes, dtype=torch.bool, device=device)
     for step in range(max_step):
-        a = engine.act(obs)
+        a = engine.act(obs, explore=False) if sac else engine.act(obs)
         obs, r, d, s = env.step(a)
         total += torch.where(alive, r, torch.zeros_like(r))
         alive &= d == 0
@@ -121,7 +123,7 @@ def main(config):
     max_step = MAX_STEP[env_type] * (8 if config.render else 1)
     hirl = config.agent == "HIRL"
     esac = config.agent == "SAC" and config.type == "ESAC"
-    batch, buffer_size, checkpoint_rate = 128, config.buffer_size, 25  # train_all.py:190-208
+    batch, buffer_size, checkpoint_rate = 128, config.buffer_size, config.checkpoint_rate  # train_all.py:190-208
     warm_up_rate = 20 if config.agent == "SAC" else 10  # train_sac.py:203 / train_all.py:207
 
     replay = DeviceReplay(buffer_size, device)
@@ -160,19 +162,20 @@ def main(config):
         if hirl and config.bc_actor and os.path.exists(config.bc_actor):
             eng.bc_actor.copy_(E.pack(torch.load(config.bc_actor, map_location="cpu"), E.ACTOR_LAYOUT, E.ACTOR_SIZE, device))
 
-    # RANDOM EXPLORATION: 20 episodes of uniform actions in the reference (train_all.py:266-282) = 20*maxStep transitions
-    obs = env.reset()
-    for _ in range(math.ceil(20 * max_step / (n * world))):
-        env.step(torch.rand((n, 4), device=device) * 2 - 1)
-
     log_dir = os.path.join(config.result_dir, env_type, config.agent, config.model_name, time.strftime("%Y_%m_%d_%H_%M"))
     model_dir = os.path.join(log_dir, "model")
-    if rank == 0:
-        os.makedirs(model_dir, exist_ok=True)
-    expert_num = batch if (hirl or esac) else 0
-    high_score, success_rate, arttir = -math.inf, 0.0, 1
-    t0 = time.time()
-    for episode in range(config.episodes):
+    os.makedirs(model_dir, exist_ok=True)
+    run = {"episode": 0, "expert_num": batch if (hirl or esac) else 0, "high_score": -math.inf, "success_rate": 0.0, "arttir": 1}
+    if config.resume:  # every rank restores its own shard: <resume>/state_rank<r>.pt
+        run = CK.load_run(os.path.join(config.resume, f"state_rank{rank}.pt"), eng, env, replay)
+    else:
+        # RANDOM EXPLORATION: 20 episodes of uniform actions in the reference (train_all.py:266-282) = 20*maxStep transitions
+        env.reset()
+        for _ in range(math.ceil(20 * max_step / (n * world))):
+            env.step(torch.rand((n, 4), device=device) * 2 - 1)
+    expert_num, high_score, success_rate, arttir = run["expert_num"], run["high_score"], run["success_rate"], run["arttir"]
+    t0, episode0 = time.time(), run["episode"]
+    for episode in range(episode0, config.episodes):
         w_now, warm = bc_weight_schedule(config.type, episode, config.bc_weight) if hirl else (0.0, 0.0)
         for step in range(max_step):
             actions = eng.act(env.obs, seed=seed + 1, row0=env.env_id0) if sac else eng.act(env.obs, sigma=0.1, seed=seed + 1, row0=env.env_id0)
@@ -191,23 +194,30 @@ def main(config):
         if rank == 0:
             c, a, b, r_, f, w = eng.losses_host()
             st = env.stats_dict()
-            sps = (episode + 1) * max_step * n * world / (time.time() - t0)
+            sps = (episode + 1 - episode0) * max_step * n * world / (time.time() - t0)
             names = ("q1", "q2", "policy", "entropy_loss", "alpha") if sac else ("critic", "actor", "bc", "rl", "bc_weight")
             vals = (c, a, b, r_, w)
             print(f"Episode {episode + 1}: " + " ".join(f"{k} {v:.4f}" for k, v in zip(names, vals)) + f" | episodes {st['episodes']} "
                   f"kills {st['kills']} fire-success {st['fire_success_episodes']} | {sps:,.0f} env steps/s", flush=True)
-        if (episode + 1) % checkpoint_rate == 0 and rank == 0 and not sac:  # VALIDATION, train_all.py:400-402
-            mean, std, succ, fire = validate(eng, env_type, 50, max_step, config.random, seed + 12345, device)
+        if (episode + 1) % checkpoint_rate == 0 and rank == 0:  # VALIDATION, train_all.py:400-402 / train_sac.py:431-433
+            mean, std, succ, fire = validate(eng, env_type, 50, max_step, config.random, seed + 12345, device, sac)
             if mean > high_score or succ / 50 >= success_rate or arttir % 5 == 0:
                 tag = checkpoint_tag(arttir, succ, 50, mean)
-                for name, flat, layout in (("Critic_", eng.critic, E.CRITIC_LAYOUT), ("Actor_", eng.actor, E.ACTOR_LAYOUT),
-                                           ("TargetCritic_", eng.target_critic, E.CRITIC_LAYOUT), ("TargetActor_", eng.target_actor, E.ACTOR_LAYOUT)):
-                    torch.save({k: v.cpu().clone() for k, v in E.unpack(flat, layout).items()}, os.path.join(model_dir, tag + name + "Harfang_GYM"))
+                if sac:  # SacAgent.save_models, SAC/agent.py:440-444
+                    eng.save_models(model_dir, tag)
+                else:    # Agent.saveCheckpoints, HIRL.py:336-342
+                    for name, flat, layout in (("Critic_", eng.critic, E.CRITIC_LAYOUT), ("Actor_", eng.actor, E.ACTOR_LAYOUT),
+                                               ("TargetCritic_", eng.target_critic, E.CRITIC_LAYOUT), ("TargetActor_", eng.target_actor, E.ACTOR_LAYOUT)):
+                        torch.save({k: v.cpu().clone() for k, v in E.unpack(flat, layout).items()}, os.path.join(model_dir, tag + name + "Harfang_GYM"))
                 high_score, success_rate = max(high_score, mean), max(success_rate, succ / 50)
             print(f"Validation {arttir}: avg reward {mean:.2f} (std {std:.2f}) success {succ / 50:.2f} fire success {fire / 50:.2f}", flush=True)
             arttir += 1
+        if config.snapshot_every and (episode + 1) % config.snapshot_every == 0:  # whole-run state for --resume (one file per rank)
+            CK.save_run(os.path.join(log_dir, f"state_rank{rank}.pt"), eng, env, replay,
+                        {"episode": episode + 1, "expert_num": expert_num, "high_score": high_score, "success_rate": success_rate, "arttir": arttir})
     if world > 1:
         torch.distributed.destroy_process_group()
+    return log_dir
 
 
 def parser():
@@ -231,6 +241,9 @@ def parser():
     p.add_argument("--expert_csv", type=str, default=None)
     p.add_argument("--bc_actor", type=str, default=None)
     p.add_argument("--result_dir", type=str, default="results")
+    p.add_argument("--checkpoint_rate", type=int, default=25, help="episodes between validations (train_all.py:206)")
+    p.add_argument("--snapshot_every", type=int, default=25, help="episodes between whole-run snapshots (0: never)")
+    p.add_argument("--resume", type=str, default=None, help="run directory holding state_rank<r>.pt to continue from")
     return p
 
 
