@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--sweep", action="store_true", help="also sweep the env-step kernel over 4k..4M envs per launch")
     p.add_argument("--actions", default="policy", choices=["policy", "uniform"],
                    help="uniform: U(-1,1)^4 actions instead of the live actor (SURVEY.md 8d C2's second run, decoupled from the policy)")
+    p.add_argument("--serial", action="store_true",
+                   help="one stream, strict act -> step -> sample -> learn order (default: the next act + step overlap critic-only learns)")
     p.add_argument("--staged", action="store_true",
                    help="use the stage-by-stage update path of the sharded build on one rank too (costs of the N > 1 launch sequence)")
     return p.parse_args()
@@ -143,36 +145,50 @@ class Loop:
         self.env.reset()
         self.t = 0
         self.actions = torch.zeros((n, 4), device=device)
+        from hirl4ucav_amd.utils.pipeline import VectorStepPipeline
+        self.pipe = VectorStepPipeline(device, overlap=not getattr(args, "serial", False) and not self.sac)
+        self.record, self.rec, self.pool = False, {"act": [], "env": [], "learn": []}, []
 
-    def step(self, ev=None):
+    def _timed(self, name, fn):
+        """Bracket fn() with HIP events on the stream it launches on (the current one) while recording is on."""
+        if not self.record:
+            return fn()
+        if not self.pool:  # event creation is slow enough to stall the issue thread: make them outside the timed region
+            raise RuntimeError("event pool exhausted")
+        a, b = self.pool.pop(), self.pool.pop()
+        a.record()
+        fn()
+        b.record()
+        self.rec[name].append((a, b))
+
+    def _act_env(self):
         e, env = self.eng, self.env
-        if ev:
-            ev[0].record()
         if self.uniform:  # env.action_space.sample() for every env (train_all.py:272)
-            self.actions.uniform_(-1.0, 1.0)
+            self._timed("act", lambda: self.actions.uniform_(-1.0, 1.0))
         elif self.sac:
-            e.act(env.obs, seed=1, row0=env.env_id0, out=self.actions)  # SacAgent.explore
+            self._timed("act", lambda: e.act(env.obs, seed=1, row0=env.env_id0, out=self.actions))  # SacAgent.explore
         else:
-            e.act(env.obs, sigma=0.1, seed=1, row0=env.env_id0, out=self.actions)  # actionNoise 0.1, HIRL.py:160
-        if ev:
-            ev[1].record()
-        env.step(self.actions)
-        if ev:
-            ev[2].record()
+            self._timed("act", lambda: e.act(env.obs, sigma=0.1, seed=1, row0=env.env_id0, out=self.actions))  # actionNoise 0.1, HIRL.py:160
+        self._timed("env", lambda: env.step(self.actions))
+
+    def _learn(self):
+        e = self.eng
         if self.sac:  # train_sac.py:401-403
             e.sample(self.replay, seed=2 + self.rank)
             e.learn()
-            if ev:
-                ev[3].record()
-            self.t += 1
             return
         e.sample(self.replay, self.expert, self.bc_table, n_main=e.batch - self.expert_num, seed=2 + self.rank)
+        # a critic-only learn() leaves the acting network alone: the next act + env.step go out on the side stream now
+        self.pipe.prefetch(self._act_env, acting_net_untouched=not e.actor_trainable)
         # soft weight: estimated at the start of every max_step-long "episode" of vector steps, kept in between
         # (the reference re-estimates at most once per episode, SURVEY.md quirk 2)
         w = 100 if (self.t % self.max_step == 0) else None
         e.learn(bc_weight_now=w, bc_warm_up_weight=0.0)
-        if ev:
-            ev[3].record()
+
+    def step(self):
+        self.pipe.act_and_step(self._act_env)
+        self._timed("learn", self._learn)
+        self.pipe.join()
         self.t += 1
 
 
@@ -267,19 +283,19 @@ def main():
         loop.step()
     # per-stage HIP events (recorded on the stream the kernels are launched on = torch's current stream)
     nev = min(args.steps, 512)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(nev)]
+    loop.pool = [torch.cuda.Event(enable_timing=True) for _ in range(6 * (nev + 1))]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        loop.step(evs[k] if k < nev else None)
+        loop.record = k < nev
+        loop.step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    stage = np.array([[e[i].elapsed_time(e[i + 1]) * 1e3 for i in range(3)] for e in evs])  # us: act, env, sample+learn
-    act_us, env_us, learn_us = (float(np.median(stage[:, i])) for i in range(3))
+    act_us, env_us, learn_us = (float(np.median([a.elapsed_time(b) * 1e3 for a, b in loop.rec[k]])) for k in ("act", "env", "learn"))
     n_total = args.envs * world
     value = n_total * args.steps / dt
     res = {
@@ -291,7 +307,7 @@ def main():
                                 f"(BASELINE.json configs[2])" if args.agent == "sac" else
                                 f"{args.envs} parallel {args.scenario} envs per GPU, HIRL-soft fp32, 1 learn(B={args.batch}) per vector step "
                                 f"(BASELINE.json configs[1])"), "envs_per_gpu": args.envs, "batch": args.batch,
-                   "actions": args.actions, "update_path": "staged" if (args.staged or world > 1) and args.agent == "hirl" else "one-call",
+                   "actions": args.actions, "issue_order": "two streams" if loop.pipe.overlap else "serial", "update_path": "staged" if (args.staged or world > 1) and args.agent == "hirl" else "one-call",
                    "parallelism": f"dp{world}: env shards + replicated nets, RCCL all-reduce of the flat gradients"},
         "update_steps_per_s": round(args.steps / dt, 1),
         "stage_us": {"act(1 kernel)": round(act_us, 2), "env_step(1 kernel)": round(env_us, 2), "sample+learn(6-12 kernels)": round(learn_us, 2)},

@@ -107,6 +107,52 @@ def validate(engine, scenario, episodes, max_step, if_random, seed, device, sac=
     return float(scores.mean()), float(scores.std()), success, fire
 
 
+def load_expert(config, rng_seed=0):
+    """read_data(data_dir) (train_all.py:222-228); without a file (the Drive data is not available, README.md:6,30) a
+    synthetic stand-in of the same shape."""
+    if config.expert_csv and os.path.exists(config.expert_csv):
+        return read_data(config.expert_csv)
+    rng = np.random.default_rng(rng_seed)
+    es = rng.uniform(-1, 1, (20000, 13))
+    es[:, 7:9] = np.where(rng.random((20000, 2)) < 0.5, 1, -1)
+    es[:, 12] = rng.uniform(0, 0.2, 20000)
+    ea = rng.uniform(-1, 1, (20000, 4))
+    ea[:, 3] = np.where(rng.random(20000) < 1e-3, 1, -1)
+    return es, ea
+
+
+def train_bc(config, device, seed, max_step):
+    """The BC branch of train_all.py:244-260: maxStep train_actor() calls per 'episode' on the expert (s, a) table, validation
+    every checkpoint_rate episodes from --bc_validate_from on, actor checkpoints with the reference's tag and file name."""
+    env_type, batch = config.env, 128
+    eng = E.HirlEngine(batch=batch, lr_actor=1e-3, slope=0.01, use_bc=True, device=device)  # BC.py:129-135 leaky_relu
+    eng.load_params(init_actor_state_dict(), init_critic_state_dict())
+    es, ea = load_expert(config)
+    tab = np.zeros((es.shape[0], 32), np.float32)
+    tab[:, 0:13], tab[:, 13:17] = es, ea
+    bc_table = torch.from_numpy(tab).to(device)
+    table = DeviceReplay(es.shape[0], device)  # the sampler wants a main ring as well; the BC step reads only the BC rows
+    table.store_rows(bc_table)
+    log_dir = os.path.join(config.result_dir, env_type, config.agent, config.model_name, time.strftime("%Y_%m_%d_%H_%M"))
+    model_dir = os.path.join(log_dir, "model")
+    os.makedirs(model_dir, exist_ok=True)
+    high_score, success_rate, arttir = -math.inf, 0.0, 1
+    for episode in range(config.episodes):
+        for _ in range(max_step):
+            eng.sample(table, None, bc_table, seed=seed + 2)
+            eng.bc_train_actor()
+        print(f"Episode {episode + 1}: bc_loss {eng.losses_host()[2]:.6f}", flush=True)
+        if (episode + 1) % config.checkpoint_rate == 0 and (episode + 1) >= config.bc_validate_from:  # train_all.py:259
+            mean, std, succ, fire = validate(eng, env_type, 50, max_step, config.random, seed + 12345, device)
+            if mean > high_score or succ / 50 >= success_rate or arttir % 5 == 0:
+                torch.save({k: v.cpu().clone() for k, v in E.unpack(eng.actor, E.ACTOR_LAYOUT).items()},
+                           os.path.join(model_dir, checkpoint_tag(arttir, succ, 50, mean) + "Actor_Harfang_GYM"))
+                high_score, success_rate = max(high_score, mean), max(success_rate, succ / 50)
+            print(f"Validation {arttir}: avg reward {mean:.2f} (std {std:.2f}) success {succ / 50:.2f} fire success {fire / 50:.2f}", flush=True)
+            arttir += 1
+    return log_dir
+
+
 def main(config):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -121,6 +167,8 @@ def main(config):
     seed = config.seed or 0
     env_type, n = config.env, config.num_envs
     max_step = MAX_STEP[env_type] * (8 if config.render else 1)
+    if config.agent == "BC":
+        return train_bc(config, device, seed, max_step)
     hirl = config.agent == "HIRL"
     esac = config.agent == "SAC" and config.type == "ESAC"
     batch, buffer_size, checkpoint_rate = 128, config.buffer_size, config.checkpoint_rate  # train_all.py:190-208
@@ -143,15 +191,7 @@ def main(config):
     expert_len = bc_len = 0
     expert = bc_table = None
     if hirl or esac:
-        if config.expert_csv and os.path.exists(config.expert_csv):
-            es, ea = read_data(config.expert_csv)
-        else:  # no Drive data here (README.md:6,30): synthetic stand-in of the same shape
-            rng = np.random.default_rng(0)
-            es = rng.uniform(-1, 1, (20000, 13))
-            es[:, 7:9] = np.where(rng.random((20000, 2)) < 0.5, 1, -1)
-            es[:, 12] = rng.uniform(0, 0.2, 20000)
-            ea = rng.uniform(-1, 1, (20000, 4))
-            ea[:, 3] = np.where(rng.random(20000) < 1e-3, 1, -1)
+        es, ea = load_expert(config)
         rows, succ = label_expert(es, ea, device)
         expert = DeviceReplay(rows.shape[0] + 10, device)
         expert.store_rows(rows, succ)
@@ -222,7 +262,7 @@ def main(config):
 
 def parser():
     p = argparse.ArgumentParser()  # the reference's flags, train_all.py:489-513
-    p.add_argument("--agent", type=str, default="HIRL", choices=["HIRL", "TD3", "SAC"])  # SAC: the train_sac.py path (D2)
+    p.add_argument("--agent", type=str, default="HIRL", choices=["HIRL", "TD3", "BC", "SAC"])  # SAC: the train_sac.py path (D2)
     p.add_argument("--port", type=int, default=None)
     p.add_argument("--type", type=str, default="soft", choices=["soft", "linear", "fixed", "SAC", "ESAC"])  # SAC / ESAC: train_sac.py:440-458
     p.add_argument("--bc_weight", type=float, default=0.5)
@@ -242,6 +282,7 @@ def parser():
     p.add_argument("--bc_actor", type=str, default=None)
     p.add_argument("--result_dir", type=str, default="results")
     p.add_argument("--checkpoint_rate", type=int, default=25, help="episodes between validations (train_all.py:206)")
+    p.add_argument("--bc_validate_from", type=int, default=1000, help="BC: first episode with validation (train_all.py:259)")
     p.add_argument("--snapshot_every", type=int, default=25, help="episodes between whole-run snapshots (0: never)")
     p.add_argument("--resume", type=str, default=None, help="run directory holding state_rank<r>.pt to continue from")
     return p

@@ -330,3 +330,30 @@ def test_bc_train_actor_matches_oracle_and_reference(eng_mod, golden_dir):
         s_, a_, v_ = D.net_probe(f)
         dv = np.abs(v_ - g["probe_val"][k])
         assert (dv > 2e-6).mean() <= 0.03 and dv.max() < 5e-5
+
+
+def test_two_stream_issue_order_is_bit_identical_to_serial():
+    """bench.py / train_all issue the next act + env.step beside a critic-only learn() on a second stream
+    (utils/pipeline.py).  Same reads and writes as the strict serial order of train_all.py:343-361: networks, Adam moments,
+    env state, replay rows must come out bit for bit equal.  256 envs = one workgroup, so the replay insert order is fixed."""
+    import argparse
+
+    import bench
+
+    def run(serial):
+        args = argparse.Namespace(envs=256, batch=128, scenario="straight_line", agent="hirl", actions="policy", staged=False, serial=serial)
+        loop = bench.Loop(args, 0, 1, torch.device("cuda", 0))
+        assert loop.pipe.overlap == (not serial)
+        for _ in range(61):
+            loop.step()
+        torch.cuda.synchronize()
+        lo = (loop.eng.losses.data_ptr() - loop.eng.arena.data_ptr()) // 4
+        arena = loop.eng.arena.clone()
+        arena[lo:lo + 8] = 0  # logged loss sums: float atomics
+        n = int(loop.replay.total.item())
+        return arena.cpu(), loop.env.state.cpu().clone(), loop.replay.ring[:min(n, 1 << 16)].cpu().clone(), n, loop.pipe.issued
+
+    a, b = run(True), run(False)
+    assert not b[4] and a[3] == b[3] >= 61 * 200  # call 61 is an actor call: nothing of step 62 is in flight
+    for x, y, name in zip(a[:3], b[:3], ("arena", "env state", "replay")):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), name
