@@ -17,8 +17,11 @@ constexpr int H1 = 256;
 constexpr int H2 = 512;
 constexpr int XP = 20;       // padded input row (13 or 17 used)
 constexpr int RT = 16;       // rows per tile (MFMA M)
-constexpr int LDA1 = H1 + 4; // LDS pitch of a [16][256] tile (+4: ds_read_b128 rows land on distinct 16-B slots)
-constexpr int LDA2 = H2 + 4;
+// LDS pitch of a [16][256] / [16][512] tile: = 8 mod 64 dwords.  A ds_read_b128 is served in four fixed 16-lane groups
+// ({0-3,12-15,20-27}, ...) over 64 banks; with lane -> (row = l & 15, 16-B piece = l >> 4) a pitch of 8 mod 16 dwords puts the 16
+// lanes of every group on 16 different 16-B slots (a pitch of 4 mod 64 leaves one 2-way conflict per group).
+constexpr int LDA1 = H1 + 8;
+constexpr int LDA2 = H2 + 8;
 constexpr float LN_EPS = 1e-5f;
 
 typedef float v4f __attribute__((ext_vector_type(4)));

@@ -357,8 +357,9 @@ __device__ __forceinline__ float u01(uint32_t u) { return ((float)(u >> 8) + 0.5
 
 // ---------------------------------------------------------------------------------------------------------------
 // act_fused: the whole policy for 16 observation rows in ONE workgroup — layer 1 + LN1 (VALU), z2 = h1 W2^T for all 512
-// columns (two 16-column MFMA tiles per wave, K = 256), then LN2 + final layer + tanh + exploration noise + clamp with one
-// wave per row straight from the LDS copy of z2.  No z2 round trip through HBM, no second launch.
+// columns (two 16-column MFMA tiles per wave, K = 256; W2 streams through LDS in 32-wide k-chunks, register-prefetched one
+// chunk ahead), then LN2 + final layer + tanh + exploration noise + clamp with one wave per row straight from the LDS copy
+// of z2.  No z2 round trip through HBM, no second launch.
 // chooseAction / chooseActionSmallNoise / chooseActionNoNoise, HIRL.py:192-212.
 // ---------------------------------------------------------------------------------------------------------------
 struct ActFusedArgs {
@@ -375,13 +376,17 @@ struct ActFusedArgs {
     uint32_t row0, call;
 };
 
+constexpr int ACT_KC = 32;            // k-chunk of W2 staged through LDS: 128 B per column = whole cache lines
+constexpr int ACT_LDW = ACT_KC + 8;   // pitch = 8 mod 16 dwords: conflict-free ds_read_b128 (see LDA1)
+
 __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
-    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * LDA2 + RT * XP + RT * 2 + H1 * 13];
+    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * LDA2 + RT * XP + RT * 2 + H1 * 13 + H2 * ACT_LDW];
     float* h1s = lds;
     float* z2s = h1s + RT * LDA1;
     float* xs = z2s + RT * LDA2;
     float* sts = xs + RT * XP;
     float* w1s = sts + RT * 2;
+    float* w2s = w1s + H1 * 13;  // [H2][ACT_LDW]: one k-chunk of W2, every column
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * RT;
     const int nrow = min(RT, A.rows - r0);
@@ -391,6 +396,12 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     const int u = tid & (H1 - 1), rq = (tid >> 8) * 4;
     STAMP_DECL;
     STAMP();
+    // W2 chunk loader: 8 lanes cover one column's 128 B, a wave 8 columns, the workgroup 128 columns per pass, 4 passes.
+    // Every byte of W2 enters this CU exactly once, as whole lines, and is shared by all 16 waves from LDS.
+    const int piece = tid & 7, colb = tid >> 3;
+    const float* w2g = net + m.W2() + (size_t)colb * H1 + piece * 4;
+    float4 pre0 = *reinterpret_cast<const float4*>(w2g), pre1 = *reinterpret_cast<const float4*>(w2g + (size_t)128 * H1),
+           pre2 = *reinterpret_cast<const float4*>(w2g + (size_t)256 * H1), pre3 = *reinterpret_cast<const float4*>(w2g + (size_t)384 * H1);
     // all independent operands first
     float xv = 0.0f;
     if (tid < RT * 13) {
@@ -437,23 +448,46 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         const int row = rq + r;
         h1s[row * LDA1 + u] = act_f(g1v * ((z1[r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
     }
+    float* w2w = w2s + colb * ACT_LDW + piece * 4;
+    *reinterpret_cast<float4*>(w2w) = pre0;
+    *reinterpret_cast<float4*>(w2w + 128 * ACT_LDW) = pre1;
+    *reinterpret_cast<float4*>(w2w + 256 * ACT_LDW) = pre2;
+    *reinterpret_cast<float4*>(w2w + 384 * ACT_LDW) = pre3;
     __syncthreads();
     STAMP();
-    {   // z2 tiles: columns 16*wave .. and 256 + 16*wave ..
+    {   // z2 tiles: columns 16*wave .. and 256 + 16*wave ..; k ascending, chunk by chunk
         const int r = lane & 15, g = lane >> 4;
         v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         const float* ap = h1s + r * LDA1 + 4 * g;
-        const float* b0 = net + m.W2() + (size_t)(wave * 16 + r) * H1 + 4 * g;
-        const float* b1 = b0 + (size_t)256 * H1;
-#pragma unroll 4
-        for (int kk = 0; kk < H1; kk += 16) {
-            const float4 a4 = *reinterpret_cast<const float4*>(ap + kk);
-            const float4 p4 = *reinterpret_cast<const float4*>(b0 + kk);
-            const float4 q4 = *reinterpret_cast<const float4*>(b1 + kk);
-            acc0 = mfma16(a4.x, p4.x, acc0); acc1 = mfma16(a4.x, q4.x, acc1);
-            acc0 = mfma16(a4.y, p4.y, acc0); acc1 = mfma16(a4.y, q4.y, acc1);
-            acc0 = mfma16(a4.z, p4.z, acc0); acc1 = mfma16(a4.z, q4.z, acc1);
-            acc0 = mfma16(a4.w, p4.w, acc0); acc1 = mfma16(a4.w, q4.w, acc1);
+        const float* bp0 = w2s + (wave * 16 + r) * ACT_LDW + 4 * g;
+        const float* bp1 = bp0 + 256 * ACT_LDW;
+        for (int c = 0; c < H1 / ACT_KC; ++c) {
+            const bool more = c + 1 < H1 / ACT_KC;
+            if (more) {  // next chunk: in flight while this one is multiplied
+                const float* gsrc = w2g + (c + 1) * ACT_KC;
+                pre0 = *reinterpret_cast<const float4*>(gsrc);
+                pre1 = *reinterpret_cast<const float4*>(gsrc + (size_t)128 * H1);
+                pre2 = *reinterpret_cast<const float4*>(gsrc + (size_t)256 * H1);
+                pre3 = *reinterpret_cast<const float4*>(gsrc + (size_t)384 * H1);
+            }
+#pragma unroll
+            for (int j = 0; j < ACT_KC; j += 16) {
+                const float4 a4 = *reinterpret_cast<const float4*>(ap + c * ACT_KC + j);
+                const float4 p4 = *reinterpret_cast<const float4*>(bp0 + j);
+                const float4 q4 = *reinterpret_cast<const float4*>(bp1 + j);
+                acc0 = mfma16(a4.x, p4.x, acc0); acc1 = mfma16(a4.x, q4.x, acc1);
+                acc0 = mfma16(a4.y, p4.y, acc0); acc1 = mfma16(a4.y, q4.y, acc1);
+                acc0 = mfma16(a4.z, p4.z, acc0); acc1 = mfma16(a4.z, q4.z, acc1);
+                acc0 = mfma16(a4.w, p4.w, acc0); acc1 = mfma16(a4.w, q4.w, acc1);
+            }
+            if (more) {
+                __syncthreads();  // every wave is done with this chunk
+                *reinterpret_cast<float4*>(w2w) = pre0;
+                *reinterpret_cast<float4*>(w2w + 128 * ACT_LDW) = pre1;
+                *reinterpret_cast<float4*>(w2w + 256 * ACT_LDW) = pre2;
+                *reinterpret_cast<float4*>(w2w + 384 * ACT_LDW) = pre3;
+                __syncthreads();
+            }
         }
         const float bb0 = net[m.b2() + wave * 16 + r], bb1 = net[m.b2() + 256 + wave * 16 + r];
 #pragma unroll
@@ -470,7 +504,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         float mean, rstd, o[4];
         head_row<4>(z2s + wave * LDA2, net, m, slope, xh, y, mean, rstd, o);
         if (lane < 4) {
-            float a = tanhf(o[lane]);
+            float a = tanhf(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // no dynamic register index
             if (A.noise) {
                 a = fminf(fmaxf(a + A.noise[(A.noise_per_row ? (size_t)r * 4 : 0) + lane], -1.0f), 1.0f);
             } else if (A.sigma > 0.0f) {

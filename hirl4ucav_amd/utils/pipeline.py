@@ -4,7 +4,12 @@ The reference runs these strictly one after the other (train_all.py:343-361).  T
 the TD3-style agents touch the acting network on every SECOND learn() (HIRL.py:291,332), and learn() reads the minibatch
 tiles the sampler gathered, never the replay ring.  So on a critic-only learn() the next step's act + env.step can run
 beside it on a second HIP stream, as soon as the sampler has read the ring — same reads, same writes, same values: the
-results are bit-identical to the serial order (tests/test_hirl_gpu.py), only the latency of one stage hides under the other.
+results are bit-identical to the serial order (tests/test_hirl_gpu.py).
+
+Measured on one MI355X at 4,096 envs, B = 128 (profiles/README.md): 145 us/step against 143 serial — act's 256 workgroups and
+learn's 1024-thread workgroups want the same CUs and LDS, so the stages mostly take turns anyway and the two event hand-offs
+cost what little is hidden.  bench.py therefore keeps the serial order by default (`--overlap` turns this on); the class stays
+because the exchange latency of the sharded update (N > 1) is the case it can still pay for, once that is measurable.
 """
 import torch
 

@@ -333,7 +333,7 @@ def test_bc_train_actor_matches_oracle_and_reference(eng_mod, golden_dir):
 
 
 def test_two_stream_issue_order_is_bit_identical_to_serial():
-    """bench.py / train_all issue the next act + env.step beside a critic-only learn() on a second stream
+    """bench.py --overlap issues the next act + env.step beside a critic-only learn() on a second stream
     (utils/pipeline.py).  Same reads and writes as the strict serial order of train_all.py:343-361: networks, Adam moments,
     env state, replay rows must come out bit for bit equal.  256 envs = one workgroup, so the replay insert order is fixed."""
     import argparse
@@ -341,7 +341,7 @@ def test_two_stream_issue_order_is_bit_identical_to_serial():
     import bench
 
     def run(serial):
-        args = argparse.Namespace(envs=256, batch=128, scenario="straight_line", agent="hirl", actions="policy", staged=False, serial=serial)
+        args = argparse.Namespace(envs=256, batch=128, scenario="straight_line", agent="hirl", actions="policy", staged=False, overlap=not serial)
         loop = bench.Loop(args, 0, 1, torch.device("cuda", 0))
         assert loop.pipe.overlap == (not serial)
         for _ in range(61):

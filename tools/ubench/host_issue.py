@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import bench  # noqa: E402
 
 for serial in (True, False):
-    args = argparse.Namespace(envs=4096, batch=128, scenario="straight_line", agent="hirl", actions="policy", staged=False, serial=serial)
+    args = argparse.Namespace(envs=4096, batch=128, scenario="straight_line", agent="hirl", actions="policy", staged=False, overlap=not serial)
     loop = bench.Loop(args, 0, 1, torch.device("cuda", 0))
     for _ in range(300):
         loop.step()
