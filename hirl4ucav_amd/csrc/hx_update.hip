@@ -1079,17 +1079,30 @@ __device__ __forceinline__ float effective_w(int kind, float given, float warm, 
     return w > 1.0f ? 1.0f : w;  // HIRL.py:308
 }
 
-constexpr int kWgTilesPerBlock = (H2 / 16) * (H1 / 64);  // 128 workgroups: 16 (n) x 64 (k) of dW2, one 16 x 16 tile per wave
-constexpr int kWgVecWgs = H2 / 64;                       // 8 workgroups: 64 columns x 4 row groups, 512-wide vector gradients
-constexpr int kWgL1Wgs = H1 / 64;                        // 4 workgroups: layer-1 gradients
+constexpr int kWgTilesPerBlock = H2 / 16;                // 32 workgroups: 16 (n) x 256 (k) of dW2, one 16 x 16 tile per wave
+constexpr int kWgVecWgs = H2 / 64;                       // 8 workgroups: 64 columns x 16 row groups, 512-wide vector gradients
+constexpr int kWgL1Wgs = H1 / 64;                        // 4 workgroups: layer-1 gradients, 64 units x 16 row groups
+constexpr int kWgRG = kWide / 64;                        // row groups = waves: the batch rows of a column are split 16 ways
 constexpr int kWgPerJob = kWgTilesPerBlock + kWgVecWgs + kWgL1Wgs;
 constexpr int kWgRowChunk = 256;                         // rows whose per-row scalars are staged in LDS at a time
 
-__global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
-    __shared__ __attribute__((aligned(16))) float lds[kWgRowChunk * XP + kWgRowChunk * 12 + 4 * 64 * 20];
+// fixed-order sum of the 16 row groups' partial results of one (column, item): red[group][64][20]
+__device__ __forceinline__ float sum_groups(const float* p) {
+    float v[kWgRG];
+#pragma unroll
+    for (int g = 0; g < kWgRG; ++g) v[g] = p[g * 64 * 20];
+#pragma unroll
+    for (int w = 1; w < kWgRG; w *= 2)
+#pragma unroll
+        for (int g = 0; g < kWgRG; g += 2 * w) v[g] += v[g + w];
+    return v[0];
+}
+
+__global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
+    __shared__ __attribute__((aligned(16))) float lds[kWgRowChunk * XP + kWgRowChunk * 12 + kWgRG * 64 * 20];
     float* xs = lds;                          // [chunk][XP]   inputs (layer-1 job)
     float* rinfo = lds + kWgRowChunk * XP;    // [chunk][<=12] per-row scalars
-    float* red = rinfo + kWgRowChunk * 12;    // [4][64][20]   cross-row-group reduction
+    float* red = rinfo + kWgRowChunk * 12;    // [16][64][20]  cross-row-group reduction
 
     const int j = blockIdx.x / kWgPerJob, b = blockIdx.x % kWgPerJob;
     if (j >= A.njobs) return;
@@ -1106,7 +1119,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
         // dW2[n][k] = sum_r scale dz2[r][n] h1[r][k].  Wave tile 16 (n) x 16 (k); the reduction runs over the batch rows,
         // 16 per MFMA group.  All operands of a 128-row chunk (32 + 32 dwords per lane) are requested before the first
         // MFMA: with B = 128 the whole job is one round trip to L2 instead of one per 16 rows.
-        const int n0 = (b / (H1 / 64)) * 16, k0 = (b % (H1 / 64)) * 64 + wave * 16;
+        const int n0 = b * 16, k0 = wave * 16;
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < J.nslots; ++s) {
@@ -1152,7 +1165,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
             for (int c0 = 0; c0 < J.rows[s]; c0 += kWgRowChunk) {
                 const int nr = min(kWgRowChunk, J.rows[s] - c0);
                 __syncthreads();
-                for (int e = tid; e < nr; e += kThreads) {
+                for (int e = tid; e < nr; e += kWide) {
                     rinfo[e * RP] = S.st2[(size_t)(c0 + e) * 2];
                     rinfo[e * RP + 1] = S.st2[(size_t)(c0 + e) * 2 + 1];
                     const float4 d4 = *reinterpret_cast<const float4*>(S.dout + (size_t)(c0 + e) * OW);
@@ -1161,18 +1174,18 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
                     rinfo[e * RP + 6] = d5.x; rinfo[e * RP + 7] = d5.y; rinfo[e * RP + 8] = d5.z; rinfo[e * RP + 9] = d5.w;
                 }
                 __syncthreads();
-                for (int rb = rg; rb < nr; rb += 64) {  // 16 rows per thread per block, all loads in flight together
-                    float zv[16], dv[16];
+                for (int rb = rg; rb < nr; rb += kWgRG * 8) {  // 8 rows per thread per block, all loads in flight together
+                    float zv[8], dv[8];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int r = rb + 4 * i;
+                    for (int i = 0; i < 8; ++i) {
+                        const int r = rb + kWgRG * i;
                         const bool ok = r < nr;
                         zv[i] = ok ? S.z2[(size_t)(c0 + r) * H2 + n] : 0.0f;
                         dv[i] = ok ? S.dz2[(size_t)(c0 + r) * H2 + n] : 0.0f;
                     }
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int r = rb + 4 * i;
+                    for (int i = 0; i < 8; ++i) {
+                        const int r = rb + kWgRG * i;
                         if (r < nr) {
                             const float* ri = rinfo + r * RP;
                             const float xh = (zv[i] - ri[0]) * ri[1];
@@ -1199,16 +1212,12 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
 #pragma unroll
         for (int jj = 0; jj < OW; ++jj) my[3 + jj] = dw3[jj];
         __syncthreads();
-        if (tid < 64) {
-            float v[3 + OW];
-#pragma unroll
-            for (int i = 0; i < 3 + OW; ++i) v[i] = (red[tid * 20 + i] + red[(64 + tid) * 20 + i]) + (red[(128 + tid) * 20 + i] + red[(192 + tid) * 20 + i]);
-            J.grad[J.m.b2() + n] = v[0];
-            J.grad[J.m.g2() + n] = J.m.no_ln ? 0.0f : v[1];
-            J.grad[J.m.be2() + n] = J.m.no_ln ? 0.0f : v[2];
-#pragma unroll
-            for (int jj = 0; jj < OW; ++jj)
-                if (jj < J.m.out) J.grad[J.m.W3() + jj * H2 + n] = v[3 + jj];
+        for (int item = wave; item < 3 + J.m.out; item += kWgRG) {  // wave -> item, lane -> column: 16 partial sums each
+            const float v = sum_groups(red + lane * 20 + item);
+            if (item == 0) J.grad[J.m.b2() + n] = v;
+            else if (item == 1) J.grad[J.m.g2() + n] = J.m.no_ln ? 0.0f : v;
+            else if (item == 2) J.grad[J.m.be2() + n] = J.m.no_ln ? 0.0f : v;
+            else J.grad[J.m.W3() + (item - 3) * H2 + n] = v;
         }
         if (vb == 0 && tid < J.m.out) J.grad[J.m.b3() + tid] = db3;
         STAMP();
@@ -1230,8 +1239,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
             for (int c0 = 0; c0 < J.rows[s]; c0 += kWgRowChunk) {
                 const int nr = min(kWgRowChunk, J.rows[s] - c0);
                 __syncthreads();
-                for (int e = tid; e < nr * XP; e += kThreads) xs[e] = S.x[(size_t)c0 * XP + e];
-                for (int e = tid; e < nr; e += kThreads) {
+                for (int e = tid; e < nr * XP; e += kWide) xs[e] = S.x[(size_t)c0 * XP + e];
+                for (int e = tid; e < nr; e += kWide) {
                     const float* lp = S.lnp + (size_t)(c0 + e) * 8;
                     rinfo[e * 8] = S.st1[(size_t)(c0 + e) * 2];
                     rinfo[e * 8 + 1] = S.st1[(size_t)(c0 + e) * 2 + 1];
@@ -1239,18 +1248,18 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
                     rinfo[e * 8 + 3] = ((lp[1] + lp[3]) + (lp[5] + lp[7])) * (1.0f / H1);
                 }
                 __syncthreads();
-                for (int rb = rg; rb < nr; rb += 64) {
-                    float zv[16], dv[16];
+                for (int rb = rg; rb < nr; rb += kWgRG * 8) {
+                    float zv[8], dv[8];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int r = rb + 4 * i;
+                    for (int i = 0; i < 8; ++i) {
+                        const int r = rb + kWgRG * i;
                         const bool ok = r < nr;
                         zv[i] = ok ? S.z1[(size_t)(c0 + r) * H1 + k] : 0.0f;
                         dv[i] = ok ? S.dh1[(size_t)(c0 + r) * H1 + k] : 0.0f;
                     }
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int r = rb + 4 * i;
+                    for (int i = 0; i < 8; ++i) {
+                        const int r = rb + kWgRG * i;
                         if (r < nr) {
                             const float* ri = rinfo + r * 8;
                             const float xh = (zv[i] - ri[0]) * ri[1];
@@ -1273,14 +1282,12 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs A) {
 #pragma unroll
         for (int i = 0; i < 17; ++i) my[3 + i] = dw1[i];
         __syncthreads();
-        if (tid < 64) {
-            float v[20];
-#pragma unroll
-            for (int i = 0; i < 20; ++i) v[i] = (red[tid * 20 + i] + red[(64 + tid) * 20 + i]) + (red[(128 + tid) * 20 + i] + red[(192 + tid) * 20 + i]);
-            J.grad[J.m.b1() + k] = v[0];
-            J.grad[J.m.g1() + k] = J.m.no_ln ? 0.0f : v[1];
-            J.grad[J.m.be1() + k] = J.m.no_ln ? 0.0f : v[2];
-            for (int i = 0; i < in; ++i) J.grad[J.m.W1() + k * in + i] = v[3 + i];
+        for (int item = wave; item < 3 + in; item += kWgRG) {
+            const float v = sum_groups(red + lane * 20 + item);
+            if (item == 0) J.grad[J.m.b1() + k] = v;
+            else if (item == 1) J.grad[J.m.g1() + k] = J.m.no_ln ? 0.0f : v;
+            else if (item == 2) J.grad[J.m.be1() + k] = J.m.no_ln ? 0.0f : v;
+            else J.grad[J.m.W1() + k * in + (item - 3)] = v;
         }
         STAMP();
         STAMP_FLUSH(48, b == kWgTilesPerBlock + kWgVecWgs && j == 0 && tid == 0);
@@ -1587,7 +1594,7 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
             J.net = N->critic + h * kQ.padded(); J.grad = N->grad_critic + h * kQ.padded(); J.m = kQ;
             J.ws[0] = s[S_C1 + h]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
         }
-        hipLaunchKernelGGL(wgrad_kernel, dim3(W.njobs * kWgPerJob), dim3(kThreads), 0, st, W);
+        hipLaunchKernelGGL(wgrad_kernel, dim3(W.njobs * kWgPerJob), dim3(kWide), 0, st, W);
     }
     HX_CHECK_LAUNCH("hx_hirl_critic_grads");
     return 0;
@@ -1701,7 +1708,7 @@ int hx_hirl_actor_wgrad(const HxNets* N, const HxHyper* Hy, int32_t batch, int32
     J.ws[0] = s[S_API]; J.rows[0] = batch; J.wmode[0] = 1;
     J.nslots = 1;
     if (bc) { J.ws[1] = s[S_ABC]; J.rows[1] = batch; J.wmode[1] = 2; J.nslots = 2; }
-    hipLaunchKernelGGL(wgrad_kernel, dim3(kWgPerJob), dim3(kThreads), 0, (hipStream_t)stream, W);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(kWgPerJob), dim3(kWide), 0, (hipStream_t)stream, W);
     HX_CHECK_LAUNCH("hx_hirl_actor_wgrad");
     return 0;
 }
@@ -1786,7 +1793,7 @@ int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int
         WgJob& J = W.job[0];
         J = WgJob{};
         J.net = N->actor; J.grad = N->grad_actor; J.m = kActor; J.ws[0] = s[S_ABC]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
-        hipLaunchKernelGGL(wgrad_kernel, dim3(kWgPerJob), dim3(kThreads), 0, st, W);
+        hipLaunchKernelGGL(wgrad_kernel, dim3(kWgPerJob), dim3(kWide), 0, st, W);
     }
     HX_CHECK_LAUNCH("hx_bc_train_actor");
     return hx_adam(N, Hy, 2, step, 1.0f, 0, 0.0f, 0.0f, B, stream);
@@ -1887,7 +1894,7 @@ int hx_sac_critic_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
             J.net = h ? q2 : q1; J.grad = N->grad_critic + h * kQs.padded(); J.m = kQs;
             J.ws[0] = s[SS_Q1 + h]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
         }
-        hipLaunchKernelGGL(wgrad_kernel, dim3(W.njobs * kWgPerJob), dim3(kThreads), 0, st, W);
+        hipLaunchKernelGGL(wgrad_kernel, dim3(W.njobs * kWgPerJob), dim3(kWide), 0, st, W);
     }
     HX_CHECK_LAUNCH("hx_sac_critic_grads");
     return 0;
@@ -1947,7 +1954,7 @@ int hx_sac_policy_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
         WgJob& J = W.job[0];
         J = WgJob{};
         J.net = N->policy; J.grad = N->grad_policy; J.m = kPolicy; J.ws[0] = s[SS_PC]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
-        hipLaunchKernelGGL(wgrad_kernel, dim3(kWgPerJob), dim3(kThreads), 0, st, W);
+        hipLaunchKernelGGL(wgrad_kernel, dim3(kWgPerJob), dim3(kWide), 0, st, W);
     }
     HX_CHECK_LAUNCH("hx_sac_policy_grads");
     return 0;

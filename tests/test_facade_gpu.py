@@ -288,7 +288,8 @@ def test_expert_collector_bc_pipeline(tmp_path, capsys):
         T.MAX_STEP["straight_line"] = 1500
     log = capsys.readouterr().out
     losses = [float(l.split("bc_loss")[1]) for l in log.splitlines() if l.startswith("Episode")]
-    assert len(losses) == 3 and losses[-1] < 0.5 * losses[0] and "Validation 1:" in log
+    # an untrained actor's MSE against the pilot's stick levels is ~0.1-0.5; 900 steps bring the minibatch loss below 1e-3
+    assert len(losses) == 3 and max(losses) < 1e-3 and "Validation 1:" in log
     files = os.listdir(os.path.join(d, "model"))
     assert len(files) == 1 and files[0].endswith("Actor_Harfang_GYM")
     sd = torch.load(os.path.join(d, "model", files[0]))
