@@ -203,54 +203,49 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
     const int u = tid & (H1 - 1), rq = (tid >> 8) * 4;
     STAMP_DECL;
     STAMP();
-    {
-        const float4* W1v = reinterpret_cast<const float4*>(J.net + J.m.W1());
-        const int n4 = H1 * in / 4;  // 832 or 1088 float4
-        for (int e = tid; e < n4; e += kWide) reinterpret_cast<float4*>(w1s)[e] = W1v[e];
-    }
+    // Every global operand of the prologue is requested before the first one is consumed: W1 (one or two float4 per thread),
+    // the layer-1 vectors and this thread's element of the 16 x XP input tile travel together — one round trip, not three.
+    const float4* W1v = reinterpret_cast<const float4*>(J.net + J.m.W1());
+    const int n4 = H1 * in / 4;  // 832 or 1088 float4
+    const float4 wv0 = tid < n4 ? W1v[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 wv1 = tid + kWide < n4 ? W1v[tid + kWide] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float bias1 = J.net[J.m.b1() + u], g1v = J.net[J.m.g1() + u], be1v = J.net[J.m.be1() + u];
-
-    // 1. input tile xs[16][XP]
-    STAMP();
-    if (tid < RT * XP) xs[tid] = 0.0f;
-    __syncthreads();
-    STAMP();
-    if (tid < RT * 13) {
-        const int r = tid / 13, c = tid % 13;
-        if (r < nrow) xs[r * XP + c] = src_row(J.src, r0 + r)[J.col0 + c];
-    }
-    if (in == 17) {
-        if (J.act_mode == 0) {
-            if (tid >= 256 && tid < 256 + RT * 4) {
-                const int r = (tid - 256) >> 2, c = tid & 3;
-                if (r < nrow) xs[r * XP + 13 + c] = src_row(J.src, r0 + r)[13 + c];
-            }
-        } else if (J.act_mode == 3) {  // action rows prepared by an earlier kernel (SAC: sampled tanh-Gaussian actions)
-            if (tid >= 256 && tid < 256 + RT * 4) {
-                const int r = (tid - 256) >> 2, c = tid & 3;
-                if (r < nrow) xs[r * XP + 13 + c] = J.noise[(size_t)(r0 + r) * 4 + c];
-            }
-        } else if (wave < nrow) {
-            // head of the previous net: wave w owns row w
-            const int r = wave;
-            RowReg<H2> xh, y;
-            float mean, rstd, o[4];
-            head_row<4>(J.prev.ws.z2 + (size_t)(r0 + r) * H2, J.prev.net, J.prev.m, slope, xh, y, mean, rstd, o);
-            if (lane < 4) {
-                float a = tanhf(o[lane]);  // Actor.forward's tanh, HIRL.py:140
-                if (J.noise) {              // target smoothing, HIRL.py:264-267
-                    const float e = fminf(fmaxf(J.noise[lane], -J.noise_clamp), J.noise_clamp);
-                    a = fminf(fmaxf(a + e, -1.0f), 1.0f);
-                }
-                xs[r * XP + 13 + lane] = a;
-                if (nt == 0) J.prev.ws.outv[(size_t)(r0 + r) * OW + lane] = a;
-            }
-            if (nt == 0 && lane == 0) {
-                J.prev.ws.st2[(size_t)(r0 + r) * 2] = mean;
-                J.prev.ws.st2[(size_t)(r0 + r) * 2 + 1] = rstd;
-            }
+    // 1. input tile xs[16][XP]: thread -> (row, column); columns 13..16 carry the action of a 17-wide net, the rest is zero
+    const int xr = tid / XP, xc = tid % XP;
+    const bool head_mode = in == 17 && J.act_mode != 0 && J.act_mode != 3;
+    float xv = 0.0f;
+    if (tid < RT * XP && xr < nrow) {
+        if (xc < 13) xv = src_row(J.src, r0 + xr)[J.col0 + xc];
+        else if (in == 17 && xc < 17) {
+            if (J.act_mode == 0) xv = src_row(J.src, r0 + xr)[xc];                             // replayed action, row cols 13..16
+            else if (J.act_mode == 3) xv = J.noise[(size_t)(r0 + xr) * 4 + (xc - 13)];        // action rows of an earlier kernel (SAC)
         }
     }
+    STAMP();
+    if (head_mode && wave < nrow) {
+        // head of the previous net: wave w owns row w (its loads go out right behind the ones above, nothing waited on yet)
+        const int r = wave;
+        RowReg<H2> xh, y;
+        float mean, rstd, o[4];
+        head_row<4>(J.prev.ws.z2 + (size_t)(r0 + r) * H2, J.prev.net, J.prev.m, slope, xh, y, mean, rstd, o);
+        if (lane < 4) {
+            float a = tanhf(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // Actor.forward's tanh, HIRL.py:140
+            if (J.noise) {              // target smoothing, HIRL.py:264-267
+                const float e = fminf(fmaxf(J.noise[lane], -J.noise_clamp), J.noise_clamp);
+                a = fminf(fmaxf(a + e, -1.0f), 1.0f);
+            }
+            xs[r * XP + 13 + lane] = a;
+            if (nt == 0) J.prev.ws.outv[(size_t)(r0 + r) * OW + lane] = a;
+        }
+        if (nt == 0 && lane == 0) {
+            J.prev.ws.st2[(size_t)(r0 + r) * 2] = mean;
+            J.prev.ws.st2[(size_t)(r0 + r) * 2 + 1] = rstd;
+        }
+    }
+    STAMP();
+    if (tid < n4) reinterpret_cast<float4*>(w1s)[tid] = wv0;
+    if (tid + kWide < n4) reinterpret_cast<float4*>(w1s)[tid + kWide] = wv1;
+    if (tid < RT * XP && !(head_mode && xc >= 13 && xc < 17 && xr < nrow)) xs[tid] = xv;  // those four belong to the head wave
     __syncthreads();
     STAMP();
 
@@ -1376,50 +1371,60 @@ struct SampleArgs {
     int do_sample;  // 0: idx / idx_bc are inputs (parity tests, the N = 1 facade), only gather
 };
 
-// 1024 threads: thread (t = tid & 127.., part) — the all-pairs duplicate check of a 128-row group is spread over 8
-// threads per row (a lone wave retires about one instruction per 8 cycles, so serial scans are what cost time here).
+// 1024 threads.  With B <= 512 the two index streams (replay / expert rows, BC rows) are drawn side by side by the two halves
+// of the workgroup; the all-pairs duplicate check of a group is spread over several threads per row (a lone wave retires
+// about one instruction per 8 cycles, so serial scans are what cost time here).  The gather reads the indices from LDS.
 __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
     __shared__ __attribute__((aligned(16))) int cand[1024];
     __shared__ int dupf[1024];
+    __shared__ int fin[2][1024];
     const int tid = threadIdx.x;
     const int B = A.batch;
-    const int parts = 1024 / ((B + 63) / 64 * 64) > 0 ? 1024 / ((B + 63) / 64 * 64) : 1;  // threads per row
-    const int t = tid / parts, part = tid % parts;
+    const int np = B <= 512 ? 2 : 1;            // streams drawn in parallel
+    const int width = 1024 / np;                // threads per stream
+    const int bpad = (B + 63) / 64 * 64;
+    const int parts = width / bpad > 0 ? width / bpad : 1;  // threads per row
+    const int tl = tid % width, base = (tid / width) * width;
+    const int t = tl / parts, part = tl % parts;
     if (A.do_sample) {
         const unsigned long long tot = *A.total;
         const uint32_t len_main = (uint32_t)(tot < (unsigned long long)A.cap ? tot : (unsigned long long)A.cap);
         const uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
-        for (int stream = 0; stream < 2; ++stream) {  // 0: replay / expert rows, 1: BC rows
+        for (int pass = 0; pass < 2 / np; ++pass) {
+            const int stream = np == 2 ? tid / width : pass;  // 0: replay / expert rows, 1: BC rows
             int* out = stream == 1 ? A.idx_bc : A.idx;
-            if (!out) continue;
+            const bool live = out != nullptr && t < B;
             const bool main_grp = t < A.n_main;
             const uint32_t len = stream == 1 ? (uint32_t)A.bc_len : (main_grp ? len_main : (uint32_t)A.expert_len);
             const int lo = (stream == 1 || main_grp) ? 0 : A.n_main;  // groups: [0, n_main) and [n_main, batch)
             int v = 0;
-            bool dup = t < B;
+            bool dup = live;
             for (int round = 0; round < 128; ++round) {
                 if (dup) {
                     uint32_t u[4];
                     philox4x32_10((uint32_t)t, A.call, (uint32_t)stream, (uint32_t)round, k0, k1, u);
                     v = len ? (int)__umulhi(u[0], len) : 0;
                 }
-                if (part == 0 && t < B) {
-                    cand[t] = v;
-                    dupf[t] = 0;
+                if (part == 0 && live) {
+                    cand[base + t] = v;
+                    dupf[base + t] = 0;
                 }
                 __syncthreads();
-                if (t < B) {  // my slice of the earlier members of my group
+                if (live) {  // my slice of the earlier members of my group
                     const int span = (B + parts - 1) / parts;
                     const int s0 = max(lo, part * span), s1 = min(t, (part + 1) * span);
                     bool d = false;
-                    for (int s = s0; s < s1; ++s) d |= cand[s] == v;
-                    if (d) dupf[t] = 1;
+                    for (int s = s0; s < s1; ++s) d |= cand[base + s] == v;
+                    if (d) dupf[base + t] = 1;
                 }
                 __syncthreads();
-                dup = t < B && dupf[t] != 0;
+                dup = live && dupf[base + t] != 0;
                 if (!__syncthreads_or(dup)) break;  // nobody redraws: done (the common case after the first round)
             }
-            if (part == 0 && t < B) out[t] = v;
+            if (part == 0 && live) {
+                out[t] = v;
+                fin[stream][t] = v;
+            }
             __syncthreads();
         }
         if (tid < 4 && A.noise) {
@@ -1429,22 +1434,22 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
             const float rad = sqrtf(-2.0f * __logf(ua)), ang = 6.28318530717958647692f * ub;
             A.noise[tid] = A.sigma * ((tid & 1) ? rad * __sinf(ang) : rad * __cosf(ang));
         }
-        __threadfence_block();
+    } else {
+        for (int e = tid; e < B; e += 1024) {
+            fin[0][e] = A.idx[e];
+            if (A.idx_bc) fin[1][e] = A.idx_bc[e];
+        }
         __syncthreads();
     }
-    // gather: 8 lanes per row, one 16-B piece each
-    if (A.rows) {
-        for (int e = tid; e < B * 8; e += 1024) {
-            const int r = e >> 3, c = e & 7;
-            const float* src = (r < A.n_main ? A.ring : A.expert_ring) + (size_t)A.idx[r] * 32;
-            reinterpret_cast<float4*>(A.rows)[e] = reinterpret_cast<const float4*>(src)[c];
-        }
-    }
-    if (A.bc_rows && A.bc_table && A.idx_bc) {
-        for (int e = tid; e < B * 8; e += 1024) {
-            const int r = e >> 3, c = e & 7;
-            reinterpret_cast<float4*>(A.bc_rows)[e] = reinterpret_cast<const float4*>(A.bc_table + (size_t)A.idx_bc[r] * 32)[c];
-        }
+    // gather: 8 lanes per row, one 16-B piece each; both tiles' loads are in flight together
+    const bool bc = A.bc_rows && A.bc_table && A.idx_bc;
+    for (int e = tid; e < B * 8; e += 1024) {
+        const int r = e >> 3, c = e & 7;
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f), q = m;
+        if (A.rows) m = reinterpret_cast<const float4*>((r < A.n_main ? A.ring : A.expert_ring) + (size_t)fin[0][r] * 32)[c];
+        if (bc) q = reinterpret_cast<const float4*>(A.bc_table + (size_t)fin[1][r] * 32)[c];
+        if (A.rows) reinterpret_cast<float4*>(A.rows)[e] = m;
+        if (bc) reinterpret_cast<float4*>(A.bc_rows)[e] = q;
     }
 }
 
