@@ -352,8 +352,8 @@ __device__ __forceinline__ float u01(uint32_t u) { return ((float)(u >> 8) + 0.5
 
 // ---------------------------------------------------------------------------------------------------------------
 // act_fused: the whole policy for 16 observation rows in ONE workgroup — layer 1 + LN1 (VALU), z2 = h1 W2^T for all 512
-// columns (two 16-column MFMA tiles per wave, K = 256; W2 streams through LDS in 32-wide k-chunks, register-prefetched one
-// chunk ahead), then LN2 + final layer + tanh + exploration noise + clamp with one wave per row straight from the LDS copy
+// columns (two 16-column MFMA tiles per wave, K = 256; W2 streams through two LDS buffers in 16-wide k-chunks, register-
+// prefetched two chunks ahead), then LN2 + final layer + tanh + exploration noise + clamp with one wave per row straight from the LDS copy
 // of z2.  No z2 round trip through HBM, no second launch.
 // chooseAction / chooseActionSmallNoise / chooseActionNoNoise, HIRL.py:192-212.
 // ---------------------------------------------------------------------------------------------------------------
@@ -371,17 +371,20 @@ struct ActFusedArgs {
     uint32_t row0, call;
 };
 
-constexpr int ACT_KC = 32;            // k-chunk of W2 staged through LDS: 128 B per column = whole cache lines
+constexpr int ACT_KC = 16;            // k-chunk of W2 staged through LDS (64 B per column), double-buffered
 constexpr int ACT_LDW = ACT_KC + 8;   // pitch = 8 mod 16 dwords: conflict-free ds_read_b128 (see LDA1)
+constexpr int ACT_NCH = H1 / ACT_KC;  // 16 chunks
+static_assert(2 * H2 * ACT_LDW >= RT * LDA2, "the z2 tile reuses the W2 chunk buffers");
 
 __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
-    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * LDA2 + RT * XP + RT * 2 + H1 * 13 + H2 * ACT_LDW];
+    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2 + H1 * 13 + 2 * H2 * ACT_LDW];
     float* h1s = lds;
-    float* z2s = h1s + RT * LDA1;
-    float* xs = z2s + RT * LDA2;
+    float* xs = h1s + RT * LDA1;
     float* sts = xs + RT * XP;
     float* w1s = sts + RT * 2;
-    float* w2s = w1s + H1 * 13;  // [H2][ACT_LDW]: one k-chunk of W2, every column
+    float* wb0 = w1s + H1 * 13;        // [H2][ACT_LDW]: even k-chunks of W2, every column
+    float* wb1 = wb0 + H2 * ACT_LDW;   // odd k-chunks
+    float* z2s = wb0;                  // [RT][LDA2] once the last chunk has been multiplied
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * RT;
     const int nrow = min(RT, A.rows - r0);
@@ -391,12 +394,17 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     const int u = tid & (H1 - 1), rq = (tid >> 8) * 4;
     STAMP_DECL;
     STAMP();
-    // W2 chunk loader: 8 lanes cover one column's 128 B, a wave 8 columns, the workgroup 128 columns per pass, 4 passes.
-    // Every byte of W2 enters this CU exactly once, as whole lines, and is shared by all 16 waves from LDS.
-    const int piece = tid & 7, colb = tid >> 3;
+    // W2 chunk loader: 4 lanes cover one column's 64 B, the workgroup 256 columns per pass, 2 passes.  Every byte of W2 enters
+    // this CU once and is shared by all 16 waves from LDS.  Two register sets run two chunks ahead of the multiply, two LDS
+    // buffers one chunk ahead: per chunk one barrier, and the LDS stores of chunk c+1 sit under the MFMAs of chunk c.
+    const int piece = tid & 3, colb = tid >> 2;
     const float* w2g = net + m.W2() + (size_t)colb * H1 + piece * 4;
-    float4 pre0 = *reinterpret_cast<const float4*>(w2g), pre1 = *reinterpret_cast<const float4*>(w2g + (size_t)128 * H1),
-           pre2 = *reinterpret_cast<const float4*>(w2g + (size_t)256 * H1), pre3 = *reinterpret_cast<const float4*>(w2g + (size_t)384 * H1);
+    const int w2w = colb * ACT_LDW + piece * 4;
+#define ACT_LOAD(ra, rb, c) { ra = *reinterpret_cast<const float4*>(w2g + (c) * ACT_KC); rb = *reinterpret_cast<const float4*>(w2g + (size_t)256 * H1 + (c) * ACT_KC); }
+#define ACT_STORE(buf, ra, rb) { *reinterpret_cast<float4*>((buf) + w2w) = ra; *reinterpret_cast<float4*>((buf) + w2w + 256 * ACT_LDW) = rb; }
+    float4 e0, e1, o0, o1;  // even / odd register sets
+    ACT_LOAD(e0, e1, 0);
+    ACT_LOAD(o0, o1, 1);
     // all independent operands first
     float xv = 0.0f;
     if (tid < RT * 13) {
@@ -443,50 +451,43 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         const int row = rq + r;
         h1s[row * LDA1 + u] = act_f(g1v * ((z1[r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
     }
-    float* w2w = w2s + colb * ACT_LDW + piece * 4;
-    *reinterpret_cast<float4*>(w2w) = pre0;
-    *reinterpret_cast<float4*>(w2w + 128 * ACT_LDW) = pre1;
-    *reinterpret_cast<float4*>(w2w + 256 * ACT_LDW) = pre2;
-    *reinterpret_cast<float4*>(w2w + 384 * ACT_LDW) = pre3;
+    ACT_STORE(wb0, e0, e1);
+    ACT_LOAD(e0, e1, 2);
     __syncthreads();
     STAMP();
     {   // z2 tiles: columns 16*wave .. and 256 + 16*wave ..; k ascending, chunk by chunk
         const int r = lane & 15, g = lane >> 4;
         v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         const float* ap = h1s + r * LDA1 + 4 * g;
-        const float* bp0 = w2s + (wave * 16 + r) * ACT_LDW + 4 * g;
-        const float* bp1 = bp0 + 256 * ACT_LDW;
-        for (int c = 0; c < H1 / ACT_KC; ++c) {
-            const bool more = c + 1 < H1 / ACT_KC;
-            if (more) {  // next chunk: in flight while this one is multiplied
-                const float* gsrc = w2g + (c + 1) * ACT_KC;
-                pre0 = *reinterpret_cast<const float4*>(gsrc);
-                pre1 = *reinterpret_cast<const float4*>(gsrc + (size_t)128 * H1);
-                pre2 = *reinterpret_cast<const float4*>(gsrc + (size_t)256 * H1);
-                pre3 = *reinterpret_cast<const float4*>(gsrc + (size_t)384 * H1);
+        const int boff = (wave * 16 + r) * ACT_LDW + 4 * g;
+#define ACT_MUL(buf, c) { \
+            const float4 a4 = *reinterpret_cast<const float4*>(ap + (c) * ACT_KC); \
+            const float4 p4 = *reinterpret_cast<const float4*>((buf) + boff); \
+            const float4 q4 = *reinterpret_cast<const float4*>((buf) + boff + 256 * ACT_LDW); \
+            acc0 = mfma16(a4.x, p4.x, acc0); acc1 = mfma16(a4.x, q4.x, acc1); \
+            acc0 = mfma16(a4.y, p4.y, acc0); acc1 = mfma16(a4.y, q4.y, acc1); \
+            acc0 = mfma16(a4.z, p4.z, acc0); acc1 = mfma16(a4.z, q4.z, acc1); \
+            acc0 = mfma16(a4.w, p4.w, acc0); acc1 = mfma16(a4.w, q4.w, acc1); }
+        for (int c = 0; c < ACT_NCH; c += 2) {
+            // even chunk c is in wb0; the odd set holds chunk c+1, the even set chunk c+2 (in flight)
+            ACT_STORE(wb1, o0, o1);
+            if (c + 3 < ACT_NCH) ACT_LOAD(o0, o1, c + 3);
+            ACT_MUL(wb0, c);
+            __syncthreads();
+            // odd chunk c+1 is in wb1
+            if (c + 2 < ACT_NCH) {
+                ACT_STORE(wb0, e0, e1);
+                if (c + 4 < ACT_NCH) ACT_LOAD(e0, e1, c + 4);
             }
-#pragma unroll
-            for (int j = 0; j < ACT_KC; j += 16) {
-                const float4 a4 = *reinterpret_cast<const float4*>(ap + c * ACT_KC + j);
-                const float4 p4 = *reinterpret_cast<const float4*>(bp0 + j);
-                const float4 q4 = *reinterpret_cast<const float4*>(bp1 + j);
-                acc0 = mfma16(a4.x, p4.x, acc0); acc1 = mfma16(a4.x, q4.x, acc1);
-                acc0 = mfma16(a4.y, p4.y, acc0); acc1 = mfma16(a4.y, q4.y, acc1);
-                acc0 = mfma16(a4.z, p4.z, acc0); acc1 = mfma16(a4.z, q4.z, acc1);
-                acc0 = mfma16(a4.w, p4.w, acc0); acc1 = mfma16(a4.w, q4.w, acc1);
-            }
-            if (more) {
-                __syncthreads();  // every wave is done with this chunk
-                *reinterpret_cast<float4*>(w2w) = pre0;
-                *reinterpret_cast<float4*>(w2w + 128 * ACT_LDW) = pre1;
-                *reinterpret_cast<float4*>(w2w + 256 * ACT_LDW) = pre2;
-                *reinterpret_cast<float4*>(w2w + 384 * ACT_LDW) = pre3;
-                __syncthreads();
-            }
+            ACT_MUL(wb1, c + 1);
+            __syncthreads();
         }
+#undef ACT_MUL
+#undef ACT_LOAD
+#undef ACT_STORE
         const float bb0 = net[m.b2() + wave * 16 + r], bb1 = net[m.b2() + 256 + wave * 16 + r];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 4; ++q) {  // every wave is past the last barrier: the chunk buffers are free for z2
             z2s[(4 * g + q) * LDA2 + wave * 16 + r] = acc0[q] + bb0;
             z2s[(4 * g + q) * LDA2 + 256 + wave * 16 + r] = acc1[q] + bb1;
         }
@@ -832,16 +833,14 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
     }
     __syncthreads();
     STAMP();
-    if (lead && tid == 0) {
-        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-        for (int w = 0; w < 16; ++w) {
-            p0 += red[w][0]; p1 += red[w][1]; p2 += red[w][2]; p3 += red[w][3];
-        }
-        if (J.mode == BM_CRITIC_TD) atomicAdd(&A.losses[J.loss_slot], p0);
-        if (J.mode == BM_CRITIC_PI) atomicAdd(&A.losses[3], p3);
-        if (J.mode == BM_ACTOR_BC) {
-            atomicAdd(&A.losses[2], p2);
-            atomicAdd(&A.losses[4], p1);
+    if (lead && wave == 0) {  // lane -> (row w = lane & 15, partial c = lane >> 4): one DPP sum over each 16-lane row
+        const int c = lane >> 4;
+        const float p = sum16(red[lane & 15][c]);
+        if ((lane & 15) == 0) {
+            if (J.mode == BM_CRITIC_TD && c == 0) atomicAdd(&A.losses[J.loss_slot], p);
+            if (J.mode == BM_CRITIC_PI && c == 3) atomicAdd(&A.losses[3], p);
+            if (J.mode == BM_ACTOR_BC && c == 2) atomicAdd(&A.losses[2], p);
+            if (J.mode == BM_ACTOR_BC && c == 1) atomicAdd(&A.losses[4], p);
         }
     }
     // ---------------- dh1 tile on fp32 MFMA: wave = (column tile ct, K quarter kq), K = 512 ----------------
