@@ -1158,6 +1158,15 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
             const float sc = scale[s];
             for (int c0 = 0; c0 < J.rows[s]; c0 += kWgRowChunk) {
                 const int nr = min(kWgRowChunk, J.rows[s] - c0);
+                // this thread's first 8 rows are requested before the per-row scalars are staged: one round trip, not two
+                float zv[8], dv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = rg + kWgRG * i;
+                    const bool ok = r < nr;
+                    zv[i] = ok ? S.z2[(size_t)(c0 + r) * H2 + n] : 0.0f;
+                    dv[i] = ok ? S.dz2[(size_t)(c0 + r) * H2 + n] : 0.0f;
+                }
                 __syncthreads();
                 for (int e = tid; e < nr; e += kWide) {
                     rinfo[e * RP] = S.st2[(size_t)(c0 + e) * 2];
@@ -1169,13 +1178,14 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
                 }
                 __syncthreads();
                 for (int rb = rg; rb < nr; rb += kWgRG * 8) {  // 8 rows per thread per block, all loads in flight together
-                    float zv[8], dv[8];
+                    if (rb != rg) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int r = rb + kWgRG * i;
-                        const bool ok = r < nr;
-                        zv[i] = ok ? S.z2[(size_t)(c0 + r) * H2 + n] : 0.0f;
-                        dv[i] = ok ? S.dz2[(size_t)(c0 + r) * H2 + n] : 0.0f;
+                        for (int i = 0; i < 8; ++i) {
+                            const int r = rb + kWgRG * i;
+                            const bool ok = r < nr;
+                            zv[i] = ok ? S.z2[(size_t)(c0 + r) * H2 + n] : 0.0f;
+                            dv[i] = ok ? S.dz2[(size_t)(c0 + r) * H2 + n] : 0.0f;
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -1232,6 +1242,14 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
             const float sc = scale[s];
             for (int c0 = 0; c0 < J.rows[s]; c0 += kWgRowChunk) {
                 const int nr = min(kWgRowChunk, J.rows[s] - c0);
+                float zv[8], dv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = rg + kWgRG * i;
+                    const bool ok = r < nr;
+                    zv[i] = ok ? S.z1[(size_t)(c0 + r) * H1 + k] : 0.0f;
+                    dv[i] = ok ? S.dh1[(size_t)(c0 + r) * H1 + k] : 0.0f;
+                }
                 __syncthreads();
                 for (int e = tid; e < nr * XP; e += kWide) xs[e] = S.x[(size_t)c0 * XP + e];
                 for (int e = tid; e < nr; e += kWide) {
@@ -1243,13 +1261,14 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
                 }
                 __syncthreads();
                 for (int rb = rg; rb < nr; rb += kWgRG * 8) {
-                    float zv[8], dv[8];
+                    if (rb != rg) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int r = rb + kWgRG * i;
-                        const bool ok = r < nr;
-                        zv[i] = ok ? S.z1[(size_t)(c0 + r) * H1 + k] : 0.0f;
-                        dv[i] = ok ? S.dh1[(size_t)(c0 + r) * H1 + k] : 0.0f;
+                        for (int i = 0; i < 8; ++i) {
+                            const int r = rb + kWgRG * i;
+                            const bool ok = r < nr;
+                            zv[i] = ok ? S.z1[(size_t)(c0 + r) * H1 + k] : 0.0f;
+                            dv[i] = ok ? S.dh1[(size_t)(c0 + r) * H1 + k] : 0.0f;
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
