@@ -42,7 +42,10 @@ def parse():
     p.add_argument("--warmup", type=int, default=200)
     p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     p.add_argument("--batch", type=int, default=128)
-    p.add_argument("--scenario", default="straight_line")
+    p.add_argument("--scenario", default="straight_line", choices=["straight_line", "serpentine", "circular", "mixed"],
+                   help="mixed: scenario id = env id mod 3, sorted so that each third of the shard is one scenario (BASELINE.json configs[4])")
+    p.add_argument("--type", default="soft", choices=["soft", "linear", "fixed"], help="HIRL BC-weight schedule (train_all.py:328-339)")
+    p.add_argument("--bc_weight", type=float, default=0.5, help="linear / fixed: the weight (configs[3]: linear, 0.5)")
     p.add_argument("--agent", default="hirl", choices=["hirl", "sac"], help="sac: BASELINE.json configs[2] (use --envs 16384 --scenario serpentine)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -105,7 +108,10 @@ class Loop:
         n = args.envs
         self.max_step = 1900 if args.scenario == "circular" else 1500  # train_all.py:159-183
         self.replay = DeviceReplay(max(1 << 20, 2 * n), device)
-        self.env = BatchedHarfangEnv(n, scenario=args.scenario, device=device, seed=0, max_step=self.max_step, auto_reset=True,
+        scenario = getattr(args, "scenario", "straight_line")
+        if scenario == "mixed":  # contiguous thirds: wavefronts never mix scenarios
+            scenario = np.sort((np.arange(n) + rank * n) % 3).astype(np.int32)
+        self.env = BatchedHarfangEnv(n, scenario=scenario, device=device, seed=0, max_step=self.max_step, auto_reset=True,
                                      random_reset=True, env_id0=rank * n, replay=self.replay)
         rng = np.random.default_rng(0)  # same networks and expert set on every rank (replicas)
         actor, critic, bc = init_params(rng)
@@ -184,7 +190,13 @@ class Loop:
         self.pipe.prefetch(self._act_env, acting_net_untouched=not e.actor_trainable)
         # soft weight: estimated at the start of every max_step-long "episode" of vector steps, kept in between
         # (the reference re-estimates at most once per episode)
-        w = 100 if (self.t % self.max_step == 0) else None
+        kind = getattr(self.args, "type", "soft")
+        if kind == "soft":
+            w = 100 if (self.t % self.max_step == 0) else None
+        elif kind == "linear":  # bc_weight - episode / 5000, floored at 0 (train_all.py:328-331); episode = max_step vector steps
+            w = max(self.args.bc_weight - (self.t // self.max_step) / 5000.0, 0.0)
+        else:
+            w = self.args.bc_weight
         e.learn(bc_weight_now=w, bc_warm_up_weight=0.0)
 
     def step(self):
@@ -284,8 +296,22 @@ def main():
     for _ in range(args.warmup):
         loop.step()
     # per-stage HIP events (recorded on the stream the kernels are launched on = torch's current stream)
+    ar_events = []
+    if world > 1:  # exchange step: HIP events around every gradient all-reduce of the first steps (on the stream it is enqueued on)
+        inner = loop.eng._allreduce
+
+        def timed_allreduce(t):
+            if loop.record and loop.pool:
+                a, b = loop.pool.pop(), loop.pool.pop()
+                a.record()
+                inner(t)
+                b.record()
+                ar_events.append((t.numel() * 4, a, b))
+            else:
+                inner(t)
+        loop.eng._allreduce = timed_allreduce
     nev = min(args.steps, 512)
-    loop.pool = [torch.cuda.Event(enable_timing=True) for _ in range(6 * (nev + 1))]
+    loop.pool = [torch.cuda.Event(enable_timing=True) for _ in range(16 * (nev + 1))]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -307,7 +333,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"{args.envs} parallel {args.scenario} envs per GPU, SAC fp32, 1 learn(B={args.batch}) per vector step "
                                 f"(BASELINE.json configs[2])" if args.agent == "sac" else
-                                f"{args.envs} parallel {args.scenario} envs per GPU, HIRL-soft fp32, 1 learn(B={args.batch}) per vector step "
+                                f"{args.envs} parallel {args.scenario} envs per GPU, HIRL-{args.type} fp32, 1 learn(B={args.batch}) per vector step "
                                 f"(BASELINE.json configs[1])"), "envs_per_gpu": args.envs, "batch": args.batch,
                    "actions": args.actions, "issue_order": "two streams" if loop.pipe.overlap else "serial", "update_path": "staged" if (args.staged or world > 1) and args.agent == "hirl" else "one-call",
                    "parallelism": f"dp{world}: env shards + replicated nets, RCCL all-reduce of the flat gradients"},
@@ -328,6 +354,12 @@ def main():
     res["roofline_act"] = {"kernels": "act_fused_kernel", "bound": "mfma", "unit": "TFLOP/s",
                            "achieved": round(ACTOR_FLOP * args.envs / act_us / 1e6, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
                            "frac": round(ACTOR_FLOP * args.envs / act_us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 5), "us": round(act_us, 2)}
+    if ar_events:  # SURVEY.md 8d "collective bytes": per message size, median us and bus bandwidth 2 (n-1)/n * bytes / t
+        by = {}
+        for nbytes, a, b in ar_events:
+            by.setdefault(nbytes, []).append(a.elapsed_time(b) * 1e3)
+        res["allreduce"] = [{"bytes": k, "calls": len(v), "median_us": round(float(np.median(v)), 2),
+                             "busbw_GBps": round(2 * (world - 1) / world * k / float(np.median(v)) / 1e3, 2)} for k, v in sorted(by.items())]
     res["env_stats"] = loop.env.stats_dict()
     if rank == 0:
         if args.sweep:
