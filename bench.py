@@ -16,6 +16,7 @@ episodes (random_reset, Philox), synthetic 20,000-row expert set, seeded-init ne
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -156,6 +157,7 @@ class Loop:
         from hirl4ucav_amd.utils.pipeline import VectorStepPipeline
         self.pipe = VectorStepPipeline(device, overlap=getattr(args, "overlap", False) and not self.sac)
         self.record, self.rec, self.pool = False, {"act": [], "env": [], "learn": []}, []
+        self.kpool, self.krec = [], []
 
     def _timed(self, name, fn):
         """Bracket fn() with HIP events on the stream it launches on (the current one) while recording is on."""
@@ -177,7 +179,12 @@ class Loop:
             self._timed("act", lambda: e.act(env.obs, seed=1, row0=env.env_id0, out=self.actions))  # SacAgent.explore
         else:
             self._timed("act", lambda: e.act(env.obs, sigma=0.1, seed=1, row0=env.env_id0, out=self.actions))  # actionNoise 0.1, HIRL.py:160
+        if self.record and self.kpool and self.t % 8 == 0:  # every 8th launch (the stamped launch costs ~9 us extra): the env kernel's own duration (what rocprofv3 reports), next to the bracketing events
+            a, b = self.kpool.pop(), self.kpool.pop()
+            env.time_next_steps(a, b)
+            self.krec.append((a, b))
         self._timed("env", lambda: env.step(self.actions))
+        env.time_next_steps(None, None)
 
     def _learn(self):
         e = self.eng
@@ -312,6 +319,8 @@ def main():
         loop.eng._allreduce = timed_allreduce
     nev = min(args.steps, 512)
     loop.pool = [torch.cuda.Event(enable_timing=True) for _ in range(16 * (nev + 1))]
+    L = loop.lib.load()
+    loop.kpool = [ctypes.c_void_p(L.hx_event_create()) for _ in range(2 * (nev + 1))]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -324,6 +333,12 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     act_us, env_us, learn_us = (float(np.median([a.elapsed_time(b) * 1e3 for a, b in loop.rec[k]])) for k in ("act", "env", "learn"))
+    kern = []
+    for a, b in loop.krec:  # kernel-only durations of the env-step launches inside the timed region
+        us = ctypes.c_float()
+        loop.lib.call("hx_event_elapsed_us", a, b, ctypes.byref(us))
+        kern.append(us.value)
+    env_kernel_us = float(np.mean(kern))  # mean, like the rocprofv3 --stats average it must agree with
     n_total = args.envs * world
     value = n_total * args.steps / dt
     res = {
@@ -341,9 +356,12 @@ def main():
         "stage_us": {"act(1 kernel)": round(act_us, 2), "env_step(1 kernel)": round(env_us, 2), "sample+learn(6-12 kernels)": round(learn_us, 2)},
     }
     # roofline of the env-step kernel (the kernel the metric counts): algorithmic bytes / live-measured launch time
-    res["roofline"] = {"kernel": "env_step_kernel<INSERT>", "bound": "hbm", "achieved": round(ENV_BYTES_FUSED * args.envs / env_us / 1e3, 1),
-                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ENV_BYTES_FUSED * args.envs / env_us / 1e3 / HBM_PEAK_GBPS, 4),
-                       "traffic": None, "bytes_per_launch": ENV_BYTES_FUSED * args.envs, "us_per_launch": round(env_us, 2),
+    res["roofline"] = {"kernel": "env_step_kernel<INSERT>", "bound": "hbm", "achieved": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3, 1),
+                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3 / HBM_PEAK_GBPS, 4),
+                       "traffic": None, "bytes_per_launch": ENV_BYTES_FUSED * args.envs, "us_per_launch": round(env_kernel_us, 2),
+                       "launches_timed": len(kern),
+                       "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the "
+                                 "timed region's first launches; stage_us brackets the launch with events and so includes the dispatch gap",
                        "traffic_note": "PMC (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per the gfx950 calibration) at "
                                        "1,048,576 envs per launch: 226.9 MB read + 351.6 MB written = 1.003 x the 576.7 MB algorithmic bytes "
                                        "(profiles/r01_pmc_*_env_1M.csv); not collectable inside this process"}

@@ -21,7 +21,8 @@ _vp, _i32, _i64, _u32, _u64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_in
 
 class HxStepOpts(ctypes.Structure):
     _fields_ = [("max_step", _i32), ("auto_reset", _i32), ("randomize", _i32), ("env_id0", _u32), ("seed", _u64),
-                ("episode_ctr", _vp), ("ring", _vp), ("ring_success", _vp), ("cap", _i64), ("total", _vp), ("stats", _vp)]
+                ("episode_ctr", _vp), ("ring", _vp), ("ring_success", _vp), ("cap", _i64), ("total", _vp), ("stats", _vp),
+                ("ev_start", _vp), ("ev_stop", _vp)]
 
 
 class HxError(RuntimeError):
@@ -33,6 +34,8 @@ _SIGNATURES = {
     "hx_env_step": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(HxStepOpts), _vp],
     "hx_env_rearm": [_vp, _i64, _i64, _vp, _vp],
     "hx_label_transitions": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "hx_event_destroy": [_vp],
+    "hx_event_elapsed_us": [_vp, _vp, ctypes.POINTER(ctypes.c_float)],
 }
 
 _lib = None
@@ -54,6 +57,8 @@ def load():
     L = ctypes.CDLL(SO_PATH)
     L.hx_last_error.restype = ctypes.c_char_p
     L.hx_version.restype = ctypes.c_int
+    L.hx_event_create.restype = ctypes.c_void_p
+    L.hx_event_create.argtypes = []
     for name, args in _SIGNATURES.items():
         fn = getattr(L, name)
         fn.argtypes = args

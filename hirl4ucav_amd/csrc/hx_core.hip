@@ -22,6 +22,26 @@ int hx_debug_copy_dword(const float* src, float* dst, int64_t n, void* stream) {
     HX_CHECK_LAUNCH("hx_debug_copy_dword");
     return 0;
 }
+void* hx_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) {
+        hx::fail(HX_ERR_ARG, "hx_event_create: hipEventCreate failed");
+        return nullptr;
+    }
+    return (void*)e;
+}
+int hx_event_destroy(void* ev) {
+    HX_REQUIRE(ev, "hx_event_destroy: null event");
+    HX_REQUIRE(hipEventDestroy((hipEvent_t)ev) == hipSuccess, "hx_event_destroy: hipEventDestroy failed");
+    return 0;
+}
+int hx_event_elapsed_us(void* start, void* stop, float* us) {
+    HX_REQUIRE(start && stop && us, "hx_event_elapsed_us: bad arguments");
+    float ms = 0.0f;
+    HX_REQUIRE(hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) == hipSuccess, "hx_event_elapsed_us: events not complete");
+    *us = ms * 1000.0f;
+    return 0;
+}
 const char* hx_last_error(void) { return hx::error_buffer(); }
 int hx_version(void) { return 100; }
 }

@@ -17,6 +17,7 @@
 // Numerics: this file is compiled with -ffp-contract=off; state-evolving arithmetic uses only + - * / sqrt in a
 // fixed order, so masks are reproducible bit for bit.  asinf/atan2f/acosf appear only in the observation.
 #include "hx_common.h"
+#include <hip/hip_ext.h>
 
 namespace {
 
@@ -630,9 +631,17 @@ int hx_env_step(float* state, int64_t n, int64_t stride, const float* actions, f
     if (A.o.ring) {
         HX_REQUIRE(A.o.cap > 0 && A.o.total, "hx_env_step: ring needs cap and total");
         HX_REQUIRE((reinterpret_cast<uintptr_t>(A.o.ring) & 15u) == 0, "hx_env_step: ring must be 16-byte aligned");
-        hipLaunchKernelGGL(env_step_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, A);
+        if (A.o.ev_start && A.o.ev_stop)
+            hipExtLaunchKernelGGL(env_step_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
+                                  (hipEvent_t)A.o.ev_start, (hipEvent_t)A.o.ev_stop, 0, A);
+        else
+            hipLaunchKernelGGL(env_step_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, A);
     } else {
-        hipLaunchKernelGGL(env_step_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, A);
+        if (A.o.ev_start && A.o.ev_stop)
+            hipExtLaunchKernelGGL(env_step_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
+                                  (hipEvent_t)A.o.ev_start, (hipEvent_t)A.o.ev_stop, 0, A);
+        else
+            hipLaunchKernelGGL(env_step_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, A);
     }
     HX_CHECK_LAUNCH("hx_env_step");
     return 0;

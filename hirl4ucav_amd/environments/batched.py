@@ -71,6 +71,11 @@ class BatchedHarfangEnv:
                   _lib.stream_ptr())
         return self.obs, self.reward, self.done, self.success
 
+    def time_next_steps(self, start=None, stop=None):
+        """Measurement: hx_event_create() handles that the following step launches stamp with the kernel's own begin / end
+        (None, None switches it off).  Read with hx_event_elapsed_us after a synchronise."""
+        self._opts.ev_start, self._opts.ev_stop = getattr(start, "value", start), getattr(stop, "value", stop)
+
     def rearm(self, mask=None):
         _lib.call("hx_env_rearm", _lib.ptr(self.state), self.n, self.n, _lib.ptr(mask), _lib.stream_ptr())
 

@@ -63,6 +63,10 @@ const char* hx_last_error(void);
 int hx_version(void);
 /* PMC calibration helper: dst[i] = src[i], one dword per lane (the env kernel's access shape), n floats */
 int hx_debug_copy_dword(const float* src, float* dst, int64_t n, void* stream);
+/* Kernel-duration events for HxStepOpts.ev_start / ev_stop (bench.py's live roofline measurement). */
+void* hx_event_create(void);
+int hx_event_destroy(void* ev);
+int hx_event_elapsed_us(void* start, void* stop, float* us /* host */);
 
 /* Optional per-call behaviour of hx_env_step.  All pointers device memory (or NULL = feature off). */
 typedef struct HxStepOpts {
@@ -79,6 +83,8 @@ typedef struct HxStepOpts {
     int64_t cap;
     uint64_t* total;       /* transitions ever stored; slot = total % cap (buffer.py:36 position) */
     uint64_t* stats;       /* [HX_STAT_COUNT] or NULL */
+    void* ev_start;        /* measurement only (host handles from hx_event_create, or NULL): the launch stamps the kernel's own */
+    void* ev_stop;         /* begin / end into them — the duration rocprofv3 reports, without the dispatch gap around it */
 } HxStepOpts;
 
 /* HarfangEnv.reset / random_reset (+ Serpentine/Circular variants): HarfangEnv_GYM.py:34-81,171-188,374-406,440-474.
