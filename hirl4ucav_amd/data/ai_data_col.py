@@ -38,7 +38,15 @@ def collect(scenario, episodes, if_random, seed=0, noise_std=0.0, device="cuda")
         if t % 64 == 63 and bool((obs[:, 12] <= 0).all()):
             break
         obs = env.step(a)[0]
-    S, A = S[:steps].cpu().numpy().astype(np.float64), A[:steps].cpu().numpy().astype(np.float64)
+    return filter_episodes(S[:steps].cpu().numpy().astype(np.float64), A[:steps].cpu().numpy().astype(np.float64))
+
+
+def filter_episodes(S, A):
+    """S [T, E, 13], A [T, E, 4] (one column per episode) -> (states, actions, info): the reference's validity rule
+    (ai_data_col.py:86): an episode counts when the opponent was destroyed within 2000 steps and the launch came 0..20 steps
+    after the first tick with lock and missile; each kept episode runs from its reset observation to the first observation
+    that shows the opponent destroyed."""
+    steps, episodes = S.shape[0], S.shape[1]
     states, actions, delt, invalid, lengths = [], [], [], 0, []
     for e in range(episodes):
         dead = np.nonzero(S[:, e, 12] <= 0)[0]
@@ -46,7 +54,7 @@ def collect(scenario, episodes, if_random, seed=0, noise_std=0.0, device="cuda")
         can = np.nonzero((S[:n, e, 7] > 0) & (S[:n, e, 8] > 0))[0]
         fired = np.nonzero(A[:n, e, 3] > 0)[0]
         lock, fire = (int(can[0]) if len(can) else 0), (int(fired[0]) if len(fired) else 0)
-        if not len(dead) or n > MAX_EPISODE_STEP or fire - lock > 20 or fire - lock < 0:  # ai_data_col.py:86
+        if not len(dead) or n > MAX_EPISODE_STEP or fire - lock > 20 or fire - lock < 0:
             invalid += 1
             continue
         states.append(S[:n, e]); actions.append(A[:n, e]); delt.append(fire - lock); lengths.append(n)

@@ -114,3 +114,54 @@ def test_checkpoint_view_uses_reference_key_names(tmp_path):
     assert list(loaded) == list(H.CRITIC_KEYS)  # a reference Critic.load_state_dict accepts it
     # hidden-weight bounds of kaiming_uniform_(a=0.01, 'relu'): sqrt(6 / fan_in)
     assert sd["full1.weight"].abs().max() <= np.sqrt(6 / 17) and sd["full2.weight"].abs().max() <= np.sqrt(6 / 256)
+
+
+def test_expert_pilot_steers_to_the_target_and_fires_only_on_lock():
+    """hirl4ucav_amd/data/expert_pilot.py: body-frame bearing -> stick levels; launch rule of ai_data_col.py:62-63."""
+    from hirl4ucav_amd.data.expert_pilot import ALLY_QUAT, OPPO_POS, pursuit_actions
+
+    n = 4
+    state = torch.zeros((37, n))
+    state[ALLY_QUAT] = 1.0                       # identity attitude: nose along +Z, Y up, X right
+    state[OPPO_POS + 2] = 1000.0                 # all targets 1 km ahead ...
+    state[OPPO_POS + 1, 1] = 300.0               # ... env 1: and above
+    state[OPPO_POS + 0, 2] = 300.0               # ... env 2: and to the right
+    state[OPPO_POS + 0, 3] = -300.0              # ... env 3: and to the left
+    obs = torch.zeros((n, 13))
+    obs[:, 7], obs[:, 8] = torch.tensor([1.0, 1.0, -1.0, 1.0]), torch.tensor([1.0, -1.0, 1.0, 1.0])
+    a = pursuit_actions(state, obs)
+    assert a.shape == (n, 4) and float(a.abs().max()) <= 1.0
+    assert torch.all(a[0, :3] == 0)                                   # dead ahead: sticks centred
+    assert a[1, 0] < 0 and a[1, 1] == 0 and a[1, 2] == 0               # above: pull up (positive pitch level = nose down)
+    assert a[2, 2] > 0 and a[2, 1] < 0 and a[3, 2] < 0 and a[3, 1] > 0  # right / left: yaw toward it, bank into the turn
+    assert a[:, 3].tolist() == [1.0, -1.0, -1.0, 1.0]                  # locked AND missile on the rail
+    g = torch.Generator().manual_seed(0)
+    b = pursuit_actions(state, obs, noise_std=0.05, generator=g)
+    assert not torch.equal(a[:, :3], b[:, :3]) and torch.equal(a[:, 3], b[:, 3])
+
+
+def test_collector_episode_filter():
+    """ai_data_col.py:86: keep an episode iff destroyed within 2000 steps and 0 <= fire - lock <= 20; rows run to the first
+    destroyed observation inclusive; kept episodes are concatenated in order."""
+    from hirl4ucav_amd.data.ai_data_col import filter_episodes
+
+    T, E = 60, 5
+    S = np.zeros((T, E, 13))
+    A = np.zeros((T, E, 4))
+    S[:, :, 7], S[:, :, 8], S[:, :, 12], A[:, :, 3] = -1, 1, 0.2, -1
+    S[:, :, 0] = np.arange(T)[:, None] + 100 * np.arange(E)[None, :]   # tag rows: step + 100 * episode
+    # 0: lock at 10, fire at 10, destroyed at 30 -> kept (31 rows)         1: never destroyed -> dropped
+    # 2: lock at 5, fire at 30 (delay 25) -> dropped                       3: lock at 8, no launch recorded (fire = 0) -> dropped (negative delay)
+    # 4: lock at 20, fire at 40 (delay 20), destroyed at 50 -> kept (51 rows)
+    for e, (lock, fire, dead) in {0: (10, 10, 30), 2: (5, 30, 45), 3: (8, None, 40), 4: (20, 40, 50)}.items():
+        S[lock:, e, 7] = 1
+        if fire is not None:
+            A[fire, e, 3] = 1
+            S[fire + 1:, e, 8] = -1
+        S[dead:, e, 12] = 0
+    S[12:, 1, 7] = 1
+    s, a, info = filter_episodes(S, A)
+    assert info == {"episodes": 5, "invalid": 3, "lengths": [31, 51], "delt": [0, 20]}
+    assert s.shape == (82, 13) and a.shape == (82, 4)
+    assert s[:31, 0].tolist() == list(range(31)) and s[31:, 0].tolist() == [400 + t for t in range(51)]
+    assert s[30, 12] == 0 and s[29, 12] > 0 and int((a[:, 3] > 0).sum()) == 2
