@@ -54,9 +54,11 @@ def parse():
     p.add_argument("--actions", default="policy", choices=["policy", "uniform"],
                    help="uniform: U(-1,1)^4 actions instead of the live actor (SURVEY.md 8d C2's second run, decoupled from the policy)")
     p.add_argument("--overlap", action="store_true",
-                   help="issue the next act + env.step on a second stream beside critic-only learns (bit-identical results; measured "
-                        "no faster on one MI355X: 145 vs 143 us/step, the kernels contend for the same CUs/LDS). Default: one stream, "
-                        "the reference's strict act -> step -> sample -> learn order")
+                   help="issue the next act + env.step on a second stream beside critic-only learns (bit-identical results). On one "
+                        "GPU it does not pay (145 vs 143 us/step: the kernels contend for the same CUs/LDS), so the default there is the "
+                        "reference's strict act -> step -> sample -> learn order; with N > 1 it is ON by default, because there the side "
+                        "stream fills the time the main stream spends waiting in the gradient all-reduce")
+    p.add_argument("--serial", action="store_true", help="force the one-stream order at N > 1 too")
     p.add_argument("--staged", action="store_true",
                    help="use the stage-by-stage update path of the sharded build on one rank too (costs of the N > 1 launch sequence)")
     return p.parse_args()
@@ -155,7 +157,7 @@ class Loop:
         self.t = 0
         self.actions = torch.zeros((n, 4), device=device)
         from hirl4ucav_amd.utils.pipeline import VectorStepPipeline
-        self.pipe = VectorStepPipeline(device, overlap=getattr(args, "overlap", False) and not self.sac)
+        self.pipe = VectorStepPipeline(device, overlap=(getattr(args, "overlap", False) or (world > 1 and not getattr(args, "serial", False))) and not self.sac)
         self.record, self.rec, self.pool = False, {"act": [], "env": [], "learn": []}, []
         self.kpool, self.krec = [], []
 
