@@ -364,9 +364,10 @@ struct ActFusedArgs {
     int rows;
     float slope;
     float* actions;      // [rows][4]
-    const float* noise;  // nullptr, [4] (shared) or [rows][4]
+    const float* noise;  // deterministic head: nullptr, [4] (shared) or [rows][4] additive noise; Gaussian head: eps [rows][4] or nullptr
     int noise_per_row;
     float sigma;
+    int mode;            // Gaussian head: 0 exploit tanh(mean), 1 sample with eps, 2 sample with Philox
     uint64_t seed;
     uint32_t row0, call;
 };
@@ -374,20 +375,38 @@ struct ActFusedArgs {
 constexpr int ACT_KC = 16;            // k-chunk of W2 staged through LDS (64 B per column), double-buffered
 constexpr int ACT_LDW = ACT_KC + 8;   // pitch = 8 mod 16 dwords: conflict-free ds_read_b128 (see LDA1)
 constexpr int ACT_NCH = H1 / ACT_KC;  // 16 chunks
-static_assert(2 * H2 * ACT_LDW >= RT * LDA2, "the z2 tile reuses the W2 chunk buffers");
 
+__device__ __forceinline__ float pick8(const float (&o)[8], int i) {
+    return i == 0 ? o[0] : i == 1 ? o[1] : i == 2 ? o[2] : i == 3 ? o[3] : i == 4 ? o[4] : i == 5 ? o[5] : i == 6 ? o[6] : o[7];
+}
+// one standard-normal draw per (row, component j) of the acting kernels: Philox4x32-10(seed; row, call, tag) + Box-Muller
+__device__ __forceinline__ float philox_normal(uint32_t row, uint32_t call, uint32_t tag, uint64_t seed, int j) {
+    uint32_t u[4];
+    philox4x32_10(row, call, tag, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), u);
+    const float ua = u01(u[j & 2]), ub = u01(u[(j & 2) + 1]);
+    const float rad = sqrtf(-2.0f * logf(ua)), ang = 6.28318530717958647692f * ub;
+    return (j & 1) ? rad * sinf(ang) : rad * cosf(ang);
+}
+
+// NRT = 16-row tiles per workgroup: 1 keeps 256 workgroups busy at 4,096 rows; 2 (from 8,192 rows on) multiplies every W2
+// chunk against two row tiles, halving W2's L2 traffic and the barriers per MFMA.
+// GAUSS = the SAC policy: plain Linear-ReLU stack (m.no_ln), 8-wide head = mean ++ log_std, tanh-Gaussian sample
+// (SacAgent.explore / exploit, SAC/agent.py:183-196, GaussianPolicy.sample, SAC/model.py:63-82).
+template <int NRT, bool GAUSS>
 __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
-    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2 + H1 * 13 + 2 * H2 * ACT_LDW];
+    constexpr int ROWS = NRT * RT;
+    static_assert(2 * H2 * ACT_LDW >= ROWS * LDA2, "the z2 tile reuses the W2 chunk buffers");
+    __shared__ __attribute__((aligned(16))) float lds[ROWS * LDA1 + ROWS * XP + ROWS * 2 + H1 * 13 + 2 * H2 * ACT_LDW];
     float* h1s = lds;
-    float* xs = h1s + RT * LDA1;
-    float* sts = xs + RT * XP;
-    float* w1s = sts + RT * 2;
+    float* xs = h1s + ROWS * LDA1;
+    float* sts = xs + ROWS * XP;
+    float* w1s = sts + ROWS * 2;
     float* wb0 = w1s + H1 * 13;        // [H2][ACT_LDW]: even k-chunks of W2, every column
     float* wb1 = wb0 + H2 * ACT_LDW;   // odd k-chunks
-    float* z2s = wb0;                  // [RT][LDA2] once the last chunk has been multiplied
+    float* z2s = wb0;                  // [ROWS][LDA2] once the last chunk has been multiplied
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int r0 = blockIdx.x * RT;
-    const int nrow = min(RT, A.rows - r0);
+    const int r0 = blockIdx.x * ROWS;
+    const int nrow = min(ROWS, A.rows - r0);
     const float* net = A.net;
     const Mlp m = A.m;
     const float slope = A.slope;
@@ -407,67 +426,77 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     ACT_LOAD(o0, o1, 1);
     // all independent operands first
     float xv = 0.0f;
-    if (tid < RT * 13) {
+    if (tid < ROWS * 13) {
         const int r = tid / 13;
-        if (r < nrow) xv = A.obs[(size_t)r0 * 13 + tid];  // the 16 x 13 tile is contiguous
+        if (r < nrow) xv = A.obs[(size_t)r0 * 13 + tid];  // the ROWS x 13 tile is contiguous
     }
     float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < H1 * 13 / 4) wv = reinterpret_cast<const float4*>(net + m.W1())[tid];
     const float bias1 = net[m.b1() + u], g1v = net[m.g1() + u], be1v = net[m.be1() + u];
     if (tid < H1 * 13 / 4) reinterpret_cast<float4*>(w1s)[tid] = wv;
-    if (tid < RT * XP) xs[tid] = 0.0f;
+    if (tid < ROWS * XP) xs[tid] = 0.0f;
     __syncthreads();
-    if (tid < RT * 13) xs[(tid / 13) * XP + tid % 13] = xv;
+    if (tid < ROWS * 13) xs[(tid / 13) * XP + tid % 13] = xv;
     __syncthreads();
-    float z1[4];
-    {
+    float z1[NRT][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z1[r] = bias1;
+    for (int t = 0; t < NRT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z1[t][r] = bias1;
         const float* wrow = w1s + u * 13;
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
             const float w = wrow[i];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z1[r] += xs[(rq + r) * XP + i] * w;
+            for (int r = 0; r < 4; ++r) z1[t][r] += xs[(t * RT + rq + r) * XP + i] * w;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h1s[(rq + r) * LDA1 + u] = z1[r];
+        for (int r = 0; r < 4; ++r) h1s[(t * RT + rq + r) * LDA1 + u] = z1[t][r];
     }
     __syncthreads();
-    {
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {  // LN1 statistics: wave w owns rows w, 16 + w
+        const int row = t * RT + wave;
         float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = h1s[wave * LDA1 + i * 64 + lane];
+        for (int i = 0; i < 4; ++i) v[i] = h1s[row * LDA1 + i * 64 + lane];
         float mean, rstd;
         row_stats<4>(v, H1, mean, rstd);
+        if (m.no_ln) { mean = 0.0f; rstd = 1.0f; }
         if (lane == 0) {
-            sts[wave * 2] = mean;
-            sts[wave * 2 + 1] = rstd;
+            sts[row * 2] = mean;
+            sts[row * 2 + 1] = rstd;
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = rq + r;
-        h1s[row * LDA1 + u] = act_f(g1v * ((z1[r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
-    }
+    for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = t * RT + rq + r;
+            h1s[row * LDA1 + u] = act_f(g1v * ((z1[t][r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
+        }
     ACT_STORE(wb0, e0, e1);
     ACT_LOAD(e0, e1, 2);
     __syncthreads();
     STAMP();
-    {   // z2 tiles: columns 16*wave .. and 256 + 16*wave ..; k ascending, chunk by chunk
+    {   // z2 tiles: columns 16*wave .. and 256 + 16*wave .. of every row tile; k ascending, chunk by chunk
         const int r = lane & 15, g = lane >> 4;
-        v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        v4f acc[NRT][2];
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) acc[t][0] = acc[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
         const float* ap = h1s + r * LDA1 + 4 * g;
         const int boff = (wave * 16 + r) * ACT_LDW + 4 * g;
 #define ACT_MUL(buf, c) { \
-            const float4 a4 = *reinterpret_cast<const float4*>(ap + (c) * ACT_KC); \
+            float4 a4[NRT]; \
+            _Pragma("unroll") for (int t = 0; t < NRT; ++t) a4[t] = *reinterpret_cast<const float4*>(ap + t * RT * LDA1 + (c) * ACT_KC); \
             const float4 p4 = *reinterpret_cast<const float4*>((buf) + boff); \
             const float4 q4 = *reinterpret_cast<const float4*>((buf) + boff + 256 * ACT_LDW); \
-            acc0 = mfma16(a4.x, p4.x, acc0); acc1 = mfma16(a4.x, q4.x, acc1); \
-            acc0 = mfma16(a4.y, p4.y, acc0); acc1 = mfma16(a4.y, q4.y, acc1); \
-            acc0 = mfma16(a4.z, p4.z, acc0); acc1 = mfma16(a4.z, q4.z, acc1); \
-            acc0 = mfma16(a4.w, p4.w, acc0); acc1 = mfma16(a4.w, q4.w, acc1); }
+            _Pragma("unroll") for (int t = 0; t < NRT; ++t) { \
+                acc[t][0] = mfma16(a4[t].x, p4.x, acc[t][0]); acc[t][1] = mfma16(a4[t].x, q4.x, acc[t][1]); \
+                acc[t][0] = mfma16(a4[t].y, p4.y, acc[t][0]); acc[t][1] = mfma16(a4[t].y, q4.y, acc[t][1]); \
+                acc[t][0] = mfma16(a4[t].z, p4.z, acc[t][0]); acc[t][1] = mfma16(a4[t].z, q4.z, acc[t][1]); \
+                acc[t][0] = mfma16(a4[t].w, p4.w, acc[t][0]); acc[t][1] = mfma16(a4[t].w, q4.w, acc[t][1]); } }
         for (int c = 0; c < ACT_NCH; c += 2) {
             // even chunk c is in wb0; the odd set holds chunk c+1, the even set chunk c+2 (in flight)
             ACT_STORE(wb1, o0, o1);
@@ -487,35 +516,61 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 #undef ACT_STORE
         const float bb0 = net[m.b2() + wave * 16 + r], bb1 = net[m.b2() + 256 + wave * 16 + r];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {  // every wave is past the last barrier: the chunk buffers are free for z2
-            z2s[(4 * g + q) * LDA2 + wave * 16 + r] = acc0[q] + bb0;
-            z2s[(4 * g + q) * LDA2 + 256 + wave * 16 + r] = acc1[q] + bb1;
-        }
+        for (int t = 0; t < NRT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // every wave is past the last barrier: the chunk buffers are free for z2
+                z2s[(t * RT + 4 * g + q) * LDA2 + wave * 16 + r] = acc[t][0][q] + bb0;
+                z2s[(t * RT + 4 * g + q) * LDA2 + 256 + wave * 16 + r] = acc[t][1][q] + bb1;
+            }
     }
     __syncthreads();
     STAMP();
-    if (wave < nrow) {  // head: wave w owns row w
-        const int r = r0 + wave;
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {  // head: wave w owns rows w, 16 + w
+        const int lr = t * RT + wave;
+        if (lr >= nrow) continue;
+        const int r = r0 + lr;
         RowReg<H2> xh, y;
-        float mean, rstd, o[4];
-        head_row<4>(z2s + wave * LDA2, net, m, slope, xh, y, mean, rstd, o);
-        if (lane < 4) {
-            float a = tanhf(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // no dynamic register index
-            if (A.noise) {
-                a = fminf(fmaxf(a + A.noise[(A.noise_per_row ? (size_t)r * 4 : 0) + lane], -1.0f), 1.0f);
-            } else if (A.sigma > 0.0f) {
-                uint32_t uu[4];
-                philox4x32_10(A.row0 + (uint32_t)r, A.call, 0x61637421u, 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32), uu);
-                const float ua = u01(uu[lane & 2]), ub = u01(uu[(lane & 2) + 1]);
-                const float rad = sqrtf(-2.0f * logf(ua)), ang = 6.28318530717958647692f * ub;
-                const float n = (lane & 1) ? rad * sinf(ang) : rad * cosf(ang);
-                a = fminf(fmaxf(a + A.sigma * n, -1.0f), 1.0f);
+        float mean, rstd;
+        if (!GAUSS) {
+            float o[4];
+            head_row<4>(z2s + lr * LDA2, net, m, slope, xh, y, mean, rstd, o);
+            if (lane < 4) {
+                float a = tanhf(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // no dynamic register index
+                if (A.noise) {
+                    a = fminf(fmaxf(a + A.noise[(A.noise_per_row ? (size_t)r * 4 : 0) + lane], -1.0f), 1.0f);
+                } else if (A.sigma > 0.0f) {
+                    const float n = philox_normal(A.row0 + (uint32_t)r, A.call, 0x61637421u, A.seed, lane);
+                    a = fminf(fmaxf(a + A.sigma * n, -1.0f), 1.0f);
+                }
+                A.actions[(size_t)r * 4 + lane] = a;
             }
-            A.actions[(size_t)r * 4 + lane] = a;
+        } else {
+            float o[8];
+            head_row<8>(z2s + lr * LDA2, net, m, slope, xh, y, mean, rstd, o);
+            if (lane < 4) {
+                const float mu = pick8(o, lane);
+                float a = mu;
+                if (A.mode != 0) {
+                    const float ls = fminf(fmaxf(pick8(o, 4 + lane), -20.0f), 2.0f);  // model.py:65-66
+                    const float e = A.mode == 1 ? A.noise[(size_t)r * 4 + lane] : philox_normal(A.row0 + (uint32_t)r, A.call, 0x53414331u, A.seed, lane);
+                    a = mu + expf(ls) * e;
+                }
+                A.actions[(size_t)r * 4 + lane] = tanhf(a);
+            }
         }
     }
     STAMP();
     STAMP_FLUSH(56, (blockIdx.x == 0 || blockIdx.x == 200) && tid == 0);
+}
+
+// 16 rows per workgroup fill the chip up to 4,096 rows; from 8,192 rows on 32 rows per workgroup reuse every W2 chunk twice
+template <bool GAUSS>
+static void launch_act(const ActFusedArgs& H, hipStream_t st) {
+    if (H.rows >= 8192)
+        hipLaunchKernelGGL((act_fused_kernel<2, GAUSS>), dim3((unsigned)((H.rows + 2 * RT - 1) / (2 * RT))), dim3(kWide), 0, st, H);
+    else
+        hipLaunchKernelGGL((act_fused_kernel<1, GAUSS>), dim3((unsigned)((H.rows + RT - 1) / RT)), dim3(kWide), 0, st, H);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -894,9 +949,6 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
 // ---------------------------------------------------------------------------------------------------------------
 // SAC (hirl/agents/SAC): small per-row kernels around the shared fwd_l2 / bwd_l2<3> / wgrad machinery.  One wave per row.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float pick8(const float (&o)[8], int i) {
-    return i == 0 ? o[0] : i == 1 ? o[1] : i == 2 ? o[2] : i == 3 ? o[3] : i == 4 ? o[4] : i == 5 ? o[5] : i == 6 ? o[6] : o[7];
-}
 // GaussianPolicy.sample (SAC/model.py:69-82) from the policy's z2 rows: mean, log_std = chunk(head), clamp(log_std, -20, 2),
 // x = mean + exp(log_std) eps, a = tanh(x), entropy = -sum_j (log N(x_j) - log(1 - a_j^2 + 1e-6)).
 struct GaussArgs {
@@ -1546,8 +1598,8 @@ int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* acti
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act: bad noise mode");
     (void)ws;
     ActFusedArgs H{actor, kActor, obs, (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
-                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, seed, row0, call};
-    hipLaunchKernelGGL(act_fused_kernel, dim3((unsigned)((rows + RT - 1) / RT)), dim3(kWide), 0, (hipStream_t)stream, H);
+                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call};
+    launch_act<false>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_actor_act");
     return 0;
 }
@@ -1847,14 +1899,9 @@ static void sac_slots(const HxSacNets* N, int B, Slot* s) {
 int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps, uint64_t seed,
                uint32_t row0, uint32_t call, float* ws, void* stream) {
     HX_REQUIRE(policy && obs && actions && ws && rows > 0 && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act: bad arguments");
-    FwdArgs F{};
-    F.njobs = 1; F.slope = 0.0f;
-    FwdJob& J = F.job[0];
-    J.net = policy; J.m = kPolicy; J.src = RowSrc{obs, nullptr, nullptr, 0, 13}; J.rows = (int)rows;
-    J.ws = Slot{}; J.ws.z2 = ws;
-    launch_fwd(F, (hipStream_t)stream);
-    GaussArgs G{policy, kPolicy, ws, eps, (int)rows, mode, actions, nullptr, nullptr, seed, row0, call};
-    hipLaunchKernelGGL(gauss_head_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, G);
+    (void)ws;
+    ActFusedArgs H{policy, kPolicy, obs, (int)rows, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call};
+    launch_act<true>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_sac_act");
     return 0;
 }

@@ -66,6 +66,28 @@ def probes_of(e, eng_mod):
     return out
 
 
+def test_act_row_tilings_agree_bit_for_bit(eng_mod):
+    """hx_actor_act runs 16 rows per workgroup below 8,192 rows and 32 from there on (every W2 chunk multiplied against two row
+    tiles): the per-row arithmetic is the same, so the outputs must be identical, ragged tail included."""
+    params = D.make_params(D.PARAM_SEED)
+    e = eng_mod.HirlEngine(batch=128)
+    e.load_params(params["actor"], params["critic"], params["bc_actor"])
+    rng = np.random.default_rng(5)
+    n = 8192 + 37
+    obs = torch.from_numpy(rng.uniform(-1, 1, (n, 13)).astype(np.float32)).cuda()
+    per = torch.from_numpy(rng.normal(0, 0.3, (n, 4)).astype(np.float32)).cuda()
+    big = e.act(obs, noise=per)
+    parts = [e.act(obs[i:i + 4096], noise=per[i:i + 4096]) for i in range(0, n, 4096)]
+    assert torch.equal(big, torch.cat(parts))
+    o = H.HirlOracle(params["actor"], params["critic"], params["bc_actor"])
+    np.testing.assert_allclose(big[-200:].cpu().numpy(), o.choose_action(obs[-200:].cpu().numpy(), per[-200:].cpu().numpy()), rtol=1e-5, atol=1e-6)
+    # Philox exploration noise is keyed by the global row: the tiling does not change the draw
+    a1 = e.act(obs, sigma=0.1, seed=9)
+    e.act_calls -= 1
+    a2 = torch.cat([e.act(obs[:4096], sigma=0.1, seed=9, row0=0)] + [None] * 0)
+    assert torch.equal(a1[:4096], a2)
+
+
 def test_actor_act_matches_oracle_and_reference(eng_mod, golden_dir):
     params = D.make_params(D.PARAM_SEED)
     e = eng_mod.HirlEngine(batch=128)

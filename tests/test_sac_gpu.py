@@ -62,6 +62,15 @@ def test_sac_act_matches_oracle(SE):
         np.testing.assert_allclose(e.act(torch.from_numpy(obs).cuda(), eps=torch.from_numpy(eps).cuda()).cpu().numpy(), o.explore(obs, eps), rtol=1e-5, atol=2e-6)
     a = e.act(torch.zeros((5000, 13), device="cuda")).cpu().numpy()  # Philox sampling
     assert np.all(np.abs(a) <= 1) and a.std() > 0.05
+    # from 8,192 rows on the kernel runs 32 rows per workgroup: same arithmetic per row, so bit-identical to the 16-row tiling
+    n = 8192 + 21
+    obs = torch.from_numpy(rng.uniform(-1, 1, (n, 13)).astype(np.float32)).cuda()
+    eps = torch.from_numpy(rng.normal(0, 1, (n, 4)).astype(np.float32)).cuda()
+    for kw in ({"explore": False}, {"eps": eps}):
+        big = e.act(obs, **kw)
+        parts = [e.act(obs[i:i + 4096], **({"eps": eps[i:i + 4096]} if "eps" in kw else kw)) for i in range(0, n, 4096)]
+        assert torch.equal(big, torch.cat(parts))
+    np.testing.assert_allclose(e.act(obs, eps=eps)[-300:].cpu().numpy(), o.explore(obs[-300:].cpu().numpy(), eps[-300:].cpu().numpy()), rtol=1e-5, atol=2e-6)
 
 
 def test_sac_learn_matches_oracle_and_reference(SE, golden_dir):
