@@ -20,7 +20,7 @@ class HxSacNets(ctypes.Structure):
 
 
 class HxSacBatch(ctypes.Structure):
-    _fields_ = [("rows", _vp), ("batch", _i32), ("eps_next", _vp), ("eps_cur", _vp)]
+    _fields_ = [("rows", _vp), ("batch", _i32), ("eps_next", _vp), ("eps_cur", _vp), ("seed", ctypes.c_uint64), ("call", ctypes.c_uint32)]
 
 
 _lib.register("hx_sac_act", [_vp, _vp, ctypes.c_int64, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp])
@@ -159,8 +159,7 @@ class SacEngine:
                   expert.ring.data_ptr() if expert is not None else None, E.len_of(expert), None, 0, self.batch, n_main,
                   1, int(seed), self.sample_calls, 0.0, self._idx.data_ptr(), None, self._noise.data_ptr(), self.rows.data_ptr(), None,
                   _lib.stream_ptr())
-        self.eps_next.normal_()
-        self.eps_cur.normal_()
+        self._seed = int(seed)  # learn() without injected draws: Normal.rsample's eps comes from Philox(seed; row, learn call) in-kernel
 
     def _allreduce(self, t):
         if self.world > 1:
@@ -169,10 +168,12 @@ class SacEngine:
     def learn(self, eps_next=None, eps_cur=None):
         """SacAgent.learn(False) (agent.py:276-327) on the minibatch last assembled.  Enqueues only."""
         st = _lib.stream_ptr()
-        if eps_next is not None:
+        if eps_next is not None:  # injected draws (parity tests, the façade's torch.randn)
             self.eps_next.copy_(eps_next.reshape(-1))
             self.eps_cur.copy_(eps_cur.reshape(-1))
-        batch = HxSacBatch(self.rows.data_ptr(), self.batch, self.eps_next.data_ptr(), self.eps_cur.data_ptr())
+            batch = HxSacBatch(self.rows.data_ptr(), self.batch, self.eps_next.data_ptr(), self.eps_cur.data_ptr(), 0, 0)
+        else:
+            batch = HxSacBatch(self.rows.data_ptr(), self.batch, None, None, getattr(self, "_seed", 0), self.learning_steps + 1)
         nets, hyper, gs = ctypes.byref(self.nets), ctypes.byref(self.hyper), 1.0 / self.world
         self.learning_steps += 1
         _lib.call("hx_sac_critic_grads", nets, ctypes.byref(batch), hyper, int(self.learning_steps % self.interval == 0), st)

@@ -1910,7 +1910,7 @@ int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actio
  * policy.sample(s') with eps_next, y = r + (1 - d) gamma (min Q_target(s', a') + alpha H'), q1_loss / q2_loss -> losses[0..1],
  * grad_critic.  Also evaluates policy(s) for the policy half.  Follow with hx_sac_adam(which = 0). */
 int hx_sac_critic_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, int32_t polyak_first, void* stream) {
-    HX_REQUIRE(N && Bt && Hy && Bt->rows && Bt->eps_next && Bt->eps_cur && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_sac_critic_grads: bad arguments");
+    HX_REQUIRE(N && Bt && Hy && Bt->rows && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_sac_critic_grads: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int B = Bt->batch;
     Slot s[S_COUNT];
@@ -1933,7 +1933,7 @@ int hx_sac_critic_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
         launch_fwd(F, st);
     }
     {   // a', H' = policy.sample(s')
-        GaussArgs G{N->policy, kPolicy, s[SS_PN].z2, Bt->eps_next, B, 1, X.act_n, X.ent_n, nullptr, 0, 0, 0};
+        GaussArgs G{N->policy, kPolicy, s[SS_PN].z2, Bt->eps_next, B, Bt->eps_next ? 1 : 2, X.act_n, X.ent_n, nullptr, Bt->seed, 0x40000000u, Bt->call};
         hipLaunchKernelGGL(gauss_head_kernel, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, st, G);
     }
     {   // target Q1/Q2 (s', a')
@@ -1973,7 +1973,7 @@ int hx_sac_critic_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
 /* Policy half (SAC/agent.py:315-319, 376-406): a~, H = policy.sample(s) with eps_cur, Q1/Q2(s, a~) with the UPDATED critics,
  * policy_loss = mean(-min Q - alpha H) -> losses[2], mean entropy -> losses[4], grad_policy.  Follow with hx_sac_adam(which = 1). */
 int hx_sac_policy_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, void* stream) {
-    HX_REQUIRE(N && Bt && Hy && Bt->rows && Bt->eps_cur && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_sac_policy_grads: bad arguments");
+    HX_REQUIRE(N && Bt && Hy && Bt->rows && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_sac_policy_grads: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int B = Bt->batch;
     Slot s[S_COUNT];
@@ -1982,7 +1982,7 @@ int hx_sac_policy_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
     const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
     const float* q1 = N->critic; const float* q2 = N->critic + kQs.padded();
     {
-        GaussArgs G{N->policy, kPolicy, s[SS_PC].z2, Bt->eps_cur, B, 1, X.act_c, nullptr, X.aux_c, 0, 0, 0};
+        GaussArgs G{N->policy, kPolicy, s[SS_PC].z2, Bt->eps_cur, B, Bt->eps_cur ? 1 : 2, X.act_c, nullptr, X.aux_c, Bt->seed, 0x80000000u, Bt->call};
         hipLaunchKernelGGL(gauss_head_kernel, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, st, G);
     }
     {

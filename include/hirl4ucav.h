@@ -224,6 +224,8 @@ typedef struct HxSacBatch {
     int32_t batch;         /* multiple of 16 */
     const float* eps_next; /* [batch][4] standard-normal draws of policy.sample(next_states) (SAC/agent.py:204) */
     const float* eps_cur;  /* [batch][4] draws of policy.sample(states) in calc_policy_loss (SAC/agent.py:380) */
+    uint64_t seed;         /* eps_next / eps_cur NULL: the draws come from Philox4x32-10(seed; row, call) inside the kernels */
+    uint32_t call;         /* (distinct streams for the two samples), no draw buffers and no launches to fill them */
 } HxSacBatch;
 
 int hx_sac_policy_param_count(void);
