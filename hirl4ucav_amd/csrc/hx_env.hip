@@ -128,57 +128,64 @@ struct Env {
     uint32_t flags, counters;
 };
 
-__device__ __forceinline__ void load_plane(Plane& P, const float* __restrict__ s, int64_t stride, int64_t i, int w0) {
-    P.p = {s[(w0 + 0) * stride + i], s[(w0 + 1) * stride + i], s[(w0 + 2) * stride + i]};
-    P.v = {s[(w0 + 3) * stride + i], s[(w0 + 4) * stride + i], s[(w0 + 5) * stride + i]};
-    P.qw = s[(w0 + 6) * stride + i];
-    P.qx = s[(w0 + 7) * stride + i];
-    P.qy = s[(w0 + 8) * stride + i];
-    P.qz = s[(w0 + 9) * stride + i];
-    P.lp = s[(w0 + 10) * stride + i];
-    P.lr = s[(w0 + 11) * stride + i];
-    P.ly = s[(w0 + 12) * stride + i];
+// State words are visited in order through a cursor whose base is UNIFORM (block base + w * stride lives in SGPRs, two scalar
+// adds per word) and whose per-lane part is the 32-bit thread index: every access is `global_load/store v, v_tid, s[base]` — no
+// 64-bit multiply-add per word per lane, which used to be a quarter of the kernel's instructions.
+struct RCursor {
+    const float* __restrict__ p;  // uniform
+    int64_t stride;
+    uint32_t lane;
+    __device__ __forceinline__ float next() {
+        const float v = p[lane];
+        p += stride;
+        return v;
+    }
+};
+struct WCursor {
+    float* __restrict__ p;  // uniform
+    int64_t stride;
+    uint32_t lane;
+    __device__ __forceinline__ void put(float v) {
+        p[lane] = v;
+        p += stride;
+    }
+};
+__device__ __forceinline__ void load_plane(Plane& P, RCursor& c) {
+    P.p.x = c.next(); P.p.y = c.next(); P.p.z = c.next();
+    P.v.x = c.next(); P.v.y = c.next(); P.v.z = c.next();
+    P.qw = c.next(); P.qx = c.next(); P.qy = c.next(); P.qz = c.next();
+    P.lp = c.next(); P.lr = c.next(); P.ly = c.next();
 }
-__device__ __forceinline__ void store_plane(const Plane& P, float* __restrict__ s, int64_t stride, int64_t i, int w0) {
-    s[(w0 + 0) * stride + i] = P.p.x;
-    s[(w0 + 1) * stride + i] = P.p.y;
-    s[(w0 + 2) * stride + i] = P.p.z;
-    s[(w0 + 3) * stride + i] = P.v.x;
-    s[(w0 + 4) * stride + i] = P.v.y;
-    s[(w0 + 5) * stride + i] = P.v.z;
-    s[(w0 + 6) * stride + i] = P.qw;
-    s[(w0 + 7) * stride + i] = P.qx;
-    s[(w0 + 8) * stride + i] = P.qy;
-    s[(w0 + 9) * stride + i] = P.qz;
-    s[(w0 + 10) * stride + i] = P.lp;
-    s[(w0 + 11) * stride + i] = P.lr;
-    s[(w0 + 12) * stride + i] = P.ly;
+__device__ __forceinline__ void store_plane(const Plane& P, WCursor& c) {
+    c.put(P.p.x); c.put(P.p.y); c.put(P.p.z);
+    c.put(P.v.x); c.put(P.v.y); c.put(P.v.z);
+    c.put(P.qw); c.put(P.qx); c.put(P.qy); c.put(P.qz);
+    c.put(P.lp); c.put(P.lr); c.put(P.ly);
 }
-__device__ __forceinline__ void load_env(Env& E, const float* __restrict__ s, int64_t stride, int64_t i) {
-    load_plane(E.ally, s, stride, i, 0);
-    load_plane(E.opp, s, stride, i, 13);
-    E.mp = {s[26 * stride + i], s[27 * stride + i], s[28 * stride + i]};
-    E.mv = {s[29 * stride + i], s[30 * stride + i], s[31 * stride + i]};
-    E.health = s[32 * stride + i];
-    E.lock_timer = s[33 * stride + i];
-    E.missile_age = s[34 * stride + i];
-    E.flags = __float_as_uint(s[35 * stride + i]);
-    E.counters = __float_as_uint(s[36 * stride + i]);
+// i = i0 + lane with i0 uniform across the workgroup (blockIdx.x * kBlock)
+__device__ __forceinline__ void load_env(Env& E, const float* __restrict__ s, int64_t stride, int64_t i0, uint32_t lane) {
+    RCursor c{s + i0, stride, lane};
+    load_plane(E.ally, c);
+    load_plane(E.opp, c);
+    E.mp.x = c.next(); E.mp.y = c.next(); E.mp.z = c.next();
+    E.mv.x = c.next(); E.mv.y = c.next(); E.mv.z = c.next();
+    E.health = c.next();
+    E.lock_timer = c.next();
+    E.missile_age = c.next();
+    E.flags = __float_as_uint(c.next());
+    E.counters = __float_as_uint(c.next());
 }
-__device__ __forceinline__ void store_env(const Env& E, float* __restrict__ s, int64_t stride, int64_t i) {
-    store_plane(E.ally, s, stride, i, 0);
-    store_plane(E.opp, s, stride, i, 13);
-    s[26 * stride + i] = E.mp.x;
-    s[27 * stride + i] = E.mp.y;
-    s[28 * stride + i] = E.mp.z;
-    s[29 * stride + i] = E.mv.x;
-    s[30 * stride + i] = E.mv.y;
-    s[31 * stride + i] = E.mv.z;
-    s[32 * stride + i] = E.health;
-    s[33 * stride + i] = E.lock_timer;
-    s[34 * stride + i] = E.missile_age;
-    s[35 * stride + i] = __uint_as_float(E.flags);
-    s[36 * stride + i] = __uint_as_float(E.counters);
+__device__ __forceinline__ void store_env(const Env& E, float* __restrict__ s, int64_t stride, int64_t i0, uint32_t lane) {
+    WCursor c{s + i0, stride, lane};
+    store_plane(E.ally, c);
+    store_plane(E.opp, c);
+    c.put(E.mp.x); c.put(E.mp.y); c.put(E.mp.z);
+    c.put(E.mv.x); c.put(E.mv.y); c.put(E.mv.z);
+    c.put(E.health);
+    c.put(E.lock_timer);
+    c.put(E.missile_age);
+    c.put(__uint_as_float(E.flags));
+    c.put(__uint_as_float(E.counters));
 }
 
 // ---- Philox4x32-10 (Salmon et al., SC'11) ---------------------------------------------------------------
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(StepArgs A) {
     float4 act = {0.f, 0.f, 0.f, 0.f};
     bool trunc = false, store = false;
     if (active) {
-        load_env(E, A.state, A.stride, i);
+        load_env(E, A.state, A.stride, i0, (uint32_t)tid);
         act = reinterpret_cast<const float4*>(A.actions)[i];
         uint32_t ep = E.counters & 0xFFFFu;
         ep = ep < 65535u ? ep + 1u : ep;
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(StepArgs A) {
             env_reset(E, scen, A.o.randomize != 0, A.o.seed, A.o.env_id0 + (uint32_t)i, epi);
             observe(E, O);
         }
-        store_env(E, A.state, A.stride, i);
+        store_env(E, A.state, A.stride, i0, (uint32_t)tid);
         float* out = s_obs + tid * HX_OBS_DIM;
 #pragma unroll
         for (int j = 0; j < HX_OBS_DIM; ++j) out[j] = O.obs[j];
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(kBlock) void env_reset_kernel(ResetArgs A) {
     const uint32_t scen = (uint32_t)(A.scenario ? A.scenario[i] : A.scenario_all);
     const uint32_t epi = A.episode_ctr ? A.episode_ctr[i] : 0u;
     env_reset(E, scen, A.randomize != 0, A.seed, A.env_id0 + (uint32_t)i, epi);
-    store_env(E, A.state, A.stride, i);
+    store_env(E, A.state, A.stride, (int64_t)blockIdx.x * kBlock, threadIdx.x);
     if (A.obs) {
         Observed O;
         observe(E, O);
