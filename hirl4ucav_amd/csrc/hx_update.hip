@@ -1442,56 +1442,65 @@ struct SampleArgs {
 };
 
 // 1024 threads.  With B <= 512 the two index streams (replay / expert rows, BC rows) are drawn side by side by the two halves
-// of the workgroup; the all-pairs duplicate check of a group is spread over several threads per row (a lone wave retires
-// about one instruction per 8 cycles, so serial scans are what cost time here).  The gather reads the indices from LDS.
+// of the workgroup.  "Without replacement" = inside a group, of several rows that drew the same index the lowest row keeps it
+// and the others redraw.  The check is a hash set in LDS (key = group | index, owner = lowest row that drew it: atomicCAS +
+// atomicMin, linear probing, load <= 0.3), O(1) per row and round instead of an all-pairs scan.  The gather reads the indices
+// from LDS.
+constexpr int kSampleSlots = 4096;
+__device__ __forceinline__ uint32_t sample_hash(uint32_t k) { return (k * 2654435761u) >> 20; }  // top 12 bits
+
 __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
-    __shared__ __attribute__((aligned(16))) int cand[1024];
-    __shared__ int dupf[1024];
+    __shared__ uint32_t hkey[2][kSampleSlots];
+    __shared__ int hown[2][kSampleSlots];
     __shared__ int fin[2][1024];
     const int tid = threadIdx.x;
     const int B = A.batch;
     const int np = B <= 512 ? 2 : 1;            // streams drawn in parallel
     const int width = 1024 / np;                // threads per stream
-    const int bpad = (B + 63) / 64 * 64;
-    const int parts = width / bpad > 0 ? width / bpad : 1;  // threads per row
-    const int tl = tid % width, base = (tid / width) * width;
-    const int t = tl / parts, part = tl % parts;
+    const int t = tid % width, tab = tid / width;
     if (A.do_sample) {
         const unsigned long long tot = *A.total;
         const uint32_t len_main = (uint32_t)(tot < (unsigned long long)A.cap ? tot : (unsigned long long)A.cap);
         const uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
         for (int pass = 0; pass < 2 / np; ++pass) {
-            const int stream = np == 2 ? tid / width : pass;  // 0: replay / expert rows, 1: BC rows
+            const int stream = np == 2 ? tab : pass;  // 0: replay / expert rows, 1: BC rows
             int* out = stream == 1 ? A.idx_bc : A.idx;
             const bool live = out != nullptr && t < B;
             const bool main_grp = t < A.n_main;
             const uint32_t len = stream == 1 ? (uint32_t)A.bc_len : (main_grp ? len_main : (uint32_t)A.expert_len);
-            const int lo = (stream == 1 || main_grp) ? 0 : A.n_main;  // groups: [0, n_main) and [n_main, batch)
-            int v = 0;
+            const uint32_t grp = (stream == 1 || main_grp) ? 0u : 0x80000000u;  // groups: [0, n_main) and [n_main, batch)
+            uint32_t* keys = hkey[tab];
+            int* owns = hown[tab];
+            for (int e = t; e < kSampleSlots; e += width) {
+                keys[e] = 0xFFFFFFFFu;
+                owns[e] = 0x7FFFFFFF;
+            }
+            __syncthreads();
+            uint32_t key = 0;
             bool dup = live;
             for (int round = 0; round < 128; ++round) {
                 if (dup) {
                     uint32_t u[4];
                     philox4x32_10((uint32_t)t, A.call, (uint32_t)stream, (uint32_t)round, k0, k1, u);
-                    v = len ? (int)__umulhi(u[0], len) : 0;
-                }
-                if (part == 0 && live) {
-                    cand[base + t] = v;
-                    dupf[base + t] = 0;
-                }
-                __syncthreads();
-                if (live) {  // my slice of the earlier members of my group
-                    const int span = (B + parts - 1) / parts;
-                    const int s0 = max(lo, part * span), s1 = min(t, (part + 1) * span);
-                    bool d = false;
-                    for (int s = s0; s < s1; ++s) d |= cand[base + s] == v;
-                    if (d) dupf[base + t] = 1;
+                    key = grp | (len ? __umulhi(u[0], len) : 0u);
+                    uint32_t h = sample_hash(key);
+                    for (int probe = 0; probe < kSampleSlots; ++probe) {  // bounded: the set never fills (<= B + redraws keys)
+                        const uint32_t k = atomicCAS(&keys[h], 0xFFFFFFFFu, key);
+                        if (k == 0xFFFFFFFFu || k == key) break;
+                        h = (h + 1) & (kSampleSlots - 1);
+                    }
+                    atomicMin(&owns[h], t);
                 }
                 __syncthreads();
-                dup = live && dupf[base + t] != 0;
+                if (live) {  // every row looks its index up again: a redraw of a lower row may have taken it over
+                    uint32_t h = sample_hash(key);
+                    for (int probe = 0; probe < kSampleSlots && keys[h] != key; ++probe) h = (h + 1) & (kSampleSlots - 1);
+                    dup = owns[h] != t;
+                }
                 if (!__syncthreads_or(dup)) break;  // nobody redraws: done (the common case after the first round)
             }
-            if (part == 0 && live) {
+            if (live) {
+                const int v = (int)(key & 0x7FFFFFFFu);
                 out[t] = v;
                 fin[stream][t] = v;
             }

@@ -294,6 +294,14 @@ def test_device_sampler(eng_mod):
     rep.total += 100000  # ring wrapped: the whole capacity is live
     idx3, _, _ = e.sample(rep, exp, bc, n_main=128, seed=9)
     assert idx3.max().item() >= 300 and idx3.max().item() < 5000
+    # large minibatches (one index stream at a time): 1,024 of 5,000 and 1,024 of 1,500 collide in the first round for certain
+    big = eng_mod.HirlEngine(batch=1024)
+    bc2 = torch.from_numpy(rng.normal(size=(1500, 32)).astype(np.float32)).cuda()
+    for call in range(5):
+        idx, idx_bc, _ = big.sample(rep, None, bc2, seed=3)
+        i, b = idx.cpu().numpy(), idx_bc.cpu().numpy()
+        assert len(set(i)) == 1024 and i.min() >= 0 and i.max() < 5000 and len(set(b)) == 1024 and b.max() < 1500
+        np.testing.assert_array_equal(big.rows.reshape(1024, 32).cpu().numpy(), rep.ring.cpu().numpy()[i])
 
 
 def test_staged_path_equals_fused_path(eng_mod):
