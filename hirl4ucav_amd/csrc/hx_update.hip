@@ -1397,20 +1397,46 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
     }
     const int i = (blockIdx.x * kThreads + threadIdx.x) * 4;
     if (i >= A.n) return;
-    float pv[4], gv[4], mv[4], vv[4];
-    const int cnt = min(4, A.n - i);
-    for (int c = 0; c < cnt; ++c) { pv[c] = A.p[i + c]; gv[c] = A.g[i + c] * A.gscale; mv[c] = A.m[i + c]; vv[c] = A.v[i + c]; }
-    for (int c = 0; c < cnt; ++c) {
-        adam_update(pv[c], mv[c], vv[c], gv[c], A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
-        A.p[i + c] = pv[c]; A.m[i + c] = mv[c]; A.v[i + c] = vv[c];
+    if (i + 4 <= A.n) {  // the flat buffers are 16-B aligned and a multiple of 4 floats long: one 16-B access per array
+        float4 p4 = *reinterpret_cast<const float4*>(A.p + i), g4 = *reinterpret_cast<const float4*>(A.g + i);
+        float4 m4 = *reinterpret_cast<const float4*>(A.m + i), v4 = *reinterpret_cast<const float4*>(A.v + i);
+        adam_update(p4.x, m4.x, v4.x, g4.x * A.gscale, A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
+        adam_update(p4.y, m4.y, v4.y, g4.y * A.gscale, A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
+        adam_update(p4.z, m4.z, v4.z, g4.z * A.gscale, A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
+        adam_update(p4.w, m4.w, v4.w, g4.w * A.gscale, A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
+        *reinterpret_cast<float4*>(A.p + i) = p4;
+        *reinterpret_cast<float4*>(A.m + i) = m4;
+        *reinterpret_cast<float4*>(A.v + i) = v4;
+        return;
+    }
+    for (int c = 0; c < A.n - i; ++c) {  // ragged tail
+        float pv = A.p[i + c], mv = A.m[i + c], vv = A.v[i + c];
+        adam_update(pv, mv, vv, A.g[i + c] * A.gscale, A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
+        A.p[i + c] = pv; A.m[i + c] = mv; A.v[i + c] = vv;
     }
 }
 
-__global__ __launch_bounds__(kThreads) void polyak_kernel(float* target, const float* source, int n, float tau) {
-    const int i = (blockIdx.x * kThreads + threadIdx.x) * 4;
+// up to two (target, source) segments in one launch: blocks [0, nb1) walk the first, the rest the second
+__global__ __launch_bounds__(kThreads) void polyak_kernel(float* target, const float* source, int n, float tau, float* target2 = nullptr,
+                                                          const float* source2 = nullptr, int n2 = 0) {
+    const int nb1 = (n / 4 + kThreads) / kThreads;
+    int blk = blockIdx.x;
+    if (blk >= nb1) {
+        blk -= nb1; target = target2; source = source2; n = n2;
+    }
+    const int i = (blk * kThreads + threadIdx.x) * 4;
     if (i >= n) return;
-    const int cnt = min(4, n - i);
-    for (int c = 0; c < cnt; ++c) target[i + c] = target[i + c] * (1.0f - tau) + source[i + c] * tau;  // HIRL.py:13
+    if (i + 4 <= n) {
+        float4 t4 = *reinterpret_cast<const float4*>(target + i);
+        const float4 s4 = *reinterpret_cast<const float4*>(source + i);
+        t4.x = t4.x * (1.0f - tau) + s4.x * tau;  // HIRL.py:13
+        t4.y = t4.y * (1.0f - tau) + s4.y * tau;
+        t4.z = t4.z * (1.0f - tau) + s4.z * tau;
+        t4.w = t4.w * (1.0f - tau) + s4.w * tau;
+        *reinterpret_cast<float4*>(target + i) = t4;
+        return;
+    }
+    for (int c = 0; c < n - i; ++c) target[i + c] = target[i + c] * (1.0f - tau) + source[i + c] * tau;
 }
 
 
@@ -1706,6 +1732,7 @@ int hx_adam(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t step, flo
     A.finish_actor = which == 1;  // which == 2: the actor's Adam step alone (BC pre-training)
     A.w_kind = w_kind; A.w_given = w_given; A.warm = warm; A.inv_batch = 1.0f / (batch > 0 ? batch : 1);
     A.soft_count = N->soft_count; A.wstate = N->wstate; A.losses = N->losses; A.use_bc = Hy->use_bc;
+    HX_REQUIRE((((uintptr_t)A.p | (uintptr_t)A.g | (uintptr_t)A.m | (uintptr_t)A.v) & 15u) == 0, "hx_adam: buffers must be 16-byte aligned");
     hipLaunchKernelGGL(adam_kernel, dim3((A.n / 4 + kThreads) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, A);
     HX_CHECK_LAUNCH("hx_adam");
     return 0;
@@ -1823,8 +1850,8 @@ int hx_sample_batch(const uint64_t* total, int64_t cap, const float* ring, const
 int hx_polyak(const HxNets* N, const HxHyper* Hy, void* stream) {
     HX_REQUIRE(N && Hy, "hx_polyak: bad arguments");
     const int nc = 2 * kQ.padded(), na = kActor.size();
-    hipLaunchKernelGGL(polyak_kernel, dim3((nc / 4 + kThreads) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, N->target_critic, N->critic, nc, Hy->tau);
-    hipLaunchKernelGGL(polyak_kernel, dim3((na / 4 + kThreads) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, N->target_actor, N->actor, na, Hy->tau);
+    hipLaunchKernelGGL(polyak_kernel, dim3((nc / 4 + kThreads) / kThreads + (na / 4 + kThreads) / kThreads), dim3(kThreads), 0, (hipStream_t)stream,
+                       N->target_critic, N->critic, nc, Hy->tau, N->target_actor, N->actor, na);
     HX_CHECK_LAUNCH("hx_polyak");
     return 0;
 }
