@@ -44,7 +44,10 @@ constexpr int kThreads = 256;
 constexpr int kWide = 1024;  // fwd_l2 / bwd_l2 workgroups: 16 waves = one per row of the tile in the prologue, and
                              // 4 column tiles x 4 K-quarters (split-K, LDS reduce) in the MFMA phase.  B = 128 runs ONE
                              // workgroup per CU, so 4 waves per SIMD are what hides the prologue's load/reduce latency.
-constexpr int kNT = 64;  // z2 / dh1 columns per workgroup (4 column tiles x 16)
+constexpr int kNT = 64;  // fwd_l2: z2 columns per workgroup (4 column tiles x 16, 4 K-quarters): launch A already has 192-384 workgroups
+// bwd_l2: dh1 columns per workgroup.  Its launches have one or two jobs, so 32 columns (2 column tiles x 8 K-parts per
+// workgroup, 64-128 workgroups) still fit the chip in one round and halve the MFMA work on each workgroup's critical path.
+constexpr int kNTB = 32, kCTB = kNTB / 16, kKSB = 16 / kCTB, kColWgB = H1 / kNTB;
 constexpr int OW = 8;    // row pitch of the per-slot head output / head gradient arrays
 
 // minibatch row r comes from main[idx[r]] if r < nb else from exp[idx[r]]; idx == nullptr: row r of `main` itself
@@ -73,7 +76,7 @@ struct Slot {
     float* dz2;   // [R][H2]
     float* dh1;   // [R][H1]
     float* dout;  // [R][8]    gradient wrt the head pre-activation o
-    float* lnp;   // [R][4][2] LN1-backward row sums (sum dxhat, sum dxhat*xhat) over each 64-column tile of dh1
+    float* lnp;   // [R][kColWgB][2] LN1-backward row sums (sum dxhat, sum dxhat*xhat) over each workgroup's columns of dh1
 };
 
 struct Head {  // a previous net whose output is (part of) this net's input
@@ -607,6 +610,18 @@ struct BwdArgs {
     int* soft_count;
 };
 
+// one LN1-backward row sum from the per-workgroup partials bwd_l2 left in lnp ([kColWgB][2], stride 2): fixed-order tree
+__device__ __forceinline__ float lnp_sum(const float* lp) {
+    float v[kColWgB];
+#pragma unroll
+    for (int c = 0; c < kColWgB; ++c) v[c] = lp[2 * c];
+#pragma unroll
+    for (int w = 1; w < kColWgB; w *= 2)
+#pragma unroll
+        for (int c = 0; c < kColWgB; c += 2 * w) v[c] += v[c + w];
+    return v[0];
+}
+
 // LDS image of one net's head parameters: g2[512] be2[512] W3[out][512] (padded to OUTMAX rows) b3[out]
 template <int OUTMAX>
 struct HeadImage {
@@ -668,7 +683,7 @@ __device__ __forceinline__ void head_regs(const RowReg<H2>& z, const float* hp, 
 template <int GRP>
 __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
     __shared__ __attribute__((aligned(16))) float dz2s[RT * LDA2];
-    __shared__ __attribute__((aligned(16))) float kred[3 * 4 * 256];  // split-K partial tiles
+    __shared__ __attribute__((aligned(16))) float kred[(kKSB - 1) * kCTB * 256];  // split-K partial tiles
     constexpr int IMG = GRP == 3 ? 8 : 4;  // head width of this instantiation's LDS images
     typedef HeadImage<IMG> Img;
     constexpr int kHpStride = Img::kStride;
@@ -679,13 +694,13 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
 
     int b = blockIdx.x, j = 0;
     for (; j < A.njobs; ++j) {
-        const int nb = tiles_of(A.job[j].rows) * (H1 / kNT);
+        const int nb = tiles_of(A.job[j].rows) * kColWgB;
         if (b < nb) break;
         b -= nb;
     }
     if (j >= A.njobs) return;
     const BwdJob& J = A.job[j];
-    const int rt = b / (H1 / kNT), nt = b % (H1 / kNT);
+    const int rt = b / kColWgB, nt = b % kColWgB;
     const int r0 = rt * RT;
     const int nrow = min(RT, J.rows - r0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -693,14 +708,14 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
     const bool lead = nt == 0;  // the column-tile-0 workgroup of a row tile also publishes dz2 / st2 / dout / losses
     const bool live = wave < nrow;  // wave w owns row w of the tile
     const size_t R = (size_t)(r0 + (live ? wave : 0));
-    const int ct = wave & 3, kq = wave >> 2;
-    const int n0 = nt * kNT + ct * 16;
+    const int ct = wave % kCTB, kq = wave / kCTB;
+    const int n0 = nt * kNTB + ct * 16;
     STAMP_DECL;
     STAMP();
 
     // ---------------- issue phase ----------------
-    BFrag<H2 / 4> bfrag;
-    bfrag.load(J.net + J.m.W2() + (size_t)(kq * (H2 / 4)) * H1 + n0 + (lane & 15), H1);
+    BFrag<H2 / kKSB> bfrag;
+    bfrag.load(J.net + J.m.W2() + (size_t)(kq * (H2 / kKSB)) * H1 + n0 + (lane & 15), H1);
     RowReg<H2> z, za, zb;
 #pragma unroll
     for (int i = 0; i < 8; ++i) z.v[i] = za.v[i] = zb.v[i] = 0.0f;
@@ -739,9 +754,9 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
                 cz.load(C.ws.z1 + R * H1);
                 cst0 = C.ws.st1[R * 2];
                 cst1 = C.ws.st1[R * 2 + 1];
-                const float* lp = C.ws.lnp + R * 8;
-                cs1 = ((lp[0] + lp[2]) + (lp[4] + lp[6])) * (1.0f / H1);
-                cs2 = ((lp[1] + lp[3]) + (lp[5] + lp[7])) * (1.0f / H1);
+                const float* lp = C.ws.lnp + R * (2 * kColWgB);
+                cs1 = lnp_sum(lp) * (1.0f / H1);
+                cs2 = lnp_sum(lp + 1) * (1.0f / H1);
             }
             // g1 | be1 (512 floats) by threads 0..511; W1[k][13..16] (1024 floats) one per thread
             if (tid < 2 * H1) c1v[0] = C.net[C.m.g1() + tid];
@@ -753,7 +768,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
         }
     }
     // epilogue operands of the waves that finish the tile (kq == 0): z1, g1, be1 of their 4 rows x 1 column; LN1 stats via LDS
-    constexpr bool kEpiPrefetch = GRP != 0;  // the TD instantiation has no registers to spare: it loads these in the epilogue
+    constexpr bool kEpiPrefetch = true;  // (with 64-column workgroups the TD instantiation had no registers to spare for this)
     float ez1[4] = {0.f, 0.f, 0.f, 0.f}, eg1 = 0.f, ebe1 = 0.f;
     if (kEpiPrefetch && kq == 0) {
         const int r = lane & 15, g = lane >> 4;
@@ -902,11 +917,11 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
     {
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_a_lds_b_frag<H2 / 4>(dz2s + kq * (H2 / 4), LDA2, bfrag, acc);
-        if (kq) *reinterpret_cast<float4*>(kred + (((kq - 1) * 4 + ct) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        acc = tile_a_lds_b_frag<H2 / kKSB>(dz2s + kq * (H2 / kKSB), LDA2, bfrag, acc);
+        if (kq) *reinterpret_cast<float4*>(kred + (((kq - 1) * kCTB + ct) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         __syncthreads();  // partial tiles visible; dz2s is dead from here on
         STAMP();
-        float* ps = dz2s;  // reused as [4 column tiles][16 rows][2]
+        float* ps = dz2s;  // reused as [kCTB column tiles][16 rows][2]
         if (!kEpiPrefetch && kq == 0) {
             eg1 = J.net[J.m.g1() + n0 + r];
             ebe1 = J.net[J.m.be1() + n0 + r];
@@ -919,7 +934,15 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
             // backward, which then need no cross-column reduction of their own)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float v = (acc[q] + kred[((0 * 4 + ct) * 64 + lane) * 4 + q]) + (kred[((1 * 4 + ct) * 64 + lane) * 4 + q] + kred[((2 * 4 + ct) * 64 + lane) * 4 + q]);
+                float part[kKSB];  // fixed-order tree over the K-parts
+                part[0] = acc[q];
+#pragma unroll
+                for (int k = 1; k < kKSB; ++k) part[k] = kred[(((k - 1) * kCTB + ct) * 64 + lane) * 4 + q];
+#pragma unroll
+                for (int w = 1; w < kKSB; w *= 2)
+#pragma unroll
+                    for (int k = 0; k < kKSB; k += 2 * w) part[k] += part[k + w];
+                const float v = part[0];
                 const int row = 4 * g + q;
                 float p1 = 0.0f, p2 = 0.0f;
                 if (row < nrow) {
@@ -938,8 +961,10 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
         }
         __syncthreads();
         if (tid < nrow * 2) {
-            const float v = (ps[tid] + ps[RT * 2 + tid]) + (ps[2 * RT * 2 + tid] + ps[3 * RT * 2 + tid]);
-            J.ws.lnp[(size_t)(r0 + (tid >> 1)) * 8 + nt * 2 + (tid & 1)] = v;
+            float v = ps[tid];
+#pragma unroll
+            for (int c = 1; c < kCTB; ++c) v += ps[c * RT * 2 + tid];
+            J.ws.lnp[(size_t)(r0 + (tid >> 1)) * (2 * kColWgB) + nt * 2 + (tid & 1)] = v;
         }
         STAMP();
         STAMP_FLUSH(16, blockIdx.x == 3 && tid == 0);
@@ -1305,11 +1330,11 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
                 __syncthreads();
                 for (int e = tid; e < nr * XP; e += kWide) xs[e] = S.x[(size_t)c0 * XP + e];
                 for (int e = tid; e < nr; e += kWide) {
-                    const float* lp = S.lnp + (size_t)(c0 + e) * 8;
+                    const float* lp = S.lnp + (size_t)(c0 + e) * (2 * kColWgB);
                     rinfo[e * 8] = S.st1[(size_t)(c0 + e) * 2];
                     rinfo[e * 8 + 1] = S.st1[(size_t)(c0 + e) * 2 + 1];
-                    rinfo[e * 8 + 2] = ((lp[0] + lp[2]) + (lp[4] + lp[6])) * (1.0f / H1);
-                    rinfo[e * 8 + 3] = ((lp[1] + lp[3]) + (lp[5] + lp[7])) * (1.0f / H1);
+                    rinfo[e * 8 + 2] = lnp_sum(lp) * (1.0f / H1);
+                    rinfo[e * 8 + 3] = lnp_sum(lp + 1) * (1.0f / H1);
                 }
                 __syncthreads();
                 for (int rb = rg; rb < nr; rb += kWgRG * 8) {
@@ -1561,7 +1586,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-constexpr size_t kSlotFloats = XP + H1 + 2 + H1 + H2 + 2 + OW + H2 + H1 + OW + 8;  // per row
+constexpr size_t kSlotFloats = XP + H1 + 2 + H1 + H2 + 2 + OW + H2 + H1 + OW + 2 * kColWgB;  // per row
 
 Slot carve_slot(float* base, int rows) {
     Slot s;
@@ -1576,7 +1601,7 @@ Slot carve_slot(float* base, int rows) {
     s.dz2 = p; p += (size_t)rows * H2;
     s.dh1 = p; p += (size_t)rows * H1;
     s.dout = p; p += (size_t)rows * OW;
-    s.lnp = p; p += (size_t)rows * 8;
+    s.lnp = p; p += (size_t)rows * (2 * kColWgB);
     return s;
 }
 
@@ -1597,7 +1622,7 @@ void launch_fwd(const FwdArgs& F, hipStream_t st) {
 }
 int bwd_blocks(const BwdArgs& a) {
     int n = 0;
-    for (int j = 0; j < a.njobs; ++j) n += ((a.job[j].rows + RT - 1) / RT) * (H1 / kNT);
+    for (int j = 0; j < a.njobs; ++j) n += ((a.job[j].rows + RT - 1) / RT) * kColWgB;
     return n;
 }
 
