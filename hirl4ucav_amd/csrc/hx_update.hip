@@ -168,18 +168,23 @@ struct FwdArgs {
 
 __device__ __forceinline__ int tiles_of(int rows) { return (rows + RT - 1) / RT; }
 
-// WIDE = false: 64 columns per workgroup, split-K 4 (latency mode, B = 128: 8 column tiles per row tile keep ~190 CUs busy)
-// WIDE = true : 256 columns per workgroup, one 16-column tile per wave, full K (throughput mode, thousands of rows: the
-//               prologue is recomputed 2x per row tile instead of 8x)
-template <bool WIDE>
+// NT = 64 / 32: columns per workgroup in latency mode (B = 128): CT = NT/16 column tiles x KS = 16/CT K-parts over the 16 waves,
+//                partial sums meet in LDS.  64 when the launch has three or more nets (192+ workgroups), 32 for one or two nets
+//                (then 128-256 workgroups still run in one round and each carries half the MFMA work).
+// NT = 256     : one 16-column tile per wave, full K (throughput mode, thousands of rows: the prologue is recomputed 2x per
+//                row tile instead of 8x or 16x)
+template <int NT>
 __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
-    constexpr int NTW = WIDE ? 256 : kNT;
-    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2 + 3 * 4 * 256 + H1 * 17];
+    constexpr bool WIDE = NT == 256;
+    constexpr int NTW = NT;
+    constexpr int CT = WIDE ? 1 : NT / 16, KS = WIDE ? 1 : 16 / CT;  // column tiles / K-parts per workgroup (latency mode)
+    constexpr int KRED = WIDE ? 4 : (KS - 1) * CT * 256;
+    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2 + KRED + H1 * 17];
     float* h1s = lds;
     float* xs = lds + RT * LDA1;
     float* sts = xs + RT * XP;
-    float* kred = sts + RT * 2;   // [3 K-quarters][4 column tiles][64 lanes][4]
-    float* w1s = kred + 3 * 4 * 256;  // W1 [256][in], staged with coalesced loads (a per-thread row walk is 17 scattered requests)
+    float* kred = sts + RT * 2;   // [KS - 1 K-parts][CT column tiles][64 lanes][4]
+    float* w1s = kred + KRED;     // W1 [256][in], staged with coalesced loads (a per-thread row walk is 17 scattered requests)
 
     // which job / row tile / column tile
     int b = blockIdx.x, j = 0;
@@ -201,8 +206,8 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
     const float slope = A.slope;
     const int in = J.m.in;
     // operands that do not depend on the prologue are requested first: their latency hides behind the gather
-    BtFrag<H1 / 4> bfrag;
-    if (!WIDE) bfrag.load(J.net + J.m.W2() + (size_t)(nt * kNT + (wave & 3) * 16 + (lane & 15)) * H1 + (wave >> 2) * (H1 / 4));
+    BtFrag<H1 / KS> bfrag;
+    if (!WIDE) bfrag.load(J.net + J.m.W2() + (size_t)(nt * NT + (wave % CT) * 16 + (lane & 15)) * H1 + (wave / CT) * (H1 / KS));
     const int u = tid & (H1 - 1), rq = (tid >> 8) * 4;
     STAMP_DECL;
     STAMP();
@@ -317,21 +322,28 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
             if (row < nrow) J.ws.z2[(size_t)(r0 + row) * H2 + n0 + r] = acc[q] + bias;
         }
     } else {
-        // wave = (column tile ct, K quarter kq); partial sums meet in LDS
-        const int ct = wave & 3, kq = wave >> 2;
-        const int n0 = nt * kNT + ct * 16;
+        // wave = (column tile ct, K part kq); partial sums meet in LDS
+        const int ct = wave % CT, kq = wave / CT;
+        const int n0 = nt * NT + ct * 16;
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_a_lds_bt_frag<H1 / 4>(h1s + kq * (H1 / 4), LDA1, bfrag, acc);
-        if (kq) *reinterpret_cast<float4*>(kred + (((kq - 1) * 4 + ct) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        acc = tile_a_lds_bt_frag<H1 / KS>(h1s + kq * (H1 / KS), LDA1, bfrag, acc);
+        if (kq) *reinterpret_cast<float4*>(kred + (((kq - 1) * CT + ct) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         __syncthreads();
         if (kq == 0) {
             const float bias = J.net[J.m.b2() + n0 + r];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float v = (acc[q] + kred[((0 * 4 + ct) * 64 + lane) * 4 + q]) + (kred[((1 * 4 + ct) * 64 + lane) * 4 + q] + kred[((2 * 4 + ct) * 64 + lane) * 4 + q]);
+                float part[KS];  // fixed-order tree over the K-parts
+                part[0] = acc[q];
+#pragma unroll
+                for (int k = 1; k < KS; ++k) part[k] = kred[(((k - 1) * CT + ct) * 64 + lane) * 4 + q];
+#pragma unroll
+                for (int w = 1; w < KS; w *= 2)
+#pragma unroll
+                    for (int k = 0; k < KS; k += 2 * w) part[k] += part[k + w];
                 const int row = 4 * g + q;
-                if (row < nrow) J.ws.z2[(size_t)(r0 + row) * H2 + n0 + r] = v + bias;
+                if (row < nrow) J.ws.z2[(size_t)(r0 + row) * H2 + n0 + r] = part[0] + bias;
             }
         }
         STAMP();
@@ -1616,9 +1628,11 @@ int fwd_row_tiles(const FwdArgs& a) {
 void launch_fwd(const FwdArgs& F, hipStream_t st) {
     const int tiles = fwd_row_tiles(F);
     if (tiles >= 128)
-        hipLaunchKernelGGL(fwd_l2_kernel<true>, dim3(tiles * (H2 / 256)), dim3(kWide), 0, st, F);
+        hipLaunchKernelGGL(fwd_l2_kernel<256>, dim3(tiles * (H2 / 256)), dim3(kWide), 0, st, F);
+    else if (tiles * (H2 / 32) <= 256)  // one or two nets at B = 128: 32-column workgroups still fit the chip in one round
+        hipLaunchKernelGGL(fwd_l2_kernel<32>, dim3(tiles * (H2 / 32)), dim3(kWide), 0, st, F);
     else
-        hipLaunchKernelGGL(fwd_l2_kernel<false>, dim3(tiles * (H2 / kNT)), dim3(kWide), 0, st, F);
+        hipLaunchKernelGGL(fwd_l2_kernel<kNT>, dim3(tiles * (H2 / kNT)), dim3(kWide), 0, st, F);
 }
 int bwd_blocks(const BwdArgs& a) {
     int n = 0;
