@@ -1292,11 +1292,11 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
                             dg += sc * dy * xh;
 #pragma unroll
                             for (int jj = 0; jj < OW; ++jj) dw3[jj] += sc * ri[2 + jj] * h2;
+                            // db3[j] = sum_r dout[r][j]: lanes 0..out-1 of the first column block, over this row group's rows
+                            if (vb == 0 && lane < J.m.out) db3 += sc * ri[2 + lane];
                         }
                     }
                 }
-                if (vb == 0 && tid < J.m.out)
-                    for (int r = 0; r < nr; ++r) db3 += sc * rinfo[r * RP + 2 + tid];
             }
         }
         STAMP();
@@ -1304,6 +1304,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
         my[0] = db2; my[1] = dg; my[2] = dbe;
 #pragma unroll
         for (int jj = 0; jj < OW; ++jj) my[3 + jj] = dw3[jj];
+        my[3 + OW] = db3;
         __syncthreads();
         for (int item = wave; item < 3 + J.m.out; item += kWgRG) {  // wave -> item, lane -> column: 16 partial sums each
             const float v = sum_groups(red + lane * 20 + item);
@@ -1312,7 +1313,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
             else if (item == 2) J.grad[J.m.be2() + n] = J.m.no_ln ? 0.0f : v;
             else J.grad[J.m.W3() + (item - 3) * H2 + n] = v;
         }
-        if (vb == 0 && tid < J.m.out) J.grad[J.m.b3() + tid] = db3;
+        if (vb == 0 && wave == kWgRG - 1 && lane < J.m.out) J.grad[J.m.b3() + lane] = sum_groups(red + lane * 20 + 3 + OW);
         STAMP();
         STAMP_FLUSH(40, b == kWgTilesPerBlock && j == 0 && tid == 0);
         return;
