@@ -1703,24 +1703,26 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
         F.job[0] = FwdJob{N->target_actor, kActor, src, 17, 0, Head{}, nullptr, 0.f, s[S_TA], B, 0};
         F.job[1] = FwdJob{N->critic, kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C1], B, 1};
         F.job[2] = FwdJob{N->critic + kQ.padded(), kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C2], B, 1};
-        if (actor_fwd) {
-            const RowSrc bcsrc{Bt->bc_rows ? Bt->bc_rows : Bt->rows, nullptr, nullptr, 0, 32};
-            const bool bc = Hy->use_bc != 0;
+        if (actor_fwd) {  // the delayed actor step's forwards ride along, split so that NEITHER launch exceeds 256 workgroups
             F.zero_nf = 5; F.zero_i = N->soft_count;  // + actor / bc / rl / bc_fire accumulators and the soft count
-            int n = 3;
-            F.job[n++] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1};
-            if (bc) F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1};
-            if (bc && actor_fwd == 2) F.job[n++] = FwdJob{N->bc_actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0};
-            F.njobs = n;
+            F.job[3] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1};
+            F.njobs = 4;
         }
         launch_fwd(F, st);
     }
-    {   // launch B: targetCritic Q1/Q2 (s', clamp(targetActor(s') + clamp(noise)))
+    {   // launch B: targetCritic Q1/Q2 (s', clamp(targetActor(s') + clamp(noise)))  [+ actor(s_bc), bc_actor(s)]
         FwdArgs F{};
         F.njobs = 2; F.slope = Hy->slope;
         const Head prev{N->target_actor, kActor, s[S_TA]};
         F.job[0] = FwdJob{tc1, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC1], B, 0};
         F.job[1] = FwdJob{tc2, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC2], B, 0};
+        if (actor_fwd && Hy->use_bc) {
+            const RowSrc bcsrc{Bt->bc_rows ? Bt->bc_rows : Bt->rows, nullptr, nullptr, 0, 32};
+            int n = 2;
+            F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1};
+            if (actor_fwd == 2) F.job[n++] = FwdJob{N->bc_actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0};
+            F.njobs = n;
+        }
         launch_fwd(F, st);
     }
     {   // launch C: y, loss, dq, LN2 backward, dh1 for both heads
