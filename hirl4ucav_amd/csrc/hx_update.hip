@@ -365,6 +365,61 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 __device__ __forceinline__ float u01(uint32_t u) { return ((float)(u >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
+// LDS image of one net's head parameters: g2[512] be2[512] W3[out][512] (padded to OUTMAX rows) b3[out]
+template <int OUTMAX>
+struct HeadImage {
+    static constexpr int kStride = (2 + OUTMAX) * H2 + 8;
+    static constexpr int kPer = ((2 + OUTMAX) * (H2 / 4) + kWide - 1) / kWide;  // float4 per thread to stage it
+    float4 v[kPer];
+    float b3v;
+    // g2, be2, W3 rows are contiguous in the parameter block from g2()
+    __device__ __forceinline__ void fetch(const float* __restrict__ net, const Mlp& m, int tid) {
+        b3v = tid < m.out ? net[m.b3() + tid] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int e = tid + i * kWide;
+            v[i] = e < (2 + m.out) * (H2 / 4) ? reinterpret_cast<const float4*>(net + m.g2())[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void store(float* hp, const float* __restrict__ net, const Mlp& m, int tid) const {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int e = tid + i * kWide;
+            if (e < (2 + m.out) * (H2 / 4)) reinterpret_cast<float4*>(hp)[e] = v[i];
+        }
+        (void)net;
+        if (tid < m.out) hp[(2 + OUTMAX) * H2 + tid] = b3v;
+    }
+};
+// head from registers + the LDS image: LN2 stats of z, y = g2 xhat + be2, o[j] = act(y) . W3[j] + b3[j]
+// OUTMAX = how many outputs are computed, IMG = head width the LDS image was laid out for (HeadImage<IMG>)
+template <int OUTMAX, int IMG>
+__device__ __forceinline__ void head_regs(const RowReg<H2>& z, const float* hp, int out, float slope, RowReg<H2>& xhat, RowReg<H2>& y,
+                                          float& mean, float& rstd, float (&o)[OUTMAX], int no_ln = 0) {
+    RowReg<H2> g, be;
+    row_stats<8>(z.v, H2, mean, rstd);
+    if (no_ln) { mean = 0.0f; rstd = 1.0f; }
+    g.load(hp);
+    be.load(hp + H2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        xhat.v[i] = (z.v[i] - mean) * rstd;
+        y.v[i] = g.v[i] * xhat.v[i] + be.v[i];
+    }
+#pragma unroll
+    for (int j = 0; j < OUTMAX; ++j) {
+        float acc = 0.0f;
+        if (j < out) {
+            RowReg<H2> w;
+            w.load(hp + (2 + j) * H2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += act_f(y.v[i], slope) * w.v[i];
+            acc = wave_sum(acc) + hp[(2 + IMG) * H2 + j];
+        }
+        o[j] = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // act_fused: the whole policy for 16 observation rows in ONE workgroup — layer 1 + LN1 (VALU), z2 = h1 W2^T for all 512
 // columns (two 16-column MFMA tiles per wave, K = 256; W2 streams through two LDS buffers in 16-wide k-chunks, register-
@@ -439,6 +494,12 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     float4 e0, e1, o0, o1;  // even / odd register sets
     ACT_LOAD(e0, e1, 0);
     ACT_LOAD(o0, o1, 1);
+    // head parameters (g2, be2, W3, b3): requested now, parked in 4-8 registers, laid out in LDS once h1 is dead
+    typedef HeadImage<GAUSS ? 8 : 4> Img;
+    static_assert(Img::kStride <= ROWS * LDA1 + ROWS * XP + ROWS * 2 + H1 * 13, "the head image reuses the prologue's LDS");
+    Img himg;
+    himg.fetch(net, m, tid);
+    float* hps = lds;
     // all independent operands first
     float xv = 0.0f;
     if (tid < ROWS * 13) {
@@ -537,6 +598,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
                 z2s[(t * RT + 4 * g + q) * LDA2 + wave * 16 + r] = acc[t][0][q] + bb0;
                 z2s[(t * RT + 4 * g + q) * LDA2 + 256 + wave * 16 + r] = acc[t][1][q] + bb1;
             }
+        himg.store(hps, net, m, tid);  // ... and h1 / x / W1 are dead: their LDS takes the head image
     }
     __syncthreads();
     STAMP();
@@ -545,11 +607,12 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         const int lr = t * RT + wave;
         if (lr >= nrow) continue;
         const int r = r0 + lr;
-        RowReg<H2> xh, y;
+        RowReg<H2> xh, y, z;
         float mean, rstd;
+        z.load(z2s + lr * LDA2);
         if (!GAUSS) {
             float o[4];
-            head_row<4>(z2s + lr * LDA2, net, m, slope, xh, y, mean, rstd, o);
+            head_regs<4, 4>(z, hps, m.out, slope, xh, y, mean, rstd, o, m.no_ln);
             if (lane < 4) {
                 float a = tanhf(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // no dynamic register index
                 if (A.noise) {
@@ -562,7 +625,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             }
         } else {
             float o[8];
-            head_row<8>(z2s + lr * LDA2, net, m, slope, xh, y, mean, rstd, o);
+            head_regs<8, 8>(z, hps, m.out, slope, xh, y, mean, rstd, o, m.no_ln);
             if (lane < 4) {
                 const float mu = pick8(o, lane);
                 float a = mu;
@@ -632,58 +695,6 @@ __device__ __forceinline__ float lnp_sum(const float* lp) {
 #pragma unroll
         for (int c = 0; c < kColWgB; c += 2 * w) v[c] += v[c + w];
     return v[0];
-}
-
-// LDS image of one net's head parameters: g2[512] be2[512] W3[out][512] (padded to OUTMAX rows) b3[out]
-template <int OUTMAX>
-struct HeadImage {
-    static constexpr int kStride = (2 + OUTMAX) * H2 + 8;
-    static constexpr int kPer = ((2 + OUTMAX) * (H2 / 4) + kWide - 1) / kWide;  // float4 per thread to stage it
-    float4 v[kPer];
-    // g2, be2, W3 rows are contiguous in the parameter block from g2()
-    __device__ __forceinline__ void fetch(const float* __restrict__ net, const Mlp& m, int tid) {
-#pragma unroll
-        for (int i = 0; i < kPer; ++i) {
-            const int e = tid + i * kWide;
-            v[i] = e < (2 + m.out) * (H2 / 4) ? reinterpret_cast<const float4*>(net + m.g2())[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    __device__ __forceinline__ void store(float* hp, const float* __restrict__ net, const Mlp& m, int tid) const {
-#pragma unroll
-        for (int i = 0; i < kPer; ++i) {
-            const int e = tid + i * kWide;
-            if (e < (2 + m.out) * (H2 / 4)) reinterpret_cast<float4*>(hp)[e] = v[i];
-        }
-        if (tid < m.out) hp[(2 + OUTMAX) * H2 + tid] = net[m.b3() + tid];
-    }
-};
-// head from registers + the LDS image: LN2 stats of z, y = g2 xhat + be2, o[j] = act(y) . W3[j] + b3[j]
-// OUTMAX = how many outputs are computed, IMG = head width the LDS image was laid out for (HeadImage<IMG>)
-template <int OUTMAX, int IMG>
-__device__ __forceinline__ void head_regs(const RowReg<H2>& z, const float* hp, int out, float slope, RowReg<H2>& xhat, RowReg<H2>& y,
-                                          float& mean, float& rstd, float (&o)[OUTMAX], int no_ln = 0) {
-    RowReg<H2> g, be;
-    row_stats<8>(z.v, H2, mean, rstd);
-    if (no_ln) { mean = 0.0f; rstd = 1.0f; }
-    g.load(hp);
-    be.load(hp + H2);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        xhat.v[i] = (z.v[i] - mean) * rstd;
-        y.v[i] = g.v[i] * xhat.v[i] + be.v[i];
-    }
-#pragma unroll
-    for (int j = 0; j < OUTMAX; ++j) {
-        float acc = 0.0f;
-        if (j < out) {
-            RowReg<H2> w;
-            w.load(hp + (2 + j) * H2);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc += act_f(y.v[i], slope) * w.v[i];
-            acc = wave_sum(acc) + hp[(2 + IMG) * H2 + j];
-        }
-        o[j] = acc;
-    }
 }
 
 // GRP 0: BM_CRITIC_TD jobs, 1: BM_CRITIC_PI, 2: BM_ACTOR_PI / BM_ACTOR_BC, 3: BM_GIVEN — the head gradient was written to ws.dout
