@@ -42,9 +42,9 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWide = 1024;  // fwd_l2 / bwd_l2 workgroups: 16 waves = one per row of the tile in the prologue, and
-                             // 4 column tiles x 4 K-quarters (split-K, LDS reduce) in the MFMA phase.  B = 128 runs ONE
+                             // CT column tiles x 16/CT K-parts (split-K, LDS reduce) in the MFMA phase.  B = 128 runs ONE
                              // workgroup per CU, so 4 waves per SIMD are what hides the prologue's load/reduce latency.
-constexpr int kNT = 64;  // fwd_l2: z2 columns per workgroup (4 column tiles x 16, 4 K-quarters): launch A already has 192-384 workgroups
+constexpr int kNT = 64;  // fwd_l2: z2 columns per workgroup (4 column tiles x 16, 4 K-quarters) when a launch carries three or more nets
 // bwd_l2: dh1 columns per workgroup.  Its launches have one or two jobs, so 32 columns (2 column tiles x 8 K-parts per
 // workgroup, 64-128 workgroups) still fit the chip in one round and halve the MFMA work on each workgroup's critical path.
 constexpr int kNTB = 32, kCTB = kNTB / 16, kKSB = 16 / kCTB, kColWgB = H1 / kNTB;
@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
     }
     const int rg = wave;  // row group: rows rg, rg + 4, ...
     if (b < kWgTilesPerBlock + kWgVecWgs) {
-        // column n: db2, dg2, dbe2, dW3[j][n] (+ db3 by the first workgroup); 64 columns x 4 row groups
+        // column n: db2, dg2, dbe2, dW3[j][n] (+ db3 by the first workgroup); 64 columns x 16 row groups
         constexpr int RP = 12;  // rinfo pitch: mean, rstd, dout[0..7], pad
         const int vb = b - kWgTilesPerBlock;
         const int n = vb * 64 + lane;
@@ -1330,7 +1330,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
         return;
     }
     // layer 1: hidden unit k; dz1 = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) with the row means taken from the
-    // per-tile partial sums bwd_l2 left in lnp -> no cross-column work here.  64 units x 4 row groups per workgroup.
+    // per-workgroup partial sums bwd_l2 left in lnp -> no cross-column work here.  64 units x 16 row groups per workgroup.
     {
         const int k = (b - kWgTilesPerBlock - kWgVecWgs) * 64 + lane;
         const int in = J.m.in;
