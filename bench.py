@@ -39,8 +39,8 @@ LEARN_FLOP_PER_SAMPLE = 3810816  # HIRL-soft learn(), averaged over the actor-ev
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=2000)
-    p.add_argument("--warmup", type=int, default=200)
+    p.add_argument("--steps", type=int, default=20000)  # ~2.2 s of GPU time: long enough for the clocks to settle
+    p.add_argument("--warmup", type=int, default=2000)
     p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     p.add_argument("--batch", type=int, default=128)
     p.add_argument("--scenario", default="straight_line", choices=["straight_line", "serpentine", "circular", "mixed"],
