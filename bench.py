@@ -326,7 +326,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        loop.record = k < nev
+        loop.record = k >= args.steps - nev  # the last steps of the timed region: clocks settled
         loop.step()
     barrier()
     dt = time.perf_counter() - t0
@@ -363,7 +363,7 @@ def main():
                        "traffic": None, "bytes_per_launch": ENV_BYTES_FUSED * args.envs, "us_per_launch": round(env_kernel_us, 2),
                        "launches_timed": len(kern),
                        "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the "
-                                 "timed region's first launches; stage_us brackets the launch with events and so includes the dispatch gap",
+                                 "timed region's last launches; stage_us brackets the launch with events and so includes the dispatch gap",
                        "traffic_note": "PMC (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per the gfx950 calibration) at "
                                        "1,048,576 envs per launch: 226.9 MB read + 351.6 MB written = 1.003 x the 576.7 MB algorithmic bytes "
                                        "(profiles/r01_pmc_*_env_1M.csv); not collectable inside this process"}
