@@ -1,19 +1,21 @@
 """Workload for the HBM-traffic counters of the env-step kernel (run under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one
-counter per pass): a calibration copy with the same access shape over a known byte count, then env steps at 1M envs."""
+counter per pass): a calibration copy with the same access shape over a known byte count, then env steps at HX_PMC_ENVS envs
+(default 1,048,576)."""
+import os
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hirl4ucav_amd import _lib
 from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
 from hirl4ucav_amd.utils.buffer import DeviceReplay
 import ctypes
 _lib.register("hx_debug_copy_dword", [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p])
-n = 1 << 20
+n = int(os.environ.get("HX_PMC_ENVS", 1 << 20))
 cal = 128 << 20  # floats: 512 MiB read + 512 MiB written, well past the 256 MiB Infinity Cache
 a, b = torch.zeros(cal, device="cuda"), torch.zeros(cal, device="cuda")
 for _ in range(3):
     _lib.call("hx_debug_copy_dword", a.data_ptr(), b.data_ptr(), cal, _lib.stream_ptr())
-rep = DeviceReplay(4 * n)
+rep = DeviceReplay(max(4 * n, 1 << 20))
 env = BatchedHarfangEnv(n, scenario="straight_line", seed=0, max_step=1500, auto_reset=True, replay=rep)
 env.reset()
 act = torch.rand(n, 4, device="cuda") * 2 - 1
