@@ -364,9 +364,18 @@ def main():
                        "launches_timed": len(kern),
                        "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the "
                                  "timed region's last launches; stage_us brackets the launch with events and so includes the dispatch gap",
-                       "traffic_note": "PMC (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per the gfx950 calibration) at "
-                                       "1,048,576 envs per launch: 226.9 MB read + 351.6 MB written = 1.003 x the 576.7 MB algorithmic bytes "
-                                       "(profiles/r01_pmc_*_env_1M.csv); not collectable inside this process"}
+                       "traffic_note": "not collectable inside this process"}
+    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass, gfx950 FETCH x2
+    # calibration): a separate run of the same kernel at the same size, committed under profiles/
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_env_traffic.json")
+    if os.path.exists(pmc_file):
+        with open(pmc_file) as f:
+            pmc = json.load(f).get(str(args.envs))
+        if pmc:
+            res["roofline"]["traffic"] = pmc["traffic_bytes"]
+            res["roofline"]["traffic_note"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of tools/pmc_env.py at {args.envs} envs per launch "
+                                               f"(profiles/r01p_pmc_*.csv): {pmc['fetch_bytes']} B fetched (FETCH_SIZE x 2, calibrated) + {pmc['write_bytes']} B "
+                                               f"written = {pmc['ratio']} x the algorithmic bytes")
     res["roofline_update"] = {"kernels": "fwd_l2/bwd_l2/wgrad/adam (one learn)", "bound": "mfma", "unit": "TFLOP/s",
                               "achieved": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
                               "frac": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 5),
