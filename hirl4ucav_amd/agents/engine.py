@@ -219,16 +219,15 @@ class HirlEngine:
             gs = 1.0 / self.world
             _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, (2 if w_kind == 1 else 1) if actor_phase else 0, st)
             self._allreduce(self.grad_critic)
-            _lib.call("hx_adam", nets, hyper, 0, self.critic_step, gs, 0, 0.0, 0.0, B, st)
+            pk = 16 if do_polyak else 0  # + 16: soft_update of the target in the same launch (nothing reads it in between)
+            _lib.call("hx_adam", nets, hyper, 0 | pk, self.critic_step, gs, 0, 0.0, 0.0, B, st)
             if actor_phase:
                 _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, int(w_kind == 1), 1, st)
                 if w_kind == 1:
                     self._allreduce(self.soft_count)
                 _lib.call("hx_hirl_actor_wgrad", nets, hyper, B, B * self.world, w_kind, w_given, float(bc_warm_up_weight), st)
                 self._allreduce(self.grad_actor)
-                _lib.call("hx_adam", nets, hyper, 1, self.actor_step, gs, w_kind, w_given, float(bc_warm_up_weight), B * self.world, st)
-                if do_polyak:
-                    _lib.call("hx_polyak", nets, hyper, st)
+                _lib.call("hx_adam", nets, hyper, 1 | pk, self.actor_step, gs, w_kind, w_given, float(bc_warm_up_weight), B * self.world, st)
         self.actor_trainable = not self.actor_trainable  # HIRL.py:332
 
     def bc_train_actor(self):

@@ -1422,6 +1422,10 @@ struct AdamArgs {
     // SAC policy step: also the log-alpha step (SAC/agent.py:322-325, 408-414)
     float* alpha_state;  // [4]: log_alpha, m, v, alpha; nullptr = not a SAC policy step
     float target_entropy, alpha_step_size;
+    // soft_update of this network's target in the same pass (HIRL.py:11-13,327-330): nothing reads the targets between this
+    // Adam step and the end of learn(), so target <- (1 - tau) target + tau p_new here equals the reference's separate pass
+    float* target;       // nullptr = no Polyak this call
+    float tau;
 };
 
 __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
@@ -1456,12 +1460,21 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
         *reinterpret_cast<float4*>(A.p + i) = p4;
         *reinterpret_cast<float4*>(A.m + i) = m4;
         *reinterpret_cast<float4*>(A.v + i) = v4;
+        if (A.target) {
+            float4 t4 = *reinterpret_cast<const float4*>(A.target + i);
+            t4.x = t4.x * (1.0f - A.tau) + p4.x * A.tau;  // HIRL.py:13
+            t4.y = t4.y * (1.0f - A.tau) + p4.y * A.tau;
+            t4.z = t4.z * (1.0f - A.tau) + p4.z * A.tau;
+            t4.w = t4.w * (1.0f - A.tau) + p4.w * A.tau;
+            *reinterpret_cast<float4*>(A.target + i) = t4;
+        }
         return;
     }
     for (int c = 0; c < A.n - i; ++c) {  // ragged tail
         float pv = A.p[i + c], mv = A.m[i + c], vv = A.v[i + c];
         adam_update(pv, mv, vv, A.g[i + c] * A.gscale, A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
         A.p[i + c] = pv; A.m[i + c] = mv; A.v[i + c] = vv;
+        if (A.target) A.target[i + c] = A.target[i + c] * (1.0f - A.tau) + pv * A.tau;
     }
 }
 
@@ -1769,6 +1782,8 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
  * bc_weight bookkeeping: w_kind 0 given, 1 estimate from soft_count, 2 reuse stored). */
 int hx_adam(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t step, float grad_scale, int32_t w_kind, float w_given,
             float warm, int32_t batch, void* stream) {
+    const bool polyak = (which & 16) != 0;  // + 16: soft_update of this network's target in the same launch
+    which &= 15;
     HX_REQUIRE(N && Hy && step >= 1 && which >= 0 && which <= 2, "hx_adam: bad arguments");
     const double b1 = 0.9, b2 = 0.999;
     const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
@@ -1785,6 +1800,10 @@ int hx_adam(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t step, flo
     A.finish_actor = which == 1;  // which == 2: the actor's Adam step alone (BC pre-training)
     A.w_kind = w_kind; A.w_given = w_given; A.warm = warm; A.inv_batch = 1.0f / (batch > 0 ? batch : 1);
     A.soft_count = N->soft_count; A.wstate = N->wstate; A.losses = N->losses; A.use_bc = Hy->use_bc;
+    if (polyak) {
+        A.target = which == 0 ? N->target_critic : N->target_actor;
+        A.tau = Hy->tau;
+    }
     HX_REQUIRE((((uintptr_t)A.p | (uintptr_t)A.g | (uintptr_t)A.m | (uintptr_t)A.v) & 15u) == 0, "hx_adam: buffers must be 16-byte aligned");
     hipLaunchKernelGGL(adam_kernel, dim3((A.n / 4 + kThreads) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, A);
     HX_CHECK_LAUNCH("hx_adam");
@@ -1917,11 +1936,11 @@ int hx_hirl_learn(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t
     // 5 launches on a critic-only call, 10 on an actor call (the actor's critic-independent forwards ride in launch A)
     int rc = hx_hirl_critic_grads(N, Bt, Hy, actor_phase ? (w_kind == 1 ? 2 : 1) : 0, stream);
     if (rc) return rc;
-    if ((rc = hx_adam(N, Hy, 0, critic_step, 1.0f, 0, 0.0f, 0.0f, Bt->batch, stream)) || !actor_phase) return rc;
+    const int pk = do_polyak ? 16 : 0;  // the Polyak passes ride in the two Adam launches
+    if ((rc = hx_adam(N, Hy, 0 | pk, critic_step, 1.0f, 0, 0.0f, 0.0f, Bt->batch, stream)) || !actor_phase) return rc;
     if ((rc = hx_hirl_actor_backward(N, Bt, Hy, w_kind == 1, 1, stream))) return rc;
     if ((rc = hx_hirl_actor_wgrad(N, Hy, Bt->batch, Bt->batch, w_kind, w_given, warm, stream))) return rc;
-    if ((rc = hx_adam(N, Hy, 1, actor_step, 1.0f, w_kind, w_given, warm, Bt->batch, stream))) return rc;
-    if (do_polyak) rc = hx_polyak(N, Hy, stream);
+    if ((rc = hx_adam(N, Hy, 1 | pk, actor_step, 1.0f, w_kind, w_given, warm, Bt->batch, stream))) return rc;
     return rc;
 }
 

@@ -177,10 +177,11 @@ int hx_hirl_actor_backward(const HxNets* nets, const HxBatch* batch, const HxHyp
  * 2: the stored weight.  w is clipped to <= 1 (HIRL.py:308). */
 int hx_hirl_actor_wgrad(const HxNets* nets, const HxHyper* hyper, int32_t batch, int32_t count_batch, int32_t w_kind,
                         float w_given, float warm, void* stream);
-/* which 0 critic / 1 actor; step = 1-based Adam step; grad is scaled by grad_scale first (1/world after a SUM). */
+/* which 0 critic / 1 actor / 2 actor alone (BC pre-training), + 16: also soft_update (HIRL.py:11-13) this network's target with the new
+ * parameters in the same launch; step = 1-based Adam step; grad is scaled by grad_scale first (1/world after a SUM). */
 int hx_adam(const HxNets* nets, const HxHyper* hyper, int32_t which, int32_t step, float grad_scale, int32_t w_kind,
             float w_given, float warm, int32_t batch, void* stream);
-int hx_polyak(const HxNets* nets, const HxHyper* hyper, void* stream);
+int hx_polyak(const HxNets* nets, const HxHyper* hyper, void* stream); /* both targets in a launch of their own */
 /* BC.Agent.train_actor (hirl/agents/BC.py:160-185): one behaviour-cloning step on batch->bc_rows: loss = mse(actor(s_bc),
  * a_bc), backward, actor.optimizer.step(); losses[2] receives the loss.  hyper->slope = 0.01 gives BC.py's LeakyReLU actor.
  * (hx_adam's which = 2 is the actor step without HIRL's actor_loss / bc_weight bookkeeping.) */
