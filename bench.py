@@ -59,6 +59,8 @@ def parse():
                         "reference's strict act -> step -> sample -> learn order; with N > 1 it is ON by default, because there the side "
                         "stream fills the time the main stream spends waiting in the gradient all-reduce")
     p.add_argument("--serial", action="store_true", help="force the one-stream order at N > 1 too")
+    p.add_argument("--separate-launches", dest="separate_launches", action="store_true",
+                   help="act and env step as two launches on every step (default: one fused launch, hx_actor_act_step)")
     p.add_argument("--staged", action="store_true",
                    help="use the stage-by-stage update path of the sharded build on one rank too (costs of the N > 1 launch sequence)")
     return p.parse_args()
@@ -158,7 +160,8 @@ class Loop:
         self.actions = torch.zeros((n, 4), device=device)
         from hirl4ucav_amd.utils.pipeline import VectorStepPipeline
         self.pipe = VectorStepPipeline(device, overlap=(getattr(args, "overlap", False) or (world > 1 and not getattr(args, "serial", False))) and not self.sac)
-        self.record, self.rec, self.pool = False, {"act": [], "env": [], "learn": []}, []
+        self.record, self.rec, self.pool = False, {"act": [], "env": [], "act+env": [], "learn": []}, []
+        self.separate = getattr(args, "separate_launches", False)
         self.kpool, self.krec = [], []
 
     def _timed(self, name, fn):
@@ -175,18 +178,26 @@ class Loop:
 
     def _act_env(self):
         e, env = self.eng, self.env
-        if self.uniform:  # env.action_space.sample() for every env (train_all.py:272)
-            self._timed("act", lambda: self.actions.uniform_(-1.0, 1.0))
-        elif self.sac:
-            self._timed("act", lambda: e.act(env.obs, seed=1, row0=env.env_id0, out=self.actions))  # SacAgent.explore
-        else:
-            self._timed("act", lambda: e.act(env.obs, sigma=0.1, seed=1, row0=env.env_id0, out=self.actions))  # actionNoise 0.1, HIRL.py:160
-        if self.record and self.kpool and self.t % 8 == 0:  # every 8th launch (the stamped launch costs ~9 us extra): the env kernel's own duration (what rocprofv3 reports), next to the bracketing events
-            a, b = self.kpool.pop(), self.kpool.pop()
-            env.time_next_steps(a, b)
-            self.krec.append((a, b))
-        self._timed("env", lambda: env.step(self.actions))
-        env.time_next_steps(None, None)
+        # The env kernel's own duration (what rocprofv3 reports) is sampled on every 8th recorded step: there the two stages go
+        # out as separate launches, act then a STAMPED env step (a stamped launch costs ~9 us extra, hence not on every step).
+        stamped = self.record and self.kpool and self.t % 8 == 0
+        if self.uniform or self.separate or stamped:
+            if self.uniform:  # env.action_space.sample() for every env (train_all.py:272)
+                self._timed("act", lambda: self.actions.uniform_(-1.0, 1.0))
+            elif self.sac:
+                self._timed("act", lambda: e.act(env.obs, seed=1, row0=env.env_id0, out=self.actions))  # SacAgent.explore
+            else:
+                self._timed("act", lambda: e.act(env.obs, sigma=0.1, seed=1, row0=env.env_id0, out=self.actions))  # actionNoise 0.1, HIRL.py:160
+            if stamped:
+                a, b = self.kpool.pop(), self.kpool.pop()
+                env.time_next_steps(a, b)
+                self.krec.append((a, b))
+            self._timed("env", lambda: env.step(self.actions))
+            env.time_next_steps(None, None)
+        elif self.sac:   # explore + env.step in one launch
+            self._timed("act+env", lambda: e.act_step(env, seed=1, out=self.actions))
+        else:            # chooseAction + env.step in one launch (same results, bit for bit: tests/test_hirl_gpu.py)
+            self._timed("act+env", lambda: e.act_step(env, sigma=0.1, seed=1, out=self.actions))
 
     def _learn(self):
         e = self.eng
@@ -334,7 +345,8 @@ def main():
         tt = torch.tensor([dt], device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    act_us, env_us, learn_us = (float(np.median([a.elapsed_time(b) * 1e3 for a, b in loop.rec[k]])) for k in ("act", "env", "learn"))
+    med = {k: (float(np.median([a.elapsed_time(b) * 1e3 for a, b in v])) if v else None) for k, v in loop.rec.items()}
+    act_us, env_us, learn_us = med["act"], med["env"], med["learn"]
     kern = []
     for a, b in loop.krec:  # kernel-only durations of the env-step launches inside the timed region
         us = ctypes.c_float()
@@ -352,10 +364,12 @@ def main():
                                 f"(BASELINE.json configs[2])" if args.agent == "sac" else
                                 f"{args.envs} parallel {args.scenario} envs per GPU, HIRL-{args.type} fp32, 1 learn(B={args.batch}) per vector step "
                                 f"(BASELINE.json configs[1])"), "envs_per_gpu": args.envs, "batch": args.batch,
-                   "actions": args.actions, "issue_order": "two streams" if loop.pipe.overlap else "serial", "update_path": "staged" if (args.staged or world > 1) and args.agent == "hirl" else "one-call",
+                   "actions": args.actions, "act_env": "two launches" if (loop.separate or loop.uniform) else "one launch (hx_actor_act_step / hx_sac_act_step)", "issue_order": "two streams" if loop.pipe.overlap else "serial", "update_path": "staged" if (args.staged or world > 1) and args.agent == "hirl" else "one-call",
                    "parallelism": f"dp{world}: env shards + replicated nets, RCCL all-reduce of the flat gradients"},
         "update_steps_per_s": round(args.steps / dt, 1),
-        "stage_us": {"act(1 kernel)": round(act_us, 2), "env_step(1 kernel)": round(env_us, 2), "sample+learn(6-12 kernels)": round(learn_us, 2)},
+        "stage_us": {"act+env_step(1 kernel)": None if med["act+env"] is None else round(med["act+env"], 2),
+                     "act(own launch, sampled steps)": round(act_us, 2), "env_step(own launch, sampled steps)": round(env_us, 2),
+                     "sample+learn(6-11 kernels)": round(learn_us, 2)},
     }
     # roofline of the env-step kernel (the kernel the metric counts): algorithmic bytes / live-measured launch time
     res["roofline"] = {"kernel": "env_step_kernel<INSERT>", "bound": "hbm", "achieved": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3, 1),

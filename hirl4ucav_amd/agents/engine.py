@@ -34,6 +34,8 @@ class HxHyper(ctypes.Structure):
 
 _P = ctypes.POINTER
 _lib.register("hx_actor_act", [_vp, _vp, ctypes.c_int64, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _f32, _vp, _vp])
+_lib.register("hx_actor_act_step", [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32,
+                                     ctypes.c_uint32, _f32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
 _lib.register("hx_hirl_critic_grads", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _vp])
 _lib.register("hx_hirl_actor_backward", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _vp])
 _lib.register("hx_hirl_actor_wgrad", [_P(HxNets), _P(HxHyper), _i32, _i32, _i32, _f32, _f32, _vp])
@@ -163,6 +165,24 @@ class HirlEngine:
                   _lib.ptr(noise), float(sigma), int(seed), int(row0), self.act_calls, self.slope, self._act_ws.data_ptr(),
                   _lib.stream_ptr())
         return out
+
+    def act_step(self, env, noise=None, sigma=0.0, seed=0, out=None):
+        """chooseAction for every env of `env` (a BatchedHarfangEnv) AND env.step with those actions in ONE launch
+        (train_all.py:343-345): same results as act(env.obs, ...) followed by env.step(actions), bit for bit.
+        -> (actions, obs, reward, done, success); env.obs holds the next observations afterwards."""
+        n = env.n
+        if out is None:
+            out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        mode = 0
+        if noise is not None:
+            mode = 1 if noise.numel() == 4 else 2
+        elif sigma > 0:
+            mode = 3
+        self.act_calls += 1
+        _lib.call("hx_actor_act_step", self.actor.data_ptr(), env.state.data_ptr(), n, n, env.obs.data_ptr(), out.data_ptr(), mode,
+                  _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope, env.reward.data_ptr(),
+                  env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
+        return out, env.obs, env.reward, env.done, env.success
 
     # ---- learning --------------------------------------------------------------------------------------------
     def _allreduce(self, t):

@@ -24,6 +24,8 @@ class HxSacBatch(ctypes.Structure):
 
 
 _lib.register("hx_sac_act", [_vp, _vp, ctypes.c_int64, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp])
+_lib.register("hx_sac_act_step", [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                   _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
 _lib.register("hx_sac_critic_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _i32, _vp])
 _lib.register("hx_sac_policy_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _vp])
 _lib.register("hx_sac_adam", [_P(HxSacNets), _P(E.HxHyper), _i32, _i32, _f32, _f32, _vp])
@@ -145,6 +147,19 @@ class SacEngine:
         _lib.call("hx_sac_act", self.policy.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode, _lib.ptr(eps), int(seed), int(row0),
                   self.act_calls, self._act_ws.data_ptr(), _lib.stream_ptr())
         return out
+
+    def act_step(self, env, eps=None, explore=True, seed=0, out=None):
+        """explore / exploit for every env of `env` AND env.step with those actions in one launch (train_sac.py:238-241); same
+        results as act(env.obs, ...) followed by env.step(actions).  -> (actions, obs, reward, done, success)."""
+        n = env.n
+        if out is None:
+            out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        mode = 0 if not explore else (1 if eps is not None else 2)
+        self.act_calls += 1
+        _lib.call("hx_sac_act_step", self.policy.data_ptr(), env.state.data_ptr(), n, n, env.obs.data_ptr(), out.data_ptr(), mode,
+                  _lib.ptr(eps), int(seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(), env.done.data_ptr(),
+                  env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
+        return out, env.obs, env.reward, env.done, env.success
 
     def assemble(self, ring, idx):
         _lib.call("hx_sample_batch", None, 0, ring.data_ptr(), None, 0, None, 0, self.batch, self.batch, 0, 0, 0, 0.0, idx.data_ptr(), None,

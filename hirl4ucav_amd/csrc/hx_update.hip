@@ -22,6 +22,7 @@
 //   adam / polyak  elementwise over the flat buffers, 16 B per lane.
 #include "hx_common.h"
 #include "hx_nn.h"
+#include "hx_env_dev.h"
 
 using namespace hxnn;
 
@@ -430,7 +431,7 @@ __device__ __forceinline__ void head_regs(const RowReg<H2>& z, const float* hp, 
 struct ActFusedArgs {
     const float* net;
     Mlp m;
-    const float* obs;  // [rows][13]
+    float* obs;        // [rows][13]; written only by the ENV instantiations (next observation)
     int rows;
     float slope;
     float* actions;      // [rows][4]
@@ -440,6 +441,13 @@ struct ActFusedArgs {
     int mode;            // Gaussian head: 0 exploit tanh(mean), 1 sample with eps, 2 sample with Philox
     uint64_t seed;
     uint32_t row0, call;
+    // ENV instantiations: HarfangEnv.step for the same rows in the tail of this launch (obs is then in/out)
+    float* state;
+    int64_t stride;
+    float* reward;
+    uint8_t* done;
+    int8_t* success;
+    HxStepOpts o;
 };
 
 constexpr int ACT_KC = 16;            // k-chunk of W2 staged through LDS (64 B per column), double-buffered
@@ -462,9 +470,15 @@ __device__ __forceinline__ float philox_normal(uint32_t row, uint32_t call, uint
 // chunk against two row tiles, halving W2's L2 traffic and the barriers per MFMA.
 // GAUSS = the SAC policy: plain Linear-ReLU stack (m.no_ln), 8-wide head = mean ++ log_std, tanh-Gaussian sample
 // (SacAgent.explore / exploit, SAC/agent.py:183-196, GaussianPolicy.sample, SAC/model.py:63-82).
-template <int NRT, bool GAUSS>
+// ENV   = the env step of the same rows runs in the tail: the 16 (32) actions meet in LDS and the lanes of wave 0 each step
+//         one env (hx_env_dev.h: the code of env_step_kernel, contraction off), with the fused replay insert — no second
+//         launch, and the env's ~2,500-instruction chain runs on every CU at once instead of on 16 of them.
+template <int NRT, bool GAUSS, bool ENV>
 __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     constexpr int ROWS = NRT * RT;
+    __shared__ float s_act[ENV ? ROWS * 4 : 4];
+    __shared__ unsigned long long s_base;
+    __shared__ int s_nstore;
     static_assert(2 * H2 * ACT_LDW >= ROWS * LDA2, "the z2 tile reuses the W2 chunk buffers");
     __shared__ __attribute__((aligned(16))) float lds[ROWS * LDA1 + ROWS * XP + ROWS * 2 + H1 * 13 + 2 * H2 * ACT_LDW];
     float* h1s = lds;
@@ -622,6 +636,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
                     a = fminf(fmaxf(a + A.sigma * n, -1.0f), 1.0f);
                 }
                 A.actions[(size_t)r * 4 + lane] = a;
+                if (ENV) s_act[lr * 4 + lane] = a;
             }
         } else {
             float o[8];
@@ -634,7 +649,119 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
                     const float e = A.mode == 1 ? A.noise[(size_t)r * 4 + lane] : philox_normal(A.row0 + (uint32_t)r, A.call, 0x53414331u, A.seed, lane);
                     a = mu + expf(ls) * e;
                 }
-                A.actions[(size_t)r * 4 + lane] = tanhf(a);
+                a = tanhf(a);
+                A.actions[(size_t)r * 4 + lane] = a;
+                if (ENV) s_act[lr * 4 + lane] = a;
+            }
+        }
+    }
+    if (ENV) {
+        using namespace hxenv;
+        constexpr int kRowPitch = HX_ROW_WORDS + 1;
+        float* s_row = wb1;                    // [ROWS][33] replay rows   (the odd chunk buffer is free since the last barrier)
+        float* s_obs = wb1 + ROWS * kRowPitch;  // [ROWS][13] next observations
+        __syncthreads();  // actions of all rows in s_act
+        if (wave == 0) {
+            const int e = lane;
+            const bool active = e < nrow;
+            const int64_t i = (int64_t)r0 + e;
+            const bool insert = A.o.ring != nullptr;
+            Env E;
+            float4 act = {0.f, 0.f, 0.f, 0.f};
+            float prev[HX_OBS_DIM];
+            bool trunc = false, store = false;
+            if (active) {
+                load_env(E, A.state, A.stride, r0, (uint32_t)e);
+                act = *reinterpret_cast<const float4*>(s_act + e * 4);
+#pragma unroll
+                for (int j = 0; j < HX_OBS_DIM; ++j) prev[j] = insert ? A.obs[i * HX_OBS_DIM + j] : 0.0f;
+                uint32_t ep = E.counters & 0xFFFFu;
+                ep = ep < 65535u ? ep + 1u : ep;
+                trunc = A.o.max_step > 0 && (int)ep >= A.o.max_step;  // train_all.py:346-347
+                store = insert && !trunc;
+            }
+            // ring slots: one atomic per workgroup, issued before the arithmetic that hides its latency
+            const unsigned long long bal = __ballot(store);
+            const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+            const int nstore = __popcll(bal);
+            unsigned long long base = 0ull;
+            if (lane == 0 && nstore > 0) base = atomicAdd((unsigned long long*)A.o.total, (unsigned long long)nstore);
+            float reward = 0.0f;
+            int success = 0;
+            bool done = false, ended = false;
+            Observed O;
+            unsigned st_kill = 0, st_fs = 0, st_tl = 0, st_fire = 0, st_good = 0, st_lock = 0;
+            if (active) {
+                const bool fire = act.w > 0.0f;  // float(action[3] > 0)  HarfangEnv_GYM.py:150
+                sim_step(E, act.x, act.y, act.z, fire);
+                wrap_step(E, O, reward, success);
+                uint32_t ep = E.counters & 0xFFFFu;
+                ep = ep < 65535u ? ep + 1u : ep;
+                E.counters = (E.counters & 0xFFFF0000u) | ep;
+                done = (E.flags & HX_F_DONE) != 0u;
+                ended = A.o.auto_reset && (done || trunc);
+                st_fire = (E.flags & HX_F_FIRED) ? 1u : 0u;
+                st_good = success == 1 ? 1u : 0u;
+                st_lock = (E.flags & HX_F_LOCKED) ? 1u : 0u;
+                st_kill = (ended && (E.flags & HX_F_EPISODE_SUCCESS)) ? 1u : 0u;
+                st_fs = (ended && (E.flags & HX_F_FIRE_SUCCESS)) ? 1u : 0u;
+                st_tl = (ended && !done) ? 1u : 0u;
+                A.reward[i] = reward;
+                A.done[i] = done ? 1 : 0;
+                A.success[i] = (int8_t)success;
+            }
+            if (store) {  // row = s[13] a[4] s'[13] r done   (Transition, buffer.py:8)
+                float* row = s_row + rank * kRowPitch;
+#pragma unroll
+                for (int j = 0; j < HX_OBS_DIM; ++j) row[j] = prev[j];
+                row[13] = act.x; row[14] = act.y; row[15] = act.z; row[16] = act.w;
+#pragma unroll
+                for (int j = 0; j < HX_OBS_DIM; ++j) row[17 + j] = O.obs[j];
+                row[30] = reward;
+                row[31] = done ? 1.0f : 0.0f;
+            }
+            if (lane == 0) {
+                s_base = base;
+                s_nstore = nstore;
+            }
+            if (store && A.o.ring_success) {
+                const unsigned long long b0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                                              (unsigned)__builtin_amdgcn_readfirstlane((int)(base & 0xFFFFFFFFull));
+                A.o.ring_success[(b0 + (unsigned long long)rank) % (unsigned long long)A.o.cap] = (int8_t)success;
+            }
+            if (active) {
+                if (ended) {
+                    const uint32_t scen = (E.flags >> HX_F_SCEN_SHIFT) & 3u;
+                    const uint32_t epi = A.o.episode_ctr[i] + 1u;
+                    A.o.episode_ctr[i] = epi;
+                    env_reset(E, scen, A.o.randomize != 0, A.o.seed, A.o.env_id0 + (uint32_t)i, epi);
+                    observe(E, O);
+                }
+                store_env(E, A.state, A.stride, r0, (uint32_t)e);
+#pragma unroll
+                for (int j = 0; j < HX_OBS_DIM; ++j) s_obs[e * HX_OBS_DIM + j] = O.obs[j];
+            }
+            if (A.o.stats) {
+                const unsigned vals[HX_STAT_COUNT] = {ended ? 1u : 0u, st_kill, st_fs, st_tl, st_fire, st_good, st_lock, active ? 1u : 0u};
+                unsigned mine = 0;
+#pragma unroll
+                for (int k = 0; k < HX_STAT_COUNT; ++k) {
+                    const unsigned c = (unsigned)__popcll(__ballot(vals[k] != 0u));
+                    if (lane == k) mine = c;
+                }
+                if (lane < HX_STAT_COUNT && mine) atomicAdd((unsigned long long*)&A.o.stats[lane], (unsigned long long)mine);
+            }
+        }
+        __syncthreads();  // rows, next observations, s_base / s_nstore
+        for (int k = tid; k < nrow * HX_OBS_DIM; k += kWide) A.obs[(size_t)r0 * HX_OBS_DIM + k] = s_obs[k];
+        const int nstore = s_nstore;
+        if (nstore > 0) {  // 16 B per lane, rows contiguous in the ring (modulo wrap)
+            const unsigned long long base = s_base, cap = (unsigned long long)A.o.cap;
+            float4* ring4 = reinterpret_cast<float4*>(A.o.ring);
+            for (int k = tid; k < nstore * (HX_ROW_WORDS / 4); k += kWide) {
+                const int rr = k >> 3, c = (k & 7) * 4;
+                const float* src = s_row + rr * kRowPitch + c;
+                ring4[((base + (unsigned long long)rr) % cap) * (HX_ROW_WORDS / 4) + (k & 7)] = make_float4(src[0], src[1], src[2], src[3]);
             }
         }
     }
@@ -643,12 +770,22 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 }
 
 // 16 rows per workgroup fill the chip up to 4,096 rows; from 8,192 rows on 32 rows per workgroup reuse every W2 chunk twice
+// The env tail pays while the launch is ONE round of workgroups (256 CUs x 16 or 32 rows): beyond that every extra round repeats
+// the ~8 us tail, and the env kernel on its own (thousands of envs per launch, 10-14 us) is the cheaper way.
+constexpr int64_t kFuseEnvMax = 8192;
+
 template <bool GAUSS>
 static void launch_act(const ActFusedArgs& H, hipStream_t st) {
-    if (H.rows >= 8192)
-        hipLaunchKernelGGL((act_fused_kernel<2, GAUSS>), dim3((unsigned)((H.rows + 2 * RT - 1) / (2 * RT))), dim3(kWide), 0, st, H);
-    else
-        hipLaunchKernelGGL((act_fused_kernel<1, GAUSS>), dim3((unsigned)((H.rows + RT - 1) / RT)), dim3(kWide), 0, st, H);
+    const bool env = H.state != nullptr;
+    if (H.rows >= 8192) {
+        const dim3 grid((unsigned)((H.rows + 2 * RT - 1) / (2 * RT)));
+        if (env) hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, true>), grid, dim3(kWide), 0, st, H);
+        else hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, false>), grid, dim3(kWide), 0, st, H);
+    } else {
+        const dim3 grid((unsigned)((H.rows + RT - 1) / RT));
+        if (env) hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, true>), grid, dim3(kWide), 0, st, H);
+        else hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, false>), grid, dim3(kWide), 0, st, H);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1696,10 +1833,39 @@ int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* acti
     HX_REQUIRE(actor && obs && actions && rows > 0, "hx_actor_act: bad arguments");
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act: bad noise mode");
     (void)ws;
-    ActFusedArgs H{actor, kActor, obs, (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
-                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call};
+    ActFusedArgs H{actor, kActor, const_cast<float*>(obs), (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
+                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}};
     launch_act<false>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_actor_act");
+    return 0;
+}
+
+static int check_step_args(const float* state, int64_t n, int64_t stride, const float* obs_io, const float* actions, const float* reward,
+                           const uint8_t* done, const int8_t* success, const HxStepOpts& o, const char* who) {
+    HX_REQUIRE(state && obs_io && actions && reward && done && success && n > 0 && stride >= n, "%s: bad buffers", who);
+    HX_REQUIRE(n < (int64_t)1 << 31, "%s: at most 2^31 - 1 envs per launch", who);
+    HX_REQUIRE(!o.auto_reset || o.episode_ctr, "%s: auto_reset needs episode_ctr", who);
+    HX_REQUIRE(!o.ring || (o.cap > 0 && o.total && (reinterpret_cast<uintptr_t>(o.ring) & 15u) == 0), "%s: ring needs cap, total and 16-byte alignment", who);
+    return 0;
+}
+
+/* chooseAction + HarfangEnv.step for n envs in ONE launch (train_all.py:343-345): actions = clamp(actor(obs_io) + noise, -1, 1) as
+ * hx_actor_act, then hx_env_step with those actions in the tail of the same kernel — obs_io in: current observation, out: next. */
+int hx_actor_act_step(const float* actor, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+                      const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward,
+                      uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
+    HX_REQUIRE(actor, "hx_actor_act_step: null actor");
+    HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act_step: bad noise mode");
+    const HxStepOpts o = opts ? *opts : HxStepOpts{};
+    if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_actor_act_step")) return rc;
+    if (n > kFuseEnvMax) {  // more than one round of workgroups: the env step is cheaper as a launch of its own
+        if (int rc = hx_actor_act(actor, obs_io, n, actions, noise_mode, noise, sigma, seed, row0, call, slope, nullptr, stream)) return rc;
+        return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
+    }
+    ActFusedArgs H{actor, kActor, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
+                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o};
+    launch_act<false>(H, (hipStream_t)stream);
+    HX_CHECK_LAUNCH("hx_actor_act_step");
     return 0;
 }
 
@@ -2006,11 +2172,30 @@ static void sac_slots(const HxSacNets* N, int B, Slot* s) {
  * standard-normal draws eps[rows][4]; 2: sample with Philox(seed; row0 + row, call).  ws: hx_act_workspace_floats(rows). */
 int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps, uint64_t seed,
                uint32_t row0, uint32_t call, float* ws, void* stream) {
-    HX_REQUIRE(policy && obs && actions && ws && rows > 0 && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act: bad arguments");
+    HX_REQUIRE(policy && obs && actions && rows > 0 && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act: bad arguments");
     (void)ws;
-    ActFusedArgs H{policy, kPolicy, obs, (int)rows, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call};
+    ActFusedArgs H{policy, kPolicy, const_cast<float*>(obs), (int)rows, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
+                   nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}};
     launch_act<true>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_sac_act");
+    return 0;
+}
+
+/* SacAgent.explore / exploit + HarfangEnv.step in one launch (train_sac.py:238-241): hx_sac_act, then hx_env_step in the kernel's tail. */
+int hx_sac_act_step(const float* policy, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t mode,
+                    const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,
+                    const HxStepOpts* opts, void* stream) {
+    HX_REQUIRE(policy && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act_step: bad arguments");
+    const HxStepOpts o = opts ? *opts : HxStepOpts{};
+    if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_sac_act_step")) return rc;
+    if (n > kFuseEnvMax) {
+        if (int rc = hx_sac_act(policy, obs_io, n, actions, mode, eps, seed, row0, call, nullptr, stream)) return rc;
+        return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
+    }
+    ActFusedArgs H{policy, kPolicy, obs_io, (int)n, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
+                   state, stride, reward, done, success, o};
+    launch_act<true>(H, (hipStream_t)stream);
+    HX_CHECK_LAUNCH("hx_sac_act_step");
     return 0;
 }
 

@@ -214,12 +214,18 @@ def main(config):
         for _ in range(math.ceil(20 * max_step / (n * world))):
             env.step(torch.rand((n, 4), device=device) * 2 - 1)
     expert_num, high_score, success_rate, arttir = run["expert_num"], run["high_score"], run["success_rate"], run["arttir"]
+    actions = torch.zeros((n, 4), device=device)
     t0, episode0 = time.time(), run["episode"]
     for episode in range(episode0, config.episodes):
         w_now, warm = bc_weight_schedule(config.type, episode, config.bc_weight) if hirl else (0.0, 0.0)
         for step in range(max_step):
-            actions = eng.act(env.obs, seed=seed + 1, row0=env.env_id0) if sac else eng.act(env.obs, sigma=0.1, seed=seed + 1, row0=env.env_id0)
-            env.step(actions)
+            if config.separate_launches:  # chooseAction, then env.step: two launches
+                eng.act(env.obs, seed=seed + 1, row0=env.env_id0, out=actions) if sac else eng.act(env.obs, sigma=0.1, seed=seed + 1, row0=env.env_id0, out=actions)
+                env.step(actions)
+            elif sac:                     # the same in ONE launch (identical values; only the order in which a step's rows enter the
+                eng.act_step(env, seed=seed + 1, out=actions)              # replay ring depends on the workgroup schedule)
+            else:
+                eng.act_step(env, sigma=0.1, seed=seed + 1, out=actions)
             if step == max_step - 1:
                 break
             expert_num = expert_num_after(expert_num, step, warm_up_rate)
@@ -283,6 +289,9 @@ def parser():
     p.add_argument("--result_dir", type=str, default="results")
     p.add_argument("--checkpoint_rate", type=int, default=25, help="episodes between validations (train_all.py:206)")
     p.add_argument("--bc_validate_from", type=int, default=1000, help="BC: first episode with validation (train_all.py:259)")
+    p.add_argument("--separate_launches", action="store_true",
+                   help="chooseAction and env.step as two launches (default: one fused launch). With <= 256 envs this keeps the replay "
+                        "insert order, and so the whole run, reproducible bit for bit")
     p.add_argument("--snapshot_every", type=int, default=25, help="episodes between whole-run snapshots (0: never)")
     p.add_argument("--resume", type=str, default=None, help="run directory holding state_rank<r>.pt to continue from")
     return p

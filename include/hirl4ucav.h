@@ -132,6 +132,11 @@ int64_t hx_act_workspace_floats(int64_t rows);
 int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
                  const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* ws,
                  void* stream);
+/* chooseAction + HarfangEnv.step for n envs in ONE launch (train_all.py:343-345): the actions of hx_actor_act (also written to
+ * `actions`), then hx_env_step with them in the tail of the same kernel.  obs_io in: current observations, out: next. */
+int hx_actor_act_step(const float* actor, float* state, int64_t n, int64_t stride, float* obs_io, float* actions,
+                      int32_t noise_mode, const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope,
+                      float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts /* host, may be NULL */, void* stream);
 
 /* Minibatch of Agent.learn (HIRL.py:223-251), already assembled by hx_sample_batch into compact row tiles:
  * rows[batch][HX_ROW_WORDS] = s[13] a[4] s'[13] r done (buffer rows first, then expert rows, HIRL.py:229-233);
@@ -235,6 +240,10 @@ int64_t hx_sac_workspace_floats(int32_t batch);
  * Philox4x32-10(seed; row0 + row, call).  ws: hx_act_workspace_floats(rows). */
 int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps,
                uint64_t seed, uint32_t row0, uint32_t call, float* ws, void* stream);
+/* SacAgent.explore / exploit + HarfangEnv.step in one launch (train_sac.py:238-241). */
+int hx_sac_act_step(const float* policy, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t mode,
+                    const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,
+                    const HxStepOpts* opts /* host, may be NULL */, void* stream);
 /* SacAgent.learn (SAC/agent.py:276-327) in the stages a sharded run separates:
  *   hx_sac_critic_grads   [soft_update of the target critics first on every 3rd call :278-279]; target y = r + (1-d) gamma
  *                         (min Q_target(s', a') + alpha H') :202-210; q1_loss, q2_loss :361-374 -> losses[0..1]; grad_critic

@@ -223,7 +223,8 @@ def test_resumed_run_continues_bit_identically(tmp_path, capsys, agent_args):
     from hirl4ucav_amd import train_all as T
 
     env_name = agent_args[-1]
-    common = agent_args + ["--random", "--seed", "3", "--num_envs", "256", "--buffer_size", "32768", "--checkpoint_rate", "2"]
+    common = agent_args + ["--random", "--seed", "3", "--num_envs", "256", "--buffer_size", "32768", "--checkpoint_rate", "2",
+                           "--separate_launches"]  # one env workgroup: the replay insert order, and with it the run, is reproducible
     T.MAX_STEP[env_name] = 48
     try:
         a = T.main(T.parser().parse_args(common + ["--episodes", "3", "--snapshot_every", "3", "--result_dir", str(tmp_path / "a")]))

@@ -371,7 +371,8 @@ def test_two_stream_issue_order_is_bit_identical_to_serial():
     import bench
 
     def run(serial):
-        args = argparse.Namespace(envs=256, batch=128, scenario="straight_line", agent="hirl", actions="policy", staged=False, overlap=not serial)
+        args = argparse.Namespace(envs=256, batch=128, scenario="straight_line", agent="hirl", actions="policy", staged=False, overlap=not serial,
+                                  separate_launches=True)  # one env workgroup: the replay insert order is fixed
         loop = bench.Loop(args, 0, 1, torch.device("cuda", 0))
         assert loop.pipe.overlap == (not serial)
         for _ in range(61):
@@ -387,3 +388,36 @@ def test_two_stream_issue_order_is_bit_identical_to_serial():
     assert not b[4] and a[3] == b[3] >= 61 * 200  # call 61 is an actor call: nothing of step 62 is in flight
     for x, y, name in zip(a[:3], b[:3], ("arena", "env state", "replay")):
         assert torch.equal(x.view(torch.int32), y.view(torch.int32)), name
+
+
+@pytest.mark.parametrize("n", [83, 4096, 8192 + 40])
+def test_act_step_in_one_launch_equals_act_then_step(eng_mod, n):
+    """hx_actor_act_step = hx_actor_act followed by hx_env_step, in the tail of the same kernel (16 or 32 envs per workgroup on
+    the lanes of one wave): actions, state words, observations, rewards, masks, statistics and the replay rows must be
+    identical — only the ORDER of the rows a step appends to the ring may differ (slots are handed out per workgroup)."""
+    from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    params = D.make_params(D.PARAM_SEED)
+    engs, envs, reps = [], [], []
+    for _ in range(2):
+        e = eng_mod.HirlEngine(batch=128)
+        e.load_params(params["actor"], params["critic"], params["bc_actor"])
+        rep = DeviceReplay(1 << 19)
+        env = BatchedHarfangEnv(n, scenario=np.arange(n) % 3, seed=3, max_step=9, auto_reset=True, random_reset=True, env_id0=100, replay=rep)
+        env.reset()
+        engs.append(e); envs.append(env); reps.append(rep)
+    acts = torch.zeros((n, 4), device="cuda")
+    for k in range(24):  # crosses the 9-step time limit twice: unstored steps, in-place resets
+        engs[0].act(envs[0].obs, sigma=0.3, seed=5, row0=100, out=acts)
+        envs[0].step(acts)
+        a2 = engs[1].act_step(envs[1], sigma=0.3, seed=5)[0]
+        assert torch.equal(acts, a2), f"actions, step {k}"
+        for name in ("state", "obs", "reward", "done", "success", "episode_ctr", "stats"):
+            x, y = getattr(envs[0], name), getattr(envs[1], name)
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), f"{name}, step {k}"
+    tot = int(reps[0].total.item())
+    assert tot == int(reps[1].total.item()) == n * 24 - n * 2 and tot <= reps[0].capacity
+    rows = [np.concatenate([r.ring[:tot].cpu().numpy(), r.success[:tot].cpu().numpy().astype(np.float32)[:, None]], 1) for r in reps]
+    rows = [x[np.lexsort(x.T[::-1])] for x in rows]
+    np.testing.assert_array_equal(rows[0].view(np.uint32), rows[1].view(np.uint32))

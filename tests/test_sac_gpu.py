@@ -108,3 +108,35 @@ def test_sac_learn_matches_oracle_and_reference(SE, golden_dir):
         off, n = SE.POLICY_BLOCK["g2"]
         assert torch.all(e.policy[off:off + n] == 1) and torch.all(e.policy[SE.POLICY_BLOCK["be2"][0]:SE.POLICY_BLOCK["be2"][0] + n] == 0)
     assert e.learning_steps == 8
+
+
+def test_sac_act_step_in_one_launch_equals_act_then_step(SE):
+    """hx_sac_act_step = hx_sac_act followed by hx_env_step (explore with given draws, with Philox, and exploit)."""
+    from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    params = sac_params()
+    n = 8192 + 17
+    engs, envs, reps = [], [], []
+    for _ in range(2):
+        e = SE.SacEngine(batch=128)
+        e.load_params(params["policy"], params["q1"], params["q2"])
+        rep = DeviceReplay(1 << 19)
+        env = BatchedHarfangEnv(n, scenario="serpentine", seed=1, max_step=7, auto_reset=True, random_reset=True, replay=rep)
+        env.reset()
+        engs.append(e); envs.append(env); reps.append(rep)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    acts = torch.zeros((n, 4), device="cuda")
+    for k in range(12):
+        kw = [{"explore": False}, {"eps": torch.randn((n, 4), device="cuda", generator=g)}, {"seed": 4}][k % 3]
+        engs[0].act(envs[0].obs, out=acts, **kw)
+        envs[0].step(acts)
+        a2 = engs[1].act_step(envs[1], **kw)[0]
+        assert torch.equal(acts, a2), f"actions, step {k}"
+        for name in ("state", "obs", "reward", "done", "success", "episode_ctr", "stats"):
+            assert torch.equal(getattr(envs[0], name).view(torch.uint8), getattr(envs[1], name).view(torch.uint8)), f"{name}, step {k}"
+    tot = int(reps[0].total.item())
+    assert tot == int(reps[1].total.item()) and 0 < tot <= reps[0].capacity
+    rows = [r.ring[:tot].cpu().numpy() for r in reps]
+    rows = [x[np.lexsort(x.T[::-1])] for x in rows]
+    np.testing.assert_array_equal(rows[0].view(np.uint32), rows[1].view(np.uint32))
