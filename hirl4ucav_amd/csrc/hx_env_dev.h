@@ -3,8 +3,8 @@
 // Shared by hx_env.hip (env_step_kernel & co) and hx_update.hip (the act + env step fused launch).
 //
 // Numerics: everything in here is compiled with floating-point contraction OFF, whatever the including translation unit uses:
-// state-evolving arithmetic is + - * / sqrt in a fixed order, so state words and masks are reproducible bit for bit against
-// oracle/env_oracle.c.  asinf/atan2f/acosf appear only in the observation.
+// state-evolving arithmetic is + - * / sqrt in a fixed order, so state words and masks are reproducible bit for bit on any
+// IEEE-754 fp32 implementation (the CPU restatement the tests check against).  asinf/atan2f/acosf appear only in the observation.
 #pragma once
 #include <hip/hip_runtime.h>
 
