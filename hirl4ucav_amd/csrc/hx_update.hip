@@ -616,6 +616,14 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     }
     __syncthreads();
     STAMP();
+    // ENV: the env lanes (wave 0) request their state words and current observation now — the head phase hides the round trip
+    hxenv::Env envE;
+    float envPrev[HX_OBS_DIM];
+    if (ENV && wave == 0 && lane < nrow) {
+        hxenv::load_env(envE, A.state, A.stride, r0, (uint32_t)lane);
+#pragma unroll
+        for (int j = 0; j < HX_OBS_DIM; ++j) envPrev[j] = A.o.ring ? A.obs[((size_t)r0 + lane) * HX_OBS_DIM + j] : 0.0f;
+    }
 #pragma unroll
     for (int t = 0; t < NRT; ++t) {  // head: wave w owns rows w, 16 + w
         const int lr = t * RT + wave;
@@ -666,15 +674,12 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             const bool active = e < nrow;
             const int64_t i = (int64_t)r0 + e;
             const bool insert = A.o.ring != nullptr;
-            Env E;
+            Env& E = envE;
             float4 act = {0.f, 0.f, 0.f, 0.f};
-            float prev[HX_OBS_DIM];
+            float (&prev)[HX_OBS_DIM] = envPrev;
             bool trunc = false, store = false;
             if (active) {
-                load_env(E, A.state, A.stride, r0, (uint32_t)e);
                 act = *reinterpret_cast<const float4*>(s_act + e * 4);
-#pragma unroll
-                for (int j = 0; j < HX_OBS_DIM; ++j) prev[j] = insert ? A.obs[i * HX_OBS_DIM + j] : 0.0f;
                 uint32_t ep = E.counters & 0xFFFFu;
                 ep = ep < 65535u ? ep + 1u : ep;
                 trunc = A.o.max_step > 0 && (int)ep >= A.o.max_step;  // train_all.py:346-347
