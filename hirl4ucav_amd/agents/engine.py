@@ -115,7 +115,6 @@ class HirlEngine:
         self.soft_count, self._idx, self._idx_bc = sc.view(torch.int32), ix.view(torch.int32), ixb.view(torch.int32)
         self.losses, self.wstate, self._noise = self.losses[:8], self.wstate[:1], self._noise[:4]
         self.soft_count = self.soft_count[:1]
-        self._act_ws = None
         self.sample_calls = 0
         self.nets = HxNets(*(t.data_ptr() for t in (self.actor, self.critic, self.target_actor, self.target_critic, self.bc_actor,
                                                      self.grad_actor, self.grad_critic, self.m_actor, self.v_actor, self.m_critic,
@@ -151,8 +150,6 @@ class HirlEngine:
         noise: None and sigma == 0 -> NoNoise; tensor [4] -> one shared draw; tensor [N, 4] -> per row; sigma > 0 and
         noise None -> Philox N(0, sigma^2) per row and component."""
         n = obs.shape[0]
-        if self._act_ws is None or self._act_ws.numel() < n * H2:
-            self._act_ws = torch.empty(n * H2, dtype=torch.float32, device=self.device)
         if out is None:
             out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         mode = 0
@@ -162,7 +159,7 @@ class HirlEngine:
             mode = 3
         self.act_calls += 1
         _lib.call("hx_actor_act", (net if net is not None else self.actor).data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode,
-                  _lib.ptr(noise), float(sigma), int(seed), int(row0), self.act_calls, self.slope, self._act_ws.data_ptr(),
+                  _lib.ptr(noise), float(sigma), int(seed), int(row0), self.act_calls, self.slope, None,
                   _lib.stream_ptr())
         return out
 

@@ -101,7 +101,7 @@ class SacEngine:
         self.learning_steps = 0
         self.group = group
         self.world = torch.distributed.get_world_size(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
-        self._act_ws, self.act_calls, self.sample_calls = None, 0, 0
+        self.act_calls, self.sample_calls = 0, 0
 
     def load_params(self, policy, q1, q2, hard_update_target=True):
         self.policy.copy_(pack_mlp(policy, POLICY_BLOCK, POLICY_SIZE, 13, 8, self.device))
@@ -138,14 +138,12 @@ class SacEngine:
     def act(self, obs, eps=None, explore=True, seed=0, row0=0, out=None):
         """explore (agent.py:183-188): sampled tanh-Gaussian action (eps [N, 4] given, else Philox); exploit (:191-196): tanh(mean)."""
         n = obs.shape[0]
-        if self._act_ws is None or self._act_ws.numel() < n * H2:
-            self._act_ws = torch.empty(n * H2, dtype=torch.float32, device=self.device)
         if out is None:
             out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         mode = 0 if not explore else (1 if eps is not None else 2)
         self.act_calls += 1
         _lib.call("hx_sac_act", self.policy.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode, _lib.ptr(eps), int(seed), int(row0),
-                  self.act_calls, self._act_ws.data_ptr(), _lib.stream_ptr())
+                  self.act_calls, None, _lib.stream_ptr())
         return out
 
     def act_step(self, env, eps=None, explore=True, seed=0, out=None):

@@ -1828,11 +1828,11 @@ int hx_debug_stamps(float* host_out) {
 int hx_actor_param_count(void) { return kActor.size(); }
 int hx_critic_param_count(void) { return 2 * kQ.padded(); }
 int64_t hx_hirl_workspace_floats(int32_t batch) { return (int64_t)S_COUNT * kSlotFloats * batch + 64; }
-int64_t hx_act_workspace_floats(int64_t rows) { return rows * (int64_t)H2; }
+int64_t hx_act_workspace_floats(int64_t rows) { (void)rows; return 0; }  // the acting kernels keep z2 in LDS: no workspace any more
 
 /* chooseAction / chooseActionSmallNoise / chooseActionNoNoise for `rows` observations (HIRL.py:192-212):
  * actions = clamp(actor(obs) + noise, -1, 1).  noise_mode 0: none, 1: noise[4] shared by all rows, 2: noise[rows][4],
- * 3: N(0, sigma^2) per row and component from Philox(seed; row0 + row, call).  ws: hx_act_workspace_floats(rows). */
+ * 3: N(0, sigma^2) per row and component from Philox(seed; row0 + row, call).  ws: unused since the whole policy runs in one kernel (may be NULL). */
 int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* actions, int32_t noise_mode, const float* noise,
                  float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* ws, void* stream) {
     HX_REQUIRE(actor && obs && actions && rows > 0, "hx_actor_act: bad arguments");
@@ -2174,7 +2174,7 @@ static void sac_slots(const HxSacNets* N, int B, Slot* s) {
 }
 
 /* SacAgent.explore / exploit (SAC/agent.py:183-196) for `rows` observations.  mode 0: exploit = tanh(mean); 1: sample with the
- * standard-normal draws eps[rows][4]; 2: sample with Philox(seed; row0 + row, call).  ws: hx_act_workspace_floats(rows). */
+ * standard-normal draws eps[rows][4]; 2: sample with Philox(seed; row0 + row, call).  ws: unused since the whole policy runs in one kernel (may be NULL). */
 int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps, uint64_t seed,
                uint32_t row0, uint32_t call, float* ws, void* stream) {
     HX_REQUIRE(policy && obs && actions && rows > 0 && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act: bad arguments");

@@ -122,13 +122,13 @@ int hx_debug_stamps(float* host_out /* host, 64 floats */); /* diagnostic builds
 int hx_actor_param_count(void);
 int hx_critic_param_count(void);
 int64_t hx_hirl_workspace_floats(int32_t batch);
-int64_t hx_act_workspace_floats(int64_t rows);
+int64_t hx_act_workspace_floats(int64_t rows); /* 0: the acting kernels need no workspace any more; their `ws` argument may be NULL */
 
 /* Agent.chooseAction / chooseActionSmallNoise / chooseActionNoNoise for `rows` observations at once
  * (hirl/agents/HIRL.py:192-212): actions = clamp(actor(obs) + noise, -1, 1).
  * noise_mode 0: none (NoNoise); 1: noise[4] shared by all rows (the reference's one draw per call); 2: noise[rows][4];
  * 3: N(0, sigma^2) per row and component from Philox4x32-10(key = seed; counter = (row0 + row, call)).
- * slope: 0 = ReLU nets (HIRL.py), 0.01 = LeakyReLU nets (TD3.py / BC.py).  ws: hx_act_workspace_floats(rows). */
+ * slope: 0 = ReLU nets (HIRL.py), 0.01 = LeakyReLU nets (TD3.py / BC.py).  ws: unused (may be NULL). */
 int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
                  const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* ws,
                  void* stream);
@@ -237,7 +237,7 @@ typedef struct HxSacBatch {
 int hx_sac_policy_param_count(void);
 int64_t hx_sac_workspace_floats(int32_t batch);
 /* SacAgent.explore / exploit (SAC/agent.py:183-196): mode 0 exploit = tanh(mean); 1 sample with eps[rows][4]; 2 sample with
- * Philox4x32-10(seed; row0 + row, call).  ws: hx_act_workspace_floats(rows). */
+ * Philox4x32-10(seed; row0 + row, call).  ws: unused (may be NULL). */
 int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps,
                uint64_t seed, uint32_t row0, uint32_t call, float* ws, void* stream);
 /* SacAgent.explore / exploit + HarfangEnv.step in one launch (train_sac.py:238-241). */
