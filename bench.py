@@ -162,14 +162,14 @@ class Loop:
         self.pipe = VectorStepPipeline(device, overlap=(getattr(args, "overlap", False) or (world > 1 and not getattr(args, "serial", False))) and not self.sac)
         self.record, self.rec, self.pool = False, {"act": [], "env": [], "act+env": [], "learn": []}, []
         self.separate = getattr(args, "separate_launches", False)
-        self.kpool, self.krec = [], []
+        self.kpool, self.krec, self.act_env_calls = [], [], 0
 
     def _timed(self, name, fn):
         """Bracket fn() with HIP events on the stream it launches on (the current one) while recording is on."""
         if not self.record:
             return fn()
-        if not self.pool:  # event creation is slow enough to stall the issue thread: make them outside the timed region
-            raise RuntimeError("event pool exhausted")
+        if len(self.pool) < 2:  # events are made outside the timed region (creation stalls the issue thread); none left: untimed
+            return fn()
         a, b = self.pool.pop(), self.pool.pop()
         a.record()
         fn()
@@ -180,7 +180,8 @@ class Loop:
         e, env = self.eng, self.env
         # The env kernel's own duration (what rocprofv3 reports) is sampled on every 8th recorded step: there the two stages go
         # out as separate launches, act then a STAMPED env step (a stamped launch costs ~9 us extra, hence not on every step).
-        stamped = self.record and self.kpool and self.t % 8 == 0
+        self.act_env_calls += 1  # (not self.t: with two streams this function runs one step ahead, always on odd t)
+        stamped = self.record and len(self.kpool) >= 2 and self.act_env_calls % 8 == 0
         if self.uniform or self.separate or stamped:
             if self.uniform:  # env.action_space.sample() for every env (train_all.py:272)
                 self._timed("act", lambda: self.actions.uniform_(-1.0, 1.0))
@@ -345,6 +346,12 @@ def main():
         tt = torch.tensor([dt], device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+    if not loop.krec:  # a run too short to contain a sampled step: take the samples right after the timed region instead
+        loop.record, loop.separate = True, True
+        for _ in range(16):
+            loop.act_env_calls = 7
+            loop.step()
+        torch.cuda.synchronize()
     med = {k: (float(np.median([a.elapsed_time(b) * 1e3 for a, b in v])) if v else None) for k, v in loop.rec.items()}
     act_us, env_us, learn_us = med["act"], med["env"], med["learn"]
     kern = []
@@ -368,8 +375,9 @@ def main():
                    "parallelism": f"dp{world}: env shards + replicated nets, RCCL all-reduce of the flat gradients"},
         "update_steps_per_s": round(args.steps / dt, 1),
         "stage_us": {"act+env_step(1 kernel)": None if med["act+env"] is None else round(med["act+env"], 2),
-                     "act(own launch, sampled steps)": round(act_us, 2), "env_step(own launch, sampled steps)": round(env_us, 2),
-                     "sample+learn(6-11 kernels)": round(learn_us, 2)},
+                     "act(own launch, sampled steps)": None if act_us is None else round(act_us, 2),
+                     "env_step(own launch, sampled steps)": None if env_us is None else round(env_us, 2),
+                     "sample+learn(6-11 kernels)": None if learn_us is None else round(learn_us, 2)},
     }
     # roofline of the env-step kernel (the kernel the metric counts): algorithmic bytes / live-measured launch time
     res["roofline"] = {"kernel": "env_step_kernel<INSERT>", "bound": "hbm", "achieved": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3, 1),
