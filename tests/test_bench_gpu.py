@@ -1,0 +1,54 @@
+"""bench.py end to end on a GPU box: the single-GPU line and the N > 1 launch form the driver uses (two ranks sharing one GPU over
+gloo — HX_BENCH_BACKEND exists for exactly this), checked against the JSON contract."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline")
+
+
+def run(cmd, env=None):
+    p = subprocess.run(cmd, cwd=ROOT, env={**os.environ, **(env or {})}, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def check(d, n_gpus, steps, warmup):
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 4096 * n_gpus * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launches_timed"] > 0 and (r["traffic"] is None or r["traffic"] > 0)
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_bench_single_gpu_line():
+    d = run([sys.executable, "bench.py", "--steps", "120", "--warmup", "20", "--cpu-seconds", "1"])
+    check(d, 1, 120, 20)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.parametrize("extra", [[], ["--serial"], ["--agent", "sac", "--scenario", "serpentine"]])
+def test_bench_two_ranks_launch_form(extra):
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ..."""
+    port = str(29600 + (os.getpid() + len(extra)) % 300)
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+             "bench.py", "--gpus", "2", "--steps", "60", "--warmup", "10", "--no-cpu-baseline"] + extra, env={"HX_BENCH_BACKEND": "gloo"})
+    check(d, 2, 60, 10)
+    assert d["allreduce"] and all(a["median_us"] > 0 for a in d["allreduce"])
+    assert d["env_stats"]["env_steps"] > 0
