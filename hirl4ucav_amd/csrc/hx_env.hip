@@ -220,6 +220,43 @@ __global__ __launch_bounds__(kBlock) void env_rearm_kernel(float* state, int64_t
     state[35 * stride + i] = __uint_as_float(f);
 }
 
+// ---- simulator-level access (the wire-protocol server of environments/wire.py): what the external simulator does between the
+// client's SET_PLANE_* / FIRE_MISSILE calls and its GET_* read-backs (dogfight_client.py), without the wrapper's latches ----
+__global__ __launch_bounds__(kBlock) void sim_tick_kernel(float* state, int64_t n, int64_t stride, const float* __restrict__ ally_cmd,
+                                                          const float* __restrict__ opp_cmd, const uint8_t* __restrict__ fire) {
+    const int64_t i0 = (int64_t)blockIdx.x * kBlock;
+    const int64_t i = i0 + threadIdx.x;
+    if (i >= n) return;
+    Env E;
+    load_env(E, state, stride, i0, threadIdx.x);
+    sim_core(E, ally_cmd[i * 3], ally_cmd[i * 3 + 1], ally_cmd[i * 3 + 2], opp_cmd[i * 3], opp_cmd[i * 3 + 1], opp_cmd[i * 3 + 2], fire[i] != 0);
+    store_env(E, state, stride, i0, threadIdx.x);
+}
+
+// out[i][16]: ally position 3, ally Euler (pitch, heading, roll) 3, opponent position 3, opponent Euler 3, target angle in degrees,
+// opponent health, target_locked (0/1), missile slot 0 loaded (0/1)
+__global__ __launch_bounds__(kBlock) void sim_readback_kernel(const float* state, int64_t n, int64_t stride, float* __restrict__ out) {
+    const int64_t i0 = (int64_t)blockIdx.x * kBlock;
+    const int64_t i = i0 + threadIdx.x;
+    if (i >= n) return;
+    Env E;
+    load_env(E, state, stride, i0, threadIdx.x);
+    Observed O;
+    observe(E, O);
+    float* o = out + i * 16;
+    o[0] = E.ally.p.x; o[1] = E.ally.p.y; o[2] = E.ally.p.z;
+    float p, h, r;
+    euler_of(E.ally, p, h, r);
+    o[3] = p; o[4] = h; o[5] = r;
+    o[6] = E.opp.p.x; o[7] = E.opp.p.y; o[8] = E.opp.p.z;
+    euler_of(E.opp, p, h, r);
+    o[9] = p; o[10] = h; o[11] = r;
+    o[12] = O.target_angle * 180.0f;
+    o[13] = E.health;
+    o[14] = E.lock_timer >= kLockDelay ? 1.0f : 0.0f;
+    o[15] = (E.flags & HX_F_SIM_SLOT) ? 1.0f : 0.0f;
+}
+
 // get_reward / get_termination  HarfangEnv_GYM.py:299-336
 __global__ __launch_bounds__(kBlock) void label_kernel(const float* __restrict__ s, const float* __restrict__ a,
                                                        const float* __restrict__ ns, int64_t n, float* reward,
@@ -295,6 +332,20 @@ int hx_env_rearm(float* state, int64_t n, int64_t stride, const uint8_t* mask, v
     HX_REQUIRE(state && n > 0 && stride >= n, "hx_env_rearm: bad state/n/stride");
     hipLaunchKernelGGL(env_rearm_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, state, n, stride, mask);
     HX_CHECK_LAUNCH("hx_env_rearm");
+    return 0;
+}
+
+int hx_sim_tick(float* state, int64_t n, int64_t stride, const float* ally_cmd, const float* opp_cmd, const uint8_t* fire, void* stream) {
+    HX_REQUIRE(state && ally_cmd && opp_cmd && fire && n > 0 && stride >= n, "hx_sim_tick: bad arguments");
+    hipLaunchKernelGGL(sim_tick_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, state, n, stride, ally_cmd, opp_cmd, fire);
+    HX_CHECK_LAUNCH("hx_sim_tick");
+    return 0;
+}
+
+int hx_sim_readback(const float* state, int64_t n, int64_t stride, float* out, void* stream) {
+    HX_REQUIRE(state && out && n > 0 && stride >= n, "hx_sim_readback: bad arguments");
+    hipLaunchKernelGGL(sim_readback_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, state, n, stride, out);
+    HX_CHECK_LAUNCH("hx_sim_readback");
     return 0;
 }
 

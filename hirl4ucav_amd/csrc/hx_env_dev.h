@@ -275,10 +275,9 @@ __device__ __forceinline__ void observe(const Env& E, Observed& O) {
     O.altitude = E.ally.p.y;
 }
 
-// E4 + E10/E11 + E5: apply the action, script the opponent, one simulator tick
-__device__ __forceinline__ void sim_step(Env& E, float a0, float a1, float a2, bool fire) {
-    // scripted opponent  HarfangEnv_GYM.py:145-147 / :342-353 / :412-421
-    float op = 0.0f, orl = 0.0f, oy = 0.0f;
+// E10/E11: the scripted opponent's commanded levels for this tick  HarfangEnv_GYM.py:145-147 / :342-353 / :412-421
+__device__ __forceinline__ void script_opponent(Env& E, float& op, float& orl, float& oy) {
+    op = 0.0f; orl = 0.0f; oy = 0.0f;
     {
         uint32_t script = E.counters >> 16;
         const uint32_t scen = (E.flags >> HX_F_SCEN_SHIFT) & 3u;
@@ -298,7 +297,11 @@ __device__ __forceinline__ void sim_step(Env& E, float a0, float a1, float a2, b
         }
         E.counters = (E.counters & 0xFFFFu) | (script << 16);
     }
-    E.flags = fire ? (E.flags | HX_F_FIRED) : (E.flags & ~HX_F_FIRED);  // now_missile_state :150-156
+}
+
+// E5: one simulator tick with the commanded levels of BOTH aircraft given (what UPDATE_SCENE does after the SET_PLANE_* / FIRE_MISSILE
+// calls of the wire protocol, dogfight_client.py): missile launch, two aircraft ticks, missile flight / hit, targeting device
+__device__ __forceinline__ void sim_core(Env& E, float a0, float a1, float a2, float op, float orl, float oy, bool fire) {
     // FIRE_MISSILE is handled before the tick, with the lock the simulator holds at that moment
     if (fire && (E.flags & HX_F_SIM_SLOT)) {
         const Axes A = quat_axes(E.ally.qw, E.ally.qx, E.ally.qy, E.ally.qz);
@@ -345,6 +348,14 @@ __device__ __forceinline__ void sim_step(Env& E, float a0, float a1, float a2, b
         const bool in_cone = (cosang > kCosLock) && (dist > kLockMin) && (dist < kLockMax);
         E.lock_timer = in_cone ? E.lock_timer + kDt : 0.0f;
     }
+}
+
+// E4 + E10/E11 + E5: apply the action, script the opponent, one simulator tick
+__device__ __forceinline__ void sim_step(Env& E, float a0, float a1, float a2, bool fire) {
+    float op, orl, oy;
+    script_opponent(E, op, orl, oy);
+    E.flags = fire ? (E.flags | HX_F_FIRED) : (E.flags & ~HX_F_FIRED);  // now_missile_state :150-156
+    sim_core(E, a0, a1, a2, op, orl, oy, fire);
 }
 
 // E6 latches + E7 reward + E8 termination on the post-tick state

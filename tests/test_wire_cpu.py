@@ -1,0 +1,91 @@
+"""The wire-protocol server (hirl4ucav_amd/environments/wire.py) on CPU: framing and command handling against a raw client, and —
+in the development container, where /root/reference exists — the UNMODIFIED reference client and wrapper
+(hirl/environments/dogfight_client.py + socket_lib.py + HarfangEnv_GYM.py) driving the server over loopback TCP, replaying the
+closed-loop golden traces (which were recorded from the same reference classes over an in-process fake of dogfight_client)."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from hirl4ucav_amd.environments import wire
+from tests._wire_backend import ALLY, OPPO, OracleSimBackend, RawClient
+
+REF = "/root/reference"
+
+
+def test_framing_and_commands_with_a_raw_client():
+    srv = wire.WireServer(OracleSimBackend()).start()
+    try:
+        c = RawClient(srv.port)
+        assert c.ask("GET_PLANESLIST")[0] == ALLY and c.ask("GET_PLANESLIST")[3] == OPPO
+        for cmd in ("DISABLE_LOG", "RETRACT_GEAR"):
+            c.send(cmd, plane_id=ALLY)                                  # unanswered commands must not produce a reply
+        c.send("SET_RENDERLESS_MODE", flag=True)
+        # the reset sequence of HarfangEnv._reset_machine / _reset_missile (HarfangEnv_GYM.py:171-188)
+        c.send("RESET_MACHINE", machine_id=OPPO); c.send("RESET_MACHINE", machine_id=ALLY)
+        c.send("SET_HEALTH", machine_id=OPPO, health_level=0.2)
+        c.send("RESET_MACHINE_MATRIX", machine_id=OPPO, position=[0, 4200, 0], rotation=[0, 0, 0])
+        c.send("RESET_MACHINE_MATRIX", machine_id=ALLY, position=[10, 3500, -4000], rotation=[0, 0, 0])
+        c.send("SET_PLANE_THRUST", plane_id=ALLY, thrust_level=1); c.send("SET_PLANE_THRUST", plane_id=OPPO, thrust_level=0.6)
+        c.send("SET_PLANE_LINEAR_SPEED", plane_id=ALLY, linear_speed=300); c.send("SET_PLANE_LINEAR_SPEED", plane_id=OPPO, linear_speed=200)
+        c.send("REARM_MACHINE", machine_id=ALLY)
+        st = c.ask("GET_PLANE_STATE", plane_id=ALLY)
+        assert st["position"] == [10.0, 3500.0, -4000.0] and st["Euler_angles"] == [0.0, 0.0, 0.0] and st["target_locked"] is False
+        assert abs(st["target_angle"] - np.degrees(np.arccos(4000 / np.sqrt(10 ** 2 + 700 ** 2 + 4000 ** 2)))) < 1e-3
+        assert c.ask("GET_HEALTH", machine_id=OPPO) == {"health_level": pytest.approx(0.2)}
+        assert c.ask("GET_MISSILESDEVICE_SLOTS_STATE", machine_id=ALLY) == {"missiles_slots": [True]}
+        z0 = st["position"][2]
+        c.send("SET_PLANE_PITCH", plane_id=ALLY, pitch_level=-0.3); c.send("FIRE_MISSILE", machine_id=ALLY, slot_id=0)
+        c.send("UPDATE_SCENE")
+        st = c.ask("GET_PLANE_STATE", plane_id=ALLY)
+        assert 4.5 < st["position"][2] - z0 < 5.5 and st["user_pitch_level"] == -0.3      # 300 m/s for 1/60 s
+        assert c.ask("GET_MISSILESDEVICE_SLOTS_STATE", machine_id=ALLY) == {"missiles_slots": [False]}
+        assert c.ask("IS_IA_ACTIVATED", machine_id=ALLY) == {}                              # answered, even if nothing to say
+        c.close()
+    finally:
+        srv.close()
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "hirl")), reason="needs the reference checkout (development container only)")
+@pytest.mark.parametrize("cls,tag", [("HarfangEnv", "straight_line"), ("HarfangSerpentineEnv", "serpentine"), ("HarfangCircularEnv", "circular")])
+def test_unmodified_reference_client_drives_the_server(cls, tag, golden_dir, monkeypatch):
+    import socket
+
+    class _Box:  # the reference imports gym only for spaces.Box(...).sample (HarfangEnv_GYM.py:3,14)
+        def __init__(self, low, high, dtype=np.float64):
+            self.low, self.high, self.dtype = np.asarray(low), np.asarray(high), dtype
+
+        def sample(self):
+            return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+    gym = types.ModuleType("gym")
+    gym.spaces = types.ModuleType("gym.spaces")
+    gym.spaces.Box = _Box
+    monkeypatch.setitem(sys.modules, "gym", gym)
+    monkeypatch.setitem(sys.modules, "gym.spaces", gym.spaces)
+    monkeypatch.syspath_prepend(REF)
+    monkeypatch.setattr(socket, "gethostbyname", lambda h: "127.0.0.1")  # socket_lib.py:5-6 resolves the container's hostname at import
+    for m in [k for k in sys.modules if k == "hirl" or k.startswith("hirl.")]:
+        monkeypatch.delitem(sys.modules, m)
+    import hirl.environments.dogfight_client as df
+    import hirl.environments.HarfangEnv_GYM as ref_env
+
+    g = np.load(os.path.join(golden_dir, f"env_closedloop_{tag}.npz"))
+    srv = wire.WireServer(OracleSimBackend()).start()
+    try:
+        df.connect("127.0.0.1", srv.port)
+        df.disable_log(); df.set_renderless_mode(True); df.set_client_update_mode(True)   # train_all.py:149-152
+        env = getattr(ref_env, cls)()
+        obs = env.reset()
+        np.testing.assert_array_equal(np.asarray(obs, np.float64), g["obs0"])
+        n = 150  # ~11 messages per step over loopback; the reference's socket has no TCP_NODELAY, so a step takes tens of ms
+        for t in range(n):
+            obs, r, d, _, s = env.step(g["actions"][t])
+            np.testing.assert_array_equal(np.asarray(obs, np.float64), g["obs"][t], err_msg=f"obs, step {t}")
+            assert float(r) == g["reward"][t] and bool(d) == bool(g["done"][t]) and int(s) == int(g["success"][t]), t
+        assert srv.messages > 10 * n
+        df.disconnect()
+    finally:
+        srv.close()
