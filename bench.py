@@ -405,6 +405,11 @@ def main():
     res["roofline_act"] = {"kernels": "act_fused_kernel", "bound": "mfma", "unit": "TFLOP/s",
                            "achieved": round(ACTOR_FLOP * args.envs / act_us / 1e6, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
                            "frac": round(ACTOR_FLOP * args.envs / act_us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 5), "us": round(act_us, 2)}
+    if world > 1:  # the replicas must still be bit-identical after K sharded updates
+        mine = torch.tensor([loop.eng.replica_checksum()], dtype=torch.int64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        res["replicas_identical"] = bool(all(int(c.item()) == int(mine.item()) for c in every))
     if ar_events:  # SURVEY.md 8d "collective bytes": per message size, median us and bus bandwidth 2 (n-1)/n * bytes / t
         by = {}
         for nbytes, a, b in ar_events:

@@ -139,6 +139,12 @@ class HirlEngine:
             self.target_actor.copy_(self.actor)
             self.target_critic.copy_(self.critic)
 
+    def replica_checksum(self):
+        """int64 sum of the bit patterns of every network and Adam moment: equal on all ranks of a sharded run, or the replicas have
+        diverged (Adam and Polyak see identical inputs on every rank).  Synchronises."""
+        t = torch.cat([self.actor, self.target_actor, self.critic, self.target_critic, self.m_actor, self.v_actor, self.m_critic, self.v_critic])
+        return int(t.view(torch.int32).to(torch.int64).sum().item())
+
     def state_dicts(self):
         return {"actor": unpack(self.actor, ACTOR_LAYOUT), "critic": unpack(self.critic, CRITIC_LAYOUT),
                 "targetActor": unpack(self.target_actor, ACTOR_LAYOUT), "targetCritic": unpack(self.target_critic, CRITIC_LAYOUT),

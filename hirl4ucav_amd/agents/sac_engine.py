@@ -110,6 +110,11 @@ class SacEngine:
         if hard_update_target:  # hard_update(critic_target, critic), agent.py:92
             self.target_critic.copy_(self.critic)
 
+    def replica_checksum(self):
+        """int64 sum of the bit patterns of the networks, Adam moments and log-alpha state: equal on all ranks of a sharded run."""
+        t = torch.cat([self.policy, self.critic, self.target_critic, self.m_policy, self.v_policy, self.m_critic, self.v_critic, self.alpha_state])
+        return int(t.view(torch.int32).to(torch.int64).sum().item())
+
     def state_dicts(self):
         return {"policy": unpack_mlp(self.policy, POLICY_BLOCK, 13, 8), "q1": unpack_mlp(self.critic[:Q_SIZE], Q_BLOCK, 17, 1),
                 "q2": unpack_mlp(self.critic[Q_SIZE:], Q_BLOCK, 17, 1), "q1_target": unpack_mlp(self.target_critic[:Q_SIZE], Q_BLOCK, 17, 1),

@@ -258,6 +258,12 @@ def main(config):
                 high_score, success_rate = max(high_score, mean), max(success_rate, succ / 50)
             print(f"Validation {arttir}: avg reward {mean:.2f} (std {std:.2f}) success {succ / 50:.2f} fire success {fire / 50:.2f}", flush=True)
             arttir += 1
+        if world > 1 and (episode + 1) % checkpoint_rate == 0:  # sharded run: the replicas must not have drifted apart
+            mine = torch.tensor([eng.replica_checksum()], dtype=torch.int64, device=device)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(every, mine)
+            if any(int(c.item()) != int(mine.item()) for c in every):
+                raise RuntimeError(f"rank {rank}: network replicas diverged at episode {episode + 1}")
         if config.snapshot_every and (episode + 1) % config.snapshot_every == 0:  # whole-run state for --resume (one file per rank)
             CK.save_run(os.path.join(log_dir, f"state_rank{rank}.pt"), eng, env, replay,
                         {"episode": episode + 1, "expert_num": expert_num, "high_score": high_score, "success_rate": success_rate, "arttir": arttir})

@@ -52,3 +52,4 @@ def test_bench_two_ranks_launch_form(extra):
     check(d, 2, 60, 10)
     assert d["allreduce"] and all(a["median_us"] > 0 for a in d["allreduce"])
     assert d["env_stats"]["env_steps"] > 0
+    assert d["replicas_identical"] is True  # 70 sharded updates later every rank holds the same networks and Adam moments, bit for bit
