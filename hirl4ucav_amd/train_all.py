@@ -156,12 +156,14 @@ def train_bc(config, device, seed, max_step):
 def main(config):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        # RCCL over xGMI; HX_DIST_BACKEND=gloo exists only to exercise this path where all ranks share one GPU (tests)
+        backend = os.environ.get("HX_DIST_BACKEND", "nccl")
+        torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
     if config.seed is not None:
         set_seed(config.seed + rank)
     seed = config.seed or 0

@@ -53,3 +53,21 @@ def test_bench_two_ranks_launch_form(extra):
     assert d["allreduce"] and all(a["median_us"] > 0 for a in d["allreduce"])
     assert d["env_stats"]["env_steps"] > 0
     assert d["replicas_identical"] is True  # 70 sharded updates later every rank holds the same networks and Adam moments, bit for bit
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.parametrize("agent", [["--agent", "HIRL", "--type", "soft", "--env", "straight_line"], ["--agent", "SAC", "--type", "SAC", "--env", "serpentine"]])
+def test_driver_two_ranks(agent, tmp_path):
+    """python -m torch.distributed.run --nproc-per-node 2 -m hirl4ucav_amd.train_all ...: env shards, all-reduced gradients, the replica
+    check at the validation episode, checkpoints from rank 0 only."""
+    port = str(29300 + os.getpid() % 300)
+    code = ("import sys; from hirl4ucav_amd import train_all as T; T.MAX_STEP['straight_line'] = T.MAX_STEP['serpentine'] = 40; "
+            "T.main(T.parser().parse_args(sys.argv[1:]))")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", port, "--no-python", sys.executable, "-c", code] + agent +
+                       ["--random", "--seed", "1", "--num_envs", "512", "--episodes", "2", "--checkpoint_rate", "2", "--snapshot_every", "0",
+                        "--buffer_size", "65536", "--result_dir", str(tmp_path)],
+                       cwd=ROOT, env={**os.environ, "HX_DIST_BACKEND": "gloo"}, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "Episode 2:" in p.stdout and "Validation 1:" in p.stdout and "diverged" not in p.stderr
+    assert p.stdout.count("Episode 2:") == 1  # rank 0 reports
