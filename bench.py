@@ -54,11 +54,11 @@ def parse():
     p.add_argument("--actions", default="policy", choices=["policy", "uniform"],
                    help="uniform: U(-1,1)^4 actions instead of the live actor (SURVEY.md 8d C2's second run, decoupled from the policy)")
     p.add_argument("--overlap", action="store_true",
-                   help="issue the next act + env.step on a second stream beside critic-only learns (bit-identical results). On one "
-                        "GPU it does not pay (145 vs 143 us/step: the kernels contend for the same CUs/LDS), so the default there is the "
-                        "reference's strict act -> step -> sample -> learn order; with N > 1 it is ON by default, because there the side "
-                        "stream fills the time the main stream spends waiting in the gradient all-reduce")
-    p.add_argument("--serial", action="store_true", help="force the one-stream order at N > 1 too")
+                   help="issue the next act + env.step on a second stream beside critic-only learns (bit-identical results); in the sharded "
+                        "path the side stream is released at the gradient all-reduce. Measured on one GPU it does not pay — 107.8 vs 100.1 "
+                        "us/step one-call, 117.5 vs 100.1 staged: every cross-stream event hand-off costs ~10 us on this runtime — so the "
+                        "default, at any N, is the reference's strict act -> step -> sample -> learn order on one stream")
+    p.add_argument("--serial", action="store_true", help="(default) one stream")
     p.add_argument("--separate-launches", dest="separate_launches", action="store_true",
                    help="act and env step as two launches on every step (default: one fused launch, hx_actor_act_step)")
     p.add_argument("--staged", action="store_true",
@@ -159,7 +159,7 @@ class Loop:
         self.t = 0
         self.actions = torch.zeros((n, 4), device=device)
         from hirl4ucav_amd.utils.pipeline import VectorStepPipeline
-        self.pipe = VectorStepPipeline(device, overlap=(getattr(args, "overlap", False) or (world > 1 and not getattr(args, "serial", False))) and not self.sac)
+        self.pipe = VectorStepPipeline(device, overlap=getattr(args, "overlap", False) and not getattr(args, "serial", False) and not self.sac)
         self.record, self.rec, self.pool = False, {"act": [], "env": [], "act+env": [], "learn": []}, []
         self.separate = getattr(args, "separate_launches", False)
         self.kpool, self.krec, self.act_env_calls = [], [], 0
@@ -208,7 +208,7 @@ class Loop:
             return
         e.sample(self.replay, self.expert, self.bc_table, n_main=e.batch - self.expert_num, seed=2 + self.rank)
         # a critic-only learn() leaves the acting network alone: the next act + env.step go out on the side stream now
-        self.pipe.prefetch(self._act_env, acting_net_untouched=not e.actor_trainable)
+        self.pipe.arm(self._act_env, acting_net_untouched=not e.actor_trainable)
         # soft weight: estimated at the start of every max_step-long "episode" of vector steps, kept in between
         # (the reference re-estimates at most once per episode)
         kind = getattr(self.args, "type", "soft")
@@ -218,7 +218,10 @@ class Loop:
             w = max(self.args.bc_weight - (self.t // self.max_step) / 5000.0, 0.0)
         else:
             w = self.args.bc_weight
-        e.learn(bc_weight_now=w, bc_warm_up_weight=0.0)
+        # sharded path: the side stream is released at the gradient all-reduce; one-call path: right away
+        if not e.staged:
+            self.pipe.fire()
+        e.learn(bc_weight_now=w, bc_warm_up_weight=0.0, before_exchange=self.pipe.fire)
 
     def step(self):
         self.pipe.act_and_step(self._act_env)

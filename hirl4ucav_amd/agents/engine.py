@@ -213,11 +213,12 @@ class HirlEngine:
                   self._noise.data_ptr(), self.rows.data_ptr(), self.bc_rows.data_ptr() if bc_table is not None else None, _lib.stream_ptr())
         return self._idx, self._idx_bc, self._noise
 
-    def learn(self, noise=None, bc_weight_now=0.0, bc_warm_up_weight=0.0):
+    def learn(self, noise=None, bc_weight_now=0.0, bc_warm_up_weight=0.0, before_exchange=None):
         """One Agent.learn (HIRL.py:221-334 / TD3.py:201-260) on the minibatch last assembled by sample() / assemble().
         noise: the (4,) target-smoothing draw (default: the one sample() drew).  bc_weight_now: 100 = estimate the soft
         weight now (HIRL.py:299), None = keep the stored device value, else the given weight.  Enqueues only; read the
-        results with losses_host()."""
+        results with losses_host().  before_exchange: called once, right before the first gradient all-reduce of the sharded path
+        (utils/pipeline.py releases its side stream there)."""
         B = self.batch
         st = _lib.stream_ptr()
         noise = self._noise if noise is None else noise
@@ -241,6 +242,8 @@ class HirlEngine:
         else:  # sharded: the same stages with the three exchanges of SURVEY.md 8e in between
             gs = 1.0 / self.world
             _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, (2 if w_kind == 1 else 1) if actor_phase else 0, st)
+            if before_exchange is not None:
+                before_exchange()
             self._allreduce(self.grad_critic)
             pk = 16 if do_polyak else 0  # + 16: soft_update of the target in the same launch (nothing reads it in between)
             _lib.call("hx_adam", nets, hyper, 0 | pk, self.critic_step, gs, 0, 0.0, 0.0, B, st)

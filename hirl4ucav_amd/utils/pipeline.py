@@ -8,8 +8,11 @@ results are bit-identical to the serial order (tests/test_hirl_gpu.py).
 
 Measured on one MI355X at 4,096 envs, B = 128 (profiles/README.md): 145 us/step against 143 serial — act's 256 workgroups and
 learn's 1024-thread workgroups want the same CUs and LDS, so the stages mostly take turns anyway and the two event hand-offs
-cost what little is hidden.  bench.py therefore keeps the serial order by default (`--overlap` turns this on); the class stays
-because the exchange latency of the sharded update (N > 1) is the case it can still pay for, once that is measurable.
+cost what little is hidden (with act + env step as one launch: 107.8 vs 100.1 us).  In the sharded path the side stream can be
+released at the gradient all-reduce (HirlEngine.learn(before_exchange=pipe.fire)), so that it works while the main stream WAITS for
+the exchange instead of beside its compute kernels; on one GPU, where that wait is empty, this form shows what the two event
+hand-offs themselves cost: 117.5 vs 100.1 us per step, i.e. ~17 us per overlapped step.  bench.py therefore keeps ONE stream by default
+at any N (`--overlap` turns this on); whether hiding a 30-us launch behind an all-reduce beats that cost is a question for an 8-GPU box.
 """
 import torch
 
@@ -19,9 +22,10 @@ class VectorStepPipeline:
         self.overlap = bool(overlap)
         self.main = torch.cuda.current_stream(device)
         self.side = torch.cuda.Stream(device) if self.overlap else None
-        self.sampled = torch.cuda.Event()
+        self.ready = torch.cuda.Event()
         self.stepped = torch.cuda.Event()
-        self.issued = False  # act + env.step of the coming step are already in flight
+        self.issued = False   # act + env.step of the coming step are already in flight
+        self._armed = None    # the issue function, waiting for fire()
 
     def act_and_step(self, fn):
         """fn() enqueues act + env.step.  Skipped when the previous learn() already issued it."""
@@ -30,19 +34,33 @@ class VectorStepPipeline:
             return
         fn()
 
-    def prefetch(self, fn, acting_net_untouched):
-        """Call between sample() and learn(): if the coming learn() leaves the acting network alone, issue the NEXT
-        step's act + env.step on the side stream behind the sampler."""
-        if not (self.overlap and acting_net_untouched):
+    def arm(self, fn, acting_net_untouched):
+        """Call between sample() and learn(): if the coming learn() leaves the acting network alone, the NEXT step's act + env.step
+        may go out on the side stream — when fire() says so."""
+        self._armed = fn if (self.overlap and acting_net_untouched) else None
+
+    def fire(self):
+        """The moment to issue the armed work: everything enqueued on the main stream so far (the sampler's ring reads included) comes
+        first, the rest of learn() runs beside it.  The sharded engine calls this right before its gradient all-reduce, so the side
+        stream works while the main stream waits for the exchange — not while it computes."""
+        fn, self._armed = self._armed, None
+        if fn is None:
             return
-        self.sampled.record(self.main)
-        self.side.wait_event(self.sampled)
+        self.ready.record(self.main)
+        self.side.wait_event(self.ready)
         with torch.cuda.stream(self.side):
             fn()
         self.stepped.record(self.side)
         self.issued = True
 
+    def prefetch(self, fn, acting_net_untouched):
+        """arm + fire at once: the side stream starts right behind the sampler."""
+        self.arm(fn, acting_net_untouched)
+        self.fire()
+
     def join(self):
-        """Call after learn(): the next sampler (and anything else on the main stream) waits for the side stream."""
+        """Call after learn(): work that nobody fired goes out now; the next sampler (and anything else on the main stream) waits
+        for the side stream."""
+        self.fire()
         if self.issued:
             self.main.wait_event(self.stepped)

@@ -43,7 +43,7 @@ def test_bench_single_gpu_line():
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
-@pytest.mark.parametrize("extra", [[], ["--serial"], ["--agent", "sac", "--scenario", "serpentine"]])
+@pytest.mark.parametrize("extra", [[], ["--overlap"], ["--agent", "sac", "--scenario", "serpentine"]])
 def test_bench_two_ranks_launch_form(extra):
     """python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ..."""
     port = str(29600 + (os.getpid() + len(extra)) % 300)

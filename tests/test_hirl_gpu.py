@@ -362,7 +362,8 @@ def test_bc_train_actor_matches_oracle_and_reference(eng_mod, golden_dir):
         assert (dv > 2e-6).mean() <= 0.03 and dv.max() < 5e-5
 
 
-def test_two_stream_issue_order_is_bit_identical_to_serial():
+@pytest.mark.parametrize("staged", [False, True])
+def test_two_stream_issue_order_is_bit_identical_to_serial(staged):
     """bench.py --overlap issues the next act + env.step beside a critic-only learn() on a second stream
     (utils/pipeline.py).  Same reads and writes as the strict serial order of train_all.py:343-361: networks, Adam moments,
     env state, replay rows must come out bit for bit equal.  256 envs = one workgroup, so the replay insert order is fixed."""
@@ -371,7 +372,7 @@ def test_two_stream_issue_order_is_bit_identical_to_serial():
     import bench
 
     def run(serial):
-        args = argparse.Namespace(envs=256, batch=128, scenario="straight_line", agent="hirl", actions="policy", staged=False, overlap=not serial,
+        args = argparse.Namespace(envs=256, batch=128, scenario="straight_line", agent="hirl", actions="policy", staged=staged, overlap=not serial,
                                   separate_launches=True)  # one env workgroup: the replay insert order is fixed
         loop = bench.Loop(args, 0, 1, torch.device("cuda", 0))
         assert loop.pipe.overlap == (not serial)
