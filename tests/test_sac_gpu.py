@@ -110,13 +110,13 @@ def test_sac_learn_matches_oracle_and_reference(SE, golden_dir):
     assert e.learning_steps == 8
 
 
-def test_sac_act_step_in_one_launch_equals_act_then_step(SE):
+@pytest.mark.parametrize("n", [4096 + 17, 8192])  # 16-row and 32-row workgroups with the env tail
+def test_sac_act_step_in_one_launch_equals_act_then_step(SE, n):
     """hx_sac_act_step = hx_sac_act followed by hx_env_step (explore with given draws, with Philox, and exploit)."""
     from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
     from hirl4ucav_amd.utils.buffer import DeviceReplay
 
     params = sac_params()
-    n = 8192 + 17
     engs, envs, reps = [], [], []
     for _ in range(2):
         e = SE.SacEngine(batch=128)
