@@ -5,7 +5,6 @@ kernels behind include/hirl4ucav.h.  Randomness comes from the same host generat
 vectorised driver (hirl4ucav_amd/train_all.py).
 """
 import os
-import random
 
 import numpy as np
 import torch

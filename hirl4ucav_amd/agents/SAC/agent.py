@@ -6,7 +6,6 @@ The networks are the Linear-ReLU stacks of the reference's un-vendored rltorch b
 weights, zero biases — that builder is not in /root/reference, so its exact initialiser is not claimed).  The known crashes of
 the reference (the 14-input bc_actor, train_episode's missing env) are not reproduced.
 """
-import math
 import os
 
 import numpy as np

@@ -8,7 +8,6 @@ all-reduce per phase over the flat gradient buffer (RCCL via torch.distributed),
 all-reduce before the actor gradients are formed.
 """
 import ctypes
-import math
 
 import numpy as np
 import torch
