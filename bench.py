@@ -12,35 +12,46 @@ The update-to-data ratio is a stated design parameter: 1 learn() o
 Workload (BASELINE.json configs[1]): 4,096 parallel straight_line envs per GPU, HIRL-soft, fp32, synthetic random-init
 episodes (random_reset, Philox), synthetic 20,000-row expert set, seeded-init networks.  Prints ONE JSON line (rank 0).
 
-    python bench.py                       # 1 GPU, defaults finish in about a minute (incl. the bounded CPU baseline)
+    python bench.py                       # 1 GPU, defaults finish in about a minute (incl. the bounded CPU baselines)
+    python bench.py --gpus N ...          # starts N ranks itself (torch.distributed.run as a child process, before this process touches
+                                          # a GPU) and relays rank 0's line; fails if fewer than N GPUs are visible
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+Shape of a run: [settle: untimed steps for --settle-s seconds, so that clocks and caches are where a long run keeps them] ->
+W warm-up steps -> barrier + synchronize -> EXACTLY K steps with nothing but the hot path on the stream -> synchronize + barrier
+(max over ranks).  Everything that needs events, stamped or split launches (stage times, the env kernel's own duration for the
+roofline, all-reduce times) runs in a SECOND pass after the clock has been read.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak, same guide
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, same guide
 ENV_BYTES_FUSED = 550            # algorithmic bytes per env-step with the fused replay insert (SURVEY.md 8d)
 ENV_BYTES_PLAIN = 370
 ACTOR_FLOP = 272896              # forward FLOPs per sample (2 * MAC, GEMMs only), SURVEY.md 8d
 LEARN_FLOP_PER_SAMPLE = 3810816  # HIRL-soft learn(), averaged over the actor-every-2nd alternation, SURVEY.md 8d
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20000)  # ~2.2 s of GPU time: long enough for the clocks to settle
+    p.add_argument("--steps", type=int, default=20000)  # ~2 s of GPU time
     p.add_argument("--warmup", type=int, default=2000)
+    p.add_argument("--settle-s", dest="settle_s", type=float, default=1.5,
+                   help="untimed steps of the same loop for this many seconds BEFORE the warm-up (clocks, caches, allocator); 0 = off")
     p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     p.add_argument("--batch", type=int, default=128)
     p.add_argument("--scenario", default="straight_line", choices=["straight_line", "serpentine", "circular", "mixed"],
@@ -48,26 +59,63 @@ def parse():
     p.add_argument("--type", default="soft", choices=["soft", "linear", "fixed"], help="HIRL BC-weight schedule (train_all.py:328-339)")
     p.add_argument("--bc_weight", type=float, default=0.5, help="linear / fixed: the weight (configs[3]: linear, 0.5)")
     p.add_argument("--agent", default="hirl", choices=["hirl", "sac"], help="sac: BASELINE.json configs[2] (use --envs 16384 --scenario serpentine)")
+    p.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                   help="bf16: actor inference on bf16 MFMA with fp32 accumulation, fp32 dynamics / update / optimizer (BASELINE.json configs[4])")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=12.0)
-    p.add_argument("--sweep", action="store_true", help="also sweep the env-step kernel over 4k..4M envs per launch")
+    p.add_argument("--cpu-seconds", type=float, default=20.0, help="total budget of the CPU baseline legs")
+    p.add_argument("--no-sweep", action="store_true", help="skip the env-step kernel sweep over 4k..4M envs per launch (< 1 s)")
+    p.add_argument("--sweep", action="store_true", help="(default) kept for older command lines")
     p.add_argument("--actions", default="policy", choices=["policy", "uniform"],
                    help="uniform: U(-1,1)^4 actions instead of the live actor (SURVEY.md 8d C2's second run, decoupled from the policy)")
     p.add_argument("--overlap", action="store_true",
-                   help="issue the next act + env.step on a second stream beside critic-only learns (bit-identical results); in the sharded "
-                        "path the side stream is released at the gradient all-reduce. Measured on one GPU it does not pay — 107.8 vs 100.1 "
-                        "us/step one-call, 117.5 vs 100.1 staged: every cross-stream event hand-off costs ~10 us on this runtime — so the "
-                        "default, at any N, is the reference's strict act -> step -> sample -> learn order on one stream")
+                   help="issue the next act + env.step on a second stream beside critic-only learns (bit-identical results); measured on one "
+                        "GPU it does not pay (every cross-stream event hand-off costs ~10 us on this runtime), so the default, at any N, is "
+                        "the reference's strict act -> step -> sample -> learn order on one stream")
     p.add_argument("--serial", action="store_true", help="(default) one stream")
     p.add_argument("--separate-launches", dest="separate_launches", action="store_true",
                    help="act and env step as two launches on every step (default: one fused launch, hx_actor_act_step)")
     p.add_argument("--staged", action="store_true",
                    help="use the stage-by-stage update path of the sharded build on one rank too (costs of the N > 1 launch sequence)")
-    return p.parse_args()
+    p.add_argument("--exchange", default="rccl", choices=["rccl", "oneshot"],
+                   help="gradient exchange at N > 1: RCCL all-reduce (torch.distributed) or the one-shot peer-read kernel over hipIpc mappings")
+    p.add_argument("--measure-steps", dest="measure_steps", type=int, default=256, help="steps of the instrumented second pass")
+    return p.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no launcher environment starts the N ranks itself
+# ---------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def visible_gpus():
+    import torch  # counting devices does not initialise the GPU
+
+    return torch.cuda.device_count()
+
+
+def launch_ranks(args, argv):
+    n = visible_gpus()
+    if n < args.gpus and os.environ.get("HX_BENCH_BACKEND", "nccl") == "nccl":
+        sys.stderr.write(f"bench.py: {args.gpus} GPUs requested, {n} visible - refusing to print a {n}-GPU number as a {args.gpus}-GPU one\n")
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)  # a CHILD process: this one has not touched a GPU and simply relays the exit code
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# synthetic inputs
+# ---------------------------------------------------------------------------------------------------------------------
 def synthetic_expert(rng, n=20000):
-    """SURVEY.md 8d C2: states U(-1,1)^13 with cols 7,8 in {+-1}, col 12 in [0, 0.2]; actions U(-1,1)^3 ++ fire +-1, P(+1) = 1e-3."""
+    """states U(-1,1)^13 with cols 7,8 in {+-1}, col 12 in [0, 0.2]; actions U(-1,1)^3 ++ fire +-1, P(+1) = 1e-3."""
     s = rng.uniform(-1, 1, (n, 13)).astype(np.float32)
     s[:, 7] = np.where(rng.random(n) < 0.5, 1, -1)
     s[:, 8] = np.where(rng.random(n) < 0.5, 1, -1)
@@ -100,28 +148,32 @@ def init_params(rng):
 
 
 class Loop:
-    """act -> env step (+ fused insert) -> sample -> learn, everything resident on one GPU."""
+    """act -> env step (+ fused insert) -> sample -> learn, everything resident on one GPU.  step() enqueues the hot path and nothing
+    else; step_measured() is the same step with events around the stages and, on request, act / env step as two launches with the
+    env launch stamped — it is used only AFTER the timed region."""
 
     def __init__(self, args, rank, world, device):
+        import torch
+
         from hirl4ucav_amd import _lib
         from hirl4ucav_amd.agents.engine import HirlEngine
         from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
         from hirl4ucav_amd.utils.buffer import DeviceReplay
 
-        self.lib = _lib
+        self.torch, self.lib = torch, _lib
         self.args, self.rank, self.world = args, rank, world
         n = args.envs
         self.max_step = 1900 if args.scenario == "circular" else 1500  # train_all.py:159-183
         self.replay = DeviceReplay(max(1 << 20, 2 * n), device)
-        scenario = getattr(args, "scenario", "straight_line")
+        scenario = args.scenario
         if scenario == "mixed":  # contiguous thirds: wavefronts never mix scenarios
             scenario = np.sort((np.arange(n) + rank * n) % 3).astype(np.int32)
         self.env = BatchedHarfangEnv(n, scenario=scenario, device=device, seed=0, max_step=self.max_step, auto_reset=True,
                                      random_reset=True, env_id0=rank * n, replay=self.replay)
         rng = np.random.default_rng(0)  # same networks and expert set on every rank (replicas)
         actor, critic, bc = init_params(rng)
-        self.sac = getattr(args, "agent", "hirl") == "sac"
-        self.uniform = getattr(args, "actions", "policy") == "uniform"
+        self.sac = args.agent == "sac"
+        self.uniform = args.actions == "uniform"
         if self.sac:
             from hirl4ucav_amd.agents.sac_engine import SacEngine
 
@@ -137,8 +189,12 @@ class Loop:
         else:
             self.eng = HirlEngine(batch=args.batch, device=device)
             self.eng.load_params(actor, critic, bc)
-            if getattr(args, "staged", False):
+            if args.staged:
                 self.eng.staged = True
+            if hasattr(self.eng, "set_act_dtype"):
+                self.eng.set_act_dtype(args.dtype)
+            if world > 1 and args.exchange == "oneshot":
+                self.eng.use_oneshot_exchange()
         es, ea = synthetic_expert(rng)
         # BC table rows (s, a) and the expert replay ring labelled on the GPU (train_all.py:289-306)
         bc_rows = np.zeros((es.shape[0], 32), np.float32)
@@ -153,54 +209,38 @@ class Loop:
                   _lib.stream_ptr())
         self.expert = DeviceReplay(m + 10, device)
         self.expert.store_rows(torch.cat([s_t, a_t, ns_t, r[:, None], dn.float()[:, None]], 1), sc)
-        self.expert_len, self.bc_len = m, es.shape[0]
         self.expert_num = 0  # steady state of the 128 -> 0 decay (train_all.py:356-357)
         self.env.reset()
         self.t = 0
         self.actions = torch.zeros((n, 4), device=device)
         from hirl4ucav_amd.utils.pipeline import VectorStepPipeline
-        self.pipe = VectorStepPipeline(device, overlap=getattr(args, "overlap", False) and not getattr(args, "serial", False) and not self.sac)
-        self.record, self.rec, self.pool = False, {"act": [], "env": [], "act+env": [], "learn": []}, []
-        self.separate = getattr(args, "separate_launches", False)
-        self.kpool, self.krec, self.act_env_calls = [], [], 0
+        self.pipe = VectorStepPipeline(device, overlap=args.overlap and not args.serial and not self.sac)
+        self.separate = args.separate_launches
+        self.rec = {"act": [], "env": [], "act+env": [], "learn": []}
+        self.krec = []
 
-    def _timed(self, name, fn):
-        """Bracket fn() with HIP events on the stream it launches on (the current one) while recording is on."""
-        if not self.record:
-            return fn()
-        if len(self.pool) < 2:  # events are made outside the timed region (creation stalls the issue thread); none left: untimed
-            return fn()
-        a, b = self.pool.pop(), self.pool.pop()
-        a.record()
-        fn()
-        b.record()
-        self.rec[name].append((a, b))
-
-    def _act_env(self):
+    # ---- the hot path ------------------------------------------------------------------------------------------------
+    def _act_env(self, timed=None, split=False, stamp=None):
         e, env = self.eng, self.env
-        # The env kernel's own duration (what rocprofv3 reports) is sampled on every 8th recorded step: there the two stages go
-        # out as separate launches, act then a STAMPED env step (a stamped launch costs ~9 us extra, hence not on every step).
-        self.act_env_calls += 1  # (not self.t: with two streams this function runs one step ahead, always on odd t)
-        stamped = self.record and len(self.kpool) >= 2 and self.act_env_calls % 8 == 0
-        if self.uniform or self.separate or stamped:
+        t = timed or (lambda name, fn: fn())
+        if self.uniform or self.separate or split:
             if self.uniform:  # env.action_space.sample() for every env (train_all.py:272)
-                self._timed("act", lambda: self.actions.uniform_(-1.0, 1.0))
+                t("act", lambda: self.actions.uniform_(-1.0, 1.0))
             elif self.sac:
-                self._timed("act", lambda: e.act(env.obs, seed=1, row0=env.env_id0, out=self.actions))  # SacAgent.explore
+                t("act", lambda: e.act(env.obs, seed=1, row0=env.env_id0, out=self.actions))  # SacAgent.explore
             else:
-                self._timed("act", lambda: e.act(env.obs, sigma=0.1, seed=1, row0=env.env_id0, out=self.actions))  # actionNoise 0.1, HIRL.py:160
-            if stamped:
-                a, b = self.kpool.pop(), self.kpool.pop()
-                env.time_next_steps(a, b)
-                self.krec.append((a, b))
-            self._timed("env", lambda: env.step(self.actions))
-            env.time_next_steps(None, None)
+                t("act", lambda: e.act(env.obs, sigma=0.1, seed=1, row0=env.env_id0, out=self.actions))  # actionNoise 0.1, HIRL.py:160
+            if stamp is not None:
+                env.time_next_steps(*stamp)
+            t("env", lambda: env.step(self.actions))
+            if stamp is not None:
+                env.time_next_steps(None, None)
         elif self.sac:   # explore + env.step in one launch
-            self._timed("act+env", lambda: e.act_step(env, seed=1, out=self.actions))
+            t("act+env", lambda: e.act_step(env, seed=1, out=self.actions))
         else:            # chooseAction + env.step in one launch (same results, bit for bit: tests/test_hirl_gpu.py)
-            self._timed("act+env", lambda: e.act_step(env, sigma=0.1, seed=1, out=self.actions))
+            t("act+env", lambda: e.act_step(env, sigma=0.1, seed=1, out=self.actions))
 
-    def _learn(self):
+    def _learn(self, act_env):
         e = self.eng
         if self.sac:  # train_sac.py:401-403
             e.sample(self.replay, seed=2 + self.rank)
@@ -208,10 +248,10 @@ class Loop:
             return
         e.sample(self.replay, self.expert, self.bc_table, n_main=e.batch - self.expert_num, seed=2 + self.rank)
         # a critic-only learn() leaves the acting network alone: the next act + env.step go out on the side stream now
-        self.pipe.arm(self._act_env, acting_net_untouched=not e.actor_trainable)
+        self.pipe.arm(act_env, acting_net_untouched=not e.actor_trainable)
         # soft weight: estimated at the start of every max_step-long "episode" of vector steps, kept in between
         # (the reference re-estimates at most once per episode)
-        kind = getattr(self.args, "type", "soft")
+        kind = self.args.type
         if kind == "soft":
             w = 100 if (self.t % self.max_step == 0) else None
         elif kind == "linear":  # bc_weight - episode / 5000, floored at 0 (train_all.py:328-331); episode = max_step vector steps
@@ -225,36 +265,86 @@ class Loop:
 
     def step(self):
         self.pipe.act_and_step(self._act_env)
-        self._timed("learn", self._learn)
+        self._learn(self._act_env)
         self.pipe.join()
         self.t += 1
 
+    # ---- the same step with instruments (second pass only) -----------------------------------------------------------------
+    def step_measured(self, split, pool, kpool):
+        torch = self.torch
 
-def cpu_baseline(args, seconds):
-    """The oracle (CPU restatement) timed on this host on a BOUNDED sample of the same workload: the same loop
-    (actor forward for all envs, env step for all envs with insert, one HIRL learn at B = 128) for as many vector steps
-    as fit in about `seconds`."""
+        def timed(name, fn):
+            a, b = pool.pop(), pool.pop()
+            a.record()
+            fn()
+            b.record()
+            self.rec[name].append((a, b))
+
+        stamp = None
+        if split and not self.uniform:
+            stamp = (kpool.pop(), kpool.pop())
+            self.krec.append(stamp)
+        act_env = lambda: self._act_env(timed, split, stamp)  # noqa: E731
+        self.pipe.act_and_step(act_env)
+        timed("learn", lambda: self._learn(act_env))
+        self.pipe.join()
+        self.t += 1
+        del torch
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baselines (BASELINE.md 3 / SURVEY.md 8d): reported beside the GPU number, never a target.  The oracle may serve this leg.
+# ---------------------------------------------------------------------------------------------------------------------
+def host_cpu():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
+def baseline_port(args, seconds):
+    """The oracle timed on a BOUNDED sample of the same workload: the same loop (actor forward for all envs, env step for all
+    envs with insert — the envs split over all host cores —, one HIRL learn at B = 128) for as many vector steps as fit."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle import hirl_oracle as H
     from tests import _oracle as ox
 
     n = args.envs
+    cores = os.cpu_count() or 1
     rng = np.random.default_rng(0)
     actor, critic, bc = init_params(rng)
     es, ea = synthetic_expert(rng)
     o = H.HirlOracle(actor, critic, bc)
     envs, obs = ox.reset_batch(n, 0, 1, seed=0)
-    cap = 1 << 18
-    ring = np.zeros((cap, 32), np.float32)
-    rs = np.zeros(cap, np.int8)
-    total = np.zeros(1, np.uint64)
+    chunks = [(k * n // cores, (k + 1) * n // cores) for k in range(cores) if (k + 1) * n // cores > k * n // cores]
+    cap = 1 << 14
+    rings = [np.zeros((cap, 32), np.float32) for _ in chunks]   # one private ring segment per worker (no shared head on the CPU side)
+    totals = [np.zeros(1, np.uint64) for _ in chunks]
     epi = np.zeros(n, np.uint32)
-    steps, t0 = 0, time.perf_counter()
+    pool = ThreadPoolExecutor(len(chunks))  # ctypes releases the GIL inside ox_env_step_batch
+
+    def work(k, a):
+        lo, hi = chunks[k]
+        ox.step_batch(envs[lo:hi], a[lo:hi], obs[lo:hi], max_step=1500, auto_reset=1, randomize=1, seed=0, env_id0=lo, episode_ctr=epi[lo:hi],
+                      ring=rings[k], total=totals[k])
+
+    steps, t_env, t0 = 0, 0.0, time.perf_counter()
     while True:
         a = o.choose_action(obs, rng.normal(0, 0.1, (n, 4)).astype(np.float32))
-        ox.step_batch(envs, a, obs, max_step=1500, auto_reset=1, randomize=1, seed=0, episode_ctr=epi, ring=ring, ring_succ=rs, total=total)
-        m = min(int(total[0]), cap)
-        idx = rng.integers(0, m, args.batch)
-        rows = ring[idx]
+        te = time.perf_counter()
+        list(pool.map(lambda k: work(k, a), range(len(chunks))))
+        t_env += time.perf_counter() - te
+        ring = rings[steps % len(rings)]
+        m = max(min(int(totals[steps % len(rings)][0]), cap), 1)
+        rows = ring[rng.integers(0, m, args.batch)]
         ibc = rng.integers(0, es.shape[0], args.batch)
         o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), (es[ibc], ea[ibc]),
                 rng.normal(0, 0.2, 4).astype(np.float32), 100 if steps == 0 else o.bc_weight, 0.0)
@@ -262,13 +352,154 @@ def cpu_baseline(args, seconds):
         dt = time.perf_counter() - t0
         if dt > seconds or steps >= 2000:
             break
-    return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{steps} vector steps of {n} envs (oracle: scalar C env step on 1 thread + torch-CPU actor forward and "
-                      f"HIRL learn on {torch.get_num_threads()} threads), {dt:.1f} s",
-            "update_steps_per_s": round(steps / dt, 2)}
+    pool.shutdown()
+    return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s: oracle C env step on {len(chunks)} threads (B1: "
+                      f"{n * steps / max(t_env, 1e-9):,.0f} env steps/s for the integrator alone) + torch-CPU actor forward and HIRL learn "
+                      f"on {torch.get_num_threads()} threads",
+            "update_steps_per_s": round(steps / dt, 2),
+            "b1_batched_cpu": {"value": round(n * steps / max(t_env, 1e-9), 1), "unit": "env steps/s", "cores": len(chunks),
+                               "what": "the oracle's batched env step alone (C, one thread per core over env slices)"}}
+
+
+def baseline_reference_plumbing(seconds):
+    """B0 (configs[0]): ONE env behind the reference's loopback framing — 4-byte big-endian length + JSON (socket_lib.py:86-143), the
+    wrapper's message sequence per step (HarfangEnv_GYM.py:139-158: 6 level setters [+ FIRE_MISSILE] + UPDATE_SCENE; :193-251: 4
+    request/reply read-backs), no TCP_NODELAY on the client (the reference sets none) — with the oracle simulator as the server and
+    the oracle's eager CPU HIRL agent doing chooseAction + learn every step, as train_all.py:341-361 does."""
+    import torch
+
+    from hirl4ucav_amd.environments.wire import ALLY, OPPO, WireServer
+    from oracle import hirl_oracle as H
+    from tests._wire_backend import OracleSimBackend
+
+    rng = np.random.default_rng(0)
+    actor, critic, bc = init_params(rng)
+    es, ea = synthetic_expert(rng)
+    agent = H.HirlOracle(actor, critic, bc)
+    srv = WireServer(OracleSimBackend(), "127.0.0.1", 0).start()
+    sock = socket.create_connection(("127.0.0.1", srv.port))
+    sent = [0]
+
+    def send(command, **a):
+        body = json.dumps({"command": command, "args": a}).encode()
+        sock.sendall(len(body).to_bytes(4, "big") + body)
+        sent[0] += 1
+
+    def exact(k):
+        buf = b""
+        while len(buf) < k:
+            buf += sock.recv(k - len(buf))
+        return buf
+
+    def ask(command, **a):
+        send(command, **a)
+        return json.loads(exact(int.from_bytes(exact(4), "big")).decode())
+
+    def observe():
+        pa, po = ask("GET_PLANE_STATE", plane_id=ALLY), ask("GET_PLANE_STATE", plane_id=OPPO)
+        h = ask("GET_HEALTH", machine_id=OPPO)["health_level"]
+        slot = ask("GET_MISSILESDEVICE_SLOTS_STATE", machine_id=ALLY)["missiles_slots"][0]
+        d = (np.asarray(pa["position"]) - np.asarray(po["position"])) / 10000.0
+        return np.concatenate([d, np.asarray(pa["Euler_angles"]) / np.pi, [pa["target_angle"] / 180.0, 1.0 if pa["target_locked"] else -1.0,
+                               1.0 if slot else -1.0], np.asarray(po["Euler_angles"]) / np.pi, [h]]), float(np.linalg.norm(d) * 10000.0)
+
+    obs, _ = observe()
+    mem, steps, t0 = [], 0, time.perf_counter()
+    while True:
+        a = agent.choose_action(obs.astype(np.float32)[None], rng.normal(0, 0.1, 4).astype(np.float32))[0]
+        send("SET_PLANE_PITCH", plane_id=ALLY, pitch_level=float(a[0]))
+        send("SET_PLANE_ROLL", plane_id=ALLY, roll_level=float(a[1]))
+        send("SET_PLANE_YAW", plane_id=ALLY, yaw_level=float(a[2]))
+        send("SET_PLANE_PITCH", plane_id=OPPO, pitch_level=0.0)
+        send("SET_PLANE_ROLL", plane_id=OPPO, roll_level=0.0)
+        send("SET_PLANE_YAW", plane_id=OPPO, yaw_level=0.0)
+        if a[3] > 0:
+            send("FIRE_MISSILE", machine_id=ALLY, slot_id=0)
+        send("UPDATE_SCENE")
+        nobs, dist = observe()
+        r = -1e-4 * dist - 10.0 * nobs[6] - (8.0 if a[3] > 0 else 0.0)
+        mem.append(np.concatenate([obs, a, nobs, [r, 0.0]]).astype(np.float32))
+        obs = nobs
+        if len(mem) >= 128:
+            rows = np.stack([mem[i] for i in rng.choice(len(mem), 128, replace=False)])
+            ibc = rng.choice(es.shape[0], 128, replace=False)
+            agent.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), (es[ibc], ea[ibc]),
+                        rng.normal(0, 0.2, 4).astype(np.float32), 100 if len(mem) == 128 else agent.bc_weight, 0.0)
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds or steps >= 5000:
+            break
+    sock.close()
+    srv.close()
+    return {"value": round(steps / dt, 2), "unit": "env steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "what": "configs[0]: 1 env behind the reference's socket framing (loopback TCP + JSON), eager CPU HIRL chooseAction + learn per step",
+            "sample": f"{steps} env steps in {dt:.1f} s, {sent[0] / max(steps, 1):.1f} messages per step, learn() from step 128 on"}
+
+
+def baseline_eager_rocm_learn(args, seconds, device):
+    """B2: the same HIRL learn() as stock eager PyTorch-ROCm ops on the GPU (the oracle's functional restatement with its tensors
+    on the device) — what the reference's agent costs when only its device string changes."""
+    import torch
+
+    from oracle import hirl_oracle as H
+
+    rng = np.random.default_rng(0)
+    actor, critic, bc = init_params(rng)
+    es, ea = synthetic_expert(rng)
+    o = H.HirlOracle(actor, critic, bc, device=device)
+    rows = torch.from_numpy(rng.uniform(-1, 1, (4096, 32)).astype(np.float32)).to(device)
+    est, eat = torch.from_numpy(es).to(device), torch.from_numpy(ea).to(device)
+    noise = torch.from_numpy(rng.normal(0, 0.2, 4).astype(np.float32)).to(device)
+
+    def one(k):
+        idx = torch.randint(0, rows.shape[0], (args.batch,), device=device)
+        ib = torch.randint(0, est.shape[0], (args.batch,), device=device)
+        b = rows[idx]
+        o.learn((b[:, 0:13], b[:, 13:17], b[:, 17:30], b[:, 30], (b[:, 31] > 0.9).float()), (est[ib], eat[ib]), noise, 100 if k == 0 else o.bc_weight, 0.0)
+
+    for k in range(4):
+        one(k)
+    torch.cuda.synchronize()
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds and steps < 4000:
+        one(steps + 4)
+        steps += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(steps / dt, 1), "unit": "learn() calls/s", "kind": "port",
+            "what": "HIRL learn(B=128) as eager PyTorch-ROCm ops on the same GPU (autograd + hand-written Adam/Polyak of the oracle)",
+            "sample": f"{steps} calls in {dt:.1f} s"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def stamped_env_us(env, actions, launches):
+    """The env-step kernel's OWN duration (begin/end stamps of hipExtLaunchKernelGGL, what rocprofv3 reports) over `launches` launches."""
+    import torch
+
+    from hirl4ucav_amd import _lib
+
+    L = _lib.load()
+    evs = [(ctypes.c_void_p(L.hx_event_create()), ctypes.c_void_p(L.hx_event_create())) for _ in range(launches)]
+    for s, e in evs:
+        env.time_next_steps(s, e)
+        env.step(actions)
+    env.time_next_steps(None, None)
+    torch.cuda.synchronize()
+    us = []
+    for s, e in evs:
+        v = ctypes.c_float()
+        _lib.call("hx_event_elapsed_us", s, e, ctypes.byref(v))
+        us.append(v.value)
+        L.hx_event_destroy(s)
+        L.hx_event_destroy(e)
+    return us
 
 
 def env_sweep(device):
+    """The env-step kernel with the fused insert over 4k..4M envs per launch: the kernel's own duration, algorithmic 550 B per env-step."""
+    import torch
+
     from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
     from hirl4ucav_amd.utils.buffer import DeviceReplay
 
@@ -280,15 +511,7 @@ def env_sweep(device):
         a = torch.rand(n, 4, device=device) * 2 - 1
         for _ in range(3):
             env.step(a)
-        iters = 30
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(iters):
-            env.step(a)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / iters
+        us = float(np.median(stamped_env_us(env, a, 16)))
         out.append({"envs_per_launch": n, "us": round(us, 2), "GBps": round(ENV_BYTES_FUSED * n / us / 1e3, 1),
                     "frac": round(ENV_BYTES_FUSED * n / us / 1e3 / HBM_PEAK_GBPS, 4)})
         del env, rep
@@ -296,19 +519,40 @@ def env_sweep(device):
     return out
 
 
-def main():
-    args = parse()
+def profile_traffic(envs):
+    """HBM bytes per launch of the env-step kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per
+    pass, gfx950 FETCH x2 calibration: tools/pmc_env.py).  Not measured by this run: reported under its own key with the file it came from."""
+    f = os.path.join(REPO, "profiles", "pmc_env_traffic.json")
+    if not os.path.exists(f):
+        return None
+    with open(f) as fh:
+        doc = json.load(fh)
+    pmc = doc.get(str(envs))
+    if not pmc:
+        return None
+    return {"bytes": pmc["traffic_bytes"], "fetch_bytes": pmc["fetch_bytes"], "write_bytes": pmc["write_bytes"], "ratio_to_algorithmic": pmc["ratio"],
+            "source": "profiles/pmc_env_traffic.json", "kernel_build": doc.get("kernel_build", "round 1 kernel (before the pair-lane layout)"),
+            "note": "separate rocprofv3 --pmc passes of tools/pmc_env.py at this size; a profile artefact, not a measurement of this run"}
+
+
+def run_rank(args):
+    import torch
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
-    if not torch.cuda.is_available():
+    backend = os.environ.get("HX_BENCH_BACKEND", "nccl")  # gloo exists only to exercise this code path where all ranks share one GPU
+    ngpu = torch.cuda.device_count()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if ngpu < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if world > ngpu and backend == "nccl":
+        raise SystemExit(f"bench.py: {world} GPUs requested, {ngpu} visible")
+    local = int(os.environ.get("LOCAL_RANK", "0")) % ngpu
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL over xGMI.  HX_BENCH_BACKEND=gloo exists only to exercise this code path where all ranks share one GPU.
-        backend = os.environ.get("HX_BENCH_BACKEND", "nccl")
         torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
     loop = Loop(args, rank, world, device)
 
@@ -317,31 +561,26 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # ---- settle (declared, untimed), warm-up ----
+    settle_steps = 0
+    if args.settle_s > 0:
+        t_end = time.perf_counter() + args.settle_s
+        while time.perf_counter() < t_end:
+            for _ in range(32):
+                loop.step()
+            settle_steps += 32
+            if world > 1:  # every rank must leave the phase after the same number of collective calls
+                flag = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], device=device)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                if float(flag.item()) == 0.0:
+                    break
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         loop.step()
-    # per-stage HIP events (recorded on the stream the kernels are launched on = torch's current stream)
-    ar_events = []
-    if world > 1:  # exchange step: HIP events around every gradient all-reduce of the first steps (on the stream it is enqueued on)
-        inner = loop.eng._allreduce
-
-        def timed_allreduce(t):
-            if loop.record and loop.pool:
-                a, b = loop.pool.pop(), loop.pool.pop()
-                a.record()
-                inner(t)
-                b.record()
-                ar_events.append((t.numel() * 4, a, b))
-            else:
-                inner(t)
-        loop.eng._allreduce = timed_allreduce
-    nev = min(args.steps, 512)
-    loop.pool = [torch.cuda.Event(enable_timing=True) for _ in range(16 * (nev + 1))]
-    L = loop.lib.load()
-    loop.kpool = [ctypes.c_void_p(L.hx_event_create()) for _ in range(2 * (nev + 1))]
+    # ---- the timed region: K steps, nothing else on the stream ----
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        loop.record = k >= args.steps - nev  # the last steps of the timed region: clocks settled
+    for _ in range(args.steps):
         loop.step()
     barrier()
     dt = time.perf_counter() - t0
@@ -349,70 +588,95 @@ def main():
         tt = torch.tensor([dt], device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    if not loop.krec:  # a run too short to contain a sampled step: take the samples right after the timed region instead
-        loop.record, loop.separate = True, True
-        for _ in range(16):
-            loop.act_env_calls = 7
-            loop.step()
-        torch.cuda.synchronize()
+
+    # ---- second pass: stage events; every 4th step act and env step as two launches with the env launch stamped ----
+    ar_events = []
+    m_steps = max(int(args.measure_steps), 16)
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(12 * (m_steps + 1))]
+    L = loop.lib.load()
+    kpool = [ctypes.c_void_p(L.hx_event_create()) for _ in range(2 * (m_steps // 4 + 2))]
+    if world > 1:  # exchange step: events around every gradient exchange (on the stream it is enqueued on)
+        inner = loop.eng._allreduce
+
+        def timed_allreduce(t):
+            if len(pool) >= 2:
+                a, b = pool.pop(), pool.pop()
+                a.record()
+                inner(t)
+                b.record()
+                ar_events.append((t.numel() * 4, a, b))
+            else:
+                inner(t)
+        loop.eng._allreduce = timed_allreduce
+    for k in range(m_steps):
+        loop.step_measured(split=(k % 4 == 3), pool=pool, kpool=kpool)
+    barrier()
+    if world > 1:
+        loop.eng._allreduce = inner
     med = {k: (float(np.median([a.elapsed_time(b) * 1e3 for a, b in v])) if v else None) for k, v in loop.rec.items()}
-    act_us, env_us, learn_us = med["act"], med["env"], med["learn"]
     kern = []
-    for a, b in loop.krec:  # kernel-only durations of the env-step launches inside the timed region
+    for a, b in loop.krec:
         us = ctypes.c_float()
         loop.lib.call("hx_event_elapsed_us", a, b, ctypes.byref(us))
         kern.append(us.value)
+    if not kern:  # uniform actions: the loop has no act launch to split off; stamp plain env steps
+        kern = stamped_env_us(loop.env, loop.actions, 32)
     env_kernel_us = float(np.mean(kern))  # mean, like the rocprofv3 --stats average it must agree with
+    act_us, learn_us = med["act"], med["learn"]
+
     n_total = args.envs * world
     value = n_total * args.steps / dt
+    dt_name = "f32" if args.dtype == "f32" else "bf16 policy inference (fp32 accumulate) + f32 dynamics/update"
     res = {
         "metric": "env steps/sec (whole node) + HIRL update steps/sec at 4096 envs/GPU", "value": round(value, 1),
-        "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_s": args.settle_s, "settle_steps": settle_steps,
         "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": (f"{args.envs} parallel {args.scenario} envs per GPU, SAC fp32, 1 learn(B={args.batch}) per vector step "
                                 f"(BASELINE.json configs[2])" if args.agent == "sac" else
-                                f"{args.envs} parallel {args.scenario} envs per GPU, HIRL-{args.type} fp32, 1 learn(B={args.batch}) per vector step "
+                                f"{args.envs} parallel {args.scenario} envs per GPU, HIRL-{args.type} {dt_name}, 1 learn(B={args.batch}) per vector step "
                                 f"(BASELINE.json configs[1])"), "envs_per_gpu": args.envs, "batch": args.batch,
-                   "actions": args.actions, "act_env": "two launches" if (loop.separate or loop.uniform) else "one launch (hx_actor_act_step / hx_sac_act_step)", "issue_order": "two streams" if loop.pipe.overlap else "serial", "update_path": "staged" if (args.staged or world > 1) and args.agent == "hirl" else "one-call",
-                   "parallelism": f"dp{world}: env shards + replicated nets, RCCL all-reduce of the flat gradients"},
+                   "actions": args.actions, "act_env": "two launches" if (loop.separate or loop.uniform) else "one launch (hx_actor_act_step / hx_sac_act_step)",
+                   "issue_order": "two streams" if loop.pipe.overlap else "serial",
+                   "update_path": "staged" if (args.staged or world > 1) and args.agent == "hirl" else "one-call",
+                   "parallelism": f"dp{world}: env shards + replicated nets, {'one-shot peer-read' if (world > 1 and args.exchange == 'oneshot') else 'RCCL'} "
+                                  f"all-reduce of the flat gradients; effective batch = {args.batch} x {world}"},
         "update_steps_per_s": round(args.steps / dt, 1),
-        "stage_us": {"act+env_step(1 kernel)": None if med["act+env"] is None else round(med["act+env"], 2),
-                     "act(own launch, sampled steps)": None if act_us is None else round(act_us, 2),
-                     "env_step(own launch, sampled steps)": None if env_us is None else round(env_us, 2),
-                     "sample+learn(6-11 kernels)": None if learn_us is None else round(learn_us, 2)},
+        "timed_region": "K x step() between two barrier + synchronize pairs; no events, no stamped or split launches inside (those are the second pass)",
+        "stage_us": {"pass": f"second pass, {m_steps} steps after the timed region (events add a few us per step)",
+                     "act+env_step(1 kernel)": None if med["act+env"] is None else round(med["act+env"], 2),
+                     "act(own launch, every 4th step)": None if act_us is None else round(act_us, 2),
+                     "env_step(own launch, every 4th step)": None if med["env"] is None else round(med["env"], 2),
+                     "sample+learn": None if learn_us is None else round(learn_us, 2)},
     }
     # roofline of the env-step kernel (the kernel the metric counts): algorithmic bytes / live-measured launch time
-    res["roofline"] = {"kernel": "env_step_kernel<INSERT>", "bound": "hbm", "achieved": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3, 1),
-                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3 / HBM_PEAK_GBPS, 4),
-                       "traffic": None, "bytes_per_launch": ENV_BYTES_FUSED * args.envs, "us_per_launch": round(env_kernel_us, 2),
-                       "launches_timed": len(kern),
-                       "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the "
-                                 "timed region's last launches; stage_us brackets the launch with events and so includes the dispatch gap",
-                       "traffic_note": "not collectable inside this process"}
-    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass, gfx950 FETCH x2
-    # calibration): a separate run of the same kernel at the same size, committed under profiles/
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_env_traffic.json")
-    if os.path.exists(pmc_file):
-        with open(pmc_file) as f:
-            pmc = json.load(f).get(str(args.envs))
-        if pmc:
-            res["roofline"]["traffic"] = pmc["traffic_bytes"]
-            res["roofline"]["traffic_note"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of tools/pmc_env.py at {args.envs} envs per launch "
-                                               f"(profiles/r01p_pmc_*.csv): {pmc['fetch_bytes']} B fetched (FETCH_SIZE x 2, calibrated) + {pmc['write_bytes']} B "
-                                               f"written = {pmc['ratio']} x the algorithmic bytes")
-    res["roofline_update"] = {"kernels": "fwd_l2/bwd_l2/wgrad/adam (one learn)", "bound": "mfma", "unit": "TFLOP/s",
-                              "achieved": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
-                              "frac": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 5),
-                              "us_per_learn": round(learn_us, 2)}
-    res["roofline_act"] = {"kernels": "act_fused_kernel", "bound": "mfma", "unit": "TFLOP/s",
-                           "achieved": round(ACTOR_FLOP * args.envs / act_us / 1e6, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
-                           "frac": round(ACTOR_FLOP * args.envs / act_us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 5), "us": round(act_us, 2)}
-    if world > 1:  # the replicas must still be bit-identical after K sharded updates
+    res["roofline"] = {"kernel": "env_step_kernel<PAIR, INSERT, EPB> (hx_env.hip)", "bound": "hbm",
+                       "achieved": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None,
+                       "bytes_per_launch": ENV_BYTES_FUSED * args.envs, "us_per_launch": round(env_kernel_us, 2), "launches_timed": len(kern),
+                       "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the launches of "
+                                 "the second pass (act and env step issued as two launches there; the timed loop runs them as ONE kernel)",
+                       "traffic_note": "PMC counters are not collectable inside this process: see traffic_from_profiles",
+                       "traffic_from_profiles": profile_traffic(args.envs)}
+    if learn_us:
+        res["roofline_update"] = {"kernels": "sample + fwd_l2/bwd_l2/wgrad/adam (one learn)", "bound": "mfma", "unit": "TFLOP/s",
+                                  "achieved": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
+                                  "frac": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 5),
+                                  "us_per_learn": round(learn_us, 2)}
+    if act_us:
+        peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS
+        res["roofline_act"] = {"kernels": "act_fused_kernel", "bound": "mfma", "unit": "TFLOP/s",
+                               "achieved": round(ACTOR_FLOP * args.envs / act_us / 1e6, 3), "peak": peak,
+                               "frac": round(ACTOR_FLOP * args.envs / act_us / 1e6 / peak, 5), "us": round(act_us, 2)}
+    if world > 1:  # the replicas must still be bit-identical after every sharded update so far
         mine = torch.tensor([loop.eng.replica_checksum()], dtype=torch.int64, device=device)
         every = [torch.zeros_like(mine) for _ in range(world)]
         torch.distributed.all_gather(every, mine)
         res["replicas_identical"] = bool(all(int(c.item()) == int(mine.item()) for c in every))
+        ids = [None] * world
+        torch.distributed.all_gather_object(ids, (socket.gethostname(), str(getattr(torch.cuda.get_device_properties(local), "uuid", local))))
+        res["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(), "backend": backend, "distinct_gpus": len(set(ids)),
+                             "exchange": getattr(loop.eng, "exchange_name", "rccl")}
     if ar_events:  # SURVEY.md 8d "collective bytes": per message size, median us and bus bandwidth 2 (n-1)/n * bytes / t
         by = {}
         for nbytes, a, b in ar_events:
@@ -421,14 +685,30 @@ def main():
                              "busbw_GBps": round(2 * (world - 1) / world * k / float(np.median(v)) / 1e3, 2)} for k, v in sorted(by.items())]
     res["env_stats"] = loop.env.stats_dict()
     if rank == 0:
-        if args.sweep:
+        if not args.no_sweep:
             res["roofline_env_sweep"] = env_sweep(device)
-        if world == 1 and not args.no_cpu_baseline and args.agent == "hirl":
-            res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        if world == 1 and not args.no_cpu_baseline:
+            model, cores = host_cpu()
+            budget = max(args.cpu_seconds, 1.0)
+            if args.agent == "hirl":
+                res["cpu_baseline"] = baseline_port(args, 0.5 * budget)
+                res["cpu_baseline"]["host"] = f"{model}, {cores} logical cores"
+                res["cpu_baseline"]["b0_reference_plumbing"] = baseline_reference_plumbing(0.3 * budget)
+                res["cpu_baseline"]["b2_eager_rocm_learn"] = baseline_eager_rocm_learn(args, 0.2 * budget, device)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    launched = "WORLD_SIZE" in os.environ or "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        return launch_ranks(args, argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -22,7 +22,12 @@ _vp, _i32, _i64, _u32, _u64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_in
 class HxStepOpts(ctypes.Structure):
     _fields_ = [("max_step", _i32), ("auto_reset", _i32), ("randomize", _i32), ("env_id0", _u32), ("seed", _u64),
                 ("episode_ctr", _vp), ("ring", _vp), ("ring_success", _vp), ("cap", _i64), ("total", _vp), ("stats", _vp),
-                ("ev_start", _vp), ("ev_stop", _vp)]
+                ("ev_start", _vp), ("ev_stop", _vp), ("layout", _i32)]
+
+
+def layout(pair, envs_per_block):
+    """HX_LAYOUT(pair, envs_per_block) of include/hirl4ucav.h: force the env-step launch shape (0 = library's choice)."""
+    return ((1 if pair else 0) << 8) | (int(envs_per_block) // 4)
 
 
 class HxError(RuntimeError):

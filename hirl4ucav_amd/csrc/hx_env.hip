@@ -23,8 +23,7 @@
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kWaves = kBlock / 64;
+constexpr int kBlock = 256;  // reset / rearm / label / sim_* kernels
 
 using namespace hxenv;
 
@@ -37,128 +36,156 @@ struct StepArgs {
     uint8_t* done;
     int8_t* success;
     HxStepOpts o;
+    double inv_cap;  // 1 / o.cap
 };
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 
-// Cooperative, fully coalesced copy of `count` floats between a row-major global tile and LDS.
-__device__ __forceinline__ void tile_load(float* __restrict__ lds, const float* __restrict__ g, int count) {
-    for (int e = threadIdx.x; e < count; e += kBlock) lds[e] = g[e];
-}
-__device__ __forceinline__ void tile_store(float* __restrict__ g, const float* __restrict__ lds, int count) {
-    for (int e = threadIdx.x; e < count; e += kBlock) g[e] = lds[e];
+// Copy `count` (<= FULL) floats between a row-major global tile and LDS, 16 B per lane with a fixed trip count (every load is
+// requested before the first store needs it); the last `count % 4` floats of a ragged final tile go as dwords.
+// Both ends are 16-B aligned: tiles start at multiples of 32 envs x 13 floats.
+template <int THREADS, int FULL>
+__device__ __forceinline__ void tile_copy(float* __restrict__ dst, const float* __restrict__ src, int count, int tid) {
+    constexpr int TRIPS = (FULL / 4 + THREADS - 1) / THREADS;
+    const int n4 = count >> 2;
+#pragma unroll
+    for (int it = 0; it < TRIPS; ++it) {
+        const int k = tid + it * THREADS;
+        if (k < n4) reinterpret_cast<float4*>(dst)[k] = reinterpret_cast<const float4*>(src)[k];
+    }
+    if (tid < (count & 3)) dst[4 * n4 + tid] = src[4 * n4 + tid];
 }
 
-template <bool INSERT>
-__global__ __launch_bounds__(kBlock) void env_step_kernel(StepArgs A) {
-    // one LDS object: [obs tile 256*13][row tile 256*33 (INSERT)] + small scratch
-    constexpr int kObsTile = kBlock * HX_OBS_DIM;
-    constexpr int kRowPitch = HX_ROW_WORDS + 1;  // +1: conflict-free per-lane row writes
-    __shared__ float lds[kObsTile + (INSERT ? kBlock * kRowPitch : 0)];
-    __shared__ unsigned long long s_base;
-    __shared__ int s_wcount[kWaves];
-    __shared__ unsigned s_stat[kWaves][HX_STAT_COUNT];
+// HarfangEnv.step for EPB envs per workgroup.  PAIR: two adjacent lanes per env (hx_env_dev.h), EPB * 2 threads; else one lane per
+// env.  The row-major observation tile (and with INSERT the replay rows) meet in LDS so that every global access of the
+// workgroup is a contiguous run: SoA state words 256 B (128 B x 2 with PAIR) per wave-instruction, tiles 16 B per lane.
+template <bool PAIR, bool INSERT, int EPB>
+__global__ __launch_bounds__(EPB*(PAIR ? 2 : 1)) void env_step_kernel(StepArgs A) {
+    constexpr int THREADS = EPB * (PAIR ? 2 : 1);
+    constexpr int WAVES = THREADS / 64;
+    constexpr int kObsTile = EPB * HX_OBS_DIM;
+    __shared__ float lds[kObsTile + (INSERT ? EPB * kRowPitch : 0)];
+    __shared__ unsigned s_slot0;  // ring slot of the workgroup's first row
+    __shared__ int s_wcount[WAVES];
+    __shared__ unsigned s_stat[WAVES][HX_STAT_COUNT];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
-    const int64_t i0 = (int64_t)blockIdx.x * kBlock;
-    const int64_t i = i0 + tid;
-    const int nblk = (int)((A.n - i0) < kBlock ? (A.n - i0) : kBlock);
-    const bool active = tid < nblk;
+    const int e = PAIR ? tid >> 1 : tid;       // env of this lane inside the tile
+    const bool is_opp = PAIR && (tid & 1);     // the lane that owns the opponent aircraft
+    const bool own = !is_opp;                  // the env lane: ally, missile, targeting, wrapper
+    const int64_t i0 = (int64_t)blockIdx.x * EPB;
+    const int64_t i = i0 + e;
+    const int nblk = (int)((A.n - i0) < EPB ? (A.n - i0) : EPB);
+    const bool active = e < nblk;
     float* s_obs = lds;
     float* s_row = lds + kObsTile;
 
-    if (INSERT) tile_load(s_obs, A.obs_io + i0 * HX_OBS_DIM, nblk * HX_OBS_DIM);
+    if (INSERT) tile_copy<THREADS, kObsTile>(s_obs, A.obs_io + i0 * HX_OBS_DIM, nblk * HX_OBS_DIM, tid);
 
-    Env E;
+    Stepper<PAIR> T;
     float4 act = {0.f, 0.f, 0.f, 0.f};
     bool trunc = false, store = false;
     if (active) {
-        load_env(E, A.state, A.stride, i0, (uint32_t)tid);
+        T.load(A.state, A.stride, i0, (uint32_t)e, is_opp);
         act = reinterpret_cast<const float4*>(A.actions)[i];
-        uint32_t ep = E.counters & 0xFFFFu;
+        uint32_t ep = T.episode_step();
         ep = ep < 65535u ? ep + 1u : ep;
         trunc = A.o.max_step > 0 && (int)ep >= A.o.max_step;  // train_all.py:346-347
         store = INSERT && !trunc;
     }
-    // ring slots: ballot -> per-wave rank -> one atomic per workgroup (issued before the arithmetic)
+    // ring slots: ballot over the env lanes -> per-wave rank -> one atomic per workgroup (issued before the arithmetic)
     int rank = 0, nstore = 0;
     if (INSERT) {
-        const unsigned long long b = __ballot(store);
-        rank = __popcll(b & ((1ull << lane_id()) - 1ull));
+        const unsigned long long b = __ballot(store && own);
+        const unsigned below = PAIR ? (lane_id() & ~1u) : lane_id();  // both lanes of a pair get the env's rank
+        rank = __popcll(b & ((1ull << below) - 1ull));
         if (lane_id() == 0) s_wcount[wave] = __popcll(b);
     }
     __syncthreads();
     if (INSERT) {
         int before = 0;
-        for (int w = 0; w < kWaves; ++w) {
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
             before += (w < wave) ? s_wcount[w] : 0;
             nstore += s_wcount[w];
         }
         rank += before;
-        if (tid == 0 && nstore > 0) s_base = atomicAdd((unsigned long long*)A.o.total, (unsigned long long)nstore);
+        if (tid == 0 && nstore > 0)
+            s_slot0 = ring_slot(atomicAdd((unsigned long long*)A.o.total, (unsigned long long)nstore), (unsigned long long)A.o.cap, A.inv_cap);
     }
 
-    float reward = 0.0f;
-    int success = 0;
-    bool done = false, ended = false;
-    Observed O;
+    Wrapped W{};
+    V3 eu{}, eu2{};
+    bool ended = false;
     unsigned st_kill = 0, st_fs = 0, st_tl = 0, st_fire = 0, st_good = 0, st_lock = 0;
     if (active) {
-        const bool fire = act.w > 0.0f;  // float(action[3] > 0)  HarfangEnv_GYM.py:150
-        sim_step(E, act.x, act.y, act.z, fire);
-        wrap_step(E, O, reward, success);
-        uint32_t ep = E.counters & 0xFFFFu;
-        ep = ep < 65535u ? ep + 1u : ep;
-        E.counters = (E.counters & 0xFFFF0000u) | ep;
-        done = (E.flags & HX_F_DONE) != 0u;
-        ended = A.o.auto_reset && (done || trunc);
-        st_fire = (E.flags & HX_F_FIRED) ? 1u : 0u;
-        st_good = success == 1 ? 1u : 0u;
-        st_lock = (E.flags & HX_F_LOCKED) ? 1u : 0u;
-        st_kill = (ended && (E.flags & HX_F_EPISODE_SUCCESS)) ? 1u : 0u;
-        st_fs = (ended && (E.flags & HX_F_FIRE_SUCCESS)) ? 1u : 0u;
-        st_tl = (ended && !done) ? 1u : 0u;
-        A.reward[i] = reward;
-        A.done[i] = done ? 1 : 0;
-        A.success[i] = (int8_t)success;
-    }
-    if (INSERT) {
-        if (store) {
+        T.step(act, is_opp, eu, eu2, W);
+        unsigned ended_own = 0;
+        if (own) {
+            ended_own = (A.o.auto_reset && (W.done || trunc)) ? 1u : 0u;
+            st_fire = (T.S.flags & HX_F_FIRED) ? 1u : 0u;
+            st_good = W.success == 1 ? 1u : 0u;
+            st_lock = (T.S.flags & HX_F_LOCKED) ? 1u : 0u;
+            st_kill = (ended_own && (T.S.flags & HX_F_EPISODE_SUCCESS)) ? 1u : 0u;
+            st_fs = (ended_own && (T.S.flags & HX_F_FIRE_SUCCESS)) ? 1u : 0u;
+            st_tl = (ended_own && !W.done) ? 1u : 0u;
+            A.reward[i] = W.reward;
+            A.done[i] = W.done ? 1 : 0;
+            A.success[i] = (int8_t)W.success;
+        }
+        if (PAIR) {
+            const unsigned theirs = swap1u(ended_own);
+            ended = (own ? ended_own : theirs) != 0u;
+        } else {
+            ended = ended_own != 0u;
+        }
+        if (INSERT && store) {
             // row = s[13] a[4] s'[13] r done   (Transition, buffer.py:8; sample() drops step_success :48)
             float* row = s_row + rank * kRowPitch;
-            const float* prev = s_obs + tid * HX_OBS_DIM;
+            if (!PAIR || is_opp) {  // the previous observation: copied by the opponent lane (PAIR) while its partner finishes the wrapper
+                const float* prev = s_obs + e * HX_OBS_DIM;
 #pragma unroll
-            for (int j = 0; j < HX_OBS_DIM; ++j) row[j] = prev[j];
-            row[13] = act.x;
-            row[14] = act.y;
-            row[15] = act.z;
-            row[16] = act.w;
-#pragma unroll
-            for (int j = 0; j < HX_OBS_DIM; ++j) row[17 + j] = O.obs[j];
-            row[30] = reward;
-            row[31] = done ? 1.0f : 0.0f;
+                for (int j = 0; j < HX_OBS_DIM; ++j) row[j] = prev[j];
+            }
+            if (own) {
+                row[13] = act.x; row[14] = act.y; row[15] = act.z; row[16] = act.w;
+                row[17] = W.o0; row[18] = W.o1; row[19] = W.o2;
+                row[20] = eu.x; row[21] = eu.y; row[22] = eu.z;
+                row[23] = W.o6; row[24] = W.o7; row[25] = W.o8;
+                row[29] = W.o12;
+                row[30] = W.reward;
+                row[31] = W.done ? 1.0f : 0.0f;
+            }
+            if (!PAIR) { row[26] = eu2.x; row[27] = eu2.y; row[28] = eu2.z; }
+            else if (is_opp) { row[26] = eu.x; row[27] = eu.y; row[28] = eu.z; }
         }
     }
-    __syncthreads();  // every lane has consumed its previous observation; rows complete; s_base visible
-    if (INSERT && store && A.o.ring_success) {
-        A.o.ring_success[(s_base + (unsigned long long)rank) % (unsigned long long)A.o.cap] = (int8_t)success;
-    }
+    __syncthreads();  // every lane has consumed its previous observation; rows complete; s_slot0 visible
+    if (INSERT && store && own && A.o.ring_success) A.o.ring_success[wrap_slot(s_slot0 + (unsigned)rank, (unsigned)A.o.cap)] = (int8_t)W.success;
     if (active) {
         if (ended) {
-            const uint32_t scen = (E.flags >> HX_F_SCEN_SHIFT) & 3u;
-            const uint32_t epi = A.o.episode_ctr[i] + 1u;
-            A.o.episode_ctr[i] = epi;
-            env_reset(E, scen, A.o.randomize != 0, A.o.seed, A.o.env_id0 + (uint32_t)i, epi);
-            observe(E, O);
+            uint32_t epi = 0u;
+            if (own) {
+                epi = A.o.episode_ctr[i] + 1u;
+                A.o.episode_ctr[i] = epi;
+            }
+            T.reset(is_opp, A.o.randomize != 0, A.o.seed, A.o.env_id0 + (uint32_t)i, epi, eu, eu2, W);
         }
-        store_env(E, A.state, A.stride, i0, (uint32_t)tid);
-        float* out = s_obs + tid * HX_OBS_DIM;
-#pragma unroll
-        for (int j = 0; j < HX_OBS_DIM; ++j) out[j] = O.obs[j];
+        T.store(A.state, A.stride, i0, (uint32_t)e, is_opp);
+        float* out = s_obs + e * HX_OBS_DIM;
+        if (own) {
+            out[0] = W.o0; out[1] = W.o1; out[2] = W.o2;
+            out[3] = eu.x; out[4] = eu.y; out[5] = eu.z;
+            out[6] = W.o6; out[7] = W.o7; out[8] = W.o8;
+            out[12] = W.o12;
+        }
+        if (!PAIR) { out[9] = eu2.x; out[10] = eu2.y; out[11] = eu2.z; }
+        else if (is_opp) { out[9] = eu.x; out[10] = eu.y; out[11] = eu.z; }
     }
     if (A.o.stats) {
-        const unsigned vals[HX_STAT_COUNT] = {ended ? 1u : 0u, st_kill, st_fs, st_tl, st_fire, st_good, st_lock, active ? 1u : 0u};
+        const bool mine = active && own;
+        const unsigned vals[HX_STAT_COUNT] = {(mine && ended) ? 1u : 0u, st_kill, st_fs, st_tl, st_fire, st_good, st_lock, mine ? 1u : 0u};
 #pragma unroll
         for (int k = 0; k < HX_STAT_COUNT; ++k) {
             const unsigned c = (unsigned)__popcll(__ballot(vals[k] != 0u));
@@ -166,23 +193,74 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(StepArgs A) {
         }
     }
     __syncthreads();
-    tile_store(A.obs_io + i0 * HX_OBS_DIM, s_obs, nblk * HX_OBS_DIM);
+    tile_copy<THREADS, kObsTile>(A.obs_io + i0 * HX_OBS_DIM, s_obs, nblk * HX_OBS_DIM, tid);
     if (INSERT && nstore > 0) {
         // 16 B per lane, 1 KiB per wave-instruction, rows contiguous in the ring (modulo wrap)
-        const unsigned long long base = s_base, cap = (unsigned long long)A.o.cap;
+        const unsigned slot0 = s_slot0, cap = (unsigned)A.o.cap;
         float4* ring4 = reinterpret_cast<float4*>(A.o.ring);
-        for (int e = tid; e < nstore * (HX_ROW_WORDS / 4); e += kBlock) {
-            const int r = e >> 3, c = (e & 7) * 4;
-            const float* src = s_row + r * kRowPitch + c;
-            const float4 v = {src[0], src[1], src[2], src[3]};
-            ring4[((base + (unsigned long long)r) % cap) * (HX_ROW_WORDS / 4) + (e & 7)] = v;
+#pragma unroll
+        for (int it = 0; it < EPB * (HX_ROW_WORDS / 4) / THREADS; ++it) {  // fixed trip count: every store is issued before the first waits
+            const int k = tid + it * THREADS;
+            if (k < nstore * (HX_ROW_WORDS / 4)) {
+                const int r = k >> 3, c = (k & 7) * 4;
+                const float* src = s_row + r * kRowPitch + c;
+                const float4 v = {src[0], src[1], src[2], src[3]};
+                ring4[(size_t)wrap_slot(slot0 + (unsigned)r, cap) * (HX_ROW_WORDS / 4) + (k & 7)] = v;
+            }
         }
     }
     if (A.o.stats && tid < HX_STAT_COUNT) {
         unsigned c = 0;
-        for (int w = 0; w < kWaves; ++w) c += s_stat[w][tid];
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) c += s_stat[w][tid];
         if (c) atomicAdd((unsigned long long*)&A.o.stats[tid], (unsigned long long)c);
     }
+}
+
+// Launch shape by size (measured on MI355X, profiles/r02a_env_sweep.jsonl): two lanes per env everywhere (half the dependent chain,
+// ~66 VGPRs instead of ~98); envs per workgroup so that a launch has about 64..256 workgroups while it is latency-bound (4,096
+// envs: 6.4 us with 64 envs per workgroup, 7.6 with 256) and 256 once it is bandwidth-bound (>= 64k envs: one ring-head atomic per 256
+// rows, 6 workgroups per CU).  Up to 256 envs ONE workgroup steps them all, which keeps the replay insert order — and with it a whole
+// training run — reproducible bit for bit.
+struct Layout {
+    bool pair;
+    int epb;
+};
+inline Layout pick_layout(int64_t n, int32_t forced) {
+    if (forced) return Layout{(forced >> 8) != 0, (forced & 0xFF) * 4};
+    if (n <= 256) return Layout{true, 256};
+    if (n <= 8192) return Layout{true, 64};
+    if (n <= 32768) return Layout{true, 128};
+    return Layout{true, 256};
+}
+
+template <bool PAIR, bool INSERT, int EPB>
+void launch_step_shape(const StepArgs& A, hipStream_t st) {
+    const dim3 grid((unsigned)((A.n + EPB - 1) / EPB)), block(EPB * (PAIR ? 2 : 1));
+    if (A.o.ev_start && A.o.ev_stop)
+        hipExtLaunchKernelGGL((env_step_kernel<PAIR, INSERT, EPB>), grid, block, 0, st, (hipEvent_t)A.o.ev_start, (hipEvent_t)A.o.ev_stop, 0, A);
+    else
+        hipLaunchKernelGGL((env_step_kernel<PAIR, INSERT, EPB>), grid, block, 0, st, A);
+}
+template <bool INSERT>
+int launch_step(const StepArgs& A, hipStream_t st) {
+    const Layout L = pick_layout(A.n, A.o.layout);
+    if (L.pair) {
+        switch (L.epb) {
+            case 32: launch_step_shape<true, INSERT, 32>(A, st); return 0;
+            case 64: launch_step_shape<true, INSERT, 64>(A, st); return 0;
+            case 128: launch_step_shape<true, INSERT, 128>(A, st); return 0;
+            case 256: launch_step_shape<true, INSERT, 256>(A, st); return 0;
+            case 512: launch_step_shape<true, INSERT, 512>(A, st); return 0;
+        }
+    } else {
+        switch (L.epb) {
+            case 64: launch_step_shape<false, INSERT, 64>(A, st); return 0;
+            case 128: launch_step_shape<false, INSERT, 128>(A, st); return 0;
+            case 256: launch_step_shape<false, INSERT, 256>(A, st); return 0;
+        }
+    }
+    return -1;
 }
 
 struct ResetArgs {
@@ -207,16 +285,16 @@ __global__ __launch_bounds__(kBlock) void env_reset_kernel(ResetArgs A) {
     env_reset(E, scen, A.randomize != 0, A.seed, A.env_id0 + (uint32_t)i, epi);
     store_env(E, A.state, A.stride, (int64_t)blockIdx.x * kBlock, threadIdx.x);
     if (A.obs) {
-        Observed O;
-        observe(E, O);
-        for (int j = 0; j < HX_OBS_DIM; ++j) A.obs[i * HX_OBS_DIM + j] = O.obs[j];
+        float o[HX_OBS_DIM];
+        observe(E, o);
+        for (int j = 0; j < HX_OBS_DIM; ++j) A.obs[i * HX_OBS_DIM + j] = o[j];
     }
 }
 
 __global__ __launch_bounds__(kBlock) void env_rearm_kernel(float* state, int64_t n, int64_t stride, const uint8_t* mask) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n || (mask && !mask[i])) return;
-    const uint32_t f = __float_as_uint(state[35 * stride + i]) | HX_F_SIM_SLOT;
+    const uint32_t f = __float_as_uint(state[35 * stride + i]) | HX_F_SIM_SLOT;  // df.rearm_machine
     state[35 * stride + i] = __uint_as_float(f);
 }
 
@@ -241,20 +319,18 @@ __global__ __launch_bounds__(kBlock) void sim_readback_kernel(const float* state
     if (i >= n) return;
     Env E;
     load_env(E, state, stride, i0, threadIdx.x);
-    Observed O;
-    observe(E, O);
+    const Axes A = quat_axes(E.ally.qw, E.ally.qx, E.ally.qy, E.ally.qz);
+    const Axes B = quat_axes(E.opp.qw, E.opp.qx, E.opp.qy, E.opp.qz);
+    const V3 ea = euler_rad(A), eo = euler_rad(B);  // radians, as GET_PLANE_STATE reports them
     float* o = out + i * 16;
     o[0] = E.ally.p.x; o[1] = E.ally.p.y; o[2] = E.ally.p.z;
-    float p, h, r;
-    euler_of(E.ally, p, h, r);
-    o[3] = p; o[4] = h; o[5] = r;
+    o[3] = ea.x; o[4] = ea.y; o[5] = ea.z;
     o[6] = E.opp.p.x; o[7] = E.opp.p.y; o[8] = E.opp.p.z;
-    euler_of(E.opp, p, h, r);
-    o[9] = p; o[10] = h; o[11] = r;
-    o[12] = O.target_angle * 180.0f;
-    o[13] = E.health;
-    o[14] = E.lock_timer >= kLockDelay ? 1.0f : 0.0f;
-    o[15] = (E.flags & HX_F_SIM_SLOT) ? 1.0f : 0.0f;
+    o[9] = eo.x; o[10] = eo.y; o[11] = eo.z;
+    o[12] = target_angle_deg(geometry(E.ally.p, A.Z, E.opp.p).cosang);
+    o[13] = E.s.health;
+    o[14] = E.s.lock_timer >= kLockDelay ? 1.0f : 0.0f;
+    o[15] = (E.s.flags & HX_F_SIM_SLOT) ? 1.0f : 0.0f;
 }
 
 // get_reward / get_termination  HarfangEnv_GYM.py:299-336
@@ -306,24 +382,20 @@ int hx_env_step(float* state, int64_t n, int64_t stride, const float* actions, f
     HX_REQUIRE(state && actions && obs_io && reward && done && success, "hx_env_step: null buffer");
     HX_REQUIRE(n > 0 && stride >= n, "hx_env_step: bad n/stride");
     HX_REQUIRE((reinterpret_cast<uintptr_t>(actions) & 15u) == 0, "hx_env_step: actions must be 16-byte aligned");
-    StepArgs A{state, n, stride, actions, obs_io, reward, done, success, HxStepOpts{}};
+    StepArgs A{state, n, stride, actions, obs_io, reward, done, success, HxStepOpts{}, 0.0};
     if (opts) A.o = *opts;
+    HX_REQUIRE(stride < ((int64_t)1 << 25), "hx_env_step: stride must be below 2^25 envs (32-bit byte offsets inside a launch)");
     HX_REQUIRE(!A.o.auto_reset || A.o.episode_ctr, "hx_env_step: auto_reset needs episode_ctr");
+    int rc;
     if (A.o.ring) {
-        HX_REQUIRE(A.o.cap > 0 && A.o.total, "hx_env_step: ring needs cap and total");
+        HX_REQUIRE(A.o.cap >= 512 && A.o.cap < ((int64_t)1 << 31) && A.o.total, "hx_env_step: ring needs 512 <= cap < 2^31 and total");
+        A.inv_cap = 1.0 / (double)A.o.cap;
         HX_REQUIRE((reinterpret_cast<uintptr_t>(A.o.ring) & 15u) == 0, "hx_env_step: ring must be 16-byte aligned");
-        if (A.o.ev_start && A.o.ev_stop)
-            hipExtLaunchKernelGGL(env_step_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
-                                  (hipEvent_t)A.o.ev_start, (hipEvent_t)A.o.ev_stop, 0, A);
-        else
-            hipLaunchKernelGGL(env_step_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, A);
+        rc = launch_step<true>(A, (hipStream_t)stream);
     } else {
-        if (A.o.ev_start && A.o.ev_stop)
-            hipExtLaunchKernelGGL(env_step_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
-                                  (hipEvent_t)A.o.ev_start, (hipEvent_t)A.o.ev_stop, 0, A);
-        else
-            hipLaunchKernelGGL(env_step_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, A);
+        rc = launch_step<false>(A, (hipStream_t)stream);
     }
+    HX_REQUIRE(rc == 0, "hx_env_step: unknown layout %d", A.o.layout);
     HX_CHECK_LAUNCH("hx_env_step");
     return 0;
 }

@@ -448,6 +448,7 @@ struct ActFusedArgs {
     uint8_t* done;
     int8_t* success;
     HxStepOpts o;
+    double inv_cap;  // 1 / o.cap
 };
 
 constexpr int ACT_KC = 16;            // k-chunk of W2 staged through LDS (64 B per column), double-buffered
@@ -477,7 +478,7 @@ template <int NRT, bool GAUSS, bool ENV>
 __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     constexpr int ROWS = NRT * RT;
     __shared__ float s_act[ENV ? ROWS * 4 : 4];
-    __shared__ unsigned long long s_base;
+    __shared__ unsigned s_base;  // ring slot of the workgroup's first row
     __shared__ int s_nstore;
     static_assert(2 * H2 * ACT_LDW >= ROWS * LDA2, "the z2 tile reuses the W2 chunk buffers");
     __shared__ __attribute__((aligned(16))) float lds[ROWS * LDA1 + ROWS * XP + ROWS * 2 + H1 * 13 + 2 * H2 * ACT_LDW];
@@ -616,13 +617,16 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     }
     __syncthreads();
     STAMP();
-    // ENV: the env lanes (wave 0) request their state words and current observation now — the head phase hides the round trip
-    hxenv::Env envE;
+    // ENV: the env lanes (wave 0, two lanes per env: hx_env_dev.h "Pair") request their state words and the current observation
+    // now — the head phase hides the round trip
+    hxenv::Stepper<true> envT;
     float envPrev[HX_OBS_DIM];
-    if (ENV && wave == 0 && lane < nrow) {
-        hxenv::load_env(envE, A.state, A.stride, r0, (uint32_t)lane);
+    const int env_e = lane >> 1;            // env of this lane inside the workgroup's rows
+    const bool env_opp = (lane & 1) != 0;   // this lane owns the opponent aircraft
+    if (ENV && wave == 0 && env_e < nrow) {
+        envT.load(A.state, A.stride, r0, (uint32_t)env_e, env_opp);
 #pragma unroll
-        for (int j = 0; j < HX_OBS_DIM; ++j) envPrev[j] = A.o.ring ? A.obs[((size_t)r0 + lane) * HX_OBS_DIM + j] : 0.0f;
+        for (int j = 0; j < HX_OBS_DIM; ++j) envPrev[j] = (A.o.ring && env_opp) ? A.obs[((size_t)r0 + env_e) * HX_OBS_DIM + j] : 0.0f;
     }
 #pragma unroll
     for (int t = 0; t < NRT; ++t) {  // head: wave w owns rows w, 16 + w
@@ -665,89 +669,101 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     }
     if (ENV) {
         using namespace hxenv;
-        constexpr int kRowPitch = HX_ROW_WORDS + 1;
         float* s_row = wb1;                    // [ROWS][33] replay rows   (the odd chunk buffer is free since the last barrier)
         float* s_obs = wb1 + ROWS * kRowPitch;  // [ROWS][13] next observations
         __syncthreads();  // actions of all rows in s_act
-        if (wave == 0) {
-            const int e = lane;
+        if (wave == 0 && lane < 2 * ROWS) {
+            const int e = env_e;
+            const bool is_opp = env_opp, own = !env_opp;
             const bool active = e < nrow;
             const int64_t i = (int64_t)r0 + e;
             const bool insert = A.o.ring != nullptr;
-            Env& E = envE;
+            Stepper<true>& T = envT;
             float4 act = {0.f, 0.f, 0.f, 0.f};
-            float (&prev)[HX_OBS_DIM] = envPrev;
             bool trunc = false, store = false;
             if (active) {
                 act = *reinterpret_cast<const float4*>(s_act + e * 4);
-                uint32_t ep = E.counters & 0xFFFFu;
+                uint32_t ep = T.episode_step();
                 ep = ep < 65535u ? ep + 1u : ep;
                 trunc = A.o.max_step > 0 && (int)ep >= A.o.max_step;  // train_all.py:346-347
                 store = insert && !trunc;
             }
             // ring slots: one atomic per workgroup, issued before the arithmetic that hides its latency
-            const unsigned long long bal = __ballot(store);
-            const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+            const unsigned long long bal = __ballot(store && own);
+            const int rank = __popcll(bal & ((1ull << (lane & ~1)) - 1ull));  // both lanes of a pair get the env's rank
             const int nstore = __popcll(bal);
             unsigned long long base = 0ull;
             if (lane == 0 && nstore > 0) base = atomicAdd((unsigned long long*)A.o.total, (unsigned long long)nstore);
-            float reward = 0.0f;
-            int success = 0;
-            bool done = false, ended = false;
-            Observed O;
+            Wrapped W{};
+            V3 eu{}, eu2{};
+            bool ended = false;
             unsigned st_kill = 0, st_fs = 0, st_tl = 0, st_fire = 0, st_good = 0, st_lock = 0;
             if (active) {
-                const bool fire = act.w > 0.0f;  // float(action[3] > 0)  HarfangEnv_GYM.py:150
-                sim_step(E, act.x, act.y, act.z, fire);
-                wrap_step(E, O, reward, success);
-                uint32_t ep = E.counters & 0xFFFFu;
-                ep = ep < 65535u ? ep + 1u : ep;
-                E.counters = (E.counters & 0xFFFF0000u) | ep;
-                done = (E.flags & HX_F_DONE) != 0u;
-                ended = A.o.auto_reset && (done || trunc);
-                st_fire = (E.flags & HX_F_FIRED) ? 1u : 0u;
-                st_good = success == 1 ? 1u : 0u;
-                st_lock = (E.flags & HX_F_LOCKED) ? 1u : 0u;
-                st_kill = (ended && (E.flags & HX_F_EPISODE_SUCCESS)) ? 1u : 0u;
-                st_fs = (ended && (E.flags & HX_F_FIRE_SUCCESS)) ? 1u : 0u;
-                st_tl = (ended && !done) ? 1u : 0u;
-                A.reward[i] = reward;
-                A.done[i] = done ? 1 : 0;
-                A.success[i] = (int8_t)success;
+                T.step(act, is_opp, eu, eu2, W);
+                unsigned ended_own = 0;
+                if (own) {
+                    ended_own = (A.o.auto_reset && (W.done || trunc)) ? 1u : 0u;
+                    st_fire = (T.S.flags & HX_F_FIRED) ? 1u : 0u;
+                    st_good = W.success == 1 ? 1u : 0u;
+                    st_lock = (T.S.flags & HX_F_LOCKED) ? 1u : 0u;
+                    st_kill = (ended_own && (T.S.flags & HX_F_EPISODE_SUCCESS)) ? 1u : 0u;
+                    st_fs = (ended_own && (T.S.flags & HX_F_FIRE_SUCCESS)) ? 1u : 0u;
+                    st_tl = (ended_own && !W.done) ? 1u : 0u;
+                    A.reward[i] = W.reward;
+                    A.done[i] = W.done ? 1 : 0;
+                    A.success[i] = (int8_t)W.success;
+                }
+                const unsigned theirs = swap1u(ended_own);
+                ended = (own ? ended_own : theirs) != 0u;
             }
-            if (store) {  // row = s[13] a[4] s'[13] r done   (Transition, buffer.py:8)
+            if (store) {  // row = s[13] a[4] s'[13] r done   (Transition, buffer.py:8): each lane of the pair writes its share
                 float* row = s_row + rank * kRowPitch;
+                if (is_opp) {
 #pragma unroll
-                for (int j = 0; j < HX_OBS_DIM; ++j) row[j] = prev[j];
-                row[13] = act.x; row[14] = act.y; row[15] = act.z; row[16] = act.w;
-#pragma unroll
-                for (int j = 0; j < HX_OBS_DIM; ++j) row[17 + j] = O.obs[j];
-                row[30] = reward;
-                row[31] = done ? 1.0f : 0.0f;
+                    for (int j = 0; j < HX_OBS_DIM; ++j) row[j] = envPrev[j];
+                    row[26] = eu.x; row[27] = eu.y; row[28] = eu.z;
+                } else {
+                    row[13] = act.x; row[14] = act.y; row[15] = act.z; row[16] = act.w;
+                    row[17] = W.o0; row[18] = W.o1; row[19] = W.o2;
+                    row[20] = eu.x; row[21] = eu.y; row[22] = eu.z;
+                    row[23] = W.o6; row[24] = W.o7; row[25] = W.o8;
+                    row[29] = W.o12;
+                    row[30] = W.reward;
+                    row[31] = W.done ? 1.0f : 0.0f;
+                }
             }
+            // the workgroup's first ring slot, uniform across the wave
+            const unsigned long long b0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(base & 0xFFFFFFFFull));
+            const unsigned slot0 = nstore > 0 ? ring_slot(b0, (unsigned long long)A.o.cap, A.inv_cap) : 0u;
             if (lane == 0) {
-                s_base = base;
+                s_base = slot0;
                 s_nstore = nstore;
             }
-            if (store && A.o.ring_success) {
-                const unsigned long long b0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-                                              (unsigned)__builtin_amdgcn_readfirstlane((int)(base & 0xFFFFFFFFull));
-                A.o.ring_success[(b0 + (unsigned long long)rank) % (unsigned long long)A.o.cap] = (int8_t)success;
-            }
+            if (store && own && A.o.ring_success) A.o.ring_success[wrap_slot(slot0 + (unsigned)rank, (unsigned)A.o.cap)] = (int8_t)W.success;
             if (active) {
                 if (ended) {
-                    const uint32_t scen = (E.flags >> HX_F_SCEN_SHIFT) & 3u;
-                    const uint32_t epi = A.o.episode_ctr[i] + 1u;
-                    A.o.episode_ctr[i] = epi;
-                    env_reset(E, scen, A.o.randomize != 0, A.o.seed, A.o.env_id0 + (uint32_t)i, epi);
-                    observe(E, O);
+                    uint32_t epi = 0u;
+                    if (own) {
+                        epi = A.o.episode_ctr[i] + 1u;
+                        A.o.episode_ctr[i] = epi;
+                    }
+                    T.reset(is_opp, A.o.randomize != 0, A.o.seed, A.o.env_id0 + (uint32_t)i, epi, eu, eu2, W);
                 }
-                store_env(E, A.state, A.stride, r0, (uint32_t)e);
-#pragma unroll
-                for (int j = 0; j < HX_OBS_DIM; ++j) s_obs[e * HX_OBS_DIM + j] = O.obs[j];
+                T.store(A.state, A.stride, r0, (uint32_t)e, is_opp);
+                float* out = s_obs + e * HX_OBS_DIM;
+                if (own) {
+                    out[0] = W.o0; out[1] = W.o1; out[2] = W.o2;
+                    out[3] = eu.x; out[4] = eu.y; out[5] = eu.z;
+                    out[6] = W.o6; out[7] = W.o7; out[8] = W.o8;
+                    out[12] = W.o12;
+                } else {
+                    out[9] = eu.x; out[10] = eu.y; out[11] = eu.z;
+                }
             }
             if (A.o.stats) {
-                const unsigned vals[HX_STAT_COUNT] = {ended ? 1u : 0u, st_kill, st_fs, st_tl, st_fire, st_good, st_lock, active ? 1u : 0u};
+                const bool mine_ = active && own;
+                const unsigned vals[HX_STAT_COUNT] = {(mine_ && ended) ? 1u : 0u, st_kill, st_fs, st_tl, st_fire, st_good, st_lock, mine_ ? 1u : 0u};
                 unsigned mine = 0;
 #pragma unroll
                 for (int k = 0; k < HX_STAT_COUNT; ++k) {
@@ -761,12 +777,12 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         for (int k = tid; k < nrow * HX_OBS_DIM; k += kWide) A.obs[(size_t)r0 * HX_OBS_DIM + k] = s_obs[k];
         const int nstore = s_nstore;
         if (nstore > 0) {  // 16 B per lane, rows contiguous in the ring (modulo wrap)
-            const unsigned long long base = s_base, cap = (unsigned long long)A.o.cap;
+            const unsigned slot0 = s_base, cap = (unsigned)A.o.cap;
             float4* ring4 = reinterpret_cast<float4*>(A.o.ring);
             for (int k = tid; k < nstore * (HX_ROW_WORDS / 4); k += kWide) {
                 const int rr = k >> 3, c = (k & 7) * 4;
                 const float* src = s_row + rr * kRowPitch + c;
-                ring4[((base + (unsigned long long)rr) % cap) * (HX_ROW_WORDS / 4) + (k & 7)] = make_float4(src[0], src[1], src[2], src[3]);
+                ring4[(size_t)wrap_slot(slot0 + (unsigned)rr, cap) * (HX_ROW_WORDS / 4) + (k & 7)] = make_float4(src[0], src[1], src[2], src[3]);
             }
         }
     }
@@ -1839,7 +1855,7 @@ int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* acti
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act: bad noise mode");
     (void)ws;
     ActFusedArgs H{actor, kActor, const_cast<float*>(obs), (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
-                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}};
+                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0};
     launch_act<false>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_actor_act");
     return 0;
@@ -1850,7 +1866,9 @@ static int check_step_args(const float* state, int64_t n, int64_t stride, const 
     HX_REQUIRE(state && obs_io && actions && reward && done && success && n > 0 && stride >= n, "%s: bad buffers", who);
     HX_REQUIRE(n < (int64_t)1 << 31, "%s: at most 2^31 - 1 envs per launch", who);
     HX_REQUIRE(!o.auto_reset || o.episode_ctr, "%s: auto_reset needs episode_ctr", who);
-    HX_REQUIRE(!o.ring || (o.cap > 0 && o.total && (reinterpret_cast<uintptr_t>(o.ring) & 15u) == 0), "%s: ring needs cap, total and 16-byte alignment", who);
+    HX_REQUIRE(stride < ((int64_t)1 << 25), "%s: stride must be below 2^25 envs", who);
+    HX_REQUIRE(!o.ring || (o.cap >= 512 && o.cap < ((int64_t)1 << 31) && o.total && (reinterpret_cast<uintptr_t>(o.ring) & 15u) == 0),
+               "%s: ring needs 512 <= cap < 2^31, total and 16-byte alignment", who);
     return 0;
 }
 
@@ -1868,7 +1886,8 @@ int hx_actor_act_step(const float* actor, float* state, int64_t n, int64_t strid
         return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
     }
     ActFusedArgs H{actor, kActor, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
-                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o};
+                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
+                   o.cap > 0 ? 1.0 / (double)o.cap : 0.0};
     launch_act<false>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_actor_act_step");
     return 0;
@@ -2180,7 +2199,7 @@ int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actio
     HX_REQUIRE(policy && obs && actions && rows > 0 && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act: bad arguments");
     (void)ws;
     ActFusedArgs H{policy, kPolicy, const_cast<float*>(obs), (int)rows, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
-                   nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}};
+                   nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0};
     launch_act<true>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_sac_act");
     return 0;
@@ -2198,7 +2217,7 @@ int hx_sac_act_step(const float* policy, float* state, int64_t n, int64_t stride
         return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
     }
     ActFusedArgs H{policy, kPolicy, obs_io, (int)n, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
-                   state, stride, reward, done, success, o};
+                   state, stride, reward, done, success, o, o.cap > 0 ? 1.0 / (double)o.cap : 0.0};
     launch_act<true>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_sac_act_step");
     return 0;

@@ -16,7 +16,7 @@ SCENARIOS = {"straight_line": 0, "serpentine": 1, "circular": 2}
 
 class BatchedHarfangEnv:
     def __init__(self, num_envs, scenario="straight_line", device="cuda", seed=0, max_step=0, auto_reset=True,
-                 random_reset=True, env_id0=0, replay=None, collect_stats=True):
+                 random_reset=True, env_id0=0, replay=None, collect_stats=True, layout=0):
         self.n = int(num_envs)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -40,6 +40,7 @@ class BatchedHarfangEnv:
         self.episode_ctr = torch.zeros(self.n, dtype=torch.int32, device=d)
         self.stats = torch.zeros(len(_lib.STAT_NAMES), dtype=torch.int64, device=d) if collect_stats else None
         self.replay = replay
+        self.layout = int(layout)  # 0: the library picks the launch shape; _lib.layout(pair, envs_per_block) forces one (tests, tuning)
         self._opts = _lib.HxStepOpts()
         self._refresh_opts()
 
@@ -52,6 +53,7 @@ class BatchedHarfangEnv:
         o.ring, o.ring_success = (_lib.ptr(r.ring), _lib.ptr(r.success)) if r is not None else (None, None)
         o.cap, o.total = (r.capacity, _lib.ptr(r.total)) if r is not None else (0, None)
         o.stats = _lib.ptr(self.stats)
+        o.layout = self.layout
 
     def reset(self, mask=None):
         """reset() / random_reset() of every env (or of the envs with mask != 0) -> obs [N, 13]."""

@@ -85,7 +85,11 @@ typedef struct HxStepOpts {
     uint64_t* stats;       /* [HX_STAT_COUNT] or NULL */
     void* ev_start;        /* measurement only (host handles from hx_event_create, or NULL): the launch stamps the kernel's own */
     void* ev_stop;         /* begin / end into them — the duration rocprofv3 reports, without the dispatch gap around it */
+    int32_t layout;        /* 0: the library picks the launch shape from n.  HX_LAYOUT(pair, envs_per_block) forces one (tuning,
+                              tests): pair = 1 steps each env on two adjacent lanes (ally + shared | opponent), 0 on one lane;
+                              envs_per_block in {32, 64, 128, 256, 512} (pair) / {64, 128, 256} (solo).  Same results bit for bit. */
 } HxStepOpts;
+#define HX_LAYOUT(pair, envs_per_block) ((((pair) ? 1 : 0) << 8) | ((envs_per_block) / 4))
 
 /* HarfangEnv.reset / random_reset (+ Serpentine/Circular variants): HarfangEnv_GYM.py:34-81,171-188,374-406,440-474.
  * mask: NULL = all envs, else only envs with mask[i] != 0.  scenario: per-env ids (NULL = scenario_all for all).

@@ -22,10 +22,12 @@
  *      project's own, specified in docs/DYNAMICS.md.  **Dynamics parity with Harfang: UNPINNED.**
  *      What is checked for the simulator is GPU == this scalar restatement on identical (state, action).
  *
- * Numerics: fp32 throughout, compiled with -ffp-contract=off so every product and sum rounds once, in
- * the order written here.  State-evolving arithmetic uses only + - * / sqrt (all correctly rounded on
- * both the host and gfx950), so integer masks (done / lock / success) can be compared bit-exactly.
- * libm transcendentals (asinf/atan2f/acosf) appear only in the observation.
+ * Numerics (model v2, docs/DYNAMICS.md): fp32 throughout, compiled with -ffp-contract=off so the compiler
+ * fuses nothing on its own; where the model says "fma" the code calls fmaf() — ONE correctly rounded
+ * operation on the host exactly as v_fma_f32 is on gfx950.  Everything, the inverse trigonometry of the
+ * read-back included (ox_asin / ox_acos / ox_atan2 below: polynomials, not libm), is built from
+ * + - * / sqrt fma, all correctly rounded on both sides, so state words, masks, observations and rewards
+ * can be compared bit for bit.
  *
  * Layout here is array-of-structs on purpose (the product is struct-of-arrays): the oracle is an
  * independent restatement, not a copy of the kernel.
@@ -117,18 +119,73 @@ typedef struct {
 #define PI_F 3.14159265358979323846f
 #define RAD2DEG 57.29577951308232f
 
-static inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
-static inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+#define HALF_PI_F 1.57079632679489661923f
+#define INV_PI_F 0.31830988618379067154f /* Euler angles / pi     constants.py NormStates, HarfangEnv_GYM.py:199-201 */
+#define INV_180_F (1.0f / 180.0f)        /* target_angle / 180    HarfangEnv_GYM.py:234 */
+#define INV_1E4_F 1.0e-4f                /* positions / 10000     HarfangEnv_GYM.py:196-198 */
 
-/* rotation matrix columns (images of body X, Y, Z) of a unit quaternion */
+static inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* a.b accumulated from the x component: fma(az, bz, fma(ay, by, ax*bx)) */
+static inline float dot3(const float* a, const float* b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+
+/* ---- inverse trigonometry of the read-back (docs/DYNAMICS.md "Angles"): max error 1e-7 rad ---------------- */
+static const float ASIN_C[5] = {0.16666673123836517f, 0.07498761266469955f, 0.045020218938589096f, 0.02643335610628128f,
+                                0.038328301161527634f};
+static const float ATAN_C[9] = {1.0f, -0.3333309292793274f, 0.19993053376674652f, -0.14207129180431366f, 0.10654657334089279f,
+                                -0.07533632218837738f, 0.04303884133696556f, -0.01628268137574196f, 0.0029034700710326433f};
+
+/* z P(z), Horner from the highest coefficient */
+static float asin_tail(float z) {
+    float p = ASIN_C[4];
+    for (int k = 3; k >= 0; --k) p = fmaf(p, z, ASIN_C[k]);
+    return p * z;
+}
+/* shared core: |x| <= 1/2: z = x^2, s = |x|;  else z = (1 - |x|)/2, s = sqrt(z);  t = s + s z P(z) */
+static float asin_core(float a, int* big) {
+    *big = a > 0.5f;
+    float z = *big ? fmaf(-0.5f, a, 0.5f) : a * a;
+    float s = *big ? sqrtf(z) : a;
+    return fmaf(s, asin_tail(z), s);
+}
+float ox_asin(float x) {
+    int big;
+    float t = asin_core(fabsf(x), &big);
+    float r = big ? fmaf(-2.0f, t, HALF_PI_F) : t;
+    return x < 0.0f ? -r : r;
+}
+float ox_acos(float x) {
+    int big;
+    float t = asin_core(fabsf(x), &big);
+    if (big) {
+        float t2 = t + t;
+        return x < 0.0f ? PI_F - t2 : t2;
+    }
+    return x < 0.0f ? HALF_PI_F + t : HALF_PI_F - t;
+}
+float ox_atan2(float y, float x) {
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    float a = mx > 0.0f ? mn / mx : 0.0f;
+    float t = a * a;
+    float p = ATAN_C[8];
+    for (int k = 7; k >= 0; --k) p = fmaf(p, t, ATAN_C[k]);
+    float r = a * p;
+    if (ay > ax) r = HALF_PI_F - r;
+    if (x < 0.0f) r = PI_F - r;
+    return y < 0.0f ? -r : r;
+}
+
+/* rotation matrix columns (images of body X, Y, Z) of a unit quaternion:
+ *   X = (1 - 2yy - 2zz, 2xy + 2wz, 2xz - 2wy)   Y = (2xy - 2wz, 1 - 2xx - 2zz, 2yz + 2wx)   Z = (2xz + 2wy, 2yz - 2wx, 1 - 2xx - 2yy)
+ * with the doublings done first (exact) and one fma per remaining product-sum */
 static void quat_axes(const float* q, float* aX, float* aY, float* aZ) {
     const float w = q[0], x = q[1], y = q[2], z = q[3];
-    const float xx = x * x, yy = y * y, zz = z * z;
-    const float xy = x * y, xz = x * z, yz = y * z;
-    const float wx = w * x, wy = w * y, wz = w * z;
-    aX[0] = 1.0f - 2.0f * (yy + zz); aX[1] = 2.0f * (xy + wz);        aX[2] = 2.0f * (xz - wy);
-    aY[0] = 2.0f * (xy - wz);        aY[1] = 1.0f - 2.0f * (xx + zz); aY[2] = 2.0f * (yz + wx);
-    aZ[0] = 2.0f * (xz + wy);        aZ[1] = 2.0f * (yz - wx);        aZ[2] = 1.0f - 2.0f * (xx + yy);
+    const float x2 = x + x, y2 = y + y, z2 = z + z;
+    const float xy2 = x2 * y, xz2 = x2 * z, yz2 = y2 * z;
+    const float ax = fmaf(-x2, x, 1.0f), ay = fmaf(-y2, y, 1.0f);
+    aX[0] = fmaf(-z2, z, ay); aX[1] = fmaf(w, z2, xy2);  aX[2] = fmaf(-w, y2, xz2);
+    aY[0] = fmaf(-w, z2, xy2); aY[1] = fmaf(-z2, z, ax); aY[2] = fmaf(w, x2, yz2);
+    aZ[0] = fmaf(w, y2, xz2);  aZ[1] = fmaf(-w, x2, yz2); aZ[2] = fmaf(-y2, y, ax);
 }
 
 /* Euler angles (pitch about X, heading about Y, roll about Z) of R = Ry(h) Rx(p) Rz(r); pitch > 0 is nose
@@ -136,9 +193,9 @@ static void quat_axes(const float* q, float* aX, float* aY, float* aZ) {
 static void quat_euler(const float* q, float* e) {
     float aX[3], aY[3], aZ[3];
     quat_axes(q, aX, aY, aZ);
-    e[0] = asinf(clampf(-aZ[1], -1.0f, 1.0f));
-    e[1] = atan2f(aZ[0], aZ[2]);
-    e[2] = atan2f(aX[1], aY[1]);
+    e[0] = ox_asin(clampf(-aZ[1], -1.0f, 1.0f));
+    e[1] = ox_atan2(aZ[0], aZ[2]);
+    e[2] = ox_atan2(aX[1], aY[1]);
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -155,10 +212,10 @@ static void plane_tick(OxPlane* P, const float* cmd, float thrust) {
     quat_axes(P->q, aX, aY, aZ);
     /* c. atmosphere, dynamic pressure, control effectiveness */
     float h = clampf(P->pos[1], 0.0f, 30000.0f);
-    float x = 1.0f - LAPSE * h;
+    float x = fmaf(-LAPSE, h, 1.0f);
     x = x < 0.05f ? 0.05f : x;
     float x2 = x * x;
-    float sigma = (x2 * x2) * sqrtf(sqrtf(x));
+    float sigma = (x2 * x2) * fmaf(0.25f, x, 0.75f);
     float hr = RHO0_HALF * sigma;
     float s2 = dot3(P->vel, P->vel);
     float s = sqrtf(s2);
@@ -167,44 +224,52 @@ static void plane_tick(OxPlane* P, const float* cmd, float thrust) {
     /* d. angular velocity: body rates from the levels, wing-leveller, "easy steering" world yaw */
     float wx = (K_PITCH * P->lvl[0]) * eff;
     float wy = (K_YAW * P->lvl[2]) * eff;
-    float wz = (K_ROLL * P->lvl[1]) * eff - K_LEVEL * aX[1];
+    float wz = fmaf(K_ROLL * P->lvl[1], eff, -(K_LEVEL * aX[1]));
     float Om = -((K_EASY * aX[1]) * eff);
-    /* e. attitude: q += dt/2 * ( q (x) (0,w_body) + (0,0,Om,0) (x) q ), renormalise */
+    /* e. attitude: q += dt/2 * ( q (x) (0,w_body) + (0,0,Om,0) (x) q ), renormalise with ONE reciprocal */
     {
         const float qw = P->q[0], qx = P->q[1], qy = P->q[2], qz = P->q[3];
-        float dw = -(qx * wx + qy * wy) - qz * wz;
-        float dx = (qw * wx + qy * wz) - qz * wy;
-        float dy = (qw * wy + qz * wx) - qx * wz;
-        float dz = (qw * wz + qx * wy) - qy * wx;
-        dw = dw - Om * qy;
-        dx = dx + Om * qz;
-        dy = dy + Om * qw;
-        dz = dz - Om * qx;
+        float dq[4];
+        dq[0] = fmaf(-Om, qy, -fmaf(qz, wz, fmaf(qy, wy, qx * wx)));
+        dq[1] = fmaf(Om, qz, fmaf(-qz, wy, fmaf(qy, wz, qw * wx)));
+        dq[2] = fmaf(Om, qw, fmaf(-qx, wz, fmaf(qz, wx, qw * wy)));
+        dq[3] = fmaf(-Om, qx, fmaf(-qy, wx, fmaf(qx, wy, qw * wz)));
         const float hdt = 0.5f * DT;
-        float nw = qw + hdt * dw, nx = qx + hdt * dx, ny = qy + hdt * dy, nz = qz + hdt * dz;
-        float n = sqrtf(((nw * nw + nx * nx) + ny * ny) + nz * nz);
-        P->q[0] = nw / n; P->q[1] = nx / n; P->q[2] = ny / n; P->q[3] = nz / n;
+        float nq[4];
+        for (int c = 0; c < 4; ++c) nq[c] = fmaf(hdt, dq[c], P->q[c]);
+        float n2 = nq[0] * nq[0];
+        for (int c = 1; c < 4; ++c) n2 = fmaf(nq[c], nq[c], n2);
+        float inv = 1.0f / sqrtf(n2);
+        for (int c = 0; c < 4; ++c) P->q[c] = nq[c] * inv;
     }
     /* f. specific forces in body axes (pre-rotation axes) */
     float vbx = dot3(P->vel, aX), vby = dot3(P->vel, aY), vbz = dot3(P->vel, aZ);
     float k = hr * s;
     float fx = -((CD_X * k) * vbx);
-    float fy = (CL_0 * hr) * (vbz * vbz) - (CD_Y * k) * vby;
-    float fz = T_MAX * thrust - (CD_Z * k) * vbz;
+    float fy = fmaf(CL_0 * hr, vbz * vbz, -((CD_Y * k) * vby));
+    float fz = fmaf(-(CD_Z * k), vbz, T_MAX * thrust);
     float acc[3];
-    for (int c = 0; c < 3; ++c) acc[c] = (aX[c] * fx + aY[c] * fy) + aZ[c] * fz;
+    for (int c = 0; c < 3; ++c) acc[c] = fmaf(aZ[c], fz, fmaf(aY[c], fy, aX[c] * fx));
     acc[1] = acc[1] - GRAV;
     /* g. semi-implicit Euler */
     for (int c = 0; c < 3; ++c) {
-        P->vel[c] = P->vel[c] + acc[c] * DT;
-        P->pos[c] = P->pos[c] + P->vel[c] * DT;
+        P->vel[c] = fmaf(acc[c], DT, P->vel[c]);
+        P->pos[c] = fmaf(P->vel[c], DT, P->pos[c]);
     }
 }
 
 static float scenario_thrust_opp(uint32_t flags) { return ((flags >> F_SCEN_SHIFT) & 3u) == 2u ? 0.8f : 0.6f; }
 
-/* One UPDATE_SCENE.  ally_cmd / opp_cmd = (pitch, roll, yaw) levels, fire = FIRE_MISSILE was sent before the
- * tick.  Returns cos(target angle) through *cosang for the read-back. */
+/* ally -> opponent geometry: distance and cos(target angle); shared by the targeting device and the read-back */
+static void target_geometry(const OxEnv* E, float* dist, float* cosang) {
+    float aX[3], aY[3], aZ[3], d[3];
+    quat_axes(E->ally.q, aX, aY, aZ);
+    for (int c = 0; c < 3; ++c) d[c] = E->opp.pos[c] - E->ally.pos[c];
+    *dist = sqrtf(dot3(d, d));
+    *cosang = dot3(aZ, d) / *dist;
+}
+
+/* One UPDATE_SCENE.  ally_cmd / opp_cmd = (pitch, roll, yaw) levels, fire = FIRE_MISSILE was sent before the tick. */
 void ox_sim_tick(OxEnv* E, const float* ally_cmd, const float* opp_cmd, int fire) {
     /* missile leaves the rail before the tick, with the lock state the simulator holds at that moment */
     if (fire && (E->flags & F_SIM_SLOT)) {
@@ -215,7 +280,7 @@ void ox_sim_tick(OxEnv* E, const float* ally_cmd, const float* opp_cmd, int fire
         if (E->lock_timer >= LOCK_DELAY) E->flags |= F_M_GUIDED; else E->flags &= ~F_M_GUIDED;
         for (int c = 0; c < 3; ++c) {
             E->mpos[c] = E->ally.pos[c];
-            E->mvel[c] = E->ally.vel[c] + aZ[c] * M_BOOST;
+            E->mvel[c] = fmaf(aZ[c], M_BOOST, E->ally.vel[c]);
         }
         E->missile_age = 0.0f;
     }
@@ -223,23 +288,24 @@ void ox_sim_tick(OxEnv* E, const float* ally_cmd, const float* opp_cmd, int fire
     plane_tick(&E->opp, opp_cmd, scenario_thrust_opp(E->flags));
     /* missile */
     if (E->flags & F_M_ACTIVE) {
-        float to[3];
-        for (int c = 0; c < 3; ++c) to[c] = E->opp.pos[c] - E->mpos[c];
         float ms = sqrtf(dot3(E->mvel, E->mvel));
+        float ims = 1.0f / ms;
         float dir[3];
-        for (int c = 0; c < 3; ++c) dir[c] = E->mvel[c] / ms;
+        for (int c = 0; c < 3; ++c) dir[c] = E->mvel[c] * ims;
         if (E->flags & F_M_GUIDED) {
-            float dist = sqrtf(dot3(to, to));
+            float to[3];
+            for (int c = 0; c < 3; ++c) to[c] = E->opp.pos[c] - E->mpos[c];
+            float idist = 1.0f / sqrtf(dot3(to, to));
             float nd[3];
-            for (int c = 0; c < 3; ++c) nd[c] = dir[c] + M_TURN * (to[c] / dist - dir[c]);
-            float nn = sqrtf(dot3(nd, nd));
-            for (int c = 0; c < 3; ++c) dir[c] = nd[c] / nn;
+            for (int c = 0; c < 3; ++c) nd[c] = fmaf(M_TURN, fmaf(to[c], idist, -dir[c]), dir[c]);
+            float inn = 1.0f / sqrtf(dot3(nd, nd));
+            for (int c = 0; c < 3; ++c) dir[c] = nd[c] * inn;
         }
-        float ms2 = ms + M_ACC * DT;
+        float ms2 = fmaf(M_ACC, DT, ms);
         ms2 = ms2 > M_VMAX ? M_VMAX : ms2;
         for (int c = 0; c < 3; ++c) {
             E->mvel[c] = dir[c] * ms2;
-            E->mpos[c] = E->mpos[c] + E->mvel[c] * DT;
+            E->mpos[c] = fmaf(E->mvel[c], DT, E->mpos[c]);
         }
         E->missile_age = E->missile_age + DT;
         float d[3];
@@ -254,26 +320,20 @@ void ox_sim_tick(OxEnv* E, const float* ally_cmd, const float* opp_cmd, int fire
     }
     /* targeting device of the ally */
     {
-        float aX[3], aY[3], aZ[3], d[3];
-        quat_axes(E->ally.q, aX, aY, aZ);
-        for (int c = 0; c < 3; ++c) d[c] = E->opp.pos[c] - E->ally.pos[c];
-        float dist = sqrtf(dot3(d, d));
-        float cosang = dot3(aZ, d) / dist;
+        float dist, cosang;
+        target_geometry(E, &dist, &cosang);
         int in_cone = (cosang > COS_LOCK) && (dist > LOCK_MIN) && (dist < LOCK_MAX);
         E->lock_timer = in_cone ? E->lock_timer + DT : 0.0f;
     }
 }
 
 void ox_sim_readback(const OxEnv* E, OxReadback* rb) {
-    float aX[3], aY[3], aZ[3], d[3];
     for (int c = 0; c < 3; ++c) { rb->ally_pos[c] = E->ally.pos[c]; rb->opp_pos[c] = E->opp.pos[c]; }
     quat_euler(E->ally.q, rb->ally_euler);
     quat_euler(E->opp.q, rb->opp_euler);
-    quat_axes(E->ally.q, aX, aY, aZ);
-    for (int c = 0; c < 3; ++c) d[c] = E->opp.pos[c] - E->ally.pos[c];
-    float dist = sqrtf(dot3(d, d));
-    float cosang = clampf(dot3(aZ, d) / dist, -1.0f, 1.0f);
-    rb->target_angle_deg = acosf(cosang) * RAD2DEG;
+    float dist, cosang;
+    target_geometry(E, &dist, &cosang);
+    rb->target_angle_deg = ox_acos(clampf(cosang, -1.0f, 1.0f)) * RAD2DEG;
     rb->health = E->health;
     rb->target_locked = E->lock_timer >= LOCK_DELAY;
     rb->slot0 = (E->flags & F_SIM_SLOT) != 0;
@@ -337,12 +397,12 @@ void ox_wrap_observe(uint32_t* flags, const OxReadback* rb, float* obs) {
     f = (f & ~F_SLOT_PREV) | ((f & F_SLOT) ? F_SLOT_PREV : 0u);
     f = (f & ~F_SLOT) | (rb->slot0 ? F_SLOT : 0u);
     *flags = f;
-    for (int c = 0; c < 3; ++c) obs[c] = (rb->ally_pos[c] - rb->opp_pos[c]) / 10000.0f; /* :196-198,213-215,237 */
-    for (int c = 0; c < 3; ++c) obs[3 + c] = rb->ally_euler[c] / PI_F;                  /* :199-201 */
-    obs[6] = rb->target_angle_deg / 180.0f;                                              /* :234 */
+    for (int c = 0; c < 3; ++c) obs[c] = (rb->ally_pos[c] - rb->opp_pos[c]) * INV_1E4_F; /* / 10000  :196-198,213-215,237 */
+    for (int c = 0; c < 3; ++c) obs[3 + c] = rb->ally_euler[c] * INV_PI_F;              /* / pi  :199-201 */
+    obs[6] = rb->target_angle_deg * INV_180_F;                                           /* / 180  :234 */
     obs[7] = (f & F_LOCKED) ? 1.0f : -1.0f;                                              /* :229-232 */
     obs[8] = (f & F_SLOT) ? 1.0f : -1.0f;                                                /* :252-255 */
-    for (int c = 0; c < 3; ++c) obs[9 + c] = rb->opp_euler[c] / PI_F;                   /* :216-218 */
+    for (int c = 0; c < 3; ++c) obs[9 + c] = rb->opp_euler[c] * INV_PI_F;               /* :216-218 */
     obs[12] = rb->health;                                                                /* :241 */
 }
 
@@ -352,11 +412,11 @@ float ox_wrap_reward(uint32_t* flags, const OxReadback* rb, int8_t* success) {
     uint32_t f = *flags;
     float d[3];
     for (int c = 0; c < 3; ++c) d[c] = rb->ally_pos[c] - rb->opp_pos[c];
-    float loc_diff = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]); /* :190-191 */
+    float loc_diff = sqrtf(dot3(d, d)); /* :190-191 */
     float r = 0.0f;
     int8_t s = 0;
     r = r - 0.0001f * loc_diff;                       /* :107 */
-    r = r - (rb->target_angle_deg / 180.0f) * 10.0f;  /* :110 */
+    r = r - (rb->target_angle_deg * INV_180_F) * 10.0f; /* :110 */
     if (rb->ally_pos[1] < 2000.0f) r = r - 4.0f;      /* :112-113 */
     if (rb->ally_pos[1] > 7000.0f) r = r - 4.0f;      /* :115-116 */
     if (f & F_FIRED) {                                /* :119 */
@@ -409,12 +469,12 @@ void ox_env_observe(const OxEnv* E, float* obs) {
     OxReadback rb;
     ox_sim_readback(E, &rb);
     uint32_t f = E->flags;
-    for (int c = 0; c < 3; ++c) obs[c] = (rb.ally_pos[c] - rb.opp_pos[c]) / 10000.0f;
-    for (int c = 0; c < 3; ++c) obs[3 + c] = rb.ally_euler[c] / PI_F;
-    obs[6] = rb.target_angle_deg / 180.0f;
+    for (int c = 0; c < 3; ++c) obs[c] = (rb.ally_pos[c] - rb.opp_pos[c]) * INV_1E4_F;
+    for (int c = 0; c < 3; ++c) obs[3 + c] = rb.ally_euler[c] * INV_PI_F;
+    obs[6] = rb.target_angle_deg * INV_180_F;
     obs[7] = (f & F_LOCKED) ? 1.0f : -1.0f;
     obs[8] = (f & F_SLOT) ? 1.0f : -1.0f;
-    for (int c = 0; c < 3; ++c) obs[9 + c] = rb.opp_euler[c] / PI_F;
+    for (int c = 0; c < 3; ++c) obs[9 + c] = rb.opp_euler[c] * INV_PI_F;
     obs[12] = rb.health;
 }
 

@@ -367,13 +367,11 @@ def test_two_stream_issue_order_is_bit_identical_to_serial(staged):
     """bench.py --overlap issues the next act + env.step beside a critic-only learn() on a second stream
     (utils/pipeline.py).  Same reads and writes as the strict serial order of train_all.py:343-361: networks, Adam moments,
     env state, replay rows must come out bit for bit equal.  256 envs = one workgroup, so the replay insert order is fixed."""
-    import argparse
-
     import bench
 
     def run(serial):
-        args = argparse.Namespace(envs=256, batch=128, scenario="straight_line", agent="hirl", actions="policy", staged=staged, overlap=not serial,
-                                  separate_launches=True)  # one env workgroup: the replay insert order is fixed
+        # --separate-launches + 256 envs: ONE env workgroup, so the replay insert order is fixed
+        args = bench.parse(["--envs", "256", "--separate-launches"] + (["--staged"] if staged else []) + ([] if serial else ["--overlap"]))
         loop = bench.Loop(args, 0, 1, torch.device("cuda", 0))
         assert loop.pipe.overlap == (not serial)
         for _ in range(61):
