@@ -310,7 +310,7 @@ def host_cpu():
 
 def baseline_port(args, seconds):
     """The oracle timed on a BOUNDED sample of the same workload: the same loop (actor forward for all envs, env step for all
-    envs with insert — the envs split over all host cores —, one HIRL learn at B = 128) for as many vector steps as fit."""
+    envs with insert — the envs split over host threads, >= 256 envs each —, one HIRL learn at B = 128) for as many vector steps as fit."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
 
@@ -324,7 +324,8 @@ def baseline_port(args, seconds):
     es, ea = synthetic_expert(rng)
     o = H.HirlOracle(actor, critic, bc)
     envs, obs = ox.reset_batch(n, 0, 1, seed=0)
-    chunks = [(k * n // cores, (k + 1) * n // cores) for k in range(cores) if (k + 1) * n // cores > k * n // cores]
+    workers = max(1, min(cores, n // 256))
+    chunks = [(k * n // workers, (k + 1) * n // workers) for k in range(workers)]
     cap = 1 << 14
     rings = [np.zeros((cap, 32), np.float32) for _ in chunks]   # one private ring segment per worker (no shared head on the CPU side)
     totals = [np.zeros(1, np.uint64) for _ in chunks]
@@ -336,12 +337,10 @@ def baseline_port(args, seconds):
         ox.step_batch(envs[lo:hi], a[lo:hi], obs[lo:hi], max_step=1500, auto_reset=1, randomize=1, seed=0, env_id0=lo, episode_ctr=epi[lo:hi],
                       ring=rings[k], total=totals[k])
 
-    steps, t_env, t0 = 0, 0.0, time.perf_counter()
+    steps, t0 = 0, time.perf_counter()
     while True:
         a = o.choose_action(obs, rng.normal(0, 0.1, (n, 4)).astype(np.float32))
-        te = time.perf_counter()
         list(pool.map(lambda k: work(k, a), range(len(chunks))))
-        t_env += time.perf_counter() - te
         ring = rings[steps % len(rings)]
         m = max(min(int(totals[steps % len(rings)][0]), cap), 1)
         rows = ring[rng.integers(0, m, args.batch)]
@@ -354,12 +353,42 @@ def baseline_port(args, seconds):
             break
     pool.shutdown()
     return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s: oracle C env step on {len(chunks)} threads (B1: "
-                      f"{n * steps / max(t_env, 1e-9):,.0f} env steps/s for the integrator alone) + torch-CPU actor forward and HIRL learn "
-                      f"on {torch.get_num_threads()} threads",
-            "update_steps_per_s": round(steps / dt, 2),
-            "b1_batched_cpu": {"value": round(n * steps / max(t_env, 1e-9), 1), "unit": "env steps/s", "cores": len(chunks),
-                               "what": "the oracle's batched env step alone (C, one thread per core over env slices)"}}
+            "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s: oracle C env step on {len(chunks)} threads + torch-CPU actor forward and "
+                      f"HIRL learn on {torch.get_num_threads()} threads",
+            "update_steps_per_s": round(steps / dt, 2)}
+
+
+def baseline_batched_cpu(seconds):
+    """B1: the batched CPU integrator alone on ALL host cores — the oracle's C env step (no policy, no update), one thread per logical
+    core, 1,024 envs per thread, uniform random actions: the fairest CPU line for the env half of the metric."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from tests import _oracle as ox
+
+    cores = os.cpu_count() or 1
+    per = 1024
+    n = cores * per
+    envs, obs = ox.reset_batch(n, 0, 1, seed=0)
+    rng = np.random.default_rng(1)
+    a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    epi = np.zeros(n, np.uint32)
+    pool = ThreadPoolExecutor(cores)
+
+    def work(k):
+        lo, hi = k * per, (k + 1) * per
+        for _ in range(8):  # 8 steps per dispatch: the Python hand-off stays below 1 % of the thread's time
+            ox.step_batch(envs[lo:hi], a[lo:hi], obs[lo:hi], max_step=1500, auto_reset=1, randomize=1, seed=0, env_id0=lo, episode_ctr=epi[lo:hi])
+
+    list(pool.map(work, range(cores)))  # warm
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        list(pool.map(work, range(cores)))
+        steps += 8
+    dt = time.perf_counter() - t0
+    pool.shutdown()
+    return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": cores, "kind": "port",
+            "what": "the oracle's batched env step alone (scalar C, -O2, one thread per logical core, no policy / update)",
+            "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s"}
 
 
 def baseline_reference_plumbing(seconds):
@@ -405,7 +434,9 @@ def baseline_reference_plumbing(seconds):
                                1.0 if slot else -1.0], np.asarray(po["Euler_angles"]) / np.pi, [h]]), float(np.linalg.norm(d) * 10000.0)
 
     obs, _ = observe()
-    mem, steps, t0 = [], 0, time.perf_counter()
+    # the replay memory starts with 128 rows, as after the reference's exploration episodes (train_all.py:266-282): learn() runs from step 1
+    mem = [rng.uniform(-1, 1, 32).astype(np.float32) for _ in range(128)]
+    steps, t0 = 0, time.perf_counter()
     while True:
         a = agent.choose_action(obs.astype(np.float32)[None], rng.normal(0, 0.1, 4).astype(np.float32))[0]
         send("SET_PLANE_PITCH", plane_id=ALLY, pitch_level=float(a[0]))
@@ -434,7 +465,7 @@ def baseline_reference_plumbing(seconds):
     srv.close()
     return {"value": round(steps / dt, 2), "unit": "env steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "what": "configs[0]: 1 env behind the reference's socket framing (loopback TCP + JSON), eager CPU HIRL chooseAction + learn per step",
-            "sample": f"{steps} env steps in {dt:.1f} s, {sent[0] / max(steps, 1):.1f} messages per step, learn() from step 128 on"}
+            "sample": f"{steps} env steps in {dt:.1f} s, {sent[0] / max(steps, 1):.1f} messages per step, one learn(B=128) per step"}
 
 
 def baseline_eager_rocm_learn(args, seconds, device):
@@ -691,10 +722,11 @@ def run_rank(args):
             model, cores = host_cpu()
             budget = max(args.cpu_seconds, 1.0)
             if args.agent == "hirl":
-                res["cpu_baseline"] = baseline_port(args, 0.5 * budget)
+                res["cpu_baseline"] = baseline_port(args, 0.4 * budget)
                 res["cpu_baseline"]["host"] = f"{model}, {cores} logical cores"
                 res["cpu_baseline"]["b0_reference_plumbing"] = baseline_reference_plumbing(0.3 * budget)
-                res["cpu_baseline"]["b2_eager_rocm_learn"] = baseline_eager_rocm_learn(args, 0.2 * budget, device)
+                res["cpu_baseline"]["b1_batched_cpu"] = baseline_batched_cpu(0.15 * budget)
+                res["cpu_baseline"]["b2_eager_rocm_learn"] = baseline_eager_rocm_learn(args, 0.15 * budget, device)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

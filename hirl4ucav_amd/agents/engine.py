@@ -24,7 +24,7 @@ class HxBatch(ctypes.Structure):
 
 class HxNets(ctypes.Structure):
     _fields_ = [(k, _vp) for k in ("actor", "critic", "target_actor", "target_critic", "bc_actor", "grad_actor", "grad_critic",
-                                   "m_actor", "v_actor", "m_critic", "v_critic", "losses", "soft_count", "wstate", "ws")]
+                                   "m_actor", "v_actor", "m_critic", "v_critic", "losses", "soft_count", "wstate", "ws", "actor_w2_bf16")]
 
 
 class HxHyper(ctypes.Structure):
@@ -35,6 +35,10 @@ _P = ctypes.POINTER
 _lib.register("hx_actor_act", [_vp, _vp, ctypes.c_int64, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _f32, _vp, _vp])
 _lib.register("hx_actor_act_step", [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32,
                                      ctypes.c_uint32, _f32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
+_lib.register("hx_pack_w2_bf16", [_vp, _i32, _vp, _vp])
+_lib.register("hx_actor_act_bf16", [_vp, _vp, _vp, ctypes.c_int64, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _f32, _vp])
+_lib.register("hx_actor_act_step_bf16", [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32,
+                                          ctypes.c_uint32, _f32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
 _lib.register("hx_hirl_critic_grads", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _vp])
 _lib.register("hx_hirl_actor_backward", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _vp])
 _lib.register("hx_hirl_actor_wgrad", [_P(HxNets), _P(HxHyper), _i32, _i32, _i32, _f32, _f32, _vp])
@@ -117,7 +121,8 @@ class HirlEngine:
         self.sample_calls = 0
         self.nets = HxNets(*(t.data_ptr() for t in (self.actor, self.critic, self.target_actor, self.target_critic, self.bc_actor,
                                                      self.grad_actor, self.grad_critic, self.m_actor, self.v_actor, self.m_critic,
-                                                     self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)))
+                                                     self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None)
+        self.act_dtype, self.w2_bf16 = "f32", None
         self.hyper = HxHyper(gamma, tau, lr_actor, lr_critic, slope, 0.5, 10000.0, int(use_bc))  # HIRL.py:162,182
         self.use_bc, self.slope = bool(use_bc), float(slope)
         self.actor_trainable, self.update_count = True, 0   # HIRL.py:157,166
@@ -137,6 +142,23 @@ class HirlEngine:
         if hard_update_targets:  # hard_update, HIRL.py:15-17,172,176
             self.target_actor.copy_(self.actor)
             self.target_critic.copy_(self.critic)
+        self.refresh_bf16()
+
+    def set_act_dtype(self, dtype):
+        """"f32": policy inference on fp32 MFMA (parity 1e-5).  "bf16": its 256 -> 512 layer on bf16 MFMA from a bf16 image of W2 that
+        every actor Adam step keeps current (BASELINE.json configs[4]); learn() is fp32 either way."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(dtype)
+        self.act_dtype = dtype
+        if dtype == "bf16" and self.w2_bf16 is None:
+            self.w2_bf16 = torch.zeros(H2 * H1, dtype=torch.bfloat16, device=self.device)
+        self.nets.actor_w2_bf16 = self.w2_bf16.data_ptr() if dtype == "bf16" else None
+        self.refresh_bf16()
+
+    def refresh_bf16(self):
+        """Rebuild the bf16 image from the fp32 actor (after load_params / a checkpoint restore; hx_adam maintains it otherwise)."""
+        if self.act_dtype == "bf16":
+            _lib.call("hx_pack_w2_bf16", self.actor.data_ptr(), 13, self.w2_bf16.data_ptr(), _lib.stream_ptr())
 
     def replica_checksum(self):
         """int64 sum of the bit patterns of every network and Adam moment: equal on all ranks of a sharded run, or the replicas have
@@ -163,6 +185,10 @@ class HirlEngine:
         elif sigma > 0:
             mode = 3
         self.act_calls += 1
+        if self.act_dtype == "bf16" and net is None:
+            _lib.call("hx_actor_act_bf16", self.actor.data_ptr(), self.w2_bf16.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode, _lib.ptr(noise),
+                      float(sigma), int(seed), int(row0), self.act_calls, self.slope, _lib.stream_ptr())
+            return out
         _lib.call("hx_actor_act", (net if net is not None else self.actor).data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode,
                   _lib.ptr(noise), float(sigma), int(seed), int(row0), self.act_calls, self.slope, None,
                   _lib.stream_ptr())
@@ -181,6 +207,11 @@ class HirlEngine:
         elif sigma > 0:
             mode = 3
         self.act_calls += 1
+        if self.act_dtype == "bf16":
+            _lib.call("hx_actor_act_step_bf16", self.actor.data_ptr(), self.w2_bf16.data_ptr(), env.state.data_ptr(), n, n, env.obs.data_ptr(),
+                      out.data_ptr(), mode, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
+                      env.reward.data_ptr(), env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
+            return out, env.obs, env.reward, env.done, env.success
         _lib.call("hx_actor_act_step", self.actor.data_ptr(), env.state.data_ptr(), n, n, env.obs.data_ptr(), out.data_ptr(), mode,
                   _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope, env.reward.data_ptr(),
                   env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())

@@ -449,7 +449,11 @@ struct ActFusedArgs {
     int8_t* success;
     HxStepOpts o;
     double inv_cap;  // 1 / o.cap
+    const uint16_t* w2b;  // BF16 instantiations: bf16 image of W2 [512][256] (hx_pack_w2_bf16 / the actor's Adam step keep it current)
 };
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+constexpr int LDB1 = H1 + 16;  // bf16 h1 tile pitch (elements) = 136 dwords = 8 mod 64: the ds_read_b128 A-operand read is conflict-free
 
 constexpr int ACT_KC = 16;            // k-chunk of W2 staged through LDS (64 B per column), double-buffered
 constexpr int ACT_LDW = ACT_KC + 8;   // pitch = 8 mod 16 dwords: conflict-free ds_read_b128 (see LDA1)
@@ -474,20 +478,30 @@ __device__ __forceinline__ float philox_normal(uint32_t row, uint32_t call, uint
 // ENV   = the env step of the same rows runs in the tail: the 16 (32) actions meet in LDS and the lanes of wave 0 each step
 //         one env (hx_env_dev.h: the code of env_step_kernel, contraction off), with the fused replay insert — no second
 //         launch, and the env's ~2,500-instruction chain runs on every CU at once instead of on 16 of them.
-template <int NRT, bool GAUSS, bool ENV>
+// BF16 = the policy's 256 -> 512 layer on v_mfma_f32_16x16x32_bf16 (BASELINE.json configs[4]: bf16 actor, fp32 dynamics): h1 is rounded to
+//         bf16 once, W2 comes from a bf16 image; accumulation, both LayerNorms, layer 1 and the head stay fp32.  Every wave owns 32 of
+//         the 512 columns and nobody else reads them, so its B fragments (16 x 16 B per lane = the 256 KB image once per
+//         workgroup) go from L2 straight into registers at kernel entry — no LDS staging, no chunk barriers; the 16 (32) rows
+//         of h1 are the only shared operand.
+template <int NRT, bool GAUSS, bool ENV, bool BF16>
 __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     constexpr int ROWS = NRT * RT;
     __shared__ float s_act[ENV ? ROWS * 4 : 4];
     __shared__ unsigned s_base;  // ring slot of the workgroup's first row
     __shared__ int s_nstore;
     static_assert(2 * H2 * ACT_LDW >= ROWS * LDA2, "the z2 tile reuses the W2 chunk buffers");
-    __shared__ __attribute__((aligned(16))) float lds[ROWS * LDA1 + ROWS * XP + ROWS * 2 + H1 * 13 + 2 * H2 * ACT_LDW];
+    // fp32: two W2 chunk buffers (reused for z2 and, in the env tail, the replay rows / next observations)
+    // bf16: the z2 tile, then the replay rows / next observations, and the bf16 h1 tile
+    constexpr int kTileA = BF16 ? ROWS * LDA2 : H2 * ACT_LDW;
+    constexpr int kTileB = BF16 ? (ENV ? ROWS * (hxenv::kRowPitch + HX_OBS_DIM) : 4) : H2 * ACT_LDW;
+    __shared__ __attribute__((aligned(16))) float lds[ROWS * LDA1 + ROWS * XP + ROWS * 2 + H1 * 13 + kTileA + kTileB];
+    __shared__ __attribute__((aligned(16))) __bf16 h1b[BF16 ? ROWS * LDB1 : 8];
     float* h1s = lds;
     float* xs = h1s + ROWS * LDA1;
     float* sts = xs + ROWS * XP;
     float* w1s = sts + ROWS * 2;
     float* wb0 = w1s + H1 * 13;        // [H2][ACT_LDW]: even k-chunks of W2, every column
-    float* wb1 = wb0 + H2 * ACT_LDW;   // odd k-chunks
+    float* wb1 = wb0 + kTileA;         // odd k-chunks
     float* z2s = wb0;                  // [ROWS][LDA2] once the last chunk has been multiplied
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * ROWS;
@@ -507,8 +521,19 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 #define ACT_LOAD(ra, rb, c) { ra = *reinterpret_cast<const float4*>(w2g + (c) * ACT_KC); rb = *reinterpret_cast<const float4*>(w2g + (size_t)256 * H1 + (c) * ACT_KC); }
 #define ACT_STORE(buf, ra, rb) { *reinterpret_cast<float4*>((buf) + w2w) = ra; *reinterpret_cast<float4*>((buf) + w2w + 256 * ACT_LDW) = rb; }
     float4 e0, e1, o0, o1;  // even / odd register sets
-    ACT_LOAD(e0, e1, 0);
-    ACT_LOAD(o0, o1, 1);
+    uint4 bq[BF16 ? 2 : 1][BF16 ? 8 : 1];  // BF16: B fragments of this wave's two column tiles, all of K
+    if constexpr (BF16) {
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint16_t* row = A.w2b + (size_t)(t * 256 + wave * 16 + r) * H1 + 8 * g;
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) bq[t][sl] = *reinterpret_cast<const uint4*>(row + 32 * sl);
+        }
+    } else {
+        ACT_LOAD(e0, e1, 0);
+        ACT_LOAD(o0, o1, 1);
+    }
     // head parameters (g2, be2, W3, b3): requested now, parked in 4-8 registers, laid out in LDS once h1 is dead
     typedef HeadImage<GAUSS ? 8 : 4> Img;
     static_assert(Img::kStride <= ROWS * LDA1 + ROWS * XP + ROWS * 2 + H1 * 13, "the head image reuses the prologue's LDS");
@@ -565,10 +590,14 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = t * RT + rq + r;
-            h1s[row * LDA1 + u] = act_f(g1v * ((z1[t][r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
+            const float hv = act_f(g1v * ((z1[t][r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
+            if (BF16) h1b[row * LDB1 + u] = (__bf16)hv;  // v_cvt_pk_bf16_f32: round to nearest even
+            else h1s[row * LDA1 + u] = hv;
         }
-    ACT_STORE(wb0, e0, e1);
-    ACT_LOAD(e0, e1, 2);
+    if (!BF16) {
+        ACT_STORE(wb0, e0, e1);
+        ACT_LOAD(e0, e1, 2);
+    }
     __syncthreads();
     STAMP();
     {   // z2 tiles: columns 16*wave .. and 256 + 16*wave .. of every row tile; k ascending, chunk by chunk
@@ -576,6 +605,19 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         v4f acc[NRT][2];
 #pragma unroll
         for (int t = 0; t < NRT; ++t) acc[t][0] = acc[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF16) {
+            // K = 256 in 8 slabs of 32: lane (r, g) holds A[row r][32 sl + 8 g ..+7] and B[32 sl + 8 g ..+7][col r]
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) {
+                    const uint4 aq = *reinterpret_cast<const uint4*>(h1b + (t * RT + r) * LDB1 + 32 * sl + 8 * g);
+                    const v8bf a8 = __builtin_bit_cast(v8bf, aq);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(v8bf, bq[0][sl]), acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(v8bf, bq[1][sl]), acc[t][1], 0, 0, 0);
+                }
+            }
+        }
         const float* ap = h1s + r * LDA1 + 4 * g;
         const int boff = (wave * 16 + r) * ACT_LDW + 4 * g;
 #define ACT_MUL(buf, c) { \
@@ -588,7 +630,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
                 acc[t][0] = mfma16(a4[t].y, p4.y, acc[t][0]); acc[t][1] = mfma16(a4[t].y, q4.y, acc[t][1]); \
                 acc[t][0] = mfma16(a4[t].z, p4.z, acc[t][0]); acc[t][1] = mfma16(a4[t].z, q4.z, acc[t][1]); \
                 acc[t][0] = mfma16(a4[t].w, p4.w, acc[t][0]); acc[t][1] = mfma16(a4[t].w, q4.w, acc[t][1]); } }
-        for (int c = 0; c < ACT_NCH; c += 2) {
+        for (int c = 0; c < (BF16 ? 0 : ACT_NCH); c += 2) {
             // even chunk c is in wb0; the odd set holds chunk c+1, the even set chunk c+2 (in flight)
             ACT_STORE(wb1, o0, o1);
             if (c + 3 < ACT_NCH) ACT_LOAD(o0, o1, c + 3);
@@ -795,17 +837,36 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 // the ~8 us tail, and the env kernel on its own (thousands of envs per launch, 10-14 us) is the cheaper way.
 constexpr int64_t kFuseEnvMax = 8192;
 
-template <bool GAUSS>
-static void launch_act(const ActFusedArgs& H, hipStream_t st) {
+template <bool GAUSS, bool BF16>
+static void launch_act_t(const ActFusedArgs& H, hipStream_t st) {
     const bool env = H.state != nullptr;
     if (H.rows >= 8192) {
         const dim3 grid((unsigned)((H.rows + 2 * RT - 1) / (2 * RT)));
-        if (env) hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, true>), grid, dim3(kWide), 0, st, H);
-        else hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, false>), grid, dim3(kWide), 0, st, H);
+        if (env) hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, true, BF16>), grid, dim3(kWide), 0, st, H);
+        else hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, false, BF16>), grid, dim3(kWide), 0, st, H);
     } else {
         const dim3 grid((unsigned)((H.rows + RT - 1) / RT));
-        if (env) hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, true>), grid, dim3(kWide), 0, st, H);
-        else hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, false>), grid, dim3(kWide), 0, st, H);
+        if (env) hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, true, BF16>), grid, dim3(kWide), 0, st, H);
+        else hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, false, BF16>), grid, dim3(kWide), 0, st, H);
+    }
+}
+template <bool GAUSS>
+static void launch_act(const ActFusedArgs& H, hipStream_t st) {
+    if (H.w2b) launch_act_t<GAUSS, true>(H, st);
+    else launch_act_t<GAUSS, false>(H, st);
+}
+
+// bf16 image of a [n] fp32 array (round to nearest even): the policy's W2 for the BF16 acting kernels
+__global__ __launch_bounds__(kThreads) void pack_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int n) {
+    const int i = (blockIdx.x * kThreads + threadIdx.x) * 2;
+    if (i + 1 < n) {
+        const float2 v = *reinterpret_cast<const float2*>(src + i);
+        typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+        const v2bf r = {(__bf16)v.x, (__bf16)v.y};
+        *reinterpret_cast<unsigned*>(dst + i) = __builtin_bit_cast(unsigned, r);
+    } else if (i < n) {
+        const __bf16 r = (__bf16)src[i];
+        dst[i] = __builtin_bit_cast(uint16_t, r);
     }
 }
 
@@ -1584,6 +1645,10 @@ struct AdamArgs {
     // Adam step and the end of learn(), so target <- (1 - tau) target + tau p_new here equals the reference's separate pass
     float* target;       // nullptr = no Polyak this call
     float tau;
+    // bf16 image of this block's W2 kept current by the step that changes it (elements [w2_lo, w2_lo + 512*256) of p): the BF16
+    // acting kernels read it; nullptr = none
+    uint16_t* w2b;
+    int w2_lo;
 };
 
 __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
@@ -1618,6 +1683,11 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
         *reinterpret_cast<float4*>(A.p + i) = p4;
         *reinterpret_cast<float4*>(A.m + i) = m4;
         *reinterpret_cast<float4*>(A.v + i) = v4;
+        if (A.w2b && i >= A.w2_lo && i < A.w2_lo + H2 * H1) {  // W2 starts at a multiple of 4 floats: the float4 is inside or outside
+            typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+            const v4bf r = {(__bf16)p4.x, (__bf16)p4.y, (__bf16)p4.z, (__bf16)p4.w};
+            *reinterpret_cast<uint2*>(A.w2b + (i - A.w2_lo)) = __builtin_bit_cast(uint2, r);
+        }
         if (A.target) {
             float4 t4 = *reinterpret_cast<const float4*>(A.target + i);
             t4.x = t4.x * (1.0f - A.tau) + p4.x * A.tau;  // HIRL.py:13
@@ -1849,15 +1919,35 @@ int64_t hx_act_workspace_floats(int64_t rows) { (void)rows; return 0; }  // the 
 /* chooseAction / chooseActionSmallNoise / chooseActionNoNoise for `rows` observations (HIRL.py:192-212):
  * actions = clamp(actor(obs) + noise, -1, 1).  noise_mode 0: none, 1: noise[4] shared by all rows, 2: noise[rows][4],
  * 3: N(0, sigma^2) per row and component from Philox(seed; row0 + row, call).  ws: unused since the whole policy runs in one kernel (may be NULL). */
-int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* actions, int32_t noise_mode, const float* noise,
-                 float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* ws, void* stream) {
+static int actor_act_impl(const float* actor, const uint16_t* w2b, const float* obs, int64_t rows, float* actions, int32_t noise_mode, const float* noise,
+                 float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream) {
     HX_REQUIRE(actor && obs && actions && rows > 0, "hx_actor_act: bad arguments");
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act: bad noise mode");
-    (void)ws;
     ActFusedArgs H{actor, kActor, const_cast<float*>(obs), (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
-                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0};
+                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0, w2b};
     launch_act<false>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_actor_act");
+    return 0;
+}
+
+int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* actions, int32_t noise_mode, const float* noise,
+                 float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* ws, void* stream) {
+    (void)ws;
+    return actor_act_impl(actor, nullptr, obs, rows, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream);
+}
+/* The same with the 256 -> 512 layer on bf16 MFMA (BASELINE.json configs[4]): w2_bf16 = hx_pack_w2_bf16 image of full2.weight. */
+int hx_actor_act_bf16(const float* actor, const uint16_t* w2_bf16, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
+                      const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream) {
+    HX_REQUIRE(w2_bf16 && (reinterpret_cast<uintptr_t>(w2_bf16) & 15u) == 0, "hx_actor_act_bf16: w2_bf16 must be a 16-byte aligned bf16 image of W2");
+    return actor_act_impl(actor, w2_bf16, obs, rows, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream);
+}
+/* bf16 image (round to nearest even) of an MLP block's W2 [512][256]; in_dim = 13 (actor / policy) or 17 (Q head) locates it. */
+int hx_pack_w2_bf16(const float* net, int32_t in_dim, uint16_t* w2_bf16, void* stream) {
+    HX_REQUIRE(net && w2_bf16 && (in_dim == 13 || in_dim == 17), "hx_pack_w2_bf16: bad arguments");
+    const Mlp m{in_dim, 1, 0};
+    const int n = H2 * H1;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((n / 2 + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, net + m.W2(), w2_bf16, n);
+    HX_CHECK_LAUNCH("hx_pack_w2_bf16");
     return 0;
 }
 
@@ -1874,7 +1964,7 @@ static int check_step_args(const float* state, int64_t n, int64_t stride, const 
 
 /* chooseAction + HarfangEnv.step for n envs in ONE launch (train_all.py:343-345): actions = clamp(actor(obs_io) + noise, -1, 1) as
  * hx_actor_act, then hx_env_step with those actions in the tail of the same kernel — obs_io in: current observation, out: next. */
-int hx_actor_act_step(const float* actor, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+static int actor_act_step_impl(const float* actor, const uint16_t* w2b, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
                       const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward,
                       uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
     HX_REQUIRE(actor, "hx_actor_act_step: null actor");
@@ -1882,15 +1972,29 @@ int hx_actor_act_step(const float* actor, float* state, int64_t n, int64_t strid
     const HxStepOpts o = opts ? *opts : HxStepOpts{};
     if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_actor_act_step")) return rc;
     if (n > kFuseEnvMax) {  // more than one round of workgroups: the env step is cheaper as a launch of its own
-        if (int rc = hx_actor_act(actor, obs_io, n, actions, noise_mode, noise, sigma, seed, row0, call, slope, nullptr, stream)) return rc;
+        if (int rc = actor_act_impl(actor, w2b, obs_io, n, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream)) return rc;
         return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
     }
     ActFusedArgs H{actor, kActor, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
                    noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
-                   o.cap > 0 ? 1.0 / (double)o.cap : 0.0};
+                   o.cap > 0 ? 1.0 / (double)o.cap : 0.0, w2b};
     launch_act<false>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_actor_act_step");
     return 0;
+}
+
+int hx_actor_act_step(const float* actor, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+                      const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward,
+                      uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
+    return actor_act_step_impl(actor, nullptr, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed, row0, call, slope, reward, done,
+                               success, opts, stream);
+}
+int hx_actor_act_step_bf16(const float* actor, const uint16_t* w2_bf16, float* state, int64_t n, int64_t stride, float* obs_io, float* actions,
+                           int32_t noise_mode, const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope,
+                           float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
+    HX_REQUIRE(w2_bf16 && (reinterpret_cast<uintptr_t>(w2_bf16) & 15u) == 0, "hx_actor_act_step_bf16: w2_bf16 must be a 16-byte aligned bf16 image of W2");
+    return actor_act_step_impl(actor, w2_bf16, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed, row0, call, slope, reward, done,
+                               success, opts, stream);
 }
 
 static void make_slots(const HxNets* N, int B, Slot* s) {
@@ -1993,6 +2097,10 @@ int hx_adam(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t step, flo
     if (polyak) {
         A.target = which == 0 ? N->target_critic : N->target_actor;
         A.tau = Hy->tau;
+    }
+    if (which != 0 && N->actor_w2_bf16) {
+        A.w2b = N->actor_w2_bf16;
+        A.w2_lo = kActor.W2();
     }
     HX_REQUIRE((((uintptr_t)A.p | (uintptr_t)A.g | (uintptr_t)A.m | (uintptr_t)A.v) & 15u) == 0, "hx_adam: buffers must be 16-byte aligned");
     hipLaunchKernelGGL(adam_kernel, dim3((A.n / 4 + kThreads) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, A);
@@ -2199,7 +2307,7 @@ int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actio
     HX_REQUIRE(policy && obs && actions && rows > 0 && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act: bad arguments");
     (void)ws;
     ActFusedArgs H{policy, kPolicy, const_cast<float*>(obs), (int)rows, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
-                   nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0};
+                   nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0, nullptr};
     launch_act<true>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_sac_act");
     return 0;
@@ -2217,7 +2325,7 @@ int hx_sac_act_step(const float* policy, float* state, int64_t n, int64_t stride
         return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
     }
     ActFusedArgs H{policy, kPolicy, obs_io, (int)n, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
-                   state, stride, reward, done, success, o, o.cap > 0 ? 1.0 / (double)o.cap : 0.0};
+                   state, stride, reward, done, success, o, o.cap > 0 ? 1.0 / (double)o.cap : 0.0, nullptr};
     launch_act<true>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_sac_act_step");
     return 0;

@@ -24,6 +24,8 @@ def load_engine_state(eng, st):
     if st["arena"].numel() != eng.arena.numel():
         raise ValueError(f"snapshot arena has {st['arena'].numel()} words, this engine {eng.arena.numel()} (different agent or batch size)")
     eng.arena.copy_(st["arena"])
+    if hasattr(eng, "refresh_bf16"):
+        eng.refresh_bf16()  # the bf16 image of the actor's W2 follows the restored fp32 parameters
     for k, v in st["counters"].items():
         setattr(eng, k, v)
 

@@ -152,6 +152,19 @@ int hx_actor_act_step(const float* actor, float* state, int64_t n, int64_t strid
                       int32_t noise_mode, const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope,
                       float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts /* host, may be NULL */, void* stream);
 
+/* bf16 policy inference (BASELINE.json configs[4] "bf16 actor/critic + fp32 dynamics"): the 256 -> 512 layer — 96 % of the policy's
+ * FLOPs — runs on v_mfma_f32_16x16x32_bf16 with h1 rounded to bf16 once and W2 read from a bf16 image; accumulation, layer 1, both
+ * LayerNorms and the head stay fp32, and so do the dynamics, the update and the optimizer.  Tolerance vs the fp32 policy: |da| <= 2e-2 on
+ * tanh outputs (tests/test_hirl_gpu.py); vs an fp32 evaluation on the SAME rounded operands: 1e-4.
+ * hx_pack_w2_bf16: w2_bf16[512][256] = bf16(W2) of the MLP block at `net` (in_dim 13 or 17), round to nearest even. */
+int hx_pack_w2_bf16(const float* net, int32_t in_dim, uint16_t* w2_bf16, void* stream);
+int hx_actor_act_bf16(const float* actor, const uint16_t* w2_bf16, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
+                      const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream);
+int hx_actor_act_step_bf16(const float* actor, const uint16_t* w2_bf16, float* state, int64_t n, int64_t stride, float* obs_io,
+                           float* actions, int32_t noise_mode, const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call,
+                           float slope, float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts /* host, may be NULL */,
+                           void* stream);
+
 /* Minibatch of Agent.learn (HIRL.py:223-251), already assembled by hx_sample_batch into compact row tiles:
  * rows[batch][HX_ROW_WORDS] = s[13] a[4] s'[13] r done (buffer rows first, then expert rows, HIRL.py:229-233);
  * bc_rows[batch][HX_ROW_WORDS]: cols 0..12 state, 13..16 action of the BC minibatch (HIRL.py:248-251; NULL for TD3). */
@@ -170,6 +183,8 @@ typedef struct HxNets {
     int32_t* soft_count; /* [1] count(soft_Q > rl_Q) (HIRL.py:303) — all-reduce it when the batch is sharded */
     float* wstate;       /* [1] the BC weight in force */
     float* ws;           /* hx_hirl_workspace_floats(batch) */
+    uint16_t* actor_w2_bf16; /* NULL, or [512][256] bf16 image of the actor's full2.weight: every Adam step of the actor refreshes it
+                                (hx_adam which = 1 / 2), the bf16 acting entry points read it */
 } HxNets;
 
 typedef struct HxHyper {

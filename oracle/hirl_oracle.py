@@ -68,8 +68,8 @@ def init_critic(rng, sd=13, ad=4, h1=256, h2=512, perturb_ln=True):
     return {k: p[k] for k in CRITIC_KEYS}
 
 
-def to_torch(p, grad=False):
-    return {k: torch.tensor(np.asarray(v), dtype=torch.float32, requires_grad=grad) for k, v in p.items()}
+def to_torch(p, grad=False, device="cpu"):
+    return {k: torch.tensor(np.asarray(v), dtype=torch.float32, device=device, requires_grad=grad) for k, v in p.items()}
 
 
 def _act(x, slope):
@@ -139,12 +139,14 @@ class HirlOracle:
     """State and update rule of hirl.agents.HIRL.Agent (and TD3.Agent with slope=0.01, use_bc=False)."""
 
     def __init__(self, actor, critic, bc_actor=None, lr_actor=1e-3, lr_critic=1e-3, tau=0.005, gamma=0.99, slope=0.0,
-                 use_bc=True):
-        self.actor = to_torch(actor, True)
-        self.critic = to_torch(critic, True)
-        self.target_actor = to_torch(actor)   # hard_update HIRL.py:172
-        self.target_critic = to_torch(critic)  # HIRL.py:176
-        self.bc_actor = to_torch(bc_actor) if bc_actor is not None else None
+                 use_bc=True, device="cpu"):
+        # device: "cpu" for every parity test; bench.py's baseline leg also runs the same eager ops on the GPU (b2_eager_rocm_learn)
+        self.dev = torch.device(device)
+        self.actor = to_torch(actor, True, self.dev)
+        self.critic = to_torch(critic, True, self.dev)
+        self.target_actor = to_torch(actor, False, self.dev)   # hard_update HIRL.py:172
+        self.target_critic = to_torch(critic, False, self.dev)  # HIRL.py:176
+        self.bc_actor = to_torch(bc_actor, False, self.dev) if bc_actor is not None else None
         self.opt_actor, self.opt_critic = Adam(self.actor, lr_actor), Adam(self.critic, lr_critic)
         self.tau, self.gamma, self.slope, self.use_bc = tau, gamma, slope, use_bc
         self.noise_clamp, self.loss_lambda, self.target_update_freq = 0.5, 10000.0, 3  # HIRL.py:162,182-183
@@ -157,20 +159,20 @@ class HirlOracle:
     def choose_action(self, state, noise=None):
         """clamp(actor(s) + noise, -1, 1); noise None = chooseActionNoNoise   HIRL.py:192-212"""
         with torch.no_grad():
-            a = actor_forward(self.actor, torch.as_tensor(state, dtype=torch.float32), self.slope)
+            a = actor_forward(self.actor, torch.as_tensor(state, dtype=torch.float32, device=self.dev), self.slope)
             if noise is not None:
-                a = (a + torch.as_tensor(noise, dtype=torch.float32)).clamp(-1, 1)
-        return a.numpy()
+                a = (a + torch.as_tensor(noise, dtype=torch.float32, device=self.dev)).clamp(-1, 1)
+        return a.cpu().numpy()
 
     def learn(self, batch, bc_batch, noise, bc_weight_now=0.0, bc_warm_up_weight=0.0):
         """batch = (s[B,13], a[B,4], s'[B,13], r[B], d[B]) already mixed buffer ++ expert rows (HIRL.py:223-243);
         bc_batch = (s_bc[B,13], a_bc[B,4]) (HIRL.py:248-251); noise = the ONE (4,) N(0, 0.2^2) draw shared by the
         whole batch (HIRL.py:265), unclamped.  Returns the reference's 6-tuple (HIRL.py:334)."""
-        s, a, ns, r, d = (torch.as_tensor(x, dtype=torch.float32) for x in batch)
+        s, a, ns, r, d = (torch.as_tensor(x, dtype=torch.float32, device=self.dev) for x in batch)
         # U8: TD target  HIRL.py:259-274
         with torch.no_grad():
             na = actor_forward(self.target_actor, ns, self.slope)
-            eps = torch.as_tensor(noise, dtype=torch.float32).clamp(-self.noise_clamp, self.noise_clamp)
+            eps = torch.as_tensor(noise, dtype=torch.float32, device=self.dev).clamp(-self.noise_clamp, self.noise_clamp)
             na = (na + eps).clamp(-1, 1)
             tq1, tq2 = critic_forward(self.target_critic, ns, na, self.slope)
             y = r.reshape(-1, 1) + self.gamma * torch.min(tq1, tq2) * (1 - d).reshape(-1, 1)
@@ -195,7 +197,7 @@ class HirlOracle:
                     self.bc_weight += bc_warm_up_weight
                 if self.bc_weight > 1:
                     self.bc_weight = 1
-                bs, ba = (torch.as_tensor(x, dtype=torch.float32) for x in bc_batch)
+                bs, ba = (torch.as_tensor(x, dtype=torch.float32, device=self.dev) for x in bc_batch)
                 bc_pred = actor_forward(self.actor, bs, self.slope)
                 bc_loss = F.mse_loss(bc_pred, ba) * self.loss_lambda                     # HIRL.py:310-311
                 self.bc_fire_loss = F.mse_loss(bc_pred[:, 3].detach(), ba[:, 3]).item() * self.loss_lambda  # :317-319

@@ -32,14 +32,38 @@ def check(d, n_gpus, steps, warmup):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["launches_timed"] > 0 and (r["traffic"] is None or r["traffic"] > 0)
+    assert "settle_s" in d and "timed_region" in d and d["stage_us"]["sample+learn"] > 0
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
 def test_bench_single_gpu_line():
-    d = run([sys.executable, "bench.py", "--steps", "120", "--warmup", "20", "--cpu-seconds", "1"])
+    d = run([sys.executable, "bench.py", "--steps", "120", "--warmup", "20", "--cpu-seconds", "6", "--settle-s", "0.3"])
     check(d, 1, 120, 20)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    # reference plumbing (one socket env), batched CPU integrator, eager ROCm learn()
+    assert 0 < c["b0_reference_plumbing"]["value"] < 5000 and c["b1_batched_cpu"]["value"] > c["value"] and c["b2_eager_rocm_learn"]["value"] > 0
+    sw = d["roofline_env_sweep"]
+    assert [r["envs_per_launch"] for r in sw] == [4096, 65536, 1 << 20, 1 << 22] and sw[2]["frac"] > 0.4  # the >= 40 % HBM evidence
+    assert d["roofline"]["traffic"] is None and "traffic_from_profiles" in d["roofline"]
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 2` on a 1-GPU box must fail loudly, not print an N = 1 number."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has several GPUs")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "1"], cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and "2 GPUs requested" in p.stderr and "{" not in p.stdout
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment starts the two ranks itself (here over gloo on the shared GPU)."""
+    d = run([sys.executable, "bench.py", "--gpus", "2", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-sweep", "--settle-s", "0.2"],
+            env={"HX_BENCH_BACKEND": "gloo"})
+    check(d, 2, 40, 5)
+    assert d["rccl_ranks"]["world_size"] == 2 and d["replicas_identical"] is True
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
@@ -48,7 +72,8 @@ def test_bench_two_ranks_launch_form(extra):
     """python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ..."""
     port = str(29600 + (os.getpid() + len(extra)) % 300)
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
-             "bench.py", "--gpus", "2", "--steps", "60", "--warmup", "10", "--no-cpu-baseline"] + extra, env={"HX_BENCH_BACKEND": "gloo"})
+             "bench.py", "--gpus", "2", "--steps", "60", "--warmup", "10", "--no-cpu-baseline", "--no-sweep", "--settle-s", "0.2"] + extra,
+            env={"HX_BENCH_BACKEND": "gloo"})
     check(d, 2, 60, 10)
     assert d["allreduce"] and all(a["median_us"] > 0 for a in d["allreduce"])
     assert d["env_stats"]["env_steps"] > 0

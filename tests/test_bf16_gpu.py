@@ -1,0 +1,149 @@
+"""bf16 policy inference (BASELINE.json configs[4]: "bf16 actor/critic + fp32 dynamics") through the C ABI
+(hx_actor_act_bf16 / hx_actor_act_step_bf16 / hx_pack_w2_bf16).
+
+Tolerances, stated separately from the fp32 path's 1e-5 (SURVEY.md 7 "bf16 config"):
+  * against an fp32 evaluation of the SAME rounded operands (W2 and h1 rounded to bf16, everything else fp32): |da| <= 1e-4 —
+    only the accumulation order of the 256-long dot products differs;
+  * against the full-fp32 policy: |da| <= 2e-2 on the tanh outputs, mean |da| <= 2e-3 (8 significant bits on two operands).
+Dynamics, masks, rewards stay exactly what the env step computes from the actions it is given: checked bit for bit."""
+import numpy as np
+import pytest
+import torch.nn.functional as F
+
+from oracle import hirl_oracle as H
+from tests import _hirl_data as D
+from tests import _oracle as ox
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from hirl4ucav_amd import _lib
+    from hirl4ucav_amd.agents import engine as E
+    from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    _lib.load()
+    return E, BatchedHarfangEnv, DeviceReplay
+
+
+def rounded_operand_policy(p, x):
+    """Actor.forward (HIRL.py:126-140) in fp32 with the two operands of the 256 -> 512 product rounded to bf16 first."""
+    p = {k: torch.as_tensor(v) for k, v in p.items()}
+    h = F.relu(F.layer_norm(F.linear(x, p["full1.weight"], p["full1.bias"]), (256,), p["layernorm1.weight"], p["layernorm1.bias"], 1e-5))
+    hb = h.to(torch.bfloat16).to(torch.float32)
+    w2 = p["full2.weight"].to(torch.bfloat16).to(torch.float32)
+    z2 = F.linear(hb.double(), w2.double(), p["full2.bias"].double()).float()  # exact products, fp64 sums: the reference value
+    h2 = F.relu(F.layer_norm(z2, (512,), p["layernorm2.weight"], p["layernorm2.bias"], 1e-5))
+    return torch.tanh(F.linear(h2, p["final.weight"], p["final.bias"]))
+
+
+@pytest.mark.parametrize("n", [1, 16, 1000, 9000])
+def test_bf16_policy_against_rounded_operands_and_fp32(mods, n):
+    E = mods[0]
+    params = D.make_params(D.PARAM_SEED)
+    e = E.HirlEngine(batch=128)
+    e.load_params(params["actor"], params["critic"], params["bc_actor"])
+    rng = np.random.default_rng(n)
+    obs = rng.uniform(-1, 1, (n, 13)).astype(np.float32)
+    d_obs = torch.from_numpy(obs).cuda()
+    a32 = e.act(d_obs).cpu().numpy()
+    e.set_act_dtype("bf16")
+    a16 = e.act(d_obs).cpu().numpy()
+    # the image is exactly bf16(W2), round to nearest even
+    w2 = torch.as_tensor(params["actor"]["full2.weight"]).to(torch.bfloat16)
+    assert torch.equal(e.w2_bf16.cpu().view(torch.int16), w2.reshape(-1).view(torch.int16))
+    ref = rounded_operand_policy(params["actor"], torch.from_numpy(obs)).numpy()
+    np.testing.assert_allclose(a16, ref, rtol=0, atol=1e-4)
+    d = np.abs(a16 - a32)
+    assert d.max() <= 2e-2 and d.mean() <= 2e-3, (d.max(), d.mean())
+    assert d.max() > 0  # it IS the bf16 path
+    # noise modes ride on top unchanged
+    per = rng.normal(0, 0.3, (n, 4)).astype(np.float32)
+    an = e.act(d_obs, noise=torch.from_numpy(per).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(an, np.clip(a16 + per, -1, 1).astype(np.float32))
+
+
+def test_bf16_image_follows_the_actor_adam_step(mods):
+    """hx_adam(which = 1) rewrites the bf16 image of W2 with the parameters it has just updated: after K learn() calls it equals
+    bf16(actor W2) bit for bit, and acting uses the NEW weights."""
+    E = mods[0]
+    params, data = D.make_params(3), D.make_data(4)
+    e = E.HirlEngine(batch=128)
+    e.load_params(params["actor"], params["critic"], params["bc_actor"])
+    e.set_act_dtype("bf16")
+    ring = torch.from_numpy(data["replay"]).cuda()
+    bc = np.zeros((D.N_EXPERT, 32), np.float32)
+    bc[:, 0:13], bc[:, 13:17] = data["expert_s"], data["expert_a"]
+    bc = torch.from_numpy(bc).cuda()
+    rng = np.random.default_rng(0)
+    obs = torch.from_numpy(rng.uniform(-1, 1, (64, 13)).astype(np.float32)).cuda()
+    before = e.act(obs).clone()
+    for k in range(5):
+        idx = torch.from_numpy(rng.integers(0, D.N_REPLAY, 128).astype(np.int32)).cuda()
+        ibc = torch.from_numpy(rng.integers(0, D.N_EXPERT, 128).astype(np.int32)).cuda()
+        e.assemble(ring, idx, bc_table=bc, idx_bc=ibc)
+        e.learn(noise=torch.from_numpy(rng.normal(0, 0.2, 4).astype(np.float32)).cuda(), bc_weight_now=0.5)
+    torch.cuda.synchronize()
+    w2 = E.unpack(e.actor, E.ACTOR_LAYOUT)["full2.weight"].to(torch.bfloat16).reshape(-1)
+    assert torch.equal(e.w2_bf16.view(torch.int16), w2.view(torch.int16))
+    assert not torch.equal(before, e.act(obs))
+    sd = {k: v.cpu().numpy() for k, v in E.unpack(e.actor, E.ACTOR_LAYOUT).items()}
+    np.testing.assert_allclose(e.act(obs).cpu().numpy(), rounded_operand_policy(sd, obs.cpu()).numpy(), rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,scenario", [(4096, "straight_line"), (131072, "mixed")])
+def test_bf16_act_step_is_act_then_step(mods, n, scenario):
+    """hx_actor_act_step_bf16 (one launch up to 8,192 envs, two beyond) == hx_actor_act_bf16 followed by hx_env_step, bit for bit:
+    actions, every state word, observations, rewards, masks, statistics, the replay rows as a multiset.  The large case is the
+    configured size of BASELINE.json configs[4] (131,072 mixed envs: scenario = id mod 3, sorted) — and its dynamics agree
+    with the oracle on a sample, from the actions the bf16 policy produced."""
+    E, Env, Replay = mods
+    params = D.make_params(D.PARAM_SEED)
+    scen = np.sort(np.arange(n) % 3).astype(np.int32) if scenario == "mixed" else scenario
+    outs = []
+    for fused in (True, False):
+        e = E.HirlEngine(batch=128)
+        e.load_params(params["actor"], params["critic"], params["bc_actor"])
+        e.set_act_dtype("bf16")
+        rep = Replay(1 << 20, "cuda")
+        env = Env(n, scenario=scen, seed=5, max_step=40, auto_reset=True, random_reset=True, replay=rep)
+        env.reset()
+        acts = torch.zeros((n, 4), device="cuda")
+        hist = []
+        for t in range(45):
+            prev = env.state.clone() if (t == 44 and not fused) else None
+            if fused:
+                e.act_step(env, sigma=0.1, seed=11, out=acts)
+            else:
+                e.act(env.obs, sigma=0.1, seed=11, row0=env.env_id0, out=acts)
+                env.step(acts)
+            hist.append(acts.clone())
+        torch.cuda.synchronize()
+        k = int(rep.total.item())
+        rows = rep.ring[:min(k, 1 << 20)].cpu().numpy().view(np.uint32)
+        rows = rows[np.lexsort(rows.T[::-1])]
+        outs.append((torch.stack(hist).cpu().numpy().view(np.uint32), env.state.cpu().numpy().view(np.uint32), env.obs.cpu().numpy().view(np.uint32),
+                     env.reward.cpu().numpy().view(np.uint32), env.done.cpu().numpy(), env.success.cpu().numpy(), rows,
+                     np.asarray(list(env.stats_dict().values()))))
+        if not fused:  # the last step of the two-launch run against the oracle on a sample of envs, from the kernel's own actions
+            sample = np.linspace(0, n - 1, 2000).astype(np.int64)
+            st = np.ascontiguousarray(prev.cpu().numpy().T[sample])
+            o_obs = np.zeros((len(sample), 13), np.float32)
+            epi = np.zeros(len(sample), np.uint32)
+            a = hist[-1].cpu().numpy()[sample]
+            ro, do, so = ox.step_batch(st, a, o_obs, max_step=0, auto_reset=0)
+            ended = (env.state[36].view(torch.int32).cpu().numpy()[sample] & 0xFFFF) == 0  # auto-reset envs hold the reset state now
+            np.testing.assert_array_equal(env.done.cpu().numpy()[sample], do)
+            np.testing.assert_array_equal(env.success.cpu().numpy()[sample], so)
+            np.testing.assert_array_equal(env.reward.cpu().numpy()[sample].view(np.uint32), ro.view(np.uint32))
+            keep = ~ended
+            np.testing.assert_array_equal(env.state.cpu().numpy().T[sample][keep].view(np.uint32), st[keep].view(np.uint32))
+            del epi
+    for x, y in zip(*outs):
+        np.testing.assert_array_equal(x, y)
+    assert outs[0][7][7] == 45 * n  # env_steps
