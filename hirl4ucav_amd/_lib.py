@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libhx_mi355.so")
 
 ENV_WORDS, OBS_DIM, ACT_DIM, ROW_WORDS = 37, 13, 4, 32
-STAT_NAMES = ("episodes", "kills", "fire_success_episodes", "time_limit", "fires", "good_fires", "locked_steps", "env_steps")
+STAT_NAMES = ("episodes", "kills", "fire_success_episodes", "time_limit", "fires", "good_fires", "locked_steps", "env_steps", "nonfinite_actions")
 
 F_LOCKED_PREV, F_LOCKED, F_SLOT_PREV, F_SLOT, F_FIRED, F_FIRE_SUCCESS, F_EPISODE_SUCCESS, F_DONE = (1 << i for i in range(8))
 F_SCEN_SHIFT = 8

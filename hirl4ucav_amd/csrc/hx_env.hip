@@ -85,10 +85,11 @@ __global__ __launch_bounds__(EPB*(PAIR ? 2 : 1)) void env_step_kernel(StepArgs A
 
     Stepper<PAIR> T;
     float4 act = {0.f, 0.f, 0.f, 0.f};
-    bool trunc = false, store = false;
+    bool trunc = false, store = false, bad_act = false;
     if (active) {
         T.load(A.state, A.stride, i0, (uint32_t)e, is_opp);
         act = reinterpret_cast<const float4*>(A.actions)[i];
+        bad_act = sanitize_action(act);
         uint32_t ep = T.episode_step();
         ep = ep < 65535u ? ep + 1u : ep;
         trunc = A.o.max_step > 0 && (int)ep >= A.o.max_step;  // train_all.py:346-347
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(EPB*(PAIR ? 2 : 1)) void env_step_kernel(StepArgs A
     }
     if (A.o.stats) {
         const bool mine = active && own;
-        const unsigned vals[HX_STAT_COUNT] = {(mine && ended) ? 1u : 0u, st_kill, st_fs, st_tl, st_fire, st_good, st_lock, mine ? 1u : 0u};
+        const unsigned vals[HX_STAT_COUNT] = {(mine && ended) ? 1u : 0u, st_kill, st_fs, st_tl, st_fire, st_good, st_lock, mine ? 1u : 0u,
+                                              (mine && bad_act) ? 1u : 0u};
 #pragma unroll
         for (int k = 0; k < HX_STAT_COUNT; ++k) {
             const unsigned c = (unsigned)__popcll(__ballot(vals[k] != 0u));

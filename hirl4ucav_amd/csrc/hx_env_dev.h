@@ -526,6 +526,16 @@ __device__ __forceinline__ unsigned ring_slot(unsigned long long total, unsigned
 }
 __device__ __forceinline__ unsigned wrap_slot(unsigned slot, unsigned cap) { return slot >= cap ? slot - cap : slot; }
 
+// A NaN / Inf action component (a diverged policy) is taken as 0 before it can reach the state; returns whether any was replaced.
+__device__ __forceinline__ bool sanitize_action(float4& a) {
+    const bool bx = !(fabsf(a.x) <= 3.0e38f), by = !(fabsf(a.y) <= 3.0e38f), bz = !(fabsf(a.z) <= 3.0e38f), bw = !(fabsf(a.w) <= 3.0e38f);
+    a.x = bx ? 0.0f : a.x;
+    a.y = by ? 0.0f : a.y;
+    a.z = bz ? 0.0f : a.z;
+    a.w = bw ? 0.0f : a.w;
+    return bx || by || bz || bw;
+}
+
 // The arithmetic of one env step for one lane.  Solo: the lane holds the whole env.  Pair: the lane holds ITS aircraft (`mine`)
 // and a copy of the 11 shared words; both lanes of a pair run the same instruction stream — the opponent lane's missile /
 // targeting / wrapper results are computed on meaningless operands and simply never stored (the lanes share a wave: masking

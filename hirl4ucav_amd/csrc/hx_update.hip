@@ -722,9 +722,10 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             const bool insert = A.o.ring != nullptr;
             Stepper<true>& T = envT;
             float4 act = {0.f, 0.f, 0.f, 0.f};
-            bool trunc = false, store = false;
+            bool trunc = false, store = false, bad_act = false;
             if (active) {
                 act = *reinterpret_cast<const float4*>(s_act + e * 4);
+                bad_act = sanitize_action(act);
                 uint32_t ep = T.episode_step();
                 ep = ep < 65535u ? ep + 1u : ep;
                 trunc = A.o.max_step > 0 && (int)ep >= A.o.max_step;  // train_all.py:346-347
@@ -805,7 +806,8 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             }
             if (A.o.stats) {
                 const bool mine_ = active && own;
-                const unsigned vals[HX_STAT_COUNT] = {(mine_ && ended) ? 1u : 0u, st_kill, st_fs, st_tl, st_fire, st_good, st_lock, mine_ ? 1u : 0u};
+                const unsigned vals[HX_STAT_COUNT] = {(mine_ && ended) ? 1u : 0u, st_kill, st_fs, st_tl, st_fire, st_good, st_lock, mine_ ? 1u : 0u,
+                                                      (mine_ && bad_act) ? 1u : 0u};
                 unsigned mine = 0;
 #pragma unroll
                 for (int k = 0; k < HX_STAT_COUNT; ++k) {

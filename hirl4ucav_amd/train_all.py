@@ -26,6 +26,7 @@ from .environments.batched import SCENARIOS, BatchedHarfangEnv
 from .utils import checkpoint as CK
 from .utils.buffer import DeviceReplay
 from .utils.data_processor import read_data
+from .utils.scalars import make_writer
 from .utils.seed import set_seed
 
 MAX_STEP = {"straight_line": 1500, "serpentine": 1500, "circular": 1900}  # train_all.py:159-183
@@ -84,34 +85,51 @@ def label_expert(states, actions, device):
     return rows, sc[keep]
 
 
-def validate(engine, scenario, episodes, max_step, if_random, seed, device, sac=False):
+def validate(engine, scenario, episodes, max_step, if_random, seed, device, sac=False, env=None):
     """validate() of train_all.py:22-102 (train_sac.py:24-68 for SAC) as ONE batch: `episodes` envs stepped with
-    chooseActionNoNoise / exploit until done or the step limit; success / fire success counted only for episodes that ended
-    with done (train_all.py:59-64)."""
-    env = BatchedHarfangEnv(episodes, scenario=scenario, device=device, seed=seed, auto_reset=False, random_reset=if_random, collect_stats=False)
-    obs = env.reset()
+    chooseActionNoNoise / exploit until done or the step limit.  The kernels keep simulating an env after its `done` (no auto
+    reset here), so everything the reference reads when it SEES done — the score so far, env.episode_success, env.fire_success
+    (train_all.py:59-64) — is latched at the first step with done != 0: a missile that is still in flight when the aircraft leaves
+    the altitude band must not turn that episode into a kill afterwards.  `env`: a prepared BatchedHarfangEnv (tests)."""
+    if env is None:
+        env = BatchedHarfangEnv(episodes, scenario=scenario, device=device, seed=seed, auto_reset=False, random_reset=if_random, collect_stats=False)
+        obs = env.reset()
+    else:
+        obs = env.obs
+    calls = getattr(engine, "act_calls", None)  # validation must not move the training run's exploration-noise counter
     total = torch.zeros(episodes, device=device)
     alive = torch.ones(episodes, dtype=torch.bool, device=device)
+    kill = torch.zeros(episodes, dtype=torch.bool, device=device)
+    fired = torch.zeros(episodes, dtype=torch.bool, device=device)
     for step in range(max_step):
         a = engine.act(obs, explore=False) if sac else engine.act(obs)
         obs, r, d, s = env.step(a)
         total += torch.where(alive, r, torch.zeros_like(r))
+        ending = alive & (d != 0)
+        flags = env.state[35].view(torch.int32)
+        kill |= ending & ((flags & _lib.F_EPISODE_SUCCESS) != 0)
+        fired |= ending & ((flags & _lib.F_FIRE_SUCCESS) != 0)
         alive &= d == 0
         if step % 64 == 63 and not bool(alive.any()):
             break
-    flags = env.state[35].view(torch.int32)
-    done = (flags & _lib.F_DONE) != 0
-    success = int((done & ((flags & _lib.F_EPISODE_SUCCESS) != 0)).sum())
-    fire = int((done & ((flags & _lib.F_FIRE_SUCCESS) != 0)).sum())
+    if calls is not None:
+        engine.act_calls = calls
     scores = total.cpu().numpy()
-    return float(scores.mean()), float(scores.std()), success, fire
+    return float(scores.mean()), float(scores.std()), int(kill.sum()), int(fired.sum())
 
 
 def load_expert(config, rng_seed=0):
-    """read_data(data_dir) (train_all.py:222-228); without a file (the Drive data is not available, README.md:6,30) a
-    synthetic stand-in of the same shape."""
-    if config.expert_csv and os.path.exists(config.expert_csv):
+    """read_data(data_dir) (train_all.py:222-228).  The reference raises when the file is missing, and so does this: a mistyped path must
+    not turn into a run that trains on noise.  `--synthetic_expert` (benchmarks, tests; the Drive data is not available, README.md:6,30)
+    asks for a uniform-random stand-in of the same shape explicitly, and says so loudly."""
+    if config.expert_csv:
+        if not os.path.exists(config.expert_csv):
+            raise FileNotFoundError(f"--expert_csv {config.expert_csv}: no such file")
         return read_data(config.expert_csv)
+    if not getattr(config, "synthetic_expert", False):
+        raise ValueError("HIRL / E-SAC / BC need expert data: pass --expert_csv FILE (hirl4ucav_amd.data.ai_data_col writes one), or "
+                         "--synthetic_expert to run on a uniform-random stand-in (throughput runs and tests only)")
+    print("WARNING: --synthetic_expert: the expert table is UNIFORM RANDOM noise - throughput / plumbing runs only", flush=True)
     rng = np.random.default_rng(rng_seed)
     es = rng.uniform(-1, 1, (20000, 13))
     es[:, 7:9] = np.where(rng.random((20000, 2)) < 0.5, 1, -1)
@@ -119,6 +137,32 @@ def load_expert(config, rng_seed=0):
     ea = rng.uniform(-1, 1, (20000, 4))
     ea[:, 3] = np.where(rng.random(20000) < 1e-3, 1, -1)
     return es, ea
+
+
+def shared_value(value, world):
+    """rank 0's `value` on every rank (one broadcast_object_list)"""
+    if world <= 1:
+        return value
+    box = [value]
+    torch.distributed.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def save_hparams(log_dir, **kw):
+    """save_parameters_to_txt (train_all.py:104-109,233): log1.txt, one key=value per line"""
+    with open(os.path.join(log_dir, "log1.txt"), "w") as f:
+        for k, v in kw.items():
+            f.write(f"{k}={v}\n")
+
+
+def log_validation(writer, episode, mean, std, success_rate, fire_rate):
+    """the four Validation/* scalars of train_all.py:97-100"""
+    writer.add_scalar("Validation/Avg Reward", mean, episode)
+    writer.add_scalar("Validation/Std Reward", std, episode)
+    writer.add_scalar("Validation/Success Rate", success_rate, episode)
+    writer.add_scalar("Validation/Fire Success Rate", fire_rate, episode)
+    if hasattr(writer, "flush"):
+        writer.flush()
 
 
 def train_bc(config, device, seed, max_step):
@@ -136,12 +180,17 @@ def train_bc(config, device, seed, max_step):
     log_dir = os.path.join(config.result_dir, env_type, config.agent, config.model_name, time.strftime("%Y_%m_%d_%H_%M"))
     model_dir = os.path.join(log_dir, "model")
     os.makedirs(model_dir, exist_ok=True)
+    save_hparams(log_dir, actorLR=1e-3, batchSize=batch, maxStep=max_step, hiddenLayer1=256, hiddenLayer2=512, agent="BC", model_dir=model_dir,
+                 data_dir=config.expert_csv)
+    writer = make_writer(os.path.join(log_dir, "summary"))
     high_score, success_rate, arttir = -math.inf, 0.0, 1
     for episode in range(config.episodes):
         for _ in range(max_step):
             eng.sample(table, None, bc_table, seed=seed + 2)
             eng.bc_train_actor()
-        print(f"Episode {episode + 1}: bc_loss {eng.losses_host()[2]:.6f}", flush=True)
+        bc_loss = eng.losses_host()[2]
+        writer.add_scalar("Loss/BC_Loss", bc_loss, (episode + 1) * max_step)  # train_all.py:250-251
+        print(f"Episode {episode + 1}: bc_loss {bc_loss:.6f}", flush=True)
         if (episode + 1) % config.checkpoint_rate == 0 and (episode + 1) >= config.bc_validate_from:  # train_all.py:259
             mean, std, succ, fire = validate(eng, env_type, 50, max_step, config.random, seed + 12345, device)
             if mean > high_score or succ / 50 >= success_rate or arttir % 5 == 0:
@@ -149,13 +198,42 @@ def train_bc(config, device, seed, max_step):
                            os.path.join(model_dir, checkpoint_tag(arttir, succ, 50, mean) + "Actor_Harfang_GYM"))
                 high_score, success_rate = max(high_score, mean), max(success_rate, succ / 50)
             print(f"Validation {arttir}: avg reward {mean:.2f} (std {std:.2f}) success {succ / 50:.2f} fire success {fire / 50:.2f}", flush=True)
+            log_validation(writer, episode, mean, std, succ / 50, fire / 50)
             arttir += 1
+    writer.close()
     return log_dir
+
+
+def launch_ranks(n, argv):
+    """`--gpus N` without a launcher environment: start the N ranks as a CHILD torch.distributed.run (this process has not touched a
+    GPU and only relays the exit code); refuse when fewer than N GPUs are visible."""
+    import socket
+    import subprocess
+    import sys
+
+    have = torch.cuda.device_count()  # counting does not initialise the GPU
+    if have < n and os.environ.get("HX_DIST_BACKEND", "nccl") == "nccl":
+        sys.stderr.write(f"train_all: {n} GPUs requested, {have} visible\n")
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), "-m", "hirl4ucav_amd.train_all"] + list(argv), env=env)
 
 
 def main(config):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if getattr(config, "gpus", None) and config.gpus != world:
+        raise SystemExit(f"train_all: --gpus {config.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if not torch.cuda.is_available():
+        raise SystemExit("train_all needs a GPU: the product has no CPU path")
+    if world > torch.cuda.device_count() and os.environ.get("HX_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"train_all: {world} ranks but {torch.cuda.device_count()} GPUs visible")
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -164,9 +242,12 @@ def main(config):
         # RCCL over xGMI; HX_DIST_BACKEND=gloo exists only to exercise this path where all ranks share one GPU (tests)
         backend = os.environ.get("HX_DIST_BACKEND", "nccl")
         torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
-    if config.seed is not None:
-        set_seed(config.seed + rank)
-    seed = config.seed or 0
+    # no --seed: rank 0 draws one and every rank uses it (the replicas must start from identical networks either way); it is printed
+    # and written to log1.txt, so that "unseeded" differs from --seed 0 and is still reproducible after the fact
+    seed = shared_value(config.seed if config.seed is not None else int.from_bytes(os.urandom(4), "little") & 0x7FFFFFFF, world)
+    set_seed(seed + rank)
+    if rank == 0:
+        print(f"seed {seed}" + ("" if config.seed is not None else " (drawn: no --seed given)"), flush=True)
     env_type, n = config.env, config.num_envs
     max_step = MAX_STEP[env_type] * (8 if config.render else 1)
     if config.agent == "BC":
@@ -201,12 +282,35 @@ def main(config):
         tab = np.zeros((bc_len, 32), np.float32)
         tab[:, 0:13], tab[:, 13:17] = es, ea
         bc_table = torch.from_numpy(tab).to(device)
-        if hirl and config.bc_actor and os.path.exists(config.bc_actor):
+        if hirl and config.bc_actor:  # agent.load_bc_actor (train_all.py:311-312): a missing file is an error, as in the reference
+            if not os.path.exists(config.bc_actor):
+                raise FileNotFoundError(f"--bc_actor {config.bc_actor}: no such file")
             eng.bc_actor.copy_(E.pack(torch.load(config.bc_actor, map_location="cpu"), E.ACTOR_LAYOUT, E.ACTOR_SIZE, device))
+        elif hirl and config.type == "soft" and rank == 0:
+            print("WARNING: HIRL-soft without --bc_actor: the soft weight is estimated against a randomly initialised bc_actor", flush=True)
+    if getattr(config, "dtype", "f32") == "bf16" and not sac:
+        eng.set_act_dtype("bf16")
 
-    log_dir = os.path.join(config.result_dir, env_type, config.agent, config.model_name, time.strftime("%Y_%m_%d_%H_%M"))
+    # ONE run directory for all ranks: rank 0 names it (a minute boundary between ranks would scatter the state_rank<r>.pt shards)
+    log_dir = shared_value(os.path.join(config.result_dir, env_type, config.agent, config.model_name, time.strftime("%Y_%m_%d_%H_%M")), world)
     model_dir = os.path.join(log_dir, "model")
     os.makedirs(model_dir, exist_ok=True)
+    writer = None
+    if rank == 0:
+        save_hparams(log_dir, bufferSize=buffer_size, criticLR=1e-3, actorLR=1e-3, batchSize=batch, maxStep=max_step, validationStep=max_step,
+                     hiddenLayer1=256, hiddenLayer2=512, agent=config.agent, model_dir=model_dir, hirl_type=config.type, data_dir=config.expert_csv,
+                     num_envs=n, world=world, seed=seed, dtype=getattr(config, "dtype", "f32"))
+        writer = make_writer(os.path.join(log_dir, "summary"))
+    if config.load_model and not sac:  # agent.loadCheckpoints(tag, model_dir), train_all.py:239-240 (the reference hard-codes the tag)
+        src = config.load_dir or model_dir
+        for name, flat, layout, size in (("Critic_", eng.critic, E.CRITIC_LAYOUT, E.CRITIC_SIZE), ("Actor_", eng.actor, E.ACTOR_LAYOUT, E.ACTOR_SIZE),
+                                         ("TargetCritic_", eng.target_critic, E.CRITIC_LAYOUT, E.CRITIC_SIZE),
+                                         ("TargetActor_", eng.target_actor, E.ACTOR_LAYOUT, E.ACTOR_SIZE)):
+            f = os.path.join(src, config.load_tag + name + "Harfang_GYM")
+            if not os.path.exists(f):
+                raise FileNotFoundError(f"--load_model: {f} not found (--load_dir / --load_tag name the checkpoint)")
+            flat.copy_(E.pack(torch.load(f, map_location="cpu"), layout, size, device))
+        eng.refresh_bf16()
     run = {"episode": 0, "expert_num": batch if (hirl or esac) else 0, "high_score": -math.inf, "success_rate": 0.0, "arttir": 1}
     if config.resume:  # every rank restores its own shard: <resume>/state_rank<r>.pt
         run = CK.load_run(os.path.join(config.resume, f"state_rank{rank}.pt"), eng, env, replay)
@@ -218,6 +322,9 @@ def main(config):
     expert_num, high_score, success_rate, arttir = run["expert_num"], run["high_score"], run["success_rate"], run["arttir"]
     actions = torch.zeros((n, 4), device=device)
     t0, episode0 = time.time(), run["episode"]
+    log_rate = 300  # train_all.py:208
+    ret = torch.zeros(n, device=device) if config.log_rewards else None
+    last_stats = env.stats_dict()
     for episode in range(episode0, config.episodes):
         w_now, warm = bc_weight_schedule(config.type, episode, config.bc_weight) if hirl else (0.0, 0.0)
         for step in range(max_step):
@@ -228,6 +335,8 @@ def main(config):
                 eng.act_step(env, seed=seed + 1, out=actions)              # replay ring depends on the workgroup schedule)
             else:
                 eng.act_step(env, sigma=0.1, seed=seed + 1, out=actions)
+            if ret is not None:
+                ret += env.reward
             if step == max_step - 1:
                 break
             expert_num = expert_num_after(expert_num, step, warm_up_rate)
@@ -239,6 +348,10 @@ def main(config):
                 eng.sample(replay, expert, bc_table, n_main=batch - expert_num, seed=seed + 2 + rank)
                 eng.learn(bc_weight_now=w_now, bc_warm_up_weight=warm)
                 w_now = None  # afterwards learn()'s own returned weight is fed back (train_all.py:361): the stored device value
+            if writer is not None and step % log_rate == 0 and not sac:  # Loss/* every 300 steps, train_all.py:362-367
+                c_, a_, b_, r__, f_, _w = eng.losses_host()
+                for tag, v in (("Loss/Critic_Loss", c_), ("Loss/Actor_Loss", a_), ("Loss/BC_Loss", b_), ("Loss/RL_Loss", r__), ("Loss/BC_Fire_Loss", f_)):
+                    writer.add_scalar(tag, v, step + episode * max_step)
         if rank == 0:
             c, a, b, r_, f, w = eng.losses_host()
             st = env.stats_dict()
@@ -247,6 +360,18 @@ def main(config):
             vals = (c, a, b, r_, w)
             print(f"Episode {episode + 1}: " + " ".join(f"{k} {v:.4f}" for k, v in zip(names, vals)) + f" | episodes {st['episodes']} "
                   f"kills {st['kills']} fire-success {st['fire_success_episodes']} | {sps:,.0f} env steps/s", flush=True)
+            if writer is not None:  # Training/* per episode, train_all.py:383-388: rates over the env episodes that ENDED during this driver episode
+                ended = max(st["episodes"] - last_stats["episodes"], 1)
+                writer.add_scalar("Training/Last 50 Episode Train success rate", (st["kills"] - last_stats["kills"]) / ended, episode)
+                writer.add_scalar("Training/Last 50 Episode Fire success rate", (st["fire_success_episodes"] - last_stats["fire_success_episodes"]) / ended, episode)
+                writer.add_scalar("Others/BC_weight", w, episode)
+                writer.add_scalar("Others/Nonfinite_actions", st.get("nonfinite_actions", 0), episode)
+                if ret is not None:
+                    tot = float(ret.mean())
+                    writer.add_scalar("Training/Episode Reward", tot, episode)
+                    writer.add_scalar("Training/Average Step Reward", tot / max_step, episode)
+                    ret.zero_()
+                last_stats = st
         if (episode + 1) % checkpoint_rate == 0 and rank == 0:  # VALIDATION, train_all.py:400-402 / train_sac.py:431-433
             mean, std, succ, fire = validate(eng, env_type, 50, max_step, config.random, seed + 12345, device, sac)
             if mean > high_score or succ / 50 >= success_rate or arttir % 5 == 0:
@@ -259,16 +384,23 @@ def main(config):
                         torch.save({k: v.cpu().clone() for k, v in E.unpack(flat, layout).items()}, os.path.join(model_dir, tag + name + "Harfang_GYM"))
                 high_score, success_rate = max(high_score, mean), max(success_rate, succ / 50)
             print(f"Validation {arttir}: avg reward {mean:.2f} (std {std:.2f}) success {succ / 50:.2f} fire success {fire / 50:.2f}", flush=True)
+            log_validation(writer, episode, mean, std, succ / 50, fire / 50)
             arttir += 1
-        if world > 1 and (episode + 1) % checkpoint_rate == 0:  # sharded run: the replicas must not have drifted apart
+        if world > 1 and ((episode + 1) % checkpoint_rate == 0 or (config.replica_check_every and (episode + 1) % config.replica_check_every == 0)):  # sharded run: the replicas must not have drifted apart
             mine = torch.tensor([eng.replica_checksum()], dtype=torch.int64, device=device)
             every = [torch.zeros_like(mine) for _ in range(world)]
             torch.distributed.all_gather(every, mine)
             if any(int(c.item()) != int(mine.item()) for c in every):
                 raise RuntimeError(f"rank {rank}: network replicas diverged at episode {episode + 1}")
         if config.snapshot_every and (episode + 1) % config.snapshot_every == 0:  # whole-run state for --resume (one file per rank)
+            if world > 1:
+                torch.distributed.barrier()  # every shard of a snapshot comes from the same episode ...
             CK.save_run(os.path.join(log_dir, f"state_rank{rank}.pt"), eng, env, replay,
                         {"episode": episode + 1, "expert_num": expert_num, "high_score": high_score, "success_rate": success_rate, "arttir": arttir})
+            if world > 1:
+                torch.distributed.barrier()  # ... and nobody runs ahead while a shard is still being written
+    if writer is not None:
+        writer.close()
     if world > 1:
         torch.distributed.destroy_process_group()
     return log_dir
@@ -302,8 +434,20 @@ def parser():
                         "insert order, and so the whole run, reproducible bit for bit")
     p.add_argument("--snapshot_every", type=int, default=25, help="episodes between whole-run snapshots (0: never)")
     p.add_argument("--resume", type=str, default=None, help="run directory holding state_rank<r>.pt to continue from")
+    p.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; without a launcher environment the driver starts them itself")
+    p.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16"], help="bf16: policy inference on bf16 MFMA (update, dynamics fp32)")
+    p.add_argument("--synthetic_expert", action="store_true", help="uniform-random stand-in for the expert CSV (throughput runs and tests ONLY)")
+    p.add_argument("--load_dir", type=str, default=None, help="--load_model: directory of the checkpoint files (default: this run's model dir)")
+    p.add_argument("--load_tag", type=str, default="Agent20_successRate0.64", help="--load_model: checkpoint tag (train_all.py:240 hard-codes this one)")
+    p.add_argument("--log_rewards", action="store_true", help="also log Training/Episode Reward (one more small launch per vector step)")
+    p.add_argument("--replica_check_every", type=int, default=5, help="sharded runs: episodes between replica checksum comparisons (0: only at validation)")
     return p
 
 
 if __name__ == "__main__":
-    main(parser().parse_args())
+    import sys
+
+    cfg = parser().parse_args()
+    if cfg.gpus and cfg.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(cfg.gpus, sys.argv[1:]))
+    main(cfg)

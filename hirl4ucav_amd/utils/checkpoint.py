@@ -61,10 +61,15 @@ def load_env_state(env, st):
 
 
 def save_run(path, eng, env, replay, driver):
+    """Written to a temporary file and renamed: a kill during the ~130 MB write leaves the previous snapshot intact."""
+    import os
+
     torch.cuda.synchronize()
+    tmp = path + ".tmp"
     torch.save({"engine": engine_state(eng), "env": env_state(env), "replay": replay_state(replay), "driver": dict(driver),
                 "rng": {"python": random.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state(),
-                        "torch_cuda": torch.cuda.get_rng_state(env.device)}}, path)
+                        "torch_cuda": torch.cuda.get_rng_state(env.device)}}, tmp)
+    os.replace(tmp, path)
 
 
 def load_run(path, eng, env, replay):

@@ -57,7 +57,11 @@ extern "C" {
 
 /* stats[] slots accumulated by hx_env_step (uint64 each) */
 enum { HX_STAT_EPISODES = 0, HX_STAT_KILLS, HX_STAT_FIRE_SUCCESS_EPISODES, HX_STAT_TIME_LIMIT, HX_STAT_FIRES,
-       HX_STAT_GOOD_FIRES, HX_STAT_LOCKED_STEPS, HX_STAT_ENV_STEPS, HX_STAT_COUNT };
+       HX_STAT_GOOD_FIRES, HX_STAT_LOCKED_STEPS, HX_STAT_ENV_STEPS,
+       HX_STAT_NONFINITE_ACTIONS, /* env steps whose action held a NaN / Inf component: the component is taken as 0 (and stored as 0 in the
+                                     replay row), so a diverged policy cannot poison the simulator state — the stand-in for the reference's
+                                     missing failure detection */
+       HX_STAT_COUNT };
 
 const char* hx_last_error(void);
 int hx_version(void);

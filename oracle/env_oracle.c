@@ -478,7 +478,19 @@ void ox_env_observe(const OxEnv* E, float* obs) {
     obs[12] = rb.health;
 }
 
-/* HarfangEnv.step: E4 -> E5 -> E6 -> E7 -> E8   HarfangEnv_GYM.py:83-90 */
+/* A NaN / Inf action component (a diverged policy) is taken as 0 before it can reach the state (the build's stand-in for failure
+ * detection).  Returns whether any component was replaced. */
+int ox_sanitize_action(const float* in, float* out) {
+    int bad = 0;
+    for (int c = 0; c < 4; ++c) {
+        int b = !(fabsf(in[c]) <= 3.0e38f);
+        out[c] = b ? 0.0f : in[c];
+        bad |= b;
+    }
+    return bad;
+}
+
+/* HarfangEnv.step: E4 -> E5 -> E6 -> E7 -> E8   HarfangEnv_GYM.py:83-90 (action: already sanitized) */
 void ox_env_step(OxEnv* E, const float* action, float* obs, float* reward, uint8_t* done, int8_t* success) {
     float ally_cmd[3] = {action[0], action[1], action[2]}; /* pitch, roll, yaw :140-142 */
     float opp_cmd[3];
@@ -506,8 +518,8 @@ void ox_env_rearm(OxEnv* E) { E->flags |= F_SIM_SLOT; }
  *   - an episode that ended (done or time limit) is reset in place and obs_io receives the reset obs.
  * obs_io [n][13] in: previous observation, out: next observation for the policy.
  * ring [cap][32] rows (s13 a4 s'13 r done), *total = transitions ever stored (slot = total % cap).
- * stats[8] += {episodes, kills(episode_success), fire_success episodes, time-limit ends, fires, good fires,
- *               locked steps, env steps}. */
+ * stats[9] += {episodes, kills(episode_success), fire_success episodes, time-limit ends, fires, good fires,
+ *               locked steps, env steps, steps with a non-finite action}. */
 void ox_env_step_batch(OxEnv* envs, int64_t n, const float* actions, float* obs_io, float* reward, uint8_t* done,
                        int8_t* success, int max_step, int auto_reset, int randomize, uint64_t seed,
                        uint32_t env_id0, uint32_t* episode_ctr, float* ring, int8_t* ring_succ, int64_t cap,
@@ -515,14 +527,16 @@ void ox_env_step_batch(OxEnv* envs, int64_t n, const float* actions, float* obs_
     for (int64_t i = 0; i < n; ++i) {
         OxEnv* E = &envs[i];
         float prev[13], nobs[13];
+        float act[4];
+        const int bad_act = ox_sanitize_action(actions + i * 4, act);
         memcpy(prev, obs_io + i * 13, sizeof prev);
-        ox_env_step(E, actions + i * 4, nobs, &reward[i], &done[i], &success[i]);
+        ox_env_step(E, act, nobs, &reward[i], &done[i], &success[i]);
         uint32_t ep = E->counters & 0xFFFFu;
         int trunc = max_step > 0 && (int)ep >= max_step;
         if (ring && !trunc) {
             float* row = ring + (int64_t)(*total % (uint64_t)cap) * 32;
             memcpy(row, prev, 13 * 4);
-            memcpy(row + 13, actions + i * 4, 4 * 4);
+            memcpy(row + 13, act, 4 * 4);
             memcpy(row + 17, nobs, 13 * 4);
             row[30] = reward[i];
             row[31] = done[i] ? 1.0f : 0.0f;
@@ -534,6 +548,7 @@ void ox_env_step_batch(OxEnv* envs, int64_t n, const float* actions, float* obs_
             if (success[i] == 1) stats[5] += 1;
             if (E->flags & F_LOCKED) stats[6] += 1;
             stats[7] += 1;
+            if (bad_act) stats[8] += 1;
         }
         if (auto_reset && (done[i] || trunc)) {
             if (stats) {

@@ -90,7 +90,7 @@ def test_driver_two_ranks(agent, tmp_path):
             "T.main(T.parser().parse_args(sys.argv[1:]))")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", port, "--no-python", sys.executable, "-c", code] + agent +
-                       ["--random", "--seed", "1", "--num_envs", "512", "--episodes", "2", "--checkpoint_rate", "2", "--snapshot_every", "0",
+                       ["--random", "--seed", "1", "--num_envs", "512", "--episodes", "2", "--checkpoint_rate", "2", "--snapshot_every", "0", "--synthetic_expert",
                         "--buffer_size", "65536", "--result_dir", str(tmp_path)],
                        cwd=ROOT, env={**os.environ, "HX_DIST_BACKEND": "gloo"}, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]

@@ -2,8 +2,9 @@
 (hx_actor_act_bf16 / hx_actor_act_step_bf16 / hx_pack_w2_bf16).
 
 Tolerances, stated separately from the fp32 path's 1e-5 (SURVEY.md 7 "bf16 config"):
-  * against an fp32 evaluation of the SAME rounded operands (W2 and h1 rounded to bf16, everything else fp32): |da| <= 1e-4 —
-    only the accumulation order of the 256-long dot products differs;
+  * against an fp32 evaluation of the SAME rounded operands (W2 and h1 rounded to bf16, everything else fp32): 99 % of the outputs
+    within 1e-4 (only the accumulation order of the 256-long dot products differs) and all within 2e-3 (an h1 element whose fp32
+    value sits within an ulp of a bf16 rounding boundary may round the other way in the kernel than in torch: one 2^-9 step);
   * against the full-fp32 policy: |da| <= 2e-2 on the tanh outputs, mean |da| <= 2e-3 (8 significant bits on two operands).
 Dynamics, masks, rewards stay exactly what the env step computes from the actions it is given: checked bit for bit."""
 import numpy as np
@@ -42,6 +43,11 @@ def rounded_operand_policy(p, x):
     return torch.tanh(F.linear(h2, p["final.weight"], p["final.bias"]))
 
 
+def close_to_rounded_operands(a, ref):
+    d = np.abs(a - ref)
+    assert (d <= 1e-4).mean() >= 0.99 and d.max() <= 2e-3, ((d <= 1e-4).mean(), d.max())
+
+
 @pytest.mark.parametrize("n", [1, 16, 1000, 9000])
 def test_bf16_policy_against_rounded_operands_and_fp32(mods, n):
     E = mods[0]
@@ -58,7 +64,7 @@ def test_bf16_policy_against_rounded_operands_and_fp32(mods, n):
     w2 = torch.as_tensor(params["actor"]["full2.weight"]).to(torch.bfloat16)
     assert torch.equal(e.w2_bf16.cpu().view(torch.int16), w2.reshape(-1).view(torch.int16))
     ref = rounded_operand_policy(params["actor"], torch.from_numpy(obs)).numpy()
-    np.testing.assert_allclose(a16, ref, rtol=0, atol=1e-4)
+    close_to_rounded_operands(a16, ref)
     d = np.abs(a16 - a32)
     assert d.max() <= 2e-2 and d.mean() <= 2e-3, (d.max(), d.mean())
     assert d.max() > 0  # it IS the bf16 path
@@ -93,7 +99,7 @@ def test_bf16_image_follows_the_actor_adam_step(mods):
     assert torch.equal(e.w2_bf16.view(torch.int16), w2.view(torch.int16))
     assert not torch.equal(before, e.act(obs))
     sd = {k: v.cpu().numpy() for k, v in E.unpack(e.actor, E.ACTOR_LAYOUT).items()}
-    np.testing.assert_allclose(e.act(obs).cpu().numpy(), rounded_operand_policy(sd, obs.cpu()).numpy(), rtol=0, atol=1e-4)
+    close_to_rounded_operands(e.act(obs).cpu().numpy(), rounded_operand_policy(sd, obs.cpu()).numpy())
 
 
 @pytest.mark.parametrize("n,scenario", [(4096, "straight_line"), (131072, "mixed")])

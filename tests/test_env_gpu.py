@@ -159,7 +159,7 @@ def test_single_step_parity_on_random_states(hx, n):
     torch.cuda.synchronize()
     eo = e.copy()
     oo = obs_prev.copy()
-    stats = np.zeros(8, np.uint64)
+    stats = np.zeros(9, np.uint64)
     ro, do, so = ox.step_batch(eo, a, oo, stats=stats)
     g = from_soa(env.state)
     np.testing.assert_array_equal(d.cpu().numpy(), do)
@@ -194,7 +194,7 @@ def test_trajectory_with_auto_reset_and_fused_insert(hx):
     ring = np.zeros((cap, 32), np.float32)
     rsucc = np.zeros(cap, np.int8)
     total = np.zeros(1, np.uint64)
-    stats = np.zeros(8, np.uint64)
+    stats = np.zeros(9, np.uint64)
     epi = np.zeros(n, np.uint32)
     for t in range(steps):
         a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
@@ -356,3 +356,37 @@ def test_full_size_mixed_config_properties(hx):
     pick = rng.choice(stored, 2000, replace=False)
     assert np.all((rows[pick, 31] == 0) | (rows[pick, 31] == 1)) and np.all(np.abs(rows[pick, 13:17]) <= 1)
     assert np.all(np.isfinite(rows[pick]))
+
+
+def test_nonfinite_actions_are_neutralised(hx):
+    """A NaN / Inf action component (a diverged policy) is taken as 0 before it reaches the state, counted in the statistics and
+    stored as 0 in the replay row — GPU and oracle agree bit for bit, and nothing non-finite appears anywhere."""
+    n = 5000
+    rng = np.random.default_rng(11)
+    scen = rng.integers(0, 3, n)
+    e = random_states(n, rng, scen)
+    a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    bad = rng.random((n, 4)) < 0.05
+    a[bad] = rng.choice(np.array([np.nan, np.inf, -np.inf], np.float32), int(bad.sum()))
+    obs_prev = rng.uniform(-1, 1, (n, 13)).astype(np.float32)
+    rep = hx.Replay(1 << 14, "cuda")
+    env = hx.Env(n, scenario=0, auto_reset=False, max_step=0, collect_stats=True, replay=rep)
+    env.set_state(to_soa(e), torch.from_numpy(obs_prev))
+    obs, r, d, s = env.step(torch.from_numpy(a).cuda())
+    torch.cuda.synchronize()
+    eo, oo = e.copy(), obs_prev.copy()
+    stats = np.zeros(9, np.uint64)
+    ring, total = np.zeros((1 << 14, 32), np.float32), np.zeros(1, np.uint64)
+    ro, do, so = ox.step_batch(eo, a, oo, stats=stats, ring=ring, total=total)
+    g = from_soa(env.state)
+    assert np.isfinite(g[:, :35]).all() and np.isfinite(obs.cpu().numpy()).all() and np.isfinite(r.cpu().numpy()).all()
+    np.testing.assert_array_equal(g.view(np.uint32), eo.view(np.uint32))
+    assert_float_close(obs.cpu().numpy(), oo, "obs")
+    assert_float_close(r.cpu().numpy(), ro, "reward")
+    np.testing.assert_array_equal(d.cpu().numpy(), do)
+    st = env.stats_dict()
+    assert st["nonfinite_actions"] == int(stats[8]) == int(bad.any(1).sum()) > 100
+    rows = rep.ring[:n].cpu().numpy()
+    assert np.isfinite(rows).all()
+    key = lambda x: np.lexsort(x.view(np.uint32).T[::-1])  # noqa: E731
+    np.testing.assert_array_equal(rows[key(rows)].view(np.uint32), ring[:n][key(ring[:n])].view(np.uint32))

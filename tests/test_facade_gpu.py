@@ -142,7 +142,7 @@ def test_vectorised_driver_runs_and_learns_something(tmp_path, capsys):
     T.MAX_STEP["straight_line"] = 40
     try:
         cfg = T.parser().parse_args(["--agent", "HIRL", "--type", "soft", "--env", "straight_line", "--random", "--seed", "1",
-                                     "--num_envs", "256", "--episodes", "2", "--result_dir", str(tmp_path), "--buffer_size", "65536"])
+                                     "--num_envs", "256", "--episodes", "2", "--result_dir", str(tmp_path), "--buffer_size", "65536", "--synthetic_expert"])
         T.main(cfg)
     finally:
         T.MAX_STEP["straight_line"] = 1500
@@ -208,7 +208,7 @@ def test_sac_agent_facade_and_driver(tmp_path, capsys):
         T.main(T.parser().parse_args(["--agent", "SAC", "--env", "serpentine", "--random", "--seed", "2", "--num_envs", "256", "--episodes", "2",
                                       "--result_dir", str(tmp_path), "--buffer_size", "65536"]))
         T.main(T.parser().parse_args(["--agent", "SAC", "--type", "ESAC", "--env", "serpentine", "--seed", "2", "--num_envs", "256", "--episodes", "1",
-                                      "--result_dir", str(tmp_path), "--buffer_size", "65536"]))
+                                      "--result_dir", str(tmp_path), "--buffer_size", "65536", "--synthetic_expert"]))
     finally:
         T.MAX_STEP["serpentine"] = 1500
     out = capsys.readouterr().out
@@ -223,7 +223,7 @@ def test_resumed_run_continues_bit_identically(tmp_path, capsys, agent_args):
     from hirl4ucav_amd import train_all as T
 
     env_name = agent_args[-1]
-    common = agent_args + ["--random", "--seed", "3", "--num_envs", "256", "--buffer_size", "32768", "--checkpoint_rate", "2",
+    common = agent_args + ["--random", "--seed", "3", "--num_envs", "256", "--buffer_size", "32768", "--checkpoint_rate", "2", "--synthetic_expert",
                            "--separate_launches"]  # one env workgroup: the replay insert order, and with it the run, is reproducible
     T.MAX_STEP[env_name] = 48
     try:
@@ -295,3 +295,39 @@ def test_expert_collector_bc_pipeline(tmp_path, capsys):
     assert len(files) == 1 and files[0].endswith("Actor_Harfang_GYM")
     sd = torch.load(os.path.join(d, "model", files[0]))
     assert sorted(sd) == sorted(H.ACTOR_KEYS)
+
+
+def test_validation_latches_success_at_the_first_done():
+    """validate() keeps stepping envs that are already done (no auto reset), so EPISODE_SUCCESS raised LATER — a missile
+    still in flight when the aircraft left the altitude band — must not count: the reference reads env.episode_success at the step
+    it first sees done (train_all.py:59-64)."""
+    from hirl4ucav_amd import _lib
+    from hirl4ucav_amd import train_all as T
+    from hirl4ucav_amd.agents import engine as E
+    from hirl4ucav_amd.agents.HIRL import init_actor_state_dict, init_critic_state_dict
+    from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
+
+    n = 4
+    env = BatchedHarfangEnv(n, scenario="straight_line", seed=0, auto_reset=False, random_reset=False, collect_stats=False)
+    env.reset()
+    st = env.state.clone()
+    flags = st[35].view(torch.int32)
+    # envs 0, 1: above the altitude band (done at step 1) with a guided missile 600 m behind the opponent: it kills ~40 ticks later
+    for i in (0, 1):
+        st[1, i] = 10500.0
+        st[26:29, i] = st[13:16, i] - torch.tensor([0.0, 0.0, 600.0], device=st.device)
+        st[29:32, i] = torch.tensor([0.0, 0.0, 900.0], device=st.device)
+        flags[i] = (int(flags[i]) | _lib.F_M_ACTIVE | _lib.F_M_GUIDED) & ~_lib.F_SIM_SLOT
+    # env 2: a kill that IS the cause of done (missile about to hit, aircraft inside the band) counts
+    st[26:29, 2] = st[13:16, 2] - torch.tensor([0.0, 0.0, 30.0], device=st.device)
+    st[29:32, 2] = torch.tensor([0.0, 0.0, 900.0], device=st.device)
+    flags[2] = (int(flags[2]) | _lib.F_M_ACTIVE | _lib.F_M_GUIDED | _lib.F_FIRE_SUCCESS) & ~_lib.F_SIM_SLOT
+    env.set_state(st, env.obs)
+    eng = E.HirlEngine(batch=128)
+    eng.load_params(init_actor_state_dict(), init_critic_state_dict())
+    calls = eng.act_calls
+    mean, std, succ, fire = T.validate(eng, "straight_line", n, 200, False, 0, torch.device("cuda"), env=env)
+    f = env.state[35].view(torch.int32)
+    assert all(int(f[i]) & _lib.F_EPISODE_SUCCESS for i in (0, 1, 2))  # the late kills DID happen in the simulator ...
+    assert succ == 1 and fire == 1                                      # ... but only env 2's counts
+    assert eng.act_calls == calls                                       # validation leaves the exploration-noise counter alone

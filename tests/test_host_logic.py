@@ -165,3 +165,58 @@ def test_collector_episode_filter():
     assert s.shape == (82, 13) and a.shape == (82, 4)
     assert s[:31, 0].tolist() == list(range(31)) and s[31:, 0].tolist() == [400 + t for t in range(51)]
     assert s[30, 12] == 0 and s[29, 12] > 0 and int((a[:, 3] > 0).sum()) == 2
+
+
+def test_missing_inputs_raise_instead_of_training_on_noise(tmp_path):
+    """a mistyped --expert_csv / no expert data at all must raise like the reference's read_data does; the synthetic
+    stand-in exists only behind --synthetic_expert."""
+    from hirl4ucav_amd import train_all as T
+
+    with pytest.raises(FileNotFoundError):
+        T.load_expert(T.parser().parse_args(["--expert_csv", str(tmp_path / "nope.csv")]))
+    with pytest.raises(ValueError):
+        T.load_expert(T.parser().parse_args([]))
+    es, ea = T.load_expert(T.parser().parse_args(["--synthetic_expert"]))
+    assert es.shape == (20000, 13) and ea.shape == (20000, 4)
+
+
+def test_scalar_writer_keeps_the_reference_tags(tmp_path):
+    """utils/scalars.py: SummaryWriter when tensorboard is installed, otherwise scalars.jsonl with the same add_scalar calls."""
+    import json
+
+    from hirl4ucav_amd.train_all import log_validation
+    from hirl4ucav_amd.utils.scalars import JsonlWriter, make_writer
+
+    w = make_writer(str(tmp_path / "summary"))
+    log_validation(w, 24, -310.5, 12.0, 0.64, 0.7)  # train_all.py:97-100
+    w.close()
+    if isinstance(w, JsonlWriter):
+        rows = [json.loads(line) for line in open(w.path)]
+        assert [r["tag"] for r in rows] == ["Validation/Avg Reward", "Validation/Std Reward", "Validation/Success Rate", "Validation/Fire Success Rate"]
+        assert rows[2] == {"tag": "Validation/Success Rate", "value": 0.64, "step": 24}
+
+
+def test_snapshot_is_replaced_atomically(tmp_path, monkeypatch):
+    """utils/checkpoint.save_run writes <file>.tmp and renames: a failed write must leave the previous snapshot untouched."""
+    from hirl4ucav_amd.utils import checkpoint as CK
+
+    path = tmp_path / "state_rank0.pt"
+    path.write_bytes(b"previous snapshot")
+    monkeypatch.setattr(CK.torch.cuda, "synchronize", lambda: None)
+
+    def boom(obj, f):
+        open(f, "wb").write(b"partial")
+        raise OSError("disk full")
+
+    monkeypatch.setattr(CK.torch, "save", boom)
+    monkeypatch.setattr(CK, "engine_state", lambda e: {})
+    monkeypatch.setattr(CK, "env_state", lambda e: {})
+    monkeypatch.setattr(CK, "replay_state", lambda r: {})
+    monkeypatch.setattr(CK.torch.cuda, "get_rng_state", lambda d=None: None)
+
+    class Env:
+        device = "cpu"
+
+    with pytest.raises(OSError):
+        CK.save_run(str(path), None, Env(), None, {})
+    assert path.read_bytes() == b"previous snapshot"

@@ -178,7 +178,7 @@ def test_batch_step_episode_rules():
     ring = np.zeros((cap, 32), np.float32)
     rsucc = np.zeros(cap, np.int8)
     total = np.zeros(1, np.uint64)
-    stats = np.zeros(8, np.uint64)
+    stats = np.zeros(9, np.uint64)
     epi = np.zeros(n, np.uint32)
     rng = np.random.default_rng(0)
     stored = 0

@@ -3,6 +3,7 @@
 #   collect expert data (scripted pilot) -> behaviour cloning -> HIRL-soft with that bc_actor / TD3 without -> validation.
 # Usage: tools/demo_pipeline.sh <scenario> <out_dir> [bc_episodes] [rl_episodes] [num_envs]
 set -e
+set -o pipefail
 ENV=${1:-straight_line}; OUT=${2:-gpurun_out/demo}; BC_EP=${3:-200}; RL_EP=${4:-100}; N=${5:-4096}
 mkdir -p "$OUT"
 python -m hirl4ucav_amd.data.ai_data_col --env "$ENV" --random --episodes 20 --out "$OUT/expert.csv" 2>&1 | tee "$OUT/collect.log"
