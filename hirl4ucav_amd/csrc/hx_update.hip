@@ -20,6 +20,8 @@
 //   wgrad    dW2 = dz2^T h1 on MFMA (64x64 tiles) + the vector/LN/layer-1 gradients, written into a flat gradient
 //            buffer with the parameter layout (one all-reduce message per phase when sharded);
 //   adam / polyak  elementwise over the flat buffers, 16 B per lane.
+#include <cstdlib>
+
 #include "hx_common.h"
 #include "hx_nn.h"
 #include "hx_env_dev.h"
@@ -79,6 +81,28 @@ struct Slot {
     float* dout;  // [R][8]    gradient wrt the head pre-activation o
     float* lnp;   // [R][kColWgB][2] LN1-backward row sums (sum dxhat, sum dxhat*xhat) over each workgroup's columns of dh1
 };
+
+// a slot is ONE allocation carved in a fixed order: kernels receive its base pointer only and rebuild the field pointers with a
+// dozen scalar adds — 2 dwords of kernel argument per slot instead of 22
+__host__ __device__ inline Slot carve_slot(float* base, int rows) {
+    Slot s;
+    float* p = base;
+    s.x = p; p += (size_t)rows * XP;
+    s.z1 = p; p += (size_t)rows * H1;
+    s.st1 = p; p += (size_t)rows * 2;
+    s.h1 = p; p += (size_t)rows * H1;
+    s.z2 = p; p += (size_t)rows * H2;
+    s.st2 = p; p += (size_t)rows * 2;
+    s.outv = p; p += (size_t)rows * OW;
+    s.dz2 = p; p += (size_t)rows * H2;
+    s.dh1 = p; p += (size_t)rows * H1;
+    s.dout = p; p += (size_t)rows * OW;
+    s.lnp = p; p += (size_t)rows * (2 * kColWgB);
+    return s;
+}
+// Mlp <-> 10 bits
+__host__ __device__ inline uint32_t mlp_bits(const Mlp& m) { return (uint32_t)m.in | ((uint32_t)m.out << 5) | ((uint32_t)(m.no_ln ? 1 : 0) << 9); }
+__host__ __device__ inline Mlp mlp_of(uint32_t b) { return Mlp{(int)(b & 31u), (int)((b >> 5) & 15u), (int)((b >> 9) & 1u)}; }
 
 struct Head {  // a previous net whose output is (part of) this net's input
     const float* net;
@@ -167,6 +191,45 @@ struct FwdArgs {
     int* zero_i;
 };
 
+// What the kernel actually receives: 64 bytes per job (ONE s_load_dwordx16), the job picked by blockIdx.y.  A kernel argument
+// block of 1.7 KB read field by field behind branches cost a chain of 6-8 dependent scalar-load round trips before the first
+// vector load went out (~1.5-2 us of a ~10 us launch); the compact form is one round trip, and everything else is scalar ALU.
+struct FwdJobC {
+    const float* net; const float* src; const float* noise; const float* prev_net;
+    float* ws; float* prev_ws;
+    uint32_t cfg;  // m:10 | prev.m:10 | act_mode:2 | save:1 | col0:6
+    int32_t rows;
+    float noise_clamp;
+    float slope;   // (per launch; carried in every job so that the job's own 64 bytes are all a workgroup waits for)
+};
+static_assert(sizeof(FwdJobC) == 64, "one s_load_dwordx16");
+struct FwdArgsC {
+    FwdJobC job[6];
+    float slope;
+    int zero_nf;
+    float* zero_f;
+    int* zero_i;
+};
+inline FwdJobC pack_fwd(const FwdJob& J) {
+    FwdJobC c{};
+    c.net = J.net; c.src = J.src.main; c.noise = J.noise; c.prev_net = J.prev.net;
+    c.ws = J.ws.x; c.prev_ws = J.prev.ws.x;
+    c.cfg = mlp_bits(J.m) | (mlp_bits(J.prev.m) << 10) | ((uint32_t)J.act_mode << 20) | ((uint32_t)(J.save ? 1 : 0) << 22) | ((uint32_t)J.col0 << 23);
+    c.rows = J.rows; c.noise_clamp = J.noise_clamp;
+    return c;
+}
+__device__ __forceinline__ FwdJob expand_fwd(const FwdJobC& c) {
+    FwdJob J;
+    J.net = c.net; J.m = mlp_of(c.cfg & 1023u);
+    J.src = RowSrc{c.src, nullptr, nullptr, 0, 32};
+    J.col0 = (int)(c.cfg >> 23); J.act_mode = (int)((c.cfg >> 20) & 3u);
+    J.prev.net = c.prev_net; J.prev.m = mlp_of((c.cfg >> 10) & 1023u); J.prev.ws = carve_slot(c.prev_ws, c.rows);
+    J.noise = c.noise; J.noise_clamp = c.noise_clamp;
+    J.ws = carve_slot(c.ws, c.rows);
+    J.rows = c.rows; J.save = (int)((c.cfg >> 22) & 1u);
+    return J;
+}
+
 __device__ __forceinline__ int tiles_of(int rows) { return (rows + RT - 1) / RT; }
 
 // NT = 64 / 32: columns per workgroup in latency mode (B = 128): CT = NT/16 column tiles x KS = 16/CT K-parts over the 16 waves,
@@ -175,7 +238,7 @@ __device__ __forceinline__ int tiles_of(int rows) { return (rows + RT - 1) / RT;
 // NT = 256     : one 16-column tile per wave, full K (throughput mode, thousands of rows: the prologue is recomputed 2x per
 //                row tile instead of 8x or 16x)
 template <int NT>
-__global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
+__global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A) {
     constexpr bool WIDE = NT == 256;
     constexpr int NTW = NT;
     constexpr int CT = WIDE ? 1 : NT / 16, KS = WIDE ? 1 : 16 / CT;  // column tiles / K-parts per workgroup (latency mode)
@@ -187,24 +250,15 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
     float* kred = sts + RT * 2;   // [KS - 1 K-parts][CT column tiles][64 lanes][4]
     float* w1s = kred + KRED;     // W1 [256][in], staged with coalesced loads (a per-thread row walk is 17 scattered requests)
 
-    // which job / row tile / column tile
-    int b = blockIdx.x, j = 0;
-    for (; j < A.njobs; ++j) {
-        const int nb = tiles_of(A.job[j].rows) * (H2 / NTW);
-        if (b < nb) break;
-        b -= nb;
-    }
-    if (j >= A.njobs) return;
-    if (blockIdx.x == 0) {
-        if ((int)threadIdx.x < A.zero_nf) A.zero_f[threadIdx.x] = 0.0f;
-        if (threadIdx.x == 0 && A.zero_i) *A.zero_i = 0;
-    }
-    const FwdJob& J = A.job[j];
+    // job = blockIdx.y; row tile / column tile from blockIdx.x
+    const int b = blockIdx.x;
+    const FwdJobC& jc = A.job[blockIdx.y];
+    const FwdJob J = expand_fwd(jc);
     const int rt = b / (H2 / NTW), nt = b % (H2 / NTW);
     const int r0 = rt * RT;
     const int nrow = min(RT, J.rows - r0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const float slope = A.slope;
+    const float slope = jc.slope;
     const int in = J.m.in;
     // operands that do not depend on the prologue are requested first: their latency hides behind the gather
     BtFrag<H1 / KS> bfrag;
@@ -349,6 +403,11 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgs A) {
         }
         STAMP();
         STAMP_FLUSH(0, blockIdx.x == 5 && tid == 0);
+    }
+    // accumulators of LATER launches are cleared here, at the end: their kernel-argument words are off every workgroup's critical path
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if ((int)threadIdx.x < A.zero_nf) A.zero_f[threadIdx.x] = 0.0f;
+        if (threadIdx.x == 0 && A.zero_i) *A.zero_i = 0;
     }
 }
 
@@ -521,16 +580,8 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 #define ACT_LOAD(ra, rb, c) { ra = *reinterpret_cast<const float4*>(w2g + (c) * ACT_KC); rb = *reinterpret_cast<const float4*>(w2g + (size_t)256 * H1 + (c) * ACT_KC); }
 #define ACT_STORE(buf, ra, rb) { *reinterpret_cast<float4*>((buf) + w2w) = ra; *reinterpret_cast<float4*>((buf) + w2w + 256 * ACT_LDW) = rb; }
     float4 e0, e1, o0, o1;  // even / odd register sets
-    uint4 bq[BF16 ? 2 : 1][BF16 ? 8 : 1];  // BF16: B fragments of this wave's two column tiles, all of K
-    if constexpr (BF16) {
-        const int r = lane & 15, g = lane >> 4;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const uint16_t* row = A.w2b + (size_t)(t * 256 + wave * 16 + r) * H1 + 8 * g;
-#pragma unroll
-            for (int sl = 0; sl < 8; ++sl) bq[t][sl] = *reinterpret_cast<const uint4*>(row + 32 * sl);
-        }
-    } else {
+    uint4 bq[BF16 ? 2 : 1][BF16 ? 8 : 1];  // BF16: B fragments of this wave's two column tiles, all of K (requested below)
+    if constexpr (!BF16) {
         ACT_LOAD(e0, e1, 0);
         ACT_LOAD(o0, o1, 1);
     }
@@ -552,6 +603,21 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     if (tid < H1 * 13 / 4) reinterpret_cast<float4*>(w1s)[tid] = wv;
     if (tid < ROWS * XP) xs[tid] = 0.0f;
     __syncthreads();
+    // BF16: which 32 columns this wave owns rotates with the workgroup, so that the 256 workgroups of a launch do not all ask L2 for
+    // the same lines of the W2 image at the same moment
+    const int cw = BF16 ? ((wave + (int)blockIdx.x) & 15) : wave;
+    if constexpr (BF16) {
+        // requested only now, behind the prologue's own operands: every workgroup pulls the whole 256 KB image through L2 (64 MB per
+        // launch at 4,096 rows, ~6 us of L2 service); issued at kernel entry those requests queue up in front of OTHER workgroups'
+        // small operands and stall every prologue for that long.  From here they overlap layer 1 and LayerNorm 1.
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint16_t* row = A.w2b + (size_t)(t * 256 + cw * 16 + r) * H1 + 8 * g;
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) bq[t][sl] = *reinterpret_cast<const uint4*>(row + 32 * sl);
+        }
+    }
     if (tid < ROWS * 13) xs[(tid / 13) * XP + tid % 13] = xv;
     __syncthreads();
     float z1[NRT][4];
@@ -647,13 +713,13 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 #undef ACT_MUL
 #undef ACT_LOAD
 #undef ACT_STORE
-        const float bb0 = net[m.b2() + wave * 16 + r], bb1 = net[m.b2() + 256 + wave * 16 + r];
+        const float bb0 = net[m.b2() + cw * 16 + r], bb1 = net[m.b2() + 256 + cw * 16 + r];
 #pragma unroll
         for (int t = 0; t < NRT; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {  // every wave is past the last barrier: the chunk buffers are free for z2
-                z2s[(t * RT + 4 * g + q) * LDA2 + wave * 16 + r] = acc[t][0][q] + bb0;
-                z2s[(t * RT + 4 * g + q) * LDA2 + 256 + wave * 16 + r] = acc[t][1][q] + bb1;
+                z2s[(t * RT + 4 * g + q) * LDA2 + cw * 16 + r] = acc[t][0][q] + bb0;
+                z2s[(t * RT + 4 * g + q) * LDA2 + 256 + cw * 16 + r] = acc[t][1][q] + bb1;
             }
         himg.store(hps, net, m, tid);  // ... and h1 / x / W1 are dead: their LDS takes the head image
     }
@@ -842,7 +908,10 @@ constexpr int64_t kFuseEnvMax = 8192;
 template <bool GAUSS, bool BF16>
 static void launch_act_t(const ActFusedArgs& H, hipStream_t st) {
     const bool env = H.state != nullptr;
-    if (H.rows >= 8192) {
+    // 32 rows per workgroup: from 8,192 rows on (fp32: below that, 16-row workgroups fill the chip and the fp32 MFMA work per workgroup
+    // is the longer pole); bf16 from 2,048 rows on: there the launch is bound by every workgroup pulling W2 through L2, not by MFMA
+    static const int nrt2_bf16 = getenv("HX_ACT_BF16_NRT2_ROWS") ? atoi(getenv("HX_ACT_BF16_NRT2_ROWS")) : 8192;  // tuning knob
+    if (H.rows >= (BF16 ? nrt2_bf16 : 8192)) {
         const dim3 grid((unsigned)((H.rows + 2 * RT - 1) / (2 * RT)));
         if (env) hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, true, BF16>), grid, dim3(kWide), 0, st, H);
         else hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, false, BF16>), grid, dim3(kWide), 0, st, H);
@@ -906,6 +975,49 @@ struct BwdArgs {
     int* soft_count;
 };
 
+// compact kernel argument (see FwdJobC): 128 bytes per job, two s_load_dwordx16, job = blockIdx.y.  The heads a mode does not
+// use are simply not expanded (t1 / t2 for the TD jobs, `soft` for the critic's policy job, `crit` for the actor's policy job).
+struct BwdJobC {
+    const float* net; float* ws;
+    const float* h1_net; float* h1_ws;   // TD: t1; CRITIC_PI: soft; ACTOR_PI: crit
+    const float* h2_net; float* h2_ws;   // TD: t2
+    const float* src; const float* bonus; const float* bonus_scale;
+    uint32_t cfg;   // m:10 | h1.m:10 | h2.m:10
+    uint32_t cfg2;  // mode:3 | loss_slot:3
+    int32_t rows;
+    float gamma, lambda, slope, inv_batch;
+    float* losses; int* soft_count;
+    uint32_t pad_;
+};
+static_assert(sizeof(BwdJobC) == 128, "two s_load_dwordx16");
+struct BwdArgsC {
+    BwdJobC job[2];
+};
+inline BwdJobC pack_bwd(const BwdJob& J, const BwdArgs& A) {
+    BwdJobC c{};
+    c.net = J.net; c.ws = J.ws.x;
+    const Head& h1 = J.mode == BM_CRITIC_TD ? J.t1 : (J.mode == BM_CRITIC_PI ? J.soft : J.crit);
+    c.h1_net = h1.net; c.h1_ws = h1.ws.x;
+    c.h2_net = J.t2.net; c.h2_ws = J.t2.ws.x;
+    c.src = J.src.main; c.bonus = J.bonus; c.bonus_scale = J.bonus_scale;
+    c.cfg = mlp_bits(J.m) | (mlp_bits(h1.m) << 10) | (mlp_bits(J.t2.m) << 20);
+    c.cfg2 = (uint32_t)J.mode | ((uint32_t)J.loss_slot << 3);
+    c.rows = J.rows; c.gamma = J.gamma; c.lambda = J.lambda; c.slope = A.slope; c.inv_batch = A.inv_batch;
+    c.losses = A.losses; c.soft_count = A.soft_count;
+    return c;
+}
+__device__ __forceinline__ BwdJob expand_bwd(const BwdJobC& c) {
+    BwdJob J;
+    J.net = c.net; J.m = mlp_of(c.cfg & 1023u); J.ws = carve_slot(c.ws, c.rows); J.rows = c.rows;
+    J.mode = (int)(c.cfg2 & 7u); J.loss_slot = (int)((c.cfg2 >> 3) & 7u);
+    const Head h1{c.h1_net, mlp_of((c.cfg >> 10) & 1023u), carve_slot(c.h1_ws, c.rows)};
+    J.t1 = h1; J.soft = h1; J.crit = h1;
+    J.t2 = Head{c.h2_net, mlp_of((c.cfg >> 20) & 1023u), carve_slot(c.h2_ws, c.rows)};
+    J.src = RowSrc{c.src, nullptr, nullptr, 0, 32};
+    J.gamma = c.gamma; J.lambda = c.lambda; J.bonus = c.bonus; J.bonus_scale = c.bonus_scale;
+    return J;
+}
+
 // one LN1-backward row sum from the per-workgroup partials bwd_l2 left in lnp ([kColWgB][2], stride 2): fixed-order tree
 __device__ __forceinline__ float lnp_sum(const float* lp) {
     float v[kColWgB];
@@ -925,7 +1037,7 @@ __device__ __forceinline__ float lnp_sum(const float* lp) {
 // of the MFMA phase, the z2 rows, labels, the other nets' rows, all head parameters, the epilogue's z1 — is issued at
 // entry; there is ONE wait; head parameters are shared through LDS; the rest runs out of registers and LDS.
 template <int GRP>
-__global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
+__global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     __shared__ __attribute__((aligned(16))) float dz2s[RT * LDA2];
     __shared__ __attribute__((aligned(16))) float kred[(kKSB - 1) * kCTB * 256];  // split-K partial tiles
     constexpr int IMG = GRP == 3 ? 8 : 4;  // head width of this instantiation's LDS images
@@ -936,14 +1048,10 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgs A) {
     __shared__ float red[16][4];
     __shared__ float st1s[RT * 2];  // LN1 stats of the tile's rows (epilogue)
 
-    int b = blockIdx.x, j = 0;
-    for (; j < A.njobs; ++j) {
-        const int nb = tiles_of(A.job[j].rows) * kColWgB;
-        if (b < nb) break;
-        b -= nb;
-    }
-    if (j >= A.njobs) return;
-    const BwdJob& J = A.job[j];
+    const int b = blockIdx.x;
+    const BwdJobC& jc = AC.job[blockIdx.y];
+    const BwdJob J = expand_bwd(jc);
+    struct { float slope, inv_batch; float* losses; int* soft_count; } A{jc.slope, jc.inv_batch, jc.losses, jc.soft_count};
     const int rt = b / kColWgB, nt = b % kColWgB;
     const int r0 = rt * RT;
     const int nrow = min(RT, J.rows - r0);
@@ -1368,11 +1476,22 @@ struct WgJob {
     int rows[2];
     int nslots;
     int wmode[2];  // per slot: 0 = scale 1, 1 = scale (1 - w), 2 = scale w
+    // ADAM instantiation: the optimizer step of this block in the same launch (single GPU: no exchange between gradient and step)
+    float* p; float* mom; float* var;  // parameters (== net) and Adam moments, same layout
+    float* target;                 // nullptr, or the target network's block: soft_update with the new parameters (HIRL.py:11-13)
+    uint16_t* w2b;                 // nullptr, or the bf16 image of W2 to refresh
+};
+struct WgAdam {
+    float b1, b2, eps, step_size, bc2_sqrt, tau;
+    int finish_actor, use_bc;  // thread 0 of the launch finishes actor_loss / bc_weight (HIRL.py:321,334)
+    float* losses;
+    float* wstate;
 };
 struct WgArgs {
     WgJob job[2];
     int njobs;
     float slope;
+    WgAdam ad;
     // effective BC weight  w: 0 = given, 1 = estimate from soft_count (HIRL.py:304-306), 2 = reuse *wstate
     int w_kind;
     float w_given, warm, inv_batch;
@@ -1380,19 +1499,60 @@ struct WgArgs {
     const float* wstate;
 };
 
-// torch.optim.Adam (defaults) on one element; explicit single-rounding intrinsics so that every caller rounds alike
+// torch.optim.Adam (defaults) on one element, and soft_update.  Contraction is OFF in these two: HIP's __fmul_rn / __fsub_rn are plain
+// operators, which the compiler may or may not fuse depending on the surrounding kernel — and the fused wgrad + Adam launch must
+// round exactly like adam_kernel (the one-call and the staged update paths are compared bit for bit).
+#pragma clang fp contract(off)
 __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float b1, float b2, float eps, float step_size, float bc2_sqrt) {
-    m = __fmaf_rn(g, 1.0f - b1, __fmul_rn(m, b1));
-    v = __fmaf_rn(__fmul_rn(g, g), 1.0f - b2, __fmul_rn(v, b2));
-    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
-    p = __fsub_rn(p, __fmul_rn(step_size, __fdiv_rn(m, denom)));
+    m = __builtin_fmaf(g, 1.0f - b1, m * b1);
+    v = __builtin_fmaf(g * g, 1.0f - b2, v * b2);
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
 }
+__device__ __forceinline__ float polyak_update(float target, float p, float tau) { return target * (1.0f - tau) + p * tau; }  // HIRL.py:13
+#pragma clang fp contract(fast)
 __device__ __forceinline__ float effective_w(int kind, float given, float warm, float inv_batch, const int* count, const float* wstate) {
     float w = given;
     if (kind == 1) w = (float)(*count) * inv_batch + warm;
     if (kind == 2) w = *wstate;
     return w > 1.0f ? 1.0f : w;  // HIRL.py:308
 }
+
+// compact kernel argument (see FwdJobC): 128 bytes per job; everything a workgroup needs before its first vector load is in its own job
+struct WgJobC {
+    const float* net; float* grad;
+    float* ws0; float* ws1;
+    float* mom; float* var; float* target; uint16_t* w2b;
+    uint32_t cfg;  // m:10 | nslots:2 | wmode0:2 | wmode1:2 | w_kind:2 | adam.finish_actor:1 | adam.use_bc:1
+    int32_t rows0, rows1;
+    float slope, w_given, warm, inv_batch;
+    float b1, b2, eps, step_size, bc2_sqrt, tau;
+    uint32_t pad_;
+    const int* soft_count; float* wstate; float* losses;
+};
+static_assert(sizeof(WgJobC) == 144, "WgJobC layout");
+struct WgArgsC {
+    WgJobC job[2];
+};
+
+// One parameter of the fused step: Adam with the gradient just produced, then (optionally) Polyak of the target and the bf16 image.
+// p/m/v/t are this element's values requested at kernel entry (their latency hides under the gradient's own operand loads).
+struct AdamElem {
+    float p, m, v, t;
+    __device__ __forceinline__ void fetch(const WgJob& J, int idx) {
+        p = J.p[idx];
+        m = J.mom[idx];
+        v = J.var[idx];
+        t = J.target ? J.target[idx] : 0.0f;
+    }
+    __device__ __forceinline__ void apply(const WgJob& J, const WgAdam& a, int idx, float g) {
+        adam_update(p, m, v, g, a.b1, a.b2, a.eps, a.step_size, a.bc2_sqrt);
+        J.p[idx] = p;
+        J.mom[idx] = m;
+        J.var[idx] = v;
+        if (J.target) J.target[idx] = polyak_update(t, p, a.tau);
+    }
+};
 
 constexpr int kWgTilesPerBlock = H2 / 16;                // 32 workgroups: 16 (n) x 256 (k) of dW2, one 16 x 16 tile per wave
 constexpr int kWgVecWgs = H2 / 64;                       // 8 workgroups: 64 columns x 16 row groups, 512-wide vector gradients
@@ -1413,22 +1573,63 @@ __device__ __forceinline__ float sum_groups(const float* p) {
     return v[0];
 }
 
-__global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
+// ADAM: each thread applies the optimizer step to the gradient elements it has just produced (every parameter's gradient is
+// produced by exactly one thread), so a single-GPU learn() has no separate Adam / Polyak launch.  Same adam_update on the same
+// gradient values as adam_kernel: the one-call and the staged (sharded) paths stay bit-identical.
+__device__ __forceinline__ void expand_wg(const WgJobC& c, WgJob& J, WgArgs& A) {
+    J.net = c.net; J.grad = c.grad; J.m = mlp_of(c.cfg & 1023u);
+    J.nslots = (int)((c.cfg >> 10) & 3u);
+    J.wmode[0] = (int)((c.cfg >> 12) & 3u); J.wmode[1] = (int)((c.cfg >> 14) & 3u);
+    J.ws[0] = carve_slot(c.ws0, c.rows0); J.ws[1] = carve_slot(c.ws1, c.rows1);
+    J.rows[0] = c.rows0; J.rows[1] = c.rows1;
+    J.p = const_cast<float*>(c.net); J.mom = c.mom; J.var = c.var; J.target = c.target; J.w2b = c.w2b;
+    A.slope = c.slope; A.w_kind = (int)((c.cfg >> 16) & 3u); A.w_given = c.w_given; A.warm = c.warm; A.inv_batch = c.inv_batch;
+    A.soft_count = c.soft_count; A.wstate = c.wstate;
+    A.ad.b1 = c.b1; A.ad.b2 = c.b2; A.ad.eps = c.eps; A.ad.step_size = c.step_size; A.ad.bc2_sqrt = c.bc2_sqrt; A.ad.tau = c.tau;
+    A.ad.finish_actor = (int)((c.cfg >> 18) & 1u); A.ad.use_bc = (int)((c.cfg >> 19) & 1u);
+    A.ad.losses = c.losses; A.ad.wstate = c.wstate;
+}
+inline WgJobC pack_wg(const WgJob& J, const WgArgs& A) {
+    WgJobC c{};
+    c.net = J.net; c.grad = J.grad; c.ws0 = J.ws[0].x; c.ws1 = J.nslots > 1 ? J.ws[1].x : J.ws[0].x;
+    c.mom = J.mom; c.var = J.var; c.target = J.target; c.w2b = J.w2b;
+    c.cfg = mlp_bits(J.m) | ((uint32_t)J.nslots << 10) | ((uint32_t)J.wmode[0] << 12) | ((uint32_t)J.wmode[1] << 14) | ((uint32_t)A.w_kind << 16) |
+            ((uint32_t)(A.ad.finish_actor ? 1 : 0) << 18) | ((uint32_t)(A.ad.use_bc ? 1 : 0) << 19);
+    c.rows0 = J.rows[0]; c.rows1 = J.nslots > 1 ? J.rows[1] : J.rows[0];
+    c.slope = A.slope; c.w_given = A.w_given; c.warm = A.warm; c.inv_batch = A.inv_batch;
+    c.b1 = A.ad.b1; c.b2 = A.ad.b2; c.eps = A.ad.eps; c.step_size = A.ad.step_size; c.bc2_sqrt = A.ad.bc2_sqrt; c.tau = A.ad.tau;
+    c.soft_count = A.soft_count; c.wstate = const_cast<float*>(A.wstate); c.losses = A.ad.losses;
+    return c;
+}
+
+template <bool ADAM>
+__global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
     __shared__ __attribute__((aligned(16))) float lds[kWgRowChunk * XP + kWgRowChunk * 12 + kWgRG * 64 * 20];
     float* xs = lds;                          // [chunk][XP]   inputs (layer-1 job)
     float* rinfo = lds + kWgRowChunk * XP;    // [chunk][<=12] per-row scalars
     float* red = rinfo + kWgRowChunk * 12;    // [16][64][20]  cross-row-group reduction
 
-    const int j = blockIdx.x / kWgPerJob, b = blockIdx.x % kWgPerJob;
-    if (j >= A.njobs) return;
-    const WgJob& J = A.job[j];
+    const int j = blockIdx.y, b = blockIdx.x;
+    WgJob J;
+    WgArgs A;
+    expand_wg(AC.job[j], J, A);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float slope = A.slope;
     STAMP_DECL;
     STAMP();
     const float w = effective_w(A.w_kind, A.w_given, A.warm, A.inv_batch, A.soft_count, A.wstate);
     float scale[2];
+#pragma unroll
     for (int s = 0; s < 2; ++s) scale[s] = J.wmode[s] == 0 ? 1.0f : (J.wmode[s] == 1 ? 1.0f - w : w);
+    if (ADAM && A.ad.finish_actor && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {  // what adam_kernel's thread 0 does on an actor step
+        if (A.ad.use_bc) {
+            A.ad.losses[1] = A.ad.losses[2] * w + A.ad.losses[3] * (1.0f - w);  // HIRL.py:321
+            A.ad.losses[5] = w;
+            *A.ad.wstate = w;
+        } else {
+            A.ad.losses[1] = A.ad.losses[3];  // TD3.py:236
+        }
+    }
 
     if (b < kWgTilesPerBlock) {
         // dW2[n][k] = sum_r scale dz2[r][n] h1[r][k].  Wave tile 16 (n) x 16 (k); the reduction runs over the batch rows,
@@ -1437,7 +1638,8 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
         const int n0 = b * 16, k0 = wave * 16;
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < J.nslots; ++s) {
+        #pragma unroll
+        for (int s = 0; s < 2; ++s) if (s < J.nslots) {  // compile-time slot index: J lives in registers, not in scratch
             const float sc = scale[s];
             const float* dz = J.ws[s].dz2 + n0 + r;
             const float* h1 = J.ws[s].h1 + k0 + r;
@@ -1456,11 +1658,29 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
             }
         }
         STAMP();
+        // ADAM: this lane's four parameters are requested only now — the 64 operand registers of the reduction above are dead, so the
+        // launch keeps its 4 waves per SIMD without spilling; the round trip (L2-resident: touched once per learn()) is ~1 us
+        AdamElem ae[4];
+        if (ADAM) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ae[q].fetch(J, J.m.W2() + (n0 + 4 * g + q) * H1 + k0 + r);
+        }
         float* out = J.grad + J.m.W2();
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[(size_t)(n0 + 4 * g + q) * H1 + k0 + r] = acc[q];
+        if (ADAM) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = J.m.W2() + (n0 + 4 * g + q) * H1 + k0 + r;
+                ae[q].apply(J, A.ad, idx, acc[q]);
+                if (J.w2b) {
+                    const __bf16 bv = (__bf16)ae[q].p;
+                    J.w2b[idx - J.m.W2()] = __builtin_bit_cast(uint16_t, bv);
+                }
+            }
+        }
         STAMP();
-        STAMP_FLUSH(32, blockIdx.x == 0 && tid == 0);
+        STAMP_FLUSH(32, blockIdx.x == 0 && blockIdx.y == 0 && tid == 0);
         return;
     }
     const int rg = wave;  // row group: rows rg, rg + 4, ...
@@ -1474,7 +1694,15 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
 #pragma unroll
         for (int jj = 0; jj < OW; ++jj) w3[jj] = jj < J.m.out ? J.net[J.m.W3() + jj * H2 + n] : 0.0f;
         float db2 = 0.f, dg = 0.f, dbe = 0.f, dw3[OW] = {}, db3 = 0.f;
-        for (int s = 0; s < J.nslots; ++s) {
+        // ADAM: the parameter this wave will step (item = wave) and, for the last wave of the first column block, b3[lane]: requested
+        // now, consumed after the reduction
+        const int vitem = wave;
+        const int vidx = vitem == 0 ? J.m.b2() + n : vitem == 1 ? J.m.g2() + n : vitem == 2 ? J.m.be2() + n : J.m.W3() + (vitem - 3) * H2 + n;
+        AdamElem vae, vae3;
+        if (ADAM && vitem < 3 + J.m.out) vae.fetch(J, vidx);
+        if (ADAM && vb == 0 && wave == kWgRG - 1 && lane < J.m.out) vae3.fetch(J, J.m.b3() + lane);
+        #pragma unroll
+        for (int s = 0; s < 2; ++s) if (s < J.nslots) {  // compile-time slot index: J lives in registers, not in scratch
             const Slot& S = J.ws[s];
             const float sc = scale[s];
             for (int c0 = 0; c0 < J.rows[s]; c0 += kWgRowChunk) {
@@ -1538,14 +1766,18 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
         for (int jj = 0; jj < OW; ++jj) my[3 + jj] = dw3[jj];
         my[3 + OW] = db3;
         __syncthreads();
-        for (int item = wave; item < 3 + J.m.out; item += kWgRG) {  // wave -> item, lane -> column: 16 partial sums each
-            const float v = sum_groups(red + lane * 20 + item);
-            if (item == 0) J.grad[J.m.b2() + n] = v;
-            else if (item == 1) J.grad[J.m.g2() + n] = J.m.no_ln ? 0.0f : v;
-            else if (item == 2) J.grad[J.m.be2() + n] = J.m.no_ln ? 0.0f : v;
-            else J.grad[J.m.W3() + (item - 3) * H2 + n] = v;
+        if (vitem < 3 + J.m.out) {  // wave -> item (3 + out <= 11 items, 16 waves), lane -> column: 16 partial sums each
+            float v = sum_groups(red + lane * 20 + vitem);
+            if ((vitem == 1 || vitem == 2) && J.m.no_ln) v = 0.0f;
+            J.grad[vidx] = v;
+            if (ADAM) vae.apply(J, A.ad, vidx, v);
         }
-        if (vb == 0 && wave == kWgRG - 1 && lane < J.m.out) J.grad[J.m.b3() + lane] = sum_groups(red + lane * 20 + 3 + OW);
+        if (vb == 0 && wave == kWgRG - 1 && lane < J.m.out) {
+            const int idx = J.m.b3() + lane;
+            const float v = sum_groups(red + lane * 20 + 3 + OW);
+            J.grad[idx] = v;
+            if (ADAM) vae3.apply(J, A.ad, idx, v);
+        }
         STAMP();
         STAMP_FLUSH(40, b == kWgTilesPerBlock && j == 0 && tid == 0);
         return;
@@ -1559,7 +1791,15 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
         float db1 = 0.f, dg = 0.f, dbe = 0.f, dw1[17];
 #pragma unroll
         for (int i = 0; i < 17; ++i) dw1[i] = 0.f;
-        for (int s = 0; s < J.nslots; ++s) {
+        // ADAM: up to two items per wave (3 + in <= 20 items, 16 waves): their parameters are requested now
+        auto l1idx = [&](int item) { return item == 0 ? J.m.b1() + k : item == 1 ? J.m.g1() + k : item == 2 ? J.m.be1() + k : J.m.W1() + k * in + (item - 3); };
+        AdamElem lae[2];
+        if (ADAM) {
+            lae[0].fetch(J, l1idx(wave));
+            if (wave + kWgRG < 3 + in) lae[1].fetch(J, l1idx(wave + kWgRG));
+        }
+        #pragma unroll
+        for (int s = 0; s < 2; ++s) if (s < J.nslots) {  // compile-time slot index: J lives in registers, not in scratch
             const Slot& S = J.ws[s];
             const float sc = scale[s];
             for (int c0 = 0; c0 < J.rows[s]; c0 += kWgRowChunk) {
@@ -1617,12 +1857,16 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgs A) {
 #pragma unroll
         for (int i = 0; i < 17; ++i) my[3 + i] = dw1[i];
         __syncthreads();
-        for (int item = wave; item < 3 + in; item += kWgRG) {
-            const float v = sum_groups(red + lane * 20 + item);
-            if (item == 0) J.grad[J.m.b1() + k] = v;
-            else if (item == 1) J.grad[J.m.g1() + k] = J.m.no_ln ? 0.0f : v;
-            else if (item == 2) J.grad[J.m.be1() + k] = J.m.no_ln ? 0.0f : v;
-            else J.grad[J.m.W1() + k * in + (item - 3)] = v;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int item = wave + t * kWgRG;
+            if (item < 3 + in) {
+                const int idx = l1idx(item);
+                float v = sum_groups(red + lane * 20 + item);
+                if ((item == 1 || item == 2) && J.m.no_ln) v = 0.0f;
+                J.grad[idx] = v;
+                if (ADAM) lae[t].apply(J, A.ad, idx, v);
+            }
         }
         STAMP();
         STAMP_FLUSH(48, b == kWgTilesPerBlock + kWgVecWgs && j == 0 && tid == 0);
@@ -1692,10 +1936,10 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
         }
         if (A.target) {
             float4 t4 = *reinterpret_cast<const float4*>(A.target + i);
-            t4.x = t4.x * (1.0f - A.tau) + p4.x * A.tau;  // HIRL.py:13
-            t4.y = t4.y * (1.0f - A.tau) + p4.y * A.tau;
-            t4.z = t4.z * (1.0f - A.tau) + p4.z * A.tau;
-            t4.w = t4.w * (1.0f - A.tau) + p4.w * A.tau;
+            t4.x = polyak_update(t4.x, p4.x, A.tau);
+            t4.y = polyak_update(t4.y, p4.y, A.tau);
+            t4.z = polyak_update(t4.z, p4.z, A.tau);
+            t4.w = polyak_update(t4.w, p4.w, A.tau);
             *reinterpret_cast<float4*>(A.target + i) = t4;
         }
         return;
@@ -1704,7 +1948,7 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
         float pv = A.p[i + c], mv = A.m[i + c], vv = A.v[i + c];
         adam_update(pv, mv, vv, A.g[i + c] * A.gscale, A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
         A.p[i + c] = pv; A.m[i + c] = mv; A.v[i + c] = vv;
-        if (A.target) A.target[i + c] = A.target[i + c] * (1.0f - A.tau) + pv * A.tau;
+        if (A.target) A.target[i + c] = polyak_update(A.target[i + c], pv, A.tau);
     }
 }
 
@@ -1721,14 +1965,14 @@ __global__ __launch_bounds__(kThreads) void polyak_kernel(float* target, const f
     if (i + 4 <= n) {
         float4 t4 = *reinterpret_cast<const float4*>(target + i);
         const float4 s4 = *reinterpret_cast<const float4*>(source + i);
-        t4.x = t4.x * (1.0f - tau) + s4.x * tau;  // HIRL.py:13
-        t4.y = t4.y * (1.0f - tau) + s4.y * tau;
-        t4.z = t4.z * (1.0f - tau) + s4.z * tau;
-        t4.w = t4.w * (1.0f - tau) + s4.w * tau;
+        t4.x = polyak_update(t4.x, s4.x, tau);
+        t4.y = polyak_update(t4.y, s4.y, tau);
+        t4.z = polyak_update(t4.z, s4.z, tau);
+        t4.w = polyak_update(t4.w, s4.w, tau);
         *reinterpret_cast<float4*>(target + i) = t4;
         return;
     }
-    for (int c = 0; c < n - i; ++c) target[i + c] = target[i + c] * (1.0f - tau) + source[i + c] * tau;
+    for (int c = 0; c < n - i; ++c) target[i + c] = polyak_update(target[i + c], source[i + c], tau);
 }
 
 
@@ -1855,23 +2099,6 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr size_t kSlotFloats = XP + H1 + 2 + H1 + H2 + 2 + OW + H2 + H1 + OW + 2 * kColWgB;  // per row
 
-Slot carve_slot(float* base, int rows) {
-    Slot s;
-    float* p = base;
-    s.x = p; p += (size_t)rows * XP;
-    s.z1 = p; p += (size_t)rows * H1;
-    s.st1 = p; p += (size_t)rows * 2;
-    s.h1 = p; p += (size_t)rows * H1;
-    s.z2 = p; p += (size_t)rows * H2;
-    s.st2 = p; p += (size_t)rows * 2;
-    s.outv = p; p += (size_t)rows * OW;
-    s.dz2 = p; p += (size_t)rows * H2;
-    s.dh1 = p; p += (size_t)rows * H1;
-    s.dout = p; p += (size_t)rows * OW;
-    s.lnp = p; p += (size_t)rows * (2 * kColWgB);
-    return s;
-}
-
 enum { S_TA = 0, S_C1, S_C2, S_TC1, S_TC2, S_API, S_ABC, S_BCS, S_CPI, S_CSOFT, S_COUNT };
 
 int fwd_row_tiles(const FwdArgs& a) {
@@ -1881,18 +2108,34 @@ int fwd_row_tiles(const FwdArgs& a) {
 }
 // column tiling by size: enough row tiles to fill the chip -> wide workgroups (less prologue recomputation)
 void launch_fwd(const FwdArgs& F, hipStream_t st) {
-    const int tiles = fwd_row_tiles(F);
+    FwdArgsC C{};
+    for (int j = 0; j < F.njobs; ++j) {  // every job of a launch has the same row count (the minibatch)
+        C.job[j] = pack_fwd(F.job[j]);
+        C.job[j].slope = F.slope;
+    }
+    C.slope = F.slope; C.zero_nf = F.zero_nf; C.zero_f = F.zero_f; C.zero_i = F.zero_i;
+    const int tiles = fwd_row_tiles(F), per_job = tiles / F.njobs;
     if (tiles >= 128)
-        hipLaunchKernelGGL(fwd_l2_kernel<256>, dim3(tiles * (H2 / 256)), dim3(kWide), 0, st, F);
+        hipLaunchKernelGGL(fwd_l2_kernel<256>, dim3(per_job * (H2 / 256), F.njobs), dim3(kWide), 0, st, C);
     else if (tiles * (H2 / 32) <= 256)  // one or two nets at B = 128: 32-column workgroups still fit the chip in one round
-        hipLaunchKernelGGL(fwd_l2_kernel<32>, dim3(tiles * (H2 / 32)), dim3(kWide), 0, st, F);
+        hipLaunchKernelGGL(fwd_l2_kernel<32>, dim3(per_job * (H2 / 32), F.njobs), dim3(kWide), 0, st, C);
     else
-        hipLaunchKernelGGL(fwd_l2_kernel<kNT>, dim3(tiles * (H2 / kNT)), dim3(kWide), 0, st, F);
+        hipLaunchKernelGGL(fwd_l2_kernel<kNT>, dim3(per_job * (H2 / kNT), F.njobs), dim3(kWide), 0, st, C);
 }
-int bwd_blocks(const BwdArgs& a) {
-    int n = 0;
-    for (int j = 0; j < a.njobs; ++j) n += ((a.job[j].rows + RT - 1) / RT) * kColWgB;
-    return n;
+int bwd_blocks(const BwdArgs& a) {  // per job (every job of a launch has the same row count)
+    return ((a.job[0].rows + RT - 1) / RT) * kColWgB;
+}
+template <bool ADAM>
+void launch_wg(const WgArgs& W, hipStream_t st) {
+    WgArgsC C{};
+    for (int j = 0; j < W.njobs; ++j) C.job[j] = pack_wg(W.job[j], W);
+    hipLaunchKernelGGL(wgrad_kernel<ADAM>, dim3(kWgPerJob, W.njobs), dim3(kWide), 0, st, C);
+}
+template <int GRP>
+void launch_bwd(const BwdArgs& G, hipStream_t st) {
+    BwdArgsC C{};
+    for (int j = 0; j < G.njobs; ++j) C.job[j] = pack_bwd(G.job[j], G);
+    hipLaunchKernelGGL(bwd_l2_kernel<GRP>, dim3(bwd_blocks(G), G.njobs), dim3(kWide), 0, st, C);
 }
 
 const Mlp kActor{13, 4, 0};
@@ -2007,7 +2250,24 @@ static void make_slots(const HxNets* N, int B, Slot* s) {
  * actor_fwd: 1 = also run the delayed actor step's forward passes that do not depend on the critic update (actor(s),
  * actor(s_bc)), 2 = plus bc_actor(s) for the soft estimate — they ride in launch A instead of a launch of their own.
  */
-int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, void* stream) {
+// torch.optim.Adam's per-step scalars (defaults: betas (0.9, 0.999), eps 1e-8) for the fused wgrad + Adam launch
+static WgAdam make_adam(const HxNets* N, const HxHyper* Hy, float lr, int step, bool finish_actor) {
+    const double b1 = 0.9, b2 = 0.999;
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    WgAdam a{};
+    a.b1 = (float)b1; a.b2 = (float)b2; a.eps = 1e-8f;
+    a.step_size = (float)(lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.tau = Hy->tau;
+    a.finish_actor = finish_actor ? 1 : 0;
+    a.use_bc = Hy->use_bc;
+    a.losses = N->losses;
+    a.wstate = N->wstate;
+    return a;
+}
+
+// adam_step > 0: the critic's optimizer step (and, with polyak, the soft_update of its target) rides in the wgrad launch
+static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, void* stream, int adam_step, bool polyak) {
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_critic_grads: batch must be a positive multiple of 16");
     hipStream_t st = (hipStream_t)stream;
     const int B = Bt->batch;
@@ -2054,7 +2314,7 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
             J.net = N->critic + h * kQ.padded(); J.m = kQ; J.ws = s[S_C1 + h]; J.rows = B; J.mode = BM_CRITIC_TD;
             J.t1 = Head{tc1, kQ, s[S_TC1]}; J.t2 = Head{tc2, kQ, s[S_TC2]}; J.src = src; J.gamma = Hy->gamma;
         }
-        hipLaunchKernelGGL(bwd_l2_kernel<0>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+        launch_bwd<0>(G, st);
     }
     {   // launch D: all critic parameter gradients
         WgArgs W{};
@@ -2065,11 +2325,24 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
             J = WgJob{};
             J.net = N->critic + h * kQ.padded(); J.grad = N->grad_critic + h * kQ.padded(); J.m = kQ;
             J.ws[0] = s[S_C1 + h]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
+            if (adam_step > 0) {
+                J.p = N->critic + h * kQ.padded();
+                J.mom = N->m_critic + h * kQ.padded(); J.var = N->v_critic + h * kQ.padded();
+                J.target = polyak ? N->target_critic + h * kQ.padded() : nullptr;
+            }
         }
-        hipLaunchKernelGGL(wgrad_kernel, dim3(W.njobs * kWgPerJob), dim3(kWide), 0, st, W);
+        if (adam_step > 0) {
+            W.ad = make_adam(N, Hy, Hy->lr_critic, adam_step, false);
+            launch_wg<true>(W, st);
+        } else {
+            launch_wg<false>(W, st);
+        }
     }
     HX_CHECK_LAUNCH("hx_hirl_critic_grads");
     return 0;
+}
+int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, void* stream) {
+    return critic_grads_impl(N, Bt, Hy, actor_fwd, stream, 0, false);
 }
 
 
@@ -2148,7 +2421,7 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
         J = BwdJob{};
         J.net = N->critic; J.m = kQ; J.ws = s[S_CPI]; J.rows = B; J.mode = BM_CRITIC_PI;
         if (soft) J.soft = Head{N->critic, kQ, s[S_CSOFT]};
-        hipLaunchKernelGGL(bwd_l2_kernel<1>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+        launch_bwd<1>(G, st);
     }
     {   // launch I: actor backward for the RL batch (through tanh and the critic's input gradient) and the BC batch
         BwdArgs G{};
@@ -2167,7 +2440,7 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
             J.src = bcsrc; J.lambda = Hy->loss_lambda;
         }
         G.njobs = n;
-        hipLaunchKernelGGL(bwd_l2_kernel<2>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+        launch_bwd<2>(G, st);
     }
     HX_CHECK_LAUNCH("hx_hirl_actor_backward");
     return 0;
@@ -2176,8 +2449,8 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
 /* Stage 2b: actor parameter gradients grad_actor = w * dL_bc + (1 - w) * dL_rl (HIRL.py:321-324).
  * w_kind 0: w_given (linear / fixed schedule, train_all.py:328-333); 1: soft estimate soft_count / batch + warm
  * (HIRL.py:304-306; soft_count may have been all-reduced and `batch` is then the global batch); 2: stored weight. */
-int hx_hirl_actor_wgrad(const HxNets* N, const HxHyper* Hy, int32_t batch, int32_t count_batch, int32_t w_kind, float w_given,
-                        float warm, void* stream) {
+static int actor_wgrad_impl(const HxNets* N, const HxHyper* Hy, int32_t batch, int32_t count_batch, int32_t w_kind, float w_given,
+                            float warm, void* stream, int adam_step, bool polyak) {
     HX_REQUIRE(N && Hy && batch > 0 && count_batch > 0, "hx_hirl_actor_wgrad: bad arguments");
     Slot s[S_COUNT];
     make_slots(N, batch, s);
@@ -2191,9 +2464,21 @@ int hx_hirl_actor_wgrad(const HxNets* N, const HxHyper* Hy, int32_t batch, int32
     J.ws[0] = s[S_API]; J.rows[0] = batch; J.wmode[0] = 1;
     J.nslots = 1;
     if (bc) { J.ws[1] = s[S_ABC]; J.rows[1] = batch; J.wmode[1] = 2; J.nslots = 2; }
-    hipLaunchKernelGGL(wgrad_kernel, dim3(kWgPerJob), dim3(kWide), 0, (hipStream_t)stream, W);
+    if (adam_step > 0) {  // actor.optimizer.step() (+ soft_update of targetActor, + the bf16 image) in the same launch
+        J.p = N->actor; J.mom = N->m_actor; J.var = N->v_actor;
+        J.target = polyak ? N->target_actor : nullptr;
+        J.w2b = N->actor_w2_bf16;
+        W.ad = make_adam(N, Hy, Hy->lr_actor, adam_step, true);
+        launch_wg<true>(W, (hipStream_t)stream);
+    } else {
+        launch_wg<false>(W, (hipStream_t)stream);
+    }
     HX_CHECK_LAUNCH("hx_hirl_actor_wgrad");
     return 0;
+}
+int hx_hirl_actor_wgrad(const HxNets* N, const HxHyper* Hy, int32_t batch, int32_t count_batch, int32_t w_kind, float w_given,
+                        float warm, void* stream) {
+    return actor_wgrad_impl(N, Hy, batch, count_batch, w_kind, w_given, warm, stream, 0, false);
 }
 
 
@@ -2233,15 +2518,13 @@ int hx_polyak(const HxNets* N, const HxHyper* Hy, void* stream) {
  * (HIRL.py:327).  critic_step / actor_step: 1-based Adam step numbers of this call. */
 int hx_hirl_learn(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t critic_step, int32_t actor_phase,
                   int32_t actor_step, int32_t do_polyak, int32_t w_kind, float w_given, float warm, void* stream) {
-    // 5 launches on a critic-only call, 10 on an actor call (the actor's critic-independent forwards ride in launch A)
-    int rc = hx_hirl_critic_grads(N, Bt, Hy, actor_phase ? (w_kind == 1 ? 2 : 1) : 0, stream);
-    if (rc) return rc;
-    const int pk = do_polyak ? 16 : 0;  // the Polyak passes ride in the two Adam launches
-    if ((rc = hx_adam(N, Hy, 0 | pk, critic_step, 1.0f, 0, 0.0f, 0.0f, Bt->batch, stream)) || !actor_phase) return rc;
+    // 4 launches on a critic-only call, 8 on an actor call: the two optimizer steps (and the Polyak passes of the calls that move the
+    // targets) ride in the wgrad launches, the actor's critic-independent forwards in launches A and B
+    HX_REQUIRE(critic_step >= 1 && (!actor_phase || actor_step >= 1), "hx_hirl_learn: Adam steps are 1-based");
+    int rc = critic_grads_impl(N, Bt, Hy, actor_phase ? (w_kind == 1 ? 2 : 1) : 0, stream, critic_step, do_polyak != 0);
+    if (rc || !actor_phase) return rc;
     if ((rc = hx_hirl_actor_backward(N, Bt, Hy, w_kind == 1, 1, stream))) return rc;
-    if ((rc = hx_hirl_actor_wgrad(N, Hy, Bt->batch, Bt->batch, w_kind, w_given, warm, stream))) return rc;
-    if ((rc = hx_adam(N, Hy, 1 | pk, actor_step, 1.0f, w_kind, w_given, warm, Bt->batch, stream))) return rc;
-    return rc;
+    return actor_wgrad_impl(N, Hy, Bt->batch, Bt->batch, w_kind, w_given, warm, stream, actor_step, do_polyak != 0);
 }
 
 /* BC.Agent.train_actor (hirl/agents/BC.py:160-185): one behaviour-cloning step of the actor on the BC minibatch
@@ -2267,7 +2550,7 @@ int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int
         BwdJob& J = G.job[0];
         J = BwdJob{};
         J.net = N->actor; J.m = kActor; J.ws = s[S_ABC]; J.rows = B; J.mode = BM_ACTOR_BC; J.src = bcsrc; J.lambda = 1.0f;
-        hipLaunchKernelGGL(bwd_l2_kernel<2>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+        launch_bwd<2>(G, st);
     }
     {
         WgArgs W{};
@@ -2276,7 +2559,7 @@ int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int
         WgJob& J = W.job[0];
         J = WgJob{};
         J.net = N->actor; J.grad = N->grad_actor; J.m = kActor; J.ws[0] = s[S_ABC]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
-        hipLaunchKernelGGL(wgrad_kernel, dim3(kWgPerJob), dim3(kWide), 0, st, W);
+        launch_wg<false>(W, st);
     }
     HX_CHECK_LAUNCH("hx_bc_train_actor");
     return hx_adam(N, Hy, 2, step, 1.0f, 0, 0.0f, 0.0f, B, stream);
@@ -2380,7 +2663,7 @@ int hx_sac_critic_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
             J.t1 = Head{t1, kQs, s[SS_T1]}; J.t2 = Head{t2, kQs, s[SS_T2]}; J.src = src; J.gamma = Hy->gamma;
             J.bonus = X.ent_n; J.bonus_scale = N->alpha_state + 3; J.loss_slot = h;
         }
-        hipLaunchKernelGGL(bwd_l2_kernel<0>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+        launch_bwd<0>(G, st);
     }
     {
         WgArgs W{};
@@ -2391,7 +2674,7 @@ int hx_sac_critic_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
             J.net = h ? q2 : q1; J.grad = N->grad_critic + h * kQs.padded(); J.m = kQs;
             J.ws[0] = s[SS_Q1 + h]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
         }
-        hipLaunchKernelGGL(wgrad_kernel, dim3(W.njobs * kWgPerJob), dim3(kWide), 0, st, W);
+        launch_wg<false>(W, st);
     }
     HX_CHECK_LAUNCH("hx_sac_critic_grads");
     return 0;
@@ -2431,7 +2714,7 @@ int hx_sac_policy_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
             J = BwdJob{};
             J.net = h ? q2 : q1; J.m = kQs; J.ws = s[SS_Q1P + h]; J.rows = B; J.mode = BM_GIVEN;
         }
-        hipLaunchKernelGGL(bwd_l2_kernel<3>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+        launch_bwd<3>(G, st);
     }
     {
         PDoutArgs P{q1, q2, kQs, s[SS_Q1P], s[SS_Q2P], s[SS_PC], X.aux_c, N->alpha_state, B, 1.0f / B, N->losses};
@@ -2443,7 +2726,7 @@ int hx_sac_policy_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
         BwdJob& J = G.job[0];
         J = BwdJob{};
         J.net = N->policy; J.m = kPolicy; J.ws = s[SS_PC]; J.rows = B; J.mode = BM_GIVEN;
-        hipLaunchKernelGGL(bwd_l2_kernel<3>, dim3(bwd_blocks(G)), dim3(kWide), 0, st, G);
+        launch_bwd<3>(G, st);
     }
     {
         WgArgs W{};
@@ -2451,7 +2734,7 @@ int hx_sac_policy_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
         WgJob& J = W.job[0];
         J = WgJob{};
         J.net = N->policy; J.grad = N->grad_policy; J.m = kPolicy; J.ws[0] = s[SS_PC]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
-        hipLaunchKernelGGL(wgrad_kernel, dim3(kWgPerJob), dim3(kWide), 0, st, W);
+        launch_wg<false>(W, st);
     }
     HX_CHECK_LAUNCH("hx_sac_policy_grads");
     return 0;
