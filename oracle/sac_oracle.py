@@ -40,9 +40,14 @@ def init_mlp(rng, n_in, n_out, h1=256, h2=512):
             "4.weight": xav(n_out, h2), "4.bias": rng.normal(0, 0.05, n_out).astype(np.float32)}
 
 
+def _act(x, slope=0.0):
+    """the builder's ReLU; a module-level hook so that tests can record pre-activations / pick the subgradient at a kink"""
+    return F.relu(x)
+
+
 def mlp(p, x):
-    h = F.relu(F.linear(x, p["0.weight"], p["0.bias"]))
-    h = F.relu(F.linear(h, p["2.weight"], p["2.bias"]))
+    h = _act(F.linear(x, p["0.weight"], p["0.bias"]))
+    h = _act(F.linear(h, p["2.weight"], p["2.bias"]))
     return F.linear(h, p["4.weight"], p["4.bias"])
 
 

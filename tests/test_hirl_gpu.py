@@ -39,21 +39,114 @@ def device_tables(data):
     return ring, exp, torch.from_numpy(bc).cuda().contiguous()
 
 
-def check_grads(eng_mod, got_flat, oracle_grads, layout, what):
-    """Elementwise |diff| <= 1e-4 |g| + 2e-5 max|g|.  A hidden unit whose pre-activation is within fp32 rounding of zero
-    for some row is active on one side and not on the other (ReLU's derivative is discontinuous); that moves the handful
-    of entries fed by that unit (one row of W1, one entry of b1 / LayerNorm) by that row's share.  Such entries are
-    tolerated when they are < 1 % of the tensor AND the tensor's relative L2 error stays below 2e-3."""
+GRAD_RTOL, GRAD_ATOL_OF_MAX = 1e-4, 2e-5   # |dg| <= 1e-4 |g| + 2e-5 max|g| per tensor, EVERY entry
+FRAGILE = 4e-6                              # |pre-activation| below this: the unit's ReLU derivative is a coin toss in fp32
+
+
+def grad_mismatch(got_flat, oracle_grads, layout):
+    """-> list of (key, n_bad, worst, max|g|) for tensors with ANY entry outside |dg| <= 1e-4 |g| + 2e-5 max|g|"""
     got = got_flat.cpu().numpy()
+    out = []
     for k, off, shp in layout:
         g = oracle_grads[k].numpy().ravel()
         x = got[off:off + g.size]
-        tol = 1e-4 * np.abs(g) + 2e-5 * max(np.abs(g).max(), 1e-30)
+        tol = GRAD_RTOL * np.abs(g) + GRAD_ATOL_OF_MAX * max(np.abs(g).max(), 1e-30)
         bad = np.abs(x - g) > tol
-        rel_l2 = np.linalg.norm(x - g) / max(np.linalg.norm(g), 1e-30)
-        ok = (not bad.any()) or (bad.mean() < 0.01 + 1.0 / g.size and rel_l2 < 2e-3)
-        assert ok, (f"{what} {k}: {bad.sum()} of {g.size} off, worst {np.abs(x - g).max():.3e} vs max|g| {np.abs(g).max():.3e}, "
-                    f"rel L2 {rel_l2:.2e}")
+        if bad.any():
+            out.append((k, int(bad.sum()), float(np.abs(x - g).max()), float(np.abs(g).max())))
+    return out
+
+
+class ActProbe:
+    """Patches the oracle's activation: records every pre-activation tensor of a learn() call and, on request, evaluates the
+    backward pass with the ReLU / LeakyReLU derivative of chosen (call, row, unit) positions FLIPPED.  The forward value is untouched
+    (the activation is continuous); only the subgradient picked at a kink changes."""
+
+    def __init__(self, flips=(), module=None):
+        self.mod = module if module is not None else H
+        self.flips = {}
+        for c, r, u in flips:
+            self.flips.setdefault(c, []).append((r, u))
+        self.pre = []
+
+    def __enter__(self):
+        self._orig = self.mod._act
+
+        class Flipped(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, slope, mask):
+                ctx.slope, ctx.mask = slope, mask
+                return torch.where(x > 0, x, x * slope)
+
+            @staticmethod
+            def backward(ctx, g):
+                return g * torch.where(ctx.mask, torch.ones_like(g), torch.full_like(g, ctx.slope)), None, None
+
+        def act(x, slope=0.0):
+            c = len(self.pre)
+            self.pre.append(x.detach())
+            if c not in self.flips:
+                return self._orig(x, slope)
+            mask = (x > 0).detach().clone()
+            for r, u in self.flips[c]:
+                mask[r, u] = ~mask[r, u]
+            return Flipped.apply(x, slope, mask)
+
+        self.mod._act = act
+        return self
+
+    def __exit__(self, *exc):
+        self.mod._act = self._orig
+
+    def fragile(self):
+        out = []
+        for c, x in enumerate(self.pre):
+            if x.dim() == 2:
+                for r, u in (x.abs() < FRAGILE).nonzero().tolist():
+                    out.append((c, r, u))
+        return out
+
+
+def oracle_checked(o, run, pairs, what, module=None):
+    """ref = run(o) advances the oracle `o` by one call; `pairs` = [(engine gradient buffer, key of o.last_grads, layout)].  The engine's
+    gradients are compared under the STRICT elementwise tolerance — no entry may miss.  If some do, the only accepted explanation is a
+    hidden unit whose pre-activation sits within fp32 rounding of zero for some row (its ReLU derivative is then 0 on one side and
+    1 on the other): the oracle's backward pass is re-evaluated with those derivatives flipped (every subset of the fragile
+    positions, at most 2^6), and the engine's gradients must match ONE of these valid subgradients in every entry.  Returns ref;
+    `o` ends in the state of the matching evaluation."""
+    import copy
+    import itertools
+
+    before = copy.deepcopy(o)
+    with ActProbe(module=module) as probe:
+        ref = run(o)
+
+    def mismatches(oo):
+        m = []
+        for flat, key, layout in pairs:
+            m += layout(oo) if callable(layout) else grad_mismatch(flat, oo.last_grads[key], layout)
+        return m
+
+    first = mismatches(o)
+    if not first:
+        return ref
+    frag = probe.fragile()
+    assert frag, f"{what}: gradient entries outside the tolerance and NO pre-activation within {FRAGILE} of zero: {first}"
+    assert len(frag) <= 6, f"{what}: {len(frag)} fragile positions"
+    for k in range(1, len(frag) + 1):
+        for subset in itertools.combinations(frag, k):
+            alt = copy.deepcopy(before)
+            with ActProbe(subset, module=module):
+                ref_alt = run(alt)
+            if not mismatches(alt):
+                o.__dict__.update(alt.__dict__)
+                return ref_alt
+    raise AssertionError(f"{what}: no choice of subgradients at the {len(frag)} fragile positions {frag} reproduces the engine's gradients: {first}")
+
+
+def oracle_learn_checked(eng_mod, e, o, args, was_actor_call, what):
+    pairs = [(e.grad_critic, "critic", eng_mod.CRITIC_LAYOUT)] + ([(e.grad_actor, "actor", eng_mod.ACTOR_LAYOUT)] if was_actor_call else [])
+    return oracle_checked(o, lambda oo: oo.learn(*args), pairs, what)
 
 
 def probes_of(e, eng_mod):
@@ -148,14 +241,27 @@ def assert_losses(got, ref, what):
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=5e-6, err_msg=what)
 
 
-def check_params(e, o, E, what):
-    """After one step from identical states: all but a vanishing fraction of entries agree to 2e-6; the rest are
-    entries whose gradient is rounding noise around zero, which Adam moves by up to 2 lr in either direction."""
-    for flat, layout, ref in ((e.actor, E.ACTOR_LAYOUT, o.actor), (e.critic, E.CRITIC_LAYOUT, o.critic),
-                              (e.target_actor, E.ACTOR_LAYOUT, o.target_actor), (e.target_critic, E.CRITIC_LAYOUT, o.target_critic)):
+def check_params(e, o, E, what, was_actor_call=True):
+    """After one step from identical states, EVERY parameter obeys |dp| <= 2e-6 + 2.1e-3 min(1, 8 tol_g / |g|), tol_g the
+    gradient tolerance above: Adam divides by sqrt(v), so early in training an entry moves by ~lr sign(g) whatever |g| is — an entry
+    whose gradient is within the tolerance of zero may legitimately land 2 lr away, one whose gradient is well resolved may not move
+    by more than its relative gradient error allows.  Targets (Polyak) inherit tau times that."""
+    for flat, layout, ref, grads in ((e.actor, E.ACTOR_LAYOUT, o.actor, o.last_grads.get("actor") if was_actor_call else None),
+                                     (e.critic, E.CRITIC_LAYOUT, o.critic, o.last_grads["critic"]),
+                                     (e.target_actor, E.ACTOR_LAYOUT, o.target_actor, o.last_grads.get("actor") if was_actor_call else None),
+                                     (e.target_critic, E.CRITIC_LAYOUT, o.target_critic, o.last_grads["critic"])):
         f = flat.cpu().numpy()
-        d = np.concatenate([np.abs(f[off:off + int(np.prod(shp))] - ref[k].detach().numpy().ravel()) for k, off, shp in layout])
-        assert (d > 2e-6).mean() < 2e-4 and d.max() <= 2.1e-3, f"{what}: {(d > 2e-6).sum()} entries off, max {d.max():.2e}"
+        for k, off, shp in layout:
+            r = ref[k].detach().numpy().ravel()
+            d = np.abs(f[off:off + r.size] - r)
+            if grads is None:
+                bound = np.full_like(d, 2e-6)
+            else:
+                g = np.abs(grads[k].numpy().ravel())
+                tol = GRAD_RTOL * g + GRAD_ATOL_OF_MAX * max(g.max(), 1e-30)
+                bound = 2e-6 + 2.1e-3 * np.minimum(1.0, 8.0 * tol / np.maximum(g, 1e-30))
+            bad = d > bound
+            assert not bad.any(), f"{what} {k}: {int(bad.sum())} entries beyond their gradient-resolved bound, worst {d[bad].max():.2e}"
 
 
 def check_probes_free_running(e, E, g, k, what):
@@ -195,12 +301,10 @@ def test_learn_matches_oracle_and_reference(eng_mod, mode, golden_dir):
         if ne:
             rows = np.concatenate([rows, data["expert_rows"][g["idx_exp"][k]]], 0)
         ob = (rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31])
-        ref = o.learn(ob, (data["expert_s"][g["idx_bc"][k]], data["expert_a"][g["idx_bc"][k]]), g["noise"][k], w_in, warm)
+        ref = oracle_learn_checked(eng_mod, e, o, (ob, (data["expert_s"][g["idx_bc"][k]], data["expert_a"][g["idx_bc"][k]]), g["noise"][k], w_in, warm),
+                                   was_actor_call, f"{mode} call {k} gradients")
         assert_losses(got, ref, f"{mode} call {k} vs oracle")
-        check_grads(eng_mod, e.grad_critic, o.last_grads["critic"], eng_mod.CRITIC_LAYOUT, f"{mode} call {k} critic grad")
-        if was_actor_call:
-            check_grads(eng_mod, e.grad_actor, o.last_grads["actor"], eng_mod.ACTOR_LAYOUT, f"{mode} call {k} actor grad")
-        check_params(e, o, eng_mod, f"{mode} call {k} params")
+        check_params(e, o, eng_mod, f"{mode} call {k} params", was_actor_call)
         # the reference's own recorded run
         assert_losses(got, g["out"][k], f"{mode} call {k} vs reference golden")
         check_probes_free_running(e, eng_mod, g, k, f"{mode} call {k}")
@@ -221,13 +325,11 @@ def test_td3_learn_matches_reference(eng_mod, golden_dir):
         e.learn(noise=torch.from_numpy(g["noise"][k]).cuda())
         got = e.losses_host()
         rows = data["replay"][g["idx_buf"][k]]
-        ref = o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), None, g["noise"][k])
+        ref = oracle_learn_checked(eng_mod, e, o, ((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), None, g["noise"][k]),
+                                   was_actor_call, f"td3 call {k} gradients")
         assert_losses(got[:2], ref[:2], f"td3 call {k} vs oracle")
         assert_losses(got[:2], g["out"][k], f"td3 call {k} vs reference golden")
-        check_grads(eng_mod, e.grad_critic, o.last_grads["critic"], eng_mod.CRITIC_LAYOUT, f"td3 call {k} critic grad")
-        if was_actor_call:
-            check_grads(eng_mod, e.grad_actor, o.last_grads["actor"], eng_mod.ACTOR_LAYOUT, f"td3 call {k} actor grad")
-        check_params(e, o, eng_mod, f"td3 call {k} params")
+        check_params(e, o, eng_mod, f"td3 call {k} params", was_actor_call)
         check_probes_free_running(e, eng_mod, g, k, f"td3 call {k}")
 
 
@@ -250,13 +352,11 @@ def test_learn_ragged_batches_and_outlier_rows(eng_mod):
             e.assemble(ring, torch.from_numpy(idx).cuda(), bc_table=bc, idx_bc=torch.from_numpy(ibc).cuda())
             e.learn(noise=torch.from_numpy(noise).cuda(), bc_weight_now=100, bc_warm_up_weight=0.1)
             rows = data["replay"][idx]
-            ref = o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]),
-                          (data["expert_s"][ibc], data["expert_a"][ibc]), noise, 100, 0.1)
+            ref = oracle_learn_checked(eng_mod, e, o, ((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]),
+                                                       (data["expert_s"][ibc], data["expert_a"][ibc]), noise, 100, 0.1),
+                                       was_actor_call, f"B={B} call {k} gradients")
             assert_losses(e.losses_host(), ref, f"B={B} call {k}")
-            check_grads(eng_mod, e.grad_critic, o.last_grads["critic"], eng_mod.CRITIC_LAYOUT, f"B={B} critic grad call {k}")
-            if was_actor_call:
-                check_grads(eng_mod, e.grad_actor, o.last_grads["actor"], eng_mod.ACTOR_LAYOUT, f"B={B} actor grad call {k}")
-            check_params(e, o, eng_mod, f"B={B} call {k} params")
+            check_params(e, o, eng_mod, f"B={B} call {k} params", was_actor_call)
 
 
 def test_device_sampler(eng_mod):
@@ -350,13 +450,16 @@ def test_bc_train_actor_matches_oracle_and_reference(eng_mod, golden_dir):
         e.assemble(bc, t, bc_table=bc, idx_bc=t)
         e.bc_train_actor()
         got = e.losses_host()[2]
-        ref = H.bc_train_actor(o, (data["expert_s"][idx], data["expert_a"][idx]))
+        ref = oracle_checked(o, lambda oo: H.bc_train_actor(oo, (data["expert_s"][idx], data["expert_a"][idx])),
+                             [(e.grad_actor, "actor", eng_mod.ACTOR_LAYOUT)], f"bc call {k} actor grad")
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6, err_msg=f"bc call {k} vs oracle")
         np.testing.assert_allclose(got, g["out"][k], rtol=2e-5, atol=1e-6, err_msg=f"bc call {k} vs reference golden")
-        check_grads(eng_mod, e.grad_actor, o.last_grads["actor"], eng_mod.ACTOR_LAYOUT, f"bc call {k} actor grad")
         f = e.actor.cpu().numpy()
-        d = np.abs(f - H.flatten(o.actor, H.ACTOR_KEYS))
-        assert (d > 2e-6).mean() < 2e-4 and d.max() <= 2.1e-3
+        for kk, off, shp in eng_mod.ACTOR_LAYOUT:  # the stepped actor: every entry within its gradient-resolved bound (check_params)
+            gk = np.abs(o.last_grads["actor"][kk].numpy().ravel())
+            tol = GRAD_RTOL * gk + GRAD_ATOL_OF_MAX * max(gk.max(), 1e-30)
+            d = np.abs(f[off:off + gk.size] - o.actor[kk].detach().numpy().ravel())
+            assert (d <= 2e-6 + 2.1e-3 * np.minimum(1.0, 8.0 * tol / np.maximum(gk, 1e-30))).all(), (kk, d.max())
         s_, a_, v_ = D.net_probe(f)
         dv = np.abs(v_ - g["probe_val"][k])
         assert (dv > 2e-6).mean() <= 0.03 and dv.max() < 5e-5

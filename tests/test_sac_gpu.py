@@ -41,12 +41,13 @@ def sync(o, e, SE):
     o.learning_steps = e.learning_steps
 
 
-def grads_close(got, ref, what):
+def grad_bad(got, ref, what):
+    """-> [] or [(what, n_bad, worst)]: EVERY entry must satisfy |dg| <= 1e-4 |g| + 2e-5 max|g| (no blanket allowance; entries that miss
+    must be explained by a ReLU kink: tests/test_hirl_gpu.py::oracle_checked)"""
     g, x = ref.ravel(), got.ravel()
     tol = 1e-4 * np.abs(g) + 2e-5 * max(np.abs(g).max(), 1e-30)
     bad = np.abs(x - g) > tol
-    rel = np.linalg.norm(x - g) / max(np.linalg.norm(g), 1e-30)
-    assert (not bad.any()) or (bad.mean() < 0.01 + 1.0 / g.size and rel < 2e-3), f"{what}: {bad.sum()} of {g.size} off, rel L2 {rel:.2e}"
+    return [(what, int(bad.sum()), float(np.abs(x - g).max()))] if bad.any() else []
 
 
 def test_sac_act_matches_oracle(SE):
@@ -87,19 +88,30 @@ def test_sac_learn_matches_oracle_and_reference(SE, golden_dir):
         e.learn(torch.from_numpy(g["eps"][k, 0]).cuda(), torch.from_numpy(g["eps"][k, 1]).cuda())
         got = e.losses_host()
         rows = data["replay"][g["idx"][k]]
-        ref = o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 30], rows[:, 17:30], rows[:, 31]), g["eps"][k, 0], g["eps"][k, 1])
+        gq = e.grad_critic.cpu().numpy()
+        gp = e.grad_policy.cpu()
+
+        def all_grads(oo):  # every gradient tensor of the three networks against the oracle evaluation `oo`
+            bad = []
+            for h, name in ((0, "q1"), (1, "q2")):
+                u = SE.unpack_mlp(torch.from_numpy(gq[h * SE.Q_SIZE:(h + 1) * SE.Q_SIZE]), SE.Q_BLOCK, 17, 1)
+                for key in S.MLP_KEYS:
+                    bad += grad_bad(u[key].numpy(), oo.last_grads[name][key].numpy(), f"call {k} {name} {key}")
+            u = SE.unpack_mlp(gp, SE.POLICY_BLOCK, 13, 8)
+            for key in S.MLP_KEYS:
+                bad += grad_bad(u[key].numpy(), oo.last_grads["policy"][key].numpy(), f"call {k} policy {key}")
+            return bad
+
+        from tests.test_hirl_gpu import oracle_checked
+        ref = oracle_checked(o, lambda oo: oo.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 30], rows[:, 17:30], rows[:, 31]), g["eps"][k, 0], g["eps"][k, 1]),
+                             [(None, None, all_grads)], f"sac call {k} gradients", module=S)
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=5e-6, err_msg=f"sac call {k} vs oracle")
         # free-running vs the reference's recorded run: policy_loss = mean(-min Q) - alpha mean(H) is a difference of O(1)
         # terms that crosses zero around call 5, so it is compared with an absolute tolerance at the terms' scale
-        np.testing.assert_allclose(got, g["out"][k], rtol=5e-5, atol=1e-4, err_msg=f"sac call {k} vs reference golden")
-        gq = e.grad_critic.cpu().numpy()
-        for h, name in ((0, "q1"), (1, "q2")):
-            u = SE.unpack_mlp(torch.from_numpy(gq[h * SE.Q_SIZE:(h + 1) * SE.Q_SIZE]), SE.Q_BLOCK, 17, 1)
-            for key in S.MLP_KEYS:
-                grads_close(u[key].numpy(), o.last_grads[name][key].numpy(), f"call {k} {name} {key}")
-        u = SE.unpack_mlp(e.grad_policy.cpu(), SE.POLICY_BLOCK, 13, 8)
-        for key in S.MLP_KEYS:
-            grads_close(u[key].numpy(), o.last_grads["policy"][key].numpy(), f"call {k} policy {key}")
+        # (entry 2 only; the other five outputs keep rtol 5e-5 with an absolute floor of 2e-5)
+        others = [0, 1, 3, 4, 5]
+        np.testing.assert_allclose(np.asarray(got)[others], np.asarray(g["out"][k])[others], rtol=5e-5, atol=2e-5, err_msg=f"sac call {k} vs reference golden")
+        np.testing.assert_allclose(got[2], g["out"][k][2], rtol=5e-5, atol=1e-4, err_msg=f"sac call {k} policy_loss vs reference golden")
         sd = e.state_dicts()
         for name, ref_net in (("policy", o.policy), ("q1", o.q1), ("q2", o.q2), ("q1_target", o.q1_t), ("q2_target", o.q2_t)):
             d = np.concatenate([np.abs(sd[name][key].cpu().numpy() - ref_net[key].detach().numpy()).ravel() for key in S.MLP_KEYS])
@@ -110,9 +122,11 @@ def test_sac_learn_matches_oracle_and_reference(SE, golden_dir):
     assert e.learning_steps == 8
 
 
-@pytest.mark.parametrize("n", [4096 + 17, 8192])  # 16-row and 32-row workgroups with the env tail
+@pytest.mark.parametrize("n", [4096 + 17, 8192, 16384])  # 16-row / 32-row workgroups with the env tail; 16,384: the two-launch fallback
 def test_sac_act_step_in_one_launch_equals_act_then_step(SE, n):
-    """hx_sac_act_step = hx_sac_act followed by hx_env_step (explore with given draws, with Philox, and exploit)."""
+    """hx_sac_act_step = hx_sac_act followed by hx_env_step (explore with given draws, with Philox, and exploit).  16,384 serpentine
+    envs is BASELINE.json configs[2] at its own size: beyond 8,192 envs the entry point issues the two launches itself, and the
+    dynamics of the last step are checked against the oracle on a 2,000-env sample from the actions the policy produced."""
     from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
     from hirl4ucav_amd.utils.buffer import DeviceReplay
 
@@ -129,6 +143,7 @@ def test_sac_act_step_in_one_launch_equals_act_then_step(SE, n):
     acts = torch.zeros((n, 4), device="cuda")
     for k in range(12):
         kw = [{"explore": False}, {"eps": torch.randn((n, 4), device="cuda", generator=g)}, {"seed": 4}][k % 3]
+        prev = (envs[0].state.clone(), envs[0].obs.clone(), envs[0].episode_ctr.clone()) if (k == 11 and n == 16384) else None
         engs[0].act(envs[0].obs, out=acts, **kw)
         envs[0].step(acts)
         a2 = engs[1].act_step(envs[1], **kw)[0]
@@ -137,6 +152,20 @@ def test_sac_act_step_in_one_launch_equals_act_then_step(SE, n):
             assert torch.equal(getattr(envs[0], name).view(torch.uint8), getattr(envs[1], name).view(torch.uint8)), f"{name}, step {k}"
     tot = int(reps[0].total.item())
     assert tot == int(reps[1].total.item()) and 0 < tot <= reps[0].capacity
+    if n == 16384:
+        from tests import _oracle as ox
+
+        sample = np.linspace(0, n - 1, 2000).astype(np.int64)
+        st = np.ascontiguousarray(prev[0].cpu().numpy().T[sample])
+        o_obs = np.ascontiguousarray(prev[1].cpu().numpy()[sample])
+        epi = np.ascontiguousarray(prev[2].cpu().numpy()[sample].astype(np.uint32))
+        a = acts.cpu().numpy()[sample]
+        for j, i in enumerate(sample):  # per-env ids key the Philox reset offsets: step each sampled env with its own id
+            ro, do, so = ox.step_batch(st[j:j + 1], a[j:j + 1], o_obs[j:j + 1], max_step=7, auto_reset=1, randomize=1, seed=1, env_id0=int(i), episode_ctr=epi[j:j + 1])
+            assert (int(do[0]), int(so[0])) == (int(envs[0].done[i]), int(envs[0].success[i])), i
+            assert ro.view(np.uint32)[0] == envs[0].reward[i:i + 1].cpu().numpy().view(np.uint32)[0], i
+        np.testing.assert_array_equal(envs[0].state.cpu().numpy().T[sample].view(np.uint32), st.view(np.uint32))
+        np.testing.assert_array_equal(envs[0].obs.cpu().numpy()[sample].view(np.uint32), o_obs.view(np.uint32))
     rows = [r.ring[:tot].cpu().numpy() for r in reps]
     rows = [x[np.lexsort(x.T[::-1])] for x in rows]
     np.testing.assert_array_equal(rows[0].view(np.uint32), rows[1].view(np.uint32))
