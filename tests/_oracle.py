@@ -39,6 +39,9 @@ def lib():
         L.ox_philox4x32_10.argtypes = [_vp] * 3
         L.ox_env_step_batch.argtypes = [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_uint64, ctypes.c_uint32, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp]
+        for f in (L.ox_asin, L.ox_acos):
+            f.argtypes, f.restype = [ctypes.c_float], ctypes.c_float
+        L.ox_atan2.argtypes, L.ox_atan2.restype = [ctypes.c_float, ctypes.c_float], ctypes.c_float
         assert L.ox_sizeof_env() == 148
         _lib = L
     return _lib

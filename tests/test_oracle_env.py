@@ -197,3 +197,18 @@ def test_batch_step_episode_rules():
             stored += n
         assert int(total[0]) == stored
     assert int(stats[0]) == 2 * n and int(stats[3]) == 2 * n and np.all(epi == 2)
+
+
+def test_model_trigonometry_accuracy_and_special_values():
+    """docs/DYNAMICS.md "Angles": the read-back's asin / acos / atan2 are the model's own polynomials (so that host and gfx950 agree bit
+    for bit); against float64 they stay within 4e-7 rad, and the quadrant / end-point values are exact enough for the wrapper."""
+    L = ox.lib()
+    xs = np.linspace(-1, 1, 40001).astype(np.float32)
+    assert max(abs(L.ox_asin(float(x)) - np.arcsin(np.float64(x))) for x in xs) < 4e-7
+    assert max(abs(L.ox_acos(float(x)) - np.arccos(np.float64(x))) for x in xs) < 4e-7
+    rng = np.random.default_rng(0)
+    pts = np.concatenate([rng.normal(size=(20000, 2)), rng.normal(size=(2000, 2)) * [1e-3, 1.0], rng.normal(size=(2000, 2)) * [1.0, 1e-3]]).astype(np.float32)
+    assert max(abs(L.ox_atan2(float(y), float(x)) - np.arctan2(np.float64(y), np.float64(x))) for y, x in pts) < 4e-7
+    assert L.ox_atan2(0.0, 1.0) == 0.0 and L.ox_atan2(0.0, 0.0) == 0.0 and L.ox_asin(0.0) == 0.0 and L.ox_acos(1.0) == 0.0
+    assert abs(L.ox_atan2(1.0, 0.0) - np.pi / 2) < 2e-7 and abs(L.ox_atan2(0.0, -1.0) - np.pi) < 3e-7 and abs(L.ox_acos(-1.0) - np.pi) < 3e-7
+    assert L.ox_atan2(-1.0, 0.0) == -L.ox_atan2(1.0, 0.0) and L.ox_asin(-0.3) == -L.ox_asin(0.3)
