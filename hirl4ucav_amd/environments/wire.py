@@ -20,6 +20,11 @@ import json
 import socket
 import threading
 
+import logging
+
+log = logging.getLogger("hirl4ucav_amd.wire")
+MAX_MESSAGE = 1 << 20  # bytes: the reference's messages are a few hundred bytes; a peer cannot make the server buffer gigabytes
+
 ALLY, OPPO = "ally_1", "ennemy_2"
 PLANES = [ALLY, "ally_2", "ennemy_1", OPPO]  # the collectors take planes[0] and planes[3] (hirl/data/*/ai_data_col.py:20-22)
 
@@ -164,7 +169,10 @@ class WireServer:
         head = self._recv_exact(conn, 4)
         if head is None:
             return None
-        body = self._recv_exact(conn, int.from_bytes(head, "big"))
+        n = int.from_bytes(head, "big")
+        if n > MAX_MESSAGE:
+            raise ValueError(f"message of {n} bytes exceeds the {MAX_MESSAGE}-byte limit")
+        body = self._recv_exact(conn, n)
         return None if body is None else json.loads(body.decode())
 
     @staticmethod
@@ -177,6 +185,11 @@ class WireServer:
         """-> reply object for the ANSWERED commands, None otherwise."""
         b = self.b
         pid = args.get("plane_id", args.get("machine_id"))
+        if pid is not None and pid not in PLANES and not str(pid).startswith((ALLY, OPPO)):
+            raise ValueError(f"unknown machine id {pid!r}")
+        if command in ("SET_PLANE_PITCH", "SET_PLANE_ROLL", "SET_PLANE_YAW", "FIRE_MISSILE", "RESET_MACHINE", "RESET_MACHINE_MATRIX",
+                       "SET_PLANE_THRUST", "SET_PLANE_LINEAR_SPEED", "SET_HEALTH", "REARM_MACHINE") and pid not in (ALLY, OPPO):
+            return None  # the other two aircraft of the sandbox's mission exist in name only
         if command == "UPDATE_SCENE":
             b.tick()
         elif command == "SET_PLANE_PITCH":
@@ -230,12 +243,17 @@ class WireServer:
         with conn:
             conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             while not self._stop:
-                msg = self._recv_message(conn)
-                if msg is None:
+                try:  # a malformed message ends THIS connection, not the server (JSON errors, missing keys, unknown ids, oversize frames)
+                    msg = self._recv_message(conn)
+                    if msg is None:
+                        return
+                    self.messages += 1
+                    command = msg["command"]
+                    reply = self.handle(command, msg.get("args") or {})
+                except (ValueError, KeyError, TypeError, AttributeError, UnicodeDecodeError) as err:
+                    log.warning("closing connection after a bad message: %s", err)
                     return
-                self.messages += 1
-                reply = self.handle(msg["command"], msg.get("args", {}))
-                if msg["command"] in ANSWERED:
+                if command in ANSWERED:
                     self._send(conn, reply)
 
     def serve_forever(self):

@@ -89,3 +89,31 @@ def test_unmodified_reference_client_drives_the_server(cls, tag, golden_dir, mon
         df.disconnect()
     finally:
         srv.close()
+
+
+def test_server_survives_malformed_messages():
+    """an oversize length prefix, broken JSON, a missing 'command' key or an unknown machine id must close that
+    connection only; the server keeps serving the next client."""
+    import json
+    import socket
+    import time
+
+    from hirl4ucav_amd.environments import wire
+    from tests._wire_backend import OracleSimBackend, RawClient
+
+    srv = wire.WireServer(OracleSimBackend(), "127.0.0.1", 0).start()
+    try:
+        for payload in (b"\xff\xff\xff\xff", (5).to_bytes(4, "big") + b"{nope",
+                        (lambda b: len(b).to_bytes(4, "big") + b)(json.dumps({"args": {}}).encode()),
+                        (lambda b: len(b).to_bytes(4, "big") + b)(json.dumps({"command": "GET_PLANE_STATE", "args": {"plane_id": "intruder"}}).encode())):
+            s = socket.create_connection(("127.0.0.1", srv.port))
+            s.sendall(payload)
+            s.settimeout(5)
+            assert s.recv(16) == b""  # the server closed this connection
+            s.close()
+        time.sleep(0.05)
+        c = RawClient(srv.port)  # ... and still answers a well-formed client
+        assert c.ask("GET_HEALTH", machine_id="ennemy_2")["health_level"] > 0
+        c.close()
+    finally:
+        srv.close()
