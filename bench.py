@@ -562,7 +562,7 @@ def profile_traffic(envs):
     if not pmc:
         return None
     return {"bytes": pmc["traffic_bytes"], "fetch_bytes": pmc["fetch_bytes"], "write_bytes": pmc["write_bytes"], "ratio_to_algorithmic": pmc["ratio"],
-            "source": "profiles/pmc_env_traffic.json", "kernel_build": doc.get("kernel_build", "round 1 kernel (before the pair-lane layout)"),
+            "source": "profiles/pmc_env_traffic.json", "kernel_build": doc.get("kernel_build"), "measured_at_commit": doc.get("measured_at_commit"),
             "note": "separate rocprofv3 --pmc passes of tools/pmc_env.py at this size; a profile artefact, not a measurement of this run"}
 
 

@@ -1895,7 +1895,20 @@ struct AdamArgs {
     // acting kernels read it; nullptr = none
     uint16_t* w2b;
     int w2_lo;
+    // merged actor message of a sharded run: g holds the summed dL_rl, g2 the summed dL_bc, *countf the summed
+    // soft count; the step uses g = w g2 + (1 - w) g with w from the GLOBAL count.  nullptr: g is the finished gradient.
+    const float* g2;
+    const float* countf;
 };
+
+// the BC weight of this call (HIRL.py:299-308); countf: the soft count as a float word of the all-reduced message
+__device__ __forceinline__ float adam_w(const AdamArgs& A) {
+    if (A.countf && A.w_kind == 1) {
+        const float w = *A.countf * A.inv_batch + A.warm;
+        return w > 1.0f ? 1.0f : w;
+    }
+    return effective_w(A.w_kind, A.w_given, A.warm, A.inv_batch, A.soft_count, A.wstate);
+}
 
 __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
     if (A.alpha_state && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1907,9 +1920,10 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
         A.alpha_state[3] = expf(la);  // self.alpha = self.log_alpha.exp()
         A.losses[5] = A.alpha_state[3];
     }
+    const float wmix = A.g2 ? adam_w(A) : 0.0f;  // (read before thread 0 of block 0 may store the new weight: same value either way)
     if (A.finish_actor && blockIdx.x == 0 && threadIdx.x == 0) {
         if (A.use_bc) {
-            const float w = effective_w(A.w_kind, A.w_given, A.warm, A.inv_batch, A.soft_count, A.wstate);
+            const float w = adam_w(A);
             A.losses[1] = A.losses[2] * w + A.losses[3] * (1.0f - w);  // HIRL.py:321
             A.losses[5] = w;
             *A.wstate = w;
@@ -1922,6 +1936,13 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
     if (i + 4 <= A.n) {  // the flat buffers are 16-B aligned and a multiple of 4 floats long: one 16-B access per array
         float4 p4 = *reinterpret_cast<const float4*>(A.p + i), g4 = *reinterpret_cast<const float4*>(A.g + i);
         float4 m4 = *reinterpret_cast<const float4*>(A.m + i), v4 = *reinterpret_cast<const float4*>(A.v + i);
+        if (A.g2) {  // g = w dL_bc + (1 - w) dL_rl  (HIRL.py:321), combined AFTER the exchange
+            const float4 b4 = *reinterpret_cast<const float4*>(A.g2 + i);
+            g4.x = wmix * b4.x + (1.0f - wmix) * g4.x;
+            g4.y = wmix * b4.y + (1.0f - wmix) * g4.y;
+            g4.z = wmix * b4.z + (1.0f - wmix) * g4.z;
+            g4.w = wmix * b4.w + (1.0f - wmix) * g4.w;
+        }
         adam_update(p4.x, m4.x, v4.x, g4.x * A.gscale, A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
         adam_update(p4.y, m4.y, v4.y, g4.y * A.gscale, A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
         adam_update(p4.z, m4.z, v4.z, g4.z * A.gscale, A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
@@ -1946,7 +1967,8 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
     }
     for (int c = 0; c < A.n - i; ++c) {  // ragged tail
         float pv = A.p[i + c], mv = A.m[i + c], vv = A.v[i + c];
-        adam_update(pv, mv, vv, A.g[i + c] * A.gscale, A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
+        const float gv = A.g2 ? wmix * A.g2[i + c] + (1.0f - wmix) * A.g[i + c] : A.g[i + c];
+        adam_update(pv, mv, vv, gv * A.gscale, A.b1, A.b2, A.eps, A.step_size, A.bc2_sqrt);
         A.p[i + c] = pv; A.m[i + c] = mv; A.v[i + c] = vv;
         if (A.target) A.target[i + c] = polyak_update(A.target[i + c], pv, A.tau);
     }
@@ -2349,8 +2371,8 @@ int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, 
 /* Adam step over a flat buffer (torch.optim.Adam defaults; step = 1-based step count; grad is multiplied by
  * grad_scale first — 1/world_size after a SUM all-reduce).  which: 0 critic, 1 actor (also finishes actor_loss /
  * bc_weight bookkeeping: w_kind 0 given, 1 estimate from soft_count, 2 reuse stored). */
-int hx_adam(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t step, float grad_scale, int32_t w_kind, float w_given,
-            float warm, int32_t batch, void* stream) {
+static int adam_impl(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t step, float grad_scale, int32_t w_kind, float w_given,
+                     float warm, int32_t batch, const float* msg, void* stream) {
     const bool polyak = (which & 16) != 0;  // + 16: soft_update of this network's target in the same launch
     which &= 15;
     HX_REQUIRE(N && Hy && step >= 1 && which >= 0 && which <= 2, "hx_adam: bad arguments");
@@ -2377,11 +2399,32 @@ int hx_adam(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t step, flo
         A.w2b = N->actor_w2_bf16;
         A.w2_lo = kActor.W2();
     }
+    if (msg) {  // merged actor message: [dL_rl | dL_bc | count ...]
+        HX_REQUIRE(which == 1 && (reinterpret_cast<uintptr_t>(msg) & 15u) == 0, "hx_adam_mixed: actor step only, 16-byte aligned message");
+        A.g = msg;
+        if (Hy->use_bc) {
+            A.g2 = msg + kActor.padded();
+            A.countf = msg + 2 * kActor.padded();
+        }
+    }
     HX_REQUIRE((((uintptr_t)A.p | (uintptr_t)A.g | (uintptr_t)A.m | (uintptr_t)A.v) & 15u) == 0, "hx_adam: buffers must be 16-byte aligned");
     hipLaunchKernelGGL(adam_kernel, dim3((A.n / 4 + kThreads) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, A);
     HX_CHECK_LAUNCH("hx_adam");
     return 0;
 }
+int hx_adam(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t step, float grad_scale, int32_t w_kind, float w_given,
+            float warm, int32_t batch, void* stream) {
+    return adam_impl(N, Hy, which, step, grad_scale, w_kind, w_given, warm, batch, nullptr, stream);
+}
+/* The actor's optimizer step from the MERGED message of a sharded run (one collective for the whole actor phase):
+ * msg = [dL_rl (hx_actor_param_count() floats, padded to 4) | dL_bc (same) | soft count as a float | ...], already summed over the
+ * ranks; w = count / batch + warm (w_kind 1), the given or the stored weight otherwise; g = w dL_bc + (1 - w) dL_rl (HIRL.py:321). */
+int hx_adam_mixed(const HxNets* N, const HxHyper* Hy, int32_t polyak, int32_t step, float grad_scale, int32_t w_kind, float w_given,
+                  float warm, int32_t batch, const float* msg, void* stream) {
+    HX_REQUIRE(msg, "hx_adam_mixed: null message");
+    return adam_impl(N, Hy, 1 | (polyak ? 16 : 0), step, grad_scale, w_kind, w_given, warm, batch, msg, stream);
+}
+int64_t hx_actor_message_floats(void) { return 2 * (int64_t)kActor.padded() + 64; }
 
 /* Stage 2a (delayed actor step, HIRL.py:291-319): actor / bc_actor forward, Q1 with the UPDATED critic, the soft
  * count, backward down to dz2/dh1 of the actor.  Leaves soft_count and losses[2..4] ready; no parameter gradient yet. */
@@ -2479,6 +2522,32 @@ static int actor_wgrad_impl(const HxNets* N, const HxHyper* Hy, int32_t batch, i
 int hx_hirl_actor_wgrad(const HxNets* N, const HxHyper* Hy, int32_t batch, int32_t count_batch, int32_t w_kind, float w_given,
                         float warm, void* stream) {
     return actor_wgrad_impl(N, Hy, batch, count_batch, w_kind, w_given, warm, stream, 0, false);
+}
+
+__global__ void count_to_float_kernel(const int* count, float* out) {
+    if (threadIdx.x == 0) out[0] = count ? (float)*count : 0.0f;
+}
+/* Stage 2b of a sharded run with ONE exchange for the actor phase: the UNWEIGHTED gradients of the two actor losses and the local soft
+ * count go into one message, msg = [dL_rl | dL_bc | count, 0...] (hx_actor_message_floats()); after its all-reduce hx_adam_mixed
+ * forms w from the global count and combines.  TD3 (use_bc = 0): dL_rl only. */
+int hx_hirl_actor_wgrad_split(const HxNets* N, const HxHyper* Hy, int32_t batch, float* msg, void* stream) {
+    HX_REQUIRE(N && Hy && batch > 0 && msg && (reinterpret_cast<uintptr_t>(msg) & 15u) == 0, "hx_hirl_actor_wgrad_split: bad arguments");
+    Slot s[S_COUNT];
+    make_slots(N, batch, s);
+    const bool bc = Hy->use_bc != 0;
+    WgArgs W{};
+    W.njobs = bc ? 2 : 1; W.slope = Hy->slope; W.w_kind = 0; W.w_given = 0.0f; W.inv_batch = 1.0f / batch;
+    W.soft_count = N->soft_count; W.wstate = N->wstate;
+    for (int j = 0; j < W.njobs; ++j) {
+        WgJob& J = W.job[j];
+        J = WgJob{};
+        J.net = N->actor; J.grad = msg + j * kActor.padded(); J.m = kActor;
+        J.ws[0] = s[j == 0 ? S_API : S_ABC]; J.rows[0] = batch; J.wmode[0] = 0; J.nslots = 1;
+    }
+    launch_wg<false>(W, (hipStream_t)stream);
+    hipLaunchKernelGGL(count_to_float_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, bc ? N->soft_count : nullptr, msg + 2 * kActor.padded());
+    HX_CHECK_LAUNCH("hx_hirl_actor_wgrad_split");
+    return 0;
 }
 
 

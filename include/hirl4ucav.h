@@ -220,6 +220,15 @@ int hx_hirl_actor_wgrad(const HxNets* nets, const HxHyper* hyper, int32_t batch,
 int hx_adam(const HxNets* nets, const HxHyper* hyper, int32_t which, int32_t step, float grad_scale, int32_t w_kind,
             float w_given, float warm, int32_t batch, void* stream);
 int hx_polyak(const HxNets* nets, const HxHyper* hyper, void* stream); /* both targets in a launch of their own */
+/* Sharded runs with ONE exchange for the actor phase (SURVEY.md 8e "all-reduce dL_bc, dL_rl and the count in one message and combine
+ * locally"): hx_hirl_actor_wgrad_split writes msg = [dL_rl | dL_bc | soft count as a float, 0...] (hx_actor_message_floats() floats, each
+ * gradient hx_actor_param_count() floats padded to a multiple of 4), unweighted; after the all-reduce of msg, hx_adam_mixed forms
+ * w = count / batch + warm from the GLOBAL count (w_kind 1; given / stored weight otherwise), g = w dL_bc + (1 - w) dL_rl (HIRL.py:321),
+ * and steps the actor (grad_scale = 1 / world; polyak != 0: soft_update of targetActor in the same launch). */
+int64_t hx_actor_message_floats(void);
+int hx_hirl_actor_wgrad_split(const HxNets* nets, const HxHyper* hyper, int32_t batch, float* msg, void* stream);
+int hx_adam_mixed(const HxNets* nets, const HxHyper* hyper, int32_t polyak, int32_t step, float grad_scale, int32_t w_kind, float w_given,
+                  float warm, int32_t batch /* global */, const float* msg, void* stream);
 /* BC.Agent.train_actor (hirl/agents/BC.py:160-185): one behaviour-cloning step on batch->bc_rows: loss = mse(actor(s_bc),
  * a_bc), backward, actor.optimizer.step(); losses[2] receives the loss.  hyper->slope = 0.01 gives BC.py's LeakyReLU actor.
  * (hx_adam's which = 2 is the actor step without HIRL's actor_loss / bc_weight bookkeeping.) */
