@@ -629,15 +629,17 @@ def run_rank(args):
     if world > 1:  # exchange step: events around every gradient exchange (on the stream it is enqueued on)
         inner = loop.eng._allreduce
 
-        def timed_allreduce(t):
+        def timed_allreduce(t, kind=None):
+            call = (lambda: inner(t, kind)) if kind is not None else (lambda: inner(t))
             if len(pool) >= 2:
                 a, b = pool.pop(), pool.pop()
                 a.record()
-                inner(t)
+                out = call()
                 b.record()
                 ar_events.append((t.numel() * 4, a, b))
             else:
-                inner(t)
+                out = call()
+            return t if out is None else out
         loop.eng._allreduce = timed_allreduce
     for k in range(m_steps):
         loop.step_measured(split=(k % 4 == 3), pool=pool, kpool=kpool)

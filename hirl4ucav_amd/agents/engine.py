@@ -44,6 +44,97 @@ _lib.register("hx_hirl_actor_backward", [_P(HxNets), _P(HxBatch), _P(HxHyper), _
 _lib.register("hx_hirl_actor_wgrad", [_P(HxNets), _P(HxHyper), _i32, _i32, _i32, _f32, _f32, _vp])
 _lib.register("hx_adam", [_P(HxNets), _P(HxHyper), _i32, _i32, _f32, _i32, _f32, _f32, _i32, _vp])
 _lib.register("hx_polyak", [_P(HxNets), _P(HxHyper), _vp])
+_lib.register("hx_hirl_actor_wgrad_split", [_P(HxNets), _P(HxHyper), _i32, _vp, _vp])
+_lib.register("hx_adam_mixed", [_P(HxNets), _P(HxHyper), _i32, _i32, _f32, _i32, _f32, _f32, _i32, _vp, _vp])
+_lib.register("hx_ipc_alloc", [ctypes.c_int64, _i32, _P(_vp)])
+_lib.register("hx_ipc_free", [_vp])
+_lib.register("hx_ipc_export", [_vp, _vp])
+_lib.register("hx_ipc_import", [_vp, _P(_vp)])
+_lib.register("hx_ipc_close", [_vp])
+_lib.register("hx_allreduce_oneshot", [_vp, _P(_vp), _P(_vp), _vp, _i32, _i32, ctypes.c_int64, ctypes.c_uint32, _i32, _vp])
+
+
+class _DeviceWords:
+    """raw device memory as a torch tensor (no copy): the __cuda_array_interface__ protocol"""
+
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = {"shape": (int(nfloats),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class OneShotExchange:
+    """The exchange step over hipIpc peer mappings (include/hirl4ucav.h hx_allreduce_oneshot): every rank owns, per message kind, two
+    message buffers (epoch parity) that the peers map, and one fine-grained flag word.  Handles travel once, at construction, through
+    torch.distributed.all_gather_object (any backend)."""
+
+    def __init__(self, sizes, device, group=None, timeout_ms=5000):
+        dist = torch.distributed
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device, self.timeout_ms = device, int(timeout_ms)
+        self.kinds = list(sizes)
+        self.n = {k: (int(v) + 3) & ~3 for k, v in sizes.items()}
+        total = sum(2 * self.n[k] for k in self.kinds)
+        msg, flag = _vp(), _vp()
+        _lib.call("hx_ipc_alloc", total * 4, 0, ctypes.byref(msg))
+        _lib.call("hx_ipc_alloc", 256, 1, ctypes.byref(flag))  # word k: flag of kind k; word 32: status
+        self._own = (msg.value, flag.value)
+        hm, hf = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+        _lib.call("hx_ipc_export", msg, hm)
+        _lib.call("hx_ipc_export", flag, hf)
+        every = [None] * self.world
+        dist.all_gather_object(every, (hm.raw, hf.raw), group=group)
+        self._peers = []
+        bases, flags = [], []
+        for r, (m_h, f_h) in enumerate(every):
+            if r == self.rank:
+                bases.append(msg.value)
+                flags.append(flag.value)
+                continue
+            pm, pf = _vp(), _vp()
+            _lib.call("hx_ipc_import", ctypes.create_string_buffer(m_h, 64), ctypes.byref(pm))
+            _lib.call("hx_ipc_import", ctypes.create_string_buffer(f_h, 64), ctypes.byref(pf))
+            self._peers += [pm.value, pf.value]
+            bases.append(pm.value)
+            flags.append(pf.value)
+        self.status_ptr = flag.value + 32 * 4
+        self.epoch = {k: 0 for k in self.kinds}
+        self.own, self.bufs, self.flags, self.reduced = {}, {}, {}, {}
+        off = 0
+        arr = _vp * self.world
+        for ki, k in enumerate(self.kinds):
+            for par in (0, 1):
+                self.own[k, par] = torch.as_tensor(_DeviceWords(msg.value + off * 4, self.n[k]), device=device)
+                self.bufs[k, par] = arr(*[b + off * 4 for b in bases])
+                off += self.n[k]
+            self.flags[k] = arr(*[f + ki * 4 for f in flags])
+            self.reduced[k] = torch.zeros(self.n[k], dtype=torch.float32, device=device)
+        dist.barrier(group=group)  # every mapping exists before the first exchange
+
+    def write_buffer(self, kind):
+        """where this rank's NEXT message of `kind` must be written (the parity of the epoch its exchange will carry)"""
+        return self.own[kind, (self.epoch[kind] + 1) & 1]
+
+    def allreduce(self, kind):
+        """sum of every rank's message written into write_buffer(kind) -> a local tensor (the same bits on every rank)"""
+        self.epoch[kind] += 1
+        e = self.epoch[kind]
+        _lib.call("hx_allreduce_oneshot", self.reduced[kind].data_ptr(), self.bufs[kind, e & 1], self.flags[kind], self.status_ptr, self.world,
+                  self.rank, self.n[kind], e & 0xFFFFFFFF, self.timeout_ms, _lib.stream_ptr())
+        return self.reduced[kind]
+
+    def check(self):
+        """raises if a wait timed out since the last check (synchronises)"""
+        torch.cuda.synchronize()
+        st = torch.as_tensor(_DeviceWords(self.status_ptr, 1), device=self.device).view(torch.int32)
+        if int(st.item()) != 0:
+            raise _lib.HxError("one-shot exchange: a peer did not arrive in time (status word set)")
+
+    def close(self):
+        for p in self._peers:
+            _lib.call("hx_ipc_close", p)
+        self._peers = []
+        for p in self._own:
+            _lib.call("hx_ipc_free", p)
+        self._own = ()
 _lib.register("hx_bc_train_actor", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _vp])
 _lib.register("hx_hirl_learn", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp])
 _lib.register("hx_sample_batch", [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _i32, _i32, _i32, ctypes.c_uint64,
@@ -132,6 +223,9 @@ class HirlEngine:
         self.world = torch.distributed.get_world_size(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         self.act_calls = 0
         self.staged = self.world > 1  # stage-by-stage path with the gradient exchanges; the one-call fused path otherwise
+        # sharded runs: ONE message for the whole actor phase ([dL_rl | dL_bc | soft count], combined after the exchange)
+        self.actor_msg = torch.zeros(int(L.hx_actor_message_floats()), dtype=torch.float32, device=self.device) if self.world > 1 else None
+        self.exchange_name, self.xchg = "rccl", None
 
     # ---- parameters ------------------------------------------------------------------------------------------
     def load_params(self, actor, critic, bc_actor=None, hard_update_targets=True):
@@ -218,9 +312,22 @@ class HirlEngine:
         return out, env.obs, env.reward, env.done, env.success
 
     # ---- learning --------------------------------------------------------------------------------------------
-    def _allreduce(self, t):
-        if self.world > 1:
-            torch.distributed.all_reduce(t, group=self.group)
+    def use_oneshot_exchange(self, timeout_ms=5000):
+        """Exchange gradients with the one-shot peer-read kernel over hipIpc mappings instead of RCCL (hx_allreduce_oneshot)."""
+        if self.world <= 1:
+            return
+        self.xchg = OneShotExchange({"critic": CRITIC_SIZE, "actor": self.actor_msg.numel()}, self.device, self.group, timeout_ms)
+        self.exchange_name = "oneshot"
+
+    def _allreduce(self, t, kind=None):
+        """SUM over the ranks of `t` (a gradient message).  RCCL: in place.  One-shot: `t` is this rank's message buffer of `kind`, the
+        sum arrives in a separate local tensor (peers are still reading `t`).  -> the tensor that holds the sum"""
+        if self.world <= 1:
+            return t
+        if self.xchg is not None and kind is not None:
+            return self.xchg.allreduce(kind)
+        torch.distributed.all_reduce(t, group=self.group)
+        return t
 
     def assemble(self, ring, idx, expert_ring=None, n_main=None, bc_table=None, idx_bc=None):
         """Caller-chosen minibatch (parity tests, the N = 1 facade): gather ring[idx[r]] / expert_ring[idx[r]] and
@@ -269,21 +376,30 @@ class HirlEngine:
         if not self.staged:
             _lib.call("hx_hirl_learn", nets, ctypes.byref(batch), hyper, self.critic_step, int(actor_phase), self.actor_step,
                       int(do_polyak), w_kind, w_given, float(bc_warm_up_weight), st)
-        else:  # sharded: the same stages with the three exchanges of SURVEY.md 8e in between
+        else:  # sharded: the same stages with the exchanges of SURVEY.md 8e in between — ONE message per phase
             gs = 1.0 / self.world
+            own_critic = self.grad_critic.data_ptr()
+            if self.xchg is not None:  # peers read this rank's gradient straight out of its message buffer: wgrad writes there
+                self.nets.grad_critic = self.xchg.write_buffer("critic").data_ptr()
             _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, (2 if w_kind == 1 else 1) if actor_phase else 0, st)
             if before_exchange is not None:
                 before_exchange()
-            self._allreduce(self.grad_critic)
+            summed = self._allreduce(self.grad_critic, "critic")
+            self.nets.grad_critic = summed.data_ptr()
             pk = 16 if do_polyak else 0  # + 16: soft_update of the target in the same launch (nothing reads it in between)
             _lib.call("hx_adam", nets, hyper, 0 | pk, self.critic_step, gs, 0, 0.0, 0.0, B, st)
+            self.nets.grad_critic = own_critic
             if actor_phase:
                 _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, int(w_kind == 1), 1, st)
-                if w_kind == 1:
-                    self._allreduce(self.soft_count)
-                _lib.call("hx_hirl_actor_wgrad", nets, hyper, B, B * self.world, w_kind, w_given, float(bc_warm_up_weight), st)
-                self._allreduce(self.grad_actor)
-                _lib.call("hx_adam", nets, hyper, 1 | pk, self.actor_step, gs, w_kind, w_given, float(bc_warm_up_weight), B * self.world, st)
+                if self.world > 1:   # [dL_rl | dL_bc | count] in one message, w formed from the global count after the exchange
+                    msg = self.xchg.write_buffer("actor") if self.xchg is not None else self.actor_msg
+                    _lib.call("hx_hirl_actor_wgrad_split", nets, hyper, B, msg.data_ptr(), st)
+                    summed = self._allreduce(msg, "actor")
+                    _lib.call("hx_adam_mixed", nets, hyper, int(do_polyak), self.actor_step, gs, w_kind, w_given, float(bc_warm_up_weight),
+                              B * self.world, summed.data_ptr(), st)
+                else:                # one rank running the staged sequence (tests): the weight is known locally, bit-identical to the one-call path
+                    _lib.call("hx_hirl_actor_wgrad", nets, hyper, B, B, w_kind, w_given, float(bc_warm_up_weight), st)
+                    _lib.call("hx_adam", nets, hyper, 1 | pk, self.actor_step, gs, w_kind, w_given, float(bc_warm_up_weight), B, st)
         self.actor_trainable = not self.actor_trainable  # HIRL.py:332
 
     def bc_train_actor(self):

@@ -1,0 +1,136 @@
+// hx_xchg.hip — the exchange step of a sharded update without a collective library: a ONE-SHOT all-reduce kernel over
+// hipIpc peer mappings.  Every rank exposes its gradient message and one flag word; each rank's kernel announces "my message of this
+// epoch is complete", waits for the peers' announcements, then READS the peers' messages directly over xGMI, sums them in rank order
+// (every rank adds the same values in the same order -> bit-identical results everywhere, no second hop) and writes the sum locally.
+//
+// Why not a ring: the messages are 0.5-1.1 MB and the update is latency-bound; xGMI on MI355X is fully connected point to point (7
+// links per GPU), so one hop over all links at once beats 2 (n - 1) ring steps.  The reference has no exchange at all (single process).
+//
+// Memory model.  Messages are plain device allocations written by earlier kernels on the same stream (a kernel's end publishes its
+// stores system-wide); flags live in FINE-GRAINED device memory and are written / polled with system-scope atomics; before the peer
+// reads, the kernel executes a system-scope acquire (L1 + non-local L2 lines are invalidated).  Messages are double-buffered by epoch
+// parity: a rank overwrites buffer (e & 1) at epoch e + 2 only after it has seen every peer's flag reach e + 1, i.e. after every peer
+// finished reading epoch e — one flag per rank is enough, no "done reading" round.
+// Every spin is bounded: on a timeout the kernel raises status[0] and carries on, the host checks hx_xchg_status().
+#include <cstring>
+
+#include "hx_common.h"
+
+namespace {
+
+constexpr int kMaxWorld = 8;
+constexpr int kThreads = 256;
+
+struct OneShotArgs {
+    float* dst;
+    const float* buf[kMaxWorld];
+    unsigned* flag[kMaxWorld];
+    unsigned* status;  // [0] != 0: a wait timed out
+    int world, rank;
+    long long n;       // floats, multiple of 4
+    unsigned epoch;
+    long long spin_limit;
+};
+
+__global__ __launch_bounds__(kThreads) void oneshot_allreduce_kernel(OneShotArgs A) {
+    __shared__ int s_timeout;
+    if (threadIdx.x == 0) s_timeout = 0;
+    // 1. announce (one lane of the grid): the message was written by kernels that completed before this one started
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(A.flag[A.rank], A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    // 2. wait for every peer (one polling lane per peer and workgroup; epochs only grow: signed distance handles the wrap)
+    if ((int)threadIdx.x < A.world && (int)threadIdx.x != A.rank) {
+        long long spins = 0;
+        while ((int)(__hip_atomic_load(A.flag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - A.epoch) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > A.spin_limit) {
+                s_timeout = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_timeout) {
+        if (threadIdx.x == 0) atomicExch(A.status, 1u);
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: peers' messages are read fresh
+    // 3. sum in rank order, 16 B per lane
+    const long long n4 = A.n / 4;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads) {
+        float4 s = reinterpret_cast<const float4*>(A.buf[0])[i];
+        for (int r = 1; r < A.world; ++r) {
+            const float4 v = reinterpret_cast<const float4*>(A.buf[r])[i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(A.dst)[i] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* Device memory that peers can map (hipIpc): finegrained != 0 for the flag / status words (system-scope atomics), 0 for messages. */
+int hx_ipc_alloc(int64_t bytes, int32_t finegrained, void** dev_ptr) {
+    HX_REQUIRE(bytes > 0 && dev_ptr, "hx_ipc_alloc: bad arguments");
+    void* p = nullptr;
+    if (finegrained) HX_CHECK_HIP(hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained));
+    else HX_CHECK_HIP(hipMalloc(&p, (size_t)bytes));
+    HX_CHECK_HIP(hipMemset(p, 0, (size_t)bytes));
+    HX_CHECK_HIP(hipDeviceSynchronize());
+    *dev_ptr = p;
+    return 0;
+}
+int hx_ipc_free(void* dev_ptr) {
+    HX_REQUIRE(dev_ptr, "hx_ipc_free: null");
+    HX_CHECK_HIP(hipFree(dev_ptr));
+    return 0;
+}
+/* handle64: 64 bytes of host memory (hipIpcMemHandle_t) to hand to the peers (any byte channel: torch.distributed.all_gather_object) */
+int hx_ipc_export(void* dev_ptr, void* handle64) {
+    HX_REQUIRE(dev_ptr && handle64, "hx_ipc_export: bad arguments");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    HX_CHECK_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(handle64), dev_ptr));
+    return 0;
+}
+int hx_ipc_import(const void* handle64, void** dev_ptr) {
+    HX_REQUIRE(handle64 && dev_ptr, "hx_ipc_import: bad arguments");
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle64, sizeof h);
+    HX_CHECK_HIP(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return 0;
+}
+int hx_ipc_close(void* dev_ptr) {
+    HX_REQUIRE(dev_ptr, "hx_ipc_close: null");
+    HX_CHECK_HIP(hipIpcCloseMemHandle(dev_ptr));
+    return 0;
+}
+
+/* dst[i] = sum over ranks r = 0..world-1 (in that order) of bufs[r][i], i < n (n a multiple of 4; all pointers 16-byte aligned).
+ * bufs / flags: HOST arrays of `world` device pointers (own memory at index `rank`, peers' hipIpc mappings elsewhere); status: a device
+ * word that becomes non-zero if a peer did not arrive within `timeout_ms` (then dst is undefined); epoch: this exchange's number,
+ * increasing by 1 per call on every rank (each rank's flag word must start at 0, the first epoch is 1). */
+int hx_allreduce_oneshot(float* dst, const float* const* bufs, uint32_t* const* flags, uint32_t* status, int32_t world, int32_t rank,
+                         int64_t n, uint32_t epoch, int32_t timeout_ms, void* stream) {
+    HX_REQUIRE(dst && bufs && flags && status && world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world && n > 0 && n % 4 == 0,
+               "hx_allreduce_oneshot: bad arguments (world <= 8, n a multiple of 4)");
+    OneShotArgs A{};
+    A.dst = dst; A.status = status; A.world = world; A.rank = rank; A.n = n; A.epoch = epoch;
+    for (int r = 0; r < world; ++r) {
+        HX_REQUIRE(bufs[r] && flags[r] && (reinterpret_cast<uintptr_t>(bufs[r]) & 15u) == 0, "hx_allreduce_oneshot: null or misaligned peer pointer");
+        A.buf[r] = bufs[r];
+        A.flag[r] = flags[r];
+    }
+    A.spin_limit = (long long)(timeout_ms > 0 ? timeout_ms : 2000) * 2000;  // s_sleep 8 ~ 0.5 us per poll
+    const long long n4 = n / 4;
+    const int blocks = (int)((n4 + kThreads - 1) / kThreads < 256 ? (n4 + kThreads - 1) / kThreads : 256);
+    hipLaunchKernelGGL(oneshot_allreduce_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, A);
+    HX_CHECK_LAUNCH("hx_allreduce_oneshot");
+    return 0;
+}
+
+}  // extern "C"

@@ -297,6 +297,23 @@ int hx_sac_policy_grads(const HxSacNets* nets, const HxSacBatch* batch, const Hx
 int hx_sac_adam(const HxSacNets* nets, const HxHyper* hyper, int32_t which, int32_t step, float grad_scale, float target_entropy,
                 void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Exchange step of a sharded update without a collective library (selectable beside RCCL): one-shot all-reduce over hipIpc peer
+ * mappings (hx_xchg.hip).  The reference has no counterpart (single process); SURVEY.md 5 / 8e motivate it: 0.5-1.1 MB messages on a
+ * fully connected xGMI fabric.  hx_ipc_*: device memory peers can map; handle64 = 64 bytes (hipIpcMemHandle_t) exchanged by any channel.
+ * ------------------------------------------------------------------------------------------------------------ */
+int hx_ipc_alloc(int64_t bytes, int32_t finegrained /* 1: flag / status words */, void** dev_ptr);
+int hx_ipc_free(void* dev_ptr);
+int hx_ipc_export(void* dev_ptr, void* handle64 /* host, out */);
+int hx_ipc_import(const void* handle64 /* host */, void** dev_ptr);
+int hx_ipc_close(void* dev_ptr);
+/* dst[i] = bufs[0][i] + bufs[1][i] + ... (rank order: bit-identical on every rank), n floats (multiple of 4).  bufs / flags: host arrays of
+ * `world` (<= 8) device pointers, own memory at index `rank`; every rank calls with the same epoch = 1, 2, 3, ...; messages are
+ * double-buffered by the CALLER (epoch parity), see hx_xchg.hip.  *status != 0 afterwards: a peer did not arrive within timeout_ms. */
+int hx_allreduce_oneshot(float* dst, const float* const* bufs, uint32_t* const* flags, uint32_t* status, int32_t world, int32_t rank,
+                         int64_t n, uint32_t epoch, int32_t timeout_ms, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

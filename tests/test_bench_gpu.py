@@ -67,7 +67,7 @@ def test_bench_starts_its_own_ranks():
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
-@pytest.mark.parametrize("extra", [[], ["--overlap"], ["--agent", "sac", "--scenario", "serpentine"]])
+@pytest.mark.parametrize("extra", [[], ["--overlap"], ["--agent", "sac", "--scenario", "serpentine"], ["--exchange", "oneshot"]])
 def test_bench_two_ranks_launch_form(extra):
     """python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ..."""
     port = str(29600 + (os.getpid() + len(extra)) % 300)
@@ -78,6 +78,9 @@ def test_bench_two_ranks_launch_form(extra):
     assert d["allreduce"] and all(a["median_us"] > 0 for a in d["allreduce"])
     assert d["env_stats"]["env_steps"] > 0
     assert d["replicas_identical"] is True  # 70 sharded updates later every rank holds the same networks and Adam moments, bit for bit
+    assert d["rccl_ranks"]["exchange"] == ("oneshot" if "oneshot" in extra else "rccl") and d["rccl_ranks"]["world_size"] == 2
+    if "sac" not in extra:  # HIRL: one message per phase = the critic's 1.1 MB and the merged actor message, nothing else
+        assert len(d["allreduce"]) == 2, d["allreduce"]
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")

@@ -1,7 +1,8 @@
-"""world_size-2 gloo tests (CPU) of the N > 1 path: env shards are disjoint and reproducible, and the gradient /
-soft-count exchange the engine performs (SUM all-reduce of the flat gradient, then Adam with grad_scale = 1/world;
-SUM all-reduce of the soft count divided by the global batch) reproduces the single-process update of the global batch.
-The arithmetic stand-in on CPU is the update oracle; the collective sequence is the product's."""
+"""world_size-2 gloo tests (CPU) of the N > 1 path: env shards are disjoint and reproducible, and the exchange the engine performs —
+ONE message per phase: SUM all-reduce of the flat critic gradient, then of the merged actor message [dL_rl | dL_bc | soft count],
+Adam with grad_scale = 1/world, the BC weight from the GLOBAL count — reproduces the single-process update of the global batch.
+The arithmetic stand-in on CPU is the update oracle (the engine itself is GPU-only: tests/test_bench_gpu.py and
+tests/test_sharded_gpu.py run the real thing with two ranks on a GPU box); the collective sequence is the product's."""
 import os
 import socket
 
@@ -25,6 +26,9 @@ def _free_port():
 
 
 def _shard_grads(rank, world, port, out):
+    """One sharded learn() as HirlEngine.learn sequences it at world > 1 (agents/engine.py): critic gradient -> ONE all-reduce -> Adam
+    with grad_scale 1/world; actor phase -> ONE all-reduce of the merged message [dL_rl | dL_bc | soft count] -> w from the GLOBAL
+    count -> g = w dL_bc + (1 - w) dL_rl, scaled 1/world.  The arithmetic stand-in on CPU is the update oracle."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
@@ -36,7 +40,7 @@ def _shard_grads(rank, world, port, out):
     lo, hi = rank * B // world, (rank + 1) * B // world
     o = H.HirlOracle(params["actor"], params["critic"], params["bc_actor"])
     rows = data["replay"][idx[lo:hi]]
-    # ---- critic phase on the local shard; then exactly what HirlEngine.learn does with the flat gradient -------------
+    # ---- critic phase on the local shard ---------------------------------------------------------------------------------------
     s, a, ns, r, d = (torch.tensor(x) for x in (rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]))
     with torch.no_grad():
         na = (H.actor_forward(o.target_actor, ns) + torch.tensor(noise).clamp(-0.5, 0.5)).clamp(-1, 1)
@@ -45,17 +49,31 @@ def _shard_grads(rank, world, port, out):
     q1, q2 = H.critic_forward(o.critic, s, a)
     loss = torch.nn.functional.mse_loss(q1, y) + torch.nn.functional.mse_loss(q2, y)
     keys = list(o.critic)
-    flat = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, [o.critic[k] for k in keys])])
-    dist.all_reduce(flat)                 # HirlEngine._allreduce(grad_critic)
+    gl = torch.autograd.grad(loss, [o.critic[k] for k in keys])
+    flat = torch.cat([g.reshape(-1) for g in gl])
+    dist.all_reduce(flat)                 # exchange 1: HirlEngine._allreduce(grad_critic)
     flat *= 1.0 / world                   # hx_adam(..., grad_scale = 1/world)
-    # ---- soft count: SUM all-reduce, divided by the GLOBAL batch ------------------------------------------------------
+    off, grads = 0, {}
+    for k, g in zip(keys, gl):
+        grads[k] = flat[off:off + g.numel()].reshape(g.shape).clone()
+        off += g.numel()
+    o.opt_critic.step(o.critic, grads)    # the actor phase sees the UPDATED critic (HIRL.py:288 precedes :296)
+    # ---- actor phase: unweighted dL_rl, dL_bc and the local soft count in ONE message ---------------------------------------------
+    akeys = list(o.actor)
+    pi = H.actor_forward(o.actor, s)
+    rl_q = H.critic_q1(o.critic, s, pi)
+    g_rl = torch.autograd.grad(-rl_q.mean(), [o.actor[k] for k in akeys])
+    bs, ba = torch.tensor(data["expert_s"][ibc[lo:hi]]), torch.tensor(data["expert_a"][ibc[lo:hi]])
+    g_bc = torch.autograd.grad(torch.nn.functional.mse_loss(H.actor_forward(o.actor, bs), ba) * 10000.0, [o.actor[k] for k in akeys])
     with torch.no_grad():
-        pi = H.actor_forward(o.actor, s)
-        cnt = (H.critic_q1(o.critic, s, H.actor_forward(o.bc_actor, s)) > H.critic_q1(o.critic, s, pi)).sum().to(torch.int32).reshape(1)
-    dist.all_reduce(cnt)                  # HirlEngine._allreduce(soft_count)
-    w = float(cnt.item()) / B             # hx_hirl_actor_wgrad(count_batch = B * world)  [B here is the global batch]
+        cnt = (H.critic_q1(o.critic, s, H.actor_forward(o.bc_actor, s)) > rl_q).sum().float().reshape(1)
+    msg = torch.cat([g.reshape(-1) for g in g_rl] + [g.reshape(-1) for g in g_bc] + [cnt])   # hx_hirl_actor_wgrad_split
+    dist.all_reduce(msg)                  # exchange 2: the only collective of the actor phase
+    na_ = (msg.numel() - 1) // 2
+    w = min(float(msg[-1]) / B, 1.0)      # hx_adam_mixed: count / GLOBAL batch (+ warm = 0), clipped (HIRL.py:308)
+    g_actor = (w * msg[na_:2 * na_] + (1.0 - w) * msg[:na_]) * (1.0 / world)
     if rank == 0:
-        out["flat"], out["w"], out["loss"] = flat.numpy().copy(), w, float(loss)
+        out["flat"], out["w"], out["loss"], out["g_actor"] = flat.numpy().copy(), w, float(loss), g_actor.numpy().copy()
     dist.destroy_process_group()
 
 
@@ -64,7 +82,7 @@ def test_gradient_and_soft_count_exchange_matches_global_batch():
     with mp.Manager() as mgr:
         out = mgr.dict()
         mp.spawn(_shard_grads, args=(world, port, out), nprocs=world, join=True)
-        flat, w = out["flat"], out["w"]
+        flat, w, g_actor = out["flat"], out["w"], out["g_actor"]
     # single process, global batch
     params, data = D.make_params(3), D.make_data(4)
     rng = np.random.default_rng(0)
@@ -75,12 +93,10 @@ def test_gradient_and_soft_count_exchange_matches_global_batch():
     ret = o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), (data["expert_s"][ibc], data["expert_a"][ibc]), noise, 100, 0.0)
     ref = np.concatenate([o.last_grads["critic"][k].numpy().ravel() for k in o.critic])
     np.testing.assert_allclose(flat, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
-    # the oracle computed the soft weight with the critic AFTER its Adam step; recompute the pre-step count for the check
-    o2 = H.HirlOracle(params["actor"], params["critic"], params["bc_actor"])
-    s = torch.tensor(rows[:, 0:13])
-    with torch.no_grad():
-        c = (H.critic_q1(o2.critic, s, H.actor_forward(o2.bc_actor, s)) > H.critic_q1(o2.critic, s, H.actor_forward(o2.actor, s))).float().mean().item()
-    assert abs(w - c) < 1e-9 and 0 <= ret[5] <= 1
+    # two exchanges in all: the soft weight and the mixed actor gradient of the merged message equal the global batch's
+    assert abs(w - ret[5]) < 1e-6 and 0 <= w <= 1
+    ref_a = np.concatenate([o.last_grads["actor"][k].numpy().ravel() for k in o.actor])
+    np.testing.assert_allclose(g_actor, ref_a, rtol=2e-4, atol=2e-5 * np.abs(ref_a).max())
 
 
 def _shard_envs(rank, world, port, out):
