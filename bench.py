@@ -78,6 +78,9 @@ def parse(argv=None):
                    help="use the stage-by-stage update path of the sharded build on one rank too (costs of the N > 1 launch sequence)")
     p.add_argument("--exchange", default="rccl", choices=["rccl", "oneshot"],
                    help="gradient exchange at N > 1: RCCL all-reduce (torch.distributed) or the one-shot peer-read kernel over hipIpc mappings")
+    p.add_argument("--exchange-timeout-ms", dest="exchange_timeout_ms", type=int, default=5000,
+                   help="one-shot exchange: how long a rank waits for a peer's message before it raises (ranks that SHARE a GPU - tests - "
+                        "only make progress through pre-emption and need far longer than ranks with a GPU each)")
     p.add_argument("--measure-steps", dest="measure_steps", type=int, default=256, help="steps of the instrumented second pass")
     return p.parse_args(argv)
 
@@ -194,7 +197,7 @@ class Loop:
             if hasattr(self.eng, "set_act_dtype"):
                 self.eng.set_act_dtype(args.dtype)
             if world > 1 and args.exchange == "oneshot":
-                self.eng.use_oneshot_exchange()
+                self.eng.use_oneshot_exchange(timeout_ms=args.exchange_timeout_ms)
         es, ea = synthetic_expert(rng)
         # BC table rows (s, a) and the expert replay ring labelled on the GPU (train_all.py:289-306)
         bc_rows = np.zeros((es.shape[0], 32), np.float32)
@@ -646,6 +649,8 @@ def run_rank(args):
     barrier()
     if world > 1:
         loop.eng._allreduce = inner
+        if getattr(loop.eng, "xchg", None) is not None:
+            loop.eng.xchg.check()  # a timed-out wait leaves garbage behind: fail loudly instead of printing a number
     med = {k: (float(np.median([a.elapsed_time(b) * 1e3 for a, b in v])) if v else None) for k, v in loop.rec.items()}
     kern = []
     for a, b in loop.krec:

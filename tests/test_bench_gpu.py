@@ -67,14 +67,20 @@ def test_bench_starts_its_own_ranks():
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
-@pytest.mark.parametrize("extra", [[], ["--overlap"], ["--agent", "sac", "--scenario", "serpentine"], ["--exchange", "oneshot"]])
+# one-shot exchange with both ranks on ONE GPU: a rank's wait kernel only sees its peer's flag after the driver pre-empts it in favour of
+# the peer's queue (~0.4 s per exchange) — a functional check with few steps and a long timeout; ranks with a GPU each never wait like that
+ONESHOT = ["--exchange", "oneshot", "--exchange-timeout-ms", "120000", "--measure-steps", "16"]
+
+
+@pytest.mark.parametrize("extra", [[], ["--overlap"], ["--agent", "sac", "--scenario", "serpentine"], ONESHOT])
 def test_bench_two_ranks_launch_form(extra):
     """python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ..."""
     port = str(29600 + (os.getpid() + len(extra)) % 300)
+    steps, warm = (("12", "2") if "oneshot" in extra else ("60", "10"))
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
-             "bench.py", "--gpus", "2", "--steps", "60", "--warmup", "10", "--no-cpu-baseline", "--no-sweep", "--settle-s", "0.2"] + extra,
+             "bench.py", "--gpus", "2", "--steps", steps, "--warmup", warm, "--no-cpu-baseline", "--no-sweep", "--settle-s", "0" if "oneshot" in extra else "0.2"] + extra,
             env={"HX_BENCH_BACKEND": "gloo"})
-    check(d, 2, 60, 10)
+    check(d, 2, int(steps), int(warm))
     assert d["allreduce"] and all(a["median_us"] > 0 for a in d["allreduce"])
     assert d["env_stats"]["env_steps"] > 0
     assert d["replicas_identical"] is True  # 70 sharded updates later every rank holds the same networks and Adam moments, bit for bit
