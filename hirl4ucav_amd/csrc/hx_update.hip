@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A) {
     constexpr int NTW = NT;
     constexpr int CT = WIDE ? 1 : NT / 16, KS = WIDE ? 1 : 16 / CT;  // column tiles / K-parts per workgroup (latency mode)
     constexpr int KRED = WIDE ? 4 : (KS - 1) * CT * 256;
-    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2 + KRED + H1 * 17];
+    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2 + KRED + H1 * 17 + 8];
     float* h1s = lds;
     float* xs = lds + RT * LDA1;
     float* sts = xs + RT * XP;
@@ -263,7 +263,8 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A) {
     // operands that do not depend on the prologue are requested first: their latency hides behind the gather
     BtFrag<H1 / KS> bfrag;
     if (!WIDE) bfrag.load(J.net + J.m.W2() + (size_t)(nt * NT + (wave % CT) * 16 + (lane & 15)) * H1 + (wave / CT) * (H1 / KS));
-    const int u = tid & (H1 - 1), rq = (tid >> 8) * 4;
+    // layer 1 runs on MFMA: wave w owns hidden units 16 w .. 16 w + 15 of all 16 rows; lane (lr, lg) ends up with rows 4 lg .. 4 lg + 3 of unit u
+    const int lr = lane & 15, lg = lane >> 4, u = wave * 16 + lr;
     STAMP_DECL;
     STAMP();
     // Every global operand of the prologue is requested before the first one is consumed: W1 (one or two float4 per thread),
@@ -312,19 +313,23 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A) {
     __syncthreads();
     STAMP();
 
-    // 2. z1[r][u] = b1[u] + sum_i x[r][i] W1[u][i]: hidden unit u = tid & 255, rows 4*(tid >> 8) .. +3
+    // 2. z1[row 4 lg + q][u] = b1[u] + sum_k x[row][k] W1[u][k] on fp32 MFMA, K = 20 (13 or 17 used) in five steps: lane (lr, lg) feeds
+    //    x[lr][4 m + lg] and W1[u][4 m + lg] from LDS (10 reads and 5 MFMAs per lane instead of 85 reads and 68 FMAs)
     float z1[4];
     {
+        v4f acc = {bias1, bias1, bias1, bias1};
+        const float* wrow = w1s + u * in + lg;   // columns >= in of xs are zero; W1 is masked (the LDS words behind a row are not zeros)
+        const float* xrow = xs + lr * XP + lg;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z1[r] = bias1;
-        const float* wrow = w1s + u * in;  // bank (17 u + i) % 32: conflict-free
-        for (int i = 0; i < in; ++i) {
-            const float w = wrow[i];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) z1[r] += xs[(rq + r) * XP + i] * w;
+        for (int mm = 0; mm < 5; ++mm) {
+            const float wv = wrow[4 * mm];
+            acc = mfma16(xrow[4 * mm], 4 * mm + lg < in ? wv : 0.0f, acc);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h1s[(rq + r) * LDA1 + u] = z1[r];
+        for (int q = 0; q < 4; ++q) {
+            z1[q] = acc[q];
+            h1s[(4 * lg + q) * LDA1 + u] = z1[q];
+        }
     }
     __syncthreads();
     STAMP();
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A) {
         const bool save = J.save && nt == 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = rq + r;
+            const int row = 4 * lg + r;
             const float h = act_f(g * ((z1[r] - sts[row * 2]) * sts[row * 2 + 1]) + be, slope);
             h1s[row * LDA1 + u] = h;
             if (save && row < nrow) {
@@ -568,7 +573,8 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     const float* net = A.net;
     const Mlp m = A.m;
     const float slope = A.slope;
-    const int u = tid & (H1 - 1), rq = (tid >> 8) * 4;
+    // layer 1 runs on MFMA (as in fwd_l2): wave w owns hidden units 16 w .. 16 w + 15; lane (lr, lg) ends up with rows 4 lg .. 4 lg + 3 of unit u
+    const int lr = lane & 15, lg = lane >> 4, u = wave * 16 + lr;
     STAMP_DECL;
     STAMP();
     // W2 chunk loader: 4 lanes cover one column's 64 B, the workgroup 256 columns per pass, 2 passes.  Every byte of W2 enters
@@ -623,17 +629,19 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     float z1[NRT][4];
 #pragma unroll
     for (int t = 0; t < NRT; ++t) {
+        v4f acc = {bias1, bias1, bias1, bias1};
+        const float* wrow = w1s + u * 13 + lg;  // columns 13.. of xs are zero; W1 is masked (the LDS words behind a row are not zeros)
+        const float* xrow = xs + (t * RT + lr) * XP + lg;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z1[t][r] = bias1;
-        const float* wrow = w1s + u * 13;
-#pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            const float w = wrow[i];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) z1[t][r] += xs[(t * RT + rq + r) * XP + i] * w;
+        for (int mm = 0; mm < 4; ++mm) {  // K = 16 covers the 13 inputs
+            const float wv = wrow[4 * mm];
+            acc = mfma16(xrow[4 * mm], 4 * mm + lg < 13 ? wv : 0.0f, acc);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h1s[(t * RT + rq + r) * LDA1 + u] = z1[t][r];
+        for (int r = 0; r < 4; ++r) {
+            z1[t][r] = acc[r];
+            h1s[(t * RT + 4 * lg + r) * LDA1 + u] = z1[t][r];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -655,7 +663,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     for (int t = 0; t < NRT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = t * RT + rq + r;
+            const int row = t * RT + 4 * lg + r;
             const float hv = act_f(g1v * ((z1[t][r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
             if (BF16) h1b[row * LDB1 + u] = (__bf16)hv;  // v_cvt_pk_bf16_f32: round to nearest even
             else h1s[row * LDA1 + u] = hv;

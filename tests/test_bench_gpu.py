@@ -66,12 +66,12 @@ def test_bench_starts_its_own_ranks():
     assert d["rccl_ranks"]["world_size"] == 2 and d["replicas_identical"] is True
 
 
-@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
 # one-shot exchange with both ranks on ONE GPU: a rank's wait kernel only sees its peer's flag after the driver pre-empts it in favour of
 # the peer's queue (~0.4 s per exchange) — a functional check with few steps and a long timeout; ranks with a GPU each never wait like that
 ONESHOT = ["--exchange", "oneshot", "--exchange-timeout-ms", "120000", "--measure-steps", "16"]
 
 
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
 @pytest.mark.parametrize("extra", [[], ["--overlap"], ["--agent", "sac", "--scenario", "serpentine"], ONESHOT])
 def test_bench_two_ranks_launch_form(extra):
     """python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ..."""
