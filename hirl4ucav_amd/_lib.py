@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libhx_mi355.so")
+# HX_LIBRARY selects another build of the same library (A/B timing of two builds on one box, the phase-stamp build); never a fallback
+SO_PATH = os.environ.get("HX_LIBRARY") or os.path.join(_HERE, "libhx_mi355.so")
 
 ENV_WORDS, OBS_DIM, ACT_DIM, ROW_WORDS = 37, 13, 4, 32
 STAT_NAMES = ("episodes", "kills", "fire_success_episodes", "time_limit", "fires", "good_fires", "locked_steps", "env_steps", "nonfinite_actions")
