@@ -46,8 +46,14 @@ struct Mlp {
     __host__ __device__ int padded() const { return (size() + 3) & ~3; }
 };
 
-__device__ __forceinline__ float act_f(float y, float slope) { return y > 0.0f ? y : y * slope; }
-__device__ __forceinline__ float act_d(float y, float slope) { return y > 0.0f ? 1.0f : slope; }
+// RELU = the activation is known to be a plain ReLU at compile time (slope == 0: HIRL, SAC): one v_max instead of compare + multiply +
+// select, and the backward factor is a select instead of a select and a multiply.  The update kernels issue an instruction nearly every
+// cycle of their life (16 waves per CU), so their run time follows the instruction count; the launchers pick the instantiation from the slope.
+template <bool RELU>
+__device__ __forceinline__ float act_f(float y, float slope) { return RELU ? fmaxf(y, 0.0f) : (y > 0.0f ? y : y * slope); }
+// v * act'(y)
+template <bool RELU>
+__device__ __forceinline__ float act_bwd(float v, float y, float slope) { return RELU ? (y > 0.0f ? v : 0.0f) : v * (y > 0.0f ? 1.0f : slope); }
 
 // ---- cross-lane sums on DPP (VALU latency) instead of ds_bpermute (LDS latency) ---------------------------------
 // The update kernels run ONE wave per SIMD (B = 128 fills < 256 CUs), so every dependent reduction is exposed; a

@@ -136,7 +136,7 @@ struct RowReg {
 
 // head of an MLP block for ONE row held by a wave: LN2 stats of z2, h2 = act(LN2(z2)), o[j] = h2 . W3[j] + b3[j].
 // Leaves xhat and y (pre-activation) in registers for the backward prologue.
-template <int OUTMAX>
+template <int OUTMAX, bool RELU>
 __device__ __forceinline__ void head_row(const float* __restrict__ z2row, const float* __restrict__ net, const Mlp m, float slope,
                                          RowReg<H2>& xhat, RowReg<H2>& y, float& mean, float& rstd, float (&o)[OUTMAX]) {
     RowReg<H2> z, g, be;
@@ -157,7 +157,7 @@ __device__ __forceinline__ void head_row(const float* __restrict__ z2row, const 
             RowReg<H2> w;
             w.load(net + m.W3() + j * H2);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc += act_f(y.v[i], slope) * w.v[i];
+            for (int i = 0; i < 8; ++i) acc += act_f<RELU>(y.v[i], slope) * w.v[i];
             acc = wave_sum(acc) + net[m.b3() + j];
         }
         o[j] = acc;
@@ -237,7 +237,7 @@ __device__ __forceinline__ int tiles_of(int rows) { return (rows + RT - 1) / RT;
 //                (then 128-256 workgroups still run in one round and each carries half the MFMA work).
 // NT = 256     : one 16-column tile per wave, full K (throughput mode, thousands of rows: the prologue is recomputed 2x per
 //                row tile instead of 8x or 16x)
-template <int NT>
+template <int NT, bool RELU>
 __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A) {
     constexpr bool WIDE = NT == 256;
     constexpr int NTW = NT;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A) {
         const int r = wave;
         RowReg<H2> xh, y;
         float mean, rstd, o[4];
-        head_row<4>(J.prev.ws.z2 + (size_t)(r0 + r) * H2, J.prev.net, J.prev.m, slope, xh, y, mean, rstd, o);
+        head_row<4, RELU>(J.prev.ws.z2 + (size_t)(r0 + r) * H2, J.prev.net, J.prev.m, slope, xh, y, mean, rstd, o);
         if (lane < 4) {
             float a = tanhf(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // Actor.forward's tanh, HIRL.py:140
             if (J.noise) {              // target smoothing, HIRL.py:264-267
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * lg + r;
-            const float h = act_f(g * ((z1[r] - sts[row * 2]) * sts[row * 2 + 1]) + be, slope);
+            const float h = act_f<RELU>(g * ((z1[r] - sts[row * 2]) * sts[row * 2 + 1]) + be, slope);
             h1s[row * LDA1 + u] = h;
             if (save && row < nrow) {
                 J.ws.z1[(size_t)(r0 + row) * H1 + u] = z1[r];
@@ -458,7 +458,7 @@ struct HeadImage {
 };
 // head from registers + the LDS image: LN2 stats of z, y = g2 xhat + be2, o[j] = act(y) . W3[j] + b3[j]
 // OUTMAX = how many outputs are computed, IMG = head width the LDS image was laid out for (HeadImage<IMG>)
-template <int OUTMAX, int IMG>
+template <int OUTMAX, int IMG, bool RELU>
 __device__ __forceinline__ void head_regs(const RowReg<H2>& z, const float* hp, int out, float slope, RowReg<H2>& xhat, RowReg<H2>& y,
                                           float& mean, float& rstd, float (&o)[OUTMAX], int no_ln = 0) {
     RowReg<H2> g, be;
@@ -478,7 +478,7 @@ __device__ __forceinline__ void head_regs(const RowReg<H2>& z, const float* hp, 
             RowReg<H2> w;
             w.load(hp + (2 + j) * H2);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc += act_f(y.v[i], slope) * w.v[i];
+            for (int i = 0; i < 8; ++i) acc += act_f<RELU>(y.v[i], slope) * w.v[i];
             acc = wave_sum(acc) + hp[(2 + IMG) * H2 + j];
         }
         o[j] = acc;
@@ -547,7 +547,7 @@ __device__ __forceinline__ float philox_normal(uint32_t row, uint32_t call, uint
 //         the 512 columns and nobody else reads them, so its B fragments (16 x 16 B per lane = the 256 KB image once per
 //         workgroup) go from L2 straight into registers at kernel entry — no LDS staging, no chunk barriers; the 16 (32) rows
 //         of h1 are the only shared operand.
-template <int NRT, bool GAUSS, bool ENV, bool BF16>
+template <int NRT, bool GAUSS, bool ENV, bool BF16, bool RELU>
 __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     constexpr int ROWS = NRT * RT;
     __shared__ float s_act[ENV ? ROWS * 4 : 4];
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = t * RT + 4 * lg + r;
-            const float hv = act_f(g1v * ((z1[t][r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
+            const float hv = act_f<RELU>(g1v * ((z1[t][r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
             if (BF16) h1b[row * LDB1 + u] = (__bf16)hv;  // v_cvt_pk_bf16_f32: round to nearest even
             else h1s[row * LDA1 + u] = hv;
         }
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         z.load(z2s + lr * LDA2);
         if (!GAUSS) {
             float o[4];
-            head_regs<4, 4>(z, hps, m.out, slope, xh, y, mean, rstd, o, m.no_ln);
+            head_regs<4, 4, RELU>(z, hps, m.out, slope, xh, y, mean, rstd, o, m.no_ln);
             if (lane < 4) {
                 float a = tanhf(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // no dynamic register index
                 if (A.noise) {
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             }
         } else {
             float o[8];
-            head_regs<8, 8>(z, hps, m.out, slope, xh, y, mean, rstd, o, m.no_ln);
+            head_regs<8, 8, RELU>(z, hps, m.out, slope, xh, y, mean, rstd, o, m.no_ln);
             if (lane < 4) {
                 const float mu = pick8(o, lane);
                 float a = mu;
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 // the ~8 us tail, and the env kernel on its own (thousands of envs per launch, 10-14 us) is the cheaper way.
 constexpr int64_t kFuseEnvMax = 8192;
 
-template <bool GAUSS, bool BF16>
+template <bool GAUSS, bool BF16, bool RELU>
 static void launch_act_t(const ActFusedArgs& H, hipStream_t st) {
     const bool env = H.state != nullptr;
     // 32 rows per workgroup: from 8,192 rows on (fp32: below that, 16-row workgroups fill the chip and the fp32 MFMA work per workgroup
@@ -921,18 +921,24 @@ static void launch_act_t(const ActFusedArgs& H, hipStream_t st) {
     static const int nrt2_bf16 = getenv("HX_ACT_BF16_NRT2_ROWS") ? atoi(getenv("HX_ACT_BF16_NRT2_ROWS")) : 8192;  // tuning knob
     if (H.rows >= (BF16 ? nrt2_bf16 : 8192)) {
         const dim3 grid((unsigned)((H.rows + 2 * RT - 1) / (2 * RT)));
-        if (env) hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, true, BF16>), grid, dim3(kWide), 0, st, H);
-        else hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, false, BF16>), grid, dim3(kWide), 0, st, H);
+        if (env) hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, true, BF16, RELU>), grid, dim3(kWide), 0, st, H);
+        else hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, false, BF16, RELU>), grid, dim3(kWide), 0, st, H);
     } else {
         const dim3 grid((unsigned)((H.rows + RT - 1) / RT));
-        if (env) hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, true, BF16>), grid, dim3(kWide), 0, st, H);
-        else hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, false, BF16>), grid, dim3(kWide), 0, st, H);
+        if (env) hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, true, BF16, RELU>), grid, dim3(kWide), 0, st, H);
+        else hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, false, BF16, RELU>), grid, dim3(kWide), 0, st, H);
     }
 }
 template <bool GAUSS>
 static void launch_act(const ActFusedArgs& H, hipStream_t st) {
-    if (H.w2b) launch_act_t<GAUSS, true>(H, st);
-    else launch_act_t<GAUSS, false>(H, st);
+    // the activation is a compile-time ReLU when the slope is 0 (HIRL, SAC; the Gaussian policy is a Linear-ReLU stack by definition)
+    if (GAUSS || H.slope == 0.0f) {
+        if (H.w2b) launch_act_t<GAUSS, true, true>(H, st);
+        else launch_act_t<GAUSS, false, true>(H, st);
+    } else {
+        if (H.w2b) launch_act_t<false, true, false>(H, st);
+        else launch_act_t<false, false, false>(H, st);
+    }
 }
 
 // bf16 image of a [n] fp32 array (round to nearest even): the policy's W2 for the BF16 acting kernels
@@ -1044,7 +1050,7 @@ __device__ __forceinline__ float lnp_sum(const float* lp) {
 // Latency structure (what matters at B = 128, one workgroup per CU): EVERY global load of the workgroup — the W2 fragment
 // of the MFMA phase, the z2 rows, labels, the other nets' rows, all head parameters, the epilogue's z1 — is issued at
 // entry; there is ONE wait; head parameters are shared through LDS; the rest runs out of registers and LDS.
-template <int GRP>
+template <int GRP, bool RELU>
 __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     __shared__ __attribute__((aligned(16))) float dz2s[RT * LDA2];
     __shared__ __attribute__((aligned(16))) float kred[(kKSB - 1) * kCTB * 256];  // split-K partial tiles
@@ -1167,7 +1173,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     } else {
         RowReg<H2> xh, y;
         float mean, rstd, o[IMG];
-        head_regs<IMG, IMG>(z, hps, J.m.out, slope, xh, y, mean, rstd, o, J.m.no_ln);
+        head_regs<IMG, IMG, RELU>(z, hps, J.m.out, slope, xh, y, mean, rstd, o, J.m.no_ln);
         float dout[IMG] = {};
         if (GRP == 3) {  // head gradient supplied by a previous kernel (SAC: min-selected critics, sampled policy)
 #pragma unroll
@@ -1175,8 +1181,8 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
         } else if (GRP == 0) {
             RowReg<H2> xa, ya;
             float m1, s1, q1[1], q2[1];
-            head_regs<1, IMG>(za, hps + kHpStride, 1, slope, xa, ya, m1, s1, q1, J.t1.m.no_ln);
-            head_regs<1, IMG>(zb, hps + 2 * kHpStride, 1, slope, xa, ya, m1, s1, q2, J.t2.m.no_ln);
+            head_regs<1, IMG, RELU>(za, hps + kHpStride, 1, slope, xa, ya, m1, s1, q1, J.t1.m.no_ln);
+            head_regs<1, IMG, RELU>(zb, hps + 2 * kHpStride, 1, slope, xa, ya, m1, s1, q2, J.t2.m.no_ln);
             // HIRL.py:270-274; with `bonus` SAC's r + (1 - d) gamma (min Q' + alpha H')  SAC/agent.py:202-210
             const float target = J.bonus ? lab0 + (1.0f - lab1) * (J.gamma * (fminf(q1[0], q2[0]) + bonus))
                                          : lab0 + (J.gamma * fminf(q1[0], q2[0])) * (1.0f - lab1);
@@ -1189,7 +1195,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
             if (J.soft.net) {
                 RowReg<H2> xa, ya;
                 float m1, s1, qs[1];
-                head_regs<1, IMG>(za, hps, 1, slope, xa, ya, m1, s1, qs, J.m.no_ln);
+                head_regs<1, IMG, RELU>(za, hps, 1, slope, xa, ya, m1, s1, qs, J.m.no_ln);
                 cnt += (qs[0] > o[0]) ? 1 : 0;  // (soft_Q > rl_Q)  HIRL.py:303
             }
         } else if (J.mode == BM_ACTOR_PI) {
@@ -1200,7 +1206,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
                 const int k = lane * 4 + c;
                 const float g1 = c1s[k], be1 = c1s[H1 + k];
                 const float xh1 = (cz.v[c] - cst0) * cst1;
-                const float dxh = cdh.v[c] * act_d(g1 * xh1 + be1, slope) * g1;
+                const float dxh = act_bwd<RELU>(cdh.v[c], g1 * xh1 + be1, slope) * g1;
                 const float dz1 = cst1 * (dxh - cs1 - xh1 * cs2);
                 const float4 w4 = *reinterpret_cast<const float4*>(c1s + 2 * H1 + 4 * k);
                 da[0] += dz1 * w4.x; da[1] += dz1 * w4.y; da[2] += dz1 * w4.z; da[3] += dz1 * w4.w;
@@ -1235,7 +1241,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            dx.v[i] = dx.v[i] * act_d(y.v[i], slope) * g.v[i];
+            dx.v[i] = act_bwd<RELU>(dx.v[i], y.v[i], slope) * g.v[i];
             s1 += dx.v[i];
             s2 += dx.v[i] * xh.v[i];
         }
@@ -1308,7 +1314,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
                 if (row < nrow) {
                     J.ws.dh1[(size_t)(r0 + row) * H1 + n0 + r] = v;
                     const float xh = (ez1[q] - st1s[row * 2]) * st1s[row * 2 + 1];
-                    const float dxh = v * act_d(eg1 * xh + ebe1, slope) * eg1;
+                    const float dxh = act_bwd<RELU>(v, eg1 * xh + ebe1, slope) * eg1;
                     p1 = J.m.no_ln ? 0.0f : dxh;
                     p2 = J.m.no_ln ? 0.0f : dxh * xh;
                 }
@@ -1354,7 +1360,7 @@ __global__ __launch_bounds__(kThreads) void gauss_head_kernel(GaussArgs A) {
     if (r >= A.rows) return;
     RowReg<H2> xh, y;
     float mean_, rstd_, o[8];
-    head_row<8>(A.z2 + (size_t)r * H2, A.net, A.m, 0.0f, xh, y, mean_, rstd_, o);
+    head_row<8, true>(A.z2 + (size_t)r * H2, A.net, A.m, 0.0f, xh, y, mean_, rstd_, o);
     const int j = lane & 3;
     const float mu = pick8(o, j), ls_raw = pick8(o, 4 + j);
     const float ls = fminf(fmaxf(ls_raw, -20.0f), 2.0f);  // model.py:65-66
@@ -1404,9 +1410,9 @@ __global__ __launch_bounds__(kThreads) void q_select_kernel(QSelArgs A) {
     if (r >= A.rows) return;
     RowReg<H2> xh, y;
     float mean_, rstd_, q1[1], q2[1];
-    head_row<1>(A.s1.z2 + (size_t)r * H2, A.net1, A.m, 0.0f, xh, y, mean_, rstd_, q1);
+    head_row<1, true>(A.s1.z2 + (size_t)r * H2, A.net1, A.m, 0.0f, xh, y, mean_, rstd_, q1);
     if (lane == 0) { A.s1.st2[r * 2] = mean_; A.s1.st2[r * 2 + 1] = rstd_; }
-    head_row<1>(A.s2.z2 + (size_t)r * H2, A.net2, A.m, 0.0f, xh, y, mean_, rstd_, q2);
+    head_row<1, true>(A.s2.z2 + (size_t)r * H2, A.net2, A.m, 0.0f, xh, y, mean_, rstd_, q2);
     if (lane == 0) {
         A.s2.st2[r * 2] = mean_; A.s2.st2[r * 2 + 1] = rstd_;
         const float w1 = q1[0] < q2[0] ? 1.0f : (q1[0] == q2[0] ? 0.5f : 0.0f);
@@ -1444,7 +1450,7 @@ __global__ __launch_bounds__(kThreads) void policy_dout_kernel(PDoutArgs A) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {  // hidden unit k = lane*4 + c; plain stack: dz1 = dh1 * relu'(z1)
             const int k = lane * 4 + c;
-            const float dz1 = dh.v[c] * act_d(z.v[c], 0.0f);
+            const float dz1 = act_bwd<true>(dh.v[c], z.v[c], 0.0f);
             const float* w = net + A.mq.W1() + k * A.mq.in + 13;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) da[jj] += dz1 * w[jj];
@@ -1610,7 +1616,7 @@ inline WgJobC pack_wg(const WgJob& J, const WgArgs& A) {
     return c;
 }
 
-template <bool ADAM>
+template <bool ADAM, bool RELU>
 __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
     __shared__ __attribute__((aligned(16))) float lds[kWgRowChunk * XP + kWgRowChunk * 12 + kWgRG * 64 * 20];
     float* xs = lds;                          // [chunk][XP]   inputs (layer-1 job)
@@ -1753,8 +1759,8 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                             const float y = g2 * xh + be2;
                             float dh2 = (ri[2] * w3[0] + ri[3] * w3[1]) + (ri[4] * w3[2] + ri[5] * w3[3]);
                             if (J.m.out > 4) dh2 += (ri[6] * w3[4] + ri[7] * w3[5]) + (ri[8] * w3[6] + ri[9] * w3[7]);
-                            const float dy = dh2 * act_d(y, slope);
-                            const float h2 = act_f(y, slope);
+                            const float dy = act_bwd<RELU>(dh2, y, slope);
+                            const float h2 = act_f<RELU>(y, slope);
                             db2 += sc * dv[i];
                             dbe += sc * dy;
                             dg += sc * dy * xh;
@@ -1846,7 +1852,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                         if (r < nr) {
                             const float* ri = rinfo + r * 8;
                             const float xh = (zv[i] - ri[0]) * ri[1];
-                            const float dy = dv[i] * act_d(g1 * xh + be1, slope);
+                            const float dy = act_bwd<RELU>(dv[i], g1 * xh + be1, slope);
                             const float dz = sc * (ri[1] * (dy * g1 - ri[2] - xh * ri[3]));
                             db1 += dz;
                             dbe += sc * dy;
@@ -2145,12 +2151,14 @@ void launch_fwd(const FwdArgs& F, hipStream_t st) {
     }
     C.slope = F.slope; C.zero_nf = F.zero_nf; C.zero_f = F.zero_f; C.zero_i = F.zero_i;
     const int tiles = fwd_row_tiles(F), per_job = tiles / F.njobs;
-    if (tiles >= 128)
-        hipLaunchKernelGGL(fwd_l2_kernel<256>, dim3(per_job * (H2 / 256), F.njobs), dim3(kWide), 0, st, C);
-    else if (tiles * (H2 / 32) <= 256)  // one or two nets at B = 128: 32-column workgroups still fit the chip in one round
-        hipLaunchKernelGGL(fwd_l2_kernel<32>, dim3(per_job * (H2 / 32), F.njobs), dim3(kWide), 0, st, C);
-    else
-        hipLaunchKernelGGL(fwd_l2_kernel<kNT>, dim3(per_job * (H2 / kNT), F.njobs), dim3(kWide), 0, st, C);
+    const bool relu = F.slope == 0.0f;  // compile-time ReLU instantiations (hx_nn.h act_f)
+#define HX_FWD(NT_) do { const dim3 grid(per_job * (H2 / NT_), F.njobs); \
+        if (relu) hipLaunchKernelGGL((fwd_l2_kernel<NT_, true>), grid, dim3(kWide), 0, st, C); \
+        else hipLaunchKernelGGL((fwd_l2_kernel<NT_, false>), grid, dim3(kWide), 0, st, C); } while (0)
+    if (tiles >= 128) HX_FWD(256);
+    else if (tiles * (H2 / 32) <= 256) HX_FWD(32);  // one or two nets at B = 128: 32-column workgroups still fit the chip in one round
+    else HX_FWD(kNT);
+#undef HX_FWD
 }
 int bwd_blocks(const BwdArgs& a) {  // per job (every job of a launch has the same row count)
     return ((a.job[0].rows + RT - 1) / RT) * kColWgB;
@@ -2159,13 +2167,15 @@ template <bool ADAM>
 void launch_wg(const WgArgs& W, hipStream_t st) {
     WgArgsC C{};
     for (int j = 0; j < W.njobs; ++j) C.job[j] = pack_wg(W.job[j], W);
-    hipLaunchKernelGGL(wgrad_kernel<ADAM>, dim3(kWgPerJob, W.njobs), dim3(kWide), 0, st, C);
+    if (W.slope == 0.0f) hipLaunchKernelGGL((wgrad_kernel<ADAM, true>), dim3(kWgPerJob, W.njobs), dim3(kWide), 0, st, C);
+    else hipLaunchKernelGGL((wgrad_kernel<ADAM, false>), dim3(kWgPerJob, W.njobs), dim3(kWide), 0, st, C);
 }
 template <int GRP>
 void launch_bwd(const BwdArgs& G, hipStream_t st) {
     BwdArgsC C{};
     for (int j = 0; j < G.njobs; ++j) C.job[j] = pack_bwd(G.job[j], G);
-    hipLaunchKernelGGL(bwd_l2_kernel<GRP>, dim3(bwd_blocks(G), G.njobs), dim3(kWide), 0, st, C);
+    if (G.slope == 0.0f) hipLaunchKernelGGL((bwd_l2_kernel<GRP, true>), dim3(bwd_blocks(G), G.njobs), dim3(kWide), 0, st, C);
+    else hipLaunchKernelGGL((bwd_l2_kernel<GRP, false>), dim3(bwd_blocks(G), G.njobs), dim3(kWide), 0, st, C);
 }
 
 const Mlp kActor{13, 4, 0};
