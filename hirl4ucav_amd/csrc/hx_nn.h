@@ -60,7 +60,9 @@ __device__ __forceinline__ float act_bwd(float v, float y, float slope) { return
 // 6-step __shfl_xor tree costs ~6 LDS round trips, the DPP form 4 VALU ops + 4 v_readlane.
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+    // mov_dpp (no `old` operand: every lane has a source under these permutations) folds into ONE v_add_f32_dpp; where the compiler packs two
+    // reductions into v_pk_add_f32 it stays a bare v_mov_b32_dpp (update_dpp(0, ...) cost an extra v_mov 0 per value and step there)
+    return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 // every lane of each aligned 16-lane row ends up with that row's sum
 __device__ __forceinline__ float sum16(float v) {

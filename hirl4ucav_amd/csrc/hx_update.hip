@@ -439,11 +439,13 @@ struct HeadImage {
     float b3v;
     // g2, be2, W3 rows are contiguous in the parameter block from g2()
     __device__ __forceinline__ void fetch(const float* __restrict__ net, const Mlp& m, int tid) {
-        b3v = tid < m.out ? net[m.b3() + tid] : 0.0f;
+        // unconditional loads from clamped (valid) addresses; store() keeps only the live ones.  A conditional load merges with its zero
+        // default through register copies that WAIT for the data — in the middle of the caller's issue phase.
+        b3v = net[m.b3() + (tid < m.out ? tid : 0)];
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
             const int e = tid + i * kWide;
-            v[i] = e < (2 + m.out) * (H2 / 4) ? reinterpret_cast<const float4*>(net + m.g2())[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[i] = reinterpret_cast<const float4*>(net + m.g2())[e < (2 + m.out) * (H2 / 4) ? e : 0];
         }
     }
     __device__ __forceinline__ void store(float* hp, const float* __restrict__ net, const Mlp& m, int tid) const {
@@ -1055,6 +1057,10 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     __shared__ __attribute__((aligned(16))) float dz2s[RT * LDA2];
     __shared__ __attribute__((aligned(16))) float kred[(kKSB - 1) * kCTB * 256];  // split-K partial tiles
     constexpr int IMG = GRP == 3 ? 8 : 4;  // head width of this instantiation's LDS images
+    // head width known at compile time: the critic jobs (GRP 0, 1) have ONE output, the actor jobs (GRP 2) four; GRP 3 (SAC: policy 8 wide,
+    // Q heads 1) keeps the run-time width.  A run-time trip count over dout[] costs a select chain per step (no indexed registers).
+    constexpr int NOUT = GRP <= 1 ? 1 : (GRP == 2 ? 4 : 0);
+    constexpr int OUTW = NOUT ? NOUT : IMG;
     typedef HeadImage<IMG> Img;
     constexpr int kHpStride = Img::kStride;
     __shared__ __attribute__((aligned(16))) float hps[(GRP == 0 ? 3 : 1) * kHpStride];
@@ -1082,53 +1088,52 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     // ---------------- issue phase ----------------
     BFrag<H2 / kKSB> bfrag;
     bfrag.load(J.net + J.m.W2() + (size_t)(kq * (H2 / kKSB)) * H1 + n0 + (lane & 15), H1);
+    // Row loads are UNCONDITIONAL (R is clamped to a valid row; a wave without a row never uses them): behind `if (live)` the compiler
+    // zero-fills the registers, loads under a branch and — where the two versions merge — WAITS for the loads in the middle of the issue phase.
     RowReg<H2> z, za, zb;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) z.v[i] = za.v[i] = zb.v[i] = 0.0f;
     float lab0 = 0.f, lab1 = 0.f, tgt[4] = {0.f, 0.f, 0.f, 0.f};
     RowReg<H1> cdh, cz;
     float cst0 = 0.f, cst1 = 0.f, cs1 = 0.f, cs2 = 0.f;
-    if (live) z.load(J.ws.z2 + R * H2);
+    z.load(J.ws.z2 + R * H2);
     Img pv0, pv1, pv2;
     pv0.fetch(J.net, J.m, tid);
-    float bonus = 0.f, dgiv[GRP == 3 ? 8 : 1] = {};
+    float bonus = 0.f, bonus_scale = 0.f, dgiv[GRP == 3 ? 8 : 1] = {};
     if (GRP == 0) {
-        if (live) {
-            za.load(J.t1.ws.z2 + R * H2);
-            zb.load(J.t2.ws.z2 + R * H2);
-            const float* row = src_row(J.src, r0 + wave);
-            lab0 = row[30];
-            lab1 = row[31];
-        }
+        za.load(J.t1.ws.z2 + R * H2);
+        zb.load(J.t2.ws.z2 + R * H2);
+        const float* row = src_row(J.src, (int)R);
+        lab0 = row[30];
+        lab1 = row[31];
         pv1.fetch(J.t1.net, J.t1.m, tid);
         pv2.fetch(J.t2.net, J.t2.m, tid);
-        if (live && J.bonus) bonus = J.bonus[R] * (*J.bonus_scale);  // SAC: + alpha * entropy(s')  SAC/agent.py:205-206
+        if (J.bonus) {  // SAC: + alpha * entropy(s')  SAC/agent.py:205-206 (multiplied where it is used: no wait here)
+            bonus = J.bonus[R];
+            bonus_scale = J.bonus_scale[threadIdx.x & 0];
+        }
     }
-    if (GRP == 3 && live) {
+    if (GRP == 3) {
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) dgiv[jj] = jj < J.m.out ? J.ws.dout[R * OW + jj] : 0.0f;
+        for (int jj = 0; jj < 8; ++jj) dgiv[jj] = J.ws.dout[R * OW + jj];  // (the row pitch is 8: all in bounds; masked below)
     }
     if (GRP == 1) {
-        if (live && J.soft.net) za.load(J.soft.ws.z2 + R * H2);  // same net as J.net: shares the LDS image
+        if (J.soft.net) za.load(J.soft.ws.z2 + R * H2);  // same net as J.net: shares the LDS image
     }
     float c1v[2] = {0.f, 0.f};
     if (GRP == 2) {
         if (J.mode == BM_ACTOR_PI) {
             const Head& C = J.crit;
-            if (live) {
-                cdh.load(C.ws.dh1 + R * H1);
-                cz.load(C.ws.z1 + R * H1);
-                cst0 = C.ws.st1[R * 2];
-                cst1 = C.ws.st1[R * 2 + 1];
-                const float* lp = C.ws.lnp + R * (2 * kColWgB);
-                cs1 = lnp_sum(lp) * (1.0f / H1);
-                cs2 = lnp_sum(lp + 1) * (1.0f / H1);
-            }
+            cdh.load(C.ws.dh1 + R * H1);
+            cz.load(C.ws.z1 + R * H1);
+            cst0 = C.ws.st1[R * 2];
+            cst1 = C.ws.st1[R * 2 + 1];
+            const float* lp = C.ws.lnp + R * (2 * kColWgB);
+            cs1 = lnp_sum(lp) * (1.0f / H1);
+            cs2 = lnp_sum(lp + 1) * (1.0f / H1);
             // g1 | be1 (512 floats) by threads 0..511; W1[k][13..16] (1024 floats) one per thread
             if (tid < 2 * H1) c1v[0] = C.net[C.m.g1() + tid];
             c1v[1] = C.net[C.m.W1() + (tid >> 2) * C.m.in + 13 + (tid & 3)];
-        } else if (live) {
-            const float* row = src_row(J.src, r0 + wave);
+        } else {
+            const float* row = src_row(J.src, (int)R);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) tgt[jj] = row[13 + jj];
         }
@@ -1143,7 +1148,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = 4 * g + q;
-            if (row < nrow) ez1[q] = J.ws.z1[(size_t)(r0 + row) * H1 + n0 + r];
+            ez1[q] = J.ws.z1[(size_t)(r0 + (row < nrow ? row : 0)) * H1 + n0 + r];  // unconditional, clamped (rows >= nrow are never stored)
         }
     }
     const float st1v = tid < nrow * 2 ? J.ws.st1[(size_t)r0 * 2 + tid] : (tid & 1 ? 1.0f : 0.0f);
@@ -1172,24 +1177,24 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
         zero.store_lds(drow);
     } else {
         RowReg<H2> xh, y;
-        float mean, rstd, o[IMG];
-        head_regs<IMG, IMG, RELU>(z, hps, J.m.out, slope, xh, y, mean, rstd, o, J.m.no_ln);
-        float dout[IMG] = {};
-        if (GRP == 3) {  // head gradient supplied by a previous kernel (SAC: min-selected critics, sampled policy)
+        float mean, rstd, o[OUTW];
+        head_regs<OUTW, IMG, RELU>(z, hps, NOUT ? NOUT : J.m.out, slope, xh, y, mean, rstd, o, J.m.no_ln);
+        float dout[OUTW] = {};
+        if constexpr (GRP == 3) {  // head gradient supplied by a previous kernel (SAC: min-selected critics, sampled policy)
 #pragma unroll
-            for (int jj = 0; jj < IMG; ++jj) dout[jj] = dgiv[jj < (GRP == 3 ? 8 : 1) ? jj : 0];
-        } else if (GRP == 0) {
+            for (int jj = 0; jj < OUTW; ++jj) dout[jj] = dgiv[jj < (GRP == 3 ? 8 : 1) ? jj : 0];
+        } else if constexpr (GRP == 0) {
             RowReg<H2> xa, ya;
             float m1, s1, q1[1], q2[1];
             head_regs<1, IMG, RELU>(za, hps + kHpStride, 1, slope, xa, ya, m1, s1, q1, J.t1.m.no_ln);
             head_regs<1, IMG, RELU>(zb, hps + 2 * kHpStride, 1, slope, xa, ya, m1, s1, q2, J.t2.m.no_ln);
             // HIRL.py:270-274; with `bonus` SAC's r + (1 - d) gamma (min Q' + alpha H')  SAC/agent.py:202-210
-            const float target = J.bonus ? lab0 + (1.0f - lab1) * (J.gamma * (fminf(q1[0], q2[0]) + bonus))
+            const float target = J.bonus ? lab0 + (1.0f - lab1) * (J.gamma * (fminf(q1[0], q2[0]) + bonus * bonus_scale))
                                          : lab0 + (J.gamma * fminf(q1[0], q2[0])) * (1.0f - lab1);
             const float diff = o[0] - target;
             dout[0] = 2.0f * diff * A.inv_batch;  // d mse / dq
             part[0] += diff * diff * A.inv_batch;
-        } else if (GRP == 1) {
+        } else if constexpr (GRP == 1) {
             dout[0] = -A.inv_batch;            // rl_loss = -mean(Q1(s, pi(s)))  HIRL.py:297
             part[3] += -o[0] * A.inv_batch;
             if (J.soft.net) {
@@ -1232,11 +1237,21 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
         g.load(hps);
 #pragma unroll
         for (int i = 0; i < 8; ++i) dx.v[i] = 0.0f;
-        for (int jj = 0; jj < J.m.out; ++jj) {
-            RowReg<H2> w;
-            w.load(hps + (2 + jj) * H2);
+        if (NOUT) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) dx.v[i] += dout[jj] * w.v[i];
+            for (int jj = 0; jj < OUTW; ++jj) {
+                RowReg<H2> w;
+                w.load(hps + (2 + jj) * H2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dx.v[i] += dout[jj] * w.v[i];
+            }
+        } else {
+            for (int jj = 0; jj < J.m.out; ++jj) {
+                RowReg<H2> w;
+                w.load(hps + (2 + jj) * H2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dx.v[i] += dout[jj] * w.v[i];
+            }
         }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1258,8 +1273,8 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
                 J.ws.st2[R * 2 + 1] = rstd;
             }
             if (GRP != 3 && lane < 4) {
-                J.ws.dout[R * OW + lane] = dout[lane < IMG ? lane : 0];
-                if (J.mode != BM_ACTOR_PI) J.ws.outv[R * OW + lane] = (J.m.out == 4) ? tanhf(o[lane < IMG ? lane : 0]) : o[lane < IMG ? lane : 0];
+                J.ws.dout[R * OW + lane] = dout[lane < OUTW ? lane : 0];
+                if (J.mode != BM_ACTOR_PI) J.ws.outv[R * OW + lane] = (J.m.out == 4) ? tanhf(o[lane < OUTW ? lane : 0]) : o[lane < OUTW ? lane : 0];
             }
         }
     }
