@@ -1568,13 +1568,13 @@ struct WgArgsC {
 // p/m/v/t are this element's values requested at kernel entry (their latency hides under the gradient's own operand loads).
 struct AdamElem {
     float p, m, v, t;
-    __device__ __forceinline__ void fetch(const WgJob& J, int idx) {
+    __device__ __forceinline__ void fetch(const WgJob& J, unsigned idx) {
         p = J.p[idx];
         m = J.mom[idx];
         v = J.var[idx];
         t = J.target ? J.target[idx] : 0.0f;
     }
-    __device__ __forceinline__ void apply(const WgJob& J, const WgAdam& a, int idx, float g) {
+    __device__ __forceinline__ void apply(const WgJob& J, const WgAdam& a, unsigned idx, float g) {
         adam_update(p, m, v, g, a.b1, a.b2, a.eps, a.step_size, a.bc2_sqrt);
         J.p[idx] = p;
         J.mom[idx] = m;
@@ -1670,20 +1670,21 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         #pragma unroll
         for (int s = 0; s < 2; ++s) if (s < J.nslots) {  // compile-time slot index: J lives in registers, not in scratch
             const float sc = scale[s];
-            const float* dz = J.ws[s].dz2 + n0 + r;
-            const float* h1 = J.ws[s].h1 + k0 + r;
+            const float* dz = J.ws[s].dz2;  // uniform bases + 32-bit lane offsets: no 64-bit address arithmetic per load
+            const float* h1 = J.ws[s].h1;
+            const unsigned dzo = (unsigned)(n0 + r), h1o = (unsigned)(k0 + r);
             const int rows = J.rows[s];
             for (int c0 = 0; c0 < rows; c0 += 128) {
                 float av[32], hv[32];
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
                     const int row = c0 + 4 * i + g;  // MFMA i reduces over rows c0+4i .. c0+4i+3 (one per lane group)
-                    const bool ok = row < rows;
-                    av[i] = ok ? dz[(size_t)row * H2] : 0.0f;
-                    hv[i] = ok ? h1[(size_t)row * H1] : 0.0f;
+                    const unsigned rc = (unsigned)(row < rows ? row : rows - 1);  // unconditional loads (clamped); rows past the end get scale 0
+                    av[i] = dz[rc * (unsigned)H2 + dzo];
+                    hv[i] = h1[rc * (unsigned)H1 + h1o];
                 }
 #pragma unroll
-                for (int i = 0; i < 32; ++i) acc = mfma16(av[i] * sc, hv[i], acc);
+                for (int i = 0; i < 32; ++i) acc = mfma16(av[i] * (c0 + 4 * i + g < rows ? sc : 0.0f), hv[i], acc);
             }
         }
         STAMP();
@@ -1696,7 +1697,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         }
         float* out = J.grad + J.m.W2();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) out[(size_t)(n0 + 4 * g + q) * H1 + k0 + r] = acc[q];
+        for (int q = 0; q < 4; ++q) out[(unsigned)((n0 + 4 * g + q) * H1 + k0 + r)] = acc[q];
         if (ADAM) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1741,9 +1742,9 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int r = rg + kWgRG * i;
-                    const bool ok = r < nr;
-                    zv[i] = ok ? S.z2[(size_t)(c0 + r) * H2 + n] : 0.0f;
-                    dv[i] = ok ? S.dz2[(size_t)(c0 + r) * H2 + n] : 0.0f;
+                    const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H2 + (unsigned)n;  // unconditional, clamped
+                    zv[i] = S.z2[o];
+                    dv[i] = S.dz2[o];
                 }
                 __syncthreads();
                 for (int e = tid; e < nr; e += kWide) {
@@ -1760,16 +1761,23 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const int r = rb + kWgRG * i;
-                            const bool ok = r < nr;
-                            zv[i] = ok ? S.z2[(size_t)(c0 + r) * H2 + n] : 0.0f;
-                            dv[i] = ok ? S.dz2[(size_t)(c0 + r) * H2 + n] : 0.0f;
+                            const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H2 + (unsigned)n;
+                            zv[i] = S.z2[o];
+                            dv[i] = S.dz2[o];
                         }
                     }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int r = rb + kWgRG * i;
                         if (r < nr) {
-                            const float* ri = rinfo + r * RP;
+                            // the row's scalars in three 16-byte LDS reads (same address in every lane: broadcast)
+                            float ri[RP];
+                            {
+                                const float4* r4 = reinterpret_cast<const float4*>(rinfo + r * RP);
+                                const float4 a = r4[0], b4 = r4[1], c4 = r4[2];
+                                ri[0] = a.x; ri[1] = a.y; ri[2] = a.z; ri[3] = a.w; ri[4] = b4.x; ri[5] = b4.y; ri[6] = b4.z; ri[7] = b4.w;
+                                ri[8] = c4.x; ri[9] = c4.y; ri[10] = c4.z; ri[11] = c4.w;
+                            }
                             const float xh = (zv[i] - ri[0]) * ri[1];
                             const float y = g2 * xh + be2;
                             float dh2 = (ri[2] * w3[0] + ri[3] * w3[1]) + (ri[4] * w3[2] + ri[5] * w3[3]);
@@ -1782,7 +1790,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
 #pragma unroll
                             for (int jj = 0; jj < OW; ++jj) dw3[jj] += sc * ri[2 + jj] * h2;
                             // db3[j] = sum_r dout[r][j]: lanes 0..out-1 of the first column block, over this row group's rows
-                            if (vb == 0 && lane < J.m.out) db3 += sc * ri[2 + lane];
+                            if (vb == 0 && lane < J.m.out) db3 += sc * rinfo[r * RP + 2 + lane];
                         }
                     }
                 }
@@ -1837,9 +1845,9 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int r = rg + kWgRG * i;
-                    const bool ok = r < nr;
-                    zv[i] = ok ? S.z1[(size_t)(c0 + r) * H1 + k] : 0.0f;
-                    dv[i] = ok ? S.dh1[(size_t)(c0 + r) * H1 + k] : 0.0f;
+                    const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H1 + (unsigned)k;  // unconditional, clamped
+                    zv[i] = S.z1[o];
+                    dv[i] = S.dh1[o];
                 }
                 __syncthreads();
                 for (int e = tid; e < nr * XP; e += kWide) xs[e] = S.x[(size_t)c0 * XP + e];
@@ -1856,25 +1864,30 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const int r = rb + kWgRG * i;
-                            const bool ok = r < nr;
-                            zv[i] = ok ? S.z1[(size_t)(c0 + r) * H1 + k] : 0.0f;
-                            dv[i] = ok ? S.dh1[(size_t)(c0 + r) * H1 + k] : 0.0f;
+                            const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H1 + (unsigned)k;
+                            zv[i] = S.z1[o];
+                            dv[i] = S.dh1[o];
                         }
                     }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int r = rb + kWgRG * i;
                         if (r < nr) {
-                            const float* ri = rinfo + r * 8;
-                            const float xh = (zv[i] - ri[0]) * ri[1];
+                            const float4 ri = *reinterpret_cast<const float4*>(rinfo + r * 8);  // mean, rstd, the two LN1-backward row means
+                            const float xh = (zv[i] - ri.x) * ri.y;
                             const float dy = act_bwd<RELU>(dv[i], g1 * xh + be1, slope);
-                            const float dz = sc * (ri[1] * (dy * g1 - ri[2] - xh * ri[3]));
+                            const float dz = sc * (ri.y * (dy * g1 - ri.z - xh * ri.w));
                             db1 += dz;
                             dbe += sc * dy;
                             dg += sc * dy * xh;
-                            const float* xr = xs + r * XP;
+                            // the input row in five 16-byte LDS reads (one address for the whole wave: broadcast), not seventeen 4-byte ones
+                            const float4* xr4 = reinterpret_cast<const float4*>(xs + r * XP);
 #pragma unroll
-                            for (int ii = 0; ii < 17; ++ii) dw1[ii] += dz * xr[ii];
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 x4 = xr4[q];
+                                dw1[4 * q] += dz * x4.x; dw1[4 * q + 1] += dz * x4.y; dw1[4 * q + 2] += dz * x4.z; dw1[4 * q + 3] += dz * x4.w;
+                            }
+                            dw1[16] += dz * xs[r * XP + 16];
                         }
                     }
                 }
