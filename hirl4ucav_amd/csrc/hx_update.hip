@@ -587,11 +587,13 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     const int w2w = colb * ACT_LDW + piece * 4;
 #define ACT_LOAD(ra, rb, c) { ra = *reinterpret_cast<const float4*>(w2g + (c) * ACT_KC); rb = *reinterpret_cast<const float4*>(w2g + (size_t)256 * H1 + (c) * ACT_KC); }
 #define ACT_STORE(buf, ra, rb) { *reinterpret_cast<float4*>((buf) + w2w) = ra; *reinterpret_cast<float4*>((buf) + w2w + 256 * ACT_LDW) = rb; }
-    float4 e0, e1, o0, o1;  // even / odd register sets
+    // four register sets: chunk c travels in set c % 4 and is requested FOUR multiply phases before it is stored to LDS — with two sets
+    // (64 KB in flight per CU) the loop ran at the L2 round trip, not at the MFMA rate
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     uint4 bq[BF16 ? 2 : 1][BF16 ? 8 : 1];  // BF16: B fragments of this wave's two column tiles, all of K (requested below)
     if constexpr (!BF16) {
-        ACT_LOAD(e0, e1, 0);
-        ACT_LOAD(o0, o1, 1);
+        ACT_LOAD(ra0, rb0, 0);
+        ACT_LOAD(ra1, rb1, 1);
     }
     // head parameters (g2, be2, W3, b3): requested now, parked in 4-8 registers, laid out in LDS once h1 is dead
     typedef HeadImage<GAUSS ? 8 : 4> Img;
@@ -608,6 +610,10 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < H1 * 13 / 4) wv = reinterpret_cast<const float4*>(net + m.W1())[tid];
     const float bias1 = net[m.b1() + u], g1v = net[m.g1() + u], be1v = net[m.be1() + u];
+    if constexpr (!BF16) {  // behind the prologue's own operands
+        ACT_LOAD(ra2, rb2, 2);
+        ACT_LOAD(ra3, rb3, 3);
+    }
     if (tid < H1 * 13 / 4) reinterpret_cast<float4*>(w1s)[tid] = wv;
     if (tid < ROWS * XP) xs[tid] = 0.0f;
     __syncthreads();
@@ -671,8 +677,8 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             else h1s[row * LDA1 + u] = hv;
         }
     if (!BF16) {
-        ACT_STORE(wb0, e0, e1);
-        ACT_LOAD(e0, e1, 2);
+        ACT_STORE(wb0, ra0, rb0);
+        ACT_LOAD(ra0, rb0, 4);
     }
     __syncthreads();
     STAMP();
@@ -706,18 +712,26 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
                 acc[t][0] = mfma16(a4[t].y, p4.y, acc[t][0]); acc[t][1] = mfma16(a4[t].y, q4.y, acc[t][1]); \
                 acc[t][0] = mfma16(a4[t].z, p4.z, acc[t][0]); acc[t][1] = mfma16(a4[t].z, q4.z, acc[t][1]); \
                 acc[t][0] = mfma16(a4[t].w, p4.w, acc[t][0]); acc[t][1] = mfma16(a4[t].w, q4.w, acc[t][1]); } }
-        for (int c = 0; c < (BF16 ? 0 : ACT_NCH); c += 2) {
-            // even chunk c is in wb0; the odd set holds chunk c+1, the even set chunk c+2 (in flight)
-            ACT_STORE(wb1, o0, o1);
-            if (c + 3 < ACT_NCH) ACT_LOAD(o0, o1, c + 3);
+        static_assert(ACT_NCH % 4 == 0, "the chunk loop is unrolled by the four register sets");
+        for (int c = 0; c < (BF16 ? 0 : ACT_NCH); c += 4) {
+            // chunk c is in wb0; set 1 holds chunk c+1, sets 2, 3, 0 hold c+2, c+3, c+4 (in flight)
+            ACT_STORE(wb1, ra1, rb1);
+            if (c + 5 < ACT_NCH) ACT_LOAD(ra1, rb1, c + 5);
             ACT_MUL(wb0, c);
             __syncthreads();
-            // odd chunk c+1 is in wb1
-            if (c + 2 < ACT_NCH) {
-                ACT_STORE(wb0, e0, e1);
-                if (c + 4 < ACT_NCH) ACT_LOAD(e0, e1, c + 4);
-            }
+            ACT_STORE(wb0, ra2, rb2);
+            if (c + 6 < ACT_NCH) ACT_LOAD(ra2, rb2, c + 6);
             ACT_MUL(wb1, c + 1);
+            __syncthreads();
+            ACT_STORE(wb1, ra3, rb3);
+            if (c + 7 < ACT_NCH) ACT_LOAD(ra3, rb3, c + 7);
+            ACT_MUL(wb0, c + 2);
+            __syncthreads();
+            if (c + 4 < ACT_NCH) {
+                ACT_STORE(wb0, ra0, rb0);
+                if (c + 8 < ACT_NCH) ACT_LOAD(ra0, rb0, c + 8);
+            }
+            ACT_MUL(wb1, c + 3);
             __syncthreads();
         }
 #undef ACT_MUL
