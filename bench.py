@@ -64,6 +64,8 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="total budget of the CPU baseline legs")
     p.add_argument("--no-sweep", action="store_true", help="skip the env-step kernel sweep over 4k..4M envs per launch (< 1 s)")
+    p.add_argument("--sample-launch", action="store_true",
+                   help="draw the minibatch with a launch of its own (hx_sample_batch) instead of inside learn()'s first launch (A/B of the fused draw)")
     p.add_argument("--sweep", action="store_true", help="(default) kept for older command lines")
     p.add_argument("--actions", default="policy", choices=["policy", "uniform"],
                    help="uniform: U(-1,1)^4 actions instead of the live actor (SURVEY.md 8d C2's second run, decoupled from the policy)")
@@ -249,7 +251,8 @@ class Loop:
             e.sample(self.replay, seed=2 + self.rank)
             e.learn()
             return
-        e.sample(self.replay, self.expert, self.bc_table, n_main=e.batch - self.expert_num, seed=2 + self.rank)
+        # the draw and the gather ride in the first launch of learn() (hx_hirl_learn_sampled): same minibatch, one launch less
+        e.sample(self.replay, self.expert, self.bc_table, n_main=e.batch - self.expert_num, seed=2 + self.rank, defer=not (self.args.sample_launch or self.args.overlap))  # --overlap: the next env step may run beside learn(): draw first
         # a critic-only learn() leaves the acting network alone: the next act + env.step go out on the side stream now
         self.pipe.arm(act_env, acting_net_untouched=not e.actor_trainable)
         # soft weight: estimated at the start of every max_step-long "episode" of vector steps, kept in between

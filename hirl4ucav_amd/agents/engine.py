@@ -22,6 +22,13 @@ class HxBatch(ctypes.Structure):
     _fields_ = [("rows", _vp), ("bc_rows", _vp), ("batch", _i32), ("noise", _vp)]
 
 
+class HxSample(ctypes.Structure):
+    """the minibatch draw as a description (include/hirl4ucav.h HxSample): launch A of the update draws and gathers"""
+    _fields_ = [("total", _vp), ("cap", ctypes.c_int64), ("ring", _vp), ("expert_ring", _vp), ("expert_len", ctypes.c_int64),
+                ("bc_table", _vp), ("bc_len", ctypes.c_int64), ("n_main", _i32), ("seed", ctypes.c_uint64), ("call", ctypes.c_uint32),
+                ("sigma", _f32), ("idx", _vp), ("idx_bc", _vp)]
+
+
 class HxNets(ctypes.Structure):
     _fields_ = [(k, _vp) for k in ("actor", "critic", "target_actor", "target_critic", "bc_actor", "grad_actor", "grad_critic",
                                    "m_actor", "v_actor", "m_critic", "v_critic", "losses", "soft_count", "wstate", "ws", "actor_w2_bf16")]
@@ -137,6 +144,8 @@ class OneShotExchange:
         self._own = ()
 _lib.register("hx_bc_train_actor", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _vp])
 _lib.register("hx_hirl_learn", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp])
+_lib.register("hx_hirl_learn_sampled", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp])
+_lib.register("hx_hirl_critic_grads_sampled", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _i32, _vp])
 _lib.register("hx_sample_batch", [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _i32, _i32, _i32, ctypes.c_uint64,
                                    ctypes.c_uint32, _f32, _vp, _vp, _vp, _vp, _vp, _vp])
 
@@ -210,6 +219,7 @@ class HirlEngine:
         self.losses, self.wstate, self._noise = self.losses[:8], self.wstate[:1], self._noise[:4]
         self.soft_count = self.soft_count[:1]
         self.sample_calls = 0
+        self._pending = None  # a draw sample(defer=True) recorded for the next learn()
         self.nets = HxNets(*(t.data_ptr() for t in (self.actor, self.critic, self.target_actor, self.target_critic, self.bc_actor,
                                                      self.grad_actor, self.grad_critic, self.m_actor, self.v_actor, self.m_critic,
                                                      self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None)
@@ -338,11 +348,22 @@ class HirlEngine:
                   idx.data_ptr(), _lib.ptr(idx_bc), None, self.rows.data_ptr(), self.bc_rows.data_ptr() if bc_table is not None else None,
                   _lib.stream_ptr())
 
-    def sample(self, replay, expert=None, bc_table=None, n_main=None, seed=0, sigma=0.2):
+    def sample(self, replay, expert=None, bc_table=None, n_main=None, seed=0, sigma=0.2, defer=False):
         """Draw AND gather the next minibatch on the device (no host sync): UniformMemory.sample (buffer.py:38-48), the
-        buffer/expert mix and np.random.choice of HIRL.py:223-251, torch.normal(0, 0.2) of HIRL.py:265."""
+        buffer/expert mix and np.random.choice of HIRL.py:223-251, torch.normal(0, 0.2) of HIRL.py:265.
+        defer=True: nothing is launched now — the next learn() draws and gathers inside its first launch (hx_hirl_learn_sampled:
+        the same indices, noise, tiles and update bit for bit, one launch less); the returned tensors are filled by that learn()."""
         B = self.batch
         self.sample_calls += 1
+        if defer:
+            # (the tensors are referenced by the record: they must outlive the launch)
+            self._pending = (HxSample(replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(),
+                                      expert.ring.data_ptr() if expert is not None else None, len_of(expert), _lib.ptr(bc_table),
+                                      bc_table.shape[0] if bc_table is not None else 0, B if n_main is None else int(n_main), int(seed),
+                                      self.sample_calls, float(sigma), self._idx.data_ptr(),
+                                      self._idx_bc.data_ptr() if bc_table is not None else None), replay, expert, bc_table)
+            return self._idx, self._idx_bc, self._noise
+        self._pending = None
         _lib.call("hx_sample_batch", replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(),
                   expert.ring.data_ptr() if expert is not None else None, len_of(expert), _lib.ptr(bc_table),
                   bc_table.shape[0] if bc_table is not None else 0, B, B if n_main is None else int(n_main), 1, int(seed),
@@ -358,8 +379,12 @@ class HirlEngine:
         (utils/pipeline.py releases its side stream there)."""
         B = self.batch
         st = _lib.stream_ptr()
+        pending, self._pending = self._pending, None
+        if pending is not None and noise is not None:
+            raise _lib.HxError("learn(noise=...) after sample(defer=True): the deferred draw produces the smoothing noise itself")
         noise = self._noise if noise is None else noise
         batch = HxBatch(self.rows.data_ptr(), self.bc_rows.data_ptr() if self.use_bc else None, B, noise.data_ptr())
+        smp = ctypes.byref(pending[0]) if pending is not None else None
         nets, hyper = ctypes.byref(self.nets), ctypes.byref(self.hyper)
         if bc_weight_now is None:
             w_kind, w_given = 2, 0.0
@@ -374,14 +399,17 @@ class HirlEngine:
             self.update_count += 1
         do_polyak = actor_phase and self.update_count % self.target_update_freq == 0  # HIRL.py:327-330
         if not self.staged:
-            _lib.call("hx_hirl_learn", nets, ctypes.byref(batch), hyper, self.critic_step, int(actor_phase), self.actor_step,
+            _lib.call("hx_hirl_learn_sampled", nets, ctypes.byref(batch), hyper, smp, self.critic_step, int(actor_phase), self.actor_step,
                       int(do_polyak), w_kind, w_given, float(bc_warm_up_weight), st)
         else:  # sharded: the same stages with the exchanges of SURVEY.md 8e in between — ONE message per phase
             gs = 1.0 / self.world
             own_critic = self.grad_critic.data_ptr()
             if self.xchg is not None:  # peers read this rank's gradient straight out of its message buffer: wgrad writes there
                 self.nets.grad_critic = self.xchg.write_buffer("critic").data_ptr()
-            _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, (2 if w_kind == 1 else 1) if actor_phase else 0, st)
+            if smp is not None:
+                _lib.call("hx_hirl_critic_grads_sampled", nets, ctypes.byref(batch), hyper, smp, (2 if w_kind == 1 else 1) if actor_phase else 0, st)
+            else:
+                _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, (2 if w_kind == 1 else 1) if actor_phase else 0, st)
             if before_exchange is not None:
                 before_exchange()
             summed = self._allreduce(self.grad_critic, "critic")

@@ -21,6 +21,7 @@
 //            buffer with the parameter layout (one all-reduce message per phase when sharded);
 //   adam / polyak  elementwise over the flat buffers, 16 B per lane.
 #include <cstdlib>
+#include <type_traits>
 
 #include "hx_common.h"
 #include "hx_nn.h"
@@ -164,6 +165,83 @@ __device__ __forceinline__ void head_row(const float* __restrict__ z2row, const 
     }
 }
 
+// ---- counter-based RNG shared by the acting / sampling kernels ------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t u) { return ((float)(u >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// ---- the minibatch draw inside launch A (HxSample, hx_hirl_learn_sampled) --------------------------------------------------------
+// What sample_kernel computes for batch <= 512 — the two index streams side by side, "without replacement" by the hash set in LDS
+// (key = group | index, owner = lowest row that drew it), the redraw rounds, Philox4x32-10(seed; row, call, stream, round) — repeated by
+// EVERY workgroup of the launch (a few hundred instructions and three barriers, under the workgroup's own W1 / W2 requests); the set is
+// smaller (batch <= 256 -> 1,024 slots), which changes no result: a key's owner does not depend on where the table keeps it.
+struct SampleDev {
+    const unsigned long long* total;
+    const float* ring; const float* expert_ring; const float* bc_table;
+    float* rows; float* bc_rows; float* noise; int* idx; int* idx_bc;
+    long long cap;
+    uint32_t expert_len, bc_len;
+    int32_t n_main;
+    uint32_t call;
+    uint64_t seed;
+    float sigma;
+};
+constexpr int kFusedSlots = 1024, kFusedBatchMax = 256;
+__device__ __forceinline__ uint32_t fused_hash(uint32_t k) { return (k * 2654435761u) >> 22; }  // top 10 bits
+
+__device__ __forceinline__ void draw_fused(const SampleDev& S, int B, uint32_t (*hkey)[kFusedSlots], int (*hown)[kFusedSlots], int (*fin)[kFusedBatchMax]) {
+    const int tid = threadIdx.x;
+    const int t = tid & 511, stream = tid >> 9;  // 0: replay / expert rows, 1: BC rows
+    const unsigned long long tot = *S.total;
+    const uint32_t len_main = (uint32_t)(tot < (unsigned long long)S.cap ? tot : (unsigned long long)S.cap);
+    const uint32_t k0 = (uint32_t)S.seed, k1 = (uint32_t)(S.seed >> 32);
+    const bool live = (stream == 0 || S.idx_bc != nullptr) && t < B;
+    const bool main_grp = t < S.n_main;
+    const uint32_t len = stream == 1 ? S.bc_len : (main_grp ? len_main : S.expert_len);
+    const uint32_t grp = (stream == 1 || main_grp) ? 0u : 0x80000000u;  // groups: [0, n_main) and [n_main, batch)
+    uint32_t* keys = hkey[stream];
+    int* owns = hown[stream];
+    for (int e = t; e < kFusedSlots; e += 512) {
+        keys[e] = 0xFFFFFFFFu;
+        owns[e] = 0x7FFFFFFF;
+    }
+    __syncthreads();
+    uint32_t key = 0;
+    bool dup = live;
+    for (int round = 0; round < 128; ++round) {
+        if (dup) {
+            uint32_t u[4];
+            philox4x32_10((uint32_t)t, S.call, (uint32_t)stream, (uint32_t)round, k0, k1, u);
+            key = grp | (len ? __umulhi(u[0], len) : 0u);
+            uint32_t h = fused_hash(key);
+            for (int probe = 0; probe < kFusedSlots; ++probe) {
+                const uint32_t k = atomicCAS(&keys[h], 0xFFFFFFFFu, key);
+                if (k == 0xFFFFFFFFu || k == key) break;
+                h = (h + 1) & (kFusedSlots - 1);
+            }
+            atomicMin(&owns[h], t);
+        }
+        __syncthreads();
+        if (live) {
+            uint32_t h = fused_hash(key);
+            for (int probe = 0; probe < kFusedSlots && keys[h] != key; ++probe) h = (h + 1) & (kFusedSlots - 1);
+            dup = owns[h] != t;
+        }
+        if (!__syncthreads_or(dup)) break;
+    }
+    if (live) fin[stream][t] = (int)(key & 0x7FFFFFFFu);
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // fwd_l2
 // ---------------------------------------------------------------------------------------------------------------
@@ -189,6 +267,7 @@ struct FwdArgs {
     float* zero_f;
     int zero_nf;
     int* zero_i;
+    const SampleDev* sample;  // launch A of the *_sampled entry points: draw and gather inside this launch
 };
 
 // What the kernel actually receives: 64 bytes per job (ONE s_load_dwordx16), the job picked by blockIdx.y.  A kernel argument
@@ -237,9 +316,16 @@ __device__ __forceinline__ int tiles_of(int rows) { return (rows + RT - 1) / RT;
 //                (then 128-256 workgroups still run in one round and each carries half the MFMA work).
 // NT = 256     : one 16-column tile per wave, full K (throughput mode, thousands of rows: the prologue is recomputed 2x per
 //                row tile instead of 8x or 16x)
-template <int NT, bool RELU>
-__global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A) {
+struct NoSample {};
+// SAMPLE (launch A of hx_hirl_*_sampled, batch <= 256): the minibatch is drawn here (draw_fused) and every workgroup gathers its 16 rows
+// straight from the replay / expert rings; the workgroups of job 0 also leave the row tiles, the indices and the smoothing noise for the
+// later launches.
+template <int NT, bool RELU, bool SAMPLE>
+__global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std::conditional<SAMPLE, SampleDev, NoSample>::type SA) {
     constexpr bool WIDE = NT == 256;
+    __shared__ uint32_t s_hkey[SAMPLE ? 2 : 1][SAMPLE ? kFusedSlots : 1];
+    __shared__ int s_hown[SAMPLE ? 2 : 1][SAMPLE ? kFusedSlots : 1];
+    __shared__ int s_fin[SAMPLE ? 2 : 1][SAMPLE ? kFusedBatchMax : 1];
     constexpr int NTW = NT;
     constexpr int CT = WIDE ? 1 : NT / 16, KS = WIDE ? 1 : 16 / CT;  // column tiles / K-parts per workgroup (latency mode)
     constexpr int KRED = WIDE ? 4 : (KS - 1) * CT * 256;
@@ -278,7 +364,22 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A) {
     const int xr = tid / XP, xc = tid % XP;
     const bool head_mode = in == 17 && J.act_mode != 0 && J.act_mode != 3;
     float xv = 0.0f;
-    if (tid < RT * XP && xr < nrow) {
+    float4 tile_piece = make_float4(0.f, 0.f, 0.f, 0.f);  // SAMPLE: this thread's 16 bytes of the row tile its workgroup publishes
+    if constexpr (SAMPLE) {
+        // the draw needs *total and LDS only; W1, the vectors and the W2 fragment are already on their way
+        draw_fused(SA, J.rows, s_hkey, s_hown, s_fin);
+        if (tid < RT * XP && xr < nrow) {
+            const int r = r0 + xr;
+            const float* row = (r < SA.n_main ? SA.ring : SA.expert_ring) + (size_t)s_fin[0][r] * 32;
+            if (xc < 13) xv = row[J.col0 + xc];
+            else if (in == 17 && xc < 17 && J.act_mode == 0) xv = row[xc];
+        }
+        if (blockIdx.y == 0 && nt < 2 && tid < nrow * 8) {  // column workgroup 0 publishes rows[r0 ..], column workgroup 1 bc_rows[r0 ..]
+            const int r = r0 + (tid >> 3);
+            if (nt == 0) tile_piece = reinterpret_cast<const float4*>((r < SA.n_main ? SA.ring : SA.expert_ring) + (size_t)s_fin[0][r] * 32)[tid & 7];
+            else if (SA.bc_rows) tile_piece = reinterpret_cast<const float4*>(SA.bc_table + (size_t)s_fin[1][r] * 32)[tid & 7];
+        }
+    } else if (tid < RT * XP && xr < nrow) {
         if (xc < 13) xv = src_row(J.src, r0 + xr)[J.col0 + xc];
         else if (in == 17 && xc < 17) {
             if (J.act_mode == 0) xv = src_row(J.src, r0 + xr)[xc];                             // replayed action, row cols 13..16
@@ -409,26 +510,31 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A) {
         STAMP();
         STAMP_FLUSH(0, blockIdx.x == 5 && tid == 0);
     }
+    if constexpr (SAMPLE) {
+        if (blockIdx.y == 0) {  // what hx_sample_batch leaves behind: row tiles, indices, noise — read by the launches after this one
+            if (nt == 0 && tid < nrow * 8) reinterpret_cast<float4*>(SA.rows)[(size_t)r0 * 8 + tid] = tile_piece;
+            if (nt == 1 && SA.bc_rows && tid < nrow * 8) reinterpret_cast<float4*>(SA.bc_rows)[(size_t)r0 * 8 + tid] = tile_piece;
+            if (b == 2) {
+                if (tid < J.rows) {
+                    SA.idx[tid] = s_fin[0][tid];
+                    if (SA.idx_bc) SA.idx_bc[tid] = s_fin[1][tid];
+                }
+                if (tid < 4 && SA.noise) {  // the (4,) target-smoothing draw, HIRL.py:265 (sample_kernel's arithmetic)
+                    uint32_t uu[4];
+                    philox4x32_10(0xFFFFFFF0u, SA.call, 2u, 0u, (uint32_t)SA.seed, (uint32_t)(SA.seed >> 32), uu);
+                    const float ua = u01(uu[tid & 2]), ub = u01(uu[(tid & 2) + 1]);
+                    const float rad = sqrtf(-2.0f * __logf(ua)), ang = 6.28318530717958647692f * ub;
+                    SA.noise[tid] = SA.sigma * ((tid & 1) ? rad * __sinf(ang) : rad * __cosf(ang));
+                }
+            }
+        }
+    }
     // accumulators of LATER launches are cleared here, at the end: their kernel-argument words are off every workgroup's critical path
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         if ((int)threadIdx.x < A.zero_nf) A.zero_f[threadIdx.x] = 0.0f;
         if (threadIdx.x == 0 && A.zero_i) *A.zero_i = 0;
     }
 }
-
-// ---- counter-based RNG shared by the acting / sampling kernels ------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-__device__ __forceinline__ float u01(uint32_t u) { return ((float)(u >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 // LDS image of one net's head parameters: g2[512] be2[512] W3[out][512] (padded to OUTMAX rows) b3[out]
 template <int OUTMAX>
@@ -2195,8 +2301,14 @@ void launch_fwd(const FwdArgs& F, hipStream_t st) {
     const int tiles = fwd_row_tiles(F), per_job = tiles / F.njobs;
     const bool relu = F.slope == 0.0f;  // compile-time ReLU instantiations (hx_nn.h act_f)
 #define HX_FWD(NT_) do { const dim3 grid(per_job * (H2 / NT_), F.njobs); \
-        if (relu) hipLaunchKernelGGL((fwd_l2_kernel<NT_, true>), grid, dim3(kWide), 0, st, C); \
-        else hipLaunchKernelGGL((fwd_l2_kernel<NT_, false>), grid, dim3(kWide), 0, st, C); } while (0)
+        if (relu) hipLaunchKernelGGL((fwd_l2_kernel<NT_, true, false>), grid, dim3(kWide), 0, st, C, NoSample{}); \
+        else hipLaunchKernelGGL((fwd_l2_kernel<NT_, false, false>), grid, dim3(kWide), 0, st, C, NoSample{}); } while (0)
+    if (F.sample) {  // (the callers checked: three or four jobs of at most 256 rows -> the 64-column tiling)
+        const dim3 grid(per_job * (H2 / kNT), F.njobs);
+        if (relu) hipLaunchKernelGGL((fwd_l2_kernel<kNT, true, true>), grid, dim3(kWide), 0, st, C, *F.sample);
+        else hipLaunchKernelGGL((fwd_l2_kernel<kNT, false, true>), grid, dim3(kWide), 0, st, C, *F.sample);
+        return;
+    }
     if (tiles >= 128) HX_FWD(256);
     else if (tiles * (H2 / 32) <= 256) HX_FWD(32);  // one or two nets at B = 128: 32-column workgroups still fit the chip in one round
     else HX_FWD(kNT);
@@ -2349,10 +2461,29 @@ static WgAdam make_adam(const HxNets* N, const HxHyper* Hy, float lr, int step, 
 }
 
 // adam_step > 0: the critic's optimizer step (and, with polyak, the soft_update of its target) rides in the wgrad launch
-static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, void* stream, int adam_step, bool polyak) {
+static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, void* stream, int adam_step, bool polyak,
+                             const HxSample* S = nullptr) {
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_critic_grads: batch must be a positive multiple of 16");
     hipStream_t st = (hipStream_t)stream;
     const int B = Bt->batch;
+    SampleDev SD{};
+    bool fused = false;
+    if (S) {  // the minibatch is drawn by this call: inside launch A (batch <= 256) or by the sampling launch first
+        HX_REQUIRE(S->total && S->cap > 0 && S->ring && S->idx && Bt->rows && Bt->noise && S->n_main >= 0 && S->n_main <= B,
+                   "hx_hirl_*_sampled: the draw needs total, cap, ring, idx and the output tiles rows / noise");
+        HX_REQUIRE(S->n_main == B || S->expert_ring, "hx_hirl_*_sampled: expert rows requested without an expert ring");
+        HX_REQUIRE(!S->bc_table == !S->idx_bc && (!S->bc_table || Bt->bc_rows), "hx_hirl_*_sampled: bc_table, idx_bc and bc_rows go together");
+        fused = B <= kFusedBatchMax;
+        if (fused) {
+            SD = SampleDev{(const unsigned long long*)S->total, S->ring, S->expert_ring ? S->expert_ring : S->ring, S->bc_table,
+                           const_cast<float*>(Bt->rows), S->bc_table ? const_cast<float*>(Bt->bc_rows) : nullptr, const_cast<float*>(Bt->noise),
+                           S->idx, S->idx_bc, (long long)S->cap, (uint32_t)S->expert_len, (uint32_t)S->bc_len, S->n_main, S->call, S->seed, S->sigma};
+        } else if (int rc = hx_sample_batch(S->total, S->cap, S->ring, S->expert_ring, S->expert_len, S->bc_table, S->bc_len, B, S->n_main, 1, S->seed,
+                                            S->call, S->sigma, S->idx, S->idx_bc, const_cast<float*>(Bt->noise), const_cast<float*>(Bt->rows),
+                                            S->bc_table ? const_cast<float*>(Bt->bc_rows) : nullptr, stream)) {
+            return rc;
+        }
+    }
     Slot s[S_COUNT];
     make_slots(N, B, s);
     const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
@@ -2370,6 +2501,7 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
             F.job[3] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1};
             F.njobs = 4;
         }
+        F.sample = fused ? &SD : nullptr;
         launch_fwd(F, st);
     }
     {   // launch B: targetCritic Q1/Q2 (s', clamp(targetActor(s') + clamp(noise)))  [+ actor(s_bc), bc_actor(s)]
@@ -2425,6 +2557,10 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
 }
 int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, void* stream) {
     return critic_grads_impl(N, Bt, Hy, actor_fwd, stream, 0, false);
+}
+int hx_hirl_critic_grads_sampled(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t actor_fwd, void* stream) {
+    HX_REQUIRE(S, "hx_hirl_critic_grads_sampled: null sample description");
+    return critic_grads_impl(N, Bt, Hy, actor_fwd, stream, 0, false, S);
 }
 
 
@@ -2649,8 +2785,13 @@ int hx_hirl_learn(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t
                   int32_t actor_step, int32_t do_polyak, int32_t w_kind, float w_given, float warm, void* stream) {
     // 4 launches on a critic-only call, 8 on an actor call: the two optimizer steps (and the Polyak passes of the calls that move the
     // targets) ride in the wgrad launches, the actor's critic-independent forwards in launches A and B
+    return hx_hirl_learn_sampled(N, Bt, Hy, nullptr, critic_step, actor_phase, actor_step, do_polyak, w_kind, w_given, warm, stream);
+}
+/* The same with the minibatch drawn and gathered inside the first launch (sample == NULL: the tiles of Bt are inputs, as above). */
+int hx_hirl_learn_sampled(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t critic_step, int32_t actor_phase,
+                          int32_t actor_step, int32_t do_polyak, int32_t w_kind, float w_given, float warm, void* stream) {
     HX_REQUIRE(critic_step >= 1 && (!actor_phase || actor_step >= 1), "hx_hirl_learn: Adam steps are 1-based");
-    int rc = critic_grads_impl(N, Bt, Hy, actor_phase ? (w_kind == 1 ? 2 : 1) : 0, stream, critic_step, do_polyak != 0);
+    int rc = critic_grads_impl(N, Bt, Hy, actor_phase ? (w_kind == 1 ? 2 : 1) : 0, stream, critic_step, do_polyak != 0, S);
     if (rc || !actor_phase) return rc;
     if ((rc = hx_hirl_actor_backward(N, Bt, Hy, w_kind == 1, 1, stream))) return rc;
     return actor_wgrad_impl(N, Hy, Bt->batch, Bt->batch, w_kind, w_given, warm, stream, actor_step, do_polyak != 0);

@@ -345,7 +345,7 @@ def main(config):
                     eng.sample(replay, expert if esac else None, n_main=batch - expert_num, seed=seed + 2 + rank)
                     eng.learn()
                     continue
-                eng.sample(replay, expert, bc_table, n_main=batch - expert_num, seed=seed + 2 + rank)
+                eng.sample(replay, expert, bc_table, n_main=batch - expert_num, seed=seed + 2 + rank, defer=True)  # drawn inside learn()'s first launch
                 eng.learn(bc_weight_now=w_now, bc_warm_up_weight=warm)
                 w_now = None  # afterwards learn()'s own returned weight is fed back (train_all.py:361): the stored device value
             if writer is not None and step % log_rate == 0 and not sac:  # Loss/* every 300 steps, train_all.py:362-367

@@ -251,6 +251,27 @@ int hx_sample_batch(const uint64_t* total, int64_t cap, const float* ring, const
                     uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc, float* noise, float* rows, float* bc_rows,
                     void* stream);
 
+/* The draw of hx_sample_batch(do_sample = 1) as a description instead of a launch: hx_hirl_learn_sampled / hx_hirl_critic_grads_sampled
+ * draw the indices and gather the rows inside the FIRST launch of the update (every workgroup repeats the cheap draw, each gathers
+ * its own 16 rows straight from the rings) — the same indices, noise, row tiles and results, bit for bit, as hx_sample_batch followed
+ * by hx_hirl_learn / hx_hirl_critic_grads, with one launch and one kernel boundary less (UniformMemory.sample buffer.py:38-48 + the
+ * minibatch assembly HIRL.py:223-251 + the noise draw HIRL.py:265).  The tiles HxBatch points at (rows, bc_rows, noise) are OUTPUTS
+ * then (the later launches read them); idx / idx_bc receive the drawn indices.  batch <= 256 takes the fused path, larger batches run
+ * the separate sampling launch inside the same call. */
+typedef struct HxSample {
+    const uint64_t* total; int64_t cap; const float* ring;   /* main replay ring (hx_env_step's HxStepOpts.total / cap / ring) */
+    const float* expert_ring; int64_t expert_len;            /* NULL / 0: no expert rows (n_main == batch) */
+    const float* bc_table; int64_t bc_len;                   /* NULL / 0: no BC minibatch (TD3) */
+    int32_t n_main;                                          /* rows [0, n_main) from the main ring, the rest from the expert ring */
+    uint64_t seed; uint32_t call; float sigma;               /* Philox4x32-10(seed; row, call); noise[4] = sigma N(0, 1) */
+    int32_t* idx; int32_t* idx_bc;                           /* [batch] out (idx_bc NULL without a BC table) */
+} HxSample;
+/* hx_hirl_critic_grads / hx_hirl_learn with the minibatch drawn and gathered in their first launch (arguments as theirs + the draw). */
+int hx_hirl_critic_grads_sampled(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, const HxSample* sample, int32_t actor_fwd,
+                                 void* stream);
+int hx_hirl_learn_sampled(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, const HxSample* sample, int32_t critic_step,
+                          int32_t actor_phase, int32_t actor_step, int32_t do_polyak, int32_t w_kind, float w_given, float warm, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------------------
  * SAC (hirl/agents/SAC, the non-imitative branch train_sac.py uses).  Networks are the plain Linear-ReLU stacks of the

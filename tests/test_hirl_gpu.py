@@ -404,6 +404,50 @@ def test_device_sampler(eng_mod):
         np.testing.assert_array_equal(big.rows.reshape(1024, 32).cpu().numpy(), rep.ring.cpu().numpy()[i])
 
 
+@pytest.mark.parametrize("staged", [False, True])
+@pytest.mark.parametrize("use_bc", [True, False])
+def test_deferred_draw_is_bit_identical_to_the_sampling_launch(eng_mod, staged, use_bc):
+    """sample(defer=True) + learn() (hx_hirl_learn_sampled / hx_hirl_critic_grads_sampled: the draw and the gather run inside the first
+    launch of the update) against sample() + learn() (hx_sample_batch, then the update): the same indices, smoothing noise, row tiles,
+    losses and — after 14 calls — the same networks and Adam moments, bit for bit.  The main ring has few live rows at first (many
+    redraw rounds), then wraps; expert rows are mixed in; HIRL (BC minibatch) and TD3 (none)."""
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    params = D.make_params(31)
+    rng = np.random.default_rng(7)
+    rep = DeviceReplay(6000)
+    rep.ring.copy_(torch.from_numpy(rng.normal(size=(6000, 32)).astype(np.float32)))
+    rep.ring[:, 31] = (rep.ring[:, 31] > 1.0).float()   # done flags
+    rep.total += 140                                     # 96 of 140 without replacement: collisions in every round
+    exp = DeviceReplay(64)
+    exp.store_rows(torch.from_numpy(rng.normal(size=(40, 32)).astype(np.float32)))
+    bc = torch.from_numpy(rng.normal(size=(150, 32)).astype(np.float32)).cuda() if use_bc else None
+    engines = []
+    for _ in range(2):
+        e = eng_mod.HirlEngine(batch=128, use_bc=use_bc, slope=0.0 if use_bc else 0.01)
+        e.staged = staged
+        e.load_params(params["actor"], params["critic"], params["bc_actor"] if use_bc else None)
+        engines.append(e)
+    a, b = engines
+    for k in range(14):
+        if k == 7:
+            rep.total += 100000  # wrapped: the whole capacity is live
+        w = (100 if k % 4 == 0 else None) if use_bc else 0.0
+        outs = []
+        for e, defer in ((a, False), (b, True)):
+            idx, idx_bc, noise = e.sample(rep, exp, bc, n_main=96, seed=11, defer=defer)
+            e.learn(bc_weight_now=w, bc_warm_up_weight=0.05)
+            outs.append((idx.clone(), idx_bc.clone(), noise.clone(), e.rows.clone(), e.bc_rows.clone(), e.losses_host()))
+        for x, y, name in zip(outs[0][:5], outs[1][:5], ("idx", "idx_bc", "noise", "rows", "bc_rows")):
+            if use_bc or name not in ("idx_bc", "bc_rows"):
+                assert torch.equal(x, y), (k, name)
+        np.testing.assert_allclose(outs[0][5], outs[1][5], rtol=1e-6, atol=1e-7, err_msg=f"call {k}")  # (loss sums: atomic order)
+        i = outs[1][0].cpu().numpy()
+        assert len(set(i[:96])) == 96 and len(set(i[96:])) == 32 and i[:96].max() < (140 if k < 7 else 6000) and i[96:].max() < 40
+    for name in ("actor", "critic", "target_actor", "target_critic", "m_actor", "v_actor", "m_critic", "v_critic"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
 def test_staged_path_equals_fused_path(eng_mod):
     """The stage-by-stage sequence a sharded run uses (critic_grads -> [all-reduce] -> adam -> actor_backward -> [all-reduce
     count] -> actor_wgrad -> [all-reduce] -> adam -> polyak) and the single-GPU one-call path (actor forwards folded into the
