@@ -1704,17 +1704,20 @@ struct AdamElem {
 };
 
 constexpr int kWgTilesPerBlock = H2 / 16;                // 32 workgroups: 16 (n) x 256 (k) of dW2, one 16 x 16 tile per wave
-constexpr int kWgVecWgs = H2 / 64;                       // 8 workgroups: 64 columns x 16 row groups, 512-wide vector gradients
-constexpr int kWgL1Wgs = H1 / 64;                        // 4 workgroups: layer-1 gradients, 64 units x 16 row groups
-constexpr int kWgRG = kWide / 64;                        // row groups = waves: the batch rows of a column are split 16 ways
+constexpr int kWgCols = 32;                              // columns per vector / layer-1 workgroup (half a wave)
+constexpr int kWgVecWgs = H2 / kWgCols;                  // 16 workgroups: 32 columns x 32 row groups, 512-wide vector gradients
+constexpr int kWgL1Wgs = H1 / kWgCols;                   // 8 workgroups: layer-1 gradients, 32 units x 32 row groups
+constexpr int kWgRG = kWide / kWgCols;                   // row groups = half waves: the batch rows of a column are split 32 ways
 constexpr int kWgPerJob = kWgTilesPerBlock + kWgVecWgs + kWgL1Wgs;
 constexpr int kWgRowChunk = 256;                         // rows whose per-row scalars are staged in LDS at a time
 
-// fixed-order sum of the 16 row groups' partial results of one (column, item): red[group][64][20]
+// fixed-order sum of the 16 row groups' partial results of one (column, item): red[group][64][kRedP]; the odd pitch keeps the 64 lanes of a
+// wave on 64 different banks (pitch 20: 16 banks, every read and write of the reduction four-way conflicted)
+constexpr int kRedP = 21;
 __device__ __forceinline__ float sum_groups(const float* p) {
     float v[kWgRG];
 #pragma unroll
-    for (int g = 0; g < kWgRG; ++g) v[g] = p[g * 64 * 20];
+    for (int g = 0; g < kWgRG; ++g) v[g] = p[g * kWgCols * kRedP];
 #pragma unroll
     for (int w = 1; w < kWgRG; w *= 2)
 #pragma unroll
@@ -1753,10 +1756,10 @@ inline WgJobC pack_wg(const WgJob& J, const WgArgs& A) {
 
 template <bool ADAM, bool RELU>
 __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
-    __shared__ __attribute__((aligned(16))) float lds[kWgRowChunk * XP + kWgRowChunk * 12 + kWgRG * 64 * 20];
+    __shared__ __attribute__((aligned(16))) float lds[kWgRowChunk * XP + kWgRowChunk * 12 + kWgRG * kWgCols * kRedP];
     float* xs = lds;                          // [chunk][XP]   inputs (layer-1 job)
     float* rinfo = lds + kWgRowChunk * XP;    // [chunk][<=12] per-row scalars
-    float* red = rinfo + kWgRowChunk * 12;    // [16][64][20]  cross-row-group reduction
+    float* red = rinfo + kWgRowChunk * 12;    // [16][64][kRedP]  cross-row-group reduction
 
     const int j = blockIdx.y, b = blockIdx.x;
     WgJob J;
@@ -1833,53 +1836,62 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         STAMP_FLUSH(32, blockIdx.x == 0 && blockIdx.y == 0 && tid == 0);
         return;
     }
-    const int rg = wave;  // row group: rows rg, rg + 4, ...
+    // Vector and layer-1 workgroups: 32 columns x 32 row groups (half a wave per row group): four batch rows per thread at B = 128.
+    // (64 columns x 16 row groups put eight rows on every thread: these workgroups, not the MFMA tiles, set the launch's duration.)
+    const int cl = lane & (kWgCols - 1);           // column inside the workgroup
+    const int rg = wave * 2 + (lane >> 5);         // row group: rows rg, rg + 32, ...
+    const int oitem = tid / kWgCols, ocol = tid % kWgCols;  // after the reduction: thread -> (item, column)
     if (b < kWgTilesPerBlock + kWgVecWgs) {
-        // column n: db2, dg2, dbe2, dW3[j][n] (+ db3 by the first workgroup); 64 columns x 16 row groups
+        // column n: db2, dg2, dbe2, dW3[j][n] (+ db3 by the first workgroup)
         constexpr int RP = 12;  // rinfo pitch: mean, rstd, dout[0..7], pad
         const int vb = b - kWgTilesPerBlock;
-        const int n = vb * 64 + lane;
+        const int n = vb * kWgCols + cl;
         const float g2 = J.net[J.m.g2() + n], be2 = J.net[J.m.be2() + n];
         float w3[OW];
 #pragma unroll
         for (int jj = 0; jj < OW; ++jj) w3[jj] = jj < J.m.out ? J.net[J.m.W3() + jj * H2 + n] : 0.0f;
         float db2 = 0.f, dg = 0.f, dbe = 0.f, dw3[OW] = {}, db3 = 0.f;
-        // ADAM: the parameter this wave will step (item = wave) and, for the last wave of the first column block, b3[lane]: requested
-        // now, consumed after the reduction
-        const int vitem = wave;
-        const int vidx = vitem == 0 ? J.m.b2() + n : vitem == 1 ? J.m.g2() + n : vitem == 2 ? J.m.be2() + n : J.m.W3() + (vitem - 3) * H2 + n;
-        AdamElem vae, vae3;
-        if (ADAM && vitem < 3 + J.m.out) vae.fetch(J, vidx);
-        if (ADAM && vb == 0 && wave == kWgRG - 1 && lane < J.m.out) vae3.fetch(J, J.m.b3() + lane);
+        // ADAM: the parameter this thread will step after the reduction (item oitem of column ocol; the last items: b3), requested now
+        const int on = vb * kWgCols + ocol;
+        const unsigned vidx = (unsigned)(oitem == 0 ? J.m.b2() + on : oitem == 1 ? J.m.g2() + on : oitem == 2 ? J.m.be2() + on : J.m.W3() + (oitem - 3) * H2 + on);
+        const bool vlive = oitem < 3 + J.m.out;
+        const bool b3live = vb == 0 && oitem == 3 + OW && ocol < J.m.out;  // (item 3 + OW of the reduction tile carries db3)
+        const unsigned b3idx = (unsigned)(J.m.b3() + (ocol < J.m.out ? ocol : 0));
+        AdamElem vae;
+        if (ADAM && (vlive || b3live)) vae.fetch(J, b3live ? b3idx : vidx);
         #pragma unroll
         for (int s = 0; s < 2; ++s) if (s < J.nslots) {  // compile-time slot index: J lives in registers, not in scratch
             const Slot& S = J.ws[s];
             const float sc = scale[s];
             for (int c0 = 0; c0 < J.rows[s]; c0 += kWgRowChunk) {
                 const int nr = min(kWgRowChunk, J.rows[s] - c0);
-                // this thread's first 8 rows are requested before the per-row scalars are staged: one round trip, not two
-                float zv[8], dv[8];
+                // this thread's first 4 rows are requested before the per-row scalars are staged: one round trip, not two
+                float zv[4], dv[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < 4; ++i) {
                     const int r = rg + kWgRG * i;
                     const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H2 + (unsigned)n;  // unconditional, clamped
                     zv[i] = S.z2[o];
                     dv[i] = S.dz2[o];
                 }
+                // the per-row scalars are requested BEFORE the barrier that frees the LDS tile: one round trip with the loads above
+                static_assert(kWgRowChunk <= kWide, "staging: one row per thread");
+                const int er = tid < nr ? tid : 0;
+                const float2 st2v = *reinterpret_cast<const float2*>(S.st2 + (size_t)(c0 + er) * 2);
+                const float4 d4 = *reinterpret_cast<const float4*>(S.dout + (size_t)(c0 + er) * OW);
+                const float4 d5 = *reinterpret_cast<const float4*>(S.dout + (size_t)(c0 + er) * OW + 4);
                 __syncthreads();
-                for (int e = tid; e < nr; e += kWide) {
-                    rinfo[e * RP] = S.st2[(size_t)(c0 + e) * 2];
-                    rinfo[e * RP + 1] = S.st2[(size_t)(c0 + e) * 2 + 1];
-                    const float4 d4 = *reinterpret_cast<const float4*>(S.dout + (size_t)(c0 + e) * OW);
-                    const float4 d5 = *reinterpret_cast<const float4*>(S.dout + (size_t)(c0 + e) * OW + 4);
-                    rinfo[e * RP + 2] = d4.x; rinfo[e * RP + 3] = d4.y; rinfo[e * RP + 4] = d4.z; rinfo[e * RP + 5] = d4.w;
-                    rinfo[e * RP + 6] = d5.x; rinfo[e * RP + 7] = d5.y; rinfo[e * RP + 8] = d5.z; rinfo[e * RP + 9] = d5.w;
+                if (tid < nr) {
+                    float4* r4 = reinterpret_cast<float4*>(rinfo + tid * RP);
+                    r4[0] = make_float4(st2v.x, st2v.y, d4.x, d4.y);
+                    r4[1] = make_float4(d4.z, d4.w, d5.x, d5.y);
+                    r4[2] = make_float4(d5.z, d5.w, 0.0f, 0.0f);
                 }
                 __syncthreads();
-                for (int rb = rg; rb < nr; rb += kWgRG * 8) {  // 8 rows per thread per block, all loads in flight together
+                for (int rb = rg; rb < nr; rb += kWgRG * 4) {  // 4 rows per thread per block, all loads in flight together
                     if (rb != rg) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
+                        for (int i = 0; i < 4; ++i) {
                             const int r = rb + kWgRG * i;
                             const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H2 + (unsigned)n;
                             zv[i] = S.z2[o];
@@ -1887,10 +1899,10 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                         }
                     }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
+                    for (int i = 0; i < 4; ++i) {
                         const int r = rb + kWgRG * i;
                         if (r < nr) {
-                            // the row's scalars in three 16-byte LDS reads (same address in every lane: broadcast)
+                            // the row's scalars in three 16-byte LDS reads (one address per half wave: broadcast)
                             float ri[RP];
                             {
                                 const float4* r4 = reinterpret_cast<const float4*>(rinfo + r * RP);
@@ -1909,80 +1921,89 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                             dg += sc * dy * xh;
 #pragma unroll
                             for (int jj = 0; jj < OW; ++jj) dw3[jj] += sc * ri[2 + jj] * h2;
-                            // db3[j] = sum_r dout[r][j]: lanes 0..out-1 of the first column block, over this row group's rows
-                            if (vb == 0 && lane < J.m.out) db3 += sc * rinfo[r * RP + 2 + lane];
+                            // db3[j] = sum_r dout[r][j]: columns 0..out-1 of the first column block, over this row group's rows
+                            if (vb == 0 && cl < J.m.out) db3 += sc * rinfo[r * RP + 2 + cl];
                         }
                     }
                 }
             }
         }
         STAMP();
-        float* my = red + (rg * 64 + lane) * 20;
+        float* my = red + (rg * kWgCols + cl) * kRedP;
         my[0] = db2; my[1] = dg; my[2] = dbe;
 #pragma unroll
         for (int jj = 0; jj < OW; ++jj) my[3 + jj] = dw3[jj];
         my[3 + OW] = db3;
         __syncthreads();
-        if (vitem < 3 + J.m.out) {  // wave -> item (3 + out <= 11 items, 16 waves), lane -> column: 16 partial sums each
-            float v = sum_groups(red + lane * 20 + vitem);
-            if ((vitem == 1 || vitem == 2) && J.m.no_ln) v = 0.0f;
-            J.grad[vidx] = v;
-            if (ADAM) vae.apply(J, A.ad, vidx, v);
-        }
-        if (vb == 0 && wave == kWgRG - 1 && lane < J.m.out) {
-            const int idx = J.m.b3() + lane;
-            const float v = sum_groups(red + lane * 20 + 3 + OW);
+        if (vlive || b3live) {  // thread -> (item, column): 32 partial sums each
+            float v = sum_groups(red + ocol * kRedP + oitem);
+            if ((oitem == 1 || oitem == 2) && J.m.no_ln) v = 0.0f;
+            const unsigned idx = b3live ? b3idx : vidx;
             J.grad[idx] = v;
-            if (ADAM) vae3.apply(J, A.ad, idx, v);
+            if (ADAM) vae.apply(J, A.ad, idx, v);
         }
         STAMP();
         STAMP_FLUSH(40, b == kWgTilesPerBlock && j == 0 && tid == 0);
         return;
     }
     // layer 1: hidden unit k; dz1 = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) with the row means taken from the
-    // per-workgroup partial sums bwd_l2 left in lnp -> no cross-column work here.  64 units x 16 row groups per workgroup.
+    // per-workgroup partial sums bwd_l2 left in lnp -> no cross-column work here.
     {
-        const int k = (b - kWgTilesPerBlock - kWgVecWgs) * 64 + lane;
+        const int kb = (b - kWgTilesPerBlock - kWgVecWgs) * kWgCols;
+        const int k = kb + cl;
         const int in = J.m.in;
         const float g1 = J.net[J.m.g1() + k], be1 = J.net[J.m.be1() + k];
         float db1 = 0.f, dg = 0.f, dbe = 0.f, dw1[17];
 #pragma unroll
         for (int i = 0; i < 17; ++i) dw1[i] = 0.f;
-        // ADAM: up to two items per wave (3 + in <= 20 items, 16 waves): their parameters are requested now
-        auto l1idx = [&](int item) { return item == 0 ? J.m.b1() + k : item == 1 ? J.m.g1() + k : item == 2 ? J.m.be1() + k : J.m.W1() + k * in + (item - 3); };
-        AdamElem lae[2];
-        if (ADAM) {
-            lae[0].fetch(J, l1idx(wave));
-            if (wave + kWgRG < 3 + in) lae[1].fetch(J, l1idx(wave + kWgRG));
-        }
+        // ADAM: the parameter this thread will step (item oitem of unit kb + ocol; 3 + in <= 20 items x 32 units), requested now
+        const int ok = kb + ocol;
+        const unsigned lidx = (unsigned)(oitem == 0 ? J.m.b1() + ok : oitem == 1 ? J.m.g1() + ok : oitem == 2 ? J.m.be1() + ok : J.m.W1() + ok * in + (oitem - 3));
+        const bool llive = oitem < 3 + in;
+        AdamElem lae;
+        if (ADAM && llive) lae.fetch(J, lidx);
         #pragma unroll
         for (int s = 0; s < 2; ++s) if (s < J.nslots) {  // compile-time slot index: J lives in registers, not in scratch
             const Slot& S = J.ws[s];
             const float sc = scale[s];
             for (int c0 = 0; c0 < J.rows[s]; c0 += kWgRowChunk) {
                 const int nr = min(kWgRowChunk, J.rows[s] - c0);
-                float zv[8], dv[8];
+                float zv[4], dv[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < 4; ++i) {
                     const int r = rg + kWgRG * i;
                     const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H1 + (unsigned)k;  // unconditional, clamped
                     zv[i] = S.z1[o];
                     dv[i] = S.dh1[o];
                 }
+                // the chunk's shared operands are requested BEFORE the barrier that frees the LDS tiles: one round trip with the loads above
+                static_assert(kWgRowChunk * XP <= 5 * kWide && kWgRowChunk <= kWide && kColWgB == 8, "staging: five words + one row per thread");
+                float xst[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const int e = tid + q * kWide;
+                    xst[q] = S.x[(size_t)c0 * XP + (e < nr * XP ? e : 0)];
+                }
+                const int er = tid < nr ? tid : 0;
+                const float2 st1v = *reinterpret_cast<const float2*>(S.st1 + (size_t)(c0 + er) * 2);
+                const float4* lp4 = reinterpret_cast<const float4*>(S.lnp + (size_t)(c0 + er) * (2 * kColWgB));  // [8 column workgroups][2]
+                const float4 l0 = lp4[0], l1 = lp4[1], l2 = lp4[2], l3 = lp4[3];
                 __syncthreads();
-                for (int e = tid; e < nr * XP; e += kWide) xs[e] = S.x[(size_t)c0 * XP + e];
-                for (int e = tid; e < nr; e += kWide) {
-                    const float* lp = S.lnp + (size_t)(c0 + e) * (2 * kColWgB);
-                    rinfo[e * 8] = S.st1[(size_t)(c0 + e) * 2];
-                    rinfo[e * 8 + 1] = S.st1[(size_t)(c0 + e) * 2 + 1];
-                    rinfo[e * 8 + 2] = lnp_sum(lp) * (1.0f / H1);
-                    rinfo[e * 8 + 3] = lnp_sum(lp + 1) * (1.0f / H1);
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const int e = tid + q * kWide;
+                    if (e < nr * XP) xs[e] = xst[q];
+                }
+                if (tid < nr) {  // lnp_sum's fixed-order tree over the eight partials of each of the two row sums
+                    const float s1 = ((l0.x + l0.z) + (l1.x + l1.z)) + ((l2.x + l2.z) + (l3.x + l3.z));
+                    const float s2 = ((l0.y + l0.w) + (l1.y + l1.w)) + ((l2.y + l2.w) + (l3.y + l3.w));
+                    *reinterpret_cast<float4*>(rinfo + tid * 8) = make_float4(st1v.x, st1v.y, s1 * (1.0f / H1), s2 * (1.0f / H1));
                 }
                 __syncthreads();
-                for (int rb = rg; rb < nr; rb += kWgRG * 8) {
+                for (int rb = rg; rb < nr; rb += kWgRG * 4) {
                     if (rb != rg) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
+                        for (int i = 0; i < 4; ++i) {
                             const int r = rb + kWgRG * i;
                             const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H1 + (unsigned)k;
                             zv[i] = S.z1[o];
@@ -1990,7 +2011,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                         }
                     }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
+                    for (int i = 0; i < 4; ++i) {
                         const int r = rb + kWgRG * i;
                         if (r < nr) {
                             const float4 ri = *reinterpret_cast<const float4*>(rinfo + r * 8);  // mean, rstd, the two LN1-backward row means
@@ -2000,7 +2021,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                             db1 += dz;
                             dbe += sc * dy;
                             dg += sc * dy * xh;
-                            // the input row in five 16-byte LDS reads (one address for the whole wave: broadcast), not seventeen 4-byte ones
+                            // the input row in five 16-byte LDS reads (one address per half wave: broadcast), not seventeen 4-byte ones
                             const float4* xr4 = reinterpret_cast<const float4*>(xs + r * XP);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
@@ -2014,21 +2035,16 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
             }
         }
         STAMP();
-        float* my = red + (rg * 64 + lane) * 20;
+        float* my = red + (rg * kWgCols + cl) * kRedP;
         my[0] = db1; my[1] = dg; my[2] = dbe;
 #pragma unroll
         for (int i = 0; i < 17; ++i) my[3 + i] = dw1[i];
         __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int item = wave + t * kWgRG;
-            if (item < 3 + in) {
-                const int idx = l1idx(item);
-                float v = sum_groups(red + lane * 20 + item);
-                if ((item == 1 || item == 2) && J.m.no_ln) v = 0.0f;
-                J.grad[idx] = v;
-                if (ADAM) lae[t].apply(J, A.ad, idx, v);
-            }
+        if (llive) {
+            float v = sum_groups(red + ocol * kRedP + oitem);
+            if ((oitem == 1 || oitem == 2) && J.m.no_ln) v = 0.0f;
+            J.grad[lidx] = v;
+            if (ADAM) lae.apply(J, A.ad, lidx, v);
         }
         STAMP();
         STAMP_FLUSH(48, b == kWgTilesPerBlock + kWgVecWgs && j == 0 && tid == 0);

@@ -13,4 +13,4 @@ for r in rows[:9]:
     n=r["Name"].replace("(anonymous namespace)::","").split("(")[0].replace("void ","")
     print("%-46s calls %6s  mean %8.2f us  %5s%%" % (n[:46], r["Calls"], float(r["AverageNs"])/1e3, r["Percentage"][:5]))
 PY
-tail -1 $R/gpurun_out/kstats_$L.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('under rocprof:', round(d['ms_per_step']*1e3,2), 'us/step')"
+grep "^{" $R/gpurun_out/kstats_$L.log | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(\"under rocprof:\", round(d[\"ms_per_step\"]*1e3,2), \"us/step\")"
