@@ -57,7 +57,11 @@ __global__ __launch_bounds__(kThreads) void oneshot_allreduce_kernel(OneShotArgs
         if (threadIdx.x == 0) atomicExch(A.status, 1u);
         return;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: peers' messages are read fresh
+    // system-scope acquire: peers' messages are read fresh.  ONE wave per workgroup executes it (the invalidate covers the CU's caches and
+    // L2; the barrier orders the other waves' loads behind it) — executed by every wave it costs ~30 us per launch on MI355X
+    // (tools/ubench/handoff_probe.hip: an acquire fence per wave 29 us, a release fence by one thread per workgroup 1.6 us).
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __syncthreads();
     // 3. sum in rank order, 16 B per lane
     const long long n4 = A.n / 4;
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads) {
