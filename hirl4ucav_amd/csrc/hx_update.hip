@@ -625,6 +625,13 @@ struct ActFusedArgs {
 };
 
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+// The bf16 image of W2 is stored in the ORDER THE ACTING KERNEL READS IT: for each (column tile of 16, k-slab of 32) one contiguous
+// 1 KB block holding lane 0..63's 16 bytes — lane (r = column in the tile, g = k group): elements k = 32 slab + 8 g .. + 7 of column r.
+// A wave's B-fragment load is then ONE contiguous kilobyte (8 full cache lines); from the row-major image every 4-lane quad of the same
+// load touched four different columns = four 16-byte requests, and the 256 KB image took ~5 us to reach the registers.
+__host__ __device__ inline uint32_t w2_image_index(uint32_t col, uint32_t k) {
+    return ((((col >> 4) * 8u + (k >> 5)) * 4u + ((k >> 3) & 3u)) * 16u + (col & 15u)) * 8u + (k & 7u);
+}
 constexpr int LDB1 = H1 + 16;  // bf16 h1 tile pitch (elements) = 136 dwords = 8 mod 64: the ds_read_b128 A-operand read is conflict-free
 
 constexpr int ACT_KC = 16;            // k-chunk of W2 staged through LDS (64 B per column), double-buffered
@@ -733,9 +740,9 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         const int r = lane & 15, g = lane >> 4;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const uint16_t* row = A.w2b + (size_t)(t * 256 + cw * 16 + r) * H1 + 8 * g;
+            const uint16_t* blk = A.w2b + (size_t)((t * 16 + cw) * 8) * 512 + lane * 8;  // (lane = 16 g + r: w2_image_index's block order)
 #pragma unroll
-            for (int sl = 0; sl < 8; ++sl) bq[t][sl] = *reinterpret_cast<const uint4*>(row + 32 * sl);
+            for (int sl = 0; sl < 8; ++sl) bq[t][sl] = *reinterpret_cast<const uint4*>(blk + sl * 512);
         }
     }
     if (tid < ROWS * 13) xs[(tid / 13) * XP + tid % 13] = xv;
@@ -1065,15 +1072,12 @@ static void launch_act(const ActFusedArgs& H, hipStream_t st) {
 
 // bf16 image of a [n] fp32 array (round to nearest even): the policy's W2 for the BF16 acting kernels
 __global__ __launch_bounds__(kThreads) void pack_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int n) {
-    const int i = (blockIdx.x * kThreads + threadIdx.x) * 2;
+    const int i = (blockIdx.x * kThreads + threadIdx.x) * 2;  // row-major element (column i / 256, k = i % 256); pairs stay adjacent in the image
     if (i + 1 < n) {
         const float2 v = *reinterpret_cast<const float2*>(src + i);
         typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
         const v2bf r = {(__bf16)v.x, (__bf16)v.y};
-        *reinterpret_cast<unsigned*>(dst + i) = __builtin_bit_cast(unsigned, r);
-    } else if (i < n) {
-        const __bf16 r = (__bf16)src[i];
-        dst[i] = __builtin_bit_cast(uint16_t, r);
+        *reinterpret_cast<unsigned*>(dst + w2_image_index((uint32_t)i / H1, (uint32_t)i % H1)) = __builtin_bit_cast(unsigned, r);
     }
 }
 
@@ -1828,7 +1832,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                 ae[q].apply(J, A.ad, idx, acc[q]);
                 if (J.w2b) {
                     const __bf16 bv = (__bf16)ae[q].p;
-                    J.w2b[idx - J.m.W2()] = __builtin_bit_cast(uint16_t, bv);
+                    J.w2b[w2_image_index((uint32_t)(n0 + 4 * g + q), (uint32_t)(k0 + r))] = __builtin_bit_cast(uint16_t, bv);
                 }
             }
         }
@@ -2131,7 +2135,8 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
         if (A.w2b && i >= A.w2_lo && i < A.w2_lo + H2 * H1) {  // W2 starts at a multiple of 4 floats: the float4 is inside or outside
             typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
             const v4bf r = {(__bf16)p4.x, (__bf16)p4.y, (__bf16)p4.z, (__bf16)p4.w};
-            *reinterpret_cast<uint2*>(A.w2b + (i - A.w2_lo)) = __builtin_bit_cast(uint2, r);
+            const uint32_t e = (uint32_t)(i - A.w2_lo);  // four consecutive k of one column: adjacent in the image too
+            *reinterpret_cast<uint2*>(A.w2b + w2_image_index(e / H1, e % H1)) = __builtin_bit_cast(uint2, r);
         }
         if (A.target) {
             float4 t4 = *reinterpret_cast<const float4*>(A.target + i);

@@ -19,6 +19,13 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
+def image_order(w2):
+    """bf16 W2 [512][256] in the order the acting kernel reads it (hx_update.hip w2_image_index): 1 KB blocks per (column tile of 16,
+    k-slab of 32), inside a block lane (g = k group of 8, r = column) x 8 consecutive k"""
+    t = w2.reshape(32, 16, 8, 4, 8)          # [column tile][r][slab][g][e]
+    return t.permute(0, 2, 3, 1, 4).reshape(-1)  # [column tile][slab][g][r][e]
+
+
 @pytest.fixture(scope="module")
 def mods():
     if not torch.cuda.is_available():
@@ -62,7 +69,7 @@ def test_bf16_policy_against_rounded_operands_and_fp32(mods, n):
     a16 = e.act(d_obs).cpu().numpy()
     # the image is exactly bf16(W2), round to nearest even
     w2 = torch.as_tensor(params["actor"]["full2.weight"]).to(torch.bfloat16)
-    assert torch.equal(e.w2_bf16.cpu().view(torch.int16), w2.reshape(-1).view(torch.int16))
+    assert torch.equal(e.w2_bf16.cpu().view(torch.int16), image_order(w2).view(torch.int16))
     ref = rounded_operand_policy(params["actor"], torch.from_numpy(obs)).numpy()
     close_to_rounded_operands(a16, ref)
     d = np.abs(a16 - a32)
@@ -95,8 +102,8 @@ def test_bf16_image_follows_the_actor_adam_step(mods):
         e.assemble(ring, idx, bc_table=bc, idx_bc=ibc)
         e.learn(noise=torch.from_numpy(rng.normal(0, 0.2, 4).astype(np.float32)).cuda(), bc_weight_now=0.5)
     torch.cuda.synchronize()
-    w2 = E.unpack(e.actor, E.ACTOR_LAYOUT)["full2.weight"].to(torch.bfloat16).reshape(-1)
-    assert torch.equal(e.w2_bf16.view(torch.int16), w2.view(torch.int16))
+    w2 = E.unpack(e.actor, E.ACTOR_LAYOUT)["full2.weight"].to(torch.bfloat16)
+    assert torch.equal(e.w2_bf16.view(torch.int16), image_order(w2).to(e.w2_bf16.device).view(torch.int16))
     assert not torch.equal(before, e.act(obs))
     sd = {k: v.cpu().numpy() for k, v in E.unpack(e.actor, E.ACTOR_LAYOUT).items()}
     close_to_rounded_operands(e.act(obs).cpu().numpy(), rounded_operand_policy(sd, obs.cpu()).numpy())
