@@ -17,15 +17,18 @@ class _NetView:
     """Stands in for the reference's nn.Module attributes (agent.actor, agent.critic, ...): state_dict() /
     load_state_dict() / saveCheckpoint / loadCheckpoint with the reference's key names (HIRL.py:99-103,142-146)."""
 
-    def __init__(self, flat, layout, name):
+    def __init__(self, flat, layout, name, on_load=None):
         self._flat, self._layout, self.name = flat, layout, name
         self.device = flat.device
+        self._on_load = on_load  # the acting network: the engine's images of its W2 must follow a direct write
 
     def state_dict(self):
         return {k: v.detach().clone().cpu() for k, v in E.unpack(self._flat, self._layout).items()}
 
     def load_state_dict(self, sd):
         self._flat.copy_(E.pack(sd, self._layout, self._flat.numel(), self._flat.device))
+        if self._on_load is not None:
+            self._on_load()
 
     def _path(self, ajan, model_name):
         return os.path.join(model_name, "{}".format(ajan) + self.name)  # the reference joins with a literal '\\'
@@ -94,7 +97,7 @@ class Agent:
                                 use_bc=self._use_bc, device=device)
         self.eng.load_params(init_actor_state_dict(), init_critic_state_dict(), init_actor_state_dict() if self._use_bc else None)
         e = self.eng
-        self.actor = _NetView(e.actor, E.ACTOR_LAYOUT, "Actor_" + name)
+        self.actor = _NetView(e.actor, E.ACTOR_LAYOUT, "Actor_" + name, on_load=e.refresh_images)
         self.targetActor = _NetView(e.target_actor, E.ACTOR_LAYOUT, "TargetActor_" + name)
         self.critic = _NetView(e.critic, E.CRITIC_LAYOUT, "Critic_" + name)
         self.targetCritic = _NetView(e.target_critic, E.CRITIC_LAYOUT, "TargetCritic_" + name)

@@ -31,7 +31,7 @@ class HxSample(ctypes.Structure):
 
 class HxNets(ctypes.Structure):
     _fields_ = [(k, _vp) for k in ("actor", "critic", "target_actor", "target_critic", "bc_actor", "grad_actor", "grad_critic",
-                                   "m_actor", "v_actor", "m_critic", "v_critic", "losses", "soft_count", "wstate", "ws", "actor_w2_bf16")]
+                                   "m_actor", "v_actor", "m_critic", "v_critic", "losses", "soft_count", "wstate", "ws", "actor_w2_bf16", "actor_w2_f32i")]
 
 
 class HxHyper(ctypes.Structure):
@@ -43,6 +43,10 @@ _lib.register("hx_actor_act", [_vp, _vp, ctypes.c_int64, _vp, _i32, _vp, _f32, c
 _lib.register("hx_actor_act_step", [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32,
                                      ctypes.c_uint32, _f32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
 _lib.register("hx_pack_w2_bf16", [_vp, _i32, _vp, _vp])
+_lib.register("hx_pack_w2_f32i", [_vp, _i32, _vp, _vp])
+_lib.register("hx_actor_act_f32i", [_vp, _vp, _vp, ctypes.c_int64, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _f32, _vp])
+_lib.register("hx_actor_act_step_f32i", [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32,
+                                          ctypes.c_uint32, _f32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
 _lib.register("hx_actor_act_bf16", [_vp, _vp, _vp, ctypes.c_int64, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _f32, _vp])
 _lib.register("hx_actor_act_step_bf16", [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32,
                                           ctypes.c_uint32, _f32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
@@ -222,8 +226,11 @@ class HirlEngine:
         self._pending = None  # a draw sample(defer=True) recorded for the next learn()
         self.nets = HxNets(*(t.data_ptr() for t in (self.actor, self.critic, self.target_actor, self.target_critic, self.bc_actor,
                                                      self.grad_actor, self.grad_critic, self.m_actor, self.v_actor, self.m_critic,
-                                                     self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None)
+                                                     self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None, None)
         self.act_dtype, self.w2_bf16 = "f32", None
+        # fp32 image of the actor's W2 in the acting kernel's operand order (hx_pack_w2_f32i): kept current by the actor's Adam steps
+        self.w2_f32i = torch.zeros(H2 * H1, dtype=torch.float32, device=self.device)
+        self.nets.actor_w2_f32i = self.w2_f32i.data_ptr()
         self.hyper = HxHyper(gamma, tau, lr_actor, lr_critic, slope, 0.5, 10000.0, int(use_bc))  # HIRL.py:162,182
         self.use_bc, self.slope = bool(use_bc), float(slope)
         self.actor_trainable, self.update_count = True, 0   # HIRL.py:157,166
@@ -260,9 +267,13 @@ class HirlEngine:
         self.refresh_bf16()
 
     def refresh_bf16(self):
-        """Rebuild the bf16 image from the fp32 actor (after load_params / a checkpoint restore; hx_adam maintains it otherwise)."""
+        """Rebuild the acting kernel's images of W2 from the fp32 actor (after load_params / a checkpoint restore or any direct write to
+        `self.actor`; the Adam steps maintain them otherwise): the fp32 image always, the bf16 image in bf16 mode."""
+        _lib.call("hx_pack_w2_f32i", self.actor.data_ptr(), 13, self.w2_f32i.data_ptr(), _lib.stream_ptr())
         if self.act_dtype == "bf16":
             _lib.call("hx_pack_w2_bf16", self.actor.data_ptr(), 13, self.w2_bf16.data_ptr(), _lib.stream_ptr())
+
+    refresh_images = refresh_bf16
 
     def replica_checksum(self):
         """int64 sum of the bit patterns of every network and Adam moment: equal on all ranks of a sharded run, or the replicas have
@@ -293,7 +304,11 @@ class HirlEngine:
             _lib.call("hx_actor_act_bf16", self.actor.data_ptr(), self.w2_bf16.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode, _lib.ptr(noise),
                       float(sigma), int(seed), int(row0), self.act_calls, self.slope, _lib.stream_ptr())
             return out
-        _lib.call("hx_actor_act", (net if net is not None else self.actor).data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode,
+        if net is None:  # the engine's own actor: W2 from its fp32 image (same bits as hx_actor_act, no LDS staging of W2)
+            _lib.call("hx_actor_act_f32i", self.actor.data_ptr(), self.w2_f32i.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode, _lib.ptr(noise),
+                      float(sigma), int(seed), int(row0), self.act_calls, self.slope, _lib.stream_ptr())
+            return out
+        _lib.call("hx_actor_act", net.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode,
                   _lib.ptr(noise), float(sigma), int(seed), int(row0), self.act_calls, self.slope, None,
                   _lib.stream_ptr())
         return out
@@ -316,9 +331,9 @@ class HirlEngine:
                       out.data_ptr(), mode, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
                       env.reward.data_ptr(), env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
             return out, env.obs, env.reward, env.done, env.success
-        _lib.call("hx_actor_act_step", self.actor.data_ptr(), env.state.data_ptr(), n, n, env.obs.data_ptr(), out.data_ptr(), mode,
-                  _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope, env.reward.data_ptr(),
-                  env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
+        _lib.call("hx_actor_act_step_f32i", self.actor.data_ptr(), self.w2_f32i.data_ptr(), env.state.data_ptr(), n, n, env.obs.data_ptr(),
+                  out.data_ptr(), mode, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
+                  env.reward.data_ptr(), env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
         return out, env.obs, env.reward, env.done, env.success
 
     # ---- learning --------------------------------------------------------------------------------------------

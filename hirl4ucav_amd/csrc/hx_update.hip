@@ -622,6 +622,7 @@ struct ActFusedArgs {
     HxStepOpts o;
     double inv_cap;  // 1 / o.cap
     const uint16_t* w2b;  // BF16 instantiations: bf16 image of W2 [512][256] (hx_pack_w2_bf16 / the actor's Adam step keep it current)
+    const float* w2f;     // F32I instantiations: fp32 image of W2 (hx_pack_w2_f32i)
 };
 
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
@@ -629,6 +630,10 @@ typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 // 1 KB block holding lane 0..63's 16 bytes — lane (r = column in the tile, g = k group): elements k = 32 slab + 8 g .. + 7 of column r.
 // A wave's B-fragment load is then ONE contiguous kilobyte (8 full cache lines); from the row-major image every 4-lane quad of the same
 // load touched four different columns = four 16-byte requests, and the 256 KB image took ~5 us to reach the registers.
+// the fp32 image: one 1 KB block per (column tile of 16, k-chunk of 16), lane (r, g): k = 16 chunk + 4 g .. + 3 of column r
+__host__ __device__ inline uint32_t w2f_image_index(uint32_t col, uint32_t k) {
+    return ((((col >> 4) * 16u + (k >> 4)) * 4u + ((k >> 2) & 3u)) * 16u + (col & 15u)) * 4u + (k & 3u);
+}
 __host__ __device__ inline uint32_t w2_image_index(uint32_t col, uint32_t k) {
     return ((((col >> 4) * 8u + (k >> 5)) * 4u + ((k >> 3) & 3u)) * 16u + (col & 15u)) * 8u + (k & 7u);
 }
@@ -662,8 +667,9 @@ __device__ __forceinline__ float philox_normal(uint32_t row, uint32_t call, uint
 //         the 512 columns and nobody else reads them, so its B fragments (16 x 16 B per lane = the 256 KB image once per
 //         workgroup) go from L2 straight into registers at kernel entry — no LDS staging, no chunk barriers; the 16 (32) rows
 //         of h1 are the only shared operand.
-template <int NRT, bool GAUSS, bool ENV, bool BF16, bool RELU>
+template <int NRT, bool GAUSS, bool ENV, bool BF16, bool RELU, bool F32I = false>
 __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
+    static_assert(!(BF16 && F32I), "one image format at a time");
     constexpr int ROWS = NRT * RT;
     __shared__ float s_act[ENV ? ROWS * 4 : 4];
     __shared__ unsigned s_base;  // ring slot of the workgroup's first row
@@ -671,8 +677,9 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     static_assert(2 * H2 * ACT_LDW >= ROWS * LDA2, "the z2 tile reuses the W2 chunk buffers");
     // fp32: two W2 chunk buffers (reused for z2 and, in the env tail, the replay rows / next observations)
     // bf16: the z2 tile, then the replay rows / next observations, and the bf16 h1 tile
-    constexpr int kTileA = BF16 ? ROWS * LDA2 : H2 * ACT_LDW;
-    constexpr int kTileB = BF16 ? (ENV ? ROWS * (hxenv::kRowPitch + HX_OBS_DIM) : 4) : H2 * ACT_LDW;
+    constexpr bool IMG = BF16 || F32I;  // W2 comes from an image straight into registers: no chunk buffers in LDS
+    constexpr int kTileA = IMG ? ROWS * LDA2 : H2 * ACT_LDW;
+    constexpr int kTileB = IMG ? (ENV ? ROWS * (hxenv::kRowPitch + HX_OBS_DIM) : 4) : H2 * ACT_LDW;
     __shared__ __attribute__((aligned(16))) float lds[ROWS * LDA1 + ROWS * XP + ROWS * 2 + H1 * 13 + kTileA + kTileB];
     __shared__ __attribute__((aligned(16))) __bf16 h1b[BF16 ? ROWS * LDB1 : 8];
     float* h1s = lds;
@@ -704,7 +711,13 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     // (64 KB in flight per CU) the loop ran at the L2 round trip, not at the MFMA rate
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     uint4 bq[BF16 ? 2 : 1][BF16 ? 8 : 1];  // BF16: B fragments of this wave's two column tiles, all of K (requested below)
-    if constexpr (!BF16) {
+    // F32I: every wave owns 32 of the 512 columns and nobody else reads them, so its fp32 B fragments go from L2 straight into registers
+    // in MFMA operand order — one contiguous kilobyte per load from the image — ACT_PF chunks ahead of the multiply: no LDS staging (80 KB of
+    // LDS traffic per chunk with it), no barrier per chunk; the waves stream independently.  Same k order as the staged loop: same bits.
+    constexpr int ACT_PF = 3;
+    float4 pb[F32I ? ACT_NCH : 1], qb[F32I ? ACT_NCH : 1];
+    const float* img0 = F32I ? A.w2f + (size_t)wave * (16 * 256) + lane * 4 : nullptr;  // 1 KB block (column tile `wave`, chunk c) at + 256 c floats; column tile 16 + wave 65,536 floats on
+    if constexpr (!BF16 && !F32I) {
         ACT_LOAD(ra0, rb0, 0);
         ACT_LOAD(ra1, rb1, 1);
     }
@@ -723,7 +736,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < H1 * 13 / 4) wv = reinterpret_cast<const float4*>(net + m.W1())[tid];
     const float bias1 = net[m.b1() + u], g1v = net[m.g1() + u], be1v = net[m.be1() + u];
-    if constexpr (!BF16) {  // behind the prologue's own operands
+    if constexpr (!BF16 && !F32I) {  // behind the prologue's own operands
         ACT_LOAD(ra2, rb2, 2);
         ACT_LOAD(ra3, rb3, 3);
     }
@@ -789,9 +802,16 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             if (BF16) h1b[row * LDB1 + u] = (__bf16)hv;  // v_cvt_pk_bf16_f32: round to nearest even
             else h1s[row * LDA1 + u] = hv;
         }
-    if (!BF16) {
+    if (!BF16 && !F32I) {
         ACT_STORE(wb0, ra0, rb0);
         ACT_LOAD(ra0, rb0, 4);
+    }
+    if constexpr (F32I) {  // the first chunks of this wave's columns (behind the prologue's own traffic)
+#pragma unroll
+        for (int c = 0; c < ACT_PF; ++c) {
+            pb[c] = *reinterpret_cast<const float4*>(img0 + c * 256);
+            qb[c] = *reinterpret_cast<const float4*>(img0 + (size_t)16 * 16 * 256 + c * 256);
+        }
     }
     __syncthreads();
     STAMP();
@@ -826,7 +846,38 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
                 acc[t][0] = mfma16(a4[t].z, p4.z, acc[t][0]); acc[t][1] = mfma16(a4[t].z, q4.z, acc[t][1]); \
                 acc[t][0] = mfma16(a4[t].w, p4.w, acc[t][0]); acc[t][1] = mfma16(a4[t].w, q4.w, acc[t][1]); } }
         static_assert(ACT_NCH % 4 == 0, "the chunk loop is unrolled by the four register sets");
-        for (int c = 0; c < (BF16 ? 0 : ACT_NCH); c += 4) {
+        if constexpr (F32I) {
+            float4 an[NRT];  // the h1 fragment of the NEXT chunk: its LDS round trip runs under this chunk's MFMAs
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) an[t] = *reinterpret_cast<const float4*>(ap + t * RT * LDA1);
+#pragma unroll
+            for (int c = 0; c < ACT_NCH; ++c) {
+                float4 a4[NRT];
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) a4[t] = an[t];
+                if (c + ACT_PF < ACT_NCH) {
+                    pb[c + ACT_PF] = *reinterpret_cast<const float4*>(img0 + (c + ACT_PF) * 256);
+                    qb[c + ACT_PF] = *reinterpret_cast<const float4*>(img0 + (size_t)16 * 16 * 256 + (c + ACT_PF) * 256);
+                }
+                if (c + 1 < ACT_NCH) {
+#pragma unroll
+                    for (int t = 0; t < NRT; ++t) an[t] = *reinterpret_cast<const float4*>(ap + t * RT * LDA1 + (c + 1) * ACT_KC);
+                }
+                // the requests stay HERE, ahead of the multiply: the scheduler otherwise sinks them to just before their use (fewer live
+                // registers) and every chunk then waits a full L2 / LDS round trip
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 p4 = pb[c], q4 = qb[c];
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) {
+                    acc[t][0] = mfma16(a4[t].x, p4.x, acc[t][0]); acc[t][1] = mfma16(a4[t].x, q4.x, acc[t][1]);
+                    acc[t][0] = mfma16(a4[t].y, p4.y, acc[t][0]); acc[t][1] = mfma16(a4[t].y, q4.y, acc[t][1]);
+                    acc[t][0] = mfma16(a4[t].z, p4.z, acc[t][0]); acc[t][1] = mfma16(a4[t].z, q4.z, acc[t][1]);
+                    acc[t][0] = mfma16(a4[t].w, p4.w, acc[t][0]); acc[t][1] = mfma16(a4[t].w, q4.w, acc[t][1]);
+                }
+            }
+            __syncthreads();  // every wave has read its last h1 fragment: the tile's LDS may now take z2 and the head image
+        }
+        for (int c = 0; c < ((BF16 || F32I) ? 0 : ACT_NCH); c += 4) {
             // chunk c is in wb0; set 1 holds chunk c+1, sets 2, 3, 0 hold c+2, c+3, c+4 (in flight)
             ACT_STORE(wb1, ra1, rb1);
             if (c + 5 < ACT_NCH) ACT_LOAD(ra1, rb1, c + 5);
@@ -1042,7 +1093,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 // the ~8 us tail, and the env kernel on its own (thousands of envs per launch, 10-14 us) is the cheaper way.
 constexpr int64_t kFuseEnvMax = 8192;
 
-template <bool GAUSS, bool BF16, bool RELU>
+template <bool GAUSS, bool BF16, bool RELU, bool F32I = false>
 static void launch_act_t(const ActFusedArgs& H, hipStream_t st) {
     const bool env = H.state != nullptr;
     // 32 rows per workgroup: from 8,192 rows on (fp32: below that, 16-row workgroups fill the chip and the fp32 MFMA work per workgroup
@@ -1050,12 +1101,12 @@ static void launch_act_t(const ActFusedArgs& H, hipStream_t st) {
     static const int nrt2_bf16 = getenv("HX_ACT_BF16_NRT2_ROWS") ? atoi(getenv("HX_ACT_BF16_NRT2_ROWS")) : 8192;  // tuning knob
     if (H.rows >= (BF16 ? nrt2_bf16 : 8192)) {
         const dim3 grid((unsigned)((H.rows + 2 * RT - 1) / (2 * RT)));
-        if (env) hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, true, BF16, RELU>), grid, dim3(kWide), 0, st, H);
-        else hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, false, BF16, RELU>), grid, dim3(kWide), 0, st, H);
+        if (env) hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, true, BF16, RELU, F32I>), grid, dim3(kWide), 0, st, H);
+        else hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, false, BF16, RELU, F32I>), grid, dim3(kWide), 0, st, H);
     } else {
         const dim3 grid((unsigned)((H.rows + RT - 1) / RT));
-        if (env) hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, true, BF16, RELU>), grid, dim3(kWide), 0, st, H);
-        else hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, false, BF16, RELU>), grid, dim3(kWide), 0, st, H);
+        if (env) hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, true, BF16, RELU, F32I>), grid, dim3(kWide), 0, st, H);
+        else hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, false, BF16, RELU, F32I>), grid, dim3(kWide), 0, st, H);
     }
 }
 template <bool GAUSS>
@@ -1063,9 +1114,11 @@ static void launch_act(const ActFusedArgs& H, hipStream_t st) {
     // the activation is a compile-time ReLU when the slope is 0 (HIRL, SAC; the Gaussian policy is a Linear-ReLU stack by definition)
     if (GAUSS || H.slope == 0.0f) {
         if (H.w2b) launch_act_t<GAUSS, true, true>(H, st);
+        else if (!GAUSS && H.w2f) launch_act_t<false, false, true, true>(H, st);
         else launch_act_t<GAUSS, false, true>(H, st);
     } else {
         if (H.w2b) launch_act_t<false, true, false>(H, st);
+        else if (H.w2f) launch_act_t<false, false, false, true>(H, st);
         else launch_act_t<false, false, false>(H, st);
     }
 }
@@ -1079,6 +1132,11 @@ __global__ __launch_bounds__(kThreads) void pack_bf16_kernel(const float* __rest
         const v2bf r = {(__bf16)v.x, (__bf16)v.y};
         *reinterpret_cast<unsigned*>(dst + w2_image_index((uint32_t)i / H1, (uint32_t)i % H1)) = __builtin_bit_cast(unsigned, r);
     }
+}
+
+__global__ __launch_bounds__(kThreads) void pack_f32i_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
+    const int i = (blockIdx.x * kThreads + threadIdx.x) * 4;  // four consecutive k of one column: adjacent in the image too
+    if (i < n) *reinterpret_cast<float4*>(dst + w2f_image_index((uint32_t)i / H1, (uint32_t)i % H1)) = *reinterpret_cast<const float4*>(src + i);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1633,6 +1691,7 @@ struct WgJob {
     float* p; float* mom; float* var;  // parameters (== net) and Adam moments, same layout
     float* target;                 // nullptr, or the target network's block: soft_update with the new parameters (HIRL.py:11-13)
     uint16_t* w2b;                 // nullptr, or the bf16 image of W2 to refresh
+    float* w2f;                    // nullptr, or the fp32 image of W2 to refresh
 };
 struct WgAdam {
     float b1, b2, eps, step_size, bc2_sqrt, tau;
@@ -1675,7 +1734,7 @@ __device__ __forceinline__ float effective_w(int kind, float given, float warm, 
 struct WgJobC {
     const float* net; float* grad;
     float* ws0; float* ws1;
-    float* mom; float* var; float* target; uint16_t* w2b;
+    float* mom; float* var; float* target; uint16_t* w2b; float* w2f;
     uint32_t cfg;  // m:10 | nslots:2 | wmode0:2 | wmode1:2 | w_kind:2 | adam.finish_actor:1 | adam.use_bc:1
     int32_t rows0, rows1;
     float slope, w_given, warm, inv_batch;
@@ -1683,7 +1742,7 @@ struct WgJobC {
     uint32_t pad_;
     const int* soft_count; float* wstate; float* losses;
 };
-static_assert(sizeof(WgJobC) == 144, "WgJobC layout");
+static_assert(sizeof(WgJobC) == 152, "WgJobC layout");
 struct WgArgsC {
     WgJobC job[2];
 };
@@ -1738,7 +1797,7 @@ __device__ __forceinline__ void expand_wg(const WgJobC& c, WgJob& J, WgArgs& A) 
     J.wmode[0] = (int)((c.cfg >> 12) & 3u); J.wmode[1] = (int)((c.cfg >> 14) & 3u);
     J.ws[0] = carve_slot(c.ws0, c.rows0); J.ws[1] = carve_slot(c.ws1, c.rows1);
     J.rows[0] = c.rows0; J.rows[1] = c.rows1;
-    J.p = const_cast<float*>(c.net); J.mom = c.mom; J.var = c.var; J.target = c.target; J.w2b = c.w2b;
+    J.p = const_cast<float*>(c.net); J.mom = c.mom; J.var = c.var; J.target = c.target; J.w2b = c.w2b; J.w2f = c.w2f;
     A.slope = c.slope; A.w_kind = (int)((c.cfg >> 16) & 3u); A.w_given = c.w_given; A.warm = c.warm; A.inv_batch = c.inv_batch;
     A.soft_count = c.soft_count; A.wstate = c.wstate;
     A.ad.b1 = c.b1; A.ad.b2 = c.b2; A.ad.eps = c.eps; A.ad.step_size = c.step_size; A.ad.bc2_sqrt = c.bc2_sqrt; A.ad.tau = c.tau;
@@ -1748,7 +1807,7 @@ __device__ __forceinline__ void expand_wg(const WgJobC& c, WgJob& J, WgArgs& A) 
 inline WgJobC pack_wg(const WgJob& J, const WgArgs& A) {
     WgJobC c{};
     c.net = J.net; c.grad = J.grad; c.ws0 = J.ws[0].x; c.ws1 = J.nslots > 1 ? J.ws[1].x : J.ws[0].x;
-    c.mom = J.mom; c.var = J.var; c.target = J.target; c.w2b = J.w2b;
+    c.mom = J.mom; c.var = J.var; c.target = J.target; c.w2b = J.w2b; c.w2f = J.w2f;
     c.cfg = mlp_bits(J.m) | ((uint32_t)J.nslots << 10) | ((uint32_t)J.wmode[0] << 12) | ((uint32_t)J.wmode[1] << 14) | ((uint32_t)A.w_kind << 16) |
             ((uint32_t)(A.ad.finish_actor ? 1 : 0) << 18) | ((uint32_t)(A.ad.use_bc ? 1 : 0) << 19);
     c.rows0 = J.rows[0]; c.rows1 = J.nslots > 1 ? J.rows[1] : J.rows[0];
@@ -1834,6 +1893,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                     const __bf16 bv = (__bf16)ae[q].p;
                     J.w2b[w2_image_index((uint32_t)(n0 + 4 * g + q), (uint32_t)(k0 + r))] = __builtin_bit_cast(uint16_t, bv);
                 }
+                if (J.w2f) J.w2f[w2f_image_index((uint32_t)(n0 + 4 * g + q), (uint32_t)(k0 + r))] = ae[q].p;
             }
         }
         STAMP();
@@ -2076,6 +2136,7 @@ struct AdamArgs {
     // bf16 image of this block's W2 kept current by the step that changes it (elements [w2_lo, w2_lo + 512*256) of p): the BF16
     // acting kernels read it; nullptr = none
     uint16_t* w2b;
+    float* w2f;  // fp32 image of W2 to refresh (same range)
     int w2_lo;
     // merged actor message of a sharded run: g holds the summed dL_rl, g2 the summed dL_bc, *countf the summed
     // soft count; the step uses g = w g2 + (1 - w) g with w from the GLOBAL count.  nullptr: g is the finished gradient.
@@ -2137,6 +2198,10 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
             const v4bf r = {(__bf16)p4.x, (__bf16)p4.y, (__bf16)p4.z, (__bf16)p4.w};
             const uint32_t e = (uint32_t)(i - A.w2_lo);  // four consecutive k of one column: adjacent in the image too
             *reinterpret_cast<uint2*>(A.w2b + w2_image_index(e / H1, e % H1)) = __builtin_bit_cast(uint2, r);
+        }
+        if (A.w2f && i >= A.w2_lo && i < A.w2_lo + H2 * H1) {
+            const uint32_t e = (uint32_t)(i - A.w2_lo);
+            *reinterpret_cast<float4*>(A.w2f + w2f_image_index(e / H1, e % H1)) = p4;
         }
         if (A.target) {
             float4 t4 = *reinterpret_cast<const float4*>(A.target + i);
@@ -2379,12 +2444,12 @@ int64_t hx_act_workspace_floats(int64_t rows) { (void)rows; return 0; }  // the 
 /* chooseAction / chooseActionSmallNoise / chooseActionNoNoise for `rows` observations (HIRL.py:192-212):
  * actions = clamp(actor(obs) + noise, -1, 1).  noise_mode 0: none, 1: noise[4] shared by all rows, 2: noise[rows][4],
  * 3: N(0, sigma^2) per row and component from Philox(seed; row0 + row, call).  ws: unused since the whole policy runs in one kernel (may be NULL). */
-static int actor_act_impl(const float* actor, const uint16_t* w2b, const float* obs, int64_t rows, float* actions, int32_t noise_mode, const float* noise,
+static int actor_act_impl(const float* actor, const uint16_t* w2b, const float* w2f, const float* obs, int64_t rows, float* actions, int32_t noise_mode, const float* noise,
                  float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream) {
     HX_REQUIRE(actor && obs && actions && rows > 0, "hx_actor_act: bad arguments");
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act: bad noise mode");
     ActFusedArgs H{actor, kActor, const_cast<float*>(obs), (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
-                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0, w2b};
+                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0, w2b, w2f};
     launch_act<false>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_actor_act");
     return 0;
@@ -2393,13 +2458,13 @@ static int actor_act_impl(const float* actor, const uint16_t* w2b, const float* 
 int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* actions, int32_t noise_mode, const float* noise,
                  float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* ws, void* stream) {
     (void)ws;
-    return actor_act_impl(actor, nullptr, obs, rows, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream);
+    return actor_act_impl(actor, nullptr, nullptr, obs, rows, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream);
 }
 /* The same with the 256 -> 512 layer on bf16 MFMA (BASELINE.json configs[4]): w2_bf16 = hx_pack_w2_bf16 image of full2.weight. */
 int hx_actor_act_bf16(const float* actor, const uint16_t* w2_bf16, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
                       const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream) {
     HX_REQUIRE(w2_bf16 && (reinterpret_cast<uintptr_t>(w2_bf16) & 15u) == 0, "hx_actor_act_bf16: w2_bf16 must be a 16-byte aligned bf16 image of W2");
-    return actor_act_impl(actor, w2_bf16, obs, rows, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream);
+    return actor_act_impl(actor, w2_bf16, nullptr, obs, rows, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream);
 }
 /* bf16 image (round to nearest even) of an MLP block's W2 [512][256]; in_dim = 13 (actor / policy) or 17 (Q head) locates it. */
 int hx_pack_w2_bf16(const float* net, int32_t in_dim, uint16_t* w2_bf16, void* stream) {
@@ -2424,7 +2489,7 @@ static int check_step_args(const float* state, int64_t n, int64_t stride, const 
 
 /* chooseAction + HarfangEnv.step for n envs in ONE launch (train_all.py:343-345): actions = clamp(actor(obs_io) + noise, -1, 1) as
  * hx_actor_act, then hx_env_step with those actions in the tail of the same kernel — obs_io in: current observation, out: next. */
-static int actor_act_step_impl(const float* actor, const uint16_t* w2b, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+static int actor_act_step_impl(const float* actor, const uint16_t* w2b, const float* w2f, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
                       const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward,
                       uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
     HX_REQUIRE(actor, "hx_actor_act_step: null actor");
@@ -2432,12 +2497,12 @@ static int actor_act_step_impl(const float* actor, const uint16_t* w2b, float* s
     const HxStepOpts o = opts ? *opts : HxStepOpts{};
     if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_actor_act_step")) return rc;
     if (n > kFuseEnvMax) {  // more than one round of workgroups: the env step is cheaper as a launch of its own
-        if (int rc = actor_act_impl(actor, w2b, obs_io, n, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream)) return rc;
+        if (int rc = actor_act_impl(actor, w2b, w2f, obs_io, n, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream)) return rc;
         return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
     }
     ActFusedArgs H{actor, kActor, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
                    noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
-                   o.cap > 0 ? 1.0 / (double)o.cap : 0.0, w2b};
+                   o.cap > 0 ? 1.0 / (double)o.cap : 0.0, w2b, w2f};
     launch_act<false>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_actor_act_step");
     return 0;
@@ -2446,14 +2511,36 @@ static int actor_act_step_impl(const float* actor, const uint16_t* w2b, float* s
 int hx_actor_act_step(const float* actor, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
                       const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward,
                       uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
-    return actor_act_step_impl(actor, nullptr, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed, row0, call, slope, reward, done,
+    return actor_act_step_impl(actor, nullptr, nullptr, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed, row0, call, slope, reward, done,
                                success, opts, stream);
 }
 int hx_actor_act_step_bf16(const float* actor, const uint16_t* w2_bf16, float* state, int64_t n, int64_t stride, float* obs_io, float* actions,
                            int32_t noise_mode, const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope,
                            float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
     HX_REQUIRE(w2_bf16 && (reinterpret_cast<uintptr_t>(w2_bf16) & 15u) == 0, "hx_actor_act_step_bf16: w2_bf16 must be a 16-byte aligned bf16 image of W2");
-    return actor_act_step_impl(actor, w2_bf16, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed, row0, call, slope, reward, done,
+    return actor_act_step_impl(actor, w2_bf16, nullptr, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed, row0, call, slope, reward, done,
+                               success, opts, stream);
+}
+
+/* The fp32 policy from the re-ordered fp32 image of W2 (hx_pack_w2_f32i): bit-identical to hx_actor_act / hx_actor_act_step. */
+int hx_pack_w2_f32i(const float* net, int32_t in_dim, float* w2_f32i, void* stream) {
+    HX_REQUIRE(net && w2_f32i && (in_dim == 13 || in_dim == 17) && (reinterpret_cast<uintptr_t>(w2_f32i) & 15u) == 0, "hx_pack_w2_f32i: bad arguments");
+    const Mlp m{in_dim, 1, 0};
+    const int n = H2 * H1;
+    hipLaunchKernelGGL(pack_f32i_kernel, dim3((n / 4 + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, net + m.W2(), w2_f32i, n);
+    HX_CHECK_LAUNCH("hx_pack_w2_f32i");
+    return 0;
+}
+int hx_actor_act_f32i(const float* actor, const float* w2_f32i, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
+                      const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream) {
+    HX_REQUIRE(w2_f32i && (reinterpret_cast<uintptr_t>(w2_f32i) & 15u) == 0, "hx_actor_act_f32i: w2_f32i must be a 16-byte aligned fp32 image of W2");
+    return actor_act_impl(actor, nullptr, w2_f32i, obs, rows, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream);
+}
+int hx_actor_act_step_f32i(const float* actor, const float* w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io, float* actions,
+                           int32_t noise_mode, const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope,
+                           float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
+    HX_REQUIRE(w2_f32i && (reinterpret_cast<uintptr_t>(w2_f32i) & 15u) == 0, "hx_actor_act_step_f32i: w2_f32i must be a 16-byte aligned fp32 image of W2");
+    return actor_act_step_impl(actor, nullptr, w2_f32i, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed, row0, call, slope, reward, done,
                                success, opts, stream);
 }
 
@@ -2612,6 +2699,10 @@ static int adam_impl(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t 
         A.target = which == 0 ? N->target_critic : N->target_actor;
         A.tau = Hy->tau;
     }
+    if (which != 0 && N->actor_w2_f32i) {
+        A.w2f = N->actor_w2_f32i;
+        A.w2_lo = kActor.W2();
+    }
     if (which != 0 && N->actor_w2_bf16) {
         A.w2b = N->actor_w2_bf16;
         A.w2_lo = kActor.W2();
@@ -2728,6 +2819,7 @@ static int actor_wgrad_impl(const HxNets* N, const HxHyper* Hy, int32_t batch, i
         J.p = N->actor; J.mom = N->m_actor; J.var = N->v_actor;
         J.target = polyak ? N->target_actor : nullptr;
         J.w2b = N->actor_w2_bf16;
+        J.w2f = N->actor_w2_f32i;
         W.ad = make_adam(N, Hy, Hy->lr_actor, adam_step, true);
         launch_wg<true>(W, (hipStream_t)stream);
     } else {

@@ -169,6 +169,19 @@ int hx_actor_act_step_bf16(const float* actor, const uint16_t* w2_bf16, float* s
                            float slope, float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts /* host, may be NULL */,
                            void* stream);
 
+/* fp32 policy inference from a RE-ORDERED fp32 copy of W2 ("image", 512 x 256 floats): the same arithmetic, bit for bit, as
+ * hx_actor_act / hx_actor_act_step — but every wave reads its 32 columns of W2 as contiguous kilobytes straight into registers (MFMA
+ * operand order) instead of streaming the row-major matrix through LDS with a barrier per 16 k-values.  hx_pack_w2_f32i writes the image
+ * of the MLP block at `net`; HxNets.actor_w2_f32i (below) keeps it current through every Adam step of the actor.  The image order is an
+ * internal format (w2f_image_index in hx_update.hip); both image formats (this and the bf16 one) are for the deterministic policy head. */
+int hx_pack_w2_f32i(const float* net, int32_t in_dim, float* w2_f32i, void* stream);
+int hx_actor_act_f32i(const float* actor, const float* w2_f32i, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
+                      const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream);
+int hx_actor_act_step_f32i(const float* actor, const float* w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io,
+                           float* actions, int32_t noise_mode, const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call,
+                           float slope, float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts /* host, may be NULL */,
+                           void* stream);
+
 /* Minibatch of Agent.learn (HIRL.py:223-251), already assembled by hx_sample_batch into compact row tiles:
  * rows[batch][HX_ROW_WORDS] = s[13] a[4] s'[13] r done (buffer rows first, then expert rows, HIRL.py:229-233);
  * bc_rows[batch][HX_ROW_WORDS]: cols 0..12 state, 13..16 action of the BC minibatch (HIRL.py:248-251; NULL for TD3). */
@@ -189,6 +202,7 @@ typedef struct HxNets {
     float* ws;           /* hx_hirl_workspace_floats(batch) */
     uint16_t* actor_w2_bf16; /* NULL, or [512][256] bf16 image of the actor's full2.weight: every Adam step of the actor refreshes it
                                 (hx_adam which = 1 / 2), the bf16 acting entry points read it */
+    float* actor_w2_f32i;    /* NULL, or the fp32 image of the same matrix (hx_pack_w2_f32i), refreshed likewise; hx_actor_act*_f32i read it */
 } HxNets;
 
 typedef struct HxHyper {

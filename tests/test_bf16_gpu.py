@@ -109,6 +109,51 @@ def test_bf16_image_follows_the_actor_adam_step(mods):
     close_to_rounded_operands(e.act(obs).cpu().numpy(), rounded_operand_policy(sd, obs.cpu()).numpy())
 
 
+def f32_image_order(w2):
+    """fp32 W2 [512][256] in the fp32 image's order (hx_update.hip w2f_image_index): 1 KB blocks per (column tile of 16, k-chunk of 16),
+    inside a block lane (g = k group of 4, r = column) x 4 consecutive k"""
+    return w2.reshape(32, 16, 16, 4, 4).permute(0, 2, 3, 1, 4).reshape(-1)  # [tile][r][chunk][g][e] -> [tile][chunk][g][r][e]
+
+
+@pytest.mark.parametrize("staged", [False, True])
+@pytest.mark.parametrize("n", [1, 16, 1000, 4096, 9000])
+def test_f32_image_path_is_bit_identical_and_follows_adam(mods, staged, n):
+    """The fp32 policy from the re-ordered image of W2 (hx_actor_act_f32i, what HirlEngine.act uses for its own actor: W2 straight into
+    registers, no LDS staging) equals hx_actor_act (row-major W2 streamed through LDS) BIT FOR BIT at every size class (16- and 32-row
+    workgroups, ragged tails), and the image follows the actor through the one-call and the staged Adam steps."""
+    import ctypes
+
+    from hirl4ucav_amd import _lib
+
+    E = mods[0]
+    params, data = D.make_params(5), D.make_data(6)
+    e = E.HirlEngine(batch=128)
+    e.staged = staged
+    e.load_params(params["actor"], params["critic"], params["bc_actor"])
+    ring = torch.from_numpy(data["replay"]).cuda()
+    bc = np.zeros((D.N_EXPERT, 32), np.float32)
+    bc[:, 0:13], bc[:, 13:17] = data["expert_s"], data["expert_a"]
+    bc = torch.from_numpy(bc).cuda()
+    rng = np.random.default_rng(n)
+    obs = torch.from_numpy(rng.uniform(-1, 1, (n, 13)).astype(np.float32)).cuda()
+
+    def plain():
+        out = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        _lib.call("hx_actor_act", e.actor.data_ptr(), obs.data_ptr(), n, out.data_ptr(), 0, None, 0.0, 0, 0, 0, e.slope, None, _lib.stream_ptr())
+        return out
+
+    assert torch.equal(e.w2_f32i, f32_image_order(E.unpack(e.actor, E.ACTOR_LAYOUT)["full2.weight"]).to(e.w2_f32i.device))
+    assert torch.equal(e.act(obs), plain())
+    for k in range(4):
+        idx = torch.from_numpy(rng.integers(0, D.N_REPLAY, 128).astype(np.int32)).cuda()
+        ibc = torch.from_numpy(rng.integers(0, D.N_EXPERT, 128).astype(np.int32)).cuda()
+        e.assemble(ring, idx, bc_table=bc, idx_bc=ibc)
+        e.learn(noise=torch.from_numpy(rng.normal(0, 0.2, 4).astype(np.float32)).cuda(), bc_weight_now=0.5)
+    assert e.actor_step == 2
+    assert torch.equal(e.w2_f32i, f32_image_order(E.unpack(e.actor, E.ACTOR_LAYOUT)["full2.weight"]).to(e.w2_f32i.device))
+    assert torch.equal(e.act(obs), plain())
+
+
 @pytest.mark.parametrize("n,scenario", [(4096, "straight_line"), (131072, "mixed")])
 def test_bf16_act_step_is_act_then_step(mods, n, scenario):
     """hx_actor_act_step_bf16 (one launch up to 8,192 envs, two beyond) == hx_actor_act_bf16 followed by hx_env_step, bit for bit:
