@@ -348,7 +348,6 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
     const int in = J.m.in;
     // operands that do not depend on the prologue are requested first: their latency hides behind the gather
     BtFrag<H1 / KS> bfrag;
-    if (!WIDE) bfrag.load(J.net + J.m.W2() + (size_t)(nt * NT + (wave % CT) * 16 + (lane & 15)) * H1 + (wave / CT) * (H1 / KS));
     // layer 1 runs on MFMA: wave w owns hidden units 16 w .. 16 w + 15 of all 16 rows; lane (lr, lg) ends up with rows 4 lg .. 4 lg + 3 of unit u
     const int lr = lane & 15, lg = lane >> 4, u = wave * 16 + lr;
     STAMP_DECL;
@@ -386,6 +385,9 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
             else if (J.act_mode == 3) xv = J.noise[(size_t)(r0 + xr) * 4 + (xc - 13)];        // action rows of an earlier kernel (SAC)
         }
     }
+    // the W2 fragment of the MFMA phase: 64 separate 16-byte requests per load (adjacent lanes are adjacent COLUMNS, 1 KB apart in the
+    // row-major matrix) — behind the prologue's own operands, not in front of them
+    if (!WIDE) bfrag.load(J.net + J.m.W2() + (size_t)(nt * NT + (wave % CT) * 16 + (lane & 15)) * H1 + (wave / CT) * (H1 / KS));
     STAMP();
     if (head_mode && wave < nrow) {
         // head of the previous net: wave w owns row w (its loads go out right behind the ones above, nothing waited on yet)
