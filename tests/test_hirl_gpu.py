@@ -448,6 +448,36 @@ def test_deferred_draw_is_bit_identical_to_the_sampling_launch(eng_mod, staged, 
         assert torch.equal(getattr(a, name), getattr(b, name)), name
 
 
+@pytest.mark.parametrize("batch", [256, 512])
+def test_deferred_draw_at_other_batch_sizes(eng_mod, batch):
+    """hx_hirl_learn_sampled at the largest batch whose draw still runs inside launch A (256) and at one that falls back to the sampling
+    launch inside the same call (512): indices, tiles and the updated networks equal sample() + learn() bit for bit."""
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    params = D.make_params(33)
+    rng = np.random.default_rng(batch)
+    rep = DeviceReplay(9000)
+    rep.ring.copy_(torch.from_numpy(rng.normal(size=(9000, 32)).astype(np.float32)))
+    rep.ring[:, 31] = (rep.ring[:, 31] > 1.0).float()
+    rep.total += 2 * batch
+    exp = DeviceReplay(300)
+    exp.store_rows(torch.from_numpy(rng.normal(size=(260, 32)).astype(np.float32)))
+    bc = torch.from_numpy(rng.normal(size=(2 * batch, 32)).astype(np.float32)).cuda()
+    a, b = (eng_mod.HirlEngine(batch=batch) for _ in range(2))
+    for e in (a, b):
+        e.load_params(params["actor"], params["critic"], params["bc_actor"])
+    for k in range(6):
+        outs = []
+        for e, defer in ((a, False), (b, True)):
+            idx, idx_bc, noise = e.sample(rep, exp, bc, n_main=batch - 32, seed=5, defer=defer)
+            e.learn(bc_weight_now=100 if k % 2 == 0 else None, bc_warm_up_weight=0.1)
+            outs.append((idx.clone(), idx_bc.clone(), noise.clone(), e.rows.clone(), e.bc_rows.clone()))
+        for x, y, name in zip(outs[0], outs[1], ("idx", "idx_bc", "noise", "rows", "bc_rows")):
+            assert torch.equal(x, y), (k, name)
+    for name in ("actor", "critic", "target_actor", "target_critic", "m_actor", "v_actor", "m_critic", "v_critic"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
 def test_staged_path_equals_fused_path(eng_mod):
     """The stage-by-stage sequence a sharded run uses (critic_grads -> [all-reduce] -> adam -> actor_backward -> [all-reduce
     count] -> actor_wgrad -> [all-reduce] -> adam -> polyak) and the single-GPU one-call path (actor forwards folded into the
