@@ -727,7 +727,6 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     typedef HeadImage<GAUSS ? 8 : 4> Img;
     static_assert(Img::kStride <= ROWS * LDA1 + ROWS * XP + ROWS * 2 + H1 * 13, "the head image reuses the prologue's LDS");
     Img himg;
-    himg.fetch(net, m, tid);
     float* hps = lds;
     // all independent operands first
     float xv = 0.0f;
@@ -738,6 +737,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < H1 * 13 / 4) wv = reinterpret_cast<const float4*>(net + m.W1())[tid];
     const float bias1 = net[m.b1() + u], g1v = net[m.g1() + u], be1v = net[m.be1() + u];
+    himg.fetch(net, m, tid);  // (needed last: behind the prologue's own operands)
     if constexpr (!BF16 && !F32I) {  // behind the prologue's own operands
         ACT_LOAD(ra2, rb2, 2);
         ACT_LOAD(ra3, rb3, 3);
@@ -1271,7 +1271,6 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
 
     // ---------------- issue phase ----------------
     BFrag<H2 / kKSB> bfrag;
-    bfrag.load(J.net + J.m.W2() + (size_t)(kq * (H2 / kKSB)) * H1 + n0 + (lane & 15), H1);
     // Row loads are UNCONDITIONAL (R is clamped to a valid row; a wave without a row never uses them): behind `if (live)` the compiler
     // zero-fills the registers, loads under a branch and — where the two versions merge — WAITS for the loads in the middle of the issue phase.
     RowReg<H2> z, za, zb;
@@ -1336,6 +1335,8 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
         }
     }
     const float st1v = tid < nrow * 2 ? J.ws.st1[(size_t)r0 * 2 + tid] : (tid & 1 ? 1.0f : 0.0f);
+    // the W2 fragment of the MFMA phase (16 loads per lane, needed last) goes out behind the prologue's operands, not in front of them
+    bfrag.load(J.net + J.m.W2() + (size_t)(kq * (H2 / kKSB)) * H1 + n0 + (lane & 15), H1);
     // ---------------- one wait: publish the shared operands in LDS ----------------
     if (tid < RT * 2) st1s[tid] = st1v;
     pv0.store(hps, J.net, J.m, tid);
@@ -1924,7 +1925,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         const bool b3live = vb == 0 && oitem == 3 + OW && ocol < J.m.out;  // (item 3 + OW of the reduction tile carries db3)
         const unsigned b3idx = (unsigned)(J.m.b3() + (ocol < J.m.out ? ocol : 0));
         AdamElem vae;
-        if (ADAM && (vlive || b3live)) vae.fetch(J, b3live ? b3idx : vidx);
+        bool vae_pending = ADAM && (vlive || b3live);  // its operands are needed last: requested behind the first chunk's loads
         #pragma unroll
         for (int s = 0; s < 2; ++s) if (s < J.nslots) {  // compile-time slot index: J lives in registers, not in scratch
             const Slot& S = J.ws[s];
@@ -1946,6 +1947,10 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                 const float2 st2v = *reinterpret_cast<const float2*>(S.st2 + (size_t)(c0 + er) * 2);
                 const float4 d4 = *reinterpret_cast<const float4*>(S.dout + (size_t)(c0 + er) * OW);
                 const float4 d5 = *reinterpret_cast<const float4*>(S.dout + (size_t)(c0 + er) * OW + 4);
+                if (vae_pending) {
+                    vae.fetch(J, b3live ? b3idx : vidx);
+                    vae_pending = false;
+                }
                 __syncthreads();
                 if (tid < nr) {
                     float4* r4 = reinterpret_cast<float4*>(rinfo + tid * RP);
@@ -2027,7 +2032,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         const unsigned lidx = (unsigned)(oitem == 0 ? J.m.b1() + ok : oitem == 1 ? J.m.g1() + ok : oitem == 2 ? J.m.be1() + ok : J.m.W1() + ok * in + (oitem - 3));
         const bool llive = oitem < 3 + in;
         AdamElem lae;
-        if (ADAM && llive) lae.fetch(J, lidx);
+        bool lae_pending = ADAM && llive;  // needed last: requested behind the first chunk's loads
         #pragma unroll
         for (int s = 0; s < 2; ++s) if (s < J.nslots) {  // compile-time slot index: J lives in registers, not in scratch
             const Slot& S = J.ws[s];
@@ -2054,6 +2059,10 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                 const float2 st1v = *reinterpret_cast<const float2*>(S.st1 + (size_t)(c0 + er) * 2);
                 const float4* lp4 = reinterpret_cast<const float4*>(S.lnp + (size_t)(c0 + er) * (2 * kColWgB));  // [8 column workgroups][2]
                 const float4 l0 = lp4[0], l1 = lp4[1], l2 = lp4[2], l3 = lp4[3];
+                if (lae_pending) {
+                    lae.fetch(J, lidx);
+                    lae_pending = false;
+                }
                 __syncthreads();
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
