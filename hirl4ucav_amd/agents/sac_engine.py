@@ -16,7 +16,7 @@ _P = ctypes.POINTER
 
 class HxSacNets(ctypes.Structure):
     _fields_ = [(k, _vp) for k in ("policy", "critic", "target_critic", "grad_policy", "grad_critic", "m_policy", "v_policy", "m_critic",
-                                   "v_critic", "losses", "alpha_state", "ws")]
+                                   "v_critic", "losses", "alpha_state", "ws", "policy_w2_f32i")]
 
 
 class HxSacBatch(ctypes.Structure):
@@ -26,6 +26,9 @@ class HxSacBatch(ctypes.Structure):
 _lib.register("hx_sac_act", [_vp, _vp, ctypes.c_int64, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp])
 _lib.register("hx_sac_act_step", [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
                                    _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
+_lib.register("hx_sac_act_f32i", [_vp, _vp, _vp, ctypes.c_int64, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp])
+_lib.register("hx_sac_act_step_f32i", [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32,
+                                        ctypes.c_uint32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
 _lib.register("hx_sac_critic_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _i32, _vp])
 _lib.register("hx_sac_policy_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _vp])
 _lib.register("hx_sac_adam", [_P(HxSacNets), _P(E.HxHyper), _i32, _i32, _f32, _f32, _vp])
@@ -95,7 +98,10 @@ class SacEngine:
         self.alpha_state[3] = 1.0  # log_alpha = 0 -> alpha = 1  (agent.py:106-107)
         self.nets = HxSacNets(*(t.data_ptr() for t in (self.policy, self.critic, self.target_critic, self.grad_policy, self.grad_critic,
                                                         self.m_policy, self.v_policy, self.m_critic, self.v_critic, self.losses,
-                                                        self.alpha_state, self.ws)))
+                                                        self.alpha_state, self.ws)), None)
+        # fp32 image of the policy's W2 in the acting kernel's operand order (hx_pack_w2_f32i): kept current by hx_sac_adam(which = 1)
+        self.w2_f32i = torch.zeros(512 * 256, dtype=torch.float32, device=self.device)
+        self.nets.policy_w2_f32i = self.w2_f32i.data_ptr()
         self.hyper = E.HxHyper(gamma, tau, lr, lr, 0.0, 0.5, 0.0, 0)
         self.target_entropy, self.interval = float(target_entropy), int(target_update_interval)
         self.learning_steps = 0
@@ -109,6 +115,14 @@ class SacEngine:
         self.critic[Q_SIZE:].copy_(pack_mlp(q2, Q_BLOCK, Q_SIZE, 17, 1, self.device))
         if hard_update_target:  # hard_update(critic_target, critic), agent.py:92
             self.target_critic.copy_(self.critic)
+        self.refresh_images()
+
+    def refresh_images(self):
+        """Rebuild the acting kernel's image of the policy's W2 (after load_params / a checkpoint restore or any direct write to
+        `self.policy`; the policy's Adam step maintains it otherwise)."""
+        _lib.call("hx_pack_w2_f32i", self.policy.data_ptr(), 13, self.w2_f32i.data_ptr(), _lib.stream_ptr())
+
+    refresh_bf16 = refresh_images  # (the name utils/checkpoint.py calls after a restore)
 
     def replica_checksum(self):
         """int64 sum of the bit patterns of the networks, Adam moments and log-alpha state: equal on all ranks of a sharded run."""
@@ -147,8 +161,8 @@ class SacEngine:
             out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         mode = 0 if not explore else (1 if eps is not None else 2)
         self.act_calls += 1
-        _lib.call("hx_sac_act", self.policy.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode, _lib.ptr(eps), int(seed), int(row0),
-                  self.act_calls, None, _lib.stream_ptr())
+        _lib.call("hx_sac_act_f32i", self.policy.data_ptr(), self.w2_f32i.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode, _lib.ptr(eps),
+                  int(seed), int(row0), self.act_calls, _lib.stream_ptr())
         return out
 
     def act_step(self, env, eps=None, explore=True, seed=0, out=None):
@@ -159,8 +173,8 @@ class SacEngine:
             out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         mode = 0 if not explore else (1 if eps is not None else 2)
         self.act_calls += 1
-        _lib.call("hx_sac_act_step", self.policy.data_ptr(), env.state.data_ptr(), n, n, env.obs.data_ptr(), out.data_ptr(), mode,
-                  _lib.ptr(eps), int(seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(), env.done.data_ptr(),
+        _lib.call("hx_sac_act_step_f32i", self.policy.data_ptr(), self.w2_f32i.data_ptr(), env.state.data_ptr(), n, n, env.obs.data_ptr(),
+                  out.data_ptr(), mode, _lib.ptr(eps), int(seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(), env.done.data_ptr(),
                   env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
         return out, env.obs, env.reward, env.done, env.success
 

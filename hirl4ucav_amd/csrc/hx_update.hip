@@ -952,10 +952,13 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             float o[8];
             head_regs<8, 8, RELU>(z, hps, m.out, slope, xh, y, mean, rstd, o, m.no_ln);
             if (lane < 4) {
-                const float mu = pick8(o, lane);
+                // (selected from VALUES: a select chain over the elements of the array itself is folded back into a run-time index, which
+                //  puts the array in scratch or — promoted — in 32 KB of LDS)
+                const float o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3], o4 = o[4], o5 = o[5], o6 = o[6], o7 = o[7];
+                const float mu = lane == 0 ? o0 : lane == 1 ? o1 : lane == 2 ? o2 : o3;
                 float a = mu;
                 if (A.mode != 0) {
-                    const float ls = fminf(fmaxf(pick8(o, 4 + lane), -20.0f), 2.0f);  // model.py:65-66
+                    const float ls = fminf(fmaxf(lane == 0 ? o4 : lane == 1 ? o5 : lane == 2 ? o6 : o7, -20.0f), 2.0f);  // model.py:65-66
                     const float e = A.mode == 1 ? A.noise[(size_t)r * 4 + lane] : philox_normal(A.row0 + (uint32_t)r, A.call, 0x53414331u, A.seed, lane);
                     a = mu + expf(ls) * e;
                 }
@@ -1116,7 +1119,7 @@ static void launch_act(const ActFusedArgs& H, hipStream_t st) {
     // the activation is a compile-time ReLU when the slope is 0 (HIRL, SAC; the Gaussian policy is a Linear-ReLU stack by definition)
     if (GAUSS || H.slope == 0.0f) {
         if (H.w2b) launch_act_t<GAUSS, true, true>(H, st);
-        else if (!GAUSS && H.w2f) launch_act_t<false, false, true, true>(H, st);
+        else if (H.w2f) launch_act_t<GAUSS, false, true, true>(H, st);
         else launch_act_t<GAUSS, false, true>(H, st);
     } else {
         if (H.w2b) launch_act_t<false, true, false>(H, st);
@@ -2981,33 +2984,53 @@ static void sac_slots(const HxSacNets* N, int B, Slot* s) {
 
 /* SacAgent.explore / exploit (SAC/agent.py:183-196) for `rows` observations.  mode 0: exploit = tanh(mean); 1: sample with the
  * standard-normal draws eps[rows][4]; 2: sample with Philox(seed; row0 + row, call).  ws: unused since the whole policy runs in one kernel (may be NULL). */
-int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps, uint64_t seed,
-               uint32_t row0, uint32_t call, float* ws, void* stream) {
+static int sac_act_impl(const float* policy, const float* w2f, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps,
+                        uint64_t seed, uint32_t row0, uint32_t call, void* stream) {
     HX_REQUIRE(policy && obs && actions && rows > 0 && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act: bad arguments");
-    (void)ws;
     ActFusedArgs H{policy, kPolicy, const_cast<float*>(obs), (int)rows, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
-                   nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0, nullptr};
+                   nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0, nullptr, w2f};
     launch_act<true>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_sac_act");
     return 0;
 }
+int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps, uint64_t seed,
+               uint32_t row0, uint32_t call, float* ws, void* stream) {
+    (void)ws;
+    return sac_act_impl(policy, nullptr, obs, rows, actions, mode, eps, seed, row0, call, stream);
+}
+int hx_sac_act_f32i(const float* policy, const float* w2_f32i, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps,
+                    uint64_t seed, uint32_t row0, uint32_t call, void* stream) {
+    HX_REQUIRE(w2_f32i && (reinterpret_cast<uintptr_t>(w2_f32i) & 15u) == 0, "hx_sac_act_f32i: w2_f32i must be a 16-byte aligned fp32 image of W2");
+    return sac_act_impl(policy, w2_f32i, obs, rows, actions, mode, eps, seed, row0, call, stream);
+}
 
 /* SacAgent.explore / exploit + HarfangEnv.step in one launch (train_sac.py:238-241): hx_sac_act, then hx_env_step in the kernel's tail. */
-int hx_sac_act_step(const float* policy, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t mode,
-                    const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,
-                    const HxStepOpts* opts, void* stream) {
+static int sac_act_step_impl(const float* policy, const float* w2f, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t mode,
+                             const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,
+                             const HxStepOpts* opts, void* stream) {
     HX_REQUIRE(policy && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act_step: bad arguments");
     const HxStepOpts o = opts ? *opts : HxStepOpts{};
     if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_sac_act_step")) return rc;
     if (n > kFuseEnvMax) {
-        if (int rc = hx_sac_act(policy, obs_io, n, actions, mode, eps, seed, row0, call, nullptr, stream)) return rc;
+        if (int rc = sac_act_impl(policy, w2f, obs_io, n, actions, mode, eps, seed, row0, call, stream)) return rc;
         return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
     }
     ActFusedArgs H{policy, kPolicy, obs_io, (int)n, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
-                   state, stride, reward, done, success, o, o.cap > 0 ? 1.0 / (double)o.cap : 0.0, nullptr};
+                   state, stride, reward, done, success, o, o.cap > 0 ? 1.0 / (double)o.cap : 0.0, nullptr, w2f};
     launch_act<true>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_sac_act_step");
     return 0;
+}
+int hx_sac_act_step(const float* policy, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t mode,
+                    const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,
+                    const HxStepOpts* opts, void* stream) {
+    return sac_act_step_impl(policy, nullptr, state, n, stride, obs_io, actions, mode, eps, seed, row0, call, reward, done, success, opts, stream);
+}
+int hx_sac_act_step_f32i(const float* policy, const float* w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io, float* actions,
+                         int32_t mode, const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done,
+                         int8_t* success, const HxStepOpts* opts, void* stream) {
+    HX_REQUIRE(w2_f32i && (reinterpret_cast<uintptr_t>(w2_f32i) & 15u) == 0, "hx_sac_act_step_f32i: w2_f32i must be a 16-byte aligned fp32 image of W2");
+    return sac_act_step_impl(policy, w2_f32i, state, n, stride, obs_io, actions, mode, eps, seed, row0, call, reward, done, success, opts, stream);
 }
 
 /* Critic half of SacAgent.learn (SAC/agent.py:278-313): [Polyak of the target critics first when polyak_first], a', H' =
@@ -3152,6 +3175,10 @@ int hx_sac_adam(const HxSacNets* N, const HxHyper* Hy, int32_t which, int32_t st
     A.bc2_sqrt = (float)sqrt(bc2);
     A.gscale = grad_scale;
     A.losses = N->losses;
+    if (which == 1 && N->policy_w2_f32i) {  // the acting kernel's image of the policy's W2 follows its optimizer step
+        A.w2f = N->policy_w2_f32i;
+        A.w2_lo = kPolicy.W2();
+    }
     if (which == 1) {
         A.alpha_state = N->alpha_state;
         A.target_entropy = target_entropy;

@@ -300,6 +300,8 @@ typedef struct HxSacNets {
     float* losses;      /* [8]: q1_loss, q2_loss, policy_loss, entropy_loss, mean entropy, alpha */
     float* alpha_state; /* [4]: log_alpha, its Adam m and v, alpha = exp(log_alpha)  (SAC/agent.py:106-108) */
     float* ws;          /* hx_sac_workspace_floats(batch) */
+    float* policy_w2_f32i; /* NULL, or the fp32 image of the policy's W2 (hx_pack_w2_f32i(policy, 13, ...)): hx_sac_adam(which = 1) keeps it
+                              current, hx_sac_act*_f32i read it */
 } HxSacNets;
 
 typedef struct HxSacBatch {
@@ -317,6 +319,12 @@ int64_t hx_sac_workspace_floats(int32_t batch);
  * Philox4x32-10(seed; row0 + row, call).  ws: unused (may be NULL). */
 int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps,
                uint64_t seed, uint32_t row0, uint32_t call, float* ws, void* stream);
+/* The same from the re-ordered fp32 image of the policy's W2 (see hx_actor_act_f32i): bit-identical results, W2 straight into registers. */
+int hx_sac_act_f32i(const float* policy, const float* w2_f32i, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps,
+                    uint64_t seed, uint32_t row0, uint32_t call, void* stream);
+int hx_sac_act_step_f32i(const float* policy, const float* w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io, float* actions,
+                         int32_t mode, const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done,
+                         int8_t* success, const HxStepOpts* opts /* host, may be NULL */, void* stream);
 /* SacAgent.explore / exploit + HarfangEnv.step in one launch (train_sac.py:238-241). */
 int hx_sac_act_step(const float* policy, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t mode,
                     const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,

@@ -122,6 +122,41 @@ def test_sac_learn_matches_oracle_and_reference(SE, golden_dir):
     assert e.learning_steps == 8
 
 
+@pytest.mark.parametrize("n", [7, 4096, 16384])
+def test_sac_image_path_is_bit_identical_and_follows_adam(SE, n):
+    """hx_sac_act_f32i (the policy's W2 from its re-ordered fp32 image, what SacEngine.act uses) equals hx_sac_act (row-major W2 streamed
+    through LDS) BIT FOR BIT — exploit and Philox-sampled explore, 16- and 32-row workgroups — before and after policy Adam steps, and
+    the image is the permuted W2."""
+    from hirl4ucav_amd import _lib
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    params = sac_params()
+    e = SE.SacEngine(batch=128)
+    e.load_params(params["policy"], params["q1"], params["q2"])
+    rng = np.random.default_rng(n)
+    obs = torch.from_numpy(rng.uniform(-1, 1, (n, 13)).astype(np.float32)).cuda()
+    rep = DeviceReplay(4096)
+    rep.store_rows(torch.from_numpy(rng.normal(size=(2000, 32)).astype(np.float32)))
+
+    def image_of(policy_flat):
+        w2 = SE.unpack_mlp(policy_flat, SE.POLICY_BLOCK, 13, 8)
+        w2 = w2[[k for k in w2 if w2[k].shape == (512, 256)][0]]
+        return w2.reshape(32, 16, 16, 4, 4).permute(0, 2, 3, 1, 4).reshape(-1).to(e.w2_f32i.device)
+
+    def plain(mode, call):
+        out = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        _lib.call("hx_sac_act", e.policy.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode, None, 3, 0, call, None, _lib.stream_ptr())
+        return out
+
+    for round_ in range(2):
+        assert torch.equal(e.w2_f32i, image_of(e.policy))
+        assert torch.equal(e.act(obs, explore=False), plain(0, e.act_calls))
+        assert torch.equal(e.act(obs, explore=True, seed=3), plain(2, e.act_calls))
+        for _ in range(3):
+            e.sample(rep, seed=1)
+            e.learn()
+
+
 @pytest.mark.parametrize("n", [4096 + 17, 8192, 16384])  # 16-row / 32-row workgroups with the env tail; 16,384: the two-launch fallback
 def test_sac_act_step_in_one_launch_equals_act_then_step(SE, n):
     """hx_sac_act_step = hx_sac_act followed by hx_env_step (explore with given draws, with Philox, and exploit).  16,384 serpentine
