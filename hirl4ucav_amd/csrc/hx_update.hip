@@ -543,7 +543,8 @@ template <int OUTMAX>
 struct HeadImage {
     static constexpr int kStride = (2 + OUTMAX) * H2 + 8;
     static constexpr int kPer = ((2 + OUTMAX) * (H2 / 4) + kWide - 1) / kWide;  // float4 per thread to stage it
-    float4 v[kPer];
+    v4f v[kPer];  // (a native vector type: HIP's float4 is a struct whose copies become memcpy calls, and two of them in an array stay an
+                  //  alloca — in scratch, or promoted into 32 KB of LDS — instead of registers)
     float b3v;
     // g2, be2, W3 rows are contiguous in the parameter block from g2()
     __device__ __forceinline__ void fetch(const float* __restrict__ net, const Mlp& m, int tid) {
@@ -553,14 +554,14 @@ struct HeadImage {
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
             const int e = tid + i * kWide;
-            v[i] = reinterpret_cast<const float4*>(net + m.g2())[e < (2 + m.out) * (H2 / 4) ? e : 0];
+            v[i] = reinterpret_cast<const v4f*>(net + m.g2())[e < (2 + m.out) * (H2 / 4) ? e : 0];
         }
     }
     __device__ __forceinline__ void store(float* hp, const float* __restrict__ net, const Mlp& m, int tid) const {
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
             const int e = tid + i * kWide;
-            if (e < (2 + m.out) * (H2 / 4)) reinterpret_cast<float4*>(hp)[e] = v[i];
+            if (e < (2 + m.out) * (H2 / 4)) reinterpret_cast<v4f*>(hp)[e] = v[i];
         }
         (void)net;
         if (tid < m.out) hp[(2 + OUTMAX) * H2 + tid] = b3v;
