@@ -248,7 +248,7 @@ class Loop:
     def _learn(self, act_env):
         e = self.eng
         if self.sac:  # train_sac.py:401-403
-            e.sample(self.replay, seed=2 + self.rank)
+            e.sample(self.replay, seed=2 + self.rank, defer=not (self.args.sample_launch or self.args.overlap))
             e.learn()
             return
         # the draw and the gather ride in the first launch of learn() (hx_hirl_learn_sampled): same minibatch, one launch less

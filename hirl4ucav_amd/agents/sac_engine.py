@@ -30,6 +30,7 @@ _lib.register("hx_sac_act_f32i", [_vp, _vp, _vp, ctypes.c_int64, _vp, _i32, _vp,
 _lib.register("hx_sac_act_step_f32i", [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32,
                                         ctypes.c_uint32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
 _lib.register("hx_sac_critic_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _i32, _vp])
+_lib.register("hx_sac_critic_grads_sampled", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _P(E.HxSample), _i32, _vp])
 _lib.register("hx_sac_policy_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _vp])
 _lib.register("hx_sac_adam", [_P(HxSacNets), _P(E.HxHyper), _i32, _i32, _f32, _f32, _vp])
 
@@ -182,11 +183,19 @@ class SacEngine:
         _lib.call("hx_sample_batch", None, 0, ring.data_ptr(), None, 0, None, 0, self.batch, self.batch, 0, 0, 0, 0.0, idx.data_ptr(), None,
                   None, self.rows.data_ptr(), None, _lib.stream_ptr())
 
-    def sample(self, replay, expert=None, n_main=None, seed=0):
+    def sample(self, replay, expert=None, n_main=None, seed=0, defer=False):
         """memory.sample(batch_size) on the device (E-SAC: batch - expert_num rows from the memory followed by expert_num rows of
-        the expert memory, SAC/agent.py:286-296, train_sac.py:401-403) + the two standard-normal draw sets of the learn() call."""
+        the expert memory, SAC/agent.py:286-296, train_sac.py:401-403) + the two standard-normal draw sets of the learn() call.
+        defer=True: nothing is launched now — the next learn() draws and gathers inside its first launch (hx_sac_critic_grads_sampled)."""
         self.sample_calls += 1
         n_main = self.batch if (n_main is None or expert is None) else int(n_main)
+        self._seed = int(seed)
+        if defer:
+            self._pending = (E.HxSample(replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(),
+                                        expert.ring.data_ptr() if expert is not None else None, E.len_of(expert), None, 0, n_main, int(seed),
+                                        self.sample_calls, 0.0, self._idx.data_ptr(), None), replay, expert)
+            return
+        self._pending = None
         _lib.call("hx_sample_batch", replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(),
                   expert.ring.data_ptr() if expert is not None else None, E.len_of(expert), None, 0, self.batch, n_main,
                   1, int(seed), self.sample_calls, 0.0, self._idx.data_ptr(), None, self._noise.data_ptr(), self.rows.data_ptr(), None,
@@ -208,7 +217,12 @@ class SacEngine:
             batch = HxSacBatch(self.rows.data_ptr(), self.batch, None, None, getattr(self, "_seed", 0), self.learning_steps + 1)
         nets, hyper, gs = ctypes.byref(self.nets), ctypes.byref(self.hyper), 1.0 / self.world
         self.learning_steps += 1
-        _lib.call("hx_sac_critic_grads", nets, ctypes.byref(batch), hyper, int(self.learning_steps % self.interval == 0), st)
+        pending, self._pending = getattr(self, "_pending", None), None
+        if pending is not None:
+            _lib.call("hx_sac_critic_grads_sampled", nets, ctypes.byref(batch), hyper, ctypes.byref(pending[0]),
+                      int(self.learning_steps % self.interval == 0), st)
+        else:
+            _lib.call("hx_sac_critic_grads", nets, ctypes.byref(batch), hyper, int(self.learning_steps % self.interval == 0), st)
         self._allreduce(self.grad_critic)
         _lib.call("hx_sac_adam", nets, hyper, 0, self.learning_steps, gs, self.target_entropy, st)
         _lib.call("hx_sac_policy_grads", nets, ctypes.byref(batch), hyper, st)

@@ -2584,6 +2584,24 @@ static WgAdam make_adam(const HxNets* N, const HxHyper* Hy, float lr, int step, 
 }
 
 // adam_step > 0: the critic's optimizer step (and, with polyak, the soft_update of its target) rides in the wgrad launch
+// An HxSample for a launch-A draw: validated, then either the device-side description (batch <= 256: *fused = true, launch A draws and
+// gathers) or the sampling launch right here (larger batches).  rows / bc_rows / noise: the tiles the later launches read.
+static int prepare_draw(const HxSample* S, int B, float* rows, float* bc_rows, float* noise, void* stream, SampleDev* SD, bool* fused) {
+    HX_REQUIRE(S->total && S->cap > 0 && S->ring && S->idx && rows && S->n_main >= 0 && S->n_main <= B,
+               "hx_*_sampled: the draw needs total, cap, ring, idx and the output tile rows");
+    HX_REQUIRE(S->n_main == B || S->expert_ring, "hx_*_sampled: expert rows requested without an expert ring");
+    HX_REQUIRE(!S->bc_table == !S->idx_bc && (!S->bc_table || bc_rows), "hx_*_sampled: bc_table, idx_bc and bc_rows go together");
+    *fused = B <= kFusedBatchMax;
+    if (*fused) {
+        *SD = SampleDev{(const unsigned long long*)S->total, S->ring, S->expert_ring ? S->expert_ring : S->ring, S->bc_table, rows,
+                        S->bc_table ? bc_rows : nullptr, noise, S->idx, S->idx_bc, (long long)S->cap, (uint32_t)S->expert_len, (uint32_t)S->bc_len,
+                        S->n_main, S->call, S->seed, S->sigma};
+        return 0;
+    }
+    return hx_sample_batch(S->total, S->cap, S->ring, S->expert_ring, S->expert_len, S->bc_table, S->bc_len, B, S->n_main, 1, S->seed, S->call,
+                           S->sigma, S->idx, S->idx_bc, noise, rows, S->bc_table ? bc_rows : nullptr, stream);
+}
+
 static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, void* stream, int adam_step, bool polyak,
                              const HxSample* S = nullptr) {
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_critic_grads: batch must be a positive multiple of 16");
@@ -2592,20 +2610,8 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
     SampleDev SD{};
     bool fused = false;
     if (S) {  // the minibatch is drawn by this call: inside launch A (batch <= 256) or by the sampling launch first
-        HX_REQUIRE(S->total && S->cap > 0 && S->ring && S->idx && Bt->rows && Bt->noise && S->n_main >= 0 && S->n_main <= B,
-                   "hx_hirl_*_sampled: the draw needs total, cap, ring, idx and the output tiles rows / noise");
-        HX_REQUIRE(S->n_main == B || S->expert_ring, "hx_hirl_*_sampled: expert rows requested without an expert ring");
-        HX_REQUIRE(!S->bc_table == !S->idx_bc && (!S->bc_table || Bt->bc_rows), "hx_hirl_*_sampled: bc_table, idx_bc and bc_rows go together");
-        fused = B <= kFusedBatchMax;
-        if (fused) {
-            SD = SampleDev{(const unsigned long long*)S->total, S->ring, S->expert_ring ? S->expert_ring : S->ring, S->bc_table,
-                           const_cast<float*>(Bt->rows), S->bc_table ? const_cast<float*>(Bt->bc_rows) : nullptr, const_cast<float*>(Bt->noise),
-                           S->idx, S->idx_bc, (long long)S->cap, (uint32_t)S->expert_len, (uint32_t)S->bc_len, S->n_main, S->call, S->seed, S->sigma};
-        } else if (int rc = hx_sample_batch(S->total, S->cap, S->ring, S->expert_ring, S->expert_len, S->bc_table, S->bc_len, B, S->n_main, 1, S->seed,
-                                            S->call, S->sigma, S->idx, S->idx_bc, const_cast<float*>(Bt->noise), const_cast<float*>(Bt->rows),
-                                            S->bc_table ? const_cast<float*>(Bt->bc_rows) : nullptr, stream)) {
-            return rc;
-        }
+        HX_REQUIRE(Bt->noise, "hx_hirl_*_sampled: the draw needs the output word noise[4]");
+        if (int rc = prepare_draw(S, B, const_cast<float*>(Bt->rows), const_cast<float*>(Bt->bc_rows), const_cast<float*>(Bt->noise), stream, &SD, &fused)) return rc;
     }
     Slot s[S_COUNT];
     make_slots(N, B, s);
@@ -3037,10 +3043,16 @@ int hx_sac_act_step_f32i(const float* policy, const float* w2_f32i, float* state
 /* Critic half of SacAgent.learn (SAC/agent.py:278-313): [Polyak of the target critics first when polyak_first], a', H' =
  * policy.sample(s') with eps_next, y = r + (1 - d) gamma (min Q_target(s', a') + alpha H'), q1_loss / q2_loss -> losses[0..1],
  * grad_critic.  Also evaluates policy(s) for the policy half.  Follow with hx_sac_adam(which = 0). */
-int hx_sac_critic_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, int32_t polyak_first, void* stream) {
+static int sac_critic_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t polyak_first, void* stream) {
     HX_REQUIRE(N && Bt && Hy && Bt->rows && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_sac_critic_grads: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int B = Bt->batch;
+    SampleDev SD{};
+    bool fused = false;
+    if (S) {  // memory.sample(batch_size) inside the first forward launch (or, batch > 256, by the sampling launch right here)
+        HX_REQUIRE(!S->bc_table && !S->idx_bc, "hx_sac_critic_grads_sampled: SAC has no BC minibatch");
+        if (int rc = prepare_draw(S, B, const_cast<float*>(Bt->rows), nullptr, nullptr, stream, &SD, &fused)) return rc;
+    }
     Slot s[S_COUNT];
     sac_slots(N, B, s);
     const SacAux X = sac_aux(N, B);
@@ -3058,6 +3070,7 @@ int hx_sac_critic_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
         F.job[1] = FwdJob{N->policy, kPolicy, src, 0, 0, Head{}, nullptr, 0.f, s[SS_PC], B, 1};
         F.job[2] = FwdJob{q1, kQs, src, 0, 0, Head{}, nullptr, 0.f, s[SS_Q1], B, 1};
         F.job[3] = FwdJob{q2, kQs, src, 0, 0, Head{}, nullptr, 0.f, s[SS_Q2], B, 1};
+        F.sample = fused ? &SD : nullptr;
         launch_fwd(F, st);
     }
     {   // a', H' = policy.sample(s')
@@ -3096,6 +3109,15 @@ int hx_sac_critic_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
     }
     HX_CHECK_LAUNCH("hx_sac_critic_grads");
     return 0;
+}
+int hx_sac_critic_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, int32_t polyak_first, void* stream) {
+    return sac_critic_grads_impl(N, Bt, Hy, nullptr, polyak_first, stream);
+}
+/* The same with memory.sample (SAC/agent.py:286-296) drawn and gathered inside its first launch (HxSample without a BC table; Bt->rows is
+ * the output tile): bit-identical to hx_sample_batch followed by hx_sac_critic_grads. */
+int hx_sac_critic_grads_sampled(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t polyak_first, void* stream) {
+    HX_REQUIRE(S, "hx_sac_critic_grads_sampled: null sample description");
+    return sac_critic_grads_impl(N, Bt, Hy, S, polyak_first, stream);
 }
 
 /* Policy half (SAC/agent.py:315-319, 376-406): a~, H = policy.sample(s) with eps_cur, Q1/Q2(s, a~) with the UPDATED critics,

@@ -342,7 +342,7 @@ def main(config):
             expert_num = expert_num_after(expert_num, step, warm_up_rate)
             for _ in range(config.updates_per_step):
                 if sac:  # train_sac.py:270-273 (SAC) / :401-403 (E-SAC: expert rows mixed in while expert_num > 0)
-                    eng.sample(replay, expert if esac else None, n_main=batch - expert_num, seed=seed + 2 + rank)
+                    eng.sample(replay, expert if esac else None, n_main=batch - expert_num, seed=seed + 2 + rank, defer=True)
                     eng.learn()
                     continue
                 eng.sample(replay, expert, bc_table, n_main=batch - expert_num, seed=seed + 2 + rank, defer=True)  # drawn inside learn()'s first launch

@@ -336,6 +336,10 @@ int hx_sac_act_step(const float* policy, float* state, int64_t n, int64_t stride
  *   hx_sac_policy_grads   policy_loss = mean(-min Q(s, a~) - alpha H) with the updated critics :376-406 -> losses[2], grad_policy
  *   hx_sac_adam(1)        policy_optim.step() :318-319, then entropy_loss and alpha_optim.step() :322-325,408-414 */
 int hx_sac_critic_grads(const HxSacNets* nets, const HxSacBatch* batch, const HxHyper* hyper, int32_t polyak_first, void* stream);
+/* hx_sac_critic_grads with the minibatch drawn and gathered in its first launch (HxSample without a BC table; batch->rows is the output
+ * tile; batch <= 256 draws in-launch, larger batches run the sampling launch inside the call): same indices, tile and results. */
+int hx_sac_critic_grads_sampled(const HxSacNets* nets, const HxSacBatch* batch, const HxHyper* hyper, const HxSample* sample,
+                                int32_t polyak_first, void* stream);
 int hx_sac_policy_grads(const HxSacNets* nets, const HxSacBatch* batch, const HxHyper* hyper, void* stream);
 int hx_sac_adam(const HxSacNets* nets, const HxHyper* hyper, int32_t which, int32_t step, float grad_scale, float target_entropy,
                 void* stream);

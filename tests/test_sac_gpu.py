@@ -122,6 +122,36 @@ def test_sac_learn_matches_oracle_and_reference(SE, golden_dir):
     assert e.learning_steps == 8
 
 
+@pytest.mark.parametrize("esac", [False, True])
+def test_sac_deferred_draw_is_bit_identical_to_the_sampling_launch(SE, esac):
+    """sample(defer=True) + learn() (hx_sac_critic_grads_sampled: memory.sample inside the first forward launch) against sample() +
+    learn(): the same indices, row tile and — after 8 calls — the same networks, moments and alpha, bit for bit (SAC and E-SAC's expert mix)."""
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    params = sac_params()
+    rng = np.random.default_rng(3)
+    rep = DeviceReplay(5000)
+    rep.ring.copy_(torch.from_numpy(rng.normal(size=(5000, 32)).astype(np.float32)))
+    rep.ring[:, 31] = (rep.ring[:, 31] > 1.0).float()
+    rep.total += 150
+    exp = DeviceReplay(64)
+    exp.store_rows(torch.from_numpy(rng.normal(size=(50, 32)).astype(np.float32)))
+    a, b = (SE.SacEngine(batch=128) for _ in range(2))
+    for e in (a, b):
+        e.load_params(params["policy"], params["q1"], params["q2"])
+    for k in range(8):
+        if k == 4:
+            rep.total += 100000
+        outs = []
+        for e, defer in ((a, False), (b, True)):
+            e.sample(rep, exp if esac else None, n_main=100, seed=7, defer=defer)
+            e.learn()
+            outs.append((e._idx.clone(), e.rows.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), k
+    for name in ("policy", "critic", "target_critic", "m_policy", "v_policy", "m_critic", "v_critic", "alpha_state", "w2_f32i"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
 @pytest.mark.parametrize("n", [7, 4096, 16384])
 def test_sac_image_path_is_bit_identical_and_follows_adam(SE, n):
     """hx_sac_act_f32i (the policy's W2 from its re-ordered fp32 image, what SacEngine.act uses) equals hx_sac_act (row-major W2 streamed
