@@ -10,16 +10,18 @@
 //   UniformMemory.sample + minibatch assembly   hirl/utils/buffer.py:38-48, HIRL.py:223-251 (U6, U7): rows are gathered
 //                                               by index straight from the device-resident replay rings
 //
-// Structure (DESIGN.md "update kernels"): B = 128 is latency-bound (0.49 GFLOP per learn), so the ~1,770 eager ops
-// of the reference collapse into 5 launches (critic phase) + 6 (delayed actor phase).  Every launch is either
-//   fwd_l2   z2 = act(LN(x W1^T + b1)) W2^T + b2 for up to 3 independent nets; the 16-row layer-1 prologue (and, when the
-//            input action is another net's output, that net's LN2/final/tanh "head") is recomputed per workgroup,
-//            the 256->512 GEMM is tiled 16 rows x 64 columns per workgroup on fp32 MFMA (v_mfma_f32_16x16x4_f32:
-//            exact fp32, k-ordered fma chain — no bf16 rounding, parity holds at 1e-5);
+// Structure (DESIGN.md "update kernels"): B = 128 is 0.49 GFLOP per learn(), so the ~1,770 eager ops of the reference collapse into
+// 4 launches (critic-only call) or 8 (call with the delayed actor step), minibatch draw and optimizer steps included.  Every launch is
+//   fwd_l2   z2 = act(LN(x W1^T + b1)) W2^T + b2 for up to 4 independent nets; layer 1 (K = 13 / 17) on MFMA from LDS-staged operands, the
+//            previous net's LN2/final/tanh "head" recomputed per workgroup when the input action is another net's output, the
+//            256 -> 512 GEMM tiled 16 rows x 32 / 64 columns per workgroup on fp32 MFMA (v_mfma_f32_16x16x4_f32: fp32 products and
+//            sums, parity at 1e-5); the first forward launch can also draw and gather the minibatch (SAMPLE);
 //   bwd_l2   head + loss gradient + LN2 backward in the prologue, dh1 = dz2 W2 on MFMA;
-//   wgrad    dW2 = dz2^T h1 on MFMA (64x64 tiles) + the vector/LN/layer-1 gradients, written into a flat gradient
-//            buffer with the parameter layout (one all-reduce message per phase when sharded);
-//   adam / polyak  elementwise over the flat buffers, 16 B per lane.
+//   wgrad    dW2 = dz2^T h1 on MFMA (16 x 256 per workgroup) + the vector / LN / layer-1 gradients (32 columns x 32 row groups per
+//            workgroup), written into a flat gradient buffer with the parameter layout (one all-reduce message per phase when
+//            sharded); on one GPU the same threads apply Adam, the Polyak step of the target and refresh the W2 images (ADAM);
+//   adam / polyak  elementwise over the flat buffers, 16 B per lane (sharded path, SAC).
+// The kernels issue an instruction nearly every cycle of their life (16 waves per CU): their run time follows the instruction count.
 #include <cstdlib>
 #include <type_traits>
 
@@ -753,7 +755,6 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         // requested only now, behind the prologue's own operands: every workgroup pulls the whole 256 KB image through L2 (64 MB per
         // launch at 4,096 rows, ~6 us of L2 service); issued at kernel entry those requests queue up in front of OTHER workgroups'
         // small operands and stall every prologue for that long.  From here they overlap layer 1 and LayerNorm 1.
-        const int r = lane & 15, g = lane >> 4;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const uint16_t* blk = A.w2b + (size_t)((t * 16 + cw) * 8) * 512 + lane * 8;  // (lane = 16 g + r: w2_image_index's block order)
