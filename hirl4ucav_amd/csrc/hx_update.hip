@@ -331,12 +331,17 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
     constexpr int NTW = NT;
     constexpr int CT = WIDE ? 1 : NT / 16, KS = WIDE ? 1 : 16 / CT;  // column tiles / K-parts per workgroup (latency mode)
     constexpr int KRED = WIDE ? 4 : (KS - 1) * CT * 256;
-    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2 + KRED + H1 * 17 + 8];
+    // W2 tile of the workgroup's NT columns, [NT][LDA1] (latency modes): requested with COALESCED loads (a column's 16 or 32 threads cover 256
+    // or 512 contiguous bytes) and turned into MFMA operand order through LDS.  Straight into registers in operand order, adjacent lanes
+    // are adjacent columns, 1 KB apart in the row-major matrix: 64 separate 16-byte requests per load, 4,096 per workgroup.
+    constexpr int kW2S = WIDE ? 4 : NT * LDA1;
+    __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2 + KRED + H1 * 17 + 8 + kW2S];
     float* h1s = lds;
     float* xs = lds + RT * LDA1;
     float* sts = xs + RT * XP;
     float* kred = sts + RT * 2;   // [KS - 1 K-parts][CT column tiles][64 lanes][4]
     float* w1s = kred + KRED;     // W1 [256][in], staged with coalesced loads (a per-thread row walk is 17 scattered requests)
+    float* w2s = w1s + H1 * 17 + 8;
 
     // job = blockIdx.y; row tile / column tile from blockIdx.x
     const int b = blockIdx.x;
@@ -349,7 +354,10 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
     const float slope = jc.slope;
     const int in = J.m.in;
     // operands that do not depend on the prologue are requested first: their latency hides behind the gather
-    BtFrag<H1 / KS> bfrag;
+    // this thread's share of the W2 tile: column tid / TPC, 16-byte piece tid % TPC of each K section of TPC * 4 floats
+    constexpr int TPC = WIDE ? 16 : kWide / NT;       // threads per column: 16 (NT = 64) or 32 (NT = 32)
+    constexpr int NW2 = WIDE ? 1 : H1 / (TPC * 4);    // loads per thread: 4 or 2
+    v4f w2v[NW2];  // (native vectors: an array of HIP float4 stays an alloca)
     // layer 1 runs on MFMA: wave w owns hidden units 16 w .. 16 w + 15 of all 16 rows; lane (lr, lg) ends up with rows 4 lg .. 4 lg + 3 of unit u
     const int lr = lane & 15, lg = lane >> 4, u = wave * 16 + lr;
     STAMP_DECL;
@@ -389,7 +397,11 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
     }
     // the W2 fragment of the MFMA phase: 64 separate 16-byte requests per load (adjacent lanes are adjacent COLUMNS, 1 KB apart in the
     // row-major matrix) — behind the prologue's own operands, not in front of them
-    if (!WIDE) bfrag.load(J.net + J.m.W2() + (size_t)(nt * NT + (wave % CT) * 16 + (lane & 15)) * H1 + (wave / CT) * (H1 / KS));
+    if (!WIDE) {
+        const float* wcol = J.net + J.m.W2() + (size_t)(nt * NT + tid / TPC) * H1 + (tid % TPC) * 4;
+#pragma unroll
+        for (int i = 0; i < NW2; ++i) w2v[i] = *reinterpret_cast<const v4f*>(wcol + i * TPC * 4);
+    }
     STAMP();
     if (head_mode && wave < nrow) {
         // head of the previous net: wave w owns row w (its loads go out right behind the ones above, nothing waited on yet)
@@ -471,6 +483,10 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
             if (tid < nrow * XP) J.ws.x[(size_t)r0 * XP + tid] = xs[tid];
             if (tid < nrow * 2) J.ws.st1[(size_t)r0 * 2 + tid] = sts[tid];
         }
+        if (!WIDE) {
+#pragma unroll
+            for (int i = 0; i < NW2; ++i) *reinterpret_cast<v4f*>(w2s + (tid / TPC) * LDA1 + (tid % TPC) * 4 + i * TPC * 4) = w2v[i];
+        }
     }
     __syncthreads();
     STAMP();
@@ -492,7 +508,19 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
         const int n0 = nt * NT + ct * 16;
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_a_lds_bt_frag<H1 / KS>(h1s + kq * (H1 / KS), LDA1, bfrag, acc);
+        {   // A (h1) and B (W2 tile) fragments both from LDS: lane (r, g) reads 16 bytes at [row / column r][kq K/KS + 16 i + 4 g]
+            const float* ap = h1s + r * LDA1 + kq * (H1 / KS) + 4 * g;
+            const float* bp = w2s + (ct * 16 + r) * LDA1 + kq * (H1 / KS) + 4 * g;
+#pragma unroll
+            for (int i = 0; i < H1 / KS / 16; ++i) {
+                const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * i);
+                const float4 b4 = *reinterpret_cast<const float4*>(bp + 16 * i);
+                acc = mfma16(a4.x, b4.x, acc);
+                acc = mfma16(a4.y, b4.y, acc);
+                acc = mfma16(a4.z, b4.z, acc);
+                acc = mfma16(a4.w, b4.w, acc);
+            }
+        }
         if (kq) *reinterpret_cast<float4*>(kred + (((kq - 1) * CT + ct) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         __syncthreads();
         if (kq == 0) {
