@@ -1754,8 +1754,8 @@ struct WgArgs {
 __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float b1, float b2, float eps, float step_size, float bc2_sqrt) {
     m = __builtin_fmaf(g, 1.0f - b1, m * b1);
     v = __builtin_fmaf(g * g, 1.0f - b2, v * b2);
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
-    p = p - step_size * (m / denom);
+    const float denom = __builtin_amdgcn_sqrtf(v) * __builtin_amdgcn_rcpf(bc2_sqrt) + eps;  // hardware sqrt / reciprocal (1 ulp each)
+    p = p - step_size * (m * __builtin_amdgcn_rcpf(denom));
 }
 __device__ __forceinline__ float polyak_update(float target, float p, float tau) { return target * (1.0f - tau) + p * tau; }  // HIRL.py:13
 #pragma clang fp contract(fast)
