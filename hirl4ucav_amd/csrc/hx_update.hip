@@ -410,7 +410,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
         float mean, rstd, o[4];
         head_row<4, RELU>(J.prev.ws.z2 + (size_t)(r0 + r) * H2, J.prev.net, J.prev.m, slope, xh, y, mean, rstd, o);
         if (lane < 4) {
-            float a = tanhf(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // Actor.forward's tanh, HIRL.py:140
+            float a = fast_tanh(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // Actor.forward's tanh, HIRL.py:140
             if (J.noise) {              // target smoothing, HIRL.py:264-267
                 const float e = fminf(fmaxf(J.noise[lane], -J.noise_clamp), J.noise_clamp);
                 a = fminf(fmaxf(a + e, -1.0f), 1.0f);
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             float o[4];
             head_regs<4, 4, RELU>(z, hps, m.out, slope, xh, y, mean, rstd, o, m.no_ln);
             if (lane < 4) {
-                float a = tanhf(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // no dynamic register index
+                float a = fast_tanh(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // no dynamic register index
                 if (A.noise) {
                     a = fminf(fmaxf(a + A.noise[(A.noise_per_row ? (size_t)r * 4 : 0) + lane], -1.0f), 1.0f);
                 } else if (A.sigma > 0.0f) {
@@ -1437,13 +1437,13 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 da[jj] = wave_sum(da[jj]);
-                const float a = tanhf(o[jj]);
+                const float a = fast_tanh(o[jj]);
                 dout[jj] = da[jj] * (1.0f - a * a);
             }
         } else {  // BM_ACTOR_BC: bc_loss = lambda * mse(actor(s_bc), a_bc)  HIRL.py:310-311
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const float a = tanhf(o[jj]);
+                const float a = fast_tanh(o[jj]);
                 const float diff = a - tgt[jj];
                 dout[jj] = (2.0f * J.lambda * 0.25f * A.inv_batch) * diff * (1.0f - a * a);
                 part[2] += J.lambda * 0.25f * A.inv_batch * diff * diff;
@@ -1492,7 +1492,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
             }
             if (GRP != 3 && lane < 4) {
                 J.ws.dout[R * OW + lane] = dout[lane < OUTW ? lane : 0];
-                if (J.mode != BM_ACTOR_PI) J.ws.outv[R * OW + lane] = (J.m.out == 4) ? tanhf(o[lane < OUTW ? lane : 0]) : o[lane < OUTW ? lane : 0];
+                if (J.mode != BM_ACTOR_PI) J.ws.outv[R * OW + lane] = (J.m.out == 4) ? fast_tanh(o[lane < OUTW ? lane : 0]) : o[lane < OUTW ? lane : 0];
             }
         }
     }
