@@ -34,7 +34,7 @@ using namespace hxnn;
 // In-kernel phase stamps for diagnosis only (make STAMPS=1): s_memrealtime ticks (10 ns) between phases of ONE
 // workgroup land in hx_dbg; the shipped build compiles them out.
 #ifdef HX_STAMPS
-__device__ float hx_dbg[64];
+__device__ float hx_dbg[80];
 #define STAMP_DECL unsigned long long TS_[10]; int tsn_ = 0
 #define STAMP() TS_[tsn_++] = __builtin_amdgcn_s_memrealtime()
 #define STAMP_FLUSH(base, cond) do { if (cond) { for (int i_ = 1; i_ < tsn_; ++i_) hx_dbg[(base) + i_] = (float)(TS_[i_] - TS_[i_ - 1]); hx_dbg[(base)] = (float)tsn_; } } while (0)
@@ -705,6 +705,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     static_assert(!(BF16 && F32I), "one image format at a time");
     constexpr int ROWS = NRT * RT;
     __shared__ float s_act[ENV ? ROWS * 4 : 4];
+    __shared__ float s_noise[ROWS * 4];  // exploration noise of the workgroup's rows, drawn by the last wave(s) under the prologue's loads
     __shared__ unsigned s_base;  // ring slot of the workgroup's first row
     __shared__ int s_nstore;
     static_assert(2 * H2 * ACT_LDW >= ROWS * LDA2, "the z2 tile reuses the W2 chunk buffers");
@@ -772,6 +773,14 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     if constexpr (!BF16 && !F32I) {  // behind the prologue's own operands
         ACT_LOAD(ra2, rb2, 2);
         ACT_LOAD(ra3, rb3, 3);
+    }
+    // The standard-normal draws of the rows' exploration noise depend on (row, call, seed) only.  In the head they cost every wave ~320
+    // instructions for 4 useful lanes (Philox + Box-Muller with the library's log / sin / cos), 16 waves deep on an issue-bound phase;
+    // here ONE wave draws all 64 (row, component) values of a row tile while its own loads are in flight.  Same function, same bits.
+    const bool draw_noise = GAUSS ? (A.mode != 0 && A.mode != 1) : (!A.noise && A.sigma > 0.0f);
+    if (draw_noise && wave >= kWide / 64 - NRT) {
+        const int lrow = (kWide / 64 - 1 - wave) * RT + (lane >> 2);
+        s_noise[lrow * 4 + (lane & 3)] = philox_normal(A.row0 + (uint32_t)(r0 + lrow), A.call, GAUSS ? 0x53414331u : 0x61637421u, A.seed, lane & 3);
     }
     if (tid < H1 * 13 / 4) reinterpret_cast<float4*>(w1s)[tid] = wv;
     if (tid < ROWS * XP) xs[tid] = 0.0f;
@@ -972,8 +981,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
                 if (A.noise) {
                     a = fminf(fmaxf(a + A.noise[(A.noise_per_row ? (size_t)r * 4 : 0) + lane], -1.0f), 1.0f);
                 } else if (A.sigma > 0.0f) {
-                    const float n = philox_normal(A.row0 + (uint32_t)r, A.call, 0x61637421u, A.seed, lane);
-                    a = fminf(fmaxf(a + A.sigma * n, -1.0f), 1.0f);
+                    a = fminf(fmaxf(a + A.sigma * s_noise[lr * 4 + lane], -1.0f), 1.0f);
                 }
                 A.actions[(size_t)r * 4 + lane] = a;
                 if (ENV) s_act[lr * 4 + lane] = a;
@@ -989,7 +997,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
                 float a = mu;
                 if (A.mode != 0) {
                     const float ls = fminf(fmaxf(lane == 0 ? o4 : lane == 1 ? o5 : lane == 2 ? o6 : o7, -20.0f), 2.0f);  // model.py:65-66
-                    const float e = A.mode == 1 ? A.noise[(size_t)r * 4 + lane] : philox_normal(A.row0 + (uint32_t)r, A.call, 0x53414331u, A.seed, lane);
+                    const float e = A.mode == 1 ? A.noise[(size_t)r * 4 + lane] : s_noise[lr * 4 + lane];
                     a = mu + expf(ls) * e;
                 }
                 a = tanhf(a);
@@ -1003,6 +1011,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         float* s_row = wb1;                    // [ROWS][33] replay rows   (the odd chunk buffer is free since the last barrier)
         float* s_obs = wb1 + ROWS * kRowPitch;  // [ROWS][13] next observations
         __syncthreads();  // actions of all rows in s_act
+        STAMP();
         if (wave == 0 && lane < 2 * ROWS) {
             const int e = env_e;
             const bool is_opp = env_opp, own = !env_opp;
@@ -1032,6 +1041,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             unsigned st_kill = 0, st_fs = 0, st_tl = 0, st_fire = 0, st_good = 0, st_lock = 0;
             if (active) {
                 T.step(act, is_opp, eu, eu2, W);
+                STAMP();
                 unsigned ended_own = 0;
                 if (own) {
                     ended_own = (A.o.auto_reset && (W.done || trunc)) ? 1u : 0u;
@@ -1093,6 +1103,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
                     out[9] = eu.x; out[10] = eu.y; out[11] = eu.z;
                 }
             }
+            STAMP();
             if (A.o.stats) {
                 const bool mine_ = active && own;
                 const unsigned vals[HX_STAT_COUNT] = {(mine_ && ended) ? 1u : 0u, st_kill, st_fs, st_tl, st_fire, st_good, st_lock, mine_ ? 1u : 0u,
@@ -1106,7 +1117,9 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
                 if (lane < HX_STAT_COUNT && mine) atomicAdd((unsigned long long*)&A.o.stats[lane], (unsigned long long)mine);
             }
         }
+        STAMP();
         __syncthreads();  // rows, next observations, s_base / s_nstore
+        STAMP();
         for (int k = tid; k < nrow * HX_OBS_DIM; k += kWide) A.obs[(size_t)r0 * HX_OBS_DIM + k] = s_obs[k];
         const int nstore = s_nstore;
         if (nstore > 0) {  // 16 B per lane, rows contiguous in the ring (modulo wrap)
@@ -2474,7 +2487,7 @@ extern "C" {
 /* diagnostic builds only (make STAMPS=1): copy the 64 phase-stamp floats to host memory; returns -1 otherwise */
 int hx_debug_stamps(float* host_out) {
 #ifdef HX_STAMPS
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(hx_dbg), 64 * sizeof(float)) == hipSuccess ? 0 : -2;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(hx_dbg), 80 * sizeof(float)) == hipSuccess ? 0 : -2;
 #else
     (void)host_out;
     return -1;

@@ -136,7 +136,7 @@ int hx_label_transitions(const float* s, const float* a, const float* ns, int64_
  * Actor = one block (in 13, out 4) = 138,756 floats; Critic = two blocks (in 17, out 1), each padded from 138,241
  * to 138,244 floats so that the second head stays 16-byte aligned (hx_critic_param_count() = 276,488).
  * ------------------------------------------------------------------------------------------------------------ */
-int hx_debug_stamps(float* host_out /* host, 64 floats */); /* diagnostic builds only; -1 in the shipped build */
+int hx_debug_stamps(float* host_out /* host, 80 floats */); /* diagnostic builds only; -1 in the shipped build */
 int hx_actor_param_count(void);
 int hx_critic_param_count(void);
 int64_t hx_hirl_workspace_floats(int32_t batch);

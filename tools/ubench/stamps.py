@@ -23,7 +23,7 @@ e = loop.eng
 e.sample(loop.replay, loop.expert, loop.bc_table, n_main=128, seed=2)
 batch = HxBatch(e.rows.data_ptr(), e.bc_rows.data_ptr(), 128, e._noise.data_ptr())
 L = _lib.load()
-out = np.zeros(64, np.float32)
+out = np.zeros(80, np.float32)
 for i in range(3):
     # the one-call path: wgrad carries the optimizer step (critic-only call: critic_step i + 1, no actor phase)
     _lib.call("hx_hirl_learn", ctypes.byref(e.nets), ctypes.byref(batch), ctypes.byref(e.hyper), e.critic_step + i + 1, 0, 0, 0, 0, 0.0, 0.0, _lib.stream_ptr())
@@ -42,4 +42,4 @@ for dt in ("f32", "bf16"):
         e.act_step(loop.env, sigma=0.1, seed=1, out=loop.actions)
         torch.cuda.synchronize()
         assert L.hx_debug_stamps(out.ctypes.data_as(ctypes.c_void_p)) == 0
-        print(dt, "act+env x10ns: prologue %d | mfma %d | head+env %d" % tuple(out[57:60].tolist()))
+        print(dt, "act+env x10ns: prologue %d | mfma %d | head+sync %d | env step %d | reset/store/obs %d | stats %d | sync %d | ring+obs out %d" % tuple(out[57:65].tolist()))
