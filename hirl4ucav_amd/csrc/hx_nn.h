@@ -25,6 +25,7 @@ constexpr int LDA2 = H2 + 8;
 constexpr float LN_EPS = 1e-5f;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // offsets (in floats) inside one MLP block, reference state_dict order:
 // full{1,3}.weight, .bias, layernorm{1,3}.weight, .bias, full{2,4}.weight, .bias, layernorm{2,4}.weight, .bias, final.weight, .bias

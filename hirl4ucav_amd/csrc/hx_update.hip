@@ -38,10 +38,18 @@ __device__ float hx_dbg[80];
 #define STAMP_DECL unsigned long long TS_[10]; int tsn_ = 0
 #define STAMP() TS_[tsn_++] = __builtin_amdgcn_s_memrealtime()
 #define STAMP_FLUSH(base, cond) do { if (cond) { for (int i_ = 1; i_ < tsn_; ++i_) hx_dbg[(base) + i_] = (float)(TS_[i_] - TS_[i_ - 1]); hx_dbg[(base)] = (float)tsn_; } } while (0)
+// life span of EVERY workgroup of every launch (first stamp .. now), appended to a log: where a learn() spends its time BETWEEN workgroups
+constexpr int kSpanCap = 8192;
+__device__ unsigned long long hx_span[kSpanCap][2];
+__device__ unsigned hx_span_tag[kSpanCap];
+__device__ unsigned hx_span_n;
+#define SPAN_LOG() do { if (threadIdx.x == 0) { const unsigned long long e_ = __builtin_amdgcn_s_memrealtime(); const unsigned i_ = atomicAdd(&hx_span_n, 1u); \
+    if (i_ < (unsigned)kSpanCap) { hx_span[i_][0] = TS_[0]; hx_span[i_][1] = e_; hx_span_tag[i_] = (unsigned)__LINE__; } } } while (0)
 #else
 #define STAMP_DECL
 #define STAMP()
 #define STAMP_FLUSH(base, cond)
+#define SPAN_LOG()
 #endif
 
 namespace {
@@ -542,6 +550,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
         STAMP();
         STAMP_FLUSH(0, blockIdx.x == 5 && tid == 0);
     }
+    SPAN_LOG();
     if constexpr (SAMPLE) {
         if (blockIdx.y == 0) {  // what hx_sample_batch leaves behind: row tiles, indices, noise — read by the launches after this one
             if (nt == 0 && tid < nrow * 8) reinterpret_cast<float4*>(SA.rows)[(size_t)r0 * 8 + tid] = tile_piece;
@@ -578,13 +587,18 @@ struct HeadImage {
     float b3v;
     // g2, be2, W3 rows are contiguous in the parameter block from g2()
     __device__ __forceinline__ void fetch(const float* __restrict__ net, const Mlp& m, int tid) {
-        // unconditional loads from clamped (valid) addresses; store() keeps only the live ones.  A conditional load merges with its zero
-        // default through register copies that WAIT for the data — in the middle of the caller's issue phase.
-        b3v = net[m.b3() + (tid < m.out ? tid : 0)];
+        // Loads from clamped (valid) addresses, unconditional INSIDE a wave; store() keeps only the live ones.  (A load under a per-lane
+        // condition merges with its zero default through register copies that WAIT for the data — in the middle of the caller's issue
+        // phase.)  Whole waves past the image's end skip theirs behind a scalar branch: the address pipeline takes 16 lanes per clock
+        // whatever they ask for, and a one-output image is 6 waves' worth of the 16.
+        // (a skipping wave leaves its members unset — it never stores them; a default value would be merged with the loaded one through a
+        //  register copy that waits for the data, the very thing this function avoids)
+        const int w0 = __builtin_amdgcn_readfirstlane(tid);
+        if (w0 < m.out) b3v = net[m.b3() + (tid < m.out ? tid : 0)];
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
             const int e = tid + i * kWide;
-            v[i] = reinterpret_cast<const v4f*>(net + m.g2())[e < (2 + m.out) * (H2 / 4) ? e : 0];
+            if (w0 + i * kWide < (2 + m.out) * (H2 / 4)) v[i] = reinterpret_cast<const v4f*>(net + m.g2())[e < (2 + m.out) * (H2 / 4) ? e : 0];
         }
     }
     __device__ __forceinline__ void store(float* hp, const float* __restrict__ net, const Mlp& m, int tid) const {
@@ -1134,6 +1148,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     }
     STAMP();
     STAMP_FLUSH(56, (blockIdx.x == 0 || blockIdx.x == 200) && tid == 0);
+    SPAN_LOG();
 }
 
 // 16 rows per workgroup fill the chip up to 4,096 rows; from 8,192 rows on 32 rows per workgroup reuse every W2 chunk twice
@@ -1580,6 +1595,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
         }
         STAMP();
         STAMP_FLUSH(16, blockIdx.x == 3 && tid == 0);
+        SPAN_LOG();
     }
 }
 
@@ -1947,6 +1963,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         }
         STAMP();
         STAMP_FLUSH(32, blockIdx.x == 0 && blockIdx.y == 0 && tid == 0);
+        SPAN_LOG();
         return;
     }
     // Vector and layer-1 workgroups: 32 columns x 32 row groups (half a wave per row group): four batch rows per thread at B = 128.
@@ -1989,10 +2006,16 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                 }
                 // the per-row scalars are requested BEFORE the barrier that frees the LDS tile: one round trip with the loads above
                 static_assert(kWgRowChunk <= kWide, "staging: one row per thread");
+                // (whole waves without a row skip theirs behind a scalar branch: 2 of the 16 waves have rows at B = 128, and the address
+                //  pipeline takes 16 lanes per clock whatever they ask for)
                 const int er = tid < nr ? tid : 0;
-                const float2 st2v = *reinterpret_cast<const float2*>(S.st2 + (size_t)(c0 + er) * 2);
-                const float4 d4 = *reinterpret_cast<const float4*>(S.dout + (size_t)(c0 + er) * OW);
-                const float4 d5 = *reinterpret_cast<const float4*>(S.dout + (size_t)(c0 + er) * OW + 4);
+                v2f st2v;  // (unset in a skipping wave, which never stores it: see HeadImage::fetch)
+                v4f d4, d5;
+                if (__builtin_amdgcn_readfirstlane(tid) < nr) {
+                    st2v = *reinterpret_cast<const v2f*>(S.st2 + (size_t)(c0 + er) * 2);
+                    d4 = *reinterpret_cast<const v4f*>(S.dout + (size_t)(c0 + er) * OW);
+                    d5 = *reinterpret_cast<const v4f*>(S.dout + (size_t)(c0 + er) * OW + 4);
+                }
                 if (vae_pending) {
                     vae.fetch(J, b3live ? b3idx : vidx);
                     vae_pending = false;
@@ -2000,9 +2023,9 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                 __syncthreads();
                 if (tid < nr) {
                     float4* r4 = reinterpret_cast<float4*>(rinfo + tid * RP);
-                    r4[0] = make_float4(st2v.x, st2v.y, d4.x, d4.y);
-                    r4[1] = make_float4(d4.z, d4.w, d5.x, d5.y);
-                    r4[2] = make_float4(d5.z, d5.w, 0.0f, 0.0f);
+                    r4[0] = make_float4(st2v[0], st2v[1], d4[0], d4[1]);
+                    r4[1] = make_float4(d4[2], d4[3], d5[0], d5[1]);
+                    r4[2] = make_float4(d5[2], d5[3], 0.0f, 0.0f);
                 }
                 __syncthreads();
                 for (int rb = rg; rb < nr; rb += kWgRG * 4) {  // 4 rows per thread per block, all loads in flight together
@@ -2061,6 +2084,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         }
         STAMP();
         STAMP_FLUSH(40, b == kWgTilesPerBlock && j == 0 && tid == 0);
+        SPAN_LOG();
         return;
     }
     // layer 1: hidden unit k; dz1 = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) with the row means taken from the
@@ -2095,32 +2119,42 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                 }
                 // the chunk's shared operands are requested BEFORE the barrier that frees the LDS tiles: one round trip with the loads above
                 static_assert(kWgRowChunk * XP <= 5 * kWide && kWgRowChunk <= kWide && kColWgB == 8, "staging: five words + one row per thread");
+                // (whole waves past the end of a tile skip their loads behind a scalar branch: at B = 128 the input tile is 2.5 of the 5
+                //  passes and 2 of the 16 waves have a row; the address pipeline takes 16 lanes per clock whatever they ask for)
+                const int w0 = __builtin_amdgcn_readfirstlane(tid);
                 float xst[5];
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
                     const int e = tid + q * kWide;
-                    xst[q] = S.x[(size_t)c0 * XP + (e < nr * XP ? e : 0)];
+                    if (w0 + q * kWide < nr * XP) xst[q] = S.x[(size_t)c0 * XP + (e < nr * XP ? e : 0)];
                 }
                 const int er = tid < nr ? tid : 0;
-                const float2 st1v = *reinterpret_cast<const float2*>(S.st1 + (size_t)(c0 + er) * 2);
-                const float4* lp4 = reinterpret_cast<const float4*>(S.lnp + (size_t)(c0 + er) * (2 * kColWgB));  // [8 column workgroups][2]
-                const float4 l0 = lp4[0], l1 = lp4[1], l2 = lp4[2], l3 = lp4[3];
+                v2f st1v;  // (unset in a skipping wave, which never stores it)
+                v4f l0, l1, l2, l3;
+                if (w0 < nr) {
+                    st1v = *reinterpret_cast<const v2f*>(S.st1 + (size_t)(c0 + er) * 2);
+                    const v4f* lp4 = reinterpret_cast<const v4f*>(S.lnp + (size_t)(c0 + er) * (2 * kColWgB));  // [8 column workgroups][2]
+                    l0 = lp4[0]; l1 = lp4[1]; l2 = lp4[2]; l3 = lp4[3];
+                }
                 if (lae_pending) {
                     lae.fetch(J, lidx);
                     lae_pending = false;
                 }
+                STAMP();
                 __syncthreads();
+                STAMP();
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
                     const int e = tid + q * kWide;
                     if (e < nr * XP) xs[e] = xst[q];
                 }
                 if (tid < nr) {  // lnp_sum's fixed-order tree over the eight partials of each of the two row sums
-                    const float s1 = ((l0.x + l0.z) + (l1.x + l1.z)) + ((l2.x + l2.z) + (l3.x + l3.z));
-                    const float s2 = ((l0.y + l0.w) + (l1.y + l1.w)) + ((l2.y + l2.w) + (l3.y + l3.w));
-                    *reinterpret_cast<float4*>(rinfo + tid * 8) = make_float4(st1v.x, st1v.y, s1 * (1.0f / H1), s2 * (1.0f / H1));
+                    const float s1 = ((l0[0] + l0[2]) + (l1[0] + l1[2])) + ((l2[0] + l2[2]) + (l3[0] + l3[2]));
+                    const float s2 = ((l0[1] + l0[3]) + (l1[1] + l1[3])) + ((l2[1] + l2[3]) + (l3[1] + l3[3]));
+                    *reinterpret_cast<float4*>(rinfo + tid * 8) = make_float4(st1v[0], st1v[1], s1 * (1.0f / H1), s2 * (1.0f / H1));
                 }
                 __syncthreads();
+                STAMP();
                 for (int rb = rg; rb < nr; rb += kWgRG * 4) {
                     if (rb != rg) {
 #pragma unroll
@@ -2169,6 +2203,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         }
         STAMP();
         STAMP_FLUSH(48, b == kWgTilesPerBlock + kWgVecWgs && j == 0 && tid == 0);
+        SPAN_LOG();
     }
 }
 
@@ -2490,6 +2525,20 @@ int hx_debug_stamps(float* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(hx_dbg), 80 * sizeof(float)) == hipSuccess ? 0 : -2;
 #else
     (void)host_out;
+    return -1;
+#endif
+}
+/* diagnostic builds only: the workgroup life-span log (start, end in 10 ns ticks; tag = source line of the exit) -> host, then cleared */
+int hx_debug_spans(unsigned long long* host_spans /* [8192][2] */, unsigned* host_tags /* [8192] */, unsigned* host_n) {
+#ifdef HX_STAMPS
+    unsigned zero = 0u;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(host_n, HIP_SYMBOL(hx_span_n), sizeof(unsigned)) != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(host_spans, HIP_SYMBOL(hx_span), sizeof(unsigned long long) * 2 * kSpanCap) != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(host_tags, HIP_SYMBOL(hx_span_tag), sizeof(unsigned) * kSpanCap) != hipSuccess) return -2;
+    return hipMemcpyToSymbol(HIP_SYMBOL(hx_span_n), &zero, sizeof(unsigned)) == hipSuccess ? 0 : -2;
+#else
+    (void)host_spans; (void)host_tags; (void)host_n;
     return -1;
 #endif
 }

@@ -137,6 +137,7 @@ int hx_label_transitions(const float* s, const float* a, const float* ns, int64_
  * to 138,244 floats so that the second head stays 16-byte aligned (hx_critic_param_count() = 276,488).
  * ------------------------------------------------------------------------------------------------------------ */
 int hx_debug_stamps(float* host_out /* host, 80 floats */); /* diagnostic builds only; -1 in the shipped build */
+int hx_debug_spans(unsigned long long* host_spans /* [8192][2] */, unsigned* host_tags /* [8192] */, unsigned* host_n); /* same: workgroup life spans */
 int hx_actor_param_count(void);
 int hx_critic_param_count(void);
 int64_t hx_hirl_workspace_floats(int32_t batch);
