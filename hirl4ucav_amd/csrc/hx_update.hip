@@ -1831,26 +1831,32 @@ struct AdamElem {
     }
 };
 
-constexpr int kWgTilesPerBlock = H2 / 16;                // 32 workgroups: 16 (n) x 256 (k) of dW2, one 16 x 16 tile per wave
-constexpr int kWgCols = 32;                              // columns per vector / layer-1 workgroup (half a wave)
-constexpr int kWgVecWgs = H2 / kWgCols;                  // 16 workgroups: 32 columns x 32 row groups, 512-wide vector gradients
-constexpr int kWgL1Wgs = H1 / kWgCols;                   // 8 workgroups: layer-1 gradients, 32 units x 32 row groups
-constexpr int kWgRG = kWide / kWgCols;                   // row groups = half waves: the batch rows of a column are split 32 ways
+// 112 workgroups per job: the critic launch (two jobs) is 224 of the 256 CUs, ONE round.  Half the rows per thread of the 56-workgroup
+// partition before it: a workgroup's time is its operands' round trip plus rows-per-thread of arithmetic, and the launch is as long as
+// its slowest workgroup.
+constexpr int kWgTilesPerBlock = 2 * (H2 / 16);          // 64 workgroups: 16 (n) x 128 (k) of dW2; a 16 x 16 tile per wave PAIR, each half of the rows
+constexpr int kWgCols = 16;                              // columns per vector / layer-1 workgroup (a quarter wave)
+constexpr int kWgVecWgs = H2 / kWgCols;                  // 32 workgroups: 16 columns x 64 row groups, 512-wide vector gradients
+constexpr int kWgL1Wgs = H1 / kWgCols;                   // 16 workgroups: layer-1 gradients, 16 units x 64 row groups
+constexpr int kWgRG = kWide / kWgCols;                   // row groups = quarter waves: the batch rows of a column are split 64 ways
 constexpr int kWgPerJob = kWgTilesPerBlock + kWgVecWgs + kWgL1Wgs;
 constexpr int kWgRowChunk = 256;                         // rows whose per-row scalars are staged in LDS at a time
 
 // fixed-order sum of the 16 row groups' partial results of one (column, item): red[group][64][kRedP]; the odd pitch keeps the 64 lanes of a
 // wave on 64 different banks (pitch 20: 16 banks, every read and write of the reduction four-way conflicted)
 constexpr int kRedP = 21;
-__device__ __forceinline__ float sum_groups(const float* p) {
-    float v[kWgRG];
+// two threads per (column, item): each sums 32 of the 64 row groups (tree), the even lane adds its neighbour's half (one DPP move)
+__device__ __forceinline__ float sum_groups(const float* p, int half) {
+    constexpr int N = kWgRG / 2;
+    float v[N];
 #pragma unroll
-    for (int g = 0; g < kWgRG; ++g) v[g] = p[g * kWgCols * kRedP];
+    for (int g = 0; g < N; ++g) v[g] = p[(half * N + g) * kWgCols * kRedP];
 #pragma unroll
-    for (int w = 1; w < kWgRG; w *= 2)
+    for (int w = 1; w < N; w *= 2)
 #pragma unroll
-        for (int g = 0; g < kWgRG; g += 2 * w) v[g] += v[g + w];
-    return v[0];
+        for (int g = 0; g < N; g += 2 * w) v[g] += v[g + w];
+    const float other = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[0]), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+    return half ? other + v[0] : v[0] + other;  // (groups 0..31) + (groups 32..63) on both lanes
 }
 
 // ADAM: each thread applies the optimizer step to the gradient elements it has just produced (every parameter's gradient is
@@ -1912,10 +1918,11 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
     }
 
     if (b < kWgTilesPerBlock) {
-        // dW2[n][k] = sum_r scale dz2[r][n] h1[r][k].  Wave tile 16 (n) x 16 (k); the reduction runs over the batch rows,
-        // 16 per MFMA group.  All operands of a 128-row chunk (32 + 32 dwords per lane) are requested before the first
-        // MFMA: with B = 128 the whole job is one round trip to L2 instead of one per 16 rows.
-        const int n0 = b * 16, k0 = wave * 16;
+        // dW2[n][k] = sum_r scale dz2[r][n] h1[r][k].  Tile 16 (n) x 16 (k) per wave PAIR (w, w + 8): each wave reduces over half of the
+        // batch rows, 16 per MFMA group; all operands of a 64-row chunk (16 + 16 dwords per lane) are requested before the first MFMA.
+        // The pair then swaps half of its accumulator through LDS: wave w finishes (and steps) elements 0, 1 of every lane, wave w + 8
+        // elements 2, 3 — two parameters per lane.
+        const int n0 = (b >> 1) * 16, k0 = (b & 1) * (H1 / 2) + (wave & 7) * 16, half = wave >> 3;
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
         #pragma unroll
@@ -1925,40 +1932,49 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
             const float* h1 = J.ws[s].h1;
             const unsigned dzo = (unsigned)(n0 + r), h1o = (unsigned)(k0 + r);
             const int rows = J.rows[s];
-            for (int c0 = 0; c0 < rows; c0 += 128) {
-                float av[32], hv[32];
+            const int hr = ((rows + 7) >> 3) << 2;  // rows per half, a multiple of the MFMA's 4
+            const int rbeg = half * hr, rend = min(rows, rbeg + hr);
+            for (int c0 = rbeg; c0 < rend; c0 += 64) {
+                float av[16], hv[16];
 #pragma unroll
-                for (int i = 0; i < 32; ++i) {
+                for (int i = 0; i < 16; ++i) {
                     const int row = c0 + 4 * i + g;  // MFMA i reduces over rows c0+4i .. c0+4i+3 (one per lane group)
                     const unsigned rc = (unsigned)(row < rows ? row : rows - 1);  // unconditional loads (clamped); rows past the end get scale 0
                     av[i] = dz[rc * (unsigned)H2 + dzo];
                     hv[i] = h1[rc * (unsigned)H1 + h1o];
                 }
 #pragma unroll
-                for (int i = 0; i < 32; ++i) acc = mfma16(av[i] * (c0 + 4 * i + g < rows ? sc : 0.0f), hv[i], acc);
+                for (int i = 0; i < 16; ++i) acc = mfma16(av[i] * (c0 + 4 * i + g < rend ? sc : 0.0f), hv[i], acc);
             }
         }
         STAMP();
-        // ADAM: this lane's four parameters are requested only now — the 64 operand registers of the reduction above are dead, so the
-        // launch keeps its 4 waves per SIMD without spilling; the round trip (L2-resident: touched once per learn()) is ~1 us
-        AdamElem ae[4];
+        // ADAM: this lane's two parameters are requested only now — the operand registers of the reduction above are dead; the round trip
+        // (L2-resident: touched once per learn()) hides under the pair's exchange
+        const int q0 = 2 * half;  // this wave finishes elements q0, q0 + 1
+        AdamElem ae[2];
         if (ADAM) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ae[q].fetch(J, J.m.W2() + (n0 + 4 * g + q) * H1 + k0 + r);
+            for (int q = 0; q < 2; ++q) ae[q].fetch(J, J.m.W2() + (n0 + 4 * g + q0 + q) * H1 + k0 + r);
         }
+        float2* xch = reinterpret_cast<float2*>(red);  // [8 pairs][2 halves][64 lanes]
+        xch[((wave & 7) * 2 + half) * 64 + lane] = half ? make_float2(acc[0], acc[1]) : make_float2(acc[2], acc[3]);
+        __syncthreads();
+        const float2 got = xch[((wave & 7) * 2 + (half ^ 1)) * 64 + lane];
+        // (first half of the rows) + (second half), whoever adds them
+        const float fin[2] = {half ? got.x + acc[2] : acc[0] + got.x, half ? got.y + acc[3] : acc[1] + got.y};
         float* out = J.grad + J.m.W2();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) out[(unsigned)((n0 + 4 * g + q) * H1 + k0 + r)] = acc[q];
+        for (int q = 0; q < 2; ++q) out[(unsigned)((n0 + 4 * g + q0 + q) * H1 + k0 + r)] = fin[q];
         if (ADAM) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = J.m.W2() + (n0 + 4 * g + q) * H1 + k0 + r;
-                ae[q].apply(J, A.ad, idx, acc[q]);
+            for (int q = 0; q < 2; ++q) {
+                const int idx = J.m.W2() + (n0 + 4 * g + q0 + q) * H1 + k0 + r;
+                ae[q].apply(J, A.ad, idx, fin[q]);
                 if (J.w2b) {
                     const __bf16 bv = (__bf16)ae[q].p;
-                    J.w2b[w2_image_index((uint32_t)(n0 + 4 * g + q), (uint32_t)(k0 + r))] = __builtin_bit_cast(uint16_t, bv);
+                    J.w2b[w2_image_index((uint32_t)(n0 + 4 * g + q0 + q), (uint32_t)(k0 + r))] = __builtin_bit_cast(uint16_t, bv);
                 }
-                if (J.w2f) J.w2f[w2f_image_index((uint32_t)(n0 + 4 * g + q), (uint32_t)(k0 + r))] = ae[q].p;
+                if (J.w2f) J.w2f[w2f_image_index((uint32_t)(n0 + 4 * g + q0 + q), (uint32_t)(k0 + r))] = ae[q].p;
             }
         }
         STAMP();
@@ -1966,11 +1982,12 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         SPAN_LOG();
         return;
     }
-    // Vector and layer-1 workgroups: 32 columns x 32 row groups (half a wave per row group): four batch rows per thread at B = 128.
-    // (64 columns x 16 row groups put eight rows on every thread: these workgroups, not the MFMA tiles, set the launch's duration.)
+    // Vector and layer-1 workgroups: 16 columns x 64 row groups (a quarter wave per row group): two batch rows per thread at B = 128.
+    // (64 columns x 16 row groups put eight rows on every thread, 32 x 32 four: these workgroups, not the MFMA tiles, set the launch's duration.)
     const int cl = lane & (kWgCols - 1);           // column inside the workgroup
-    const int rg = wave * 2 + (lane >> 5);         // row group: rows rg, rg + 32, ...
-    const int oitem = tid / kWgCols, ocol = tid % kWgCols;  // after the reduction: thread -> (item, column)
+    const int rg = tid / kWgCols;                  // row group: rows rg, rg + 64, ...
+    // after the reduction: thread pair -> (item, column); each thread of the pair sums half of the row groups
+    const int ohalf = tid & 1, oitem = (tid >> 1) / kWgCols, ocol = (tid >> 1) % kWgCols;
     if (b < kWgTilesPerBlock + kWgVecWgs) {
         // column n: db2, dg2, dbe2, dW3[j][n] (+ db3 by the first workgroup)
         constexpr int RP = 12;  // rinfo pitch: mean, rstd, dout[0..7], pad
@@ -1988,7 +2005,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         const bool b3live = vb == 0 && oitem == 3 + OW && ocol < J.m.out;  // (item 3 + OW of the reduction tile carries db3)
         const unsigned b3idx = (unsigned)(J.m.b3() + (ocol < J.m.out ? ocol : 0));
         AdamElem vae;
-        bool vae_pending = ADAM && (vlive || b3live);  // its operands are needed last: requested behind the first chunk's loads
+        bool vae_pending = ADAM && (vlive || b3live) && ohalf == 0;  // its operands are needed last: requested behind the first chunk's loads
         #pragma unroll
         for (int s = 0; s < 2; ++s) if (s < J.nslots) {  // compile-time slot index: J lives in registers, not in scratch
             const Slot& S = J.ws[s];
@@ -1998,9 +2015,9 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                 // this thread's first 4 rows are requested before the per-row scalars are staged: one round trip, not two
                 float zv[4], dv[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 4; ++i) if (kWgRG * i < nr) {  // (scalar: at B = 128 row blocks 2, 3 are past the end for every thread)
                     const int r = rg + kWgRG * i;
-                    const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H2 + (unsigned)n;  // unconditional, clamped
+                    const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H2 + (unsigned)n;  // unconditional inside a block, clamped
                     zv[i] = S.z2[o];
                     dv[i] = S.dz2[o];
                 }
@@ -2028,10 +2045,11 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                     r4[2] = make_float4(d5[2], d5[3], 0.0f, 0.0f);
                 }
                 __syncthreads();
-                for (int rb = rg; rb < nr; rb += kWgRG * 4) {  // 4 rows per thread per block, all loads in flight together
-                    if (rb != rg) {
+                for (int rb0 = 0; rb0 < nr; rb0 += kWgRG * 4) {  // 4 rows per thread per block, all loads in flight together
+                    const int rb = rg + rb0;
+                    if (rb0 != 0) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
+                        for (int i = 0; i < 4; ++i) if (rb0 + kWgRG * i < nr) {
                             const int r = rb + kWgRG * i;
                             const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H2 + (unsigned)n;
                             zv[i] = S.z2[o];
@@ -2075,12 +2093,14 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         for (int jj = 0; jj < OW; ++jj) my[3 + jj] = dw3[jj];
         my[3 + OW] = db3;
         __syncthreads();
-        if (vlive || b3live) {  // thread -> (item, column): 32 partial sums each
-            float v = sum_groups(red + ocol * kRedP + oitem);
+        if (vlive || b3live) {  // thread pair -> (item, column): 32 partial sums each, the even thread finishes
+            float v = sum_groups(red + ocol * kRedP + oitem, ohalf);
             if ((oitem == 1 || oitem == 2) && J.m.no_ln) v = 0.0f;
             const unsigned idx = b3live ? b3idx : vidx;
-            J.grad[idx] = v;
-            if (ADAM) vae.apply(J, A.ad, idx, v);
+            if (ohalf == 0) {
+                J.grad[idx] = v;
+                if (ADAM) vae.apply(J, A.ad, idx, v);
+            }
         }
         STAMP();
         STAMP_FLUSH(40, b == kWgTilesPerBlock && j == 0 && tid == 0);
@@ -2097,12 +2117,12 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         float db1 = 0.f, dg = 0.f, dbe = 0.f, dw1[17];
 #pragma unroll
         for (int i = 0; i < 17; ++i) dw1[i] = 0.f;
-        // ADAM: the parameter this thread will step (item oitem of unit kb + ocol; 3 + in <= 20 items x 32 units), requested now
+        // ADAM: the parameter this thread will step (item oitem of unit kb + ocol; 3 + in <= 20 items x 16 units, two threads each), requested now
         const int ok = kb + ocol;
         const unsigned lidx = (unsigned)(oitem == 0 ? J.m.b1() + ok : oitem == 1 ? J.m.g1() + ok : oitem == 2 ? J.m.be1() + ok : J.m.W1() + ok * in + (oitem - 3));
         const bool llive = oitem < 3 + in;
         AdamElem lae;
-        bool lae_pending = ADAM && llive;  // needed last: requested behind the first chunk's loads
+        bool lae_pending = ADAM && llive && ohalf == 0;  // needed last: requested behind the first chunk's loads
         #pragma unroll
         for (int s = 0; s < 2; ++s) if (s < J.nslots) {  // compile-time slot index: J lives in registers, not in scratch
             const Slot& S = J.ws[s];
@@ -2111,9 +2131,9 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                 const int nr = min(kWgRowChunk, J.rows[s] - c0);
                 float zv[4], dv[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 4; ++i) if (kWgRG * i < nr) {  // (scalar: at B = 128 row blocks 2, 3 are past the end for every thread)
                     const int r = rg + kWgRG * i;
-                    const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H1 + (unsigned)k;  // unconditional, clamped
+                    const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H1 + (unsigned)k;  // unconditional inside a block, clamped
                     zv[i] = S.z1[o];
                     dv[i] = S.dh1[o];
                 }
@@ -2155,10 +2175,11 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                 }
                 __syncthreads();
                 STAMP();
-                for (int rb = rg; rb < nr; rb += kWgRG * 4) {
-                    if (rb != rg) {
+                for (int rb0 = 0; rb0 < nr; rb0 += kWgRG * 4) {
+                    const int rb = rg + rb0;
+                    if (rb0 != 0) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
+                        for (int i = 0; i < 4; ++i) if (rb0 + kWgRG * i < nr) {
                             const int r = rb + kWgRG * i;
                             const unsigned o = (unsigned)(c0 + (r < nr ? r : nr - 1)) * (unsigned)H1 + (unsigned)k;
                             zv[i] = S.z1[o];
@@ -2196,10 +2217,12 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         for (int i = 0; i < 17; ++i) my[3 + i] = dw1[i];
         __syncthreads();
         if (llive) {
-            float v = sum_groups(red + ocol * kRedP + oitem);
+            float v = sum_groups(red + ocol * kRedP + oitem, ohalf);
             if ((oitem == 1 || oitem == 2) && J.m.no_ln) v = 0.0f;
-            J.grad[lidx] = v;
-            if (ADAM) lae.apply(J, A.ad, lidx, v);
+            if (ohalf == 0) {
+                J.grad[lidx] = v;
+                if (ADAM) lae.apply(J, A.ad, lidx, v);
+            }
         }
         STAMP();
         STAMP_FLUSH(48, b == kWgTilesPerBlock + kWgVecWgs && j == 0 && tid == 0);
