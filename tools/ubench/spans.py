@@ -79,12 +79,23 @@ def main():
         loop.step()
     torch.cuda.synchronize()
     fetch(L)
-    for k in range(4):
+    # five steps queued back to back (the host runs ahead of the GPU after the first ones), the last two reported: one with a critic-only
+    # learn(), one with the delayed actor step
+    for _ in range(5):
         loop.step()
-        torch.cuda.synchronize()
-        spans, tags = fetch(L)
-        print("\n== step %d (%d workgroups logged) ==" % (k, len(spans)))
-        report(spans, tags, names)
+    torch.cuda.synchronize()
+    spans, tags = fetch(L)
+    order = np.argsort(spans[:, 0], kind="stable")
+    spans, tags = spans[order], tags[order]
+    act_line = [ln for ln, lab in names.items() if lab[0] == "act_fused"][0]
+    is_act = tags == act_line
+    # first workgroup of each acting launch: an act span whose predecessor in time is not an act span
+    starts = [i for i in range(len(spans)) if is_act[i] and (i == 0 or not is_act[i - 1])]
+    starts.append(len(spans))
+    for k in (len(starts) - 3, len(starts) - 2):
+        a, b = starts[k], starts[k + 1]
+        print("\n== step %d of 5 queued back to back (%d workgroups logged) ==" % (k, b - a))
+        report(spans[a:b], tags[a:b], names)
 
 
 if __name__ == "__main__":
