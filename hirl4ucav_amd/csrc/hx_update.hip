@@ -35,7 +35,7 @@ using namespace hxnn;
 // workgroup land in hx_dbg; the shipped build compiles them out.
 #ifdef HX_STAMPS
 __device__ float hx_dbg[80];
-#define STAMP_DECL unsigned long long TS_[10]; int tsn_ = 0
+#define STAMP_DECL unsigned long long TS_[16]; int tsn_ = 0
 #define STAMP() TS_[tsn_++] = __builtin_amdgcn_s_memrealtime()
 #define STAMP_FLUSH(base, cond) do { if (cond) { for (int i_ = 1; i_ < tsn_; ++i_) hx_dbg[(base) + i_] = (float)(TS_[i_] - TS_[i_ - 1]); hx_dbg[(base)] = (float)tsn_; } } while (0)
 // life span of EVERY workgroup of every launch (first stamp .. now), appended to a log: where a learn() spends its time BETWEEN workgroups
@@ -1907,6 +1907,10 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
     float scale[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) scale[s] = J.wmode[s] == 0 ? 1.0f : (J.wmode[s] == 1 ? 1.0f - w : w);
+#ifdef HX_STAMPS
+    asm volatile("" ::"v"(w));
+    STAMP();
+#endif
     if (ADAM && A.ad.finish_actor && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {  // what adam_kernel's thread 0 does on an actor step
         if (A.ad.use_bc) {
             A.ad.losses[1] = A.ad.losses[2] * w + A.ad.losses[3] * (1.0f - w);  // HIRL.py:321
@@ -2114,6 +2118,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         const int k = kb + cl;
         const int in = J.m.in;
         const float g1 = J.net[J.m.g1() + k], be1 = J.net[J.m.be1() + k];
+        STAMP();
         float db1 = 0.f, dg = 0.f, dbe = 0.f, dw1[17];
 #pragma unroll
         for (int i = 0; i < 17; ++i) dw1[i] = 0.f;
@@ -2137,6 +2142,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                     zv[i] = S.z1[o];
                     dv[i] = S.dh1[o];
                 }
+                STAMP();
                 // the chunk's shared operands are requested BEFORE the barrier that frees the LDS tiles: one round trip with the loads above
                 static_assert(kWgRowChunk * XP <= 5 * kWide && kWgRowChunk <= kWide && kColWgB == 8, "staging: five words + one row per thread");
                 // (whole waves past the end of a tile skip their loads behind a scalar branch: at B = 128 the input tile is 2.5 of the 5
@@ -2148,6 +2154,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                     const int e = tid + q * kWide;
                     if (w0 + q * kWide < nr * XP) xst[q] = S.x[(size_t)c0 * XP + (e < nr * XP ? e : 0)];
                 }
+                STAMP();
                 const int er = tid < nr ? tid : 0;
                 v2f st1v;  // (unset in a skipping wave, which never stores it)
                 v4f l0, l1, l2, l3;
@@ -2156,6 +2163,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                     const v4f* lp4 = reinterpret_cast<const v4f*>(S.lnp + (size_t)(c0 + er) * (2 * kColWgB));  // [8 column workgroups][2]
                     l0 = lp4[0]; l1 = lp4[1]; l2 = lp4[2]; l3 = lp4[3];
                 }
+                STAMP();
                 if (lae_pending) {
                     lae.fetch(J, lidx);
                     lae_pending = false;

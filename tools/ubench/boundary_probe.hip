@@ -38,9 +38,35 @@ __global__ __launch_bounds__(1024) void k2(unsigned long long* ts, const float* 
         ts[256 + blockIdx.x * 3 + 2] = t2 + (LDSF > 0 ? (unsigned long long)(lds[0] == 12345.0f) : 0ull);
     }
 }
+
+// K3: what a real prologue does — every wave of the workgroup requests NL dwords per lane from NL different arrays (3 MB + 4 KB apart),
+// lines that (fresh = 1) K1's workgroup of ANOTHER XCD has just written, or (fresh = 0) that this workgroup read one launch ago.
+template <int NL>
+__global__ __launch_bounds__(1024) void k3(unsigned long long* ts, const float* buf, int fresh) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const size_t arr = ((size_t)(3 << 20) + 4096) / 4;
+    const float* base = buf + (size_t)((blockIdx.x + (fresh ? 0 : 0)) & 255) * 1024 + threadIdx.x;
+    float v[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) v[i] = base[(size_t)i * arr];
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) acc += v[i];
+    asm volatile("" ::"v"(acc));
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { ts[256 + blockIdx.x * 3] = t0; ts[256 + blockIdx.x * 3 + 1] = t1; }
+    if (acc == 12345.678f) ts[0] = 0;
+}
+__global__ __launch_bounds__(1024) void k1w(float* buf, unsigned long long* ts, int nl) {  // writes the lines K3's workgroup (index + 1: another XCD) will read
+    const size_t arr = ((size_t)(3 << 20) + 4096) / 4;
+    float* base = buf + (size_t)((blockIdx.x + 1) & 255) * 1024 + threadIdx.x;
+    for (int i = 0; i < nl; ++i) base[(size_t)i * arr] = (float)i;
+    __syncthreads();
+    if (threadIdx.x == 0) ts[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+}
 int main() {
     float* buf; unsigned long long* ts;
-    hipMalloc((void**)&buf, 64ll << 20); hipMalloc((void**)&ts, (256 + 256 * 3) * 8);
+    hipMalloc((void**)&buf, 128ll << 20); hipMalloc((void**)&ts, (256 + 256 * 3) * 8);
     std::vector<unsigned long long> h(256 + 256 * 3);
     const char* names[] = {"1024 thr, LDS 0", "1024 thr, LDS 64 KB", "1024 thr, LDS 156 KB", "64 thr, LDS 0"};
     for (int mode = 1; mode < 4; ++mode) {
@@ -58,6 +84,27 @@ int main() {
         }
         printf("first global load of K2, source %s: %.2f us\n", mode == 1 ? "written by ANOTHER XCD's workgroup in K1" : mode == 2 ? "read-only, read by this workgroup one launch ago" : "read-only, untouched (HBM)", ld / reps);
     }
+
+    for (int fresh = 0; fresh < 2; ++fresh)
+        for (int nl : {1, 4, 16}) {
+            double lat = 0;
+            const int reps = 30;
+            for (int rep = 0; rep < reps + 2; ++rep) {
+                if (fresh) hipLaunchKernelGGL(k1w, dim3(256), dim3(1024), 0, 0, buf, ts, nl);
+                else hipLaunchKernelGGL(k1, dim3(256), dim3(1024), 0, 0, buf + (100 << 20) / 4, 0ll, ts);
+                if (nl == 1) hipLaunchKernelGGL(k3<1>, dim3(256), dim3(1024), 0, 0, ts, buf, fresh);
+                if (nl == 4) hipLaunchKernelGGL(k3<4>, dim3(256), dim3(1024), 0, 0, ts, buf, fresh);
+                if (nl == 16) hipLaunchKernelGGL(k3<16>, dim3(256), dim3(1024), 0, 0, ts, buf, fresh);
+                hipDeviceSynchronize();
+                hipMemcpy(h.data(), ts, h.size() * 8, hipMemcpyDeviceToHost);
+                std::vector<double> l(256);
+                for (int b = 0; b < 256; ++b) l[b] = (double)(h[256 + b * 3 + 1] - h[256 + b * 3]) * 0.01;
+                std::sort(l.begin(), l.end());
+                if (rep >= 2) lat += l[128];
+            }
+            printf("prologue-like batch: 16 waves x %2d dword loads per lane from %2d arrays, lines %s: all data back after %.2f us (median workgroup)\n", nl, nl,
+                   fresh ? "just written by another XCD's workgroup" : "read by this workgroup one launch ago", lat / reps);
+        }
     for (int mb : {0, 2, 8, 32})
         for (int var = 0; var < 4; ++var) {
             double g = 0, ka = 0, ld = 0, span1 = 0;
