@@ -17,11 +17,13 @@
 //            256 -> 512 GEMM tiled 16 rows x 32 / 64 columns per workgroup on fp32 MFMA (v_mfma_f32_16x16x4_f32: fp32 products and
 //            sums, parity at 1e-5); the first forward launch can also draw and gather the minibatch (SAMPLE);
 //   bwd_l2   head + loss gradient + LN2 backward in the prologue, dh1 = dz2 W2 on MFMA;
-//   wgrad    dW2 = dz2^T h1 on MFMA (16 x 256 per workgroup) + the vector / LN / layer-1 gradients (32 columns x 32 row groups per
-//            workgroup), written into a flat gradient buffer with the parameter layout (one all-reduce message per phase when
+//   wgrad    dW2 = dz2^T h1 on MFMA (16 x 128 per workgroup, a tile per wave pair over row halves) + the vector / LN / layer-1 gradients
+//            (16 columns x 64 row groups per workgroup): 112 workgroups per job, written into a flat gradient buffer with the parameter layout (one all-reduce message per phase when
 //            sharded); on one GPU the same threads apply Adam, the Polyak step of the target and refresh the W2 images (ADAM);
 //   adam / polyak  elementwise over the flat buffers, 16 B per lane (sharded path, SAC).
-// The kernels issue an instruction nearly every cycle of their life (16 waves per CU): their run time follows the instruction count.
+// The kernels issue an instruction nearly every cycle of their life (16 waves per CU): their run time follows the instruction count — and the
+// bytes their prologue asks for (a CU gets ~19 B/clk of lines another XCD has just written), and the workgroup count (a launch is as long
+// as its slowest workgroup plus the drain of its stores).
 #include <cstdlib>
 #include <type_traits>
 
