@@ -1354,19 +1354,29 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     __shared__ __attribute__((aligned(16))) float c1s[GRP == 2 ? H1 * 6 : 4];  // critic layer 1: g1 be1 W1[:,13..16]
     __shared__ float red[16][4];
     __shared__ float st1s[RT * 2];  // LN1 stats of the tile's rows (epilogue)
+    // TD job (GRP 0): EIGHT rows per workgroup, a wave PAIR per row — wave w (role 0) owns the row's own head, loss gradient and LN2
+    // backward, wave w + 8 (role 1) the two target heads; min(Q1', Q2') crosses through LDS.  Twice the workgroups (256 at B = 128, two
+    // jobs): half the row bytes per CU (rows the previous launches produced on all eight XCDs arrive at ~19 B/clk/CU, and 96 KB of them
+    // were in front of this prologue), and the three heads of a row no longer run one after the other on one wave.  The MFMA tile keeps
+    // its 16 rows (8 of them zero): that phase is the short one.
+    constexpr bool PAIRED = GRP == 0;
+    constexpr int RTB = PAIRED ? RT / 2 : RT;
+    __shared__ float tq[PAIRED ? RTB : 1];
 
     const int b = blockIdx.x;
     const BwdJobC& jc = AC.job[blockIdx.y];
     const BwdJob J = expand_bwd(jc);
     struct { float slope, inv_batch; float* losses; int* soft_count; } A{jc.slope, jc.inv_batch, jc.losses, jc.soft_count};
     const int rt = b / kColWgB, nt = b % kColWgB;
-    const int r0 = rt * RT;
-    const int nrow = min(RT, J.rows - r0);
+    const int r0 = rt * RTB;
+    const int nrow = min(RTB, J.rows - r0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float slope = A.slope;
     const bool lead = nt == 0;  // the column-tile-0 workgroup of a row tile also publishes dz2 / st2 / dout / losses
-    const bool live = wave < nrow;  // wave w owns row w of the tile
-    const size_t R = (size_t)(r0 + (live ? wave : 0));
+    const int role = PAIRED ? wave / RTB : 0, prow = PAIRED ? wave % RTB : wave;
+    const bool live = role == 0 && prow < nrow;   // wave owns row prow of the tile (own head, gradient, LN2 backward)
+    const bool tlive = role == 1 && prow < nrow;  // PAIRED: wave owns the target heads of row prow
+    const size_t R = (size_t)(r0 + (prow < nrow ? prow : 0));
     const int ct = wave % kCTB, kq = wave / kCTB;
     const int n0 = nt * kNTB + ct * 16;
     STAMP_DECL;
@@ -1380,13 +1390,18 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     float lab0 = 0.f, lab1 = 0.f, tgt[4] = {0.f, 0.f, 0.f, 0.f};
     RowReg<H1> cdh, cz;
     float cst0 = 0.f, cst1 = 0.f, cs1 = 0.f, cs2 = 0.f;
-    z.load(J.ws.z2 + R * H2);
+    // PAIRED: role 0 asks for the row of its own net (z), role 1 for the two target nets' (za, zb); both behind one scalar branch each, the
+    // skipped registers left unset (never used by that role)
+    const bool role1 = PAIRED && __builtin_amdgcn_readfirstlane(wave) >= RTB;
+    if (!role1) z.load(J.ws.z2 + R * H2);
     Img pv0, pv1, pv2;
     pv0.fetch(J.net, J.m, tid);
     float bonus = 0.f, bonus_scale = 0.f, dgiv[GRP == 3 ? 8 : 1] = {};
     if (GRP == 0) {
-        za.load(J.t1.ws.z2 + R * H2);
-        zb.load(J.t2.ws.z2 + R * H2);
+        if (role1) {
+            za.load(J.t1.ws.z2 + R * H2);
+            zb.load(J.t2.ws.z2 + R * H2);
+        }
         const float* row = src_row(J.src, (int)R);
         lab0 = row[30];
         lab1 = row[31];
@@ -1458,27 +1473,36 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     float part[4] = {0.f, 0.f, 0.f, 0.f};  // loss partials of this row
     int cnt = 0;
     float* drow = dz2s + wave * LDA2;
-    if (!live) {  // padded rows contribute zeros
+    RowReg<H2> xh, y;
+    float mean = 0.f, rstd = 0.f, o[OUTW] = {};
+    if constexpr (PAIRED) {  // the pair's two halves side by side, then one barrier
+        if (tlive) {
+            RowReg<H2> xa, ya;
+            float m1, s1, q1[1], q2[1];
+            head_regs<1, IMG, RELU>(za, hps + kHpStride, 1, slope, xa, ya, m1, s1, q1, J.t1.m.no_ln);
+            head_regs<1, IMG, RELU>(zb, hps + 2 * kHpStride, 1, slope, xa, ya, m1, s1, q2, J.t2.m.no_ln);
+            if (lane == 0) tq[prow] = fminf(q1[0], q2[0]);
+        } else if (live) {
+            head_regs<OUTW, IMG, RELU>(z, hps, NOUT ? NOUT : J.m.out, slope, xh, y, mean, rstd, o, J.m.no_ln);
+        }
+        __syncthreads();
+    }
+    if (!live) {  // padded rows (and the target-head waves' rows 8..15 of the MFMA tile) contribute zeros
         RowReg<H2> zero;
 #pragma unroll
         for (int i = 0; i < 8; ++i) zero.v[i] = 0.0f;
         zero.store_lds(drow);
     } else {
-        RowReg<H2> xh, y;
-        float mean, rstd, o[OUTW];
-        head_regs<OUTW, IMG, RELU>(z, hps, NOUT ? NOUT : J.m.out, slope, xh, y, mean, rstd, o, J.m.no_ln);
+        if constexpr (!PAIRED) head_regs<OUTW, IMG, RELU>(z, hps, NOUT ? NOUT : J.m.out, slope, xh, y, mean, rstd, o, J.m.no_ln);
         float dout[OUTW] = {};
         if constexpr (GRP == 3) {  // head gradient supplied by a previous kernel (SAC: min-selected critics, sampled policy)
 #pragma unroll
             for (int jj = 0; jj < OUTW; ++jj) dout[jj] = dgiv[jj < (GRP == 3 ? 8 : 1) ? jj : 0];
         } else if constexpr (GRP == 0) {
-            RowReg<H2> xa, ya;
-            float m1, s1, q1[1], q2[1];
-            head_regs<1, IMG, RELU>(za, hps + kHpStride, 1, slope, xa, ya, m1, s1, q1, J.t1.m.no_ln);
-            head_regs<1, IMG, RELU>(zb, hps + 2 * kHpStride, 1, slope, xa, ya, m1, s1, q2, J.t2.m.no_ln);
+            const float qmin = tq[prow];  // min(Q1', Q2') of this row, from the pair's other wave
             // HIRL.py:270-274; with `bonus` SAC's r + (1 - d) gamma (min Q' + alpha H')  SAC/agent.py:202-210
-            const float target = J.bonus ? lab0 + (1.0f - lab1) * (J.gamma * (fminf(q1[0], q2[0]) + bonus * bonus_scale))
-                                         : lab0 + (J.gamma * fminf(q1[0], q2[0])) * (1.0f - lab1);
+            const float target = J.bonus ? lab0 + (1.0f - lab1) * (J.gamma * (qmin + bonus * bonus_scale))
+                                         : lab0 + (J.gamma * qmin) * (1.0f - lab1);
             const float diff = o[0] - target;
             dout[0] = 2.0f * diff * A.inv_batch;  // d mse / dq
             part[0] += diff * diff * A.inv_batch;
@@ -2565,8 +2589,8 @@ void launch_fwd(const FwdArgs& F, hipStream_t st) {
     else HX_FWD(kNT);
 #undef HX_FWD
 }
-int bwd_blocks(const BwdArgs& a) {  // per job (every job of a launch has the same row count)
-    return ((a.job[0].rows + RT - 1) / RT) * kColWgB;
+int bwd_blocks(const BwdArgs& a, int rows_per_wg) {  // per job (every job of a launch has the same row count)
+    return ((a.job[0].rows + rows_per_wg - 1) / rows_per_wg) * kColWgB;
 }
 template <bool ADAM>
 void launch_wg(const WgArgs& W, hipStream_t st) {
@@ -2579,8 +2603,8 @@ template <int GRP>
 void launch_bwd(const BwdArgs& G, hipStream_t st) {
     BwdArgsC C{};
     for (int j = 0; j < G.njobs; ++j) C.job[j] = pack_bwd(G.job[j], G);
-    if (G.slope == 0.0f) hipLaunchKernelGGL((bwd_l2_kernel<GRP, true>), dim3(bwd_blocks(G), G.njobs), dim3(kWide), 0, st, C);
-    else hipLaunchKernelGGL((bwd_l2_kernel<GRP, false>), dim3(bwd_blocks(G), G.njobs), dim3(kWide), 0, st, C);
+    if (G.slope == 0.0f) hipLaunchKernelGGL((bwd_l2_kernel<GRP, true>), dim3(bwd_blocks(G, GRP == 0 ? RT / 2 : RT), G.njobs), dim3(kWide), 0, st, C);
+    else hipLaunchKernelGGL((bwd_l2_kernel<GRP, false>), dim3(bwd_blocks(G, GRP == 0 ? RT / 2 : RT), G.njobs), dim3(kWide), 0, st, C);
 }
 
 const Mlp kActor{13, 4, 0};
