@@ -1359,9 +1359,11 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     // jobs): half the row bytes per CU (rows the previous launches produced on all eight XCDs arrive at ~19 B/clk/CU, and 96 KB of them
     // were in front of this prologue), and the three heads of a row no longer run one after the other on one wave.  The MFMA tile keeps
     // its 16 rows (8 of them zero): that phase is the short one.
-    constexpr bool PAIRED = GRP == 0;
+    // The critic-PI job (GRP 1) pairs the same way (role 1: the soft head), the actor jobs (GRP 2) too (role 1: dL/da from the critic's
+    // layer-1 backward, four dot products over 256 hidden units).
+    constexpr bool PAIRED = GRP <= 2;
     constexpr int RTB = PAIRED ? RT / 2 : RT;
-    __shared__ float tq[PAIRED ? RTB : 1];
+    __shared__ float tq[PAIRED ? RTB * 4 : 1];
 
     const int b = blockIdx.x;
     const BwdJobC& jc = AC.job[blockIdx.y];
@@ -1417,19 +1419,21 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
         for (int jj = 0; jj < 8; ++jj) dgiv[jj] = J.ws.dout[R * OW + jj];  // (the row pitch is 8: all in bounds; masked below)
     }
     if (GRP == 1) {
-        if (J.soft.net) za.load(J.soft.ws.z2 + R * H2);  // same net as J.net: shares the LDS image
+        if (role1 && J.soft.net) za.load(J.soft.ws.z2 + R * H2);  // same net as J.net: shares the LDS image
     }
     float c1v[2] = {0.f, 0.f};
     if (GRP == 2) {
         if (J.mode == BM_ACTOR_PI) {
             const Head& C = J.crit;
-            cdh.load(C.ws.dh1 + R * H1);
-            cz.load(C.ws.z1 + R * H1);
-            cst0 = C.ws.st1[R * 2];
-            cst1 = C.ws.st1[R * 2 + 1];
-            const float* lp = C.ws.lnp + R * (2 * kColWgB);
-            cs1 = lnp_sum(lp) * (1.0f / H1);
-            cs2 = lnp_sum(lp + 1) * (1.0f / H1);
+            if (role1) {  // the pair's second wave owns dL/da
+                cdh.load(C.ws.dh1 + R * H1);
+                cz.load(C.ws.z1 + R * H1);
+                cst0 = C.ws.st1[R * 2];
+                cst1 = C.ws.st1[R * 2 + 1];
+                const float* lp = C.ws.lnp + R * (2 * kColWgB);
+                cs1 = lnp_sum(lp) * (1.0f / H1);
+                cs2 = lnp_sum(lp + 1) * (1.0f / H1);
+            }
             // g1 | be1 (512 floats) by threads 0..511; W1[k][13..16] (1024 floats) one per thread
             if (tid < 2 * H1) c1v[0] = C.net[C.m.g1() + tid];
             c1v[1] = C.net[C.m.W1() + (tid >> 2) * C.m.in + 13 + (tid & 3)];
@@ -1477,11 +1481,36 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     float mean = 0.f, rstd = 0.f, o[OUTW] = {};
     if constexpr (PAIRED) {  // the pair's two halves side by side, then one barrier
         if (tlive) {
-            RowReg<H2> xa, ya;
-            float m1, s1, q1[1], q2[1];
-            head_regs<1, IMG, RELU>(za, hps + kHpStride, 1, slope, xa, ya, m1, s1, q1, J.t1.m.no_ln);
-            head_regs<1, IMG, RELU>(zb, hps + 2 * kHpStride, 1, slope, xa, ya, m1, s1, q2, J.t2.m.no_ln);
-            if (lane == 0) tq[prow] = fminf(q1[0], q2[0]);
+            if constexpr (GRP == 0) {
+                RowReg<H2> xa, ya;
+                float m1, s1, q1[1], q2[1];
+                head_regs<1, IMG, RELU>(za, hps + kHpStride, 1, slope, xa, ya, m1, s1, q1, J.t1.m.no_ln);
+                head_regs<1, IMG, RELU>(zb, hps + 2 * kHpStride, 1, slope, xa, ya, m1, s1, q2, J.t2.m.no_ln);
+                if (lane == 0) tq[prow] = fminf(q1[0], q2[0]);
+            } else if constexpr (GRP == 1) {
+                if (J.soft.net) {
+                    RowReg<H2> xa, ya;
+                    float m1, s1, qs[1];
+                    head_regs<1, IMG, RELU>(za, hps, 1, slope, xa, ya, m1, s1, qs, J.m.no_ln);
+                    if (lane == 0) tq[prow] = qs[0];
+                }
+            } else if (J.mode == BM_ACTOR_PI) {
+                // dL/da_j = sum_k dz1_c[k] W1c[k][13 + j], dz1_c = LN1 backward of the critic's dh1 (row sums from lnp)
+                float da[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {  // RowReg<256> maps v[c] -> hidden unit k = lane*4 + c
+                    const int k = lane * 4 + c;
+                    const float g1 = c1s[k], be1 = c1s[H1 + k];
+                    const float xh1 = (cz.v[c] - cst0) * cst1;
+                    const float dxh = act_bwd<RELU>(cdh.v[c], g1 * xh1 + be1, slope) * g1;
+                    const float dz1 = cst1 * (dxh - cs1 - xh1 * cs2);
+                    const float4 w4 = *reinterpret_cast<const float4*>(c1s + 2 * H1 + 4 * k);
+                    da[0] += dz1 * w4.x; da[1] += dz1 * w4.y; da[2] += dz1 * w4.z; da[3] += dz1 * w4.w;
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) da[jj] = wave_sum(da[jj]);
+                if (lane < 4) tq[prow * 4 + lane] = lane == 0 ? da[0] : lane == 1 ? da[1] : lane == 2 ? da[2] : da[3];
+            }
         } else if (live) {
             head_regs<OUTW, IMG, RELU>(z, hps, NOUT ? NOUT : J.m.out, slope, xh, y, mean, rstd, o, J.m.no_ln);
         }
@@ -1509,30 +1538,13 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
         } else if constexpr (GRP == 1) {
             dout[0] = -A.inv_batch;            // rl_loss = -mean(Q1(s, pi(s)))  HIRL.py:297
             part[3] += -o[0] * A.inv_batch;
-            if (J.soft.net) {
-                RowReg<H2> xa, ya;
-                float m1, s1, qs[1];
-                head_regs<1, IMG, RELU>(za, hps, 1, slope, xa, ya, m1, s1, qs, J.m.no_ln);
-                cnt += (qs[0] > o[0]) ? 1 : 0;  // (soft_Q > rl_Q)  HIRL.py:303
-            }
+            if (J.soft.net) cnt += (tq[prow] > o[0]) ? 1 : 0;  // (soft_Q > rl_Q)  HIRL.py:303 — the soft head came from the pair's other wave
         } else if (J.mode == BM_ACTOR_PI) {
-            // dL/da_j = sum_k dz1_c[k] W1c[k][13 + j], dz1_c = LN1 backward of the critic's dh1 (row sums from lnp)
-            float da[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {  // RowReg<256> maps v[c] -> hidden unit k = lane*4 + c
-                const int k = lane * 4 + c;
-                const float g1 = c1s[k], be1 = c1s[H1 + k];
-                const float xh1 = (cz.v[c] - cst0) * cst1;
-                const float dxh = act_bwd<RELU>(cdh.v[c], g1 * xh1 + be1, slope) * g1;
-                const float dz1 = cst1 * (dxh - cs1 - xh1 * cs2);
-                const float4 w4 = *reinterpret_cast<const float4*>(c1s + 2 * H1 + 4 * k);
-                da[0] += dz1 * w4.x; da[1] += dz1 * w4.y; da[2] += dz1 * w4.z; da[3] += dz1 * w4.w;
-            }
+            // dL/da (the pair's other wave) through the policy's tanh
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                da[jj] = wave_sum(da[jj]);
                 const float a = fast_tanh(o[jj]);
-                dout[jj] = da[jj] * (1.0f - a * a);
+                dout[jj] = tq[prow * 4 + jj] * (1.0f - a * a);
             }
         } else {  // BM_ACTOR_BC: bc_loss = lambda * mse(actor(s_bc), a_bc)  HIRL.py:310-311
 #pragma unroll
@@ -2603,8 +2615,8 @@ template <int GRP>
 void launch_bwd(const BwdArgs& G, hipStream_t st) {
     BwdArgsC C{};
     for (int j = 0; j < G.njobs; ++j) C.job[j] = pack_bwd(G.job[j], G);
-    if (G.slope == 0.0f) hipLaunchKernelGGL((bwd_l2_kernel<GRP, true>), dim3(bwd_blocks(G, GRP == 0 ? RT / 2 : RT), G.njobs), dim3(kWide), 0, st, C);
-    else hipLaunchKernelGGL((bwd_l2_kernel<GRP, false>), dim3(bwd_blocks(G, GRP == 0 ? RT / 2 : RT), G.njobs), dim3(kWide), 0, st, C);
+    if (G.slope == 0.0f) hipLaunchKernelGGL((bwd_l2_kernel<GRP, true>), dim3(bwd_blocks(G, GRP <= 2 ? RT / 2 : RT), G.njobs), dim3(kWide), 0, st, C);
+    else hipLaunchKernelGGL((bwd_l2_kernel<GRP, false>), dim3(bwd_blocks(G, GRP <= 2 ? RT / 2 : RT), G.njobs), dim3(kWide), 0, st, C);
 }
 
 const Mlp kActor{13, 4, 0};
