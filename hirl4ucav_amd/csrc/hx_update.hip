@@ -1066,6 +1066,24 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         using namespace hxenv;
         float* s_row = wb1;                    // [ROWS][33] replay rows   (the odd chunk buffer is free since the last barrier)
         float* s_obs = wb1 + ROWS * kRowPitch;  // [ROWS][13] next observations
+        // Ring slots: one atomic per workgroup on ONE address, 256 workgroups at about the same moment — its return takes ~3 us.  Which rows
+        // are stored depends on the state only (episode step counter against max_step), so wave 0 asks for its slots as soon as its own head
+        // row is done, BEFORE the barrier that collects the other rows' actions: the wait of the other waves and the env step hide it.
+        bool trunc = false, store = false;
+        int rank = 0, nstore = 0;
+        unsigned long long base = 0ull;
+        if (wave == 0) {
+            if (lane < 2 * ROWS && env_e < nrow) {
+                uint32_t ep = envT.episode_step();
+                ep = ep < 65535u ? ep + 1u : ep;
+                trunc = A.o.max_step > 0 && (int)ep >= A.o.max_step;  // train_all.py:346-347
+                store = A.o.ring != nullptr && !trunc;
+            }
+            const unsigned long long bal = __ballot(store && !env_opp);
+            rank = __popcll(bal & ((1ull << (lane & ~1)) - 1ull));  // both lanes of a pair get the env's rank
+            nstore = __popcll(bal);
+            if (lane == 0 && nstore > 0) base = atomicAdd((unsigned long long*)A.o.total, (unsigned long long)nstore);
+        }
         __syncthreads();  // actions of all rows in s_act
         STAMP();
         if (wave == 0 && lane < 2 * ROWS) {
@@ -1073,24 +1091,13 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             const bool is_opp = env_opp, own = !env_opp;
             const bool active = e < nrow;
             const int64_t i = (int64_t)r0 + e;
-            const bool insert = A.o.ring != nullptr;
             Stepper<true>& T = envT;
             float4 act = {0.f, 0.f, 0.f, 0.f};
-            bool trunc = false, store = false, bad_act = false;
+            bool bad_act = false;
             if (active) {
                 act = *reinterpret_cast<const float4*>(s_act + e * 4);
                 bad_act = sanitize_action(act);
-                uint32_t ep = T.episode_step();
-                ep = ep < 65535u ? ep + 1u : ep;
-                trunc = A.o.max_step > 0 && (int)ep >= A.o.max_step;  // train_all.py:346-347
-                store = insert && !trunc;
             }
-            // ring slots: one atomic per workgroup, issued before the arithmetic that hides its latency
-            const unsigned long long bal = __ballot(store && own);
-            const int rank = __popcll(bal & ((1ull << (lane & ~1)) - 1ull));  // both lanes of a pair get the env's rank
-            const int nstore = __popcll(bal);
-            unsigned long long base = 0ull;
-            if (lane == 0 && nstore > 0) base = atomicAdd((unsigned long long*)A.o.total, (unsigned long long)nstore);
             Wrapped W{};
             V3 eu{}, eu2{};
             bool ended = false;
@@ -1177,11 +1184,11 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         __syncthreads();  // rows, next observations, s_base / s_nstore
         STAMP();
         for (int k = tid; k < nrow * HX_OBS_DIM; k += kWide) A.obs[(size_t)r0 * HX_OBS_DIM + k] = s_obs[k];
-        const int nstore = s_nstore;
-        if (nstore > 0) {  // 16 B per lane, rows contiguous in the ring (modulo wrap)
+        const int nst = s_nstore;
+        if (nst > 0) {  // 16 B per lane, rows contiguous in the ring (modulo wrap)
             const unsigned slot0 = s_base, cap = (unsigned)A.o.cap;
             float4* ring4 = reinterpret_cast<float4*>(A.o.ring);
-            for (int k = tid; k < nstore * (HX_ROW_WORDS / 4); k += kWide) {
+            for (int k = tid; k < nst * (HX_ROW_WORDS / 4); k += kWide) {
                 const int rr = k >> 3, c = (k & 7) * 4;
                 const float* src = s_row + rr * kRowPitch + c;
                 ring4[(size_t)wrap_slot(slot0 + (unsigned)rr, cap) * (HX_ROW_WORDS / 4) + (k & 7)] = make_float4(src[0], src[1], src[2], src[3]);
