@@ -1930,18 +1930,20 @@ constexpr int kWgRowChunk = 256;                         // rows whose per-row s
 // fixed-order sum of the 16 row groups' partial results of one (column, item): red[group][64][kRedP]; the odd pitch keeps the 64 lanes of a
 // wave on 64 different banks (pitch 20: 16 banks, every read and write of the reduction four-way conflicted)
 constexpr int kRedP = 21;
-// two threads per (column, item): each sums 32 of the 64 row groups (tree), the even lane adds its neighbour's half (one DPP move)
+// two threads per (column, item): each sums 32 of the 64 row groups (tree) — the even groups / the odd groups: one group apart is 16 banks
+// apart, so the pair's reads never meet on a bank (groups 0..31 / 32..63 would: 32 groups are a multiple of 32 banks) — the even lane
+// adds its neighbour's sum (one DPP move)
 __device__ __forceinline__ float sum_groups(const float* p, int half) {
     constexpr int N = kWgRG / 2;
     float v[N];
 #pragma unroll
-    for (int g = 0; g < N; ++g) v[g] = p[(half * N + g) * kWgCols * kRedP];
+    for (int g = 0; g < N; ++g) v[g] = p[(2 * g + half) * kWgCols * kRedP];
 #pragma unroll
     for (int w = 1; w < N; w *= 2)
 #pragma unroll
         for (int g = 0; g < N; g += 2 * w) v[g] += v[g + w];
     const float other = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[0]), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
-    return half ? other + v[0] : v[0] + other;  // (groups 0..31) + (groups 32..63) on both lanes
+    return half ? other + v[0] : v[0] + other;  // (even groups) + (odd groups) on both lanes
 }
 
 // ADAM: each thread applies the optimizer step to the gradient elements it has just produced (every parameter's gradient is
