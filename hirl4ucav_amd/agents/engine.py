@@ -8,6 +8,7 @@ all-reduce per phase over the flat gradient buffer (RCCL via torch.distributed),
 all-reduce before the actor gradients are formed.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -92,7 +93,16 @@ class OneShotExchange:
         _lib.call("hx_ipc_export", msg, hm)
         _lib.call("hx_ipc_export", flag, hf)
         every = [None] * self.world
-        dist.all_gather_object(every, (hm.raw, hf.raw), group=group)
+        uuid = str(getattr(torch.cuda.get_device_properties(device), "uuid", "")) or f"{os.uname().nodename}:{torch.cuda.current_device()}"
+        dist.all_gather_object(every, (hm.raw, hf.raw, uuid), group=group)
+        uuids = [e[2] for e in every]
+        every = [e[:2] for e in every]
+        # Ranks that SHARE a GPU (functional tests on a one-GPU box): a rank's wait kernel spinning on every CU keeps the peer's 1024-thread
+        # workgroups from being placed for seconds at a time.  A few workgroups leave the chip to the peer (3 s instead of minutes for a short
+        # run); ranks with a GPU each keep the 256 workgroups whose loads cover the xGMI round trip.  (Read once, at the first exchange.)
+        self.shared_device = len(set(uuids)) < len(uuids)
+        if self.shared_device:
+            os.environ.setdefault("HX_ONESHOT_BLOCKS", "16")
         self._peers = []
         bases, flags = [], []
         for r, (m_h, f_h) in enumerate(every):

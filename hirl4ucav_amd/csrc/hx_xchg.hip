@@ -14,6 +14,8 @@
 // Every spin is bounded: on a timeout the kernel raises status[0] and carries on, the host checks hx_xchg_status().
 #include <cstring>
 
+#include <cstdlib>
+
 #include "hx_common.h"
 
 namespace {
@@ -131,7 +133,8 @@ int hx_allreduce_oneshot(float* dst, const float* const* bufs, uint32_t* const* 
     }
     A.spin_limit = (long long)(timeout_ms > 0 ? timeout_ms : 2000) * 2000;  // s_sleep 8 ~ 0.5 us per poll
     const long long n4 = n / 4;
-    const int blocks = (int)((n4 + kThreads - 1) / kThreads < 256 ? (n4 + kThreads - 1) / kThreads : 256);
+    static const int max_blocks = getenv("HX_ONESHOT_BLOCKS") ? atoi(getenv("HX_ONESHOT_BLOCKS")) : 256;  // tuning knob
+    const int blocks = (int)((n4 + kThreads - 1) / kThreads < max_blocks ? (n4 + kThreads - 1) / kThreads : max_blocks);
     hipLaunchKernelGGL(oneshot_allreduce_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, A);
     HX_CHECK_LAUNCH("hx_allreduce_oneshot");
     return 0;

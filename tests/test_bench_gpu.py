@@ -66,8 +66,9 @@ def test_bench_starts_its_own_ranks():
     assert d["rccl_ranks"]["world_size"] == 2 and d["replicas_identical"] is True
 
 
-# one-shot exchange with both ranks on ONE GPU: a rank's wait kernel only sees its peer's flag after the driver pre-empts it in favour of
-# the peer's queue (~0.4 s per exchange) — a functional check with few steps and a long timeout; ranks with a GPU each never wait like that
+# one-shot exchange with both ranks on ONE GPU: the waiting rank's kernel shares the chip with the peer's launches — with 16 workgroups
+# (OneShotExchange picks that when ranks share a device; 256 spinning workgroups keep the peer's 1024-thread workgroups from being placed
+# for seconds at a time) — a functional check with a long timeout; ranks with a GPU each never wait like that
 ONESHOT = ["--exchange", "oneshot", "--exchange-timeout-ms", "120000", "--measure-steps", "16"]
 
 
