@@ -2310,10 +2310,16 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         my[0] = db1; my[1] = dg; my[2] = dbe;
 #pragma unroll
         for (int i = 0; i < 17; ++i) my[3 + i] = dw1[i];
+        STAMP();
         __syncthreads();
+        STAMP();
         if (llive) {
             float v = sum_groups(red + ocol * kRedP + oitem, ohalf);
             if ((oitem == 1 || oitem == 2) && J.m.no_ln) v = 0.0f;
+#ifdef HX_STAMPS
+            asm volatile("" ::"v"(v));
+            STAMP();
+#endif
             if (ohalf == 0) {
                 J.grad[lidx] = v;
                 if (ADAM) lae.apply(J, A.ad, lidx, v);
