@@ -590,7 +590,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
             }
         }
         STAMP();
-        STAMP_FLUSH(0, blockIdx.x == 5 && tid == 0);
+        STAMP_FLUSH(SAMPLE ? 8 : 0, blockIdx.x == 5 && tid == 0);
     }
     SPAN_LOG();
     if constexpr (SAMPLE) {

@@ -30,7 +30,8 @@ for i in range(3):
     torch.cuda.synchronize()
     assert L.hx_debug_stamps(out.ctypes.data_as(ctypes.c_void_p)) == 0
     print("wgrad<ADAM>(critic) x10ns: tiles: w known %d | loads+mfma %d store %d | vector: w known %d | loop %d reduce+store %d | layer1: w known %d | path entered %d | z1/dh1 issued %d | x issued %d | st1/lnp issued %d | adam issued %d | first barrier %d | staged (loads waited) %d | compute %d | partials to LDS %d | barrier %d | sum %d | Adam + stores %d" % (out[33], out[34], out[35], out[41], out[42], out[43], out[49], out[50], out[51], out[52], out[53], out[54], out[55], out[56], out[57], out[58], out[59], out[60], out[61]))
-    print("fwd (x10ns): W1 issue %d | zero+sync %d | gather+sync %d | z1 %d | stats %d | norm %d | mfma+store %d      bwd: issue+wait %d | prologue %d | lossred %d | mfma %d | epilogue %d" % tuple(out[1:8].tolist() + out[17:22].tolist()))
+    print("fwd A, with the draw (x10ns): draw + all requests issued %d | (previous net's head) %d | staging + sync (loads waited) %d | z1 %d | stats %d | norm %d | mfma+store %d" % tuple(out[9:16].tolist()))
+    print("fwd B (x10ns): requests issued %d | previous net's head %d | staging + sync (loads waited) %d | z1 %d | stats %d | norm %d | mfma+store %d      bwd: issue+wait %d | prologue %d | lossred %d | mfma %d | epilogue %d" % tuple(out[1:8].tolist() + out[17:22].tolist()))
 for dt in ("f32", "bf16"):
     e.set_act_dtype(dt)
     for i in range(3):
