@@ -2,6 +2,7 @@
 gloo — HX_BENCH_BACKEND exists for exactly this), checked against the JSON contract."""
 import json
 import os
+import signal
 import subprocess
 import sys
 
@@ -16,7 +17,21 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def run(cmd, env=None):
-    p = subprocess.run(cmd, cwd=ROOT, env={**os.environ, **(env or {})}, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    # One retry on a TIMEOUT only (never on a wrong result): two processes rendezvousing over loopback and sharing one GPU hung once in a dozen
+    # suite runs on one box (600 s without output, the same command 5 s four times in a row on the next box); a deadlock of ours would repeat.
+    for attempt in (0, 1):
+        proc = subprocess.Popen(cmd, cwd=ROOT, env={**os.environ, **(env or {})}, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                start_new_session=True)
+        try:
+            out, err = proc.communicate(timeout=300)
+            break
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)  # the launcher AND its ranks
+            proc.communicate()
+            if attempt == 1:
+                raise
+            print("bench.py timed out after 300 s: one retry", file=sys.stderr)
+    p = subprocess.CompletedProcess(cmd, proc.returncode, out, err)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]  # ONE JSON line, from rank 0
