@@ -31,6 +31,7 @@ _lib.register("hx_sac_act_step_f32i", [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_i
                                         ctypes.c_uint32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
 _lib.register("hx_sac_critic_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _i32, _vp])
 _lib.register("hx_sac_critic_grads_sampled", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _P(E.HxSample), _i32, _vp])
+_lib.register("hx_sac_critic_step", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _P(E.HxSample), _i32, _i32, _vp])
 _lib.register("hx_sac_policy_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _vp])
 _lib.register("hx_sac_adam", [_P(HxSacNets), _P(E.HxHyper), _i32, _i32, _f32, _f32, _vp])
 
@@ -218,13 +219,18 @@ class SacEngine:
         nets, hyper, gs = ctypes.byref(self.nets), ctypes.byref(self.hyper), 1.0 / self.world
         self.learning_steps += 1
         pending, self._pending = getattr(self, "_pending", None), None
-        if pending is not None:
-            _lib.call("hx_sac_critic_grads_sampled", nets, ctypes.byref(batch), hyper, ctypes.byref(pending[0]),
-                      int(self.learning_steps % self.interval == 0), st)
+        polyak_first = int(self.learning_steps % self.interval == 0)
+        if self.world == 1 and not getattr(self, "separate_critic_adam", False):
+            # one GPU: the critics' optimizer steps ride in the weight-gradient launch (bit-identical to the two calls below, one launch less)
+            _lib.call("hx_sac_critic_step", nets, ctypes.byref(batch), hyper, ctypes.byref(pending[0]) if pending is not None else None,
+                      polyak_first, self.learning_steps, st)
         else:
-            _lib.call("hx_sac_critic_grads", nets, ctypes.byref(batch), hyper, int(self.learning_steps % self.interval == 0), st)
-        self._allreduce(self.grad_critic)
-        _lib.call("hx_sac_adam", nets, hyper, 0, self.learning_steps, gs, self.target_entropy, st)
+            if pending is not None:
+                _lib.call("hx_sac_critic_grads_sampled", nets, ctypes.byref(batch), hyper, ctypes.byref(pending[0]), polyak_first, st)
+            else:
+                _lib.call("hx_sac_critic_grads", nets, ctypes.byref(batch), hyper, polyak_first, st)
+            self._allreduce(self.grad_critic)
+            _lib.call("hx_sac_adam", nets, hyper, 0, self.learning_steps, gs, self.target_entropy, st)
         _lib.call("hx_sac_policy_grads", nets, ctypes.byref(batch), hyper, st)
         if self.world > 1:  # mean entropy and the policy-loss terms are per-shard means: average them with the gradients
             self._allreduce(self.grad_policy)

@@ -3258,7 +3258,8 @@ int hx_sac_act_step_f32i(const float* policy, const float* w2_f32i, float* state
 /* Critic half of SacAgent.learn (SAC/agent.py:278-313): [Polyak of the target critics first when polyak_first], a', H' =
  * policy.sample(s') with eps_next, y = r + (1 - d) gamma (min Q_target(s', a') + alpha H'), q1_loss / q2_loss -> losses[0..1],
  * grad_critic.  Also evaluates policy(s) for the policy half.  Follow with hx_sac_adam(which = 0). */
-static int sac_critic_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t polyak_first, void* stream) {
+static int sac_critic_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t polyak_first, void* stream,
+                                 int adam_step = 0) {
     HX_REQUIRE(N && Bt && Hy && Bt->rows && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_sac_critic_grads: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int B = Bt->batch;
@@ -3319,8 +3320,23 @@ static int sac_critic_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const
             J = WgJob{};
             J.net = h ? q2 : q1; J.grad = N->grad_critic + h * kQs.padded(); J.m = kQs;
             J.ws[0] = s[SS_Q1 + h]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
+            if (adam_step > 0) {  // q1_optim.step() / q2_optim.step() ride in the wgrad launch (one GPU): the thread that produced a gradient steps it
+                J.p = N->critic + h * kQs.padded();
+                J.mom = N->m_critic + h * kQs.padded(); J.var = N->v_critic + h * kQs.padded();
+            }
         }
-        launch_wg<false>(W, st);
+        if (adam_step > 0) {
+            const double b1 = 0.9, b2 = 0.999;
+            const double bc1 = 1.0 - pow(b1, adam_step), bc2 = 1.0 - pow(b2, adam_step);
+            W.ad = WgAdam{};
+            W.ad.b1 = (float)b1; W.ad.b2 = (float)b2; W.ad.eps = 1e-8f;
+            W.ad.step_size = (float)(Hy->lr_critic / bc1);
+            W.ad.bc2_sqrt = (float)sqrt(bc2);
+            W.ad.losses = N->losses;
+            launch_wg<true>(W, st);
+        } else {
+            launch_wg<false>(W, st);
+        }
     }
     HX_CHECK_LAUNCH("hx_sac_critic_grads");
     return 0;
@@ -3337,6 +3353,12 @@ int hx_sac_critic_grads_sampled(const HxSacNets* N, const HxSacBatch* Bt, const 
 
 /* Policy half (SAC/agent.py:315-319, 376-406): a~, H = policy.sample(s) with eps_cur, Q1/Q2(s, a~) with the UPDATED critics,
  * policy_loss = mean(-min Q - alpha H) -> losses[2], mean entropy -> losses[4], grad_policy.  Follow with hx_sac_adam(which = 1). */
+/* One GPU: hx_sac_critic_grads[_sampled] + hx_sac_adam(which = 0, grad_scale 1) as ONE call with the optimizer step inside the weight-gradient
+ * launch (sample may be null: the minibatch was assembled by the caller).  Same Adam on the same gradients: bit-identical to the two calls. */
+int hx_sac_critic_step(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t polyak_first, int32_t step, void* stream) {
+    HX_REQUIRE(step >= 1, "hx_sac_critic_step: step is 1-based");
+    return sac_critic_grads_impl(N, Bt, Hy, S, polyak_first, stream, step);
+}
 int hx_sac_policy_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, void* stream) {
     HX_REQUIRE(N && Bt && Hy && Bt->rows && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_sac_policy_grads: bad arguments");
     hipStream_t st = (hipStream_t)stream;

@@ -341,6 +341,10 @@ int hx_sac_critic_grads(const HxSacNets* nets, const HxSacBatch* batch, const Hx
  * tile; batch <= 256 draws in-launch, larger batches run the sampling launch inside the call): same indices, tile and results. */
 int hx_sac_critic_grads_sampled(const HxSacNets* nets, const HxSacBatch* batch, const HxHyper* hyper, const HxSample* sample,
                                 int32_t polyak_first, void* stream);
+/* one GPU: critic gradients AND q1_optim / q2_optim steps (SAC/agent.py:278-313) in one call — the optimizer step rides in the weight-gradient
+ * launch; sample may be NULL (minibatch already assembled); step is 1-based.  Bit-identical to hx_sac_critic_grads[_sampled] + hx_sac_adam(0). */
+int hx_sac_critic_step(const HxSacNets* nets, const HxSacBatch* batch, const HxHyper* hyper, const HxSample* sample, int32_t polyak_first,
+                       int32_t step, void* stream);
 int hx_sac_policy_grads(const HxSacNets* nets, const HxSacBatch* batch, const HxHyper* hyper, void* stream);
 int hx_sac_adam(const HxSacNets* nets, const HxHyper* hyper, int32_t which, int32_t step, float grad_scale, float target_entropy,
                 void* stream);

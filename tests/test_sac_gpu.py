@@ -152,6 +152,31 @@ def test_sac_deferred_draw_is_bit_identical_to_the_sampling_launch(SE, esac):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
 
 
+@pytest.mark.parametrize("defer", [False, True])
+def test_sac_critic_step_in_the_wgrad_launch_is_bit_identical(SE, defer):
+    """hx_sac_critic_step (one GPU: q1_optim / q2_optim step inside the weight-gradient launch) against hx_sac_critic_grads[_sampled] +
+    hx_sac_adam(0): after 6 calls (two of them with the Polyak step of the targets first) the same networks, moments, targets and alpha."""
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    params = sac_params()
+    rng = np.random.default_rng(5)
+    rep = DeviceReplay(4096)
+    rep.ring.copy_(torch.from_numpy(rng.normal(size=(4096, 32)).astype(np.float32)))
+    rep.ring[:, 31] = (rep.ring[:, 31] > 1.0).float()
+    rep.total += 4096
+    a, b = (SE.SacEngine(batch=128) for _ in range(2))
+    b.separate_critic_adam = True
+    for e in (a, b):
+        e.load_params(params["policy"], params["q1"], params["q2"])
+    for k in range(6):
+        for e in (a, b):
+            e.sample(rep, None, seed=11, defer=defer)
+            e.learn()
+    for name in ("policy", "critic", "target_critic", "m_policy", "v_policy", "m_critic", "v_critic", "alpha_state", "w2_f32i"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    np.testing.assert_allclose(a.losses.cpu().numpy(), b.losses.cpu().numpy(), rtol=1e-6)  # (atomic accumulation order)
+
+
 @pytest.mark.parametrize("n", [7, 4096, 16384])
 def test_sac_image_path_is_bit_identical_and_follows_adam(SE, n):
     """hx_sac_act_f32i (the policy's W2 from its re-ordered fp32 image, what SacEngine.act uses) equals hx_sac_act (row-major W2 streamed
