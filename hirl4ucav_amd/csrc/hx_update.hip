@@ -16,7 +16,7 @@
 //            previous net's LN2/final/tanh "head" recomputed per workgroup when the input action is another net's output, the
 //            256 -> 512 GEMM tiled 16 rows x 32 / 64 columns per workgroup on fp32 MFMA (v_mfma_f32_16x16x4_f32: fp32 products and
 //            sums, parity at 1e-5); the first forward launch can also draw and gather the minibatch (SAMPLE);
-//   bwd_l2   head + loss gradient + LN2 backward in the prologue, dh1 = dz2 W2 on MFMA;
+//   bwd_l2   head + loss gradient + LN2 backward in the prologue (8 rows per workgroup, a wave pair per row), dh1 = dz2 W2 on MFMA;
 //   wgrad    dW2 = dz2^T h1 on MFMA (16 x 128 per workgroup, a tile per wave pair over row halves) + the vector / LN / layer-1 gradients
 //            (16 columns x 64 row groups per workgroup): 112 workgroups per job, written into a flat gradient buffer with the parameter layout (one all-reduce message per phase when
 //            sharded); on one GPU the same threads apply Adam, the Polyak step of the target and refresh the W2 images (ADAM);
