@@ -1,0 +1,730 @@
+// hx_act.hip — batched policy inference (gfx950): the whole policy for 16 / 32 observation rows in ONE workgroup, optionally with the
+// env step of the same rows in the kernel's tail, and the re-ordered images of W2 it reads.
+//   Agent.chooseAction / chooseActionSmallNoise / chooseActionNoNoise   hirl/agents/HIRL.py:192-212   (U5)  -> hx_actor_act*
+//   chooseAction + HarfangEnv.step                                      hirl/train_all.py:343-345           -> hx_actor_act_step*
+//   SacAgent.explore / exploit                                          hirl/agents/SAC/agent.py:183-196    -> hx_sac_act*
+#include "hx_update.h"
+#include "hx_env_dev.h"
+
+using namespace hxnn;
+using namespace hxu;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// act_fused: the whole policy for 16 observation rows in ONE workgroup — layer 1 + LN1 (VALU), z2 = h1 W2^T for all 512
+// columns (two 16-column MFMA tiles per wave, K = 256; W2 streams through two LDS buffers in 16-wide k-chunks, register-
+// prefetched two chunks ahead), then LN2 + final layer + tanh + exploration noise + clamp with one wave per row straight from the LDS copy
+// of z2.  No z2 round trip through HBM, no second launch.
+// chooseAction / chooseActionSmallNoise / chooseActionNoNoise, HIRL.py:192-212.
+// ---------------------------------------------------------------------------------------------------------------
+struct ActFusedArgs {
+    const float* net;
+    Mlp m;
+    float* obs;        // [rows][13]; written only by the ENV instantiations (next observation)
+    int rows;
+    float slope;
+    float* actions;      // [rows][4]
+    const float* noise;  // deterministic head: nullptr, [4] (shared) or [rows][4] additive noise; Gaussian head: eps [rows][4] or nullptr
+    int noise_per_row;
+    float sigma;
+    int mode;            // Gaussian head: 0 exploit tanh(mean), 1 sample with eps, 2 sample with Philox
+    uint64_t seed;
+    uint32_t row0, call;
+    // ENV instantiations: HarfangEnv.step for the same rows in the tail of this launch (obs is then in/out)
+    float* state;
+    int64_t stride;
+    float* reward;
+    uint8_t* done;
+    int8_t* success;
+    HxStepOpts o;
+    double inv_cap;  // 1 / o.cap
+    const uint16_t* w2b;  // BF16 instantiations: bf16 image of W2 [512][256] (hx_pack_w2_bf16 / the actor's Adam step keep it current)
+    const float* w2f;     // F32I instantiations: fp32 image of W2 (hx_pack_w2_f32i)
+};
+
+
+constexpr int ACT_KC = 16;            // k-chunk of W2 staged through LDS (64 B per column), double-buffered
+constexpr int ACT_LDW = ACT_KC + 8;   // pitch = 8 mod 16 dwords: conflict-free ds_read_b128 (see LDA1)
+constexpr int ACT_NCH = H1 / ACT_KC;  // 16 chunks
+
+// one standard-normal draw per (row, component j) of the acting kernels: Philox4x32-10(seed; row, call, tag) + Box-Muller
+__device__ __forceinline__ float philox_normal(uint32_t row, uint32_t call, uint32_t tag, uint64_t seed, int j) {
+    uint32_t u[4];
+    philox4x32_10(row, call, tag, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), u);
+    const float ua = u01(u[j & 2]), ub = u01(u[(j & 2) + 1]);
+    const float rad = sqrtf(-2.0f * logf(ua)), ang = 6.28318530717958647692f * ub;
+    return (j & 1) ? rad * sinf(ang) : rad * cosf(ang);
+}
+
+// NRT = 16-row tiles per workgroup: 1 keeps 256 workgroups busy at 4,096 rows; 2 (from 8,192 rows on) multiplies every W2
+// chunk against two row tiles, halving W2's L2 traffic and the barriers per MFMA.
+// GAUSS = the SAC policy: plain Linear-ReLU stack (m.no_ln), 8-wide head = mean ++ log_std, tanh-Gaussian sample
+// (SacAgent.explore / exploit, SAC/agent.py:183-196, GaussianPolicy.sample, SAC/model.py:63-82).
+// ENV   = the env step of the same rows runs in the tail: the 16 (32) actions meet in LDS and the lanes of wave 0 each step
+//         one env (hx_env_dev.h: the code of env_step_kernel, contraction off), with the fused replay insert — no second
+//         launch, and the env's ~2,500-instruction chain runs on every CU at once instead of on 16 of them.
+// BF16 = the policy's 256 -> 512 layer on v_mfma_f32_16x16x32_bf16 (BASELINE.json configs[4]: bf16 actor, fp32 dynamics): h1 is rounded to
+//         bf16 once, W2 comes from a bf16 image; accumulation, both LayerNorms, layer 1 and the head stay fp32.  Every wave owns 32 of
+//         the 512 columns and nobody else reads them, so its B fragments (16 x 16 B per lane = the 256 KB image once per
+//         workgroup) go from L2 straight into registers at kernel entry — no LDS staging, no chunk barriers; the 16 (32) rows
+//         of h1 are the only shared operand.
+template <int NRT, bool GAUSS, bool ENV, bool BF16, bool RELU, bool F32I = false>
+__global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
+    static_assert(!(BF16 && F32I), "one image format at a time");
+    constexpr int ROWS = NRT * RT;
+    __shared__ float s_act[ENV ? ROWS * 4 : 4];
+    __shared__ float s_noise[ROWS * 4];  // exploration noise of the workgroup's rows, drawn by the last wave(s) under the prologue's loads
+    __shared__ unsigned s_base;  // ring slot of the workgroup's first row
+    __shared__ int s_nstore;
+    static_assert(2 * H2 * ACT_LDW >= ROWS * LDA2, "the z2 tile reuses the W2 chunk buffers");
+    // fp32: two W2 chunk buffers (reused for z2 and, in the env tail, the replay rows / next observations)
+    // bf16: the z2 tile, then the replay rows / next observations, and the bf16 h1 tile
+    constexpr bool IMG = BF16 || F32I;  // W2 comes from an image straight into registers: no chunk buffers in LDS
+    constexpr int kTileA = IMG ? ROWS * LDA2 : H2 * ACT_LDW;
+    constexpr int kTileB = IMG ? (ENV ? ROWS * (hxenv::kRowPitch + HX_OBS_DIM) : 4) : H2 * ACT_LDW;
+    __shared__ __attribute__((aligned(16))) float lds[ROWS * LDA1 + ROWS * XP + ROWS * 2 + H1 * 13 + kTileA + kTileB];
+    __shared__ __attribute__((aligned(16))) __bf16 h1b[BF16 ? ROWS * LDB1 : 8];
+    float* h1s = lds;
+    float* xs = h1s + ROWS * LDA1;
+    float* sts = xs + ROWS * XP;
+    float* w1s = sts + ROWS * 2;
+    float* wb0 = w1s + H1 * 13;        // [H2][ACT_LDW]: even k-chunks of W2, every column
+    float* wb1 = wb0 + kTileA;         // odd k-chunks
+    float* z2s = wb0;                  // [ROWS][LDA2] once the last chunk has been multiplied
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * ROWS;
+    const int nrow = min(ROWS, A.rows - r0);
+    const float* net = A.net;
+    const Mlp m = A.m;
+    const float slope = A.slope;
+    // layer 1 runs on MFMA (as in fwd_l2): wave w owns hidden units 16 w .. 16 w + 15; lane (lr, lg) ends up with rows 4 lg .. 4 lg + 3 of unit u
+    const int lr = lane & 15, lg = lane >> 4, u = wave * 16 + lr;
+    STAMP_DECL;
+    STAMP();
+    // W2 chunk loader: 4 lanes cover one column's 64 B, the workgroup 256 columns per pass, 2 passes.  Every byte of W2 enters
+    // this CU once and is shared by all 16 waves from LDS.  Two register sets run two chunks ahead of the multiply, two LDS
+    // buffers one chunk ahead: per chunk one barrier, and the LDS stores of chunk c+1 sit under the MFMAs of chunk c.
+    const int piece = tid & 3, colb = tid >> 2;
+    const float* w2g = net + m.W2() + (size_t)colb * H1 + piece * 4;
+    const int w2w = colb * ACT_LDW + piece * 4;
+#define ACT_LOAD(ra, rb, c) { ra = *reinterpret_cast<const float4*>(w2g + (c) * ACT_KC); rb = *reinterpret_cast<const float4*>(w2g + (size_t)256 * H1 + (c) * ACT_KC); }
+#define ACT_STORE(buf, ra, rb) { *reinterpret_cast<float4*>((buf) + w2w) = ra; *reinterpret_cast<float4*>((buf) + w2w + 256 * ACT_LDW) = rb; }
+    // four register sets: chunk c travels in set c % 4 and is requested FOUR multiply phases before it is stored to LDS — with two sets
+    // (64 KB in flight per CU) the loop ran at the L2 round trip, not at the MFMA rate
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    uint4 bq[BF16 ? 2 : 1][BF16 ? 8 : 1];  // BF16: B fragments of this wave's two column tiles, all of K (requested below)
+    // F32I: every wave owns 32 of the 512 columns and nobody else reads them, so its fp32 B fragments go from L2 straight into registers
+    // in MFMA operand order — one contiguous kilobyte per load from the image — ACT_PF chunks ahead of the multiply: no LDS staging (80 KB of
+    // LDS traffic per chunk with it), no barrier per chunk; the waves stream independently.  Same k order as the staged loop: same bits.
+    constexpr int ACT_PF = 3;
+    float4 pb[F32I ? ACT_NCH : 1], qb[F32I ? ACT_NCH : 1];
+    const float* img0 = F32I ? A.w2f + (size_t)wave * (16 * 256) + lane * 4 : nullptr;  // 1 KB block (column tile `wave`, chunk c) at + 256 c floats; column tile 16 + wave 65,536 floats on
+    if constexpr (!BF16 && !F32I) {
+        ACT_LOAD(ra0, rb0, 0);
+        ACT_LOAD(ra1, rb1, 1);
+    }
+    // head parameters (g2, be2, W3, b3): requested now, parked in 4-8 registers, laid out in LDS once h1 is dead
+    typedef HeadImage<GAUSS ? 8 : 4> Img;
+    static_assert(Img::kStride <= ROWS * LDA1 + ROWS * XP + ROWS * 2 + H1 * 13, "the head image reuses the prologue's LDS");
+    Img himg;
+    float* hps = lds;
+    // all independent operands first
+    float xv = 0.0f;
+    if (tid < ROWS * 13) {
+        const int r = tid / 13;
+        if (r < nrow) xv = A.obs[(size_t)r0 * 13 + tid];  // the ROWS x 13 tile is contiguous
+    }
+    float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < H1 * 13 / 4) wv = reinterpret_cast<const float4*>(net + m.W1())[tid];
+    const float bias1 = net[m.b1() + u], g1v = net[m.g1() + u], be1v = net[m.be1() + u];
+    himg.fetch(net, m, tid);  // (needed last: behind the prologue's own operands)
+    if constexpr (!BF16 && !F32I) {  // behind the prologue's own operands
+        ACT_LOAD(ra2, rb2, 2);
+        ACT_LOAD(ra3, rb3, 3);
+    }
+    // The standard-normal draws of the rows' exploration noise depend on (row, call, seed) only.  In the head they cost every wave ~320
+    // instructions for 4 useful lanes (Philox + Box-Muller with the library's log / sin / cos), 16 waves deep on an issue-bound phase;
+    // here ONE wave draws all 64 (row, component) values of a row tile while its own loads are in flight.  Same function, same bits.
+    const bool draw_noise = GAUSS ? (A.mode != 0 && A.mode != 1) : (!A.noise && A.sigma > 0.0f);
+    if (draw_noise && wave >= kWide / 64 - NRT) {
+        const int lrow = (kWide / 64 - 1 - wave) * RT + (lane >> 2);
+        s_noise[lrow * 4 + (lane & 3)] = philox_normal(A.row0 + (uint32_t)(r0 + lrow), A.call, GAUSS ? 0x53414331u : 0x61637421u, A.seed, lane & 3);
+    }
+    if (tid < H1 * 13 / 4) reinterpret_cast<float4*>(w1s)[tid] = wv;
+    if (tid < ROWS * XP) xs[tid] = 0.0f;
+    __syncthreads();
+    // BF16: which 32 columns this wave owns rotates with the workgroup, so that the 256 workgroups of a launch do not all ask L2 for
+    // the same lines of the W2 image at the same moment
+    const int cw = BF16 ? ((wave + (int)blockIdx.x) & 15) : wave;
+    if constexpr (BF16) {
+        // requested only now, behind the prologue's own operands: every workgroup pulls the whole 256 KB image through L2 (64 MB per
+        // launch at 4,096 rows, ~6 us of L2 service); issued at kernel entry those requests queue up in front of OTHER workgroups'
+        // small operands and stall every prologue for that long.  From here they overlap layer 1 and LayerNorm 1.
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint16_t* blk = A.w2b + (size_t)((t * 16 + cw) * 8) * 512 + lane * 8;  // (lane = 16 g + r: w2_image_index's block order)
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) bq[t][sl] = *reinterpret_cast<const uint4*>(blk + sl * 512);
+        }
+    }
+    if (tid < ROWS * 13) xs[(tid / 13) * XP + tid % 13] = xv;
+    __syncthreads();
+    float z1[NRT][4];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {
+        v4f acc = {bias1, bias1, bias1, bias1};
+        const float* wrow = w1s + u * 13 + lg;  // columns 13.. of xs are zero; W1 is masked (the LDS words behind a row are not zeros)
+        const float* xrow = xs + (t * RT + lr) * XP + lg;
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {  // K = 16 covers the 13 inputs
+            const float wv = wrow[4 * mm];
+            acc = mfma16(xrow[4 * mm], 4 * mm + lg < 13 ? wv : 0.0f, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            z1[t][r] = acc[r];
+            h1s[(t * RT + 4 * lg + r) * LDA1 + u] = z1[t][r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {  // LN1 statistics: wave w owns rows w, 16 + w
+        const int row = t * RT + wave;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = h1s[row * LDA1 + i * 64 + lane];
+        float mean, rstd;
+        row_stats<4>(v, H1, mean, rstd);
+        if (m.no_ln) { mean = 0.0f; rstd = 1.0f; }
+        if (lane == 0) {
+            sts[row * 2] = mean;
+            sts[row * 2 + 1] = rstd;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = t * RT + 4 * lg + r;
+            const float hv = act_f<RELU>(g1v * ((z1[t][r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
+            if (BF16) h1b[row * LDB1 + u] = (__bf16)hv;  // v_cvt_pk_bf16_f32: round to nearest even
+            else h1s[row * LDA1 + u] = hv;
+        }
+    if (!BF16 && !F32I) {
+        ACT_STORE(wb0, ra0, rb0);
+        ACT_LOAD(ra0, rb0, 4);
+    }
+    if constexpr (F32I) {  // the first chunks of this wave's columns (behind the prologue's own traffic)
+#pragma unroll
+        for (int c = 0; c < ACT_PF; ++c) {
+            pb[c] = *reinterpret_cast<const float4*>(img0 + c * 256);
+            qb[c] = *reinterpret_cast<const float4*>(img0 + (size_t)16 * 16 * 256 + c * 256);
+        }
+    }
+    __syncthreads();
+    STAMP();
+    {   // z2 tiles: columns 16*wave .. and 256 + 16*wave .. of every row tile; k ascending, chunk by chunk
+        const int r = lane & 15, g = lane >> 4;
+        v4f acc[NRT][2];
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) acc[t][0] = acc[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF16) {
+            // K = 256 in 8 slabs of 32: lane (r, g) holds A[row r][32 sl + 8 g ..+7] and B[32 sl + 8 g ..+7][col r]
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) {
+                    const uint4 aq = *reinterpret_cast<const uint4*>(h1b + (t * RT + r) * LDB1 + 32 * sl + 8 * g);
+                    const v8bf a8 = __builtin_bit_cast(v8bf, aq);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(v8bf, bq[0][sl]), acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(v8bf, bq[1][sl]), acc[t][1], 0, 0, 0);
+                }
+            }
+        }
+        const float* ap = h1s + r * LDA1 + 4 * g;
+        const int boff = (wave * 16 + r) * ACT_LDW + 4 * g;
+#define ACT_MUL(buf, c) { \
+            float4 a4[NRT]; \
+            _Pragma("unroll") for (int t = 0; t < NRT; ++t) a4[t] = *reinterpret_cast<const float4*>(ap + t * RT * LDA1 + (c) * ACT_KC); \
+            const float4 p4 = *reinterpret_cast<const float4*>((buf) + boff); \
+            const float4 q4 = *reinterpret_cast<const float4*>((buf) + boff + 256 * ACT_LDW); \
+            _Pragma("unroll") for (int t = 0; t < NRT; ++t) { \
+                acc[t][0] = mfma16(a4[t].x, p4.x, acc[t][0]); acc[t][1] = mfma16(a4[t].x, q4.x, acc[t][1]); \
+                acc[t][0] = mfma16(a4[t].y, p4.y, acc[t][0]); acc[t][1] = mfma16(a4[t].y, q4.y, acc[t][1]); \
+                acc[t][0] = mfma16(a4[t].z, p4.z, acc[t][0]); acc[t][1] = mfma16(a4[t].z, q4.z, acc[t][1]); \
+                acc[t][0] = mfma16(a4[t].w, p4.w, acc[t][0]); acc[t][1] = mfma16(a4[t].w, q4.w, acc[t][1]); } }
+        static_assert(ACT_NCH % 4 == 0, "the chunk loop is unrolled by the four register sets");
+        if constexpr (F32I) {
+            float4 an[NRT];  // the h1 fragment of the NEXT chunk: its LDS round trip runs under this chunk's MFMAs
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) an[t] = *reinterpret_cast<const float4*>(ap + t * RT * LDA1);
+#pragma unroll
+            for (int c = 0; c < ACT_NCH; ++c) {
+                float4 a4[NRT];
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) a4[t] = an[t];
+                if (c + ACT_PF < ACT_NCH) {
+                    pb[c + ACT_PF] = *reinterpret_cast<const float4*>(img0 + (c + ACT_PF) * 256);
+                    qb[c + ACT_PF] = *reinterpret_cast<const float4*>(img0 + (size_t)16 * 16 * 256 + (c + ACT_PF) * 256);
+                }
+                if (c + 1 < ACT_NCH) {
+#pragma unroll
+                    for (int t = 0; t < NRT; ++t) an[t] = *reinterpret_cast<const float4*>(ap + t * RT * LDA1 + (c + 1) * ACT_KC);
+                }
+                // the requests stay HERE, ahead of the multiply: the scheduler otherwise sinks them to just before their use (fewer live
+                // registers) and every chunk then waits a full L2 / LDS round trip
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 p4 = pb[c], q4 = qb[c];
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) {
+                    acc[t][0] = mfma16(a4[t].x, p4.x, acc[t][0]); acc[t][1] = mfma16(a4[t].x, q4.x, acc[t][1]);
+                    acc[t][0] = mfma16(a4[t].y, p4.y, acc[t][0]); acc[t][1] = mfma16(a4[t].y, q4.y, acc[t][1]);
+                    acc[t][0] = mfma16(a4[t].z, p4.z, acc[t][0]); acc[t][1] = mfma16(a4[t].z, q4.z, acc[t][1]);
+                    acc[t][0] = mfma16(a4[t].w, p4.w, acc[t][0]); acc[t][1] = mfma16(a4[t].w, q4.w, acc[t][1]);
+                }
+            }
+            __syncthreads();  // every wave has read its last h1 fragment: the tile's LDS may now take z2 and the head image
+        }
+        for (int c = 0; c < ((BF16 || F32I) ? 0 : ACT_NCH); c += 4) {
+            // chunk c is in wb0; set 1 holds chunk c+1, sets 2, 3, 0 hold c+2, c+3, c+4 (in flight)
+            ACT_STORE(wb1, ra1, rb1);
+            if (c + 5 < ACT_NCH) ACT_LOAD(ra1, rb1, c + 5);
+            ACT_MUL(wb0, c);
+            __syncthreads();
+            ACT_STORE(wb0, ra2, rb2);
+            if (c + 6 < ACT_NCH) ACT_LOAD(ra2, rb2, c + 6);
+            ACT_MUL(wb1, c + 1);
+            __syncthreads();
+            ACT_STORE(wb1, ra3, rb3);
+            if (c + 7 < ACT_NCH) ACT_LOAD(ra3, rb3, c + 7);
+            ACT_MUL(wb0, c + 2);
+            __syncthreads();
+            if (c + 4 < ACT_NCH) {
+                ACT_STORE(wb0, ra0, rb0);
+                if (c + 8 < ACT_NCH) ACT_LOAD(ra0, rb0, c + 8);
+            }
+            ACT_MUL(wb1, c + 3);
+            __syncthreads();
+        }
+#undef ACT_MUL
+#undef ACT_LOAD
+#undef ACT_STORE
+        const float bb0 = net[m.b2() + cw * 16 + r], bb1 = net[m.b2() + 256 + cw * 16 + r];
+#pragma unroll
+        for (int t = 0; t < NRT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // every wave is past the last barrier: the chunk buffers are free for z2
+                z2s[(t * RT + 4 * g + q) * LDA2 + cw * 16 + r] = acc[t][0][q] + bb0;
+                z2s[(t * RT + 4 * g + q) * LDA2 + 256 + cw * 16 + r] = acc[t][1][q] + bb1;
+            }
+        himg.store(hps, net, m, tid);  // ... and h1 / x / W1 are dead: their LDS takes the head image
+    }
+    __syncthreads();
+    STAMP();
+    // ENV: the env lanes (wave 0, two lanes per env: hx_env_dev.h "Pair") request their state words and the current observation
+    // now — the head phase hides the round trip
+    hxenv::Stepper<true> envT;
+    float envPrev[HX_OBS_DIM];
+    const int env_e = lane >> 1;            // env of this lane inside the workgroup's rows
+    const bool env_opp = (lane & 1) != 0;   // this lane owns the opponent aircraft
+    if (ENV && wave == 0 && env_e < nrow) {
+        envT.load(A.state, A.stride, r0, (uint32_t)env_e, env_opp);
+#pragma unroll
+        for (int j = 0; j < HX_OBS_DIM; ++j) envPrev[j] = (A.o.ring && env_opp) ? A.obs[((size_t)r0 + env_e) * HX_OBS_DIM + j] : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {  // head: wave w owns rows w, 16 + w
+        const int lr = t * RT + wave;
+        if (lr >= nrow) continue;
+        const int r = r0 + lr;
+        RowReg<H2> xh, y, z;
+        float mean, rstd;
+        z.load(z2s + lr * LDA2);
+        if (!GAUSS) {
+            float o[4];
+            head_regs<4, 4, RELU>(z, hps, m.out, slope, xh, y, mean, rstd, o, m.no_ln);
+            if (lane < 4) {
+                float a = fast_tanh(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // no dynamic register index
+                if (A.noise) {
+                    a = fminf(fmaxf(a + A.noise[(A.noise_per_row ? (size_t)r * 4 : 0) + lane], -1.0f), 1.0f);
+                } else if (A.sigma > 0.0f) {
+                    a = fminf(fmaxf(a + A.sigma * s_noise[lr * 4 + lane], -1.0f), 1.0f);
+                }
+                A.actions[(size_t)r * 4 + lane] = a;
+                if (ENV) s_act[lr * 4 + lane] = a;
+            }
+        } else {
+            float o[8];
+            head_regs<8, 8, RELU>(z, hps, m.out, slope, xh, y, mean, rstd, o, m.no_ln);
+            if (lane < 4) {
+                // (selected from VALUES: a select chain over the elements of the array itself is folded back into a run-time index, which
+                //  puts the array in scratch or — promoted — in 32 KB of LDS)
+                const float o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3], o4 = o[4], o5 = o[5], o6 = o[6], o7 = o[7];
+                const float mu = lane == 0 ? o0 : lane == 1 ? o1 : lane == 2 ? o2 : o3;
+                float a = mu;
+                if (A.mode != 0) {
+                    const float ls = fminf(fmaxf(lane == 0 ? o4 : lane == 1 ? o5 : lane == 2 ? o6 : o7, -20.0f), 2.0f);  // model.py:65-66
+                    const float e = A.mode == 1 ? A.noise[(size_t)r * 4 + lane] : s_noise[lr * 4 + lane];
+                    a = mu + expf(ls) * e;
+                }
+                a = tanhf(a);
+                A.actions[(size_t)r * 4 + lane] = a;
+                if (ENV) s_act[lr * 4 + lane] = a;
+            }
+        }
+    }
+    if (ENV) {
+        using namespace hxenv;
+        float* s_row = wb1;                    // [ROWS][33] replay rows   (the odd chunk buffer is free since the last barrier)
+        float* s_obs = wb1 + ROWS * kRowPitch;  // [ROWS][13] next observations
+        // Ring slots: one atomic per workgroup on ONE address, 256 workgroups at about the same moment — its return takes ~3 us.  Which rows
+        // are stored depends on the state only (episode step counter against max_step), so wave 0 asks for its slots as soon as its own head
+        // row is done, BEFORE the barrier that collects the other rows' actions: the wait of the other waves and the env step hide it.
+        bool trunc = false, store = false;
+        int rank = 0, nstore = 0;
+        unsigned long long base = 0ull;
+        if (wave == 0) {
+            if (lane < 2 * ROWS && env_e < nrow) {
+                uint32_t ep = envT.episode_step();
+                ep = ep < 65535u ? ep + 1u : ep;
+                trunc = A.o.max_step > 0 && (int)ep >= A.o.max_step;  // train_all.py:346-347
+                store = A.o.ring != nullptr && !trunc;
+            }
+            const unsigned long long bal = __ballot(store && !env_opp);
+            rank = __popcll(bal & ((1ull << (lane & ~1)) - 1ull));  // both lanes of a pair get the env's rank
+            nstore = __popcll(bal);
+            if (lane == 0 && nstore > 0) base = atomicAdd((unsigned long long*)A.o.total, (unsigned long long)nstore);
+        }
+        __syncthreads();  // actions of all rows in s_act
+        STAMP();
+        if (wave == 0 && lane < 2 * ROWS) {
+            const int e = env_e;
+            const bool is_opp = env_opp, own = !env_opp;
+            const bool active = e < nrow;
+            const int64_t i = (int64_t)r0 + e;
+            Stepper<true>& T = envT;
+            float4 act = {0.f, 0.f, 0.f, 0.f};
+            bool bad_act = false;
+            if (active) {
+                act = *reinterpret_cast<const float4*>(s_act + e * 4);
+                bad_act = sanitize_action(act);
+            }
+            Wrapped W{};
+            V3 eu{}, eu2{};
+            bool ended = false;
+            unsigned st_kill = 0, st_fs = 0, st_tl = 0, st_fire = 0, st_good = 0, st_lock = 0;
+            if (active) {
+                T.step(act, is_opp, eu, eu2, W);
+                STAMP();
+                unsigned ended_own = 0;
+                if (own) {
+                    ended_own = (A.o.auto_reset && (W.done || trunc)) ? 1u : 0u;
+                    st_fire = (T.S.flags & HX_F_FIRED) ? 1u : 0u;
+                    st_good = W.success == 1 ? 1u : 0u;
+                    st_lock = (T.S.flags & HX_F_LOCKED) ? 1u : 0u;
+                    st_kill = (ended_own && (T.S.flags & HX_F_EPISODE_SUCCESS)) ? 1u : 0u;
+                    st_fs = (ended_own && (T.S.flags & HX_F_FIRE_SUCCESS)) ? 1u : 0u;
+                    st_tl = (ended_own && !W.done) ? 1u : 0u;
+                    A.reward[i] = W.reward;
+                    A.done[i] = W.done ? 1 : 0;
+                    A.success[i] = (int8_t)W.success;
+                }
+                const unsigned theirs = swap1u(ended_own);
+                ended = (own ? ended_own : theirs) != 0u;
+            }
+            if (store) {  // row = s[13] a[4] s'[13] r done   (Transition, buffer.py:8): each lane of the pair writes its share
+                float* row = s_row + rank * kRowPitch;
+                if (is_opp) {
+#pragma unroll
+                    for (int j = 0; j < HX_OBS_DIM; ++j) row[j] = envPrev[j];
+                    row[26] = eu.x; row[27] = eu.y; row[28] = eu.z;
+                } else {
+                    row[13] = act.x; row[14] = act.y; row[15] = act.z; row[16] = act.w;
+                    row[17] = W.o0; row[18] = W.o1; row[19] = W.o2;
+                    row[20] = eu.x; row[21] = eu.y; row[22] = eu.z;
+                    row[23] = W.o6; row[24] = W.o7; row[25] = W.o8;
+                    row[29] = W.o12;
+                    row[30] = W.reward;
+                    row[31] = W.done ? 1.0f : 0.0f;
+                }
+            }
+            // the workgroup's first ring slot, uniform across the wave
+            const unsigned long long b0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(base & 0xFFFFFFFFull));
+            const unsigned slot0 = nstore > 0 ? ring_slot(b0, (unsigned long long)A.o.cap, A.inv_cap) : 0u;
+            if (lane == 0) {
+                s_base = slot0;
+                s_nstore = nstore;
+            }
+            if (store && own && A.o.ring_success) A.o.ring_success[wrap_slot(slot0 + (unsigned)rank, (unsigned)A.o.cap)] = (int8_t)W.success;
+            if (active) {
+                if (ended) {
+                    uint32_t epi = 0u;
+                    if (own) {
+                        epi = A.o.episode_ctr[i] + 1u;
+                        A.o.episode_ctr[i] = epi;
+                    }
+                    T.reset(is_opp, A.o.randomize != 0, A.o.seed, A.o.env_id0 + (uint32_t)i, epi, eu, eu2, W);
+                }
+                T.store(A.state, A.stride, r0, (uint32_t)e, is_opp);
+                float* out = s_obs + e * HX_OBS_DIM;
+                if (own) {
+                    out[0] = W.o0; out[1] = W.o1; out[2] = W.o2;
+                    out[3] = eu.x; out[4] = eu.y; out[5] = eu.z;
+                    out[6] = W.o6; out[7] = W.o7; out[8] = W.o8;
+                    out[12] = W.o12;
+                } else {
+                    out[9] = eu.x; out[10] = eu.y; out[11] = eu.z;
+                }
+            }
+            STAMP();
+            if (A.o.stats) {
+                const bool mine_ = active && own;
+                const unsigned vals[HX_STAT_COUNT] = {(mine_ && ended) ? 1u : 0u, st_kill, st_fs, st_tl, st_fire, st_good, st_lock, mine_ ? 1u : 0u,
+                                                      (mine_ && bad_act) ? 1u : 0u};
+                unsigned mine = 0;
+#pragma unroll
+                for (int k = 0; k < HX_STAT_COUNT; ++k) {
+                    const unsigned c = (unsigned)__popcll(__ballot(vals[k] != 0u));
+                    if (lane == k) mine = c;
+                }
+                if (lane < HX_STAT_COUNT && mine) atomicAdd((unsigned long long*)&A.o.stats[lane], (unsigned long long)mine);
+            }
+        }
+        STAMP();
+        __syncthreads();  // rows, next observations, s_base / s_nstore
+        STAMP();
+        for (int k = tid; k < nrow * HX_OBS_DIM; k += kWide) A.obs[(size_t)r0 * HX_OBS_DIM + k] = s_obs[k];
+        const int nst = s_nstore;
+        if (nst > 0) {  // 16 B per lane, rows contiguous in the ring (modulo wrap)
+            const unsigned slot0 = s_base, cap = (unsigned)A.o.cap;
+            float4* ring4 = reinterpret_cast<float4*>(A.o.ring);
+            for (int k = tid; k < nst * (HX_ROW_WORDS / 4); k += kWide) {
+                const int rr = k >> 3, c = (k & 7) * 4;
+                const float* src = s_row + rr * kRowPitch + c;
+                ring4[(size_t)wrap_slot(slot0 + (unsigned)rr, cap) * (HX_ROW_WORDS / 4) + (k & 7)] = make_float4(src[0], src[1], src[2], src[3]);
+            }
+        }
+    }
+    STAMP();
+    STAMP_FLUSH(56, (blockIdx.x == 0 || blockIdx.x == 200) && tid == 0);
+    SPAN_LOG(HX_SPAN_ACT);
+}
+
+// 16 rows per workgroup fill the chip up to 4,096 rows; from 8,192 rows on 32 rows per workgroup reuse every W2 chunk twice
+// The env tail pays while the launch is ONE round of workgroups (256 CUs x 16 or 32 rows): beyond that every extra round repeats
+// the ~8 us tail, and the env kernel on its own (thousands of envs per launch, 10-14 us) is the cheaper way.
+constexpr int64_t kFuseEnvMax = 8192;
+
+template <bool GAUSS, bool BF16, bool RELU, bool F32I = false>
+static void launch_act_t(const ActFusedArgs& H, hipStream_t st) {
+    const bool env = H.state != nullptr;
+    // 32 rows per workgroup: from 8,192 rows on (fp32: below that, 16-row workgroups fill the chip and the fp32 MFMA work per workgroup
+    // is the longer pole); bf16: the same switch point by default (HX_ACT_BF16_NRT2_ROWS moves it: there the launch is bound by every workgroup pulling
+    // W2 through L2, not by MFMA)
+    static const int nrt2_bf16 = getenv("HX_ACT_BF16_NRT2_ROWS") ? atoi(getenv("HX_ACT_BF16_NRT2_ROWS")) : 8192;  // tuning knob
+    if (H.rows >= (BF16 ? nrt2_bf16 : 8192)) {
+        const dim3 grid((unsigned)((H.rows + 2 * RT - 1) / (2 * RT)));
+        if (env) hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, true, BF16, RELU, F32I>), grid, dim3(kWide), 0, st, H);
+        else hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, false, BF16, RELU, F32I>), grid, dim3(kWide), 0, st, H);
+    } else {
+        const dim3 grid((unsigned)((H.rows + RT - 1) / RT));
+        if (env) hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, true, BF16, RELU, F32I>), grid, dim3(kWide), 0, st, H);
+        else hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, false, BF16, RELU, F32I>), grid, dim3(kWide), 0, st, H);
+    }
+}
+template <bool GAUSS>
+static void launch_act(const ActFusedArgs& H, hipStream_t st) {
+    // the activation is a compile-time ReLU when the slope is 0 (HIRL, SAC; the Gaussian policy is a Linear-ReLU stack by definition)
+    if (GAUSS || H.slope == 0.0f) {
+        if (H.w2b) launch_act_t<GAUSS, true, true>(H, st);
+        else if (H.w2f) launch_act_t<GAUSS, false, true, true>(H, st);
+        else launch_act_t<GAUSS, false, true>(H, st);
+    } else {
+        if (H.w2b) launch_act_t<false, true, false>(H, st);
+        else if (H.w2f) launch_act_t<false, false, false, true>(H, st);
+        else launch_act_t<false, false, false>(H, st);
+    }
+}
+
+// bf16 image of a [n] fp32 array (round to nearest even): the policy's W2 for the BF16 acting kernels
+__global__ __launch_bounds__(kThreads) void pack_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int n) {
+    const int i = (blockIdx.x * kThreads + threadIdx.x) * 2;  // row-major element (column i / 256, k = i % 256); pairs stay adjacent in the image
+    if (i + 1 < n) {
+        const float2 v = *reinterpret_cast<const float2*>(src + i);
+        typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+        const v2bf r = {(__bf16)v.x, (__bf16)v.y};
+        *reinterpret_cast<unsigned*>(dst + w2_image_index((uint32_t)i / H1, (uint32_t)i % H1)) = __builtin_bit_cast(unsigned, r);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void pack_f32i_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
+    const int i = (blockIdx.x * kThreads + threadIdx.x) * 4;  // four consecutive k of one column: adjacent in the image too
+    if (i < n) *reinterpret_cast<float4*>(dst + w2f_image_index((uint32_t)i / H1, (uint32_t)i % H1)) = *reinterpret_cast<const float4*>(src + i);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t hx_act_workspace_floats(int64_t rows) { (void)rows; return 0; }  // the acting kernels keep z2 in LDS: no workspace any more
+
+/* chooseAction / chooseActionSmallNoise / chooseActionNoNoise for `rows` observations (HIRL.py:192-212):
+ * actions = clamp(actor(obs) + noise, -1, 1).  noise_mode 0: none, 1: noise[4] shared by all rows, 2: noise[rows][4],
+ * 3: N(0, sigma^2) per row and component from Philox(seed; row0 + row, call).  ws: unused since the whole policy runs in one kernel (may be NULL). */
+static int actor_act_impl(const float* actor, const uint16_t* w2b, const float* w2f, const float* obs, int64_t rows, float* actions, int32_t noise_mode, const float* noise,
+                 float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream) {
+    HX_REQUIRE(actor && obs && actions && rows > 0, "hx_actor_act: bad arguments");
+    HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act: bad noise mode");
+    ActFusedArgs H{actor, kActor, const_cast<float*>(obs), (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
+                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0, w2b, w2f};
+    launch_act<false>(H, (hipStream_t)stream);
+    HX_CHECK_LAUNCH("hx_actor_act");
+    return 0;
+}
+
+int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* actions, int32_t noise_mode, const float* noise,
+                 float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* ws, void* stream) {
+    (void)ws;
+    return actor_act_impl(actor, nullptr, nullptr, obs, rows, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream);
+}
+/* The same with the 256 -> 512 layer on bf16 MFMA (BASELINE.json configs[4]): w2_bf16 = hx_pack_w2_bf16 image of full2.weight. */
+int hx_actor_act_bf16(const float* actor, const uint16_t* w2_bf16, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
+                      const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream) {
+    HX_REQUIRE(w2_bf16 && (reinterpret_cast<uintptr_t>(w2_bf16) & 15u) == 0, "hx_actor_act_bf16: w2_bf16 must be a 16-byte aligned bf16 image of W2");
+    return actor_act_impl(actor, w2_bf16, nullptr, obs, rows, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream);
+}
+/* bf16 image (round to nearest even) of an MLP block's W2 [512][256]; in_dim = 13 (actor / policy) or 17 (Q head) locates it. */
+int hx_pack_w2_bf16(const float* net, int32_t in_dim, uint16_t* w2_bf16, void* stream) {
+    HX_REQUIRE(net && w2_bf16 && (in_dim == 13 || in_dim == 17), "hx_pack_w2_bf16: bad arguments");
+    const Mlp m{in_dim, 1, 0};
+    const int n = H2 * H1;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((n / 2 + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, net + m.W2(), w2_bf16, n);
+    HX_CHECK_LAUNCH("hx_pack_w2_bf16");
+    return 0;
+}
+
+static int check_step_args(const float* state, int64_t n, int64_t stride, const float* obs_io, const float* actions, const float* reward,
+                           const uint8_t* done, const int8_t* success, const HxStepOpts& o, const char* who) {
+    HX_REQUIRE(state && obs_io && actions && reward && done && success && n > 0 && stride >= n, "%s: bad buffers", who);
+    HX_REQUIRE(n < (int64_t)1 << 31, "%s: at most 2^31 - 1 envs per launch", who);
+    HX_REQUIRE(!o.auto_reset || o.episode_ctr, "%s: auto_reset needs episode_ctr", who);
+    HX_REQUIRE(stride < ((int64_t)1 << 25), "%s: stride must be below 2^25 envs", who);
+    HX_REQUIRE(!o.ring || (o.cap >= 512 && o.cap < ((int64_t)1 << 31) && o.total && (reinterpret_cast<uintptr_t>(o.ring) & 15u) == 0),
+               "%s: ring needs 512 <= cap < 2^31, total and 16-byte alignment", who);
+    return 0;
+}
+
+/* chooseAction + HarfangEnv.step for n envs in ONE launch (train_all.py:343-345): actions = clamp(actor(obs_io) + noise, -1, 1) as
+ * hx_actor_act, then hx_env_step with those actions in the tail of the same kernel — obs_io in: current observation, out: next. */
+static int actor_act_step_impl(const float* actor, const uint16_t* w2b, const float* w2f, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+                      const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward,
+                      uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
+    HX_REQUIRE(actor, "hx_actor_act_step: null actor");
+    HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act_step: bad noise mode");
+    const HxStepOpts o = opts ? *opts : HxStepOpts{};
+    if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_actor_act_step")) return rc;
+    if (n > kFuseEnvMax) {  // more than one round of workgroups: the env step is cheaper as a launch of its own
+        if (int rc = actor_act_impl(actor, w2b, w2f, obs_io, n, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream)) return rc;
+        return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
+    }
+    ActFusedArgs H{actor, kActor, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
+                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
+                   o.cap > 0 ? 1.0 / (double)o.cap : 0.0, w2b, w2f};
+    launch_act<false>(H, (hipStream_t)stream);
+    HX_CHECK_LAUNCH("hx_actor_act_step");
+    return 0;
+}
+
+int hx_actor_act_step(const float* actor, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+                      const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward,
+                      uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
+    return actor_act_step_impl(actor, nullptr, nullptr, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed, row0, call, slope, reward, done,
+                               success, opts, stream);
+}
+int hx_actor_act_step_bf16(const float* actor, const uint16_t* w2_bf16, float* state, int64_t n, int64_t stride, float* obs_io, float* actions,
+                           int32_t noise_mode, const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope,
+                           float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
+    HX_REQUIRE(w2_bf16 && (reinterpret_cast<uintptr_t>(w2_bf16) & 15u) == 0, "hx_actor_act_step_bf16: w2_bf16 must be a 16-byte aligned bf16 image of W2");
+    return actor_act_step_impl(actor, w2_bf16, nullptr, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed, row0, call, slope, reward, done,
+                               success, opts, stream);
+}
+
+/* The fp32 policy from the re-ordered fp32 image of W2 (hx_pack_w2_f32i): bit-identical to hx_actor_act / hx_actor_act_step. */
+int hx_pack_w2_f32i(const float* net, int32_t in_dim, float* w2_f32i, void* stream) {
+    HX_REQUIRE(net && w2_f32i && (in_dim == 13 || in_dim == 17) && (reinterpret_cast<uintptr_t>(w2_f32i) & 15u) == 0, "hx_pack_w2_f32i: bad arguments");
+    const Mlp m{in_dim, 1, 0};
+    const int n = H2 * H1;
+    hipLaunchKernelGGL(pack_f32i_kernel, dim3((n / 4 + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, net + m.W2(), w2_f32i, n);
+    HX_CHECK_LAUNCH("hx_pack_w2_f32i");
+    return 0;
+}
+int hx_actor_act_f32i(const float* actor, const float* w2_f32i, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
+                      const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream) {
+    HX_REQUIRE(w2_f32i && (reinterpret_cast<uintptr_t>(w2_f32i) & 15u) == 0, "hx_actor_act_f32i: w2_f32i must be a 16-byte aligned fp32 image of W2");
+    return actor_act_impl(actor, nullptr, w2_f32i, obs, rows, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream);
+}
+int hx_actor_act_step_f32i(const float* actor, const float* w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io, float* actions,
+                           int32_t noise_mode, const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope,
+                           float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
+    HX_REQUIRE(w2_f32i && (reinterpret_cast<uintptr_t>(w2_f32i) & 15u) == 0, "hx_actor_act_step_f32i: w2_f32i must be a 16-byte aligned fp32 image of W2");
+    return actor_act_step_impl(actor, nullptr, w2_f32i, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed, row0, call, slope, reward, done,
+                               success, opts, stream);
+}
+
+/* SacAgent.explore / exploit (SAC/agent.py:183-196) for `rows` observations.  mode 0: exploit = tanh(mean); 1: sample with the
+ * standard-normal draws eps[rows][4]; 2: sample with Philox(seed; row0 + row, call).  ws: unused since the whole policy runs in one kernel (may be NULL). */
+static int sac_act_impl(const float* policy, const float* w2f, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps,
+                        uint64_t seed, uint32_t row0, uint32_t call, void* stream) {
+    HX_REQUIRE(policy && obs && actions && rows > 0 && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act: bad arguments");
+    ActFusedArgs H{policy, kPolicy, const_cast<float*>(obs), (int)rows, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
+                   nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0, nullptr, w2f};
+    launch_act<true>(H, (hipStream_t)stream);
+    HX_CHECK_LAUNCH("hx_sac_act");
+    return 0;
+}
+int hx_sac_act(const float* policy, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps, uint64_t seed,
+               uint32_t row0, uint32_t call, float* ws, void* stream) {
+    (void)ws;
+    return sac_act_impl(policy, nullptr, obs, rows, actions, mode, eps, seed, row0, call, stream);
+}
+int hx_sac_act_f32i(const float* policy, const float* w2_f32i, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps,
+                    uint64_t seed, uint32_t row0, uint32_t call, void* stream) {
+    HX_REQUIRE(w2_f32i && (reinterpret_cast<uintptr_t>(w2_f32i) & 15u) == 0, "hx_sac_act_f32i: w2_f32i must be a 16-byte aligned fp32 image of W2");
+    return sac_act_impl(policy, w2_f32i, obs, rows, actions, mode, eps, seed, row0, call, stream);
+}
+
+/* SacAgent.explore / exploit + HarfangEnv.step in one launch (train_sac.py:238-241): hx_sac_act, then hx_env_step in the kernel's tail. */
+static int sac_act_step_impl(const float* policy, const float* w2f, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t mode,
+                             const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,
+                             const HxStepOpts* opts, void* stream) {
+    HX_REQUIRE(policy && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act_step: bad arguments");
+    const HxStepOpts o = opts ? *opts : HxStepOpts{};
+    if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_sac_act_step")) return rc;
+    if (n > kFuseEnvMax) {
+        if (int rc = sac_act_impl(policy, w2f, obs_io, n, actions, mode, eps, seed, row0, call, stream)) return rc;
+        return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
+    }
+    ActFusedArgs H{policy, kPolicy, obs_io, (int)n, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
+                   state, stride, reward, done, success, o, o.cap > 0 ? 1.0 / (double)o.cap : 0.0, nullptr, w2f};
+    launch_act<true>(H, (hipStream_t)stream);
+    HX_CHECK_LAUNCH("hx_sac_act_step");
+    return 0;
+}
+int hx_sac_act_step(const float* policy, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t mode,
+                    const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,
+                    const HxStepOpts* opts, void* stream) {
+    return sac_act_step_impl(policy, nullptr, state, n, stride, obs_io, actions, mode, eps, seed, row0, call, reward, done, success, opts, stream);
+}
+int hx_sac_act_step_f32i(const float* policy, const float* w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io, float* actions,
+                         int32_t mode, const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done,
+                         int8_t* success, const HxStepOpts* opts, void* stream) {
+    HX_REQUIRE(w2_f32i && (reinterpret_cast<uintptr_t>(w2_f32i) & 15u) == 0, "hx_sac_act_step_f32i: w2_f32i must be a 16-byte aligned fp32 image of W2");
+    return sac_act_step_impl(policy, w2_f32i, state, n, stride, obs_io, actions, mode, eps, seed, row0, call, reward, done, success, opts, stream);
+}
+
+}  // extern "C"
+
+HX_DEFINE_DEBUG_COLLECTORS(act, 56, 80)

@@ -6,6 +6,7 @@
 #include <cstdio>
 
 #include "../../include/hirl4ucav.h"
+#include "../../include/hirl4ucav_debug.h"
 
 namespace hx {
 
@@ -35,5 +36,13 @@ inline int fail(int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                   \
         if (e_ != hipSuccess) return ::hx::fail(HX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// diagnostic build (make stamps) only: each kernel file hands its share of the phase stamps / workgroup spans to hx_core.hip (hx_update.h)
+int dbg_stamps_fwdbwd(float* host80);
+int dbg_stamps_wgrad(float* host80);
+int dbg_stamps_act(float* host80);
+int dbg_spans_fwdbwd(unsigned long long* spans, unsigned* tags, unsigned* n, unsigned cap);
+int dbg_spans_wgrad(unsigned long long* spans, unsigned* tags, unsigned* n, unsigned cap);
+int dbg_spans_act(unsigned long long* spans, unsigned* tags, unsigned* n, unsigned cap);
 
 }  // namespace hx

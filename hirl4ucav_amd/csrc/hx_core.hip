@@ -16,6 +16,32 @@ __global__ void calib_copy_dword(const float* __restrict__ src, float* __restric
 }
 
 extern "C" {
+/* diagnostic builds only (make stamps): the 80 phase-stamp floats of the kernel files -> host memory; returns -1 in the shipped build */
+int hx_debug_stamps(float* host_out) {
+#ifdef HX_STAMPS
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    for (int i = 0; i < 80; ++i) host_out[i] = 0.0f;
+    if (int rc = hx::dbg_stamps_fwdbwd(host_out)) return rc;
+    if (int rc = hx::dbg_stamps_wgrad(host_out)) return rc;
+    return hx::dbg_stamps_act(host_out);
+#else
+    (void)host_out;
+    return -1;
+#endif
+}
+/* diagnostic builds only: the workgroup life-span logs (start, end in 10 ns ticks; tag = HX_SPAN_* kernel id) -> host, then cleared */
+int hx_debug_spans(unsigned long long* host_spans /* [8192][2] */, unsigned* host_tags /* [8192] */, unsigned* host_n) {
+#ifdef HX_STAMPS
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    *host_n = 0;
+    if (int rc = hx::dbg_spans_fwdbwd(host_spans, host_tags, host_n, 8192u)) return rc;
+    if (int rc = hx::dbg_spans_wgrad(host_spans, host_tags, host_n, 8192u)) return rc;
+    return hx::dbg_spans_act(host_spans, host_tags, host_n, 8192u);
+#else
+    (void)host_spans; (void)host_tags; (void)host_n;
+    return -1;
+#endif
+}
 int hx_debug_copy_dword(const float* src, float* dst, int64_t n, void* stream) {
     HX_REQUIRE(src && dst && n > 0, "hx_debug_copy_dword: bad arguments");
     hipLaunchKernelGGL(calib_copy_dword, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, (long long)n);

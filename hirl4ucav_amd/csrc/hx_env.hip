@@ -1,7 +1,7 @@
 // hx_env.hip — batched pursuit-lock-launch env step for gfx950 (MI355X).
 //
-// One thread per env, struct-of-arrays fp32 state in HBM (word w of env i at state[w*stride + i]: every load and
-// store of a wave is one contiguous 256-B segment), observation / replay-row tiles staged through LDS so that the
+// Two adjacent lanes per env (ally + shared words | opponent; hx_env_dev.h "Pair") or one ("Solo"), struct-of-arrays fp32 state in HBM (word
+// w of env i at state[w*stride + i]: every load and store of a wave is contiguous), observation / replay-row tiles staged through LDS so that the
 // row-major outputs leave the CU as full-line 16-B-per-lane stores, wave ballots for the store mask and the
 // episode statistics, one ring-head atomic per workgroup.
 //
@@ -14,8 +14,9 @@
 //   UniformMemory.store      hirl/utils/buffer.py:20-36 (U6), fused; episode rules train_all.py:341-361 (D1)
 //   get_reward/get_termination for expert labelling :299-336 (E13)
 //
-// Numerics: this file is compiled with -ffp-contract=off; state-evolving arithmetic uses only + - * / sqrt in a
-// fixed order, so masks are reproducible bit for bit.  asinf/atan2f/acosf appear only in the observation.
+// Numerics: this file is compiled with -ffp-contract=off; every operation of the model (docs/DYNAMICS.md, model v2) is spelled out — explicit
+// fmaf, + - * / sqrt in a fixed order, the model's own asin / acos / atan2 polynomials — so state words, masks, observations and rewards are
+// reproducible bit for bit against the scalar oracle.
 #include "hx_common.h"
 #include <hip/hip_ext.h>
 

@@ -6,7 +6,7 @@
 //         wrapper; lane 2e+1 owns the opponent aircraft.  Both run the SAME aircraft tick and Euler extraction on their own
 //         plane, so the env's dependent chain is one aircraft long instead of two; the opponent's new position crosses over
 //         with one DPP quad_perm per word.  Values are bit-identical to Solo (same functions on the same inputs).
-// Shared by hx_env.hip (env_step_kernel & co) and hx_update.hip (the act + env step fused launch).
+// Shared by hx_env.hip (env_step_kernel & co) and hx_act.hip (the act + env step fused launch).
 //
 // Numerics: fp32.  Every operation below is spelled out: `fm(a, b, c)` is ONE fused multiply-add (v_fma_f32 = C fmaf, both
 // correctly rounded), everything else rounds once per operator in the order written; the file is compiled with contraction
@@ -499,7 +499,7 @@ __device__ __forceinline__ void observe(const Env& E, float (&obs)[HX_OBS_DIM], 
 // =====================================================================================================================
 // One env step with the vectorised driver's episode rules (train_all.py:341-361), fused replay insert and statistics, for
 // a group of lanes of ONE wave (or several waves, see the barrier hooks).  Used by env_step_kernel (hx_env.hip) and by
-// the tail of act_fused_kernel (hx_update.hip).
+// the tail of act_fused_kernel (hx_act.hip).
 //
 //   PAIR = false: lane l steps env l.        PAIR = true: lanes 2e / 2e+1 step env e (ally+shared / opponent).
 //

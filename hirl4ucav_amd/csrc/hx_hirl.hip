@@ -1,0 +1,318 @@
+// hx_hirl.hip — host sequencing of Agent.learn (hirl/agents/HIRL.py:221-334), TD3.Agent.learn (hirl/agents/TD3.py:201-260) and
+// BC.Agent.train_actor (hirl/agents/BC.py:160-185): which nets ride in which launch.  4 launches on a critic-only call, 8 on a call with the
+// delayed actor step (minibatch draw and optimizer steps included); the stage entry points are what a sharded run calls between exchanges.
+#include <cmath>
+
+#include "hx_update.h"
+
+using namespace hxnn;
+using namespace hxu;
+
+namespace {
+__global__ void count_to_float_kernel(const int* count, float* out) {
+    if (threadIdx.x == 0) out[0] = count ? (float)*count : 0.0f;
+}
+}  // namespace
+
+extern "C" {
+
+int hx_actor_param_count(void) { return kActor.size(); }
+int hx_critic_param_count(void) { return 2 * kQ.padded(); }
+int64_t hx_hirl_workspace_floats(int32_t batch) { return (int64_t)S_COUNT * kSlotFloats * batch + 64; }
+int64_t hx_actor_message_floats(void) { return 2 * (int64_t)kActor.padded() + 64; }
+
+static void make_slots(const HxNets* N, int B, Slot* s) {
+    for (int i = 0; i < S_COUNT; ++i) s[i] = carve_slot(N->ws + (size_t)i * kSlotFloats * B, B);
+}
+
+/* Stage 1 (every call): TD target, critic forward, critic gradients -> grad_critic, losses[0].  HIRL.py:259-286.
+ * actor_fwd: 1 = also run the delayed actor step's forward passes that do not depend on the critic update (actor(s),
+ * actor(s_bc)), 2 = plus bc_actor(s) for the soft estimate — they ride in launch A instead of a launch of their own.
+ */
+// torch.optim.Adam's per-step scalars (defaults: betas (0.9, 0.999), eps 1e-8) for the fused wgrad + Adam launch
+static WgAdam make_adam(const HxNets* N, const HxHyper* Hy, float lr, int step, bool finish_actor) {
+    const double b1 = 0.9, b2 = 0.999;
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    WgAdam a{};
+    a.b1 = (float)b1; a.b2 = (float)b2; a.eps = 1e-8f;
+    a.step_size = (float)(lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.tau = Hy->tau;
+    a.finish_actor = finish_actor ? 1 : 0;
+    a.use_bc = Hy->use_bc;
+    a.losses = N->losses;
+    a.wstate = N->wstate;
+    return a;
+}
+
+// adam_step > 0: the critic's optimizer step (and, with polyak, the soft_update of its target) rides in the wgrad launch
+static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, void* stream, int adam_step, bool polyak,
+                             const HxSample* S = nullptr) {
+    HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_critic_grads: batch must be a positive multiple of 16");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = Bt->batch;
+    SampleDev SD{};
+    bool fused = false;
+    if (S) {  // the minibatch is drawn by this call: inside launch A (batch <= 256) or by the sampling launch first
+        HX_REQUIRE(Bt->noise, "hx_hirl_*_sampled: the draw needs the output word noise[4]");
+        if (int rc = prepare_draw(S, B, const_cast<float*>(Bt->rows), const_cast<float*>(Bt->bc_rows), const_cast<float*>(Bt->noise), stream, &SD, &fused)) return rc;
+    }
+    Slot s[S_COUNT];
+    make_slots(N, B, s);
+    const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
+    const float* tc1 = N->target_critic;
+    const float* tc2 = N->target_critic + kQ.padded();
+    {   // launch A: targetActor(s'), critic Q1/Q2 (s, a)
+        FwdArgs F{};
+        F.njobs = 3; F.slope = Hy->slope;
+        F.zero_f = N->losses; F.zero_nf = 1;  // critic_loss accumulator
+        F.job[0] = FwdJob{N->target_actor, kActor, src, 17, 0, Head{}, nullptr, 0.f, s[S_TA], B, 0};
+        F.job[1] = FwdJob{N->critic, kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C1], B, 1};
+        F.job[2] = FwdJob{N->critic + kQ.padded(), kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C2], B, 1};
+        if (actor_fwd) {  // the delayed actor step's forwards ride along, split so that NEITHER launch exceeds 256 workgroups
+            F.zero_nf = 5; F.zero_i = N->soft_count;  // + actor / bc / rl / bc_fire accumulators and the soft count
+            F.job[3] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1};
+            F.njobs = 4;
+        }
+        F.sample = fused ? &SD : nullptr;
+        launch_fwd(F, st);
+    }
+    {   // launch B: targetCritic Q1/Q2 (s', clamp(targetActor(s') + clamp(noise)))  [+ actor(s_bc), bc_actor(s)]
+        FwdArgs F{};
+        F.njobs = 2; F.slope = Hy->slope;
+        const Head prev{N->target_actor, kActor, s[S_TA]};
+        F.job[0] = FwdJob{tc1, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC1], B, 0};
+        F.job[1] = FwdJob{tc2, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC2], B, 0};
+        if (actor_fwd && Hy->use_bc) {
+            const RowSrc bcsrc{Bt->bc_rows ? Bt->bc_rows : Bt->rows, nullptr, nullptr, 0, 32};
+            int n = 2;
+            F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1};
+            if (actor_fwd == 2) F.job[n++] = FwdJob{N->bc_actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0};
+            F.njobs = n;
+        }
+        launch_fwd(F, st);
+    }
+    {   // launch C: y, loss, dq, LN2 backward, dh1 for both heads
+        BwdArgs G{};
+        G.njobs = 2; G.slope = Hy->slope; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = N->soft_count;
+        for (int h = 0; h < 2; ++h) {
+            BwdJob& J = G.job[h];
+            J = BwdJob{};
+            J.net = N->critic + h * kQ.padded(); J.m = kQ; J.ws = s[S_C1 + h]; J.rows = B; J.mode = BM_CRITIC_TD;
+            J.t1 = Head{tc1, kQ, s[S_TC1]}; J.t2 = Head{tc2, kQ, s[S_TC2]}; J.src = src; J.gamma = Hy->gamma;
+        }
+        launch_bwd(0, G, st);
+    }
+    {   // launch D: all critic parameter gradients
+        WgArgs W{};
+        W.njobs = 2; W.slope = Hy->slope; W.w_kind = 0; W.w_given = 0.f; W.inv_batch = 1.0f / B;
+        W.soft_count = N->soft_count; W.wstate = N->wstate;
+        for (int h = 0; h < 2; ++h) {
+            WgJob& J = W.job[h];
+            J = WgJob{};
+            J.net = N->critic + h * kQ.padded(); J.grad = N->grad_critic + h * kQ.padded(); J.m = kQ;
+            J.ws[0] = s[S_C1 + h]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
+            if (adam_step > 0) {
+                J.p = N->critic + h * kQ.padded();
+                J.mom = N->m_critic + h * kQ.padded(); J.var = N->v_critic + h * kQ.padded();
+                J.target = polyak ? N->target_critic + h * kQ.padded() : nullptr;
+            }
+        }
+        if (adam_step > 0) {
+            W.ad = make_adam(N, Hy, Hy->lr_critic, adam_step, false);
+            launch_wg(W, true, st);
+        } else {
+            launch_wg(W, false, st);
+        }
+    }
+    HX_CHECK_LAUNCH("hx_hirl_critic_grads");
+    return 0;
+}
+int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, void* stream) {
+    return critic_grads_impl(N, Bt, Hy, actor_fwd, stream, 0, false);
+}
+int hx_hirl_critic_grads_sampled(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t actor_fwd, void* stream) {
+    HX_REQUIRE(S, "hx_hirl_critic_grads_sampled: null sample description");
+    return critic_grads_impl(N, Bt, Hy, actor_fwd, stream, 0, false, S);
+}
+
+/* Stage 2a (delayed actor step, HIRL.py:291-319): actor / bc_actor forward, Q1 with the UPDATED critic, the soft
+ * count, backward down to dz2/dh1 of the actor.  Leaves soft_count and losses[2..4] ready; no parameter gradient yet. */
+int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t estimate_soft, int32_t fwd_done, void* stream) {
+    HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_actor_backward: batch must be a positive multiple of 16");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = Bt->batch;
+    Slot s[S_COUNT];
+    make_slots(N, B, s);
+    const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
+    const RowSrc bcsrc{Bt->bc_rows ? Bt->bc_rows : Bt->rows, nullptr, nullptr, 0, 32};
+    const bool bc = Hy->use_bc != 0, soft = bc && estimate_soft;
+    if (!fwd_done) {   // launch F: actor(s), actor(s_bc), bc_actor(s)  (hx_hirl_critic_grads(actor_fwd) can carry them instead)
+        FwdArgs F{};
+        F.slope = Hy->slope;
+        F.zero_f = N->losses + 1; F.zero_nf = 4; F.zero_i = N->soft_count;  // actor / bc / rl / bc_fire accumulators + soft count
+        int n = 0;
+        F.job[n++] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1};
+        if (bc) F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1};
+        if (soft) F.job[n++] = FwdJob{N->bc_actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0};
+        F.njobs = n;
+        launch_fwd(F, st);
+    }
+    {   // launch G: Q1(s, pi(s)) and Q1(s, bc_actor(s)) with the updated critic
+        FwdArgs F{};
+        F.slope = Hy->slope;
+        int n = 0;
+        F.job[n++] = FwdJob{N->critic, kQ, src, 0, 1, Head{N->actor, kActor, s[S_API]}, nullptr, 0.f, s[S_CPI], B, 1};
+        if (soft) F.job[n++] = FwdJob{N->critic, kQ, src, 0, 1, Head{N->bc_actor, kActor, s[S_BCS]}, nullptr, 0.f, s[S_CSOFT], B, 0};
+        F.njobs = n;
+        launch_fwd(F, st);
+    }
+    {   // launch H: rl_loss, soft count, critic backward down to dh1 (gradient wrt the action comes next)
+        BwdArgs G{};
+        G.njobs = 1; G.slope = Hy->slope; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = N->soft_count;
+        BwdJob& J = G.job[0];
+        J = BwdJob{};
+        J.net = N->critic; J.m = kQ; J.ws = s[S_CPI]; J.rows = B; J.mode = BM_CRITIC_PI;
+        if (soft) J.soft = Head{N->critic, kQ, s[S_CSOFT]};
+        launch_bwd(1, G, st);
+    }
+    {   // launch I: actor backward for the RL batch (through tanh and the critic's input gradient) and the BC batch
+        BwdArgs G{};
+        G.slope = Hy->slope; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = N->soft_count;
+        int n = 0;
+        {
+            BwdJob& J = G.job[n++];
+            J = BwdJob{};
+            J.net = N->actor; J.m = kActor; J.ws = s[S_API]; J.rows = B; J.mode = BM_ACTOR_PI;
+            J.crit = Head{N->critic, kQ, s[S_CPI]};
+        }
+        if (bc) {
+            BwdJob& J = G.job[n++];
+            J = BwdJob{};
+            J.net = N->actor; J.m = kActor; J.ws = s[S_ABC]; J.rows = B; J.mode = BM_ACTOR_BC;
+            J.src = bcsrc; J.lambda = Hy->loss_lambda;
+        }
+        G.njobs = n;
+        launch_bwd(2, G, st);
+    }
+    HX_CHECK_LAUNCH("hx_hirl_actor_backward");
+    return 0;
+}
+
+/* Stage 2b: actor parameter gradients grad_actor = w * dL_bc + (1 - w) * dL_rl (HIRL.py:321-324).
+ * w_kind 0: w_given (linear / fixed schedule, train_all.py:328-333); 1: soft estimate soft_count / batch + warm
+ * (HIRL.py:304-306; soft_count may have been all-reduced and `batch` is then the global batch); 2: stored weight. */
+static int actor_wgrad_impl(const HxNets* N, const HxHyper* Hy, int32_t batch, int32_t count_batch, int32_t w_kind, float w_given,
+                            float warm, void* stream, int adam_step, bool polyak) {
+    HX_REQUIRE(N && Hy && batch > 0 && count_batch > 0, "hx_hirl_actor_wgrad: bad arguments");
+    Slot s[S_COUNT];
+    make_slots(N, batch, s);
+    const bool bc = Hy->use_bc != 0;
+    WgArgs W{};
+    W.njobs = 1; W.slope = Hy->slope; W.w_kind = bc ? w_kind : 0; W.w_given = bc ? w_given : 0.0f; W.warm = warm;
+    W.inv_batch = 1.0f / count_batch; W.soft_count = N->soft_count; W.wstate = N->wstate;
+    WgJob& J = W.job[0];
+    J = WgJob{};
+    J.net = N->actor; J.grad = N->grad_actor; J.m = kActor;
+    J.ws[0] = s[S_API]; J.rows[0] = batch; J.wmode[0] = 1;
+    J.nslots = 1;
+    if (bc) { J.ws[1] = s[S_ABC]; J.rows[1] = batch; J.wmode[1] = 2; J.nslots = 2; }
+    if (adam_step > 0) {  // actor.optimizer.step() (+ soft_update of targetActor, + the bf16 image) in the same launch
+        J.p = N->actor; J.mom = N->m_actor; J.var = N->v_actor;
+        J.target = polyak ? N->target_actor : nullptr;
+        J.w2b = N->actor_w2_bf16;
+        J.w2f = N->actor_w2_f32i;
+        W.ad = make_adam(N, Hy, Hy->lr_actor, adam_step, true);
+        launch_wg(W, true, (hipStream_t)stream);
+    } else {
+        launch_wg(W, false, (hipStream_t)stream);
+    }
+    HX_CHECK_LAUNCH("hx_hirl_actor_wgrad");
+    return 0;
+}
+int hx_hirl_actor_wgrad(const HxNets* N, const HxHyper* Hy, int32_t batch, int32_t count_batch, int32_t w_kind, float w_given,
+                        float warm, void* stream) {
+    return actor_wgrad_impl(N, Hy, batch, count_batch, w_kind, w_given, warm, stream, 0, false);
+}
+
+/* Stage 2b of a sharded run with ONE exchange for the actor phase: the UNWEIGHTED gradients of the two actor losses and the local soft
+ * count go into one message, msg = [dL_rl | dL_bc | count, 0...] (hx_actor_message_floats()); after its all-reduce hx_adam_mixed
+ * forms w from the global count and combines.  TD3 (use_bc = 0): dL_rl only. */
+int hx_hirl_actor_wgrad_split(const HxNets* N, const HxHyper* Hy, int32_t batch, float* msg, void* stream) {
+    HX_REQUIRE(N && Hy && batch > 0 && msg && (reinterpret_cast<uintptr_t>(msg) & 15u) == 0, "hx_hirl_actor_wgrad_split: bad arguments");
+    Slot s[S_COUNT];
+    make_slots(N, batch, s);
+    const bool bc = Hy->use_bc != 0;
+    WgArgs W{};
+    W.njobs = bc ? 2 : 1; W.slope = Hy->slope; W.w_kind = 0; W.w_given = 0.0f; W.inv_batch = 1.0f / batch;
+    W.soft_count = N->soft_count; W.wstate = N->wstate;
+    for (int j = 0; j < W.njobs; ++j) {
+        WgJob& J = W.job[j];
+        J = WgJob{};
+        J.net = N->actor; J.grad = msg + j * kActor.padded(); J.m = kActor;
+        J.ws[0] = s[j == 0 ? S_API : S_ABC]; J.rows[0] = batch; J.wmode[0] = 0; J.nslots = 1;
+    }
+    launch_wg(W, false, (hipStream_t)stream);
+    hipLaunchKernelGGL(count_to_float_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, bc ? N->soft_count : nullptr, msg + 2 * kActor.padded());
+    HX_CHECK_LAUNCH("hx_hirl_actor_wgrad_split");
+    return 0;
+}
+
+/* One whole Agent.learn on a single GPU (no gradient exchange): the stages above back to back in ONE host call.
+ * actor_phase: this is an actorTrainable call (HIRL.py:291); do_polyak: its update_count hits target_update_freq
+ * (HIRL.py:327).  critic_step / actor_step: 1-based Adam step numbers of this call. */
+int hx_hirl_learn(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t critic_step, int32_t actor_phase,
+                  int32_t actor_step, int32_t do_polyak, int32_t w_kind, float w_given, float warm, void* stream) {
+    // 4 launches on a critic-only call, 8 on an actor call: the two optimizer steps (and the Polyak passes of the calls that move the
+    // targets) ride in the wgrad launches, the actor's critic-independent forwards in launches A and B
+    return hx_hirl_learn_sampled(N, Bt, Hy, nullptr, critic_step, actor_phase, actor_step, do_polyak, w_kind, w_given, warm, stream);
+}
+/* The same with the minibatch drawn and gathered inside the first launch (sample == NULL: the tiles of Bt are inputs, as above). */
+int hx_hirl_learn_sampled(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t critic_step, int32_t actor_phase,
+                          int32_t actor_step, int32_t do_polyak, int32_t w_kind, float w_given, float warm, void* stream) {
+    HX_REQUIRE(critic_step >= 1 && (!actor_phase || actor_step >= 1), "hx_hirl_learn: Adam steps are 1-based");
+    int rc = critic_grads_impl(N, Bt, Hy, actor_phase ? (w_kind == 1 ? 2 : 1) : 0, stream, critic_step, do_polyak != 0, S);
+    if (rc || !actor_phase) return rc;
+    if ((rc = hx_hirl_actor_backward(N, Bt, Hy, w_kind == 1, 1, stream))) return rc;
+    return actor_wgrad_impl(N, Hy, Bt->batch, Bt->batch, w_kind, w_given, warm, stream, actor_step, do_polyak != 0);
+}
+
+/* BC.Agent.train_actor (hirl/agents/BC.py:160-185): one behaviour-cloning step of the actor on the BC minibatch
+ * Bt->bc_rows — loss = mse(actor(s_bc), a_bc) (no loss_lambda here), backward, actor.optimizer.step().
+ * losses[2] receives the loss.  Hy->slope = 0.01 reproduces BC.py's LeakyReLU actor. */
+int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t step, void* stream) {
+    HX_REQUIRE(N && Bt && Hy && Bt->bc_rows && Bt->batch > 0 && Bt->batch % 16 == 0 && step >= 1, "hx_bc_train_actor: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = Bt->batch;
+    Slot s[S_COUNT];
+    make_slots(N, B, s);
+    const RowSrc bcsrc{Bt->bc_rows, nullptr, nullptr, 0, 32};
+    {
+        FwdArgs F{};
+        F.njobs = 1; F.slope = Hy->slope;
+        F.zero_f = N->losses + 1; F.zero_nf = 4;
+        F.job[0] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1};
+        launch_fwd(F, st);
+    }
+    {
+        BwdArgs G{};
+        G.njobs = 1; G.slope = Hy->slope; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = N->soft_count;
+        BwdJob& J = G.job[0];
+        J = BwdJob{};
+        J.net = N->actor; J.m = kActor; J.ws = s[S_ABC]; J.rows = B; J.mode = BM_ACTOR_BC; J.src = bcsrc; J.lambda = 1.0f;
+        launch_bwd(2, G, st);
+    }
+    {
+        WgArgs W{};
+        W.njobs = 1; W.slope = Hy->slope; W.w_kind = 0; W.w_given = 0.f; W.inv_batch = 1.0f / B;
+        W.soft_count = N->soft_count; W.wstate = N->wstate;
+        WgJob& J = W.job[0];
+        J = WgJob{};
+        J.net = N->actor; J.grad = N->grad_actor; J.m = kActor; J.ws[0] = s[S_ABC]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
+        launch_wg(W, false, st);
+    }
+    HX_CHECK_LAUNCH("hx_bc_train_actor");
+    return hx_adam(N, Hy, 2, step, 1.0f, 0, 0.0f, 0.0f, B, stream);
+}
+
+}  // extern "C"

@@ -65,8 +65,6 @@ enum { HX_STAT_EPISODES = 0, HX_STAT_KILLS, HX_STAT_FIRE_SUCCESS_EPISODES, HX_ST
 
 const char* hx_last_error(void);
 int hx_version(void);
-/* PMC calibration helper: dst[i] = src[i], one dword per lane (the env kernel's access shape), n floats */
-int hx_debug_copy_dword(const float* src, float* dst, int64_t n, void* stream);
 /* Kernel-duration events for HxStepOpts.ev_start / ev_stop (bench.py's live roofline measurement). */
 void* hx_event_create(void);
 int hx_event_destroy(void* ev);
@@ -136,8 +134,6 @@ int hx_label_transitions(const float* s, const float* a, const float* ns, int64_
  * Actor = one block (in 13, out 4) = 138,756 floats; Critic = two blocks (in 17, out 1), each padded from 138,241
  * to 138,244 floats so that the second head stays 16-byte aligned (hx_critic_param_count() = 276,488).
  * ------------------------------------------------------------------------------------------------------------ */
-int hx_debug_stamps(float* host_out /* host, 80 floats */); /* diagnostic builds only; -1 in the shipped build */
-int hx_debug_spans(unsigned long long* host_spans /* [8192][2] */, unsigned* host_tags /* [8192] */, unsigned* host_n); /* same: workgroup life spans */
 int hx_actor_param_count(void);
 int hx_critic_param_count(void);
 int64_t hx_hirl_workspace_floats(int32_t batch);
@@ -174,7 +170,7 @@ int hx_actor_act_step_bf16(const float* actor, const uint16_t* w2_bf16, float* s
  * hx_actor_act / hx_actor_act_step — but every wave reads its 32 columns of W2 as contiguous kilobytes straight into registers (MFMA
  * operand order) instead of streaming the row-major matrix through LDS with a barrier per 16 k-values.  hx_pack_w2_f32i writes the image
  * of the MLP block at `net`; HxNets.actor_w2_f32i (below) keeps it current through every Adam step of the actor.  The image order is an
- * internal format (w2f_image_index in hx_update.hip); both image formats (this and the bf16 one) are for the deterministic policy head. */
+ * internal format (w2f_image_index in hx_update.h); both image formats (this and the bf16 one) are for the deterministic policy head. */
 int hx_pack_w2_f32i(const float* net, int32_t in_dim, float* w2_f32i, void* stream);
 int hx_actor_act_f32i(const float* actor, const float* w2_f32i, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
                       const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream);

@@ -1,4 +1,5 @@
-"""The C-ABI library loads without a GPU and exports every symbol include/hirl4ucav.h declares (no compute)."""
+"""The C-ABI library loads without a GPU and exports every symbol include/hirl4ucav.h (product) and include/hirl4ucav_debug.h
+(measurement helpers) declare — and nothing else named hx_* (no compute)."""
 import ctypes
 import os
 import re
@@ -8,10 +9,13 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(REPO, "include", "hirl4ucav.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(hx_[a-z0-9_]+)\s*\(", text)))
+def declared_symbols(headers=("hirl4ucav.h", "hirl4ucav_debug.h")):
+    out = set()
+    for h in headers:
+        text = open(os.path.join(REPO, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(hx_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
 
 
 def test_header_declares_the_hot_path():
@@ -31,6 +35,13 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     L.hx_version.restype = ctypes.c_int
     assert L.hx_version() >= 100
+    # ... and exports nothing the headers do not declare; the debug helpers live in their own header
+    import subprocess
+
+    nm = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    exported = sorted({ln.split()[-1] for ln in nm.splitlines() if ln.split() and ln.split()[-1].startswith("hx_") and " T " in ln})
+    assert exported == declared_symbols(), sorted(set(exported) ^ set(declared_symbols()))
+    assert not [s for s in declared_symbols(("hirl4ucav.h",)) if s.startswith("hx_debug")]
 
 
 def test_argument_errors_are_reported_not_swallowed():

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 
 def image_order(w2):
-    """bf16 W2 [512][256] in the order the acting kernel reads it (hx_update.hip w2_image_index): 1 KB blocks per (column tile of 16,
+    """bf16 W2 [512][256] in the order the acting kernel reads it (hx_update.h w2_image_index): 1 KB blocks per (column tile of 16,
     k-slab of 32), inside a block lane (g = k group of 8, r = column) x 8 consecutive k"""
     t = w2.reshape(32, 16, 8, 4, 8)          # [column tile][r][slab][g][e]
     return t.permute(0, 2, 3, 1, 4).reshape(-1)  # [column tile][slab][g][r][e]
@@ -110,7 +110,7 @@ def test_bf16_image_follows_the_actor_adam_step(mods):
 
 
 def f32_image_order(w2):
-    """fp32 W2 [512][256] in the fp32 image's order (hx_update.hip w2f_image_index): 1 KB blocks per (column tile of 16, k-chunk of 16),
+    """fp32 W2 [512][256] in the fp32 image's order (hx_update.h w2f_image_index): 1 KB blocks per (column tile of 16, k-chunk of 16),
     inside a block lane (g = k group of 4, r = column) x 4 consecutive k"""
     return w2.reshape(32, 16, 16, 4, 4).permute(0, 2, 3, 1, 4).reshape(-1)  # [tile][r][chunk][g][e] -> [tile][chunk][g][r][e]
 

@@ -1,5 +1,5 @@
 """Static instruction mix of the kernels in a gfx950 assembly file (hipcc -S --cuda-device-only), to steer the instruction diet of the
-issue-bound update kernels:   python tools/asm_mix.py /tmp/hx_update.s [name filter ...]"""
+issue-bound update kernels:   python tools/asm_mix.py /tmp/hx_fwdbwd.s [name filter ...]"""
 import collections
 import re
 import sys

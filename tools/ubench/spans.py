@@ -1,7 +1,7 @@
 """Where a step's time goes BETWEEN workgroups.  The phase-stamp build (`make -C hirl4ucav_amd/csrc stamps`) logs the life span of every
 workgroup of every update / acting launch (s_memrealtime at its first instruction and at its exit, 10 ns ticks, one clock for the whole
 device).  This tool runs a few steady-state steps, then logs one step with a critic-only learn() and one with an actor learn(), groups the
-spans into launches (tag = source line of the exit, launches are serial on one stream) and prints per launch:
+spans into launches (tag = kernel id, launches are serial on one stream) and prints per launch:
 
     first workgroup start | last workgroup start | first exit | last exit          (us, relative to the step's first workgroup)
     gap = this launch's first start - the previous launch's last exit              (drain + dispatch of the boundary)
@@ -70,11 +70,8 @@ def main():
     loop = B.Loop(B.parse([]), 0, 1, torch.device("cuda", 0))
     L = _lib.load()
     L.hx_debug_spans.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]
-    # tags are source lines of the SPAN_LOG() sites: map them to kernels by order of appearance in the file
-    src = open(os.path.join(os.path.dirname(_lib.SO_PATH), "csrc", "hx_update.hip")).read().split("\n")
-    sites = [i + 1 for i, ln in enumerate(src) if ln.strip() == "SPAN_LOG();"]
-    labels = ["fwd_l2", "act_fused", "bwd_l2", "wgrad", "wgrad", "wgrad"]
-    names = {ln: (lab,) for ln, lab in zip(sites, labels)}
+    # tags are kernel ids (hx_update.h HX_SPAN_*)
+    names = {1: ("fwd_l2",), 2: ("act_fused",), 3: ("bwd_l2",), 4: ("wgrad",)}
     for _ in range(40):
         loop.step()
     torch.cuda.synchronize()

@@ -1,6 +1,5 @@
 """Phase stamps of one fwd_l2 / bwd_l2 / wgrad / act_fused workgroup.  Diagnostic build (never the product .so):
-    cd hirl4ucav_amd/csrc && for f in hx_core hx_update hx_env; do hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DHX_STAMPS \
-        $([ $f = hx_env ] && echo -ffp-contract=off) -c $f.hip -o /tmp/$f.o; done; hipcc --offload-arch=gfx950 -shared -fPIC -o ../libhx_mi355_stamps.so /tmp/hx_*.o
+    make -C hirl4ucav_amd/csrc stamps      (-> hirl4ucav_amd/libhx_mi355_stamps.so)
 """
 import ctypes
 import os
