@@ -130,12 +130,14 @@ def plane_state(rb, pid, cmd, thrust):
     st = {"position": [float(v) for v in pos], "Euler_angles": [float(v) for v in eul], "easy_steering": True,
           "health_level": 1.0 if ally else float(rb[13]), "destroyed": False, "wreck": False, "crashed": False, "active": True,
           "type": "AICRAFT", "nationality": 1 if ally else 2, "thrust_level": thrust, "brake_level": 0, "flaps_level": 0,
-          "altitude": float(pos[1]), "heading": float(eul[1]) * 57.29577951308232, "pitch_attitude": -float(eul[0]) * 57.29577951308232,
+          "altitude": float(pos[1]), "heading": (float(eul[1]) * 57.29577951308232) % 360.0, "pitch_attitude": -float(eul[0]) * 57.29577951308232,
           "roll_attitude": float(eul[2]) * 57.29577951308232, "post_combustion": True, "user_pitch_level": cmd[0], "user_roll_level": cmd[1],
           "user_yaw_level": cmd[2], "gear": False, "ia": False, "autopilot": False, "target_id": OPPO if ally else ALLY}
     if ally:
         st["target_locked"] = bool(rb[14] > 0.5)
-        st["target_out_of_range"] = False
+        # the lock envelope of docs/DYNAMICS.md "Targeting device" (100 m .. 3 km); hirl/data/straight_line/ai_env.py:18 shows the field
+        dist = sum((float(rb[c]) - float(rb[6 + c])) ** 2 for c in range(3)) ** 0.5
+        st["target_out_of_range"] = not (100.0 < dist < 3000.0)
         st["target_angle"] = float(rb[12])
     return st
 
