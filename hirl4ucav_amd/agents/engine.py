@@ -32,7 +32,8 @@ class HxSample(ctypes.Structure):
 
 class HxNets(ctypes.Structure):
     _fields_ = [(k, _vp) for k in ("actor", "critic", "target_actor", "target_critic", "bc_actor", "grad_actor", "grad_critic",
-                                   "m_actor", "v_actor", "m_critic", "v_critic", "losses", "soft_count", "wstate", "ws", "actor_w2_bf16", "actor_w2_f32i")]
+                                   "m_actor", "v_actor", "m_critic", "v_critic", "losses", "soft_count", "wstate", "ws", "actor_w2_bf16", "actor_w2_f32i",
+                                   "w2_bf16_all")]
 
 
 class HxHyper(ctypes.Structure):
@@ -45,6 +46,7 @@ _lib.register("hx_actor_act_step", [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _v
                                      ctypes.c_uint32, _f32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
 _lib.register("hx_pack_w2_bf16", [_vp, _i32, _vp, _vp])
 _lib.register("hx_pack_w2_f32i", [_vp, _i32, _vp, _vp])
+_lib.register("hx_pack_update_images", [_P(HxNets), _vp])
 _lib.register("hx_actor_act_f32i", [_vp, _vp, _vp, ctypes.c_int64, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _f32, _vp])
 _lib.register("hx_actor_act_step_f32i", [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32,
                                           ctypes.c_uint32, _f32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
@@ -236,8 +238,9 @@ class HirlEngine:
         self._pending = None  # a draw sample(defer=True) recorded for the next learn()
         self.nets = HxNets(*(t.data_ptr() for t in (self.actor, self.critic, self.target_actor, self.target_critic, self.bc_actor,
                                                      self.grad_actor, self.grad_critic, self.m_actor, self.v_actor, self.m_critic,
-                                                     self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None, None)
+                                                     self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None, None, None)
         self.act_dtype, self.w2_bf16 = "f32", None
+        self.update_dtype, self.images = "f32", None
         # fp32 image of the actor's W2 in the acting kernel's operand order (hx_pack_w2_f32i): kept current by the actor's Adam steps
         self.w2_f32i = torch.zeros(H2 * H1, dtype=torch.float32, device=self.device)
         self.nets.actor_w2_f32i = self.w2_f32i.data_ptr()
@@ -267,20 +270,51 @@ class HirlEngine:
 
     def set_act_dtype(self, dtype):
         """"f32": policy inference on fp32 MFMA (parity 1e-5).  "bf16": its 256 -> 512 layer on bf16 MFMA from a bf16 image of W2 that
-        every actor Adam step keeps current (BASELINE.json configs[4]); learn() is fp32 either way."""
+        every actor Adam step keeps current (BASELINE.json configs[4]); what learn() computes in is set_update_dtype's business."""
         if dtype not in ("f32", "bf16"):
             raise ValueError(dtype)
         self.act_dtype = dtype
-        if dtype == "bf16" and self.w2_bf16 is None:
-            self.w2_bf16 = torch.zeros(H2 * H1, dtype=torch.bfloat16, device=self.device)
-        self.nets.actor_w2_bf16 = self.w2_bf16.data_ptr() if dtype == "bf16" else None
+        self._bind_images()
         self.refresh_bf16()
 
-    def refresh_bf16(self):
-        """Rebuild the acting kernel's images of W2 from the fp32 actor (after load_params / a checkpoint restore or any direct write to
-        `self.actor`; the Adam steps maintain them otherwise): the fp32 image always, the bf16 image in bf16 mode."""
-        _lib.call("hx_pack_w2_f32i", self.actor.data_ptr(), 13, self.w2_f32i.data_ptr(), _lib.stream_ptr())
+    def set_update_dtype(self, dtype):
+        """"f32": learn() on fp32 MFMA (parity 1e-5 vs the reference).  "bf16": the three products of every network's 256 <-> 512 layer
+        (forward, input gradient, weight gradient) on bf16 MFMA with fp32 accumulation, fp32 master weights / Adam / LayerNorm / heads
+        (include/hirl4ucav.h "bf16 update path"; BASELINE.json configs[4] "bf16 actor/critic")."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(dtype)
+        self.update_dtype = dtype
+        self._bind_images()
+        self.refresh_bf16()
+
+    def _bind_images(self):
+        """which bf16 buffers the kernels see: in bf16 update mode ONE block holds every image (its first image is the acting kernel's);
+        with a bf16 policy only, the actor's image alone"""
+        if self.update_dtype == "bf16":
+            if self.images is None:
+                L = _lib.load()
+                L.hx_bf16_images_elems.restype = ctypes.c_int64
+                self.images = torch.zeros(int(L.hx_bf16_images_elems()), dtype=torch.bfloat16, device=self.device)
+            self.nets.w2_bf16_all = self.images.data_ptr()
+            self.w2_bf16 = self.images[:H2 * H1]
+            self.nets.actor_w2_bf16 = self.w2_bf16.data_ptr() if self.act_dtype == "bf16" else None
+            return
+        self.nets.w2_bf16_all = None
         if self.act_dtype == "bf16":
+            if self.w2_bf16 is None or (self.images is not None and self.w2_bf16.data_ptr() == self.images.data_ptr()):
+                self.w2_bf16 = torch.zeros(H2 * H1, dtype=torch.bfloat16, device=self.device)
+            self.nets.actor_w2_bf16 = self.w2_bf16.data_ptr()
+        else:
+            self.nets.actor_w2_bf16 = None
+
+    def refresh_bf16(self):
+        """Rebuild the kernels' images of W2 from the fp32 networks (after load_params / a checkpoint restore or any direct write to a
+        network; the optimizer and Polyak steps maintain them otherwise): the actor's fp32 image always, its bf16 image with a bf16
+        policy, every image of the update path in bf16 update mode."""
+        _lib.call("hx_pack_w2_f32i", self.actor.data_ptr(), 13, self.w2_f32i.data_ptr(), _lib.stream_ptr())
+        if self.update_dtype == "bf16":
+            _lib.call("hx_pack_update_images", ctypes.byref(self.nets), _lib.stream_ptr())
+        elif self.act_dtype == "bf16":
             _lib.call("hx_pack_w2_bf16", self.actor.data_ptr(), 13, self.w2_bf16.data_ptr(), _lib.stream_ptr())
 
     refresh_images = refresh_bf16

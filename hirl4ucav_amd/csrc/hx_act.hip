@@ -560,12 +560,29 @@ __global__ __launch_bounds__(kThreads) void pack_bf16_kernel(const float* __rest
     }
 }
 
+// the TRANSPOSED bf16 image (w2t_image_index): what bwd_l2's dh1 = dz2 W2 reads as its B operand
+__global__ __launch_bounds__(kThreads) void pack_bf16_t_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int n) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;  // row-major element (row n_ = i / 256, k = i % 256): coalesced reads
+    if (i < n) {
+        const __bf16 v = (__bf16)src[i];
+        dst[w2t_image_index((uint32_t)i % H1, (uint32_t)i / H1)] = __builtin_bit_cast(uint16_t, v);
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void pack_f32i_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
     const int i = (blockIdx.x * kThreads + threadIdx.x) * 4;  // four consecutive k of one column: adjacent in the image too
     if (i < n) *reinterpret_cast<float4*>(dst + w2f_image_index((uint32_t)i / H1, (uint32_t)i % H1)) = *reinterpret_cast<const float4*>(src + i);
 }
 
 }  // namespace
+
+namespace hxu {
+void launch_pack_bf16(const float* w2, uint16_t* image, bool transposed, hipStream_t st) {
+    const int n = H2 * H1;
+    if (transposed) hipLaunchKernelGGL(pack_bf16_t_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, w2, image, n);
+    else hipLaunchKernelGGL(pack_bf16_kernel, dim3((n / 2 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, w2, image, n);
+}
+}  // namespace hxu
 
 extern "C" {
 

@@ -15,7 +15,7 @@ namespace {
 struct FwdJobC {
     const float* net; const float* src; const float* noise; const float* prev_net;
     float* ws; float* prev_ws;
-    uint32_t cfg;  // m:10 | prev.m:10 | act_mode:2 | save:1 | col0:6
+    uint32_t cfg;  // m:10 | prev.m:10 | act_mode:2 | save:1 | col0:6 | img:3
     int32_t rows;
     float noise_clamp;
     float slope;   // (per launch; carried in every job so that the job's own 64 bytes are all a workgroup waits for)
@@ -27,12 +27,14 @@ struct FwdArgsC {
     int zero_nf;
     float* zero_f;
     int* zero_i;
+    const uint16_t* images;  // BF16 instantiations: base of the bf16 W2 images (one more scalar load beside the job's own, not behind it)
 };
 inline FwdJobC pack_fwd(const FwdJob& J) {
     FwdJobC c{};
     c.net = J.net; c.src = J.src.main; c.noise = J.noise; c.prev_net = J.prev.net;
     c.ws = J.ws.x; c.prev_ws = J.prev.ws.x;
-    c.cfg = mlp_bits(J.m) | (mlp_bits(J.prev.m) << 10) | ((uint32_t)J.act_mode << 20) | ((uint32_t)(J.save ? 1 : 0) << 22) | ((uint32_t)J.col0 << 23);
+    c.cfg = mlp_bits(J.m) | (mlp_bits(J.prev.m) << 10) | ((uint32_t)J.act_mode << 20) | ((uint32_t)(J.save ? 1 : 0) << 22) | ((uint32_t)J.col0 << 23) |
+            ((uint32_t)(J.img & 7) << 29);
     c.rows = J.rows; c.noise_clamp = J.noise_clamp;
     return c;
 }
@@ -40,7 +42,7 @@ __device__ __forceinline__ FwdJob expand_fwd(const FwdJobC& c) {
     FwdJob J;
     J.net = c.net; J.m = mlp_of(c.cfg & 1023u);
     J.src = RowSrc{c.src, nullptr, nullptr, 0, 32};
-    J.col0 = (int)(c.cfg >> 23); J.act_mode = (int)((c.cfg >> 20) & 3u);
+    J.col0 = (int)((c.cfg >> 23) & 63u); J.img = (int)(c.cfg >> 29); J.act_mode = (int)((c.cfg >> 20) & 3u);
     J.prev.net = c.prev_net; J.prev.m = mlp_of((c.cfg >> 10) & 1023u); J.prev.ws = carve_slot(c.prev_ws, c.rows);
     J.noise = c.noise; J.noise_clamp = c.noise_clamp;
     J.ws = carve_slot(c.ws, c.rows);
@@ -59,7 +61,11 @@ struct NoSample {};
 // SAMPLE (launch A of hx_hirl_*_sampled, batch <= 256): the minibatch is drawn here (draw_fused) and every workgroup gathers its 16 rows
 // straight from the replay / expert rings; the workgroups of job 0 also leave the row tiles, the indices and the smoothing noise for the
 // later launches.
-template <int NT, bool RELU, bool SAMPLE>
+// BF16 (the bf16 update path, BASELINE.json configs[4]): the 256 -> 512 product on v_mfma_f32_16x16x32_bf16 — h1 rounded to bf16 once into an
+//                LDS tile, the wave's B fragments straight from the net's bf16 image into registers (one contiguous kilobyte per load, no
+//                LDS staging of W2), fp32 accumulation; layer 1, LayerNorm, the previous net's head and everything saved for the backward
+//                pass stay fp32.
+template <int NT, bool RELU, bool SAMPLE, bool BF16 = false>
 __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std::conditional<SAMPLE, SampleDev, NoSample>::type SA) {
     constexpr bool WIDE = NT == 256;
     __shared__ uint32_t s_hkey[SAMPLE ? 2 : 1][SAMPLE ? kFusedSlots : 1];
@@ -71,8 +77,10 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
     // W2 tile of the workgroup's NT columns, [NT][LDA1] (latency modes): requested with COALESCED loads (a column's 16 or 32 threads cover 256
     // or 512 contiguous bytes) and turned into MFMA operand order through LDS.  Straight into registers in operand order, adjacent lanes
     // are adjacent columns, 1 KB apart in the row-major matrix: 64 separate 16-byte requests per load, 4,096 per workgroup.
-    constexpr int kW2S = WIDE ? 4 : NT * LDA1;
+    constexpr int kW2S = (WIDE || BF16) ? 4 : NT * LDA1;
     __shared__ __attribute__((aligned(16))) float lds[RT * LDA1 + RT * XP + RT * 2 + KRED + H1 * 17 + 8 + kW2S];
+    __shared__ __attribute__((aligned(16))) __bf16 h1b[BF16 ? RT * LDB1 : 8];  // BF16: the A operand of the MFMA phase
+    constexpr int NSL = 8 / KS;  // BF16: 32-wide k-slabs per wave (K = 256 in 8 slabs over the KS K-parts)
     float* h1s = lds;
     float* xs = lds + RT * LDA1;
     float* sts = xs + RT * XP;
@@ -95,6 +103,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
     constexpr int TPC = WIDE ? 16 : kWide / NT;       // threads per column: 16 (NT = 64) or 32 (NT = 32)
     constexpr int NW2 = WIDE ? 1 : H1 / (TPC * 4);    // loads per thread: 4 or 2
     v4f w2v[NW2];  // (native vectors: an array of HIP float4 stays an alloca)
+    uint4 bq[BF16 ? NSL : 1];  // BF16: this wave's B fragments (column tile ct, slabs kq NSL ..) from the image
     // layer 1 runs on MFMA: wave w owns hidden units 16 w .. 16 w + 15 of all 16 rows; lane (lr, lg) ends up with rows 4 lg .. 4 lg + 3 of unit u
     const int lr = lane & 15, lg = lane >> 4, u = wave * 16 + lr;
     STAMP_DECL;
@@ -134,7 +143,14 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
     }
     // the W2 fragment of the MFMA phase: 64 separate 16-byte requests per load (adjacent lanes are adjacent COLUMNS, 1 KB apart in the
     // row-major matrix) — behind the prologue's own operands, not in front of them
-    if (!WIDE) {
+    if constexpr (BF16) {
+        // column tile (of 16) and first slab of this wave; block (tile, slab) of the image is 512 elements, lane l's 16 bytes at + 8 l
+        const int ctile = WIDE ? nt * 16 + wave : nt * CT + wave % CT;
+        const int sl0 = WIDE ? 0 : (wave / CT) * NSL;
+        const uint16_t* blk = A.images + (size_t)J.img * kImgElems + (size_t)(ctile * 8 + sl0) * 512 + lane * 8;
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) bq[i] = *reinterpret_cast<const uint4*>(blk + i * 512);
+    } else if (!WIDE) {
         const float* wcol = J.net + J.m.W2() + (size_t)(nt * NT + tid / TPC) * H1 + (tid % TPC) * 4;
 #pragma unroll
         for (int i = 0; i < NW2; ++i) w2v[i] = *reinterpret_cast<const v4f*>(wcol + i * TPC * 4);
@@ -211,7 +227,8 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * lg + r;
             const float h = act_f<RELU>(g * ((z1[r] - sts[row * 2]) * sts[row * 2 + 1]) + be, slope);
-            h1s[row * LDA1 + u] = h;
+            if (BF16) h1b[row * LDB1 + u] = (__bf16)h;  // v_cvt_pk_bf16_f32: round to nearest even
+            else h1s[row * LDA1 + u] = h;
             if (save && row < nrow) {
                 J.ws.z1[(size_t)(r0 + row) * H1 + u] = z1[r];
                 J.ws.h1[(size_t)(r0 + row) * H1 + u] = h;
@@ -221,7 +238,7 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
             if (tid < nrow * XP) J.ws.x[(size_t)r0 * XP + tid] = xs[tid];
             if (tid < nrow * 2) J.ws.st1[(size_t)r0 * 2 + tid] = sts[tid];
         }
-        if (!WIDE) {
+        if (!WIDE && !BF16) {
 #pragma unroll
             for (int i = 0; i < NW2; ++i) *reinterpret_cast<v4f*>(w2s + (tid / TPC) * LDA1 + (tid % TPC) * 4 + i * TPC * 4) = w2v[i];
         }
@@ -233,7 +250,12 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
         const int n0 = nt * NTW + wave * 16;
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_a_lds_bt_global<H1>(h1s, LDA1, J.net + J.m.W2() + (size_t)(n0 + r) * H1, acc);
+        if constexpr (BF16) {
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) acc = mfma16_bf16(*reinterpret_cast<const uint4*>(h1b + r * LDB1 + 32 * i + 8 * g), bq[i], acc);
+        } else {
+            acc = tile_a_lds_bt_global<H1>(h1s, LDA1, J.net + J.m.W2() + (size_t)(n0 + r) * H1, acc);
+        }
         const float bias = J.net[J.m.b2() + n0 + r];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -246,7 +268,10 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
         const int n0 = nt * NT + ct * 16;
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        {   // A (h1) and B (W2 tile) fragments both from LDS: lane (r, g) reads 16 bytes at [row / column r][kq K/KS + 16 i + 4 g]
+        if constexpr (BF16) {  // lane (r, g): A[row r][32 sl + 8 g ..+7] from the bf16 tile, B from registers
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) acc = mfma16_bf16(*reinterpret_cast<const uint4*>(h1b + r * LDB1 + 32 * (kq * NSL + i) + 8 * g), bq[i], acc);
+        } else {   // A (h1) and B (W2 tile) fragments both from LDS: lane (r, g) reads 16 bytes at [row / column r][kq K/KS + 16 i + 4 g]
             const float* ap = h1s + r * LDA1 + kq * (H1 / KS) + 4 * g;
             const float* bp = w2s + (ct * 16 + r) * LDA1 + kq * (H1 / KS) + 4 * g;
 #pragma unroll
@@ -319,11 +344,12 @@ struct BwdJobC {
     int32_t rows;
     float gamma, lambda, slope, inv_batch;
     float* losses; int* soft_count;
-    uint32_t pad_;
+    uint32_t img_t;  // BF16 instantiations: index of this net's transposed W2 image
 };
 static_assert(sizeof(BwdJobC) == 128, "two s_load_dwordx16");
 struct BwdArgsC {
     BwdJobC job[2];
+    const uint16_t* images;  // BF16 instantiations: base of the bf16 W2 images
 };
 inline BwdJobC pack_bwd(const BwdJob& J, const BwdArgs& A) {
     BwdJobC c{};
@@ -335,7 +361,7 @@ inline BwdJobC pack_bwd(const BwdJob& J, const BwdArgs& A) {
     c.cfg = mlp_bits(J.m) | (mlp_bits(h1.m) << 10) | (mlp_bits(J.t2.m) << 20);
     c.cfg2 = (uint32_t)J.mode | ((uint32_t)J.loss_slot << 3);
     c.rows = J.rows; c.gamma = J.gamma; c.lambda = J.lambda; c.slope = A.slope; c.inv_batch = A.inv_batch;
-    c.losses = A.losses; c.soft_count = A.soft_count;
+    c.losses = A.losses; c.soft_count = A.soft_count; c.img_t = (uint32_t)J.img_t;
     return c;
 }
 __device__ __forceinline__ BwdJob expand_bwd(const BwdJobC& c) {
@@ -368,9 +394,13 @@ __device__ __forceinline__ float lnp_sum(const float* lp) {
 // Latency structure (what matters at B = 128, one workgroup per CU): EVERY global load of the workgroup — the W2 fragment
 // of the MFMA phase, the z2 rows, labels, the other nets' rows, all head parameters, the epilogue's z1 — is issued at
 // entry; there is ONE wait; head parameters are shared through LDS; the rest runs out of registers and LDS.
-template <int GRP, bool RELU>
+// BF16 (the bf16 update path): dh1 = dz2 W2 on v_mfma_f32_16x16x32_bf16 — every row's dz2 is rounded to bf16 once into the LDS tile (the copy
+// published for wgrad stays fp32), the wave's B fragments come straight from the net's TRANSPOSED bf16 image (two 16-byte loads per lane
+// instead of sixteen strided dword loads); heads, losses, LayerNorm backward and the epilogue stay fp32.
+template <int GRP, bool RELU, bool BF16 = false>
 __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
-    __shared__ __attribute__((aligned(16))) float dz2s[RT * LDA2];
+    __shared__ __attribute__((aligned(16))) float dz2s[BF16 ? kCTB * RT * 2 : RT * LDA2];  // (BF16: only the epilogue's row-sum scratch)
+    __shared__ __attribute__((aligned(16))) __bf16 dz2b[BF16 ? RT * LDB2 : 8];
     __shared__ __attribute__((aligned(16))) float kred[(kKSB - 1) * kCTB * 256];  // split-K partial tiles
     constexpr int IMG = GRP == 3 ? 8 : 4;  // head width of this instantiation's LDS images
     // head width known at compile time: the critic jobs (GRP 0, 1) have ONE output, the actor jobs (GRP 2) four; GRP 3 (SAC: policy 8 wide,
@@ -414,7 +444,9 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     STAMP();
 
     // ---------------- issue phase ----------------
-    BFrag<H2 / kKSB> bfrag;
+    BFrag<BF16 ? 16 : H2 / kKSB> bfrag;   // (BF16: unused)
+    constexpr int NSLB = (H2 / kKSB) / 32;  // BF16: 32-wide slabs of n per wave (K = 512 over the kKSB K-parts)
+    uint4 bqb[BF16 ? NSLB : 1];
     // Row loads are UNCONDITIONAL (R is clamped to a valid row; a wave without a row never uses them): behind `if (live)` the compiler
     // zero-fills the registers, loads under a branch and — where the two versions merge — WAITS for the loads in the middle of the issue phase.
     RowReg<H2> z, za, zb;
@@ -487,7 +519,13 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     }
     const float st1v = tid < nrow * 2 ? J.ws.st1[(size_t)r0 * 2 + tid] : (tid & 1 ? 1.0f : 0.0f);
     // the W2 fragment of the MFMA phase (16 loads per lane, needed last) goes out behind the prologue's operands, not in front of them
-    bfrag.load(J.net + J.m.W2() + (size_t)(kq * (H2 / kKSB)) * H1 + n0 + (lane & 15), H1);
+    if constexpr (BF16) {  // block (tile of 16 columns of dh1, slab of 32 n) of the transposed image: 512 elements, lane l's 16 bytes at + 8 l
+        const uint16_t* blk = AC.images + (size_t)jc.img_t * kImgElems + (size_t)((nt * kCTB + ct) * 16 + kq * NSLB) * 512 + lane * 8;
+#pragma unroll
+        for (int i = 0; i < NSLB; ++i) bqb[i] = *reinterpret_cast<const uint4*>(blk + i * 512);
+    } else {
+        bfrag.load(J.net + J.m.W2() + (size_t)(kq * (H2 / kKSB)) * H1 + n0 + (lane & 15), H1);
+    }
     // ---------------- one wait: publish the shared operands in LDS ----------------
     if (tid < RT * 2) st1s[tid] = st1v;
     pv0.store(hps, J.net, J.m, tid);
@@ -505,7 +543,16 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     // ---------------- prologue: head, loss gradient, LN2 backward (registers + LDS only) ----------------
     float part[4] = {0.f, 0.f, 0.f, 0.f};  // loss partials of this row
     int cnt = 0;
-    float* drow = dz2s + wave * LDA2;
+    float* drow = dz2s + (BF16 ? 0 : wave * LDA2);  // fp32 only (BF16 rows go to dz2b through store_row_bf16)
+    // BF16: lane's elements n = (i * 64 + lane) * 4 + c of the row -> four bf16 (8 bytes) at [wave][n]
+    auto store_row_bf16 = [&](const RowReg<H2>& v) {
+        typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const v4bf q = {(__bf16)v.v[4 * i], (__bf16)v.v[4 * i + 1], (__bf16)v.v[4 * i + 2], (__bf16)v.v[4 * i + 3]};
+            *reinterpret_cast<uint2*>(dz2b + wave * LDB2 + (i * 64 + lane) * 4) = __builtin_bit_cast(uint2, q);
+        }
+    };
     RowReg<H2> xh, y;
     float mean = 0.f, rstd = 0.f, o[OUTW] = {};
     if constexpr (PAIRED) {  // the pair's two halves side by side, then one barrier
@@ -549,7 +596,8 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
         RowReg<H2> zero;
 #pragma unroll
         for (int i = 0; i < 8; ++i) zero.v[i] = 0.0f;
-        zero.store_lds(drow);
+        if constexpr (BF16) store_row_bf16(zero);
+        else zero.store_lds(drow);
     } else {
         if constexpr (!PAIRED) head_regs<OUTW, IMG, RELU>(z, hps, NOUT ? NOUT : J.m.out, slope, xh, y, mean, rstd, o, J.m.no_ln);
         float dout[OUTW] = {};
@@ -618,7 +666,8 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
         if (J.m.no_ln) s1 = s2 = 0.0f;  // identity "norm": dz2 = dy2
 #pragma unroll
         for (int i = 0; i < 8; ++i) dx.v[i] = rstd * (dx.v[i] - s1 - xh.v[i] * s2);
-        dx.store_lds(drow);
+        if constexpr (BF16) store_row_bf16(dx);
+        else dx.store_lds(drow);
         if (lead) {
             dx.store(J.ws.dz2 + R * H2);
             if (lane == 0) {
@@ -651,7 +700,12 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     {
         const int r = lane & 15, g = lane >> 4;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_a_lds_b_frag<H2 / kKSB>(dz2s + kq * (H2 / kKSB), LDA2, bfrag, acc);
+        if constexpr (BF16) {
+#pragma unroll
+            for (int i = 0; i < NSLB; ++i) acc = mfma16_bf16(*reinterpret_cast<const uint4*>(dz2b + r * LDB2 + 32 * (kq * NSLB + i) + 8 * g), bqb[i], acc);
+        } else {
+            acc = tile_a_lds_b_frag<BF16 ? 16 : H2 / kKSB>(dz2s + kq * (H2 / kKSB), LDA2, bfrag, acc);
+        }
         if (kq) *reinterpret_cast<float4*>(kred + (((kq - 1) * kCTB + ct) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         __syncthreads();  // partial tiles visible; dz2s is dead from here on
         STAMP();
@@ -718,8 +772,18 @@ template <int GRP>
 void launch_bwd_t(const BwdArgs& G, hipStream_t st) {
     BwdArgsC C{};
     for (int j = 0; j < G.njobs; ++j) C.job[j] = pack_bwd(G.job[j], G);
-    if (G.slope == 0.0f) hipLaunchKernelGGL((bwd_l2_kernel<GRP, true>), dim3(bwd_blocks(G, GRP <= 2 ? RT / 2 : RT), G.njobs), dim3(kWide), 0, st, C);
-    else hipLaunchKernelGGL((bwd_l2_kernel<GRP, false>), dim3(bwd_blocks(G, GRP <= 2 ? RT / 2 : RT), G.njobs), dim3(kWide), 0, st, C);
+    C.images = G.images;
+    const dim3 grid(bwd_blocks(G, GRP <= 2 ? RT / 2 : RT), G.njobs);
+    if constexpr (GRP <= 2) {  // the bf16 update path covers the HIRL / TD3 / BC jobs (GRP 3 = SAC's given head gradients: fp32)
+        static const int dbg_off = getenv("HX_DBG_BF16_OFF") ? atoi(getenv("HX_DBG_BF16_OFF")) : 0;
+        if (G.images && !(dbg_off & 2)) {
+            if (G.slope == 0.0f) hipLaunchKernelGGL((bwd_l2_kernel<GRP, true, true>), grid, dim3(kWide), 0, st, C);
+            else hipLaunchKernelGGL((bwd_l2_kernel<GRP, false, true>), grid, dim3(kWide), 0, st, C);
+            return;
+        }
+    }
+    if (G.slope == 0.0f) hipLaunchKernelGGL((bwd_l2_kernel<GRP, true>), grid, dim3(kWide), 0, st, C);
+    else hipLaunchKernelGGL((bwd_l2_kernel<GRP, false>), grid, dim3(kWide), 0, st, C);
 }
 
 }  // namespace
@@ -733,21 +797,30 @@ void launch_fwd(const FwdArgs& F, hipStream_t st) {
         C.job[j] = pack_fwd(F.job[j]);
         C.job[j].slope = F.slope;
     }
-    C.slope = F.slope; C.zero_nf = F.zero_nf; C.zero_f = F.zero_f; C.zero_i = F.zero_i;
+    C.slope = F.slope; C.zero_nf = F.zero_nf; C.zero_f = F.zero_f; C.zero_i = F.zero_i; C.images = F.images;
     const int tiles = fwd_row_tiles(F), per_job = tiles / F.njobs;
     const bool relu = F.slope == 0.0f;  // compile-time ReLU instantiations (hx_nn.h act_f)
+    static const int dbg_off = getenv("HX_DBG_BF16_OFF") ? atoi(getenv("HX_DBG_BF16_OFF")) : 0;
+    const bool bf16 = F.images != nullptr && !(dbg_off & 1);
+#define HX_FWD_T(NT_, RELU_, BF16_) hipLaunchKernelGGL((fwd_l2_kernel<NT_, RELU_, false, BF16_>), grid, dim3(kWide), 0, st, C, NoSample{})
 #define HX_FWD(NT_) do { const dim3 grid(per_job * (H2 / NT_), F.njobs); \
-        if (relu) hipLaunchKernelGGL((fwd_l2_kernel<NT_, true, false>), grid, dim3(kWide), 0, st, C, NoSample{}); \
-        else hipLaunchKernelGGL((fwd_l2_kernel<NT_, false, false>), grid, dim3(kWide), 0, st, C, NoSample{}); } while (0)
+        if (bf16) { if (relu) HX_FWD_T(NT_, true, true); else HX_FWD_T(NT_, false, true); } \
+        else { if (relu) HX_FWD_T(NT_, true, false); else HX_FWD_T(NT_, false, false); } } while (0)
     if (F.sample) {  // (the callers checked: three or four jobs of at most 256 rows -> the 64-column tiling)
         const dim3 grid(per_job * (H2 / kNT), F.njobs);
-        if (relu) hipLaunchKernelGGL((fwd_l2_kernel<kNT, true, true>), grid, dim3(kWide), 0, st, C, *F.sample);
-        else hipLaunchKernelGGL((fwd_l2_kernel<kNT, false, true>), grid, dim3(kWide), 0, st, C, *F.sample);
+        if (bf16) {
+            if (relu) hipLaunchKernelGGL((fwd_l2_kernel<kNT, true, true, true>), grid, dim3(kWide), 0, st, C, *F.sample);
+            else hipLaunchKernelGGL((fwd_l2_kernel<kNT, false, true, true>), grid, dim3(kWide), 0, st, C, *F.sample);
+        } else {
+            if (relu) hipLaunchKernelGGL((fwd_l2_kernel<kNT, true, true>), grid, dim3(kWide), 0, st, C, *F.sample);
+            else hipLaunchKernelGGL((fwd_l2_kernel<kNT, false, true>), grid, dim3(kWide), 0, st, C, *F.sample);
+        }
         return;
     }
     if (tiles >= 128) HX_FWD(256);
     else if (tiles * (H2 / 32) <= 256) HX_FWD(32);  // one or two nets at B = 128: 32-column workgroups still fit the chip in one round
     else HX_FWD(kNT);
+#undef HX_FWD_T
 #undef HX_FWD
 }
 

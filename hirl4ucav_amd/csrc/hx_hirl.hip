@@ -20,6 +20,26 @@ int hx_actor_param_count(void) { return kActor.size(); }
 int hx_critic_param_count(void) { return 2 * kQ.padded(); }
 int64_t hx_hirl_workspace_floats(int32_t batch) { return (int64_t)S_COUNT * kSlotFloats * batch + 64; }
 int64_t hx_actor_message_floats(void) { return 2 * (int64_t)kActor.padded() + 64; }
+int64_t hx_bf16_images_elems(void) { return (int64_t)IM_COUNT * (int64_t)kImgElems; }
+
+/* Rebuild every bf16 image of the update path from the fp32 networks (after parameters were loaded or written directly). */
+int hx_pack_update_images(const HxNets* N, void* stream) {
+    HX_REQUIRE(N && N->w2_bf16_all && (reinterpret_cast<uintptr_t>(N->w2_bf16_all) & 15u) == 0, "hx_pack_update_images: w2_bf16_all must be a 16-byte aligned buffer");
+    HX_REQUIRE(N->actor && N->critic && N->target_actor && N->target_critic, "hx_pack_update_images: null network");
+    hipStream_t st = (hipStream_t)stream;
+    uint16_t* im = N->w2_bf16_all;
+    launch_pack_bf16(N->actor + kActor.W2(), im + IM_ACTOR * kImgElems, false, st);
+    launch_pack_bf16(N->actor + kActor.W2(), im + IM_ACTOR_T * kImgElems, true, st);
+    launch_pack_bf16(N->target_actor + kActor.W2(), im + IM_TA * kImgElems, false, st);
+    if (N->bc_actor) launch_pack_bf16(N->bc_actor + kActor.W2(), im + IM_BC * kImgElems, false, st);
+    for (int h = 0; h < 2; ++h) {
+        launch_pack_bf16(N->critic + h * kQ.padded() + kQ.W2(), im + (IM_C1 + h) * kImgElems, false, st);
+        launch_pack_bf16(N->critic + h * kQ.padded() + kQ.W2(), im + (IM_C1_T + h) * kImgElems, true, st);
+        launch_pack_bf16(N->target_critic + h * kQ.padded() + kQ.W2(), im + (IM_TC1 + h) * kImgElems, false, st);
+    }
+    HX_CHECK_LAUNCH("hx_pack_update_images");
+    return 0;
+}
 
 static void make_slots(const HxNets* N, int B, Slot* s) {
     for (int i = 0; i < S_COUNT; ++i) s[i] = carve_slot(N->ws + (size_t)i * kSlotFloats * B, B);
@@ -66,30 +86,32 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
         FwdArgs F{};
         F.njobs = 3; F.slope = Hy->slope;
         F.zero_f = N->losses; F.zero_nf = 1;  // critic_loss accumulator
-        F.job[0] = FwdJob{N->target_actor, kActor, src, 17, 0, Head{}, nullptr, 0.f, s[S_TA], B, 0};
-        F.job[1] = FwdJob{N->critic, kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C1], B, 1};
-        F.job[2] = FwdJob{N->critic + kQ.padded(), kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C2], B, 1};
+        F.job[0] = FwdJob{N->target_actor, kActor, src, 17, 0, Head{}, nullptr, 0.f, s[S_TA], B, 0, IM_TA};
+        F.job[1] = FwdJob{N->critic, kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C1], B, 1, IM_C1};
+        F.job[2] = FwdJob{N->critic + kQ.padded(), kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C2], B, 1, IM_C2};
         if (actor_fwd) {  // the delayed actor step's forwards ride along, split so that NEITHER launch exceeds 256 workgroups
             F.zero_nf = 5; F.zero_i = N->soft_count;  // + actor / bc / rl / bc_fire accumulators and the soft count
-            F.job[3] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1};
+            F.job[3] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1, IM_ACTOR};
             F.njobs = 4;
         }
         F.sample = fused ? &SD : nullptr;
+        F.images = N->w2_bf16_all;
         launch_fwd(F, st);
     }
     {   // launch B: targetCritic Q1/Q2 (s', clamp(targetActor(s') + clamp(noise)))  [+ actor(s_bc), bc_actor(s)]
         FwdArgs F{};
         F.njobs = 2; F.slope = Hy->slope;
         const Head prev{N->target_actor, kActor, s[S_TA]};
-        F.job[0] = FwdJob{tc1, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC1], B, 0};
-        F.job[1] = FwdJob{tc2, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC2], B, 0};
+        F.job[0] = FwdJob{tc1, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC1], B, 0, IM_TC1};
+        F.job[1] = FwdJob{tc2, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC2], B, 0, IM_TC2};
         if (actor_fwd && Hy->use_bc) {
             const RowSrc bcsrc{Bt->bc_rows ? Bt->bc_rows : Bt->rows, nullptr, nullptr, 0, 32};
             int n = 2;
-            F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1};
-            if (actor_fwd == 2) F.job[n++] = FwdJob{N->bc_actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0};
+            F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1, IM_ACTOR};
+            if (actor_fwd == 2) F.job[n++] = FwdJob{N->bc_actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0, IM_BC};
             F.njobs = n;
         }
+        F.images = N->w2_bf16_all;
         launch_fwd(F, st);
     }
     {   // launch C: y, loss, dq, LN2 backward, dh1 for both heads
@@ -100,7 +122,9 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
             J = BwdJob{};
             J.net = N->critic + h * kQ.padded(); J.m = kQ; J.ws = s[S_C1 + h]; J.rows = B; J.mode = BM_CRITIC_TD;
             J.t1 = Head{tc1, kQ, s[S_TC1]}; J.t2 = Head{tc2, kQ, s[S_TC2]}; J.src = src; J.gamma = Hy->gamma;
+            J.img_t = IM_C1_T + h;
         }
+        G.images = N->w2_bf16_all;
         launch_bwd(0, G, st);
     }
     {   // launch D: all critic parameter gradients
@@ -116,8 +140,12 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
                 J.p = N->critic + h * kQ.padded();
                 J.mom = N->m_critic + h * kQ.padded(); J.var = N->v_critic + h * kQ.padded();
                 J.target = polyak ? N->target_critic + h * kQ.padded() : nullptr;
+                if (uint16_t* im = N->w2_bf16_all) {
+                    J.w2b = im + (IM_C1 + h) * kImgElems; J.w2tb = im + (IM_C1_T + h) * kImgElems; J.tgt_w2b = im + (IM_TC1 + h) * kImgElems;
+                }
             }
         }
+        W.bf16 = N->w2_bf16_all != nullptr;
         if (adam_step > 0) {
             W.ad = make_adam(N, Hy, Hy->lr_critic, adam_step, false);
             launch_wg(W, true, st);
@@ -152,19 +180,21 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
         F.slope = Hy->slope;
         F.zero_f = N->losses + 1; F.zero_nf = 4; F.zero_i = N->soft_count;  // actor / bc / rl / bc_fire accumulators + soft count
         int n = 0;
-        F.job[n++] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1};
-        if (bc) F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1};
-        if (soft) F.job[n++] = FwdJob{N->bc_actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0};
+        F.job[n++] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1, IM_ACTOR};
+        if (bc) F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1, IM_ACTOR};
+        if (soft) F.job[n++] = FwdJob{N->bc_actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0, IM_BC};
         F.njobs = n;
+        F.images = N->w2_bf16_all;
         launch_fwd(F, st);
     }
     {   // launch G: Q1(s, pi(s)) and Q1(s, bc_actor(s)) with the updated critic
         FwdArgs F{};
         F.slope = Hy->slope;
         int n = 0;
-        F.job[n++] = FwdJob{N->critic, kQ, src, 0, 1, Head{N->actor, kActor, s[S_API]}, nullptr, 0.f, s[S_CPI], B, 1};
-        if (soft) F.job[n++] = FwdJob{N->critic, kQ, src, 0, 1, Head{N->bc_actor, kActor, s[S_BCS]}, nullptr, 0.f, s[S_CSOFT], B, 0};
+        F.job[n++] = FwdJob{N->critic, kQ, src, 0, 1, Head{N->actor, kActor, s[S_API]}, nullptr, 0.f, s[S_CPI], B, 1, IM_C1};
+        if (soft) F.job[n++] = FwdJob{N->critic, kQ, src, 0, 1, Head{N->bc_actor, kActor, s[S_BCS]}, nullptr, 0.f, s[S_CSOFT], B, 0, IM_C1};
         F.njobs = n;
+        F.images = N->w2_bf16_all;
         launch_fwd(F, st);
     }
     {   // launch H: rl_loss, soft count, critic backward down to dh1 (gradient wrt the action comes next)
@@ -174,6 +204,8 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
         J = BwdJob{};
         J.net = N->critic; J.m = kQ; J.ws = s[S_CPI]; J.rows = B; J.mode = BM_CRITIC_PI;
         if (soft) J.soft = Head{N->critic, kQ, s[S_CSOFT]};
+        J.img_t = IM_C1_T;
+        G.images = N->w2_bf16_all;
         launch_bwd(1, G, st);
     }
     {   // launch I: actor backward for the RL batch (through tanh and the critic's input gradient) and the BC batch
@@ -185,14 +217,17 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
             J = BwdJob{};
             J.net = N->actor; J.m = kActor; J.ws = s[S_API]; J.rows = B; J.mode = BM_ACTOR_PI;
             J.crit = Head{N->critic, kQ, s[S_CPI]};
+            J.img_t = IM_ACTOR_T;
         }
         if (bc) {
             BwdJob& J = G.job[n++];
             J = BwdJob{};
             J.net = N->actor; J.m = kActor; J.ws = s[S_ABC]; J.rows = B; J.mode = BM_ACTOR_BC;
             J.src = bcsrc; J.lambda = Hy->loss_lambda;
+            J.img_t = IM_ACTOR_T;
         }
         G.njobs = n;
+        G.images = N->w2_bf16_all;
         launch_bwd(2, G, st);
     }
     HX_CHECK_LAUNCH("hx_hirl_actor_backward");
@@ -217,11 +252,16 @@ static int actor_wgrad_impl(const HxNets* N, const HxHyper* Hy, int32_t batch, i
     J.ws[0] = s[S_API]; J.rows[0] = batch; J.wmode[0] = 1;
     J.nslots = 1;
     if (bc) { J.ws[1] = s[S_ABC]; J.rows[1] = batch; J.wmode[1] = 2; J.nslots = 2; }
+    W.bf16 = N->w2_bf16_all != nullptr;
     if (adam_step > 0) {  // actor.optimizer.step() (+ soft_update of targetActor, + the bf16 image) in the same launch
         J.p = N->actor; J.mom = N->m_actor; J.var = N->v_actor;
         J.target = polyak ? N->target_actor : nullptr;
         J.w2b = N->actor_w2_bf16;
         J.w2f = N->actor_w2_f32i;
+        if (uint16_t* im = N->w2_bf16_all) {
+            HX_REQUIRE(!N->actor_w2_bf16 || N->actor_w2_bf16 == im + IM_ACTOR * kImgElems, "hx_hirl_learn: with w2_bf16_all set, actor_w2_bf16 must be NULL or its first image");
+            J.w2b = im + IM_ACTOR * kImgElems; J.w2tb = im + IM_ACTOR_T * kImgElems; J.tgt_w2b = im + IM_TA * kImgElems;
+        }
         W.ad = make_adam(N, Hy, Hy->lr_actor, adam_step, true);
         launch_wg(W, true, (hipStream_t)stream);
     } else {
@@ -252,6 +292,7 @@ int hx_hirl_actor_wgrad_split(const HxNets* N, const HxHyper* Hy, int32_t batch,
         J.net = N->actor; J.grad = msg + j * kActor.padded(); J.m = kActor;
         J.ws[0] = s[j == 0 ? S_API : S_ABC]; J.rows[0] = batch; J.wmode[0] = 0; J.nslots = 1;
     }
+    W.bf16 = N->w2_bf16_all != nullptr;
     launch_wg(W, false, (hipStream_t)stream);
     hipLaunchKernelGGL(count_to_float_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, bc ? N->soft_count : nullptr, msg + 2 * kActor.padded());
     HX_CHECK_LAUNCH("hx_hirl_actor_wgrad_split");
@@ -291,7 +332,8 @@ int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int
         FwdArgs F{};
         F.njobs = 1; F.slope = Hy->slope;
         F.zero_f = N->losses + 1; F.zero_nf = 4;
-        F.job[0] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1};
+        F.job[0] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1, IM_ACTOR};
+        F.images = N->w2_bf16_all;
         launch_fwd(F, st);
     }
     {
@@ -300,6 +342,8 @@ int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int
         BwdJob& J = G.job[0];
         J = BwdJob{};
         J.net = N->actor; J.m = kActor; J.ws = s[S_ABC]; J.rows = B; J.mode = BM_ACTOR_BC; J.src = bcsrc; J.lambda = 1.0f;
+        J.img_t = IM_ACTOR_T;
+        G.images = N->w2_bf16_all;
         launch_bwd(2, G, st);
     }
     {
@@ -309,6 +353,7 @@ int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int
         WgJob& J = W.job[0];
         J = WgJob{};
         J.net = N->actor; J.grad = N->grad_actor; J.m = kActor; J.ws[0] = s[S_ABC]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
+        W.bf16 = N->w2_bf16_all != nullptr;
         launch_wg(W, false, st);
     }
     HX_CHECK_LAUNCH("hx_bc_train_actor");

@@ -341,6 +341,7 @@ struct FwdJob {
     Slot ws;
     int rows;
     int save;  // write x, z1, st1, h1 (needed by the backward pass)
+    int img;   // bf16 update path: which image of FwdArgs::images holds this net's W2 (IM_*; forward images are 0..7)
 };
 struct FwdArgs {
     FwdJob job[6];
@@ -351,6 +352,7 @@ struct FwdArgs {
     int zero_nf;
     int* zero_i;
     const SampleDev* sample;  // launch A of the *_sampled entry points: draw and gather inside this launch
+    const uint16_t* images;   // nullptr: the 256 -> 512 product on fp32 MFMA; else the bf16 W2 images (HxNets.w2_bf16_all): bf16 MFMA
 };
 
 // LDS image of one net's head parameters: g2[512] be2[512] W3[out][512] (padded to OUTMAX rows) b3[out]
@@ -428,7 +430,31 @@ __host__ __device__ inline uint32_t w2f_image_index(uint32_t col, uint32_t k) {
 __host__ __device__ inline uint32_t w2_image_index(uint32_t col, uint32_t k) {
     return ((((col >> 4) * 8u + (k >> 5)) * 4u + ((k >> 3) & 3u)) * 16u + (col & 15u)) * 8u + (k & 7u);
 }
+// the TRANSPOSED bf16 image, for dh1 = dz2 W2 (B[k = n][col = k1] = W2[n][k1]): one 1 KB block per (tile of 16 columns k1, slab of 32 n),
+// lane (r = k1 in the tile, g): n = 32 slab + 8 g .. + 7
+__host__ __device__ inline uint32_t w2t_image_index(uint32_t k1, uint32_t n) {
+    return ((((k1 >> 4) * 16u + (n >> 5)) * 4u + ((n >> 3) & 3u)) * 16u + (k1 & 15u)) * 8u + (n & 7u);
+}
 constexpr int LDB1 = H1 + 16;  // bf16 h1 tile pitch (elements) = 136 dwords = 8 mod 64: the ds_read_b128 A-operand read is conflict-free
+constexpr int LDB2 = H2 + 16;  // bf16 dz2 tile pitch = 264 dwords = 8 mod 64
+// bf16 update path (BASELINE.json configs[4] "bf16 actor/critic"): HxNets.w2_bf16_all holds one image per use of a W2 —
+// forward images (w2_image_index) first, so that a FwdJobC's 3-bit field can name them, then the transposed ones (w2t_image_index)
+enum { IM_ACTOR = 0, IM_C1, IM_C2, IM_TA, IM_TC1, IM_TC2, IM_BC, IM_ACTOR_T, IM_C1_T, IM_C2_T, IM_COUNT };
+constexpr size_t kImgElems = (size_t)H2 * H1;
+__device__ __forceinline__ v8bf as_v8bf(const uint4& q) { return __builtin_bit_cast(v8bf, q); }
+__device__ __forceinline__ v4f mfma16_bf16(const uint4& a, const uint4& b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_v8bf(a), as_v8bf(b), c, 0, 0, 0);
+}
+// eight floats -> eight bf16 (round to nearest even, v_cvt_pk_bf16_f32), packed in MFMA fragment order
+__device__ __forceinline__ uint4 pack8_bf16(const float (&v)[8]) {
+    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+    uint4 q;
+    q.x = __builtin_bit_cast(unsigned, v2bf{(__bf16)v[0], (__bf16)v[1]});
+    q.y = __builtin_bit_cast(unsigned, v2bf{(__bf16)v[2], (__bf16)v[3]});
+    q.z = __builtin_bit_cast(unsigned, v2bf{(__bf16)v[4], (__bf16)v[5]});
+    q.w = __builtin_bit_cast(unsigned, v2bf{(__bf16)v[6], (__bf16)v[7]});
+    return q;
+}
 
 enum { BM_CRITIC_TD = 0, BM_CRITIC_PI = 1, BM_ACTOR_PI = 2, BM_ACTOR_BC = 3, BM_GIVEN = 4 };
 
@@ -451,6 +477,7 @@ struct BwdJob {
     const float* bonus;
     const float* bonus_scale;
     int loss_slot;
+    int img_t;  // bf16 update path: which image of BwdArgs::images holds this net's TRANSPOSED W2 (IM_*_T)
 };
 struct BwdArgs {
     BwdJob job[2];
@@ -459,6 +486,7 @@ struct BwdArgs {
     float inv_batch;  // 1 / B
     float* losses;    // [8]: critic, actor, bc, rl, bc_fire, bc_weight, -, -
     int* soft_count;
+    const uint16_t* images;  // nullptr: dh1 = dz2 W2 on fp32 MFMA; else the bf16 images: dz2 rounded to bf16, W2^T from its image
 };
 
 struct WgJob {
@@ -474,6 +502,8 @@ struct WgJob {
     float* target;                 // nullptr, or the target network's block: soft_update with the new parameters (HIRL.py:11-13)
     uint16_t* w2b;                 // nullptr, or the bf16 image of W2 to refresh
     float* w2f;                    // nullptr, or the fp32 image of W2 to refresh
+    uint16_t* w2tb;                // nullptr, or the transposed bf16 image of W2 to refresh (bf16 update path)
+    uint16_t* tgt_w2b;             // nullptr, or the bf16 image of the TARGET's W2: follows the Polyak step
 };
 struct WgAdam {
     float b1, b2, eps, step_size, bc2_sqrt, tau;
@@ -491,6 +521,7 @@ struct WgArgs {
     float w_given, warm, inv_batch;
     const int* soft_count;
     const float* wstate;
+    int bf16;  // dW2 = dz2^T h1 with both operands rounded to bf16 (fp32 accumulate): the bf16 update path
 };
 
 // torch.optim.Adam (defaults) on one element, and soft_update.  Contraction is OFF in these two: HIP's __fmul_rn / __fsub_rn are plain
@@ -532,6 +563,13 @@ struct AdamArgs {
     uint16_t* w2b;
     float* w2f;  // fp32 image of W2 to refresh (same range)
     int w2_lo;
+    // bf16 update path: up to two W2 ranges of p (the critic's two heads) with their forward / transposed images and the images of the
+    // target's W2 (written when `target` is stepped here); nseg = 0: none
+    int nseg;
+    int seg_lo[2];
+    uint16_t* seg_w2b[2];
+    uint16_t* seg_w2tb[2];
+    uint16_t* seg_tgt_w2b[2];
     // merged actor message of a sharded run: g holds the summed dL_rl, g2 the summed dL_bc, *countf the summed
     // soft count; the step uses g = w g2 + (1 - w) g with w from the GLOBAL count.  nullptr: g is the finished gradient.
     const float* g2;
@@ -576,5 +614,7 @@ void launch_bwd(int grp, const BwdArgs& G, hipStream_t st);                 // h
 void launch_wg(const WgArgs& W, bool adam, hipStream_t st);                 // hx_wgrad.hip: adam = the optimizer step rides in the launch
 void launch_adam(const AdamArgs& A, hipStream_t st);                        // hx_wgrad.hip
 void launch_polyak(float* target, const float* source, int n, float tau, float* target2, const float* source2, int n2, hipStream_t st);
+// bf16 image of the W2 [512][256] at `w2`: forward order (w2_image_index) or transposed (w2t_image_index)             hx_act.hip
+void launch_pack_bf16(const float* w2, uint16_t* image, bool transposed, hipStream_t st);
 
 }  // namespace hxu

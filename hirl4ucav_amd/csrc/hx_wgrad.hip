@@ -23,8 +23,9 @@ struct WgJobC {
     float b1, b2, eps, step_size, bc2_sqrt, tau;
     uint32_t pad_;
     const int* soft_count; float* wstate; float* losses;
+    uint16_t* w2tb; uint16_t* tgt_w2b;  // bf16 update path: the transposed image of W2 and the image of the target's W2
 };
-static_assert(sizeof(WgJobC) == 152, "WgJobC layout");
+static_assert(sizeof(WgJobC) == 168, "WgJobC layout");
 struct WgArgsC {
     WgJobC job[2];
 };
@@ -44,7 +45,10 @@ struct AdamElem {
         J.p[idx] = p;
         J.mom[idx] = m;
         J.var[idx] = v;
-        if (J.target) J.target[idx] = polyak_update(t, p, a.tau);
+        if (J.target) {
+            t = polyak_update(t, p, a.tau);
+            J.target[idx] = t;
+        }
     }
 };
 
@@ -88,6 +92,7 @@ __device__ __forceinline__ void expand_wg(const WgJobC& c, WgJob& J, WgArgs& A) 
     J.ws[0] = carve_slot(c.ws0, c.rows0); J.ws[1] = carve_slot(c.ws1, c.rows1);
     J.rows[0] = c.rows0; J.rows[1] = c.rows1;
     J.p = const_cast<float*>(c.net); J.mom = c.mom; J.var = c.var; J.target = c.target; J.w2b = c.w2b; J.w2f = c.w2f;
+    J.w2tb = c.w2tb; J.tgt_w2b = c.tgt_w2b;
     A.slope = c.slope; A.w_kind = (int)((c.cfg >> 16) & 3u); A.w_given = c.w_given; A.warm = c.warm; A.inv_batch = c.inv_batch;
     A.soft_count = c.soft_count; A.wstate = c.wstate;
     A.ad.b1 = c.b1; A.ad.b2 = c.b2; A.ad.eps = c.eps; A.ad.step_size = c.step_size; A.ad.bc2_sqrt = c.bc2_sqrt; A.ad.tau = c.tau;
@@ -97,7 +102,7 @@ __device__ __forceinline__ void expand_wg(const WgJobC& c, WgJob& J, WgArgs& A) 
 inline WgJobC pack_wg(const WgJob& J, const WgArgs& A) {
     WgJobC c{};
     c.net = J.net; c.grad = J.grad; c.ws0 = J.ws[0].x; c.ws1 = J.nslots > 1 ? J.ws[1].x : J.ws[0].x;
-    c.mom = J.mom; c.var = J.var; c.target = J.target; c.w2b = J.w2b; c.w2f = J.w2f;
+    c.mom = J.mom; c.var = J.var; c.target = J.target; c.w2b = J.w2b; c.w2f = J.w2f; c.w2tb = J.w2tb; c.tgt_w2b = J.tgt_w2b;
     c.cfg = mlp_bits(J.m) | ((uint32_t)J.nslots << 10) | ((uint32_t)J.wmode[0] << 12) | ((uint32_t)J.wmode[1] << 14) | ((uint32_t)A.w_kind << 16) |
             ((uint32_t)(A.ad.finish_actor ? 1 : 0) << 18) | ((uint32_t)(A.ad.use_bc ? 1 : 0) << 19);
     c.rows0 = J.rows[0]; c.rows1 = J.nslots > 1 ? J.rows[1] : J.rows[0];
@@ -107,7 +112,11 @@ inline WgJobC pack_wg(const WgJob& J, const WgArgs& A) {
     return c;
 }
 
-template <bool ADAM, bool RELU>
+// BF16 (the bf16 update path): dW2 = dz2^T h1 on v_mfma_f32_16x16x32_bf16 — both operands rounded to bf16 as they are loaded (32 batch rows
+// per MFMA instead of 4), fp32 accumulation per slot, the slot's BC weight applied to the fp32 sum; every other gradient (biases, LayerNorm,
+// layer 1, the head) is fp32 arithmetic on fp32 values.  With ADAM the step also refreshes the bf16 images of W2 (forward, transposed,
+// target).
+template <bool ADAM, bool RELU, bool BF16 = false>
 __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
     __shared__ __attribute__((aligned(16))) float lds[kWgRowChunk * XP + kWgRowChunk * 12 + kWgRG * kWgCols * kRedP];
     float* xs = lds;                          // [chunk][XP]   inputs (layer-1 job)
@@ -157,17 +166,43 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
             const int rows = J.rows[s];
             const int hr = ((rows + 7) >> 3) << 2;  // rows per half, a multiple of the MFMA's 4
             const int rbeg = half * hr, rend = min(rows, rbeg + hr);
-            for (int c0 = rbeg; c0 < rend; c0 += 64) {
-                float av[16], hv[16];
+            if constexpr (BF16) {
+                // MFMA m reduces over rows c0 + 32 m .. + 31: lane (r, g) feeds rows + 8 g .. + 7 of column n0 + r (A) / k0 + r (B)
+                v4f accs = {0.f, 0.f, 0.f, 0.f};
+                for (int c0 = rbeg; c0 < rend; c0 += 64) {
+                    float av[2][8], hv[2][8];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = c0 + 4 * i + g;  // MFMA i reduces over rows c0+4i .. c0+4i+3 (one per lane group)
-                    const unsigned rc = (unsigned)(row < rows ? row : rows - 1);  // unconditional loads (clamped); rows past the end get scale 0
-                    av[i] = dz[rc * (unsigned)H2 + dzo];
-                    hv[i] = h1[rc * (unsigned)H1 + h1o];
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int row = c0 + 32 * m + 8 * g + j;
+                            const unsigned rc = (unsigned)(row < rows ? row : rows - 1);  // unconditional loads (clamped)
+                            av[m][j] = dz[rc * (unsigned)H2 + dzo];
+                            hv[m][j] = h1[rc * (unsigned)H1 + h1o];
+                        }
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (c0 + 32 * m + 8 * g + j >= rend) av[m][j] = 0.0f;  // rows past this half's end contribute nothing
+                        accs = mfma16_bf16(pack8_bf16(av[m]), pack8_bf16(hv[m]), accs);
+                    }
                 }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc = mfma16(av[i] * (c0 + 4 * i + g < rend ? sc : 0.0f), hv[i], acc);
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_fmaf(sc, accs[q], acc[q]);
+            } else {
+                for (int c0 = rbeg; c0 < rend; c0 += 64) {
+                    float av[16], hv[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = c0 + 4 * i + g;  // MFMA i reduces over rows c0+4i .. c0+4i+3 (one per lane group)
+                        const unsigned rc = (unsigned)(row < rows ? row : rows - 1);  // unconditional loads (clamped); rows past the end get scale 0
+                        av[i] = dz[rc * (unsigned)H2 + dzo];
+                        hv[i] = h1[rc * (unsigned)H1 + h1o];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc = mfma16(av[i] * (c0 + 4 * i + g < rend ? sc : 0.0f), hv[i], acc);
+                }
             }
         }
         STAMP();
@@ -198,6 +233,14 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                     J.w2b[w2_image_index((uint32_t)(n0 + 4 * g + q0 + q), (uint32_t)(k0 + r))] = __builtin_bit_cast(uint16_t, bv);
                 }
                 if (J.w2f) J.w2f[w2f_image_index((uint32_t)(n0 + 4 * g + q0 + q), (uint32_t)(k0 + r))] = ae[q].p;
+                if (J.w2tb) {
+                    const __bf16 bv = (__bf16)ae[q].p;
+                    J.w2tb[w2t_image_index((uint32_t)(k0 + r), (uint32_t)(n0 + 4 * g + q0 + q))] = __builtin_bit_cast(uint16_t, bv);
+                }
+                if (J.target && J.tgt_w2b) {
+                    const __bf16 bv = (__bf16)ae[q].t;
+                    J.tgt_w2b[w2_image_index((uint32_t)(n0 + 4 * g + q0 + q), (uint32_t)(k0 + r))] = __builtin_bit_cast(uint16_t, bv);
+                }
             }
         }
         STAMP();
@@ -522,13 +565,34 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
             const uint32_t e = (uint32_t)(i - A.w2_lo);
             *reinterpret_cast<float4*>(A.w2f + w2f_image_index(e / H1, e % H1)) = p4;
         }
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (A.target) {
-            float4 t4 = *reinterpret_cast<const float4*>(A.target + i);
+            t4 = *reinterpret_cast<const float4*>(A.target + i);
             t4.x = polyak_update(t4.x, p4.x, A.tau);
             t4.y = polyak_update(t4.y, p4.y, A.tau);
             t4.z = polyak_update(t4.z, p4.z, A.tau);
             t4.w = polyak_update(t4.w, p4.w, A.tau);
             *reinterpret_cast<float4*>(A.target + i) = t4;
+        }
+        // bf16 update path: the images of every W2 this step changes follow it (forward, transposed, and the target's when it moved)
+        for (int sg = 0; sg < A.nseg; ++sg) {
+            if (i < A.seg_lo[sg] || i >= A.seg_lo[sg] + H2 * H1) continue;
+            typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+            const uint32_t e = (uint32_t)(i - A.seg_lo[sg]), col = e / H1, k = e % H1;  // four consecutive k of one column
+            const v4bf r = {(__bf16)p4.x, (__bf16)p4.y, (__bf16)p4.z, (__bf16)p4.w};
+            if (A.seg_w2b[sg]) *reinterpret_cast<uint2*>(A.seg_w2b[sg] + w2_image_index(col, k)) = __builtin_bit_cast(uint2, r);
+            if (A.seg_w2tb[sg]) {
+                const uint2 q = __builtin_bit_cast(uint2, r);
+                uint16_t* tb = A.seg_w2tb[sg];
+                tb[w2t_image_index(k, col)] = (uint16_t)(q.x & 0xFFFFu);
+                tb[w2t_image_index(k + 1, col)] = (uint16_t)(q.x >> 16);
+                tb[w2t_image_index(k + 2, col)] = (uint16_t)(q.y & 0xFFFFu);
+                tb[w2t_image_index(k + 3, col)] = (uint16_t)(q.y >> 16);
+            }
+            if (A.target && A.seg_tgt_w2b[sg]) {
+                const v4bf rt = {(__bf16)t4.x, (__bf16)t4.y, (__bf16)t4.z, (__bf16)t4.w};
+                *reinterpret_cast<uint2*>(A.seg_tgt_w2b[sg] + w2_image_index(col, k)) = __builtin_bit_cast(uint2, rt);
+            }
         }
         return;
     }
@@ -572,13 +636,17 @@ void launch_wg(const WgArgs& W, bool adam, hipStream_t st) {
     WgArgsC C{};
     for (int j = 0; j < W.njobs; ++j) C.job[j] = pack_wg(W.job[j], W);
     const dim3 grid(kWgPerJob, W.njobs);
-    if (adam) {
-        if (W.slope == 0.0f) hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(kWide), 0, st, C);
-        else hipLaunchKernelGGL((wgrad_kernel<true, false>), grid, dim3(kWide), 0, st, C);
+    const bool relu = W.slope == 0.0f;
+#define HX_WG(ADAM_, RELU_, BF16_) hipLaunchKernelGGL((wgrad_kernel<ADAM_, RELU_, BF16_>), grid, dim3(kWide), 0, st, C)
+    static const int dbg_off = getenv("HX_DBG_BF16_OFF") ? atoi(getenv("HX_DBG_BF16_OFF")) : 0;
+    if (W.bf16 && !(dbg_off & 4)) {
+        if (adam) { if (relu) HX_WG(true, true, true); else HX_WG(true, false, true); }
+        else { if (relu) HX_WG(false, true, true); else HX_WG(false, false, true); }
     } else {
-        if (W.slope == 0.0f) hipLaunchKernelGGL((wgrad_kernel<false, true>), grid, dim3(kWide), 0, st, C);
-        else hipLaunchKernelGGL((wgrad_kernel<false, false>), grid, dim3(kWide), 0, st, C);
+        if (adam) { if (relu) HX_WG(true, true, false); else HX_WG(true, false, false); }
+        else { if (relu) HX_WG(false, true, false); else HX_WG(false, false, false); }
     }
+#undef HX_WG
 }
 void launch_adam(const AdamArgs& A, hipStream_t st) {
     hipLaunchKernelGGL(adam_kernel, dim3((A.n / 4 + kThreads) / kThreads), dim3(kThreads), 0, st, A);
@@ -623,9 +691,27 @@ static int adam_impl(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t 
         A.w2f = N->actor_w2_f32i;
         A.w2_lo = kActor.W2();
     }
-    if (which != 0 && N->actor_w2_bf16) {
+    if (which != 0 && N->actor_w2_bf16 && !N->w2_bf16_all) {
         A.w2b = N->actor_w2_bf16;
         A.w2_lo = kActor.W2();
+    }
+    if (uint16_t* im = N->w2_bf16_all) {  // bf16 update path: the images of every W2 this step changes (and of the target it moves) follow it
+        HX_REQUIRE(!N->actor_w2_bf16 || N->actor_w2_bf16 == im + IM_ACTOR * kImgElems, "hx_adam: with w2_bf16_all set, actor_w2_bf16 must be NULL or its first image");
+        if (which == 0) {
+            A.nseg = 2;
+            for (int h = 0; h < 2; ++h) {
+                A.seg_lo[h] = h * kQ.padded() + kQ.W2();
+                A.seg_w2b[h] = im + (IM_C1 + h) * kImgElems;
+                A.seg_w2tb[h] = im + (IM_C1_T + h) * kImgElems;
+                A.seg_tgt_w2b[h] = im + (IM_TC1 + h) * kImgElems;
+            }
+        } else {
+            A.nseg = 1;
+            A.seg_lo[0] = kActor.W2();
+            A.seg_w2b[0] = im + IM_ACTOR * kImgElems;
+            A.seg_w2tb[0] = im + IM_ACTOR_T * kImgElems;
+            A.seg_tgt_w2b[0] = im + IM_TA * kImgElems;
+        }
     }
     if (msg) {  // merged actor message: [dL_rl | dL_bc | count ...]
         HX_REQUIRE(which == 1 && (reinterpret_cast<uintptr_t>(msg) & 15u) == 0, "hx_adam_mixed: actor step only, 16-byte aligned message");
@@ -658,6 +744,11 @@ int hx_polyak(const HxNets* N, const HxHyper* Hy, void* stream) {
     HX_REQUIRE(N && Hy, "hx_polyak: bad arguments");
     const int nc = 2 * kQ.padded(), na = kActor.size();
     launch_polyak(N->target_critic, N->critic, nc, Hy->tau, N->target_actor, N->actor, na, (hipStream_t)stream);
+    if (uint16_t* im = N->w2_bf16_all) {  // bf16 update path: the targets' images follow
+        launch_pack_bf16(N->target_actor + kActor.W2(), im + IM_TA * kImgElems, false, (hipStream_t)stream);
+        for (int h = 0; h < 2; ++h)
+            launch_pack_bf16(N->target_critic + h * kQ.padded() + kQ.W2(), im + (IM_TC1 + h) * kImgElems, false, (hipStream_t)stream);
+    }
     HX_CHECK_LAUNCH("hx_polyak");
     return 0;
 }

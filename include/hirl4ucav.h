@@ -200,7 +200,21 @@ typedef struct HxNets {
     uint16_t* actor_w2_bf16; /* NULL, or [512][256] bf16 image of the actor's full2.weight: every Adam step of the actor refreshes it
                                 (hx_adam which = 1 / 2), the bf16 acting entry points read it */
     float* actor_w2_f32i;    /* NULL, or the fp32 image of the same matrix (hx_pack_w2_f32i), refreshed likewise; hx_actor_act*_f32i read it */
+    uint16_t* w2_bf16_all;   /* NULL: the update computes in fp32 (parity 1e-5 vs the reference).  Else hx_bf16_images_elems() bf16 elements =
+                                the bf16 images of every W2 the update reads: the bf16 UPDATE path (below).  Its first 512 x 256 elements are
+                                the actor's image in the bf16 acting kernels' format: actor_w2_bf16 must then be NULL or point at them */
 } HxNets;
+
+/* bf16 update path (BASELINE.json configs[4] "bf16 actor/critic + fp32 dynamics"; SURVEY.md 7 "bf16 config").  With HxNets.w2_bf16_all set,
+ * every hx_hirl_* / hx_bc_train_actor call runs the three products of the 256 <-> 512 layer of all five networks (Actor / Critic forward
+ * HIRL.py:55-97,126-140 inside learn() HIRL.py:259-325, and their backward passes) on v_mfma_f32_16x16x32_bf16:
+ *     z2 = bf16(h1) bf16(W2)^T + b2        dh1 = bf16(dz2) bf16(W2)        dW2 = bf16(dz2)^T bf16(h1)       (fp32 accumulation)
+ * Master weights, Adam moments, LayerNorm statistics, layer 1 (K = 13 / 17), the heads, TD targets and loss sums stay fp32.  The images
+ * (forward order for z2, transposed for dh1; actor, critic x 2, the three targets, bc_actor) are kept current by every optimizer / Polyak
+ * step (hx_hirl_learn*, hx_adam*, hx_polyak, hx_bc_train_actor); after any OTHER write to a network (loading parameters) call
+ * hx_pack_update_images.  Tolerance against an fp32 evaluation on the same rounded operands: tests/test_bf16_update_gpu.py. */
+int64_t hx_bf16_images_elems(void);
+int hx_pack_update_images(const HxNets* nets, void* stream);
 
 typedef struct HxHyper {
     float gamma, tau, lr_actor, lr_critic, slope, noise_clamp, loss_lambda;

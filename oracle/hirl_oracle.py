@@ -80,17 +80,54 @@ def _ln(x, w, b):
     return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
 
 
+def _linear2(h, w, b):
+    """the 256 -> 512 layer.  fp32 F.linear — or, inside `with Bf16Layer2():`, the ROUNDED-OPERAND form the bf16 update path is tested
+    against (tests/test_bf16_update_gpu.py)."""
+    return F.linear(h, w, b)
+
+
+class _RoundedLinear2(torch.autograd.Function):
+    """z = bf16(h) bf16(W)^T + b;  dh = bf16(dz) bf16(W);  dW = bf16(dz)^T bf16(h);  db = sum(dz) — products exact, sums in fp64
+    (the reference value for fp32 accumulation in any order); everything outside these three products stays fp32."""
+
+    @staticmethod
+    def forward(ctx, h, w, b):
+        hb, wb = h.to(torch.bfloat16).double(), w.to(torch.bfloat16).double()
+        ctx.save_for_backward(hb, wb)
+        return (hb @ wb.t()).float() + b
+
+    @staticmethod
+    def backward(ctx, g):
+        hb, wb = ctx.saved_tensors
+        gb = g.to(torch.bfloat16).double()
+        return (gb @ wb).float(), (gb.t() @ hb).float(), g.sum(0)
+
+
+class Bf16Layer2:
+    """context manager: every _linear2 inside runs as _RoundedLinear2 (BASELINE.json configs[4] "bf16 actor/critic")"""
+
+    def __enter__(self):
+        global _linear2
+        self._orig = _linear2
+        _linear2 = _RoundedLinear2.apply
+        return self
+
+    def __exit__(self, *exc):
+        global _linear2
+        _linear2 = self._orig
+
+
 def actor_forward(p, x, slope=0.0):
     """tanh(W3 act(LN2(W2 act(LN1(W1 x + b1)) + b2)) + b3)   HIRL.py:126-140"""
     h = _act(_ln(F.linear(x, p["full1.weight"], p["full1.bias"]), p["layernorm1.weight"], p["layernorm1.bias"]), slope)
-    h = _act(_ln(F.linear(h, p["full2.weight"], p["full2.bias"]), p["layernorm2.weight"], p["layernorm2.bias"]), slope)
+    h = _act(_ln(_linear2(h, p["full2.weight"], p["full2.bias"]), p["layernorm2.weight"], p["layernorm2.bias"]), slope)
     return torch.tanh(F.linear(h, p["final.weight"], p["final.bias"]))
 
 
 def _q_head(p, sa, names, slope):
     a, ln1, b, ln2, f = names
     h = _act(_ln(F.linear(sa, p[a + ".weight"], p[a + ".bias"]), p[ln1 + ".weight"], p[ln1 + ".bias"]), slope)
-    h = _act(_ln(F.linear(h, p[b + ".weight"], p[b + ".bias"]), p[ln2 + ".weight"], p[ln2 + ".bias"]), slope)
+    h = _act(_ln(_linear2(h, p[b + ".weight"], p[b + ".bias"]), p[ln2 + ".weight"], p[ln2 + ".bias"]), slope)
     return F.linear(h, p[f + ".weight"], p[f + ".bias"])
 
 
@@ -155,6 +192,9 @@ class HirlOracle:
         self.actor_loss = self.bc_loss = self.rl_loss = 0.0
         self.bc_fire_loss = 0.0
         self.last_grads = {}
+        # True: grad(actor_loss) formed as w grad(bc_loss) + (1 - w) grad(rl_loss) from two backward passes (what a sharded run exchanges,
+        # SURVEY.md 8e; equal in exact arithmetic).  The rounded-operand bf16 check needs it: bf16(w dz) != w bf16(dz).
+        self.split_actor_grads = False
 
     def choose_action(self, state, noise=None):
         """clamp(actor(s) + noise, -1, 1); noise None = chooseActionNoNoise   HIRL.py:192-212"""
@@ -206,7 +246,13 @@ class HirlOracle:
             else:  # TD3.py:233-236
                 actor_loss = rl_loss
             akeys = list(self.actor)
-            agrads = dict(zip(akeys, torch.autograd.grad(actor_loss, [self.actor[k] for k in akeys])))
+            if self.split_actor_grads and self.use_bc:
+                g_bc = torch.autograd.grad(bc_loss, [self.actor[k] for k in akeys], retain_graph=True)
+                g_rl = torch.autograd.grad(rl_loss, [self.actor[k] for k in akeys])
+                w = float(self.bc_weight)
+                agrads = {k: w * a + (1.0 - w) * b for k, a, b in zip(akeys, g_bc, g_rl)}
+            else:
+                agrads = dict(zip(akeys, torch.autograd.grad(actor_loss, [self.actor[k] for k in akeys])))
             self.last_grads["actor"] = {k: g.clone() for k, g in agrads.items()}
             self.opt_actor.step(self.actor, agrads)
             self.actor_loss, self.rl_loss = actor_loss.item(), rl_loss.item()
