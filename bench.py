@@ -18,9 +18,10 @@ episodes (random_reset, Philox), synthetic 20,000-row expert set, seeded-init ne
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
 Shape of a run: [settle: untimed steps for --settle-s seconds, so that clocks and caches are where a long run keeps them] ->
-W warm-up steps -> barrier + synchronize -> EXACTLY K steps with nothing but the hot path on the stream -> synchronize + barrier
-(max over ranks).  Everything that needs events, stamped or split launches (stage times, the env kernel's own duration for the
-roofline, all-reduce times) runs in a SECOND pass after the clock has been read.
+W warm-up steps -> R = --reps (3) repetitions of { barrier + synchronize -> EXACTLY K steps with nothing but the hot path on the stream
+-> synchronize + barrier (max over ranks) }; `value` / `ms_per_step` are the MEDIAN repetition, all R are listed.
+Everything that needs events or stamped launches (stage times, the act + env launch's own duration for the roofline, the stand-alone env
+kernel, all-reduce times) runs in a SECOND pass after the clock has been read.
 """
 import argparse
 import ctypes
@@ -59,8 +60,10 @@ def parse(argv=None):
     p.add_argument("--type", default="soft", choices=["soft", "linear", "fixed"], help="HIRL BC-weight schedule (train_all.py:328-339)")
     p.add_argument("--bc_weight", type=float, default=0.5, help="linear / fixed: the weight (configs[3]: linear, 0.5)")
     p.add_argument("--agent", default="hirl", choices=["hirl", "sac"], help="sac: BASELINE.json configs[2] (use --envs 16384 --scenario serpentine)")
-    p.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                   help="bf16: actor inference on bf16 MFMA with fp32 accumulation, fp32 dynamics / update / optimizer (BASELINE.json configs[4])")
+    p.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16_policy"],
+                   help="bf16: actor AND critic — policy inference and the three 256<->512 products of every network in learn() on bf16 MFMA, fp32 "
+                        "accumulation, fp32 master weights / Adam / LayerNorm / dynamics (BASELINE.json configs[4]); bf16_policy: policy inference only")
+    p.add_argument("--reps", type=int, default=3, help="timed repetitions of K steps; value = the median repetition (SURVEY.md 8d)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="total budget of the CPU baseline legs")
     p.add_argument("--no-sweep", action="store_true", help="skip the env-step kernel sweep over 4k..4M envs per launch (< 1 s)")
@@ -77,9 +80,11 @@ def parse(argv=None):
     p.add_argument("--separate-launches", dest="separate_launches", action="store_true",
                    help="act and env step as two launches on every step (default: one fused launch, hx_actor_act_step)")
     p.add_argument("--staged", action="store_true",
-                   help="use the stage-by-stage update path of the sharded build on one rank too (costs of the N > 1 launch sequence)")
+                   help="run EXACTLY the launch sequence of a sharded rank on one rank too (stage entry points, split actor message, hx_adam_mixed, "
+                        "both exchange calls — through torch.distributed when launched by torch.distributed.run): the cost of the N > 1 step")
     p.add_argument("--exchange", default="rccl", choices=["rccl", "oneshot"],
-                   help="gradient exchange at N > 1: RCCL all-reduce (torch.distributed) or the one-shot peer-read kernel over hipIpc mappings")
+                   help="gradient exchange at N > 1: RCCL all-reduce (torch.distributed) or — EXPERIMENTAL, never run on two physical GPUs — the "
+                        "one-shot peer-read kernel over hipIpc mappings")
     p.add_argument("--exchange-timeout-ms", dest="exchange_timeout_ms", type=int, default=5000,
                    help="one-shot exchange: how long a rank waits for a peer's message before it raises (ranks that SHARE a GPU - tests - "
                         "only make progress through pre-emption and need far longer than ranks with a GPU each)")
@@ -196,8 +201,9 @@ class Loop:
             self.eng.load_params(actor, critic, bc)
             if args.staged:
                 self.eng.staged = True
-            if hasattr(self.eng, "set_act_dtype"):
-                self.eng.set_act_dtype(args.dtype)
+                self.eng.sharded_sequence = True
+            self.eng.set_act_dtype("f32" if args.dtype == "f32" else "bf16")
+            self.eng.set_update_dtype("bf16" if args.dtype == "bf16" else "f32")
             if world > 1 and args.exchange == "oneshot":
                 self.eng.use_oneshot_exchange(timeout_ms=args.exchange_timeout_ms)
         es, ea = synthetic_expert(rng)
@@ -222,7 +228,8 @@ class Loop:
         self.pipe = VectorStepPipeline(device, overlap=args.overlap and not args.serial and not self.sac)
         self.separate = args.separate_launches
         self.rec = {"act": [], "env": [], "act+env": [], "learn": []}
-        self.krec = []
+        self.krec, self.krec_fused = [], []
+        self.fused = not (self.uniform or self.separate) and n <= 8192  # act + env step as ONE launch (hx_actor_act_step up to 8,192 envs)
 
     # ---- the hot path ------------------------------------------------------------------------------------------------
     def _act_env(self, timed=None, split=False, stamp=None):
@@ -240,10 +247,15 @@ class Loop:
             t("env", lambda: env.step(self.actions))
             if stamp is not None:
                 env.time_next_steps(None, None)
-        elif self.sac:   # explore + env.step in one launch
-            t("act+env", lambda: e.act_step(env, seed=1, out=self.actions))
-        else:            # chooseAction + env.step in one launch (same results, bit for bit: tests/test_hirl_gpu.py)
-            t("act+env", lambda: e.act_step(env, sigma=0.1, seed=1, out=self.actions))
+        else:
+            if stamp is not None:  # the launch's own begin / end (hipExtLaunchKernelGGL events): up to 8,192 envs that is the fused act + env kernel
+                env.time_next_steps(*stamp)
+            if self.sac:   # explore + env.step in one launch
+                t("act+env", lambda: e.act_step(env, seed=1, out=self.actions))
+            else:          # chooseAction + env.step in one launch (same results, bit for bit: tests/test_hirl_gpu.py)
+                t("act+env", lambda: e.act_step(env, sigma=0.1, seed=1, out=self.actions))
+            if stamp is not None:
+                env.time_next_steps(None, None)
 
     def _learn(self, act_env):
         e = self.eng
@@ -254,7 +266,7 @@ class Loop:
         # the draw and the gather ride in the first launch of learn() (hx_hirl_learn_sampled): same minibatch, one launch less
         e.sample(self.replay, self.expert, self.bc_table, n_main=e.batch - self.expert_num, seed=2 + self.rank, defer=not (self.args.sample_launch or self.args.overlap))  # --overlap: the next env step may run beside learn(): draw first
         # a critic-only learn() leaves the acting network alone: the next act + env.step go out on the side stream now
-        self.pipe.arm(act_env, acting_net_untouched=not e.actor_trainable)
+        self.pipe.arm(act_env, acting_net_untouched=not e.actor_trainable, engine=e)
         # soft weight: estimated at the start of every max_step-long "episode" of vector steps, kept in between
         # (the reference re-estimates at most once per episode)
         kind = self.args.type
@@ -290,6 +302,9 @@ class Loop:
         if split and not self.uniform:
             stamp = (kpool.pop(), kpool.pop())
             self.krec.append(stamp)
+        elif not split and not self.uniform and not self.separate and len(kpool) >= 2:
+            stamp = (kpool.pop(), kpool.pop())
+            self.krec_fused.append(stamp)
         act_env = lambda: self._act_env(timed, split, stamp)  # noqa: E731
         self.pipe.act_and_step(act_env)
         timed("learn", lambda: self._learn(act_env))
@@ -361,6 +376,54 @@ def baseline_port(args, seconds):
     return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": cores, "kind": "port",
             "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s: oracle C env step on {len(chunks)} threads + torch-CPU actor forward and "
                       f"HIRL learn on {torch.get_num_threads()} threads",
+            "update_steps_per_s": round(steps / dt, 2)}
+
+
+def baseline_port_sac(args, seconds):
+    """The SAC loop (train_sac.py:238-241,401-403) on the oracle: SacOracle.explore for all envs, the oracle's C env step with insert on host
+    threads, one SacOracle.learn at B = 128 per vector step — a BOUNDED sample of the same workload."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import sac_oracle as S
+    from tests import _oracle as ox
+
+    n = args.envs
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    o = S.SacOracle(S.init_mlp(rng, 13, 8), S.init_mlp(rng, 17, 1), S.init_mlp(rng, 17, 1))
+    scen = {"straight_line": 0, "serpentine": 1, "circular": 2}.get(args.scenario, 0)
+    envs, obs = ox.reset_batch(n, scen, 1, seed=0)
+    workers = max(1, min(cores, n // 256))
+    chunks = [(k * n // workers, (k + 1) * n // workers) for k in range(workers)]
+    cap = 1 << 14
+    rings = [np.zeros((cap, 32), np.float32) for _ in chunks]
+    totals = [np.zeros(1, np.uint64) for _ in chunks]
+    epi = np.zeros(n, np.uint32)
+    pool = ThreadPoolExecutor(len(chunks))
+
+    def work(k, a):
+        lo, hi = chunks[k]
+        ox.step_batch(envs[lo:hi], a[lo:hi], obs[lo:hi], max_step=1500, auto_reset=1, randomize=1, seed=0, env_id0=lo, episode_ctr=epi[lo:hi],
+                      ring=rings[k], total=totals[k])
+
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        a = o.explore(obs, rng.normal(0, 1, (n, 4)).astype(np.float32)).astype(np.float32)
+        list(pool.map(lambda k: work(k, a), range(len(chunks))))
+        ring = rings[steps % len(rings)]
+        m = max(min(int(totals[steps % len(rings)][0]), cap), 1)
+        rows = ring[rng.integers(0, m, args.batch)]
+        o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 30], rows[:, 17:30], rows[:, 31]), rng.normal(0, 1, (args.batch, 4)).astype(np.float32),
+                rng.normal(0, 1, (args.batch, 4)).astype(np.float32))
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds or steps >= 2000:
+            break
+    pool.shutdown()
+    return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s: oracle C env step on {len(chunks)} threads + torch-CPU SAC explore and "
+                      f"learn on {torch.get_num_threads()} threads",
             "update_steps_per_s": round(steps / dt, 2)}
 
 
@@ -572,11 +635,37 @@ def profile_traffic(envs):
             "note": "separate rocprofv3 --pmc passes of tools/pmc_env.py at this size; a profile artefact, not a measurement of this run"}
 
 
+POLICY_FLOP_SAC = 2 * (13 * 256 + 256 * 512 + 512 * 8)  # GaussianPolicy forward, GEMMs only
+
+
+def workload_label(args):
+    """what THIS run computes, from its arguments; a BASELINE.json configs[] index only where the arguments match that config"""
+    if args.agent == "sac":
+        what = f"{args.envs} parallel {args.scenario} envs per GPU, SAC fp32, 1 learn(B={args.batch}) per vector step"
+        cfg = 2 if (args.envs == 16384 and args.scenario == "serpentine") else None
+        tag = " (BASELINE.json configs[2])" if cfg == 2 else ""
+        return what + tag
+    dt = {"f32": "fp32", "bf16": "bf16 actor/critic (fp32 accumulate, fp32 master weights / Adam / LayerNorm) + fp32 dynamics",
+          "bf16_policy": "bf16 policy inference (fp32 accumulate) + fp32 dynamics / update"}[args.dtype]
+    kind = f"HIRL-{args.type}" + (f" (bc_weight {args.bc_weight})" if args.type != "soft" else "")
+    what = f"{args.envs} parallel {args.scenario} envs per GPU, {kind} {dt}, 1 learn(B={args.batch}) per vector step"
+    tag = ""
+    if args.actions == "policy" and args.batch == 128:
+        if args.envs == 4096 and args.scenario == "straight_line" and args.type == "soft" and args.dtype == "f32":
+            tag = " (BASELINE.json configs[1])"
+        elif args.envs == 8192 and args.scenario == "circular" and args.type == "linear" and args.dtype == "f32":
+            tag = " (one GPU's shard of BASELINE.json configs[3])"
+        elif args.envs == 16384 and args.scenario == "mixed" and args.dtype == "bf16":
+            tag = " (one GPU's shard of BASELINE.json configs[4])"
+    return what + tag
+
+
 def run_rank(args):
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     backend = os.environ.get("HX_BENCH_BACKEND", "nccl")  # gloo exists only to exercise this code path where all ranks share one GPU
     ngpu = torch.cuda.device_count()
     if world != args.gpus:
@@ -588,7 +677,10 @@ def run_rank(args):
     local = int(os.environ.get("LOCAL_RANK", "0")) % ngpu
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # Under a launcher the process group exists at ANY world size (RCCL = backend "nccl" on ROCm): with --staged a single rank then sends
+    # its two messages per actor call through the collective library too.
+    pg = world > 1 or launched
+    if pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
     loop = Loop(args, rank, world, device)
@@ -602,37 +694,46 @@ def run_rank(args):
     settle_steps = 0
     if args.settle_s > 0:
         t_end = time.perf_counter() + args.settle_s
-        while time.perf_counter() < t_end:
+        while True:
             for _ in range(32):
                 loop.step()
             settle_steps += 32
-            if world > 1:  # every rank must leave the phase after the same number of collective calls
+            if world > 1:
+                # every rank leaves the phase after the SAME number of collective calls: the all-reduced flag alone decides (a rank-local
+                # clock test here could let one rank fall out of the loop while its peers enqueue 32 more steps and one more flag exchange)
                 flag = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], device=device)
                 torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
                 if float(flag.item()) == 0.0:
                     break
+            elif time.perf_counter() >= t_end:
+                break
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         loop.step()
-    # ---- the timed region: K steps, nothing else on the stream ----
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loop.step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=device)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    # ---- the timed region: R repetitions of K steps, nothing else on the stream ----
+    reps = []
+    for _ in range(max(int(args.reps), 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loop.step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=device)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        reps.append(dt)
+    dt = float(np.median(reps))
 
-    # ---- second pass: stage events; every 4th step act and env step as two launches with the env launch stamped ----
+    # ---- second pass: stage events; the act + env launch stamped; every 4th step act and env step as two launches, the env launch stamped ----
     ar_events = []
     m_steps = max(int(args.measure_steps), 16)
     pool = [torch.cuda.Event(enable_timing=True) for _ in range(12 * (m_steps + 1))]
     L = loop.lib.load()
-    kpool = [ctypes.c_void_p(L.hx_event_create()) for _ in range(2 * (m_steps // 4 + 2))]
-    if world > 1:  # exchange step: events around every gradient exchange (on the stream it is enqueued on)
+    kpool = [ctypes.c_void_p(L.hx_event_create()) for _ in range(2 * (m_steps + 2))]
+    exchanging = world > 1 or (args.staged and pg and args.agent == "hirl")
+    if exchanging:  # exchange step: events around every gradient exchange (on the stream it is enqueued on)
         inner = loop.eng._allreduce
 
         def timed_allreduce(t, kind=None):
@@ -650,80 +751,110 @@ def run_rank(args):
     for k in range(m_steps):
         loop.step_measured(split=(k % 4 == 3), pool=pool, kpool=kpool)
     barrier()
-    if world > 1:
+    if exchanging:
         loop.eng._allreduce = inner
         if getattr(loop.eng, "xchg", None) is not None:
             loop.eng.xchg.check()  # a timed-out wait leaves garbage behind: fail loudly instead of printing a number
     med = {k: (float(np.median([a.elapsed_time(b) * 1e3 for a, b in v])) if v else None) for k, v in loop.rec.items()}
-    kern = []
-    for a, b in loop.krec:
-        us = ctypes.c_float()
-        loop.lib.call("hx_event_elapsed_us", a, b, ctypes.byref(us))
-        kern.append(us.value)
+
+    def stamped_us(pairs):
+        out = []
+        for a, b in pairs:
+            us = ctypes.c_float()
+            loop.lib.call("hx_event_elapsed_us", a, b, ctypes.byref(us))
+            out.append(us.value)
+        return out
+
+    kern = stamped_us(loop.krec)
     if not kern:  # uniform actions: the loop has no act launch to split off; stamp plain env steps
         kern = stamped_env_us(loop.env, loop.actions, 32)
     env_kernel_us = float(np.mean(kern))  # mean, like the rocprofv3 --stats average it must agree with
+    fused = stamped_us(loop.krec_fused) if loop.fused else []
     act_us, learn_us = med["act"], med["learn"]
 
     n_total = args.envs * world
     value = n_total * args.steps / dt
-    dt_name = "f32" if args.dtype == "f32" else "bf16 policy inference (fp32 accumulate) + f32 dynamics/update"
     res = {
         "metric": "env steps/sec (whole node) + HIRL update steps/sec at 4096 envs/GPU", "value": round(value, 1),
         "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_s": args.settle_s, "settle_steps": settle_steps,
         "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": (f"{args.envs} parallel {args.scenario} envs per GPU, SAC fp32, 1 learn(B={args.batch}) per vector step "
-                                f"(BASELINE.json configs[2])" if args.agent == "sac" else
-                                f"{args.envs} parallel {args.scenario} envs per GPU, HIRL-{args.type} {dt_name}, 1 learn(B={args.batch}) per vector step "
-                                f"(BASELINE.json configs[1])"), "envs_per_gpu": args.envs, "batch": args.batch,
-                   "actions": args.actions, "act_env": "two launches" if (loop.separate or loop.uniform) else "one launch (hx_actor_act_step / hx_sac_act_step)",
+        "dtype": "f32" if args.dtype == "f32" else ("bf16" if args.dtype == "bf16" else "bf16 policy / f32 update"), "data": "synthetic",
+        "repetitions": {"count": len(reps), "statistic": "median", "ms_per_step": [round(t / args.steps * 1e3, 5) for t in reps],
+                        "value": [round(n_total * args.steps / t, 1) for t in reps]},
+        "config": {"workload": workload_label(args), "envs_per_gpu": args.envs, "batch": args.batch,
+                   "actions": args.actions, "act_env": "one launch (hx_actor_act_step / hx_sac_act_step)" if loop.fused else "two launches",
                    "issue_order": "two streams" if loop.pipe.overlap else "serial",
-                   "update_path": "staged" if (args.staged or world > 1) and args.agent == "hirl" else "one-call",
+                   "update_path": "staged (the sharded rank's launch sequence)" if (args.staged or world > 1) and args.agent == "hirl" else "one-call",
                    "parallelism": f"dp{world}: env shards + replicated nets, {'one-shot peer-read' if (world > 1 and args.exchange == 'oneshot') else 'RCCL'} "
                                   f"all-reduce of the flat gradients; effective batch = {args.batch} x {world}"},
         "update_steps_per_s": round(args.steps / dt, 1),
-        "timed_region": "K x step() between two barrier + synchronize pairs; no events, no stamped or split launches inside (those are the second pass)",
+        "timed_region": "R x [K x step() between two barrier + synchronize pairs]; no events, no stamped or split launches inside (those are the second pass)",
         "stage_us": {"pass": f"second pass, {m_steps} steps after the timed region (events add a few us per step)",
                      "act+env_step(1 kernel)": None if med["act+env"] is None else round(med["act+env"], 2),
                      "act(own launch, every 4th step)": None if act_us is None else round(act_us, 2),
                      "env_step(own launch, every 4th step)": None if med["env"] is None else round(med["env"], 2),
                      "sample+learn": None if learn_us is None else round(learn_us, 2)},
     }
-    # roofline of the env-step kernel (the kernel the metric counts): algorithmic bytes / live-measured launch time
-    res["roofline"] = {"kernel": "env_step_kernel<PAIR, INSERT, EPB> (hx_env.hip)", "bound": "hbm",
-                       "achieved": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                       "frac": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None,
-                       "bytes_per_launch": ENV_BYTES_FUSED * args.envs, "us_per_launch": round(env_kernel_us, 2), "launches_timed": len(kern),
-                       "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the launches of "
-                                 "the second pass (act and env step issued as two launches there; the timed loop runs them as ONE kernel)",
-                       "traffic_note": "PMC counters are not collectable inside this process: see traffic_from_profiles",
-                       "traffic_from_profiles": profile_traffic(args.envs)}
+    env_roof = {"kernel": "env_step_kernel<PAIR, INSERT, EPB> (hx_env.hip)", "bound": "hbm",
+                "achieved": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None,
+                "bytes_per_launch": ENV_BYTES_FUSED * args.envs, "us_per_launch": round(env_kernel_us, 2), "launches_timed": len(kern),
+                "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the launches of "
+                          "the second pass in which act and env step are issued as two launches",
+                "traffic_note": "PMC counters are not collectable inside this process: see traffic_from_profiles",
+                "traffic_from_profiles": profile_traffic(args.envs)}
+    if fused:
+        # the kernel the timed loop RUNS: policy inference + env step + replay insert in one launch.  Both roofs are quoted; `bound` names the nearer.
+        us = float(np.mean(fused))
+        flop = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
+        peak = FP32_MATRIX_PEAK_TFLOPS if (args.dtype == "f32" or args.agent == "sac") else BF16_MATRIX_PEAK_TFLOPS
+        tf, gb = flop / us / 1e6, ENV_BYTES_FUSED * args.envs / us / 1e3
+        mf, hf = tf / peak, gb / HBM_PEAK_GBPS
+        hbm = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hf, 4), "bytes_per_launch": ENV_BYTES_FUSED * args.envs}
+        mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(mf, 4), "flop_per_launch": flop}
+        first, second = (mfma, hbm) if mf >= hf else (hbm, mfma)
+        res["roofline"] = {"kernel": "act_fused_kernel<NRT, GAUSS, ENV = true, ...> (hx_act.hip): policy inference + env step + fused replay insert, the dominant "
+                                     "kernel of the timed loop", **first, "traffic": None, "other_roof": second,
+                           "us_per_launch": round(us, 2), "launches_timed": len(fused),
+                           "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the fused launches "
+                                     "of the second pass (3 of every 4 steps)",
+                           "note": "latency-bound at this size: 256 workgroups, one round; neither roof is near (DESIGN.md section 4)",
+                           "traffic_note": "PMC counters are not collectable inside this process: profiles/ holds the rocprofv3 --pmc passes"}
+        res["roofline_env_kernel"] = env_roof
+    else:
+        res["roofline"] = env_roof
     if learn_us:
-        res["roofline_update"] = {"kernels": "sample + fwd_l2/bwd_l2/wgrad/adam (one learn)", "bound": "mfma", "unit": "TFLOP/s",
-                                  "achieved": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
-                                  "frac": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 5),
-                                  "us_per_learn": round(learn_us, 2)}
-    if act_us:
-        peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS
-        res["roofline_act"] = {"kernels": "act_fused_kernel", "bound": "mfma", "unit": "TFLOP/s",
-                               "achieved": round(ACTOR_FLOP * args.envs / act_us / 1e6, 3), "peak": peak,
-                               "frac": round(ACTOR_FLOP * args.envs / act_us / 1e6 / peak, 5), "us": round(act_us, 2)}
+        peak_u = BF16_MATRIX_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MATRIX_PEAK_TFLOPS
+        res["roofline_update"] = {"kernels": "fwd_l2/bwd_l2/wgrad(+adam) (one learn, minibatch draw included)", "bound": "mfma", "unit": "TFLOP/s",
+                                  "achieved": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6, 3), "peak": peak_u,
+                                  "frac": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6 / peak_u, 5),
+                                  "us_per_learn": round(learn_us, 2), "timing": "torch events around learn() in the second pass (median)"}
+    if act_us and not loop.uniform:  # (with --actions uniform the 'act' stage is a torch uniform_ fill, not the policy)
+        peak = FP32_MATRIX_PEAK_TFLOPS if (args.dtype == "f32" or args.agent == "sac") else BF16_MATRIX_PEAK_TFLOPS
+        flop = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
+        res["roofline_act"] = {"kernels": "act_fused_kernel<ENV = false> as its own launch (every 4th step of the second pass)", "bound": "mfma", "unit": "TFLOP/s",
+                               "achieved": round(flop / act_us / 1e6, 3), "peak": peak,
+                               "frac": round(flop / act_us / 1e6 / peak, 5), "us": round(act_us, 2), "timing": "torch events (median)"}
+    if pg:
+        ids = [None] * world
+        torch.distributed.all_gather_object(ids, (socket.gethostname(), str(getattr(torch.cuda.get_device_properties(local), "uuid", local))))
+        res["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(), "backend": backend, "distinct_gpus": len(set(ids)),
+                             "exchange": getattr(loop.eng, "exchange_name", "rccl"),
+                             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}
     if world > 1:  # the replicas must still be bit-identical after every sharded update so far
         mine = torch.tensor([loop.eng.replica_checksum()], dtype=torch.int64, device=device)
         every = [torch.zeros_like(mine) for _ in range(world)]
         torch.distributed.all_gather(every, mine)
         res["replicas_identical"] = bool(all(int(c.item()) == int(mine.item()) for c in every))
-        ids = [None] * world
-        torch.distributed.all_gather_object(ids, (socket.gethostname(), str(getattr(torch.cuda.get_device_properties(local), "uuid", local))))
-        res["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(), "backend": backend, "distinct_gpus": len(set(ids)),
-                             "exchange": getattr(loop.eng, "exchange_name", "rccl")}
     if ar_events:  # SURVEY.md 8d "collective bytes": per message size, median us and bus bandwidth 2 (n-1)/n * bytes / t
         by = {}
         for nbytes, a, b in ar_events:
             by.setdefault(nbytes, []).append(a.elapsed_time(b) * 1e3)
         res["allreduce"] = [{"bytes": k, "calls": len(v), "median_us": round(float(np.median(v)), 2),
                              "busbw_GBps": round(2 * (world - 1) / world * k / float(np.median(v)) / 1e3, 2)} for k, v in sorted(by.items())]
+        if world == 1:
+            res["allreduce_note"] = ("world size 1: the collective library short-circuits an in-place all-reduce of one rank (no kernel is launched); the "
+                                     "figure is the host-side call on the stream, NOT an exchange time — the N > 1 term stays unmeasured on this box")
     res["env_stats"] = loop.env.stats_dict()
     if rank == 0:
         if not args.no_sweep:
@@ -737,8 +868,12 @@ def run_rank(args):
                 res["cpu_baseline"]["b0_reference_plumbing"] = baseline_reference_plumbing(0.3 * budget)
                 res["cpu_baseline"]["b1_batched_cpu"] = baseline_batched_cpu(0.15 * budget)
                 res["cpu_baseline"]["b2_eager_rocm_learn"] = baseline_eager_rocm_learn(args, 0.15 * budget, device)
+            else:
+                res["cpu_baseline"] = baseline_port_sac(args, 0.7 * budget)
+                res["cpu_baseline"]["host"] = f"{model}, {cores} logical cores"
+                res["cpu_baseline"]["b1_batched_cpu"] = baseline_batched_cpu(0.3 * budget)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if pg:
         torch.distributed.destroy_process_group()
     return 0
 

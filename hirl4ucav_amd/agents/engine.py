@@ -33,7 +33,7 @@ class HxSample(ctypes.Structure):
 class HxNets(ctypes.Structure):
     _fields_ = [(k, _vp) for k in ("actor", "critic", "target_actor", "target_critic", "bc_actor", "grad_actor", "grad_critic",
                                    "m_actor", "v_actor", "m_critic", "v_critic", "losses", "soft_count", "wstate", "ws", "actor_w2_bf16", "actor_w2_f32i",
-                                   "w2_bf16_all")]
+                                   "w2_bf16_all", "xchg_status")]
 
 
 class HxHyper(ctypes.Structure):
@@ -148,8 +148,10 @@ class OneShotExchange:
         """raises if a wait timed out since the last check (synchronises)"""
         torch.cuda.synchronize()
         st = torch.as_tensor(_DeviceWords(self.status_ptr, 1), device=self.device).view(torch.int32)
-        if int(st.item()) != 0:
-            raise _lib.HxError("one-shot exchange: a peer did not arrive in time (status word set)")
+        code = int(st.item())
+        if code != 0:
+            raise _lib.HxError("one-shot exchange failed (sticky, every rank stops stepping): " +
+                               ("a peer did not arrive within the timeout" if code == 1 else "a peer reported failure"))
 
     def close(self):
         for p in self._peers:
@@ -238,7 +240,7 @@ class HirlEngine:
         self._pending = None  # a draw sample(defer=True) recorded for the next learn()
         self.nets = HxNets(*(t.data_ptr() for t in (self.actor, self.critic, self.target_actor, self.target_critic, self.bc_actor,
                                                      self.grad_actor, self.grad_critic, self.m_actor, self.v_actor, self.m_critic,
-                                                     self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None, None, None)
+                                                     self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None, None, None, None)
         self.act_dtype, self.w2_bf16 = "f32", None
         self.update_dtype, self.images = "f32", None
         # fp32 image of the actor's W2 in the acting kernel's operand order (hx_pack_w2_f32i): kept current by the actor's Adam steps
@@ -255,6 +257,9 @@ class HirlEngine:
         self.staged = self.world > 1  # stage-by-stage path with the gradient exchanges; the one-call fused path otherwise
         # sharded runs: ONE message for the whole actor phase ([dL_rl | dL_bc | soft count], combined after the exchange)
         self.actor_msg = torch.zeros(int(L.hx_actor_message_floats()), dtype=torch.float32, device=self.device) if self.world > 1 else None
+        # True at world == 1: run EXACTLY the launch sequence of a sharded rank (split actor message, hx_adam_mixed, both exchange calls
+        # — through torch.distributed when a process group exists) so that its cost can be measured on one GPU (bench.py --staged)
+        self.sharded_sequence = False
         self.exchange_name, self.xchg = "rccl", None
 
     # ---- parameters ------------------------------------------------------------------------------------------
@@ -322,8 +327,20 @@ class HirlEngine:
     def replica_checksum(self):
         """int64 sum of the bit patterns of every network and Adam moment: equal on all ranks of a sharded run, or the replicas have
         diverged (Adam and Polyak see identical inputs on every rank).  Synchronises."""
+        if self.xchg is not None:
+            self.xchg.check()  # a timed-out / poisoned one-shot exchange since the last check raises here
         t = torch.cat([self.actor, self.target_actor, self.critic, self.target_critic, self.m_actor, self.v_actor, self.m_critic, self.v_critic])
         return int(t.view(torch.int32).to(torch.int64).sum().item())
+
+    def close(self):
+        """Release the one-shot exchange's peer mappings; raises if an exchange failed since the last check."""
+        if self.xchg is not None:
+            x, self.xchg = self.xchg, None
+            self.nets.xchg_status = None
+            try:
+                x.check()
+            finally:
+                x.close()
 
     def state_dicts(self):
         return {"actor": unpack(self.actor, ACTOR_LAYOUT), "critic": unpack(self.critic, CRITIC_LAYOUT),
@@ -386,12 +403,13 @@ class HirlEngine:
         if self.world <= 1:
             return
         self.xchg = OneShotExchange({"critic": CRITIC_SIZE, "actor": self.actor_msg.numel()}, self.device, self.group, timeout_ms)
+        self.nets.xchg_status = self.xchg.status_ptr  # a failed exchange freezes the optimizer steps (fail-stop), check() raises
         self.exchange_name = "oneshot"
 
     def _allreduce(self, t, kind=None):
         """SUM over the ranks of `t` (a gradient message).  RCCL: in place.  One-shot: `t` is this rank's message buffer of `kind`, the
         sum arrives in a separate local tensor (peers are still reading `t`).  -> the tensor that holds the sum"""
-        if self.world <= 1:
+        if self.world <= 1 and not (self.sharded_sequence and torch.distributed.is_available() and torch.distributed.is_initialized()):
             return t
         if self.xchg is not None and kind is not None:
             return self.xchg.allreduce(kind)
@@ -439,6 +457,12 @@ class HirlEngine:
         B = self.batch
         st = _lib.stream_ptr()
         pending, self._pending = self._pending, None
+        if pending is not None and before_exchange is not None and getattr(before_exchange, "__self__", None) is not None \
+                and getattr(before_exchange.__self__, "_armed", None) is not None:
+            # a deferred draw reads *total and the ring INSIDE learn()'s first launch; an env step released beside that launch inserts into the
+            # ring and moves *total under it (workgroups would disagree about the live length).  Draw first, then overlap.
+            raise _lib.HxError("sample(defer=True) cannot be combined with an armed VectorStepPipeline: use sample(defer=False) when the "
+                               "next env step may run beside learn()")
         if pending is not None and noise is not None:
             raise _lib.HxError("learn(noise=...) after sample(defer=True): the deferred draw produces the smoothing noise itself")
         noise = self._noise if noise is None else noise
@@ -478,7 +502,9 @@ class HirlEngine:
             self.nets.grad_critic = own_critic
             if actor_phase:
                 _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, int(w_kind == 1), 1, st)
-                if self.world > 1:   # [dL_rl | dL_bc | count] in one message, w formed from the global count after the exchange
+                if self.world > 1 or self.sharded_sequence:   # [dL_rl | dL_bc | count] in one message, w formed from the global count after the exchange
+                    if self.actor_msg is None:
+                        self.actor_msg = torch.zeros(int(_lib.load().hx_actor_message_floats()), dtype=torch.float32, device=self.device)
                     msg = self.xchg.write_buffer("actor") if self.xchg is not None else self.actor_msg
                     _lib.call("hx_hirl_actor_wgrad_split", nets, hyper, B, msg.data_ptr(), st)
                     summed = self._allreduce(msg, "actor")

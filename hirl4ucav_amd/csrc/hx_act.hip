@@ -3,6 +3,8 @@
 //   Agent.chooseAction / chooseActionSmallNoise / chooseActionNoNoise   hirl/agents/HIRL.py:192-212   (U5)  -> hx_actor_act*
 //   chooseAction + HarfangEnv.step                                      hirl/train_all.py:343-345           -> hx_actor_act_step*
 //   SacAgent.explore / exploit                                          hirl/agents/SAC/agent.py:183-196    -> hx_sac_act*
+#include <hip/hip_ext.h>
+
 #include "hx_update.h"
 #include "hx_env_dev.h"
 
@@ -518,6 +520,15 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 // the ~8 us tail, and the env kernel on its own (thousands of envs per launch, 10-14 us) is the cheaper way.
 constexpr int64_t kFuseEnvMax = 8192;
 
+// ENV launches carry HxStepOpts: with ev_start / ev_stop set the launch is stamped with the kernel's own begin / end (bench.py's live
+// roofline of the act + env launch, as hx_env_step does for the env kernel)
+template <typename K>
+static void launch_act_k(K kernel, dim3 grid, const ActFusedArgs& H, hipStream_t st) {
+    if (H.state && H.o.ev_start && H.o.ev_stop)
+        hipExtLaunchKernelGGL(kernel, grid, dim3(kWide), 0, st, (hipEvent_t)H.o.ev_start, (hipEvent_t)H.o.ev_stop, 0, H);
+    else
+        hipLaunchKernelGGL(kernel, grid, dim3(kWide), 0, st, H);
+}
 template <bool GAUSS, bool BF16, bool RELU, bool F32I = false>
 static void launch_act_t(const ActFusedArgs& H, hipStream_t st) {
     const bool env = H.state != nullptr;
@@ -527,12 +538,12 @@ static void launch_act_t(const ActFusedArgs& H, hipStream_t st) {
     static const int nrt2_bf16 = getenv("HX_ACT_BF16_NRT2_ROWS") ? atoi(getenv("HX_ACT_BF16_NRT2_ROWS")) : 8192;  // tuning knob
     if (H.rows >= (BF16 ? nrt2_bf16 : 8192)) {
         const dim3 grid((unsigned)((H.rows + 2 * RT - 1) / (2 * RT)));
-        if (env) hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, true, BF16, RELU, F32I>), grid, dim3(kWide), 0, st, H);
-        else hipLaunchKernelGGL((act_fused_kernel<2, GAUSS, false, BF16, RELU, F32I>), grid, dim3(kWide), 0, st, H);
+        if (env) launch_act_k(act_fused_kernel<2, GAUSS, true, BF16, RELU, F32I>, grid, H, st);
+        else launch_act_k(act_fused_kernel<2, GAUSS, false, BF16, RELU, F32I>, grid, H, st);
     } else {
         const dim3 grid((unsigned)((H.rows + RT - 1) / RT));
-        if (env) hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, true, BF16, RELU, F32I>), grid, dim3(kWide), 0, st, H);
-        else hipLaunchKernelGGL((act_fused_kernel<1, GAUSS, false, BF16, RELU, F32I>), grid, dim3(kWide), 0, st, H);
+        if (env) launch_act_k(act_fused_kernel<1, GAUSS, true, BF16, RELU, F32I>, grid, H, st);
+        else launch_act_k(act_fused_kernel<1, GAUSS, false, BF16, RELU, F32I>, grid, H, st);
     }
 }
 template <bool GAUSS>

@@ -574,6 +574,7 @@ struct AdamArgs {
     // soft count; the step uses g = w g2 + (1 - w) g with w from the GLOBAL count.  nullptr: g is the finished gradient.
     const float* g2;
     const float* countf;
+    const uint32_t* guard;  // nullptr, or a word that must be 0 for the step to happen (HxNets.xchg_status: a failed exchange)
 };
 
 constexpr size_t kSlotFloats = XP + H1 + 2 + H1 + H2 + 2 + OW + H2 + H1 + OW + 2 * kColWgB;  // per row

@@ -516,6 +516,7 @@ __device__ __forceinline__ float adam_w(const AdamArgs& A) {
 }
 
 __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
+    if (A.guard && __hip_atomic_load(A.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;  // failed exchange: fail-stop
     if (A.alpha_state && blockIdx.x == 0 && threadIdx.x == 0) {
         const float mean_h = A.losses[4];
         float la = A.alpha_state[0], m = A.alpha_state[1], v = A.alpha_state[2];
@@ -713,6 +714,7 @@ static int adam_impl(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t 
             A.seg_tgt_w2b[0] = im + IM_TA * kImgElems;
         }
     }
+    A.guard = N->xchg_status;
     if (msg) {  // merged actor message: [dL_rl | dL_bc | count ...]
         HX_REQUIRE(which == 1 && (reinterpret_cast<uintptr_t>(msg) & 15u) == 0, "hx_adam_mixed: actor step only, 16-byte aligned message");
         A.g = msg;

@@ -11,7 +11,13 @@
 // reads, the kernel executes a system-scope acquire (L1 + non-local L2 lines are invalidated).  Messages are double-buffered by epoch
 // parity: a rank overwrites buffer (e & 1) at epoch e + 2 only after it has seen every peer's flag reach e + 1, i.e. after every peer
 // finished reading epoch e — one flag per rank is enough, no "done reading" round.
-// Every spin is bounded: on a timeout the kernel raises status[0] and carries on, the host checks hx_xchg_status().
+// Failure is STICKY and GLOBAL (fail-stop).  Every wait is bounded by the device's constant 100 MHz clock; a rank whose wait times out sets
+// its status word, writes HX_XCHG_POISON into its OWN flag — every peer that polls that flag, now or at any later epoch, fails too instead
+// of waiting or summing — and returns without touching dst.  Once the status word is set every later exchange on that rank returns at once
+// (re-poisoning its flag), and the optimizer steps that would consume the sum are skipped (HxNets.xchg_status: hx_adam / hx_adam_mixed
+// leave parameters, moments, targets and images alone).  The host raises at its next check (OneShotExchange.check: every replica-checksum
+// cadence and at close).  EXPERIMENTAL: exercised with ranks sharing one GPU only; the cross-device visibility argument above has not
+// run on two physical GPUs.
 #include <cstring>
 
 #include <cstdlib>
@@ -31,32 +37,38 @@ struct OneShotArgs {
     int world, rank;
     long long n;       // floats, multiple of 4
     unsigned epoch;
-    long long spin_limit;
+    unsigned long long timeout_ticks;  // s_memrealtime ticks (10 ns)
 };
+constexpr unsigned kPoison = 0xFFFFFFFFu;  // a flag value no epoch takes (hx_allreduce_oneshot refuses it)
 
 __global__ __launch_bounds__(kThreads) void oneshot_allreduce_kernel(OneShotArgs A) {
-    __shared__ int s_timeout;
-    if (threadIdx.x == 0) s_timeout = 0;
-    // 1. announce (one lane of the grid): the message was written by kernels that completed before this one started
+    __shared__ int s_fail;
+    if (threadIdx.x == 0) s_fail = __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u ? 1 : 0;  // sticky
+    __syncthreads();
+    // 1. announce (one lane of the grid): the message was written by kernels that completed before this one started.  A rank that has
+    //    already failed announces POISON instead: its peers must not wait for it, nor sum what it holds.
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         __threadfence_system();
-        __hip_atomic_store(A.flag[A.rank], A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.flag[A.rank], s_fail ? kPoison : A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __syncthreads();
+    if (s_fail) return;
     // 2. wait for every peer (one polling lane per peer and workgroup; epochs only grow: signed distance handles the wrap)
     if ((int)threadIdx.x < A.world && (int)threadIdx.x != A.rank) {
-        long long spins = 0;
-        while ((int)(__hip_atomic_load(A.flag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - A.epoch) < 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            const unsigned v = __hip_atomic_load(A.flag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v == kPoison) { s_fail = 2; break; }           // the peer failed: so do we
+            if ((int)(v - A.epoch) >= 0) break;
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > A.spin_limit) {
-                s_timeout = 1;
-                break;
-            }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > A.timeout_ticks) { s_fail = 1; break; }
         }
     }
     __syncthreads();
-    if (s_timeout) {
-        if (threadIdx.x == 0) atomicExch(A.status, 1u);
+    if (s_fail) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(A.status, (unsigned)s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(A.flag[A.rank], kPoison, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
     // system-scope acquire: peers' messages are read fresh.  ONE wave per workgroup executes it (the invalidate covers the CU's caches and
@@ -118,8 +130,10 @@ int hx_ipc_close(void* dev_ptr) {
 
 /* dst[i] = sum over ranks r = 0..world-1 (in that order) of bufs[r][i], i < n (n a multiple of 4; all pointers 16-byte aligned).
  * bufs / flags: HOST arrays of `world` device pointers (own memory at index `rank`, peers' hipIpc mappings elsewhere); status: a device
- * word that becomes non-zero if a peer did not arrive within `timeout_ms` (then dst is undefined); epoch: this exchange's number,
- * increasing by 1 per call on every rank (each rank's flag word must start at 0, the first epoch is 1). */
+ * word (fine-grained memory, starts at 0) that becomes 1 if a peer did not arrive within `timeout_ms`, 2 if a peer reported failure; it is
+ * STICKY: from then on dst is left untouched, this rank's flag carries a poison value that fails every peer too, and every later call
+ * returns at once (pass the word as HxNets.xchg_status and the optimizer steps are skipped as well).  epoch: this exchange's number,
+ * increasing by 1 per call on every rank (each rank's flag word must start at 0, the first epoch is 1; 0xFFFFFFFF is reserved). */
 int hx_allreduce_oneshot(float* dst, const float* const* bufs, uint32_t* const* flags, uint32_t* status, int32_t world, int32_t rank,
                          int64_t n, uint32_t epoch, int32_t timeout_ms, void* stream) {
     HX_REQUIRE(dst && bufs && flags && status && world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world && n > 0 && n % 4 == 0,
@@ -131,9 +145,11 @@ int hx_allreduce_oneshot(float* dst, const float* const* bufs, uint32_t* const* 
         A.buf[r] = bufs[r];
         A.flag[r] = flags[r];
     }
-    A.spin_limit = (long long)(timeout_ms > 0 ? timeout_ms : 2000) * 2000;  // s_sleep 8 ~ 0.5 us per poll
+    HX_REQUIRE(epoch != kPoison, "hx_allreduce_oneshot: epoch 0xFFFFFFFF is reserved");
+    A.timeout_ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 2000) * 100000ull;  // the 100 MHz constant clock
     const long long n4 = n / 4;
-    static const int max_blocks = getenv("HX_ONESHOT_BLOCKS") ? atoi(getenv("HX_ONESHOT_BLOCKS")) : 256;  // tuning knob
+    static const int env_blocks = getenv("HX_ONESHOT_BLOCKS") ? atoi(getenv("HX_ONESHOT_BLOCKS")) : 256;  // tuning knob
+    const int max_blocks = env_blocks < 1 ? 1 : env_blocks;
     const int blocks = (int)((n4 + kThreads - 1) / kThreads < max_blocks ? (n4 + kThreads - 1) / kThreads : max_blocks);
     hipLaunchKernelGGL(oneshot_allreduce_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, A);
     HX_CHECK_LAUNCH("hx_allreduce_oneshot");

@@ -34,9 +34,14 @@ class VectorStepPipeline:
             return
         fn()
 
-    def arm(self, fn, acting_net_untouched):
+    def arm(self, fn, acting_net_untouched, engine=None):
         """Call between sample() and learn(): if the coming learn() leaves the acting network alone, the NEXT step's act + env.step
-        may go out on the side stream — when fire() says so."""
+        may go out on the side stream — when fire() says so.  engine: the agent engine whose learn() follows; a draw it DEFERRED into
+        that learn() (sample(defer=True)) reads the ring and its row count inside learn()'s first launch, which an env step running
+        beside it would change under its workgroups — refused here."""
+        if engine is not None and self.overlap and acting_net_untouched and getattr(engine, "_pending", None) is not None:
+            raise RuntimeError("VectorStepPipeline.arm: the engine holds a deferred minibatch draw (sample(defer=True)); draw with defer=False "
+                               "when the next env step may overlap learn()")
         self._armed = fn if (self.overlap and acting_net_untouched) else None
 
     def fire(self):

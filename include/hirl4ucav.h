@@ -203,6 +203,8 @@ typedef struct HxNets {
     uint16_t* w2_bf16_all;   /* NULL: the update computes in fp32 (parity 1e-5 vs the reference).  Else hx_bf16_images_elems() bf16 elements =
                                 the bf16 images of every W2 the update reads: the bf16 UPDATE path (below).  Its first 512 x 256 elements are
                                 the actor's image in the bf16 acting kernels' format: actor_w2_bf16 must then be NULL or point at them */
+    const uint32_t* xchg_status; /* NULL, or the status word of hx_allreduce_oneshot: while it is non-zero (an exchange failed: the summed
+                                gradient is garbage) hx_adam / hx_adam_mixed change nothing — no parameter, moment, target or image */
 } HxNets;
 
 /* bf16 update path (BASELINE.json configs[4] "bf16 actor/critic + fp32 dynamics"; SURVEY.md 7 "bf16 config").  With HxNets.w2_bf16_all set,
@@ -372,7 +374,8 @@ int hx_ipc_import(const void* handle64 /* host */, void** dev_ptr);
 int hx_ipc_close(void* dev_ptr);
 /* dst[i] = bufs[0][i] + bufs[1][i] + ... (rank order: bit-identical on every rank), n floats (multiple of 4).  bufs / flags: host arrays of
  * `world` (<= 8) device pointers, own memory at index `rank`; every rank calls with the same epoch = 1, 2, 3, ...; messages are
- * double-buffered by the CALLER (epoch parity), see hx_xchg.hip.  *status != 0 afterwards: a peer did not arrive within timeout_ms. */
+ * double-buffered by the CALLER (epoch parity), see hx_xchg.hip.  *status != 0 afterwards: a peer did not arrive within timeout_ms (1) or
+ * reported failure (2) — sticky and global (fail-stop): see hx_xchg.hip.  EXPERIMENTAL until it has run on two physical GPUs. */
 int hx_allreduce_oneshot(float* dst, const float* const* bufs, uint32_t* const* flags, uint32_t* status, int32_t world, int32_t rank,
                          int64_t n, uint32_t epoch, int32_t timeout_ms, void* stream);
 

@@ -47,7 +47,7 @@ def main(exchange):
         print("SHARDED_OK", e.exchange_name, flush=True)
     if e.xchg is not None:
         torch.distributed.barrier()
-        e.xchg.close()
+        e.close()  # checks the status word once more, then releases the peer mappings
     torch.distributed.destroy_process_group()
 
 

@@ -29,3 +29,18 @@ def test_cpu_baseline_legs_run_without_a_gpu():
     assert port["kind"] == "port" and port["value"] > 0
     b1 = bench.baseline_batched_cpu(0.5)
     assert b1["value"] > port["value"]
+    sac = bench.baseline_port_sac(bench.parse(["--agent", "sac", "--envs", "512", "--scenario", "serpentine"]), 1.0)
+    assert sac["kind"] == "port" and sac["value"] > 0 and "SAC" in sac["sample"]
+
+
+def test_workload_label_names_a_baseline_config_only_when_the_arguments_match():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert "configs[1]" in bench.workload_label(bench.parse([]))
+    assert "configs[" not in bench.workload_label(bench.parse(["--envs", "2048"]))
+    assert "configs[" not in bench.workload_label(bench.parse(["--actions", "uniform"]))
+    assert "configs[3]" in bench.workload_label(bench.parse(["--envs", "8192", "--scenario", "circular", "--type", "linear"]))
+    assert "configs[4]" in bench.workload_label(bench.parse(["--envs", "16384", "--scenario", "mixed", "--dtype", "bf16"]))
+    assert "configs[4]" not in bench.workload_label(bench.parse(["--envs", "16384", "--scenario", "mixed", "--dtype", "bf16_policy"]))
+    assert "configs[2]" in bench.workload_label(bench.parse(["--agent", "sac", "--envs", "16384", "--scenario", "serpentine"]))

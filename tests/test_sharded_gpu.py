@@ -57,3 +57,66 @@ def test_two_rank_update_equals_the_global_batch_update(exchange, tmp_path):
         assert (d <= 2e-5).mean() >= 0.999 and d.max() <= 1.2e-2, (k, (d <= 2e-5).mean(), d.max())
     # (rank 0's logged loss values are its own shard's means; only the weight is a global quantity)
     assert abs(got["losses"][5] - ref_losses[5]) < 1e-6  # the BC weight comes from the GLOBAL soft count: equal to the single engine's
+
+
+def test_oneshot_exchange_fails_stop():
+    """A peer that never arrives: the waiting rank's status word becomes 1 within the timeout and STAYS set, dst is untouched, its own flag
+    carries the poison value, every later exchange returns at once, the optimizer steps guarded by the word change nothing — and a rank
+    that polls the poisoned flag fails too (status 2) instead of waiting or summing (hx_xchg.hip "fail-stop")."""
+    import ctypes
+    import time
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from hirl4ucav_amd import _lib
+    from hirl4ucav_amd.agents import engine as E
+
+    _lib.load()
+    vp = ctypes.c_void_p
+    n = 1024
+
+    def words(ptr, k):
+        return torch.as_tensor(E._DeviceWords(ptr, k), device="cuda").view(torch.int32)
+
+    flag_mem, stat_mem = vp(), vp()
+    _lib.call("hx_ipc_alloc", 256, 1, ctypes.byref(flag_mem))  # word 0: rank 0's flag, word 16: rank 1's flag
+    _lib.call("hx_ipc_alloc", 256, 1, ctypes.byref(stat_mem))  # word 0: rank 0's status, word 16: rank 1's
+    msg = torch.ones(2 * n, dtype=torch.float32, device="cuda")
+    dst = torch.full((n,), -7.0, dtype=torch.float32, device="cuda")
+    bufs = (vp * 2)(msg.data_ptr(), msg.data_ptr() + 4 * n)
+    flags = (vp * 2)(flag_mem.value, flag_mem.value + 64)
+    # rank 0 waits for rank 1, which never announces
+    t0 = time.perf_counter()
+    _lib.call("hx_allreduce_oneshot", dst.data_ptr(), bufs, flags, stat_mem.value, 2, 0, n, 1, 200, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert 0.15 < time.perf_counter() - t0 < 5.0  # bounded by the device clock, not by a spin count
+    assert int(words(stat_mem.value, 1)[0]) == 1 and torch.all(dst == -7.0)
+    assert int(words(flag_mem.value, 1)[0]) == -1  # 0xFFFFFFFF: poison
+    # sticky: the next exchange returns at once and leaves dst alone, whatever the peer does meanwhile
+    words(flag_mem.value + 64, 1)[0] = 2
+    t0 = time.perf_counter()
+    _lib.call("hx_allreduce_oneshot", dst.data_ptr(), bufs, flags, stat_mem.value, 2, 0, n, 2, 200, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.1 and int(words(stat_mem.value, 1)[0]) == 1 and torch.all(dst == -7.0)
+    # global: rank 1 polls rank 0's poisoned flag and fails with status 2
+    dst1 = torch.full((n,), -7.0, dtype=torch.float32, device="cuda")
+    _lib.call("hx_allreduce_oneshot", dst1.data_ptr(), bufs, flags, stat_mem.value + 64, 2, 1, n, 2, 200, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert int(words(stat_mem.value + 64, 1)[0]) == 2 and torch.all(dst1 == -7.0)
+    # the optimizer step guarded by the status word changes nothing
+    params = D.make_params(3)
+    e = E.HirlEngine(batch=128)
+    e.load_params(params["actor"], params["critic"], params["bc_actor"])
+    e.grad_critic.fill_(1.0)
+    before = e.critic.clone()
+    e.nets.xchg_status = stat_mem.value
+    _lib.call("hx_adam", ctypes.byref(e.nets), ctypes.byref(e.hyper), 0, 1, 1.0, 0, 0.0, 0.0, 128, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(e.critic, before) and float(e.m_critic.abs().sum()) == 0.0
+    words(stat_mem.value, 1)[0] = 0  # (and with the word cleared the same call steps)
+    _lib.call("hx_adam", ctypes.byref(e.nets), ctypes.byref(e.hyper), 0, 1, 1.0, 0, 0.0, 0.0, 128, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert not torch.equal(e.critic, before)
+    e.nets.xchg_status = None
+    for m in (flag_mem, stat_mem):
+        _lib.call("hx_ipc_free", m)
