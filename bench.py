@@ -244,12 +244,14 @@ class Loop:
                 t("act", lambda: e.act(env.obs, sigma=0.1, seed=1, row0=env.env_id0, out=self.actions))  # actionNoise 0.1, HIRL.py:160
             if stamp is not None:
                 env.time_next_steps(*stamp)
+                self.krec.append(stamp)  # (recorded HERE: with --overlap the pipeline may skip this issue function altogether)
             t("env", lambda: env.step(self.actions))
             if stamp is not None:
                 env.time_next_steps(None, None)
         else:
             if stamp is not None:  # the launch's own begin / end (hipExtLaunchKernelGGL events): up to 8,192 envs that is the fused act + env kernel
                 env.time_next_steps(*stamp)
+                self.krec_fused.append(stamp)
             if self.sac:   # explore + env.step in one launch
                 t("act+env", lambda: e.act_step(env, seed=1, out=self.actions))
             else:          # chooseAction + env.step in one launch (same results, bit for bit: tests/test_hirl_gpu.py)
@@ -299,12 +301,8 @@ class Loop:
             self.rec[name].append((a, b))
 
         stamp = None
-        if split and not self.uniform:
-            stamp = (kpool.pop(), kpool.pop())
-            self.krec.append(stamp)
-        elif not split and not self.uniform and not self.separate and len(kpool) >= 2:
-            stamp = (kpool.pop(), kpool.pop())
-            self.krec_fused.append(stamp)
+        if not self.uniform and len(kpool) >= 2 and (split or not self.separate):
+            stamp = (kpool.pop(), kpool.pop())  # split: the env launch, else the fused act + env launch (filed by _act_env when it runs)
         act_env = lambda: self._act_env(timed, split, stamp)  # noqa: E731
         self.pipe.act_and_step(act_env)
         timed("learn", lambda: self._learn(act_env))
