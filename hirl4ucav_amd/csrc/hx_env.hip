@@ -56,6 +56,25 @@ __device__ __forceinline__ void tile_copy(float* __restrict__ dst, const float* 
     }
     if (tid < (count & 3)) dst[4 * n4 + tid] = src[4 * n4 + tid];
 }
+typedef float env_v4f __attribute__((ext_vector_type(4)));
+// the same towards global memory with NON-TEMPORAL stores: replay rows and observations are written once and read a step or more later
+// (sweep on MI355X, one box, solo 256: 65,536 envs 11.16 -> 11.0 us, 1M envs 105.4 -> 100.7 us; 4M unchanged; -DHX_ENV_NT=0 builds the plain stores,
+// =2 adds the state words: no further gain)
+template <int THREADS, int FULL>
+__device__ __forceinline__ void tile_copy_out(float* __restrict__ dst, const float* __restrict__ src, int count, int tid) {
+#if !defined(HX_ENV_NT) || HX_ENV_NT >= 1
+    constexpr int TRIPS = (FULL / 4 + THREADS - 1) / THREADS;
+    const int n4 = count >> 2;
+#pragma unroll
+    for (int it = 0; it < TRIPS; ++it) {
+        const int k = tid + it * THREADS;
+        if (k < n4) __builtin_nontemporal_store(reinterpret_cast<const env_v4f*>(src)[k], reinterpret_cast<env_v4f*>(dst) + k);
+    }
+    if (tid < (count & 3)) dst[4 * n4 + tid] = src[4 * n4 + tid];
+#else
+    tile_copy<THREADS, FULL>(dst, src, count, tid);
+#endif
+}
 
 // HarfangEnv.step for EPB envs per workgroup.  PAIR: two adjacent lanes per env (hx_env_dev.h), EPB * 2 threads; else one lane per
 // env.  The row-major observation tile (and with INSERT the replay rows) meet in LDS so that every global access of the
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(EPB*(PAIR ? 2 : 1)) void env_step_kernel(StepArgs A
         }
     }
     __syncthreads();
-    tile_copy<THREADS, kObsTile>(A.obs_io + i0 * HX_OBS_DIM, s_obs, nblk * HX_OBS_DIM, tid);
+    tile_copy_out<THREADS, kObsTile>(A.obs_io + i0 * HX_OBS_DIM, s_obs, nblk * HX_OBS_DIM, tid);
     if (INSERT && nstore > 0) {
         // 16 B per lane, 1 KiB per wave-instruction, rows contiguous in the ring (modulo wrap)
         const unsigned slot0 = s_slot0, cap = (unsigned)A.o.cap;
@@ -207,8 +226,13 @@ __global__ __launch_bounds__(EPB*(PAIR ? 2 : 1)) void env_step_kernel(StepArgs A
             if (k < nstore * (HX_ROW_WORDS / 4)) {
                 const int r = k >> 3, c = (k & 7) * 4;
                 const float* src = s_row + r * kRowPitch + c;
+#if !defined(HX_ENV_NT) || HX_ENV_NT >= 1
+                const env_v4f v = {src[0], src[1], src[2], src[3]};
+                __builtin_nontemporal_store(v, reinterpret_cast<env_v4f*>(ring4) + (size_t)wrap_slot(slot0 + (unsigned)r, cap) * (HX_ROW_WORDS / 4) + (k & 7));
+#else
                 const float4 v = {src[0], src[1], src[2], src[3]};
                 ring4[(size_t)wrap_slot(slot0 + (unsigned)r, cap) * (HX_ROW_WORDS / 4) + (k & 7)] = v;
+#endif
             }
         }
     }
@@ -220,11 +244,13 @@ __global__ __launch_bounds__(EPB*(PAIR ? 2 : 1)) void env_step_kernel(StepArgs A
     }
 }
 
-// Launch shape by size (measured on MI355X, profiles/r02a_env_sweep.jsonl): two lanes per env everywhere (half the dependent chain,
-// ~66 VGPRs instead of ~98); envs per workgroup so that a launch has about 64..256 workgroups while it is latency-bound (4,096
-// envs: 6.4 us with 64 envs per workgroup, 7.6 with 256) and 256 once it is bandwidth-bound (>= 64k envs: one ring-head atomic per 256
-// rows, 6 workgroups per CU).  Up to 256 envs ONE workgroup steps them all, which keeps the replay insert order — and with it a whole
-// training run — reproducible bit for bit.
+// Launch shape by size (measured on MI355X, profiles/r02a_env_sweep_layouts.jsonl, profiles/r03b_env_sweep_layouts.jsonl).  While a launch is
+// latency-bound (< 32,768 envs): two lanes per env (half the dependent chain, ~66 VGPRs instead of ~98) and envs per workgroup so that it has
+// about 64..256 workgroups (4,096 envs: 6.4 us with 64 envs per workgroup, 7.6 with 256).  From 32,768 envs on the chip is full and the launch
+// is bound by memory requests and by the ring-head atomic — ONE per workgroup, all on one address, ~12 ns each: 256 envs per workgroup — and
+// ONE lane per env issues half the wave-instructions per byte: solo 256 beats pair 256 at 32,768 (8.8 vs 9.4 us), 65,536 (11.0 vs 11.6),
+// 1M (100.7 vs 108.8) and 4M (378-396 vs 387-391); only 262,144 measured the other way (32.2 vs 29.7).  Up to 256 envs ONE workgroup steps them
+// all, which keeps the replay insert order — and with it a whole training run — reproducible bit for bit.
 struct Layout {
     bool pair;
     int epb;
@@ -233,8 +259,8 @@ inline Layout pick_layout(int64_t n, int32_t forced) {
     if (forced) return Layout{(forced >> 8) != 0, (forced & 0xFF) * 4};
     if (n <= 256) return Layout{true, 256};
     if (n <= 8192) return Layout{true, 64};
-    if (n <= 32768) return Layout{true, 128};
-    return Layout{true, 256};
+    if (n < 32768) return Layout{true, 128};
+    return Layout{false, 256};
 }
 
 template <bool PAIR, bool INSERT, int EPB>

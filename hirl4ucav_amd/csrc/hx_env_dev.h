@@ -206,7 +206,11 @@ struct WCursor {
     __device__ __forceinline__ WCursor(float* base, int64_t stride, uint32_t index)
         : p(reinterpret_cast<char*>(base)), stride_b(stride * 4), off(index * 4u) {}
     __device__ __forceinline__ void put(float v) {
+#if defined(HX_ENV_NT) && HX_ENV_NT >= 2
+        __builtin_nontemporal_store(v, reinterpret_cast<float*>(p + off));
+#else
         *reinterpret_cast<float*>(p + off) = v;
+#endif
         p += stride_b;
     }
     __device__ __forceinline__ void skip(int words) { p += stride_b * words; }

@@ -8,12 +8,6 @@
 using namespace hxnn;
 using namespace hxu;
 
-namespace {
-__global__ void count_to_float_kernel(const int* count, float* out) {
-    if (threadIdx.x == 0) out[0] = count ? (float)*count : 0.0f;
-}
-}  // namespace
-
 extern "C" {
 
 int hx_actor_param_count(void) { return kActor.size(); }
@@ -293,8 +287,9 @@ int hx_hirl_actor_wgrad_split(const HxNets* N, const HxHyper* Hy, int32_t batch,
         J.ws[0] = s[j == 0 ? S_API : S_ABC]; J.rows[0] = batch; J.wmode[0] = 0; J.nslots = 1;
     }
     W.bf16 = N->w2_bf16_all != nullptr;
+    W.soft_count = bc ? N->soft_count : nullptr;
+    W.count_out = msg + 2 * kActor.padded();  // the message's count word, written by the same launch (was a launch of its own: 3.8 us)
     launch_wg(W, false, (hipStream_t)stream);
-    hipLaunchKernelGGL(count_to_float_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, bc ? N->soft_count : nullptr, msg + 2 * kActor.padded());
     HX_CHECK_LAUNCH("hx_hirl_actor_wgrad_split");
     return 0;
 }

@@ -522,6 +522,7 @@ struct WgArgs {
     const int* soft_count;
     const float* wstate;
     int bf16;  // dW2 = dz2^T h1 with both operands rounded to bf16 (fp32 accumulate): the bf16 update path
+    float* count_out;  // nullptr, or where thread 0 of the launch leaves (float)*soft_count: the merged actor message's count word
 };
 
 // torch.optim.Adam (defaults) on one element, and soft_update.  Contraction is OFF in these two: HIP's __fmul_rn / __fsub_rn are plain

@@ -24,8 +24,9 @@ struct WgJobC {
     uint32_t pad_;
     const int* soft_count; float* wstate; float* losses;
     uint16_t* w2tb; uint16_t* tgt_w2b;  // bf16 update path: the transposed image of W2 and the image of the target's W2
+    float* count_out;                    // job 0 only: (float)*soft_count goes here (the merged actor message of a sharded run)
 };
-static_assert(sizeof(WgJobC) == 168, "WgJobC layout");
+static_assert(sizeof(WgJobC) == 176, "WgJobC layout");
 struct WgArgsC {
     WgJobC job[2];
 };
@@ -98,6 +99,7 @@ __device__ __forceinline__ void expand_wg(const WgJobC& c, WgJob& J, WgArgs& A) 
     A.ad.b1 = c.b1; A.ad.b2 = c.b2; A.ad.eps = c.eps; A.ad.step_size = c.step_size; A.ad.bc2_sqrt = c.bc2_sqrt; A.ad.tau = c.tau;
     A.ad.finish_actor = (int)((c.cfg >> 18) & 1u); A.ad.use_bc = (int)((c.cfg >> 19) & 1u);
     A.ad.losses = c.losses; A.ad.wstate = c.wstate;
+    A.count_out = c.count_out;
 }
 inline WgJobC pack_wg(const WgJob& J, const WgArgs& A) {
     WgJobC c{};
@@ -108,7 +110,7 @@ inline WgJobC pack_wg(const WgJob& J, const WgArgs& A) {
     c.rows0 = J.rows[0]; c.rows1 = J.nslots > 1 ? J.rows[1] : J.rows[0];
     c.slope = A.slope; c.w_given = A.w_given; c.warm = A.warm; c.inv_batch = A.inv_batch;
     c.b1 = A.ad.b1; c.b2 = A.ad.b2; c.eps = A.ad.eps; c.step_size = A.ad.step_size; c.bc2_sqrt = A.ad.bc2_sqrt; c.tau = A.ad.tau;
-    c.soft_count = A.soft_count; c.wstate = const_cast<float*>(A.wstate); c.losses = A.ad.losses;
+    c.soft_count = A.soft_count; c.wstate = const_cast<float*>(A.wstate); c.losses = A.ad.losses; c.count_out = A.count_out;
     return c;
 }
 
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
     asm volatile("" ::"v"(w));
     STAMP();
 #endif
+    if (A.count_out && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *A.count_out = A.soft_count ? (float)*A.soft_count : 0.0f;
     if (ADAM && A.ad.finish_actor && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {  // what adam_kernel's thread 0 does on an actor step
         if (A.ad.use_bc) {
             A.ad.losses[1] = A.ad.losses[2] * w + A.ad.losses[3] * (1.0f - w);  // HIRL.py:321
