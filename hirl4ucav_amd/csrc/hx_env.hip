@@ -391,6 +391,21 @@ __global__ __launch_bounds__(kBlock) void label_kernel(const float* __restrict__
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
+// Everything the N = 1 facade reads back after a step, packed into ONE 64-float row (one D2H copy instead of five): words 0..36 the state
+// words of env i, 37..49 its observation, 50 reward, 51 done, 52 success.
+__global__ void env_pack_row_kernel(const float* __restrict__ state, int64_t stride, int64_t i, const float* __restrict__ obs,
+                                    const float* __restrict__ reward, const uint8_t* __restrict__ done, const int8_t* __restrict__ success,
+                                    float* __restrict__ out) {
+    const int t = threadIdx.x;
+    float v = 0.0f;
+    if (t < HX_ENV_WORDS) v = state[(int64_t)t * stride + i];
+    else if (t < HX_ENV_WORDS + HX_OBS_DIM) v = obs[i * HX_OBS_DIM + (t - HX_ENV_WORDS)];
+    else if (t == 50) v = reward[i];
+    else if (t == 51) v = (float)done[i];
+    else if (t == 52) v = (float)success[i];
+    out[t] = v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -447,6 +462,14 @@ int hx_sim_readback(const float* state, int64_t n, int64_t stride, float* out, v
     HX_REQUIRE(state && out && n > 0 && stride >= n, "hx_sim_readback: bad arguments");
     hipLaunchKernelGGL(sim_readback_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, (hipStream_t)stream, state, n, stride, out);
     HX_CHECK_LAUNCH("hx_sim_readback");
+    return 0;
+}
+
+int hx_env_pack_row(const float* state, int64_t n, int64_t stride, int64_t i, const float* obs, const float* reward, const uint8_t* done,
+                    const int8_t* success, float* out, void* stream) {
+    HX_REQUIRE(state && obs && reward && done && success && out && n > 0 && stride >= n && i >= 0 && i < n, "hx_env_pack_row: bad arguments");
+    hipLaunchKernelGGL(env_pack_row_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, stride, i, obs, reward, done, success, out);
+    HX_CHECK_LAUNCH("hx_env_pack_row");
     return 0;
 }
 

@@ -5,6 +5,7 @@ the batched HIP env-step kernel (one env resident on the GPU) instead of a Harfa
 For throughput use BatchedHarfangEnv (environments/batched.py); this façade exists so that the reference's drivers
 (train_all.py, validate_all.py) and data tools keep working call for call.
 """
+import ctypes
 import inspect
 import os
 import random
@@ -54,15 +55,32 @@ class HarfangEnv:
         # makes runs repeatable: the Philox key is taken from it once
         self._env = BatchedHarfangEnv(1, scenario=self._scenario, seed=random.getrandbits(63), auto_reset=False,
                                       random_reset=False, collect_stats=False)
-        self._action = torch.zeros((1, 4), dtype=torch.float32, device=self._env.device)
+        # host <-> device traffic of a step: the kernels read the action from, and hx_env_pack_row writes the read-back row (state words,
+        # observation, reward, done, success: 64 floats) into, PINNED HOST memory the device maps — no copy calls, one synchronisation
+        self._h_action = torch.zeros((1, 4), dtype=torch.float32).pin_memory()
+        self._h_row = torch.zeros(64, dtype=torch.float32).pin_memory()
+        self._np_action, self._np_row = self._h_action.numpy(), self._h_row.numpy()
+        self._stream_sync = torch.cuda.current_stream(self._env.device).synchronize
+        _lib.register("hx_env_pack_row", [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
         self.state = None
 
     # ---- helpers ------------------------------------------------------------------------------------------------
-    def _pull(self):
-        st = self._env.state[:, 0].cpu().numpy()
+    def _readback(self):
+        """-> (state words [37], obs [13] float64, reward, success) of the one env, through the packed row"""
+        e = self._env
+        _lib.call("hx_env_pack_row", e.state.data_ptr(), 1, 1, 0, e.obs.data_ptr(), e.reward.data_ptr(), e.done.data_ptr(), e.success.data_ptr(),
+                  self._h_row.data_ptr(), _lib.stream_ptr())
+        self._stream_sync()
+        row = self._np_row
+        return row[0:37].copy(), row[37:50].astype(np.float64), float(row[50]), int(row[52])
+
+    def _pull(self, st=None):
+        if st is None:
+            st = self._env.state[:, 0].cpu().numpy()
         flags = int(st.view(np.uint32)[35])
-        self.Aircraft_Loc = [float(v) for v in st[0:3]]
-        self.Oppo_Loc = [float(v) for v in st[13:16]]
+        self.Aircraft_Loc = st[0:3].tolist()
+        self.Oppo_Loc = st[13:16].tolist()
         self.Plane_Irtifa = self.Aircraft_Loc[1]
         self.Ally_target_locked = bool(flags & _lib.F_LOCKED_PREV)
         self.n_Ally_target_locked = bool(flags & _lib.F_LOCKED)
@@ -79,9 +97,9 @@ class HarfangEnv:
     def _do_reset(self, randomize):
         self._env.random_reset = bool(randomize)
         self._env.episode_ctr += 1  # a fresh Philox counter per episode
-        obs = self._env.reset()
-        o = obs[0].cpu().numpy().astype(np.float64)
-        self._pull()
+        self._env.reset()
+        st, o, _, _ = self._readback()
+        self._pull(st)
         self.target_angle = float(o[6])
         self.success = 0
         self.state = o
@@ -95,12 +113,10 @@ class HarfangEnv:
         return self._do_reset(True)
 
     def _step(self, action):
-        self._action[0] = torch.as_tensor(np.asarray([float(action[0]), float(action[1]), float(action[2]), float(action[3])], np.float32))
-        obs, r, d, s = self._env.step(self._action)
-        o = obs[0].cpu().numpy().astype(np.float64)
-        self.reward = float(r.item())
-        self.success = int(s.item())
-        self._pull()
+        self._np_action[0] = (float(action[0]), float(action[1]), float(action[2]), float(action[3]))
+        self._env.step_from(self._h_action.data_ptr())  # (pinned host memory: the env kernel reads its 16 bytes over the host link)
+        st, o, self.reward, self.success = self._readback()
+        self._pull(st)
         self.target_angle = float(o[6])
         self.state = o
         return o
@@ -114,11 +130,11 @@ class HarfangEnv:
         return (n_state, self.reward, self.done, {}, self.now_missile_state, self.missile1_state, self.n_missile1_state,
                 self.Ally_target_locked, self.success)
 
-    def get_pos(self):  # :270-274
-        return self._env.state[0:3, 0].cpu().numpy().astype(np.float64)
+    def get_pos(self):  # :270-274  (the positions the last read-back cached: no device access)
+        return np.asarray(self.Aircraft_Loc, np.float64)
 
     def get_oppo_pos(self):  # :276-280
-        return self._env.state[13:16, 0].cpu().numpy().astype(np.float64)
+        return np.asarray(self.Oppo_Loc, np.float64)
 
     def save_parameters_to_txt(self, log_dir):  # :282-295 (dumps the source of the reward / reset / termination rules)
         with open(os.path.join(log_dir, "log2.txt"), "w") as f:

@@ -73,6 +73,14 @@ class BatchedHarfangEnv:
                   _lib.stream_ptr())
         return self.obs, self.reward, self.done, self.success
 
+    def step_from(self, actions_ptr):
+        """step() with the actions at a raw address the DEVICE can read — device memory, or pinned host memory it maps (the N = 1 facade
+        passes its pinned action buffer: no upload call)."""
+        _lib.call("hx_env_step", _lib.ptr(self.state), self.n, self.n, actions_ptr, _lib.ptr(self.obs),
+                  _lib.ptr(self.reward), _lib.ptr(self.done), _lib.ptr(self.success), ctypes.byref(self._opts),
+                  _lib.stream_ptr())
+        return self.obs, self.reward, self.done, self.success
+
     def time_next_steps(self, start=None, stop=None):
         """Measurement: hx_event_create() handles that the following step launches stamp with the kernel's own begin / end
         (None, None switches it off).  Read with hx_event_elapsed_us after a synchronise."""

@@ -244,10 +244,17 @@ def main(config):
         torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
     # no --seed: rank 0 draws one and every rank uses it (the replicas must start from identical networks either way); it is printed
     # and written to log1.txt, so that "unseeded" differs from --seed 0 and is still reproducible after the fact
-    seed = shared_value(config.seed if config.seed is not None else int.from_bytes(os.urandom(4), "little") & 0x7FFFFFFF, world)
+    # --resume: the run's seed comes from the snapshot (the Philox keys of acting noise, sampling and random_reset must not change mid-run);
+    # an explicit --seed that differs is an error
+    snap = CK.read_run(os.path.join(config.resume, f"state_rank{rank}.pt")) if config.resume else None
+    snap_seed = snap["driver"].get("seed") if snap is not None else None
+    if snap_seed is not None and config.seed is not None and int(config.seed) != int(snap_seed):
+        raise SystemExit(f"train_all: --resume {config.resume} was run with seed {snap_seed}, --seed {config.seed} given")
+    seed = shared_value(snap_seed if snap_seed is not None else
+                        (config.seed if config.seed is not None else int.from_bytes(os.urandom(4), "little") & 0x7FFFFFFF), world)
     set_seed(seed + rank)
     if rank == 0:
-        print(f"seed {seed}" + ("" if config.seed is not None else " (drawn: no --seed given)"), flush=True)
+        print(f"seed {seed}" + (" (from the snapshot)" if snap_seed is not None else "" if config.seed is not None else " (drawn: no --seed given)"), flush=True)
     env_type, n = config.env, config.num_envs
     max_step = MAX_STEP[env_type] * (8 if config.render else 1)
     if config.agent == "BC":
@@ -288,8 +295,11 @@ def main(config):
             eng.bc_actor.copy_(E.pack(torch.load(config.bc_actor, map_location="cpu"), E.ACTOR_LAYOUT, E.ACTOR_SIZE, device))
         elif hirl and config.type == "soft" and rank == 0:
             print("WARNING: HIRL-soft without --bc_actor: the soft weight is estimated against a randomly initialised bc_actor", flush=True)
-    if getattr(config, "dtype", "f32") == "bf16" and not sac:
+    dtype = getattr(config, "dtype", "f32")
+    if dtype != "f32" and not sac:  # bf16: actor AND critic (BASELINE.json configs[4]); bf16_policy: policy inference only
         eng.set_act_dtype("bf16")
+        if dtype == "bf16":
+            eng.set_update_dtype("bf16")
 
     # ONE run directory for all ranks: rank 0 names it (a minute boundary between ranks would scatter the state_rank<r>.pt shards)
     log_dir = shared_value(os.path.join(config.result_dir, env_type, config.agent, config.model_name, time.strftime("%Y_%m_%d_%H_%M")), world)
@@ -313,7 +323,8 @@ def main(config):
         eng.refresh_bf16()
     run = {"episode": 0, "expert_num": batch if (hirl or esac) else 0, "high_score": -math.inf, "success_rate": 0.0, "arttir": 1}
     if config.resume:  # every rank restores its own shard: <resume>/state_rank<r>.pt
-        run = CK.load_run(os.path.join(config.resume, f"state_rank{rank}.pt"), eng, env, replay)
+        run = CK.load_run(snap, eng, env, replay)
+        del snap
     else:
         # RANDOM EXPLORATION: 20 episodes of uniform actions in the reference (train_all.py:266-282) = 20*maxStep transitions
         env.reset()
@@ -396,7 +407,8 @@ def main(config):
             if world > 1:
                 torch.distributed.barrier()  # every shard of a snapshot comes from the same episode ...
             CK.save_run(os.path.join(log_dir, f"state_rank{rank}.pt"), eng, env, replay,
-                        {"episode": episode + 1, "expert_num": expert_num, "high_score": high_score, "success_rate": success_rate, "arttir": arttir})
+                        {"episode": episode + 1, "expert_num": expert_num, "high_score": high_score, "success_rate": success_rate, "arttir": arttir,
+                         "seed": seed})
             if world > 1:
                 torch.distributed.barrier()  # ... and nobody runs ahead while a shard is still being written
     if writer is not None:
@@ -435,7 +447,9 @@ def parser():
     p.add_argument("--snapshot_every", type=int, default=25, help="episodes between whole-run snapshots (0: never)")
     p.add_argument("--resume", type=str, default=None, help="run directory holding state_rank<r>.pt to continue from")
     p.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; without a launcher environment the driver starts them itself")
-    p.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16"], help="bf16: policy inference on bf16 MFMA (update, dynamics fp32)")
+    p.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "bf16_policy"],
+                   help="bf16: policy inference AND the 256<->512 products of learn() on bf16 MFMA (fp32 accumulate, fp32 master weights / Adam / "
+                        "LayerNorm / dynamics); bf16_policy: policy inference only")
     p.add_argument("--synthetic_expert", action="store_true", help="uniform-random stand-in for the expert CSV (throughput runs and tests ONLY)")
     p.add_argument("--load_dir", type=str, default=None, help="--load_model: directory of the checkpoint files (default: this run's model dir)")
     p.add_argument("--load_tag", type=str, default="Agent20_successRate0.64", help="--load_model: checkpoint tag (train_all.py:240 hard-codes this one)")

@@ -57,7 +57,8 @@ def load_env_state(env, st):
     env.obs.copy_(st["obs"])
     env.episode_ctr.copy_(st["episode_ctr"])
     if env.stats is not None and st["stats"] is not None:
-        env.stats.copy_(st["stats"])
+        k = min(env.stats.numel(), st["stats"].numel())  # (snapshots written before a statistics word was added hold fewer)
+        env.stats[:k].copy_(st["stats"][:k])
 
 
 def save_run(path, eng, env, replay, driver):
@@ -72,8 +73,13 @@ def save_run(path, eng, env, replay, driver):
     os.replace(tmp, path)
 
 
+def read_run(path):
+    """the snapshot as stored (its driver dict carries the run's seed: the caller needs it BEFORE it builds the env)"""
+    return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def load_run(path, eng, env, replay):
-    snap = torch.load(path, map_location="cpu", weights_only=False)
+    snap = path if isinstance(path, dict) else read_run(path)
     load_engine_state(eng, snap["engine"])
     load_env_state(env, snap["env"])
     load_replay_state(replay, snap["replay"])

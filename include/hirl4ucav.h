@@ -120,6 +120,12 @@ int hx_sim_tick(float* state, int64_t n, int64_t stride, const float* ally_cmd, 
                 void* stream);
 int hx_sim_readback(const float* state, int64_t n, int64_t stride, float* out, void* stream);
 
+/* The N = 1 facade's read-back (hirl4ucav_amd/environments/HarfangEnv_GYM.py: the attributes the reference's wrapper caches after every step,
+ * HarfangEnv_GYM.py:193-268) in one 64-float row: out[0..36] the state words of env i, [37..49] obs_io row i, [50] reward, [51] done,
+ * [52] success, [53..63] zero — ONE device-to-host copy per step instead of five. */
+int hx_env_pack_row(const float* state, int64_t n, int64_t stride, int64_t i, const float* obs, const float* reward, const uint8_t* done,
+                    const int8_t* success, float* out /* [64] */, void* stream);
+
 /* get_reward / get_termination for expert labelling (HarfangEnv_GYM.py:299-336, train_all.py:289-306):
  * s, ns [n][13], a [n][4] -> reward [n], success [n], done [n]. */
 int hx_label_transitions(const float* s, const float* a, const float* ns, int64_t n, float* reward, int8_t* success,
