@@ -28,6 +28,7 @@ struct FwdArgsC {
     float* zero_f;
     int* zero_i;
     const uint16_t* images;  // BF16 instantiations: base of the bf16 W2 images (one more scalar load beside the job's own, not behind it)
+    int rowmap;              // 1: blockIdx.x -> (row tile = b % tiles, column workgroup = b / tiles): a row tile's workgroups share an XCD
 };
 inline FwdJobC pack_fwd(const FwdJob& J) {
     FwdJobC c{};
@@ -92,7 +93,12 @@ __global__ __launch_bounds__(kWide) void fwd_l2_kernel(FwdArgsC A, typename std:
     const int b = blockIdx.x;
     const FwdJobC& jc = A.job[blockIdx.y];
     const FwdJob J = expand_fwd(jc);
-    const int rt = b / (H2 / NTW), nt = b % (H2 / NTW);
+    // Workgroups are dealt round-robin over the 8 XCDs (b % 8), each with its own L2.  rowmap: the row tile is b % tiles, so at B = 128 (8 row
+    // tiles) every workgroup of row tile rt runs on XCD rt — where the launches before this one left that tile's rows, and where the launches
+    // after it will look for what this one writes: rows another XCD has just written come back at ~19 B/clk/CU, the XCD's own at ~35.  The
+    // weights then come from every XCD's share of the Infinity Cache instead of one L2 slice per column workgroup (clean lines: cheap).
+    const int ntile_ = tiles_of(J.rows);
+    const int rt = A.rowmap ? b % ntile_ : b / (H2 / NTW), nt = A.rowmap ? b / ntile_ : b % (H2 / NTW);
     const int r0 = rt * RT;
     const int nrow = min(RT, J.rows - r0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -350,6 +356,7 @@ static_assert(sizeof(BwdJobC) == 128, "two s_load_dwordx16");
 struct BwdArgsC {
     BwdJobC job[2];
     const uint16_t* images;  // BF16 instantiations: base of the bf16 W2 images
+    int rowmap;              // 1: row tiles -> XCDs as in fwd_l2 (see there)
 };
 inline BwdJobC pack_bwd(const BwdJob& J, const BwdArgs& A) {
     BwdJobC c{};
@@ -428,7 +435,15 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     const BwdJobC& jc = AC.job[blockIdx.y];
     const BwdJob J = expand_bwd(jc);
     struct { float slope, inv_batch; float* losses; int* soft_count; } A{jc.slope, jc.inv_batch, jc.losses, jc.soft_count};
-    const int rt = b / kColWgB, nt = b % kColWgB;
+    // rowmap (see fwd_l2): the workgroups of the 16-row tile t of the forward launches run on XCD t % 8.  PAIRED kernels split it into two
+    // 8-row tiles 2t, 2t + 1: b = x + 8 k -> row tile 2 x + (k & 1), column workgroup k >> 1 (B = 128: 16 tiles of 8 rows; any other row
+    // count keeps the plain order)
+    int rt = b / kColWgB, nt = b % kColWgB;
+    if (AC.rowmap) {
+        const int ntile_ = (jc.rows + RTB - 1) / RTB;
+        if (PAIRED && ntile_ == 16) { rt = 2 * (b & 7) + ((b >> 3) & 1); nt = b >> 4; }
+        else if (!PAIRED) { rt = b % ntile_; nt = b / ntile_; }
+    }
     const int r0 = rt * RTB;
     const int nrow = min(RTB, J.rows - r0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -773,6 +788,8 @@ void launch_bwd_t(const BwdArgs& G, hipStream_t st) {
     BwdArgsC C{};
     for (int j = 0; j < G.njobs; ++j) C.job[j] = pack_bwd(G.job[j], G);
     C.images = G.images;
+    static const int rowmap = getenv("HX_XCD_ROWMAP") ? atoi(getenv("HX_XCD_ROWMAP")) : 0;
+    C.rowmap = rowmap;
     const dim3 grid(bwd_blocks(G, GRP <= 2 ? RT / 2 : RT), G.njobs);
     if constexpr (GRP <= 2) {  // the bf16 update path covers the HIRL / TD3 / BC jobs (GRP 3 = SAC's given head gradients: fp32)
         static const int dbg_off = getenv("HX_DBG_BF16_OFF") ? atoi(getenv("HX_DBG_BF16_OFF")) : 0;
@@ -798,6 +815,8 @@ void launch_fwd(const FwdArgs& F, hipStream_t st) {
         C.job[j].slope = F.slope;
     }
     C.slope = F.slope; C.zero_nf = F.zero_nf; C.zero_f = F.zero_f; C.zero_i = F.zero_i; C.images = F.images;
+    static const int rowmap = getenv("HX_XCD_ROWMAP") ? atoi(getenv("HX_XCD_ROWMAP")) : 0;
+    C.rowmap = rowmap;
     const int tiles = fwd_row_tiles(F), per_job = tiles / F.njobs;
     const bool relu = F.slope == 0.0f;  // compile-time ReLU instantiations (hx_nn.h act_f)
     static const int dbg_off = getenv("HX_DBG_BF16_OFF") ? atoi(getenv("HX_DBG_BF16_OFF")) : 0;
