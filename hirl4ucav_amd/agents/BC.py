@@ -13,7 +13,7 @@ class Agent:
         _check_dims(stateDim, actionDim, full1Dim, full2Dim, layerNorm)
         self.batchsize = int(batchsize)
         self.expert_states, self.expert_actions = np.asarray(expert_states), np.asarray(expert_actions)
-        self.eng = E.HirlEngine(batch=self.batchsize, lr_actor=actorLR, slope=0.01, use_bc=True, device=device)  # BC.py:129-135 leaky_relu
+        self.eng = E.HirlEngine(batch=self.batchsize, lr_actor=actorLR, slope=0.01, use_bc=True, device=device, layer_norm=bool(layerNorm))  # BC.py:129-135 leaky_relu
         self.eng.load_params(init_actor_state_dict(), E.unpack(self.eng.critic, E.CRITIC_LAYOUT))
         self.actor = _NetView(self.eng.actor, E.ACTOR_LAYOUT, name, on_load=self.eng.refresh_images)
         tab = np.zeros((len(self.expert_states), 32), np.float32)

@@ -17,16 +17,19 @@ class _NetView:
     """Stands in for the reference's nn.Module attributes (agent.actor, agent.critic, ...): state_dict() /
     load_state_dict() / saveCheckpoint / loadCheckpoint with the reference's key names (HIRL.py:99-103,142-146)."""
 
-    def __init__(self, flat, layout, name, on_load=None):
+    def __init__(self, flat, layout, name, on_load=None, layer_norm=True):
         self._flat, self._layout, self.name = flat, layout, name
         self.device = flat.device
         self._on_load = on_load  # the acting network: the engine's images of its W2 must follow a direct write
+        self._layer_norm = layer_norm
 
     def state_dict(self):
         return {k: v.detach().clone().cpu() for k, v in E.unpack(self._flat, self._layout).items()}
 
     def load_state_dict(self, sd):
         self._flat.copy_(E.pack(sd, self._layout, self._flat.numel(), self._flat.device))
+        if not self._layer_norm:
+            E.force_plain_layernorm(self._flat, self._layout)
         if self._on_load is not None:
             self._on_load()
 
@@ -49,10 +52,10 @@ class _NetView:
         return self
 
 
-def _check_dims(stateDim, actionDim, full1Dim, full2Dim, layerNorm):
-    if (stateDim, actionDim, full1Dim, full2Dim, bool(layerNorm)) != (13, 4, 256, 512, True):
-        raise NotImplementedError("the HIP kernels are built for the reference's network shape 13/4/256/512 with LayerNorm "
-                                  "(train_all.py:190-208)")
+def _check_dims(stateDim, actionDim, full1Dim, full2Dim, layerNorm=True):
+    """layerNorm may be True or False (both branches of HIRL.py:58-80,131-138 have kernels); the layer widths are the reference's"""
+    if (stateDim, actionDim, full1Dim, full2Dim) != (13, 4, 256, 512):
+        raise NotImplementedError("the HIP kernels are built for the reference's network shape 13/4/256/512 (train_all.py:190-208)")
 
 
 def _init_block(in_dim, out_dim, names):
@@ -93,15 +96,17 @@ class Agent:
         self.actionDim = actionDim
         self.actionNoise, self.TD3LearningNoise, self.TD3LearningNoiseClamp = 0.1, 0.2, 0.5  # HIRL.py:160-162
         self.bc_weight, self.expert_warm_up = bc_weight, expert_warm_up
+        self.layerNorm = bool(layerNorm)
         self.eng = E.HirlEngine(batch=batchSize, lr_actor=actorLR, lr_critic=criticLR, tau=tau, gamma=gamma, slope=self._slope,
-                                use_bc=self._use_bc, device=device)
+                                use_bc=self._use_bc, device=device, layer_norm=self.layerNorm)
         self.eng.load_params(init_actor_state_dict(), init_critic_state_dict(), init_actor_state_dict() if self._use_bc else None)
         e = self.eng
-        self.actor = _NetView(e.actor, E.ACTOR_LAYOUT, "Actor_" + name, on_load=e.refresh_images)
-        self.targetActor = _NetView(e.target_actor, E.ACTOR_LAYOUT, "TargetActor_" + name)
-        self.critic = _NetView(e.critic, E.CRITIC_LAYOUT, "Critic_" + name)
-        self.targetCritic = _NetView(e.target_critic, E.CRITIC_LAYOUT, "TargetCritic_" + name)
-        self.bc_actor = _NetView(e.bc_actor, E.ACTOR_LAYOUT, name)
+        ln = self.layerNorm
+        self.actor = _NetView(e.actor, E.ACTOR_LAYOUT, "Actor_" + name, on_load=e.refresh_images, layer_norm=ln)
+        self.targetActor = _NetView(e.target_actor, E.ACTOR_LAYOUT, "TargetActor_" + name, on_load=e.refresh_images, layer_norm=ln)
+        self.critic = _NetView(e.critic, E.CRITIC_LAYOUT, "Critic_" + name, on_load=e.refresh_images, layer_norm=ln)
+        self.targetCritic = _NetView(e.target_critic, E.CRITIC_LAYOUT, "TargetCritic_" + name, on_load=e.refresh_images, layer_norm=ln)
+        self.bc_actor = _NetView(e.bc_actor, E.ACTOR_LAYOUT, name, on_load=e.refresh_images, layer_norm=ln)
         self.buffer = UniformMemory(bufferSize, False)
         if self._use_bc:
             self.expert_states, self.expert_actions = np.asarray(expert_states), np.asarray(expert_actions)

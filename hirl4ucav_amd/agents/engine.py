@@ -37,7 +37,7 @@ class HxNets(ctypes.Structure):
 
 
 class HxHyper(ctypes.Structure):
-    _fields_ = [(k, _f32) for k in ("gamma", "tau", "lr_actor", "lr_critic", "slope", "noise_clamp", "loss_lambda")] + [("use_bc", _i32)]
+    _fields_ = [(k, _f32) for k in ("gamma", "tau", "lr_actor", "lr_critic", "slope", "noise_clamp", "loss_lambda")] + [("use_bc", _i32), ("no_layernorm", _i32)]
 
 
 _P = ctypes.POINTER
@@ -204,6 +204,14 @@ def unpack(flat, layout):
     return {k: flat[off:off + int(np.prod(shp))].reshape(shp) for k, off, shp in layout}
 
 
+def force_plain_layernorm(flat, layout):
+    """LayerNorm slots of a flat network buffer -> (1, 0).  A layerNorm=False agent never uses or trains the modules (they still exist in the
+    reference's state_dict, HIRL.py:28,33,114,119); the kernels' "no LayerNorm" form multiplies by the slot's weight and adds its bias."""
+    for k, off, shp in layout:
+        if k.startswith("layernorm"):
+            flat[off:off + int(np.prod(shp))] = 1.0 if k.endswith(".weight") else 0.0
+
+
 def len_of(replay):
     """live rows of a DeviceReplay used as a fixed table (expert ring): its capacity bound, no host sync"""
     return 0 if replay is None else int(getattr(replay, "fixed_len", replay.capacity))
@@ -211,7 +219,7 @@ def len_of(replay):
 
 class HirlEngine:
     def __init__(self, batch=128, lr_actor=1e-3, lr_critic=1e-3, tau=0.005, gamma=0.99, slope=0.0, use_bc=True,
-                 device="cuda", group=None):
+                 device="cuda", group=None, layer_norm=True):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.HxError("HirlEngine runs on the GPU only (no CPU path in the product)")
@@ -246,7 +254,11 @@ class HirlEngine:
         # fp32 image of the actor's W2 in the acting kernel's operand order (hx_pack_w2_f32i): kept current by the actor's Adam steps
         self.w2_f32i = torch.zeros(H2 * H1, dtype=torch.float32, device=self.device)
         self.nets.actor_w2_f32i = self.w2_f32i.data_ptr()
-        self.hyper = HxHyper(gamma, tau, lr_actor, lr_critic, slope, 0.5, 10000.0, int(use_bc))  # HIRL.py:162,182
+        # layer_norm = False: the reference's `layerNorm=False` networks (HIRL.py:70-80,92-97,135-138): both LayerNorms skipped; the modules
+        # still exist in its state_dict (HIRL.py:28,33,114,119), untrained at (1, 0) — load_params keeps the flat buffers' slots there
+        self.layer_norm = bool(layer_norm)
+        self._mode_bits = 0 if self.layer_norm else 16  # hx_actor_act*: noise_mode + 16
+        self.hyper = HxHyper(gamma, tau, lr_actor, lr_critic, slope, 0.5, 10000.0, int(use_bc), 0 if self.layer_norm else 1)  # HIRL.py:162,182
         self.use_bc, self.slope = bool(use_bc), float(slope)
         self.actor_trainable, self.update_count = True, 0   # HIRL.py:157,166
         self.critic_step, self.actor_step = 0, 0
@@ -268,6 +280,9 @@ class HirlEngine:
         self.critic.copy_(pack(critic, CRITIC_LAYOUT, CRITIC_SIZE, self.device))
         if bc_actor is not None:
             self.bc_actor.copy_(pack(bc_actor, ACTOR_LAYOUT, ACTOR_SIZE, self.device))
+        if not self.layer_norm:  # the kernels' "no LayerNorm" form multiplies by the slot's weight and adds its bias: keep them at (1, 0)
+            for flat, layout in ((self.actor, ACTOR_LAYOUT), (self.critic, CRITIC_LAYOUT), (self.bc_actor, ACTOR_LAYOUT)):
+                force_plain_layernorm(flat, layout)
         if hard_update_targets:  # hard_update, HIRL.py:15-17,172,176
             self.target_actor.copy_(self.actor)
             self.target_critic.copy_(self.critic)
@@ -362,14 +377,14 @@ class HirlEngine:
             mode = 3
         self.act_calls += 1
         if self.act_dtype == "bf16" and net is None:
-            _lib.call("hx_actor_act_bf16", self.actor.data_ptr(), self.w2_bf16.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode, _lib.ptr(noise),
+            _lib.call("hx_actor_act_bf16", self.actor.data_ptr(), self.w2_bf16.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise),
                       float(sigma), int(seed), int(row0), self.act_calls, self.slope, _lib.stream_ptr())
             return out
         if net is None:  # the engine's own actor: W2 from its fp32 image (same bits as hx_actor_act, no LDS staging of W2)
-            _lib.call("hx_actor_act_f32i", self.actor.data_ptr(), self.w2_f32i.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode, _lib.ptr(noise),
+            _lib.call("hx_actor_act_f32i", self.actor.data_ptr(), self.w2_f32i.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise),
                       float(sigma), int(seed), int(row0), self.act_calls, self.slope, _lib.stream_ptr())
             return out
-        _lib.call("hx_actor_act", net.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode,
+        _lib.call("hx_actor_act", net.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode | self._mode_bits,
                   _lib.ptr(noise), float(sigma), int(seed), int(row0), self.act_calls, self.slope, None,
                   _lib.stream_ptr())
         return out
@@ -389,11 +404,11 @@ class HirlEngine:
         self.act_calls += 1
         if self.act_dtype == "bf16":
             _lib.call("hx_actor_act_step_bf16", self.actor.data_ptr(), self.w2_bf16.data_ptr(), env.state.data_ptr(), n, n, env.obs.data_ptr(),
-                      out.data_ptr(), mode, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
+                      out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
                       env.reward.data_ptr(), env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
             return out, env.obs, env.reward, env.done, env.success
         _lib.call("hx_actor_act_step_f32i", self.actor.data_ptr(), self.w2_f32i.data_ptr(), env.state.data_ptr(), n, n, env.obs.data_ptr(),
-                  out.data_ptr(), mode, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
+                  out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
                   env.reward.data_ptr(), env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
         return out, env.obs, env.reward, env.done, env.success
 

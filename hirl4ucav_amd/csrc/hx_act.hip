@@ -605,8 +605,10 @@ int64_t hx_act_workspace_floats(int64_t rows) { (void)rows; return 0; }  // the 
 static int actor_act_impl(const float* actor, const uint16_t* w2b, const float* w2f, const float* obs, int64_t rows, float* actions, int32_t noise_mode, const float* noise,
                  float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream) {
     HX_REQUIRE(actor && obs && actions && rows > 0, "hx_actor_act: bad arguments");
+    const Mlp mA{13, 4, (noise_mode & 16) ? 1 : 0};  // + 16: layerNorm = False
+    noise_mode &= 15;
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act: bad noise mode");
-    ActFusedArgs H{actor, kActor, const_cast<float*>(obs), (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
+    ActFusedArgs H{actor, mA, const_cast<float*>(obs), (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
                    noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0, w2b, w2f};
     launch_act<false>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_actor_act");
@@ -651,14 +653,17 @@ static int actor_act_step_impl(const float* actor, const uint16_t* w2b, const fl
                       const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward,
                       uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
     HX_REQUIRE(actor, "hx_actor_act_step: null actor");
+    const int32_t mode_in = noise_mode;
+    const Mlp mA{13, 4, (noise_mode & 16) ? 1 : 0};  // + 16: layerNorm = False
+    noise_mode &= 15;
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act_step: bad noise mode");
     const HxStepOpts o = opts ? *opts : HxStepOpts{};
     if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_actor_act_step")) return rc;
     if (n > kFuseEnvMax) {  // more than one round of workgroups: the env step is cheaper as a launch of its own
-        if (int rc = actor_act_impl(actor, w2b, w2f, obs_io, n, actions, noise_mode, noise, sigma, seed, row0, call, slope, stream)) return rc;
+        if (int rc = actor_act_impl(actor, w2b, w2f, obs_io, n, actions, mode_in, noise, sigma, seed, row0, call, slope, stream)) return rc;
         return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
     }
-    ActFusedArgs H{actor, kActor, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
+    ActFusedArgs H{actor, mA, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
                    noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
                    o.cap > 0 ? 1.0 / (double)o.cap : 0.0, w2b, w2f};
     launch_act<false>(H, (hipStream_t)stream);

@@ -64,6 +64,7 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
                              const HxSample* S = nullptr) {
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_critic_grads: batch must be a positive multiple of 16");
     hipStream_t st = (hipStream_t)stream;
+    const Mlp mA{13, 4, Hy->no_layernorm ? 1 : 0}, mQ{17, 1, Hy->no_layernorm ? 1 : 0};  // layerNorm = False: HIRL.py:70-80,92-97,135-138
     const int B = Bt->batch;
     SampleDev SD{};
     bool fused = false;
@@ -75,17 +76,17 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
     make_slots(N, B, s);
     const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
     const float* tc1 = N->target_critic;
-    const float* tc2 = N->target_critic + kQ.padded();
+    const float* tc2 = N->target_critic + mQ.padded();
     {   // launch A: targetActor(s'), critic Q1/Q2 (s, a)
         FwdArgs F{};
         F.njobs = 3; F.slope = Hy->slope;
         F.zero_f = N->losses; F.zero_nf = 1;  // critic_loss accumulator
-        F.job[0] = FwdJob{N->target_actor, kActor, src, 17, 0, Head{}, nullptr, 0.f, s[S_TA], B, 0, IM_TA};
-        F.job[1] = FwdJob{N->critic, kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C1], B, 1, IM_C1};
-        F.job[2] = FwdJob{N->critic + kQ.padded(), kQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C2], B, 1, IM_C2};
+        F.job[0] = FwdJob{N->target_actor, mA, src, 17, 0, Head{}, nullptr, 0.f, s[S_TA], B, 0, IM_TA};
+        F.job[1] = FwdJob{N->critic, mQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C1], B, 1, IM_C1};
+        F.job[2] = FwdJob{N->critic + mQ.padded(), mQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C2], B, 1, IM_C2};
         if (actor_fwd) {  // the delayed actor step's forwards ride along, split so that NEITHER launch exceeds 256 workgroups
             F.zero_nf = 5; F.zero_i = N->soft_count;  // + actor / bc / rl / bc_fire accumulators and the soft count
-            F.job[3] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1, IM_ACTOR};
+            F.job[3] = FwdJob{N->actor, mA, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1, IM_ACTOR};
             F.njobs = 4;
         }
         F.sample = fused ? &SD : nullptr;
@@ -95,14 +96,14 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
     {   // launch B: targetCritic Q1/Q2 (s', clamp(targetActor(s') + clamp(noise)))  [+ actor(s_bc), bc_actor(s)]
         FwdArgs F{};
         F.njobs = 2; F.slope = Hy->slope;
-        const Head prev{N->target_actor, kActor, s[S_TA]};
-        F.job[0] = FwdJob{tc1, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC1], B, 0, IM_TC1};
-        F.job[1] = FwdJob{tc2, kQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC2], B, 0, IM_TC2};
+        const Head prev{N->target_actor, mA, s[S_TA]};
+        F.job[0] = FwdJob{tc1, mQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC1], B, 0, IM_TC1};
+        F.job[1] = FwdJob{tc2, mQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC2], B, 0, IM_TC2};
         if (actor_fwd && Hy->use_bc) {
             const RowSrc bcsrc{Bt->bc_rows ? Bt->bc_rows : Bt->rows, nullptr, nullptr, 0, 32};
             int n = 2;
-            F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1, IM_ACTOR};
-            if (actor_fwd == 2) F.job[n++] = FwdJob{N->bc_actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0, IM_BC};
+            F.job[n++] = FwdJob{N->actor, mA, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1, IM_ACTOR};
+            if (actor_fwd == 2) F.job[n++] = FwdJob{N->bc_actor, mA, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0, IM_BC};
             F.njobs = n;
         }
         F.images = N->w2_bf16_all;
@@ -114,8 +115,8 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
         for (int h = 0; h < 2; ++h) {
             BwdJob& J = G.job[h];
             J = BwdJob{};
-            J.net = N->critic + h * kQ.padded(); J.m = kQ; J.ws = s[S_C1 + h]; J.rows = B; J.mode = BM_CRITIC_TD;
-            J.t1 = Head{tc1, kQ, s[S_TC1]}; J.t2 = Head{tc2, kQ, s[S_TC2]}; J.src = src; J.gamma = Hy->gamma;
+            J.net = N->critic + h * mQ.padded(); J.m = mQ; J.ws = s[S_C1 + h]; J.rows = B; J.mode = BM_CRITIC_TD;
+            J.t1 = Head{tc1, mQ, s[S_TC1]}; J.t2 = Head{tc2, mQ, s[S_TC2]}; J.src = src; J.gamma = Hy->gamma;
             J.img_t = IM_C1_T + h;
         }
         G.images = N->w2_bf16_all;
@@ -128,12 +129,12 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
         for (int h = 0; h < 2; ++h) {
             WgJob& J = W.job[h];
             J = WgJob{};
-            J.net = N->critic + h * kQ.padded(); J.grad = N->grad_critic + h * kQ.padded(); J.m = kQ;
+            J.net = N->critic + h * mQ.padded(); J.grad = N->grad_critic + h * mQ.padded(); J.m = mQ;
             J.ws[0] = s[S_C1 + h]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
             if (adam_step > 0) {
-                J.p = N->critic + h * kQ.padded();
-                J.mom = N->m_critic + h * kQ.padded(); J.var = N->v_critic + h * kQ.padded();
-                J.target = polyak ? N->target_critic + h * kQ.padded() : nullptr;
+                J.p = N->critic + h * mQ.padded();
+                J.mom = N->m_critic + h * mQ.padded(); J.var = N->v_critic + h * mQ.padded();
+                J.target = polyak ? N->target_critic + h * mQ.padded() : nullptr;
                 if (uint16_t* im = N->w2_bf16_all) {
                     J.w2b = im + (IM_C1 + h) * kImgElems; J.w2tb = im + (IM_C1_T + h) * kImgElems; J.tgt_w2b = im + (IM_TC1 + h) * kImgElems;
                 }
@@ -163,6 +164,7 @@ int hx_hirl_critic_grads_sampled(const HxNets* N, const HxBatch* Bt, const HxHyp
 int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t estimate_soft, int32_t fwd_done, void* stream) {
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_actor_backward: batch must be a positive multiple of 16");
     hipStream_t st = (hipStream_t)stream;
+    const Mlp mA{13, 4, Hy->no_layernorm ? 1 : 0}, mQ{17, 1, Hy->no_layernorm ? 1 : 0};  // layerNorm = False: HIRL.py:70-80,92-97,135-138
     const int B = Bt->batch;
     Slot s[S_COUNT];
     make_slots(N, B, s);
@@ -174,9 +176,9 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
         F.slope = Hy->slope;
         F.zero_f = N->losses + 1; F.zero_nf = 4; F.zero_i = N->soft_count;  // actor / bc / rl / bc_fire accumulators + soft count
         int n = 0;
-        F.job[n++] = FwdJob{N->actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1, IM_ACTOR};
-        if (bc) F.job[n++] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1, IM_ACTOR};
-        if (soft) F.job[n++] = FwdJob{N->bc_actor, kActor, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0, IM_BC};
+        F.job[n++] = FwdJob{N->actor, mA, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1, IM_ACTOR};
+        if (bc) F.job[n++] = FwdJob{N->actor, mA, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1, IM_ACTOR};
+        if (soft) F.job[n++] = FwdJob{N->bc_actor, mA, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0, IM_BC};
         F.njobs = n;
         F.images = N->w2_bf16_all;
         launch_fwd(F, st);
@@ -185,8 +187,8 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
         FwdArgs F{};
         F.slope = Hy->slope;
         int n = 0;
-        F.job[n++] = FwdJob{N->critic, kQ, src, 0, 1, Head{N->actor, kActor, s[S_API]}, nullptr, 0.f, s[S_CPI], B, 1, IM_C1};
-        if (soft) F.job[n++] = FwdJob{N->critic, kQ, src, 0, 1, Head{N->bc_actor, kActor, s[S_BCS]}, nullptr, 0.f, s[S_CSOFT], B, 0, IM_C1};
+        F.job[n++] = FwdJob{N->critic, mQ, src, 0, 1, Head{N->actor, mA, s[S_API]}, nullptr, 0.f, s[S_CPI], B, 1, IM_C1};
+        if (soft) F.job[n++] = FwdJob{N->critic, mQ, src, 0, 1, Head{N->bc_actor, mA, s[S_BCS]}, nullptr, 0.f, s[S_CSOFT], B, 0, IM_C1};
         F.njobs = n;
         F.images = N->w2_bf16_all;
         launch_fwd(F, st);
@@ -196,8 +198,8 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
         G.njobs = 1; G.slope = Hy->slope; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = N->soft_count;
         BwdJob& J = G.job[0];
         J = BwdJob{};
-        J.net = N->critic; J.m = kQ; J.ws = s[S_CPI]; J.rows = B; J.mode = BM_CRITIC_PI;
-        if (soft) J.soft = Head{N->critic, kQ, s[S_CSOFT]};
+        J.net = N->critic; J.m = mQ; J.ws = s[S_CPI]; J.rows = B; J.mode = BM_CRITIC_PI;
+        if (soft) J.soft = Head{N->critic, mQ, s[S_CSOFT]};
         J.img_t = IM_C1_T;
         G.images = N->w2_bf16_all;
         launch_bwd(1, G, st);
@@ -209,14 +211,14 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
         {
             BwdJob& J = G.job[n++];
             J = BwdJob{};
-            J.net = N->actor; J.m = kActor; J.ws = s[S_API]; J.rows = B; J.mode = BM_ACTOR_PI;
-            J.crit = Head{N->critic, kQ, s[S_CPI]};
+            J.net = N->actor; J.m = mA; J.ws = s[S_API]; J.rows = B; J.mode = BM_ACTOR_PI;
+            J.crit = Head{N->critic, mQ, s[S_CPI]};
             J.img_t = IM_ACTOR_T;
         }
         if (bc) {
             BwdJob& J = G.job[n++];
             J = BwdJob{};
-            J.net = N->actor; J.m = kActor; J.ws = s[S_ABC]; J.rows = B; J.mode = BM_ACTOR_BC;
+            J.net = N->actor; J.m = mA; J.ws = s[S_ABC]; J.rows = B; J.mode = BM_ACTOR_BC;
             J.src = bcsrc; J.lambda = Hy->loss_lambda;
             J.img_t = IM_ACTOR_T;
         }
@@ -234,6 +236,7 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
 static int actor_wgrad_impl(const HxNets* N, const HxHyper* Hy, int32_t batch, int32_t count_batch, int32_t w_kind, float w_given,
                             float warm, void* stream, int adam_step, bool polyak) {
     HX_REQUIRE(N && Hy && batch > 0 && count_batch > 0, "hx_hirl_actor_wgrad: bad arguments");
+    const Mlp mA{13, 4, Hy->no_layernorm ? 1 : 0}, mQ{17, 1, Hy->no_layernorm ? 1 : 0};  // layerNorm = False: HIRL.py:70-80,92-97,135-138
     Slot s[S_COUNT];
     make_slots(N, batch, s);
     const bool bc = Hy->use_bc != 0;
@@ -242,7 +245,7 @@ static int actor_wgrad_impl(const HxNets* N, const HxHyper* Hy, int32_t batch, i
     W.inv_batch = 1.0f / count_batch; W.soft_count = N->soft_count; W.wstate = N->wstate;
     WgJob& J = W.job[0];
     J = WgJob{};
-    J.net = N->actor; J.grad = N->grad_actor; J.m = kActor;
+    J.net = N->actor; J.grad = N->grad_actor; J.m = mA;
     J.ws[0] = s[S_API]; J.rows[0] = batch; J.wmode[0] = 1;
     J.nslots = 1;
     if (bc) { J.ws[1] = s[S_ABC]; J.rows[1] = batch; J.wmode[1] = 2; J.nslots = 2; }
@@ -274,6 +277,7 @@ int hx_hirl_actor_wgrad(const HxNets* N, const HxHyper* Hy, int32_t batch, int32
  * forms w from the global count and combines.  TD3 (use_bc = 0): dL_rl only. */
 int hx_hirl_actor_wgrad_split(const HxNets* N, const HxHyper* Hy, int32_t batch, float* msg, void* stream) {
     HX_REQUIRE(N && Hy && batch > 0 && msg && (reinterpret_cast<uintptr_t>(msg) & 15u) == 0, "hx_hirl_actor_wgrad_split: bad arguments");
+    const Mlp mA{13, 4, Hy->no_layernorm ? 1 : 0}, mQ{17, 1, Hy->no_layernorm ? 1 : 0};  // layerNorm = False: HIRL.py:70-80,92-97,135-138
     Slot s[S_COUNT];
     make_slots(N, batch, s);
     const bool bc = Hy->use_bc != 0;
@@ -283,12 +287,12 @@ int hx_hirl_actor_wgrad_split(const HxNets* N, const HxHyper* Hy, int32_t batch,
     for (int j = 0; j < W.njobs; ++j) {
         WgJob& J = W.job[j];
         J = WgJob{};
-        J.net = N->actor; J.grad = msg + j * kActor.padded(); J.m = kActor;
+        J.net = N->actor; J.grad = msg + j * mA.padded(); J.m = mA;
         J.ws[0] = s[j == 0 ? S_API : S_ABC]; J.rows[0] = batch; J.wmode[0] = 0; J.nslots = 1;
     }
     W.bf16 = N->w2_bf16_all != nullptr;
     W.soft_count = bc ? N->soft_count : nullptr;
-    W.count_out = msg + 2 * kActor.padded();  // the message's count word, written by the same launch (was a launch of its own: 3.8 us)
+    W.count_out = msg + 2 * mA.padded();  // the message's count word, written by the same launch (was a launch of its own: 3.8 us)
     launch_wg(W, false, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_hirl_actor_wgrad_split");
     return 0;
@@ -319,6 +323,7 @@ int hx_hirl_learn_sampled(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy,
 int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t step, void* stream) {
     HX_REQUIRE(N && Bt && Hy && Bt->bc_rows && Bt->batch > 0 && Bt->batch % 16 == 0 && step >= 1, "hx_bc_train_actor: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    const Mlp mA{13, 4, Hy->no_layernorm ? 1 : 0}, mQ{17, 1, Hy->no_layernorm ? 1 : 0};  // layerNorm = False: HIRL.py:70-80,92-97,135-138
     const int B = Bt->batch;
     Slot s[S_COUNT];
     make_slots(N, B, s);
@@ -327,7 +332,7 @@ int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int
         FwdArgs F{};
         F.njobs = 1; F.slope = Hy->slope;
         F.zero_f = N->losses + 1; F.zero_nf = 4;
-        F.job[0] = FwdJob{N->actor, kActor, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1, IM_ACTOR};
+        F.job[0] = FwdJob{N->actor, mA, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1, IM_ACTOR};
         F.images = N->w2_bf16_all;
         launch_fwd(F, st);
     }
@@ -336,7 +341,7 @@ int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int
         G.njobs = 1; G.slope = Hy->slope; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = N->soft_count;
         BwdJob& J = G.job[0];
         J = BwdJob{};
-        J.net = N->actor; J.m = kActor; J.ws = s[S_ABC]; J.rows = B; J.mode = BM_ACTOR_BC; J.src = bcsrc; J.lambda = 1.0f;
+        J.net = N->actor; J.m = mA; J.ws = s[S_ABC]; J.rows = B; J.mode = BM_ACTOR_BC; J.src = bcsrc; J.lambda = 1.0f;
         J.img_t = IM_ACTOR_T;
         G.images = N->w2_bf16_all;
         launch_bwd(2, G, st);
@@ -347,7 +352,7 @@ int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int
         W.soft_count = N->soft_count; W.wstate = N->wstate;
         WgJob& J = W.job[0];
         J = WgJob{};
-        J.net = N->actor; J.grad = N->grad_actor; J.m = kActor; J.ws[0] = s[S_ABC]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
+        J.net = N->actor; J.grad = N->grad_actor; J.m = mA; J.ws[0] = s[S_ABC]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
         W.bf16 = N->w2_bf16_all != nullptr;
         launch_wg(W, false, st);
     }

@@ -149,7 +149,8 @@ int64_t hx_act_workspace_floats(int64_t rows); /* 0: the acting kernels need no 
  * (hirl/agents/HIRL.py:192-212): actions = clamp(actor(obs) + noise, -1, 1).
  * noise_mode 0: none (NoNoise); 1: noise[4] shared by all rows (the reference's one draw per call); 2: noise[rows][4];
  * 3: N(0, sigma^2) per row and component from Philox4x32-10(key = seed; counter = (row0 + row, call)).
- * slope: 0 = ReLU nets (HIRL.py), 0.01 = LeakyReLU nets (TD3.py / BC.py).  ws: unused (may be NULL). */
+ * slope: 0 = ReLU nets (HIRL.py), 0.01 = LeakyReLU nets (TD3.py / BC.py).  ws: unused (may be NULL).
+ * noise_mode + 16: the actor was built with layerNorm = False (HIRL.py:135-138): no LayerNorm in its forward (all hx_actor_act* entry points). */
 int hx_actor_act(const float* actor, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
                  const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* ws,
                  void* stream);
@@ -227,6 +228,9 @@ int hx_pack_update_images(const HxNets* nets, void* stream);
 typedef struct HxHyper {
     float gamma, tau, lr_actor, lr_critic, slope, noise_clamp, loss_lambda;
     int32_t use_bc; /* 1: HIRL (TD3+BC, HIRL.py), 0: TD3 (TD3.py:201-260) */
+    int32_t no_layernorm; /* 1: the agent was built with layerNorm = False: the networks' forward skips both LayerNorms (HIRL.py:70-80,92-97,
+                             135-138).  The LayerNorm slots of the flat buffers must hold (1, 0) — the reference constructs the modules either
+                             way (HIRL.py:28,33,114,119) and never trains them in this mode — and stay that way (their gradients are zero) */
 } HxHyper;
 
 /* Agent.learn, split at the points where a sharded run exchanges data; single-GPU callers run the

@@ -80,6 +80,32 @@ def _ln(x, w, b):
     return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
 
 
+class NoLayerNorm:
+    """context manager: the networks' `layerNorm=False` branches (HIRL.py:70-80,92-97,135-138): both LayerNorms are skipped (the modules
+    stay in the state_dict, untrained)"""
+
+    def __enter__(self):
+        global _ln
+        self._orig = _ln
+        _ln = lambda x, w, b: x  # noqa: E731
+        return self
+
+    def __exit__(self, *exc):
+        global _ln
+        _ln = self._orig
+
+
+class _Maybe:
+    def __init__(self, cm):
+        self.cm = cm
+
+    def __enter__(self):
+        return self.cm.__enter__() if self.cm is not None else None
+
+    def __exit__(self, *exc):
+        return self.cm.__exit__(*exc) if self.cm is not None else False
+
+
 def _linear2(h, w, b):
     """the 256 -> 512 layer.  fp32 F.linear — or, inside `with Bf16Layer2():`, the ROUNDED-OPERAND form the bf16 update path is tested
     against (tests/test_bf16_update_gpu.py)."""
@@ -166,6 +192,13 @@ class Adam:
                 p.addcdiv_(self.m[k], denom, value=-(self.lr / bc1))
 
 
+def _grads(loss, params, keys, retain_graph=False):
+    """d loss / d params[k]; a parameter the loss does not reach (the LayerNorm modules of a layerNorm=False network: torch.optim.Adam
+    skips their None gradients) gets a zero gradient, which leaves it and its moments unchanged in Adam.step above"""
+    g = torch.autograd.grad(loss, [params[k] for k in keys], retain_graph=retain_graph, allow_unused=True)
+    return [torch.zeros_like(params[k]) if x is None else x for k, x in zip(keys, g)]
+
+
 def polyak(target, source, tau):  # HIRL.py:11-13
     with torch.no_grad():
         for k in target:
@@ -176,7 +209,8 @@ class HirlOracle:
     """State and update rule of hirl.agents.HIRL.Agent (and TD3.Agent with slope=0.01, use_bc=False)."""
 
     def __init__(self, actor, critic, bc_actor=None, lr_actor=1e-3, lr_critic=1e-3, tau=0.005, gamma=0.99, slope=0.0,
-                 use_bc=True, device="cpu"):
+                 use_bc=True, device="cpu", layer_norm=True):
+        self.layer_norm = bool(layer_norm)  # False: Agent(..., layerNorm=False, ...)
         # device: "cpu" for every parity test; bench.py's baseline leg also runs the same eager ops on the GPU (b2_eager_rocm_learn)
         self.dev = torch.device(device)
         self.actor = to_torch(actor, True, self.dev)
@@ -198,13 +232,17 @@ class HirlOracle:
 
     def choose_action(self, state, noise=None):
         """clamp(actor(s) + noise, -1, 1); noise None = chooseActionNoNoise   HIRL.py:192-212"""
-        with torch.no_grad():
+        with torch.no_grad(), _Maybe(None if self.layer_norm else NoLayerNorm()):
             a = actor_forward(self.actor, torch.as_tensor(state, dtype=torch.float32, device=self.dev), self.slope)
             if noise is not None:
                 a = (a + torch.as_tensor(noise, dtype=torch.float32, device=self.dev)).clamp(-1, 1)
         return a.cpu().numpy()
 
     def learn(self, batch, bc_batch, noise, bc_weight_now=0.0, bc_warm_up_weight=0.0):
+        with _Maybe(None if self.layer_norm else NoLayerNorm()):
+            return self._learn(batch, bc_batch, noise, bc_weight_now, bc_warm_up_weight)
+
+    def _learn(self, batch, bc_batch, noise, bc_weight_now=0.0, bc_warm_up_weight=0.0):
         """batch = (s[B,13], a[B,4], s'[B,13], r[B], d[B]) already mixed buffer ++ expert rows (HIRL.py:223-243);
         bc_batch = (s_bc[B,13], a_bc[B,4]) (HIRL.py:248-251); noise = the ONE (4,) N(0, 0.2^2) draw shared by the
         whole batch (HIRL.py:265), unclamped.  Returns the reference's 6-tuple (HIRL.py:334)."""
@@ -220,7 +258,7 @@ class HirlOracle:
         q1, q2 = critic_forward(self.critic, s, a, self.slope)
         critic_loss = F.mse_loss(q1, y) + F.mse_loss(q2, y)
         keys = list(self.critic)
-        grads = dict(zip(keys, torch.autograd.grad(critic_loss, [self.critic[k] for k in keys])))
+        grads = dict(zip(keys, _grads(critic_loss, self.critic, keys)))
         self.last_grads["critic"] = {k: g.clone() for k, g in grads.items()}
         self.opt_critic.step(self.critic, grads)
         # U10: delayed actor step with the UPDATED critic  HIRL.py:291-330
@@ -247,12 +285,12 @@ class HirlOracle:
                 actor_loss = rl_loss
             akeys = list(self.actor)
             if self.split_actor_grads and self.use_bc:
-                g_bc = torch.autograd.grad(bc_loss, [self.actor[k] for k in akeys], retain_graph=True)
-                g_rl = torch.autograd.grad(rl_loss, [self.actor[k] for k in akeys])
+                g_bc = _grads(bc_loss, self.actor, akeys, retain_graph=True)
+                g_rl = _grads(rl_loss, self.actor, akeys)
                 w = float(self.bc_weight)
                 agrads = {k: w * a + (1.0 - w) * b for k, a, b in zip(akeys, g_bc, g_rl)}
             else:
-                agrads = dict(zip(akeys, torch.autograd.grad(actor_loss, [self.actor[k] for k in akeys])))
+                agrads = dict(zip(akeys, _grads(actor_loss, self.actor, akeys)))
             self.last_grads["actor"] = {k: g.clone() for k, g in agrads.items()}
             self.opt_actor.step(self.actor, agrads)
             self.actor_loss, self.rl_loss = actor_loss.item(), rl_loss.item()
@@ -267,9 +305,10 @@ class HirlOracle:
 def bc_train_actor(o, bc_batch):
     """BC.Agent.train_actor (BC.py:160-185) on an oracle built with slope=0.01: mse(actor(s), a), backward, Adam."""
     bs, ba = (torch.as_tensor(x, dtype=torch.float32) for x in bc_batch)
-    loss = F.mse_loss(actor_forward(o.actor, bs, o.slope), ba)
+    with _Maybe(None if o.layer_norm else NoLayerNorm()):
+        loss = F.mse_loss(actor_forward(o.actor, bs, o.slope), ba)
     keys = list(o.actor)
-    grads = dict(zip(keys, torch.autograd.grad(loss, [o.actor[k] for k in keys])))
+    grads = dict(zip(keys, _grads(loss, o.actor, keys)))
     o.last_grads["actor"] = {k: g.clone() for k, g in grads.items()}
     o.opt_actor.step(o.actor, grads)
     return loss.item()

@@ -22,6 +22,15 @@ def make_params(seed, h1=256, h2=512):
             "bc_actor": H.init_actor(rng, h1=h1, h2=h2)}
 
 
+def plain_layernorm(params):
+    """the same networks with every LayerNorm module at (1, 0): what a layerNorm=False agent holds (the reference constructs the modules
+    either way and never uses or trains them in that mode, HIRL.py:28,33,114,119)"""
+    out = {}
+    for net, p in params.items():
+        out[net] = {k: (np.ones_like(v) if k.endswith(".weight") else np.zeros_like(v)) if k.startswith("layernorm") else v for k, v in p.items()}
+    return out
+
+
 def _obs(rng, n):
     s = rng.uniform(-1, 1, (n, 13)).astype(np.float32)
     s[:, 7] = np.where(rng.random(n) < 0.5, 1, -1)

@@ -17,6 +17,9 @@ returned tuples for K consecutive calls, and per-call probes of every network (s
   td3_learn.npz           G5  agents.TD3.Agent.learn (leaky_relu nets), 8 calls
   bc_train.npz                agents.BC.Agent.train_actor (leaky_relu actor), 6 calls
   hirl_choose_action.npz  G7  chooseAction / chooseActionSmallNoise / chooseActionNoNoise on fixed states
+  hirl_learn_soft_noln.npz    the same Agent built with layerNorm=False (the `else` branches of HIRL.py:58-80,82-97,126-140), soft schedule,
+                              10 calls + chooseActionNoNoise on 32 states; its LayerNorm modules are loaded at (1, 0) (they exist in the
+                              state_dict, HIRL.py:28,33,114,119, and are never used or trained)   [python gen_hirl_golden.py noln]
 """
 import os
 import sys
@@ -105,9 +108,11 @@ def fill_buffers(agent, data, with_expert):
             agent.expert_buffer.store(row[0:13], row[13:17], row[17:30], row[30], row[31], 0)
 
 
-def run_hirl(mode, expert_num, schedule):
+def run_hirl(mode, expert_num, schedule, layer_norm=True):
     params, data = D.make_params(D.PARAM_SEED), D.make_data(D.DATA_SEED)
-    agent = ref_hirl.Agent(1e-3, 1e-3, 13, 4, 256, 512, 0.005, 0.99, 100000, 128, True, "g", data["expert_s"], data["expert_a"], 0.5, True)
+    if not layer_norm:
+        params = D.plain_layernorm(params)
+    agent = ref_hirl.Agent(1e-3, 1e-3, 13, 4, 256, 512, 0.005, 0.99, 100000, 128, layer_norm, "g", data["expert_s"], data["expert_a"], 0.5, True)
     load_nets(agent, params, True)
     fill_buffers(agent, data, True)
     rec = Recorder(1234)
@@ -135,7 +140,9 @@ def run_hirl(mode, expert_num, schedule):
         bc_w_in=np.asarray(w_in, np.float64), warm_in=np.asarray(warm_in, np.float64), out=np.asarray(outs, np.float64),
         probe_sum=np.asarray([[p[0] for p in row] for row in prb]), probe_abs=np.asarray([[p[1] for p in row] for row in prb]),
         probe_val=np.asarray([[p[2] for p in row] for row in prb], np.float32),
-        data_checksum=D.checksum(data), param_checksum=D.checksum(params))
+        data_checksum=D.checksum(data), param_checksum=D.checksum(params),
+        **({} if layer_norm else {"states": data["replay"][:32, 0:13].astype(np.float32),
+                                  "action_clean_after": np.asarray([agent.chooseActionNoNoise(st) for st in data["replay"][:32, 0:13].astype(np.float64)])}))
     print(mode, "bc_weight out:", [round(o[5], 4) for o in outs], "critic loss", [round(o[0], 3) for o in outs[:4]])
 
 
@@ -202,6 +209,10 @@ def run_choose_action():
 
 if __name__ == "__main__":
     _choice, _normal = np.random.choice, torch.normal
+    if sys.argv[1:] == ["noln"]:
+        run_hirl("soft_noln", 0, lambda ep: (100, 0.2 - 0.1 * ep), layer_norm=False)
+        np.random.choice, torch.normal = _choice, _normal
+        sys.exit(0)
     run_hirl("soft_e0", 0, lambda ep: (100, 0.2 - 0.1 * ep))
     run_hirl("soft_e64", 64, lambda ep: (100, 0.0))
     run_hirl("fixed_e32", 32, lambda ep: (0.5, 0.0))
@@ -209,4 +220,5 @@ if __name__ == "__main__":
     run_td3()
     run_bc()
     run_choose_action()
+    run_hirl("soft_noln", 0, lambda ep: (100, 0.2 - 0.1 * ep), layer_norm=False)
     np.random.choice, torch.normal = _choice, _normal

@@ -117,6 +117,38 @@ def test_agent_facade_reads_like_the_reference():
     assert agent.actorTrainable and agent.update_count == 2
 
 
+def test_agent_facade_without_layernorm():
+    """HIRLAgent(..., layerNorm=False, ...) — a constructor argument of the reference (HIRL.py:149-152; the driver passes True,
+    train_all.py:204): acting and learning follow the `else` branches of HIRL.py:58-80,126-140."""
+    from hirl4ucav_amd.agents.HIRL import Agent as HIRLAgent
+    from hirl4ucav_amd.utils.seed import set_seed
+
+    params, data = D.make_params(5), D.make_data(6)  # (LayerNorm entries perturbed: a layerNorm=False agent must ignore them)
+    set_seed(7)
+    agent = HIRLAgent(1e-3, 1e-3, 13, 4, 256, 512, 0.005, 0.99, 10 ** 5, 128, False, "Harfang_GYM", data["expert_s"], data["expert_a"], 0.5, True)
+    for net, p in ((agent.actor, params["actor"]), (agent.targetActor, params["actor"]), (agent.critic, params["critic"]),
+                   (agent.targetCritic, params["critic"]), (agent.bc_actor, params["bc_actor"])):
+        net.load_state_dict({k: torch.tensor(v) for k, v in p.items()})
+    plain = D.plain_layernorm(params)
+    o = H.HirlOracle(plain["actor"], plain["critic"], plain["bc_actor"], layer_norm=False)
+    s = data["replay"][0, 0:13].astype(np.float64)
+    np.testing.assert_allclose(agent.chooseActionNoNoise(s), o.choose_action(s.astype(np.float32)), rtol=1e-5, atol=1e-6)
+    o_ln = H.HirlOracle(params["actor"], params["critic"], params["bc_actor"])
+    assert np.abs(agent.chooseActionNoNoise(s) - o_ln.choose_action(s.astype(np.float32))).max() > 1e-3  # it is NOT the LayerNorm network
+    for row in data["replay"][:600]:
+        agent.store(row[0:13], row[13:17], row[17:30], row[30], row[31], 0)
+    for k in range(2):
+        st_r, st_np, st_t = random.getstate(), np.random.get_state(), torch.get_rng_state()
+        idx = random.sample(range(len(agent.buffer)), 128)
+        ibc = np.random.choice(D.N_EXPERT, 128, replace=False)
+        noise = torch.normal(mean=torch.zeros(4), std=torch.ones(4) * 0.2).numpy()
+        random.setstate(st_r); np.random.set_state(st_np); torch.set_rng_state(st_t)  # noqa: E702
+        ret = agent.learn(0.5, 0, 0.0)
+        rows = data["replay"][idx]
+        ref = o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), (data["expert_s"][ibc], data["expert_a"][ibc]), noise, 0.5, 0.0)
+        np.testing.assert_allclose([float(v) for v in ret], ref, rtol=5e-5, atol=5e-6, err_msg=f"call {k}")
+
+
 def test_checkpoints_round_trip(tmp_path):
     from hirl4ucav_amd.agents.TD3 import Agent as TD3Agent
 

@@ -311,6 +311,37 @@ def test_learn_matches_oracle_and_reference(eng_mod, mode, golden_dir):
     assert e.critic_step == 10 and e.actor_step == 5 and e.update_count == 5 and e.actor_trainable
 
 
+def test_learn_without_layernorm_matches_oracle_and_reference(eng_mod, golden_dir):
+    """The reference's `layerNorm=False` networks (HIRL.py:70-80,92-97,135-138) through HxHyper.no_layernorm / noise_mode + 16: 10 consecutive
+    learn() calls against the oracle (identical states, every gradient entry) and the reference's recorded run, then chooseActionNoNoise."""
+    g = np.load(os.path.join(golden_dir, "hirl_learn_soft_noln.npz"))
+    params, data = D.plain_layernorm(D.make_params(D.PARAM_SEED)), D.make_data(D.DATA_SEED)
+    ring, exp, bc = device_tables(data)
+    e = eng_mod.HirlEngine(batch=128, layer_norm=False)
+    e.load_params(params["actor"], params["critic"], params["bc_actor"])
+    o = H.HirlOracle(params["actor"], params["critic"], params["bc_actor"], layer_norm=False)
+    for k in range(g["out"].shape[0]):
+        w_in = 100 if g["bc_w_in"][k] == 100 else float(g["bc_w_in"][k])
+        warm = float(g["warm_in"][k])
+        was_actor_call = e.actor_trainable
+        sync_oracle(o, e, eng_mod)
+        e.assemble(ring, torch.from_numpy(g["idx_buf"][k].astype(np.int32)).cuda(), bc_table=bc, idx_bc=torch.from_numpy(g["idx_bc"][k].astype(np.int32)).cuda())
+        e.learn(noise=torch.from_numpy(g["noise"][k]).cuda(), bc_weight_now=w_in, bc_warm_up_weight=warm)
+        got = e.losses_host()
+        rows = data["replay"][g["idx_buf"][k]]
+        ob = (rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31])
+        ref = oracle_learn_checked(eng_mod, e, o, (ob, (data["expert_s"][g["idx_bc"][k]], data["expert_a"][g["idx_bc"][k]]), g["noise"][k], w_in, warm),
+                                   was_actor_call, f"noln call {k} gradients")
+        assert_losses(got, ref, f"noln call {k} vs oracle")
+        check_params(e, o, eng_mod, f"noln call {k} params", was_actor_call)
+        assert_losses(got, g["out"][k], f"noln call {k} vs reference golden")
+        check_probes_free_running(e, eng_mod, g, k, f"noln call {k}")
+    a = e.act(torch.from_numpy(g["states"]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(a, g["action_clean_after"], rtol=1e-5, atol=3e-5)  # (free-running: five actor steps of fp32 summation-order drift)
+    sd = e.state_dicts()
+    assert torch.all(sd["actor"]["layernorm1.weight"] == 1) and torch.all(sd["critic"]["layernorm4.bias"] == 0)  # untouched, as in the reference
+
+
 def test_td3_learn_matches_reference(eng_mod, golden_dir):
     g = np.load(os.path.join(golden_dir, "td3_learn.npz"))
     params, data = D.make_params(D.PARAM_SEED), D.make_data(D.DATA_SEED)

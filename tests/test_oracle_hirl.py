@@ -100,3 +100,45 @@ def test_bc_train_actor_matches_reference(golden_dir):
         s, a, v = D.net_probe(H.flatten(o.actor, H.ACTOR_KEYS))
         np.testing.assert_allclose(v, g["probe_val"][k], rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(a, g["probe_abs"][k], rtol=1e-6)
+
+
+def test_hirl_learn_without_layernorm_matches_reference(golden_dir):
+    """Agent(..., layerNorm=False, ...): the `else` branches of HIRL.py:58-80,82-97,126-140 (Linear -> ReLU -> Linear -> ReLU -> final),
+    10 consecutive learn() calls and chooseActionNoNoise afterwards, recorded from the reference; the LayerNorm modules stay at (1, 0)."""
+    g = np.load(os.path.join(golden_dir, "hirl_learn_soft_noln.npz"))
+    params, data = D.plain_layernorm(D.make_params(D.PARAM_SEED)), D.make_data(D.DATA_SEED)
+    assert D.checksum(params) == str(g["param_checksum"]) and D.checksum(data) == str(g["data_checksum"])
+    o = H.HirlOracle(params["actor"], params["critic"], params["bc_actor"], layer_norm=False)
+    for k in range(g["out"].shape[0]):
+        batch, bc = batches_for_call(g, data, k)
+        w_in = g["bc_w_in"][k]
+        ret = o.learn(batch, bc, g["noise"][k], 100 if w_in == 100 else float(w_in), float(g["warm_in"][k]))
+        np.testing.assert_allclose(ret, g["out"][k], rtol=1e-5, atol=1e-6, err_msg=f"noln call {k}")
+        check_probes(g, k, [(o.actor, H.ACTOR_KEYS), (o.critic, H.CRITIC_KEYS), (o.target_actor, H.ACTOR_KEYS),
+                            (o.target_critic, H.CRITIC_KEYS)])
+    for key in ("layernorm1.weight", "layernorm2.bias"):  # never used, never trained
+        assert torch.equal(o.actor[key].detach(), torch.as_tensor(params["actor"][key]))
+    for i, s in enumerate(g["states"]):
+        np.testing.assert_allclose(o.choose_action(s), g["action_clean_after"][i], rtol=1e-5, atol=2e-6)
+    # the LayerNorm really is off: the same call with it on gives another loss
+    o2 = H.HirlOracle(params["actor"], params["critic"], params["bc_actor"])
+    batch, bc = batches_for_call(g, data, 0)
+    assert abs(o2.learn(batch, bc, g["noise"][0], 100, float(g["warm_in"][0]))[0] - g["out"][0][0]) > 1e-2
+
+
+def test_rounded_operand_switch_is_scoped_and_close_to_fp32():
+    """Bf16Layer2 (the bf16 update path's checker) changes the 256 <-> 512 products only inside the `with` block, and only by bf16 rounding."""
+    params, data = D.make_params(3), D.make_data(4)
+    rows = data["replay"][:128]
+    batch = (rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31])
+    bc = (data["expert_s"][:128], data["expert_a"][:128])
+    noise = np.zeros(4, np.float32)
+    a, b, c = (H.HirlOracle(params["actor"], params["critic"], params["bc_actor"]) for _ in range(3))
+    la = a.learn(batch, bc, noise, 0.5)
+    with H.Bf16Layer2():
+        lb = b.learn(batch, bc, noise, 0.5)
+    lc = c.learn(batch, bc, noise, 0.5)
+    assert la == lc and la != lb
+    np.testing.assert_allclose(lb[:4], la[:4], rtol=3e-2)
+    g32, g16 = a.last_grads["critic"]["full2.weight"], b.last_grads["critic"]["full2.weight"]
+    assert float((g32 - g16).abs().max()) < 0.15 * float(g32.abs().max())  # (bf16 rounding moves a few units across their ReLU kink)
