@@ -788,8 +788,8 @@ void launch_bwd_t(const BwdArgs& G, hipStream_t st) {
     BwdArgsC C{};
     for (int j = 0; j < G.njobs; ++j) C.job[j] = pack_bwd(G.job[j], G);
     C.images = G.images;
-    static const int rowmap = getenv("HX_XCD_ROWMAP") ? atoi(getenv("HX_XCD_ROWMAP")) : 1;
-    C.rowmap = rowmap;
+    static const int rowmap = getenv("HX_XCD_ROWMAP") ? atoi(getenv("HX_XCD_ROWMAP")) : 3;  // bit 1: bwd_l2
+    C.rowmap = (rowmap >> 1) & 1;
     const dim3 grid(bwd_blocks(G, GRP <= 2 ? RT / 2 : RT), G.njobs);
     if constexpr (GRP <= 2) {  // the bf16 update path covers the HIRL / TD3 / BC jobs (GRP 3 = SAC's given head gradients: fp32)
         static const int dbg_off = getenv("HX_DBG_BF16_OFF") ? atoi(getenv("HX_DBG_BF16_OFF")) : 0;
@@ -815,8 +815,8 @@ void launch_fwd(const FwdArgs& F, hipStream_t st) {
         C.job[j].slope = F.slope;
     }
     C.slope = F.slope; C.zero_nf = F.zero_nf; C.zero_f = F.zero_f; C.zero_i = F.zero_i; C.images = F.images;
-    static const int rowmap = getenv("HX_XCD_ROWMAP") ? atoi(getenv("HX_XCD_ROWMAP")) : 1;  // (0: the plain order; A/B on one box: fp32 -0.3 us, bf16 -0.55 us per step)
-    C.rowmap = rowmap;
+    static const int rowmap = getenv("HX_XCD_ROWMAP") ? atoi(getenv("HX_XCD_ROWMAP")) : 3;  // bit 0: fwd_l2 (0: the plain order everywhere)
+    C.rowmap = rowmap & 1;
     const int tiles = fwd_row_tiles(F), per_job = tiles / F.njobs;
     const bool relu = F.slope == 0.0f;  // compile-time ReLU instantiations (hx_nn.h act_f)
     static const int dbg_off = getenv("HX_DBG_BF16_OFF") ? atoi(getenv("HX_DBG_BF16_OFF")) : 0;
