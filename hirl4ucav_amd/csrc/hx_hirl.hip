@@ -65,6 +65,7 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_critic_grads: batch must be a positive multiple of 16");
     hipStream_t st = (hipStream_t)stream;
     const Mlp mA{13, 4, Hy->no_layernorm ? 1 : 0}, mQ{17, 1, Hy->no_layernorm ? 1 : 0};  // layerNorm = False: HIRL.py:70-80,92-97,135-138
+    (void)mA; (void)mQ;
     const int B = Bt->batch;
     SampleDev SD{};
     bool fused = false;
@@ -165,6 +166,7 @@ int hx_hirl_actor_backward(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_actor_backward: batch must be a positive multiple of 16");
     hipStream_t st = (hipStream_t)stream;
     const Mlp mA{13, 4, Hy->no_layernorm ? 1 : 0}, mQ{17, 1, Hy->no_layernorm ? 1 : 0};  // layerNorm = False: HIRL.py:70-80,92-97,135-138
+    (void)mA; (void)mQ;
     const int B = Bt->batch;
     Slot s[S_COUNT];
     make_slots(N, B, s);
@@ -237,6 +239,7 @@ static int actor_wgrad_impl(const HxNets* N, const HxHyper* Hy, int32_t batch, i
                             float warm, void* stream, int adam_step, bool polyak) {
     HX_REQUIRE(N && Hy && batch > 0 && count_batch > 0, "hx_hirl_actor_wgrad: bad arguments");
     const Mlp mA{13, 4, Hy->no_layernorm ? 1 : 0}, mQ{17, 1, Hy->no_layernorm ? 1 : 0};  // layerNorm = False: HIRL.py:70-80,92-97,135-138
+    (void)mA; (void)mQ;
     Slot s[S_COUNT];
     make_slots(N, batch, s);
     const bool bc = Hy->use_bc != 0;
@@ -278,6 +281,7 @@ int hx_hirl_actor_wgrad(const HxNets* N, const HxHyper* Hy, int32_t batch, int32
 int hx_hirl_actor_wgrad_split(const HxNets* N, const HxHyper* Hy, int32_t batch, float* msg, void* stream) {
     HX_REQUIRE(N && Hy && batch > 0 && msg && (reinterpret_cast<uintptr_t>(msg) & 15u) == 0, "hx_hirl_actor_wgrad_split: bad arguments");
     const Mlp mA{13, 4, Hy->no_layernorm ? 1 : 0}, mQ{17, 1, Hy->no_layernorm ? 1 : 0};  // layerNorm = False: HIRL.py:70-80,92-97,135-138
+    (void)mA; (void)mQ;
     Slot s[S_COUNT];
     make_slots(N, batch, s);
     const bool bc = Hy->use_bc != 0;
@@ -324,6 +328,7 @@ int hx_bc_train_actor(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int
     HX_REQUIRE(N && Bt && Hy && Bt->bc_rows && Bt->batch > 0 && Bt->batch % 16 == 0 && step >= 1, "hx_bc_train_actor: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const Mlp mA{13, 4, Hy->no_layernorm ? 1 : 0}, mQ{17, 1, Hy->no_layernorm ? 1 : 0};  // layerNorm = False: HIRL.py:70-80,92-97,135-138
+    (void)mA; (void)mQ;
     const int B = Bt->batch;
     Slot s[S_COUNT];
     make_slots(N, B, s);
