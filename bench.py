@@ -870,9 +870,12 @@ def run_rank(args):
                 res["cpu_baseline"] = baseline_port_sac(args, 0.7 * budget)
                 res["cpu_baseline"]["host"] = f"{model}, {cores} logical cores"
                 res["cpu_baseline"]["b1_batched_cpu"] = baseline_batched_cpu(0.3 * budget)
-        print(json.dumps(res), flush=True)
     if pg:
         torch.distributed.destroy_process_group()
+        import ctypes  # RCCL writes a version banner through C stdio, which a redirected stdout holds back until exit: let it out
+        ctypes.CDLL(None).fflush(None)  # first, so that the record is the LAST line of stdout
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     return 0
 
 

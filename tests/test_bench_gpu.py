@@ -33,6 +33,7 @@ def run(cmd, env=None):
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]  # ONE JSON line, from rank 0
+    assert [l for l in p.stdout.splitlines() if l.strip()][-1] == lines[0], p.stdout[-600:]  # ... and nothing after it (RCCL's banner comes first)
     return json.loads(lines[0])
 
 
