@@ -872,8 +872,8 @@ def run_rank(args):
                 res["cpu_baseline"]["b1_batched_cpu"] = baseline_batched_cpu(0.3 * budget)
     if pg:
         torch.distributed.destroy_process_group()
-        import ctypes  # RCCL writes a version banner through C stdio, which a redirected stdout holds back until exit: let it out
-        ctypes.CDLL(None).fflush(None)  # first, so that the record is the LAST line of stdout
+        # RCCL writes a version banner through C stdio, which a redirected stdout holds back until exit: let it out first, so that the
+        ctypes.CDLL(None).fflush(None)  # record is the LAST line of stdout
     if rank == 0:
         print(json.dumps(res), flush=True)
     return 0

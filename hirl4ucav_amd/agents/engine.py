@@ -403,11 +403,11 @@ class HirlEngine:
             mode = 3
         self.act_calls += 1
         if self.act_dtype == "bf16":
-            _lib.call("hx_actor_act_step_bf16", self.actor.data_ptr(), self.w2_bf16.data_ptr(), env.state.data_ptr(), n, n, env.obs.data_ptr(),
+            _lib.call("hx_actor_act_step_bf16", self.actor.data_ptr(), self.w2_bf16.data_ptr(), env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(),
                       out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
                       env.reward.data_ptr(), env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
             return out, env.obs, env.reward, env.done, env.success
-        _lib.call("hx_actor_act_step_f32i", self.actor.data_ptr(), self.w2_f32i.data_ptr(), env.state.data_ptr(), n, n, env.obs.data_ptr(),
+        _lib.call("hx_actor_act_step_f32i", self.actor.data_ptr(), self.w2_f32i.data_ptr(), env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(),
                   out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
                   env.reward.data_ptr(), env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
         return out, env.obs, env.reward, env.done, env.success

@@ -175,7 +175,7 @@ class SacEngine:
             out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         mode = 0 if not explore else (1 if eps is not None else 2)
         self.act_calls += 1
-        _lib.call("hx_sac_act_step_f32i", self.policy.data_ptr(), self.w2_f32i.data_ptr(), env.state.data_ptr(), n, n, env.obs.data_ptr(),
+        _lib.call("hx_sac_act_step_f32i", self.policy.data_ptr(), self.w2_f32i.data_ptr(), env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(),
                   out.data_ptr(), mode, _lib.ptr(eps), int(seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(), env.done.data_ptr(),
                   env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
         return out, env.obs, env.reward, env.done, env.success

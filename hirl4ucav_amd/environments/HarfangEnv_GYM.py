@@ -69,7 +69,7 @@ class HarfangEnv:
     def _readback(self):
         """-> (state words [37], obs [13] float64, reward, success) of the one env, through the packed row"""
         e = self._env
-        _lib.call("hx_env_pack_row", e.state.data_ptr(), 1, 1, 0, e.obs.data_ptr(), e.reward.data_ptr(), e.done.data_ptr(), e.success.data_ptr(),
+        _lib.call("hx_env_pack_row", e.state.data_ptr(), 1, e.pitch, 0, e.obs.data_ptr(), e.reward.data_ptr(), e.done.data_ptr(), e.success.data_ptr(),
                   self._h_row.data_ptr(), _lib.stream_ptr())
         self._stream_sync()
         row = self._np_row

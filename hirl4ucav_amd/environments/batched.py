@@ -16,7 +16,7 @@ SCENARIOS = {"straight_line": 0, "serpentine": 1, "circular": 2}
 
 class BatchedHarfangEnv:
     def __init__(self, num_envs, scenario="straight_line", device="cuda", seed=0, max_step=0, auto_reset=True,
-                 random_reset=True, env_id0=0, replay=None, collect_stats=True, layout=0):
+                 random_reset=True, env_id0=0, replay=None, collect_stats=True, layout=0, pitch=0):
         self.n = int(num_envs)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -32,7 +32,13 @@ class BatchedHarfangEnv:
             self.scenario_all = 0
             self.scenario = torch.as_tensor(scenario, dtype=torch.int32, device=self.device).contiguous()
         d = self.device
-        self.state = torch.zeros((_lib.ENV_WORDS, self.n), dtype=torch.float32, device=d)
+        # struct-of-arrays state: word w of env i at state[w, i].  pitch (>= n, floats) is the distance between two words' arrays — the
+        # C ABI's `stride`.  0 = the default: n, and n + 1,056 floats from 262,144 envs on — with the arrays a power of two apart the 37
+        # streams of a launch lean on the same HBM channels: 1M envs 105.8 -> 102.6 us per launch (tools/ubench/env_pitch.py; nothing at
+        # 65,536 or 4M envs).
+        self.pitch = max(int(pitch), self.n) if pitch else (self.n + 1056 if self.n >= 262144 else self.n)
+        self._state_store = torch.zeros((_lib.ENV_WORDS, self.pitch), dtype=torch.float32, device=d)
+        self.state = self._state_store[:, :self.n]
         self.obs = torch.zeros((self.n, _lib.OBS_DIM), dtype=torch.float32, device=d)
         self.reward = torch.zeros(self.n, dtype=torch.float32, device=d)
         self.done = torch.zeros(self.n, dtype=torch.uint8, device=d)
@@ -59,7 +65,7 @@ class BatchedHarfangEnv:
         """reset() / random_reset() of every env (or of the envs with mask != 0) -> obs [N, 13]."""
         if mask is not None:
             mask = mask.to(self.device, torch.uint8).contiguous()
-        _lib.call("hx_env_reset", _lib.ptr(self.state), self.n, self.n, _lib.ptr(mask), _lib.ptr(self.scenario),
+        _lib.call("hx_env_reset", _lib.ptr(self.state), self.n, self.pitch, _lib.ptr(mask), _lib.ptr(self.scenario),
                   self.scenario_all, int(self.random_reset), self.seed, self.env_id0, _lib.ptr(self.episode_ctr),
                   _lib.ptr(self.obs), _lib.stream_ptr())
         return self.obs
@@ -68,7 +74,7 @@ class BatchedHarfangEnv:
         """actions [N, 4] fp32 on the device -> (obs [N,13], reward [N], done [N] u8, success [N] i8)."""
         if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(self.device, torch.float32).contiguous()
-        _lib.call("hx_env_step", _lib.ptr(self.state), self.n, self.n, _lib.ptr(actions), _lib.ptr(self.obs),
+        _lib.call("hx_env_step", _lib.ptr(self.state), self.n, self.pitch, _lib.ptr(actions), _lib.ptr(self.obs),
                   _lib.ptr(self.reward), _lib.ptr(self.done), _lib.ptr(self.success), ctypes.byref(self._opts),
                   _lib.stream_ptr())
         return self.obs, self.reward, self.done, self.success
@@ -76,7 +82,7 @@ class BatchedHarfangEnv:
     def step_from(self, actions_ptr):
         """step() with the actions at a raw address the DEVICE can read — device memory, or pinned host memory it maps (the N = 1 facade
         passes its pinned action buffer: no upload call)."""
-        _lib.call("hx_env_step", _lib.ptr(self.state), self.n, self.n, actions_ptr, _lib.ptr(self.obs),
+        _lib.call("hx_env_step", _lib.ptr(self.state), self.n, self.pitch, actions_ptr, _lib.ptr(self.obs),
                   _lib.ptr(self.reward), _lib.ptr(self.done), _lib.ptr(self.success), ctypes.byref(self._opts),
                   _lib.stream_ptr())
         return self.obs, self.reward, self.done, self.success
@@ -87,7 +93,7 @@ class BatchedHarfangEnv:
         self._opts.ev_start, self._opts.ev_stop = getattr(start, "value", start), getattr(stop, "value", stop)
 
     def rearm(self, mask=None):
-        _lib.call("hx_env_rearm", _lib.ptr(self.state), self.n, self.n, _lib.ptr(mask), _lib.stream_ptr())
+        _lib.call("hx_env_rearm", _lib.ptr(self.state), self.n, self.pitch, _lib.ptr(mask), _lib.stream_ptr())
 
     def stats_dict(self):
         if self.stats is None:

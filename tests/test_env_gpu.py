@@ -390,3 +390,36 @@ def test_nonfinite_actions_are_neutralised(hx):
     assert np.isfinite(rows).all()
     key = lambda x: np.lexsort(x.view(np.uint32).T[::-1])  # noqa: E731
     np.testing.assert_array_equal(rows[key(rows)].view(np.uint32), ring[:n][key(ring[:n])].view(np.uint32))
+
+
+def test_state_pitch_is_only_an_address_matter(hx):
+    """The struct-of-arrays state may sit at any pitch >= n (the C ABI's `stride`; from 262,144 envs on the default adds 1,056 floats,
+    tools/ubench/env_pitch.py): same bits as the dense layout, for the stand-alone env kernel (both launch shapes) and through a snapshot."""
+    n, steps = 5000, 12
+    rng = np.random.default_rng(9)
+    acts = [torch.from_numpy(rng.uniform(-1, 1, (n, 4)).astype(np.float32)).cuda() for _ in range(steps)]
+
+    def run(pitch, layout):
+        rep = hx.Replay(n * steps)
+        env = hx.Env(n, scenario="serpentine", seed=3, max_step=7, auto_reset=True, random_reset=True, replay=rep, pitch=pitch, layout=layout)
+        env.reset()
+        outs = []
+        for a in acts:
+            o, r, d, s = env.step(a)
+            outs.append((o.clone(), r.clone(), d.clone(), s.clone()))
+        torch.cuda.synchronize()
+        return env, rep, outs
+
+    from hirl4ucav_amd import _lib
+    e0, r0, o0 = run(0, 0)
+    assert e0.pitch == n and hx.Env(1 << 18, scenario="circular").pitch == (1 << 18) + 1056
+    for pitch, layout in ((n + 1056, 0), (n + 32, _lib.layout(True, 64)), (2 * n, _lib.layout(False, 256))):
+        e1, r1, o1 = run(pitch, layout)
+        assert e1.pitch == pitch and e1.state.shape == e0.state.shape
+        assert torch.equal(e1.state, e0.state)
+        rows = [r.ring.cpu().numpy().view(np.uint32) for r in (r0, r1)]  # (workgroups reserve their ring slots in any order: same rows, as a set)
+        rows = [a[np.lexsort(a.T[::-1])] for a in rows]
+        np.testing.assert_array_equal(rows[0], rows[1])
+        for a, b in zip(o0, o1):
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
+        assert float(e1._state_store[:, n:].abs().max()) == 0.0  # nothing written into the padding
