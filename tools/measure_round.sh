@@ -23,6 +23,8 @@ done <<'CFGS'
 --envs 16384 --scenario mixed
 --envs 16384 --scenario mixed --dtype bf16
 --envs 8192 --scenario circular --type linear --bc_weight 0.5
+--envs 65536 --scenario circular --type linear --bc_weight 0.5
+--envs 131072 --scenario mixed --dtype bf16
 --actions uniform
 --staged
 CFGS
