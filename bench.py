@@ -795,15 +795,17 @@ def run_rank(args):
     }
     env_roof = {"kernel": "env_step_kernel<PAIR, INSERT, EPB> (hx_env.hip)", "bound": "hbm",
                 "achieved": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": (profile_traffic(args.envs) or {}).get("bytes"),
                 "bytes_per_launch": ENV_BYTES_FUSED * args.envs, "us_per_launch": round(env_kernel_us, 2), "launches_timed": len(kern),
                 "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the launches of "
                           "the second pass in which act and env step are issued as two launches",
-                "traffic_note": "PMC counters are not collectable inside this process: see traffic_from_profiles",
+                "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes of this kernel at this size (not collectable inside this "
+                                "process): see traffic_from_profiles; null when no pass exists for the size",
                 "traffic_from_profiles": profile_traffic(args.envs)}
     if fused:
         # the kernel the timed loop RUNS: policy inference + env step + replay insert in one launch.  Both roofs are quoted; `bound` names the nearer.
         us = float(np.mean(fused))
+        fused_pmc = profile_traffic(f"fused_{args.envs}") if (args.agent == "hirl" and args.dtype == "f32") else None
         flop = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
         peak = FP32_MATRIX_PEAK_TFLOPS if (args.dtype == "f32" or args.agent == "sac") else BF16_MATRIX_PEAK_TFLOPS
         tf, gb = flop / us / 1e6, ENV_BYTES_FUSED * args.envs / us / 1e3
@@ -812,12 +814,15 @@ def run_rank(args):
         mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(mf, 4), "flop_per_launch": flop}
         first, second = (mfma, hbm) if mf >= hf else (hbm, mfma)
         res["roofline"] = {"kernel": "act_fused_kernel<NRT, GAUSS, ENV = true, ...> (hx_act.hip): policy inference + env step + fused replay insert, the dominant "
-                                     "kernel of the timed loop", **first, "traffic": None, "other_roof": second,
+                                     "kernel of the timed loop", **first, "traffic": (fused_pmc or {}).get("bytes"), "other_roof": second,
                            "us_per_launch": round(us, 2), "launches_timed": len(fused),
                            "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the fused launches "
                                      "of the second pass (3 of every 4 steps)",
                            "note": "latency-bound at this size: 256 workgroups, one round; neither roof is near (DESIGN.md section 4)",
-                           "traffic_note": "PMC counters are not collectable inside this process: profiles/ holds the rocprofv3 --pmc passes"}
+                           "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes of the fp32 HIRL kernel at this size (FETCH_SIZE calibrated "
+                                           "x2, WRITE_SIZE: tools/pmc_env_passes.sh); each of the 8 XCDs pulls the policy's 0.55 MB of weights into its own L2 "
+                                           "once per launch, hence ~3.4 x the env's 550 B/env-step; null for other dtypes / agents / sizes",
+                           "traffic_from_profiles": fused_pmc}
         res["roofline_env_kernel"] = env_roof
     else:
         res["roofline"] = env_roof

@@ -79,7 +79,10 @@ def test_bench_single_gpu_line():
     assert 0 < c["b0_reference_plumbing"]["value"] < 5000 and c["b1_batched_cpu"]["value"] > c["value"] and c["b2_eager_rocm_learn"]["value"] > 0
     sw = d["roofline_env_sweep"]
     assert [r["envs_per_launch"] for r in sw] == [4096, 65536, 1 << 20, 1 << 22] and sw[2]["frac"] > 0.4  # the >= 40 % HBM evidence
-    assert d["roofline"]["traffic"] is None
+    # traffic: the committed PMC passes of THIS kernel at THIS size (fp32 HIRL, 4,096 envs), labelled as a profile artefact; never invented
+    tp = d["roofline"]["traffic_from_profiles"]
+    assert d["roofline"]["traffic"] == tp["bytes"] == tp["fetch_bytes"] + tp["write_bytes"] and tp["source"] == "profiles/pmc_env_traffic.json"
+    assert d["roofline_env_kernel"]["traffic"] == d["roofline_env_kernel"]["traffic_from_profiles"]["bytes"]
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")

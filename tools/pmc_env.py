@@ -1,6 +1,7 @@
 """Workload for the HBM-traffic counters of the env-step kernel (run under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one
 counter per pass): a calibration copy with the same access shape over a known byte count, then env steps at HX_PMC_ENVS envs
-(default 1,048,576)."""
+(default 1,048,576); HX_PMC_FUSED=1 adds six launches of the fused act + env kernel at that size (<= 8,192 envs).  tools/pmc_traffic_json.py turns
+the passes' CSV files into profiles/pmc_env_traffic.json."""
 import os
 import sys
 import torch
@@ -21,5 +22,11 @@ env.reset()
 act = torch.rand(n, 4, device="cuda") * 2 - 1
 for _ in range(6):
     env.step(act)
+if os.environ.get("HX_PMC_FUSED"):  # the kernel of bench.py's timed loop: policy inference + env step + insert in ONE launch (act_fused_kernel<..., ENV>)
+    from hirl4ucav_amd.agents.engine import HirlEngine
+    eng = HirlEngine(batch=128)
+    out = torch.empty((n, 4), device="cuda")
+    for _ in range(6):
+        eng.act_step(env, sigma=0.1, seed=1, out=out)
 torch.cuda.synchronize()
 print("done", n, cal)
