@@ -12,6 +12,7 @@ SO_PATH = os.environ.get("HX_LIBRARY") or os.path.join(_HERE, "libhx_mi355.so")
 
 ENV_WORDS, OBS_DIM, ACT_DIM, ROW_WORDS = 37, 13, 4, 32
 STAT_NAMES = ("episodes", "kills", "fire_success_episodes", "time_limit", "fires", "good_fires", "locked_steps", "env_steps", "nonfinite_actions")
+STAT_WAYS, STAT_PITCH = 32, 16  # HX_STAT_WAYS, HX_STAT_PITCH: the counters are kept 32 times (way = workgroup % 32, one 128-byte line each); a statistic = the sum
 
 F_LOCKED_PREV, F_LOCKED, F_SLOT_PREV, F_SLOT, F_FIRED, F_FIRE_SUCCESS, F_EPISODE_SUCCESS, F_DONE = (1 << i for i in range(8))
 F_SCEN_SHIFT = 8

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
                     const unsigned c = (unsigned)__popcll(__ballot(vals[k] != 0u));
                     if (lane == k) mine = c;
                 }
-                if (lane < HX_STAT_COUNT && mine) atomicAdd((unsigned long long*)&A.o.stats[lane], (unsigned long long)mine);
+                if (lane < HX_STAT_COUNT && mine) atomicAdd((unsigned long long*)&A.o.stats[(blockIdx.x % HX_STAT_WAYS) * HX_STAT_PITCH + lane], (unsigned long long)mine);
             }
         }
         STAMP();

@@ -87,7 +87,6 @@ __global__ __launch_bounds__(EPB*(PAIR ? 2 : 1)) void env_step_kernel(StepArgs A
     __shared__ float lds[kObsTile + (INSERT ? EPB * kRowPitch : 0)];
     __shared__ unsigned s_slot0;  // ring slot of the workgroup's first row
     __shared__ int s_wcount[WAVES];
-    __shared__ unsigned s_stat[WAVES][HX_STAT_COUNT];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -208,11 +207,16 @@ __global__ __launch_bounds__(EPB*(PAIR ? 2 : 1)) void env_step_kernel(StepArgs A
         const bool mine = active && own;
         const unsigned vals[HX_STAT_COUNT] = {(mine && ended) ? 1u : 0u, st_kill, st_fs, st_tl, st_fire, st_good, st_lock, mine ? 1u : 0u,
                                               (mine && bad_act) ? 1u : 0u};
+        unsigned cnt = 0;
 #pragma unroll
         for (int k = 0; k < HX_STAT_COUNT; ++k) {
             const unsigned c = (unsigned)__popcll(__ballot(vals[k] != 0u));
-            if (lane_id() == 0) s_stat[wave][k] = c;
+            if (lane_id() == k) cnt = c;
         }
+        // every wave adds its own counts, HERE: the atomics' round trip runs under the output stores below (summed per workgroup and issued
+        // after them, it was the last thing the launch waited for: 0.6 us of a 65,536-env launch)
+        if (lane_id() < HX_STAT_COUNT && cnt)
+            atomicAdd((unsigned long long*)&A.o.stats[((blockIdx.x * WAVES + wave) % HX_STAT_WAYS) * HX_STAT_PITCH + lane_id()], (unsigned long long)cnt);
     }
     __syncthreads();
     tile_copy_out<THREADS, kObsTile>(A.obs_io + i0 * HX_OBS_DIM, s_obs, nblk * HX_OBS_DIM, tid);
@@ -235,12 +239,6 @@ __global__ __launch_bounds__(EPB*(PAIR ? 2 : 1)) void env_step_kernel(StepArgs A
 #endif
             }
         }
-    }
-    if (A.o.stats && tid < HX_STAT_COUNT) {
-        unsigned c = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) c += s_stat[w][tid];
-        if (c) atomicAdd((unsigned long long*)&A.o.stats[tid], (unsigned long long)c);
     }
 }
 

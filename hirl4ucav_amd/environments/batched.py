@@ -44,7 +44,7 @@ class BatchedHarfangEnv:
         self.done = torch.zeros(self.n, dtype=torch.uint8, device=d)
         self.success = torch.zeros(self.n, dtype=torch.int8, device=d)
         self.episode_ctr = torch.zeros(self.n, dtype=torch.int32, device=d)
-        self.stats = torch.zeros(len(_lib.STAT_NAMES), dtype=torch.int64, device=d) if collect_stats else None
+        self.stats = torch.zeros((_lib.STAT_WAYS, _lib.STAT_PITCH), dtype=torch.int64, device=d) if collect_stats else None  # sum over dim 0: stats_dict()
         self.replay = replay
         self.layout = int(layout)  # 0: the library picks the launch shape; _lib.layout(pair, envs_per_block) forces one (tests, tuning)
         self._opts = _lib.HxStepOpts()
@@ -98,7 +98,7 @@ class BatchedHarfangEnv:
     def stats_dict(self):
         if self.stats is None:
             return {}
-        return dict(zip(_lib.STAT_NAMES, (int(v) for v in self.stats.tolist())))
+        return dict(zip(_lib.STAT_NAMES, (int(v) for v in self.stats.sum(0).tolist())))
 
     # raw state access for parity tests (the C ABI leaves the state buffer with the caller) -------------------
     def get_state(self):

@@ -57,8 +57,13 @@ def load_env_state(env, st):
     env.obs.copy_(st["obs"])
     env.episode_ctr.copy_(st["episode_ctr"])
     if env.stats is not None and st["stats"] is not None:
-        k = min(env.stats.numel(), st["stats"].numel())  # (snapshots written before a statistics word was added hold fewer)
-        env.stats[:k].copy_(st["stats"][:k])
+        if tuple(st["stats"].shape) == tuple(env.stats.shape):
+            env.stats.copy_(st["stats"])
+        else:  # a snapshot from before the counters were kept HX_STAT_WAYS times (and possibly with fewer statistics): its totals go into way 0
+            old = st["stats"].reshape(-1)
+            k = min(env.stats.shape[1], old.numel())
+            env.stats.zero_()
+            env.stats[0, :k].copy_(old[:k])
 
 
 def save_run(path, eng, env, replay, driver):

@@ -62,6 +62,11 @@ enum { HX_STAT_EPISODES = 0, HX_STAT_KILLS, HX_STAT_FIRE_SUCCESS_EPISODES, HX_ST
                                      replay row), so a diverged policy cannot poison the simulator state — the stand-in for the reference's
                                      missing failure detection */
        HX_STAT_COUNT };
+/* The counters are kept HX_STAT_WAYS times: workgroup b adds to way b % HX_STAT_WAYS, each way in its own 128-byte line
+ * (stats[way * HX_STAT_PITCH + k]); a statistic is the SUM over the ways.  One set of counters put every workgroup's atomics of a launch
+ * on one cache line — one memory channel, ~12 ns each: 0.75 us of a 65,536-env launch. */
+#define HX_STAT_WAYS 32
+#define HX_STAT_PITCH 16
 
 const char* hx_last_error(void);
 int hx_version(void);
@@ -84,7 +89,7 @@ typedef struct HxStepOpts {
     int8_t* ring_success;  /* [cap] step_success of each stored row, or NULL */
     int64_t cap;
     uint64_t* total;       /* transitions ever stored; slot = total % cap (buffer.py:36 position) */
-    uint64_t* stats;       /* [HX_STAT_COUNT] or NULL */
+    uint64_t* stats;       /* [HX_STAT_WAYS][HX_STAT_PITCH] or NULL: see HX_STAT_WAYS */
     void* ev_start;        /* measurement only (host handles from hx_event_create, or NULL): the launch stamps the kernel's own */
     void* ev_stop;         /* begin / end into them — the duration rocprofv3 reports, without the dispatch gap around it */
     int32_t layout;        /* 0: the library picks the launch shape from n.  HX_LAYOUT(pair, envs_per_block) forces one (tuning,

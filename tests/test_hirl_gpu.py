@@ -620,9 +620,10 @@ def test_act_step_in_one_launch_equals_act_then_step(eng_mod, n):
         envs[0].step(acts)
         a2 = engs[1].act_step(envs[1], sigma=0.3, seed=5)[0]
         assert torch.equal(acts, a2), f"actions, step {k}"
-        for name in ("state", "obs", "reward", "done", "success", "episode_ctr", "stats"):
+        for name in ("state", "obs", "reward", "done", "success", "episode_ctr"):
             x, y = getattr(envs[0], name), getattr(envs[1], name)
             assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), f"{name}, step {k}"
+        assert torch.equal(envs[0].stats.sum(0), envs[1].stats.sum(0)), f"stats, step {k}"  # (kept per way = workgroup % 32: the two launch shapes spread them differently)
     tot = int(reps[0].total.item())
     assert tot == int(reps[1].total.item()) == n * 24 - n * 2 and tot <= reps[0].capacity
     rows = [np.concatenate([r.ring[:tot].cpu().numpy(), r.success[:tot].cpu().numpy().astype(np.float32)[:, None]], 1) for r in reps]

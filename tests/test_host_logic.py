@@ -220,3 +220,29 @@ def test_snapshot_is_replaced_atomically(tmp_path, monkeypatch):
     with pytest.raises(OSError):
         CK.save_run(str(path), None, Env(), None, {})
     assert path.read_bytes() == b"previous snapshot"
+
+
+def test_env_snapshot_with_single_way_statistics_still_loads():
+    """The env statistics are kept HX_STAT_WAYS times since round 3 (one 128-byte line per way; a statistic is the sum over the ways).  A
+    snapshot written before that holds ONE set of 8 or 9 totals: they go into way 0, the sums stay what they were."""
+    import types
+
+    import torch
+
+    from hirl4ucav_amd import _lib
+    from hirl4ucav_amd.utils import checkpoint as ck
+
+    def fake_env():
+        return types.SimpleNamespace(n=4, state=torch.zeros(_lib.ENV_WORDS, 4), obs=torch.zeros(4, 13), episode_ctr=torch.zeros(4, dtype=torch.int32),
+                                     stats=torch.ones((_lib.STAT_WAYS, _lib.STAT_PITCH), dtype=torch.int64))
+    for words in (8, 9):
+        env = fake_env()
+        old = {"state": torch.ones(_lib.ENV_WORDS, 4), "obs": torch.ones(4, 13), "episode_ctr": torch.full((4,), 3, dtype=torch.int32),
+               "stats": torch.arange(1, words + 1, dtype=torch.int64)}
+        ck.load_env_state(env, old)
+        assert env.stats.sum(0)[:words].tolist() == list(range(1, words + 1)) and int(env.stats.sum()) == words * (words + 1) // 2
+        assert int(env.episode_ctr[0]) == 3 and float(env.state.sum()) == _lib.ENV_WORDS * 4
+    env, env2 = fake_env(), fake_env()
+    env.stats.random_(0, 1000)
+    ck.load_env_state(env2, ck.env_state(env))  # the current format round-trips way by way
+    assert torch.equal(env.stats, env2.stats)

@@ -238,8 +238,9 @@ def test_sac_act_step_in_one_launch_equals_act_then_step(SE, n):
         envs[0].step(acts)
         a2 = engs[1].act_step(envs[1], **kw)[0]
         assert torch.equal(acts, a2), f"actions, step {k}"
-        for name in ("state", "obs", "reward", "done", "success", "episode_ctr", "stats"):
+        for name in ("state", "obs", "reward", "done", "success", "episode_ctr"):
             assert torch.equal(getattr(envs[0], name).view(torch.uint8), getattr(envs[1], name).view(torch.uint8)), f"{name}, step {k}"
+        assert torch.equal(envs[0].stats.sum(0), envs[1].stats.sum(0)), f"stats, step {k}"  # (kept per way = workgroup % 32: the two launch shapes spread them differently)
     tot = int(reps[0].total.item())
     assert tot == int(reps[1].total.item()) and 0 < tot <= reps[0].capacity
     if n == 16384:
