@@ -40,6 +40,6 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_FETCH_SIZE_env_*.csv"))):
         fv, wv = fv[len(fv) // 2:], wv[len(wv) // 2:]  # the later launches: steady state
         fb, wb = sum(fv) / len(fv) * 1024 * ff, sum(wv) / len(wv) * 1024 * wf
         out[key] = {"fetch_KiB_reported": round(sum(fv) / len(fv), 2), "write_KiB_reported": round(sum(wv) / len(wv), 2), "fetch_factor_calibrated": round(ff, 4),
-                    "write_factor_calibrated": round(wf, 4), "fetch_bytes": int(fb), "write_bytes": int(wb), "traffic_bytes": int(fb + wb),
-                    "algorithmic_bytes": ALGO[kern] * n, "ratio": round((fb + wb) / (ALGO[kern] * n), 4), "launches": len(fv)}
+                    "write_factor_calibrated": round(wf, 4), "fetch_bytes": int(fb), "write_bytes": int(wb), "traffic_bytes": int(fb) + int(wb),
+                    "algorithmic_bytes": ALGO[kern] * n, "ratio": round((int(fb) + int(wb)) / (ALGO[kern] * n), 4), "launches": len(fv)}
 print(json.dumps(out, indent=1))
