@@ -60,8 +60,10 @@ def parse(argv=None):
     p.add_argument("--type", default="soft", choices=["soft", "linear", "fixed"], help="HIRL BC-weight schedule (train_all.py:328-339)")
     p.add_argument("--bc_weight", type=float, default=0.5, help="linear / fixed: the weight (configs[3]: linear, 0.5)")
     p.add_argument("--agent", default="hirl", choices=["hirl", "sac"], help="sac: BASELINE.json configs[2] (use --envs 16384 --scenario serpentine)")
-    p.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16_policy"],
-                   help="bf16: actor AND critic — policy inference and the three 256<->512 products of every network in learn() on bf16 MFMA, fp32 "
+    p.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16_policy", "f32x9"],
+                   help="f32x9: fp32 everywhere, the policy's 256->512 product of the ACTING kernel as the exact 9-term bf16 split on the bf16 matrix cores "
+                        "(fp32 operands, exact partial products, fp32 accumulation: fp32 results up to summation order; NOT the default); "
+                        "bf16: actor AND critic — policy inference and the three 256<->512 products of every network in learn() on bf16 MFMA, fp32 "
                         "accumulation, fp32 master weights / Adam / LayerNorm / dynamics (BASELINE.json configs[4]); bf16_policy: policy inference only")
     p.add_argument("--reps", type=int, default=3, help="timed repetitions of K steps; value = the median repetition (SURVEY.md 8d)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -202,7 +204,7 @@ class Loop:
             if args.staged:
                 self.eng.staged = True
                 self.eng.sharded_sequence = True
-            self.eng.set_act_dtype("f32" if args.dtype == "f32" else "bf16")
+            self.eng.set_act_dtype({"f32": "f32", "f32x9": "f32x9"}.get(args.dtype, "bf16"))
             self.eng.set_update_dtype("bf16" if args.dtype == "bf16" else "f32")
             if world > 1 and args.exchange == "oneshot":
                 self.eng.use_oneshot_exchange(timeout_ms=args.exchange_timeout_ms)
@@ -644,7 +646,8 @@ def workload_label(args):
         tag = " (BASELINE.json configs[2])" if cfg == 2 else ""
         return what + tag
     dt = {"f32": "fp32", "bf16": "bf16 actor/critic (fp32 accumulate, fp32 master weights / Adam / LayerNorm) + fp32 dynamics",
-          "bf16_policy": "bf16 policy inference (fp32 accumulate) + fp32 dynamics / update"}[args.dtype]
+          "bf16_policy": "bf16 policy inference (fp32 accumulate) + fp32 dynamics / update",
+          "f32x9": "fp32 (acting kernel: the 256->512 product as the exact 9-term bf16 split on bf16 MFMA, fp32 accumulate)"}[args.dtype]
     kind = f"HIRL-{args.type}" + (f" (bc_weight {args.bc_weight})" if args.type != "soft" else "")
     what = f"{args.envs} parallel {args.scenario} envs per GPU, {kind} {dt}, 1 learn(B={args.batch}) per vector step"
     tag = ""
@@ -776,7 +779,7 @@ def run_rank(args):
         "metric": "env steps/sec (whole node) + HIRL update steps/sec at 4096 envs/GPU", "value": round(value, 1),
         "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_s": args.settle_s, "settle_steps": settle_steps,
         "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "f32" else ("bf16" if args.dtype == "bf16" else "bf16 policy / f32 update"), "data": "synthetic",
+        "dtype": {"f32": "f32", "bf16": "bf16", "bf16_policy": "bf16 policy / f32 update", "f32x9": "f32 (policy product: exact bf16 x 9 split)"}[args.dtype], "data": "synthetic",
         "repetitions": {"count": len(reps), "statistic": "median", "ms_per_step": [round(t / args.steps * 1e3, 5) for t in reps],
                         "value": [round(n_total * args.steps / t, 1) for t in reps]},
         "config": {"workload": workload_label(args), "envs_per_gpu": args.envs, "batch": args.batch,
@@ -807,7 +810,7 @@ def run_rank(args):
         us = float(np.mean(fused))
         fused_pmc = profile_traffic(f"fused_{args.envs}") if (args.agent == "hirl" and args.dtype == "f32") else None
         flop = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
-        peak = FP32_MATRIX_PEAK_TFLOPS if (args.dtype == "f32" or args.agent == "sac") else BF16_MATRIX_PEAK_TFLOPS
+        peak = FP32_MATRIX_PEAK_TFLOPS if (args.dtype in ("f32", "f32x9") or args.agent == "sac") else BF16_MATRIX_PEAK_TFLOPS
         tf, gb = flop / us / 1e6, ENV_BYTES_FUSED * args.envs / us / 1e3
         mf, hf = tf / peak, gb / HBM_PEAK_GBPS
         hbm = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hf, 4), "bytes_per_launch": ENV_BYTES_FUSED * args.envs}
@@ -833,7 +836,7 @@ def run_rank(args):
                                   "frac": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6 / peak_u, 5),
                                   "us_per_learn": round(learn_us, 2), "timing": "torch events around learn() in the second pass (median)"}
     if act_us and not loop.uniform:  # (with --actions uniform the 'act' stage is a torch uniform_ fill, not the policy)
-        peak = FP32_MATRIX_PEAK_TFLOPS if (args.dtype == "f32" or args.agent == "sac") else BF16_MATRIX_PEAK_TFLOPS
+        peak = FP32_MATRIX_PEAK_TFLOPS if (args.dtype in ("f32", "f32x9") or args.agent == "sac") else BF16_MATRIX_PEAK_TFLOPS
         flop = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
         res["roofline_act"] = {"kernels": "act_fused_kernel<ENV = false> as its own launch (every 4th step of the second pass)", "bound": "mfma", "unit": "TFLOP/s",
                                "achieved": round(flop / act_us / 1e6, 3), "peak": peak,

@@ -33,7 +33,7 @@ class HxSample(ctypes.Structure):
 class HxNets(ctypes.Structure):
     _fields_ = [(k, _vp) for k in ("actor", "critic", "target_actor", "target_critic", "bc_actor", "grad_actor", "grad_critic",
                                    "m_actor", "v_actor", "m_critic", "v_critic", "losses", "soft_count", "wstate", "ws", "actor_w2_bf16", "actor_w2_f32i",
-                                   "w2_bf16_all", "xchg_status")]
+                                   "w2_bf16_all", "xchg_status", "actor_w2_x9")]
 
 
 class HxHyper(ctypes.Structure):
@@ -47,6 +47,10 @@ _lib.register("hx_actor_act_step", [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _v
 _lib.register("hx_pack_w2_bf16", [_vp, _i32, _vp, _vp])
 _lib.register("hx_pack_w2_f32i", [_vp, _i32, _vp, _vp])
 _lib.register("hx_pack_update_images", [_P(HxNets), _vp])
+_lib.register("hx_pack_w2_x9", [_vp, _i32, _vp, _vp])
+_lib.register("hx_actor_act_x9", [_vp, _vp, _vp, ctypes.c_int64, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _f32, _vp])
+_lib.register("hx_actor_act_step_x9", [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32,
+                                        ctypes.c_uint32, _f32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
 _lib.register("hx_actor_act_f32i", [_vp, _vp, _vp, ctypes.c_int64, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _f32, _vp])
 _lib.register("hx_actor_act_step_f32i", [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32,
                                           ctypes.c_uint32, _f32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
@@ -248,8 +252,8 @@ class HirlEngine:
         self._pending = None  # a draw sample(defer=True) recorded for the next learn()
         self.nets = HxNets(*(t.data_ptr() for t in (self.actor, self.critic, self.target_actor, self.target_critic, self.bc_actor,
                                                      self.grad_actor, self.grad_critic, self.m_actor, self.v_actor, self.m_critic,
-                                                     self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None, None, None, None)
-        self.act_dtype, self.w2_bf16 = "f32", None
+                                                     self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None, None, None, None, None)
+        self.act_dtype, self.w2_bf16, self.w2_x9 = "f32", None, None
         self.update_dtype, self.images = "f32", None
         # fp32 image of the actor's W2 in the acting kernel's operand order (hx_pack_w2_f32i): kept current by the actor's Adam steps
         self.w2_f32i = torch.zeros(H2 * H1, dtype=torch.float32, device=self.device)
@@ -290,9 +294,13 @@ class HirlEngine:
 
     def set_act_dtype(self, dtype):
         """"f32": policy inference on fp32 MFMA (parity 1e-5).  "bf16": its 256 -> 512 layer on bf16 MFMA from a bf16 image of W2 that
-        every actor Adam step keeps current (BASELINE.json configs[4]); what learn() computes in is set_update_dtype's business."""
-        if dtype not in ("f32", "bf16"):
+        every actor Adam step keeps current (BASELINE.json configs[4]); what learn() computes in is set_update_dtype's business.
+        "f32x9": fp32 policy inference with the 256 -> 512 product as the EXACT 9-term bf16 split on the bf16 matrix cores (hx_actor_act_x9:
+        fp32 operands, every partial product exact, fp32 accumulation — fp32 results up to summation order); fp32 update only."""
+        if dtype not in ("f32", "bf16", "f32x9"):
             raise ValueError(dtype)
+        if dtype == "f32x9" and self.update_dtype != "f32":
+            raise ValueError("act dtype f32x9 goes with the fp32 update path")
         self.act_dtype = dtype
         self._bind_images()
         self.refresh_bf16()
@@ -303,6 +311,8 @@ class HirlEngine:
         (include/hirl4ucav.h "bf16 update path"; BASELINE.json configs[4] "bf16 actor/critic")."""
         if dtype not in ("f32", "bf16"):
             raise ValueError(dtype)
+        if dtype == "bf16" and self.act_dtype == "f32x9":
+            raise ValueError("act dtype f32x9 goes with the fp32 update path")
         self.update_dtype = dtype
         self._bind_images()
         self.refresh_bf16()
@@ -320,6 +330,13 @@ class HirlEngine:
             self.nets.actor_w2_bf16 = self.w2_bf16.data_ptr() if self.act_dtype == "bf16" else None
             return
         self.nets.w2_bf16_all = None
+        self.nets.actor_w2_x9 = None
+        if self.act_dtype == "f32x9":
+            if self.w2_x9 is None:
+                self.w2_x9 = torch.zeros(3 * H2 * H1, dtype=torch.bfloat16, device=self.device)  # hi | mid | lo
+            self.nets.actor_w2_x9 = self.w2_x9.data_ptr()
+            self.nets.actor_w2_bf16 = None
+            return
         if self.act_dtype == "bf16":
             if self.w2_bf16 is None or (self.images is not None and self.w2_bf16.data_ptr() == self.images.data_ptr()):
                 self.w2_bf16 = torch.zeros(H2 * H1, dtype=torch.bfloat16, device=self.device)
@@ -336,6 +353,8 @@ class HirlEngine:
             _lib.call("hx_pack_update_images", ctypes.byref(self.nets), _lib.stream_ptr())
         elif self.act_dtype == "bf16":
             _lib.call("hx_pack_w2_bf16", self.actor.data_ptr(), 13, self.w2_bf16.data_ptr(), _lib.stream_ptr())
+        elif self.act_dtype == "f32x9":
+            _lib.call("hx_pack_w2_x9", self.actor.data_ptr(), 13, self.w2_x9.data_ptr(), _lib.stream_ptr())
 
     refresh_images = refresh_bf16
 
@@ -380,6 +399,10 @@ class HirlEngine:
             _lib.call("hx_actor_act_bf16", self.actor.data_ptr(), self.w2_bf16.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise),
                       float(sigma), int(seed), int(row0), self.act_calls, self.slope, _lib.stream_ptr())
             return out
+        if self.act_dtype == "f32x9" and net is None:
+            _lib.call("hx_actor_act_x9", self.actor.data_ptr(), self.w2_x9.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise),
+                      float(sigma), int(seed), int(row0), self.act_calls, self.slope, _lib.stream_ptr())
+            return out
         if net is None:  # the engine's own actor: W2 from its fp32 image (same bits as hx_actor_act, no LDS staging of W2)
             _lib.call("hx_actor_act_f32i", self.actor.data_ptr(), self.w2_f32i.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise),
                       float(sigma), int(seed), int(row0), self.act_calls, self.slope, _lib.stream_ptr())
@@ -404,6 +427,11 @@ class HirlEngine:
         self.act_calls += 1
         if self.act_dtype == "bf16":
             _lib.call("hx_actor_act_step_bf16", self.actor.data_ptr(), self.w2_bf16.data_ptr(), env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(),
+                      out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
+                      env.reward.data_ptr(), env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
+            return out, env.obs, env.reward, env.done, env.success
+        if self.act_dtype == "f32x9":
+            _lib.call("hx_actor_act_step_x9", self.actor.data_ptr(), self.w2_x9.data_ptr(), env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(),
                       out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
                       env.reward.data_ptr(), env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
             return out, env.obs, env.reward, env.done, env.success

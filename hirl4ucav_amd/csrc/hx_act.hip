@@ -43,6 +43,7 @@ struct ActFusedArgs {
     double inv_cap;  // 1 / o.cap
     const uint16_t* w2b;  // BF16 instantiations: bf16 image of W2 [512][256] (hx_pack_w2_bf16 / the actor's Adam step keep it current)
     const float* w2f;     // F32I instantiations: fp32 image of W2 (hx_pack_w2_f32i)
+    int x9;               // X3 instantiations: w2b is the first of THREE images hi | mid | lo (hx_pack_w2_x9): the exact bf16 split of W2
 };
 
 
@@ -71,9 +72,13 @@ __device__ __forceinline__ float philox_normal(uint32_t row, uint32_t call, uint
 //         the 512 columns and nobody else reads them, so its B fragments (16 x 16 B per lane = the 256 KB image once per
 //         workgroup) go from L2 straight into registers at kernel entry — no LDS staging, no chunk barriers; the 16 (32) rows
 //         of h1 are the only shared operand.
-template <int NRT, bool GAUSS, bool ENV, bool BF16, bool RELU, bool F32I = false>
+// X3   = fp32 policy, the 256 -> 512 product on v_mfma_f32_16x16x32_bf16 EXACTLY: h1 and W2 as hi + mid + lo bf16 parts (split3_bf16: nothing
+//         is lost), all 9 partial products (each exact in fp32) accumulated in fp32 — the 8 small ones in their own accumulator, joined with
+//         hi x hi at the end.  144 matrix-core cycles per 32 k and column tile against 256 for fp32 MFMA; the B fragments stream from the three
+//         images (768 KB per workgroup) one slab ahead of the multiply.
+template <int NRT, bool GAUSS, bool ENV, bool BF16, bool RELU, bool F32I = false, bool X3 = false>
 __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
-    static_assert(!(BF16 && F32I), "one image format at a time");
+    static_assert(!(BF16 && F32I) && !(X3 && (BF16 || F32I)), "one image format at a time");
     constexpr int ROWS = NRT * RT;
     __shared__ float s_act[ENV ? ROWS * 4 : 4];
     __shared__ float s_noise[ROWS * 4];  // exploration noise of the workgroup's rows, drawn by the last wave(s) under the prologue's loads
@@ -82,11 +87,12 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     static_assert(2 * H2 * ACT_LDW >= ROWS * LDA2, "the z2 tile reuses the W2 chunk buffers");
     // fp32: two W2 chunk buffers (reused for z2 and, in the env tail, the replay rows / next observations)
     // bf16: the z2 tile, then the replay rows / next observations, and the bf16 h1 tile
-    constexpr bool IMG = BF16 || F32I;  // W2 comes from an image straight into registers: no chunk buffers in LDS
+    constexpr bool IMG = BF16 || F32I || X3;  // W2 comes from an image straight into registers: no chunk buffers in LDS
     constexpr int kTileA = IMG ? ROWS * LDA2 : H2 * ACT_LDW;
     constexpr int kTileB = IMG ? (ENV ? ROWS * (hxenv::kRowPitch + HX_OBS_DIM) : 4) : H2 * ACT_LDW;
     __shared__ __attribute__((aligned(16))) float lds[ROWS * LDA1 + ROWS * XP + ROWS * 2 + H1 * 13 + kTileA + kTileB];
     __shared__ __attribute__((aligned(16))) __bf16 h1b[BF16 ? ROWS * LDB1 : 8];
+    __shared__ __attribute__((aligned(16))) uint16_t h1x[X3 ? 3 * ROWS * LDB1 : 8];  // X3: the hi | mid | lo tiles of h1
     float* h1s = lds;
     float* xs = h1s + ROWS * LDA1;
     float* sts = xs + ROWS * XP;
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     constexpr int ACT_PF = 3;
     float4 pb[F32I ? ACT_NCH : 1], qb[F32I ? ACT_NCH : 1];
     const float* img0 = F32I ? A.w2f + (size_t)wave * (16 * 256) + lane * 4 : nullptr;  // 1 KB block (column tile `wave`, chunk c) at + 256 c floats; column tile 16 + wave 65,536 floats on
-    if constexpr (!BF16 && !F32I) {
+    if constexpr (!IMG) {
         ACT_LOAD(ra0, rb0, 0);
         ACT_LOAD(ra1, rb1, 1);
     }
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     if (tid < H1 * 13 / 4) wv = reinterpret_cast<const float4*>(net + m.W1())[tid];
     const float bias1 = net[m.b1() + u], g1v = net[m.g1() + u], be1v = net[m.be1() + u];
     himg.fetch(net, m, tid);  // (needed last: behind the prologue's own operands)
-    if constexpr (!BF16 && !F32I) {  // behind the prologue's own operands
+    if constexpr (!IMG) {  // behind the prologue's own operands
         ACT_LOAD(ra2, rb2, 2);
         ACT_LOAD(ra3, rb3, 3);
     }
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     __syncthreads();
     // BF16: which 32 columns this wave owns rotates with the workgroup, so that the 256 workgroups of a launch do not all ask L2 for
     // the same lines of the W2 image at the same moment
-    const int cw = BF16 ? ((wave + (int)blockIdx.x) & 15) : wave;
+    const int cw = (BF16 || X3) ? ((wave + (int)blockIdx.x) & 15) : wave;
     if constexpr (BF16) {
         // requested only now, behind the prologue's own operands: every workgroup pulls the whole 256 KB image through L2 (64 MB per
         // launch at 4,096 rows, ~6 us of L2 service); issued at kernel entry those requests queue up in front of OTHER workgroups'
@@ -212,9 +218,10 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             const int row = t * RT + 4 * lg + r;
             const float hv = act_f<RELU>(g1v * ((z1[t][r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
             if (BF16) h1b[row * LDB1 + u] = (__bf16)hv;  // v_cvt_pk_bf16_f32: round to nearest even
+            else if (X3) split3_bf16(hv, h1x[row * LDB1 + u], h1x[(ROWS + row) * LDB1 + u], h1x[(2 * ROWS + row) * LDB1 + u]);
             else h1s[row * LDA1 + u] = hv;
         }
-    if (!BF16 && !F32I) {
+    if (!IMG) {
         ACT_STORE(wb0, ra0, rb0);
         ACT_LOAD(ra0, rb0, 4);
     }
@@ -244,6 +251,59 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
                     acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(v8bf, bq[1][sl]), acc[t][1], 0, 0, 0);
                 }
             }
+        }
+        if constexpr (X3) {
+            // K = 256 in 8 slabs of 32; per slab 3 A fragments (LDS) and 2 x 3 B fragments (one contiguous kilobyte each, from the images)
+            v4f rest[NRT][2];
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) rest[t][0] = rest[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
+            const uint16_t* img = A.w2b + (size_t)(cw * 8) * 512 + lane * 8;  // image s at + s kImgElems, column tile 16 + cw at + 16 * 8 * 512
+            uint4 bb[2][3][2];
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) bb[0][sx][ct] = *reinterpret_cast<const uint4*>(img + (size_t)sx * kImgElems + (size_t)ct * (16 * 8 * 512));
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+                if (sl + 1 < 8) {
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+                            bb[(sl + 1) & 1][sx][ct] = *reinterpret_cast<const uint4*>(img + (size_t)sx * kImgElems + (size_t)ct * (16 * 8 * 512) + (sl + 1) * 512);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the multiply (see the F32I loop)
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) {
+                    uint4 a3[3];
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) a3[sx] = *reinterpret_cast<const uint4*>(h1x + ((sx * ROWS) + t * RT + r) * LDB1 + 32 * sl + 8 * g);
+                    const uint4(&b)[3][2] = bb[sl & 1];
+                    // smallest first: lo lo, lo mid, mid lo | lo hi, hi lo, mid mid | mid hi, hi mid -> rest; hi hi -> acc
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[2], b[2][ct], rest[t][ct]);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[2], b[1][ct], rest[t][ct]);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[1], b[2][ct], rest[t][ct]);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[2], b[0][ct], rest[t][ct]);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[0], b[2][ct], rest[t][ct]);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[1], b[1][ct], rest[t][ct]);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[1], b[0][ct], rest[t][ct]);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[0], b[1][ct], rest[t][ct]);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) acc[t][ct] = mfma16_bf16(a3[0], b[0][ct], acc[t][ct]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NRT; ++t)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[t][ct] = acc[t][ct] + rest[t][ct];
         }
         const float* ap = h1s + r * LDA1 + 4 * g;
         const int boff = (wave * 16 + r) * ACT_LDW + 4 * g;
@@ -289,7 +349,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
             }
             __syncthreads();  // every wave has read its last h1 fragment: the tile's LDS may now take z2 and the head image
         }
-        for (int c = 0; c < ((BF16 || F32I) ? 0 : ACT_NCH); c += 4) {
+        for (int c = 0; c < (IMG ? 0 : ACT_NCH); c += 4) {
             // chunk c is in wb0; set 1 holds chunk c+1, sets 2, 3, 0 hold c+2, c+3, c+4 (in flight)
             ACT_STORE(wb1, ra1, rb1);
             if (c + 5 < ACT_NCH) ACT_LOAD(ra1, rb1, c + 5);
@@ -529,26 +589,35 @@ static void launch_act_k(K kernel, dim3 grid, const ActFusedArgs& H, hipStream_t
     else
         hipLaunchKernelGGL(kernel, grid, dim3(kWide), 0, st, H);
 }
-template <bool GAUSS, bool BF16, bool RELU, bool F32I = false>
+template <bool GAUSS, bool BF16, bool RELU, bool F32I = false, bool X3 = false>
 static void launch_act_t(const ActFusedArgs& H, hipStream_t st) {
     const bool env = H.state != nullptr;
     // 32 rows per workgroup: from 8,192 rows on (fp32: below that, 16-row workgroups fill the chip and the fp32 MFMA work per workgroup
     // is the longer pole); bf16: the same switch point by default (HX_ACT_BF16_NRT2_ROWS moves it: there the launch is bound by every workgroup pulling
     // W2 through L2, not by MFMA)
     static const int nrt2_bf16 = getenv("HX_ACT_BF16_NRT2_ROWS") ? atoi(getenv("HX_ACT_BF16_NRT2_ROWS")) : 8192;  // tuning knob
-    if (H.rows >= (BF16 ? nrt2_bf16 : 8192)) {
-        const dim3 grid((unsigned)((H.rows + 2 * RT - 1) / (2 * RT)));
-        if (env) launch_act_k(act_fused_kernel<2, GAUSS, true, BF16, RELU, F32I>, grid, H, st);
-        else launch_act_k(act_fused_kernel<2, GAUSS, false, BF16, RELU, F32I>, grid, H, st);
-    } else {
+    if constexpr (!X3) {  // (X3: 16-row workgroups at every size — three bf16 tiles of 32 rows of h1 do not fit the LDS beside the rest)
+        if (H.rows >= (BF16 ? nrt2_bf16 : 8192)) {
+            const dim3 grid((unsigned)((H.rows + 2 * RT - 1) / (2 * RT)));
+            if (env) launch_act_k(act_fused_kernel<2, GAUSS, true, BF16, RELU, F32I, X3>, grid, H, st);
+            else launch_act_k(act_fused_kernel<2, GAUSS, false, BF16, RELU, F32I, X3>, grid, H, st);
+            return;
+        }
+    }
+    {
         const dim3 grid((unsigned)((H.rows + RT - 1) / RT));
-        if (env) launch_act_k(act_fused_kernel<1, GAUSS, true, BF16, RELU, F32I>, grid, H, st);
-        else launch_act_k(act_fused_kernel<1, GAUSS, false, BF16, RELU, F32I>, grid, H, st);
+        if (env) launch_act_k(act_fused_kernel<1, GAUSS, true, BF16, RELU, F32I, X3>, grid, H, st);
+        else launch_act_k(act_fused_kernel<1, GAUSS, false, BF16, RELU, F32I, X3>, grid, H, st);
     }
 }
 template <bool GAUSS>
 static void launch_act(const ActFusedArgs& H, hipStream_t st) {
     // the activation is a compile-time ReLU when the slope is 0 (HIRL, SAC; the Gaussian policy is a Linear-ReLU stack by definition)
+    if (!GAUSS && H.w2b && H.x9) {  // fp32 through the exact bf16 split (deterministic head only)
+        if (H.slope == 0.0f) launch_act_t<false, false, true, false, true>(H, st);
+        else launch_act_t<false, false, false, false, true>(H, st);
+        return;
+    }
     if (GAUSS || H.slope == 0.0f) {
         if (H.w2b) launch_act_t<GAUSS, true, true>(H, st);
         else if (H.w2f) launch_act_t<GAUSS, false, true, true>(H, st);
@@ -580,6 +649,17 @@ __global__ __launch_bounds__(kThreads) void pack_bf16_t_kernel(const float* __re
     }
 }
 
+// the hi | mid | lo images of W2 (split3_bf16), each in the bf16 image order
+__global__ __launch_bounds__(kThreads) void pack_x9_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int n) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) {
+        uint16_t hi, mid, lo;
+        split3_bf16(src[i], hi, mid, lo);
+        const uint32_t ix = w2_image_index((uint32_t)i / H1, (uint32_t)i % H1);
+        dst[ix] = hi; dst[kImgElems + ix] = mid; dst[2 * kImgElems + ix] = lo;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void pack_f32i_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
     const int i = (blockIdx.x * kThreads + threadIdx.x) * 4;  // four consecutive k of one column: adjacent in the image too
     if (i < n) *reinterpret_cast<float4*>(dst + w2f_image_index((uint32_t)i / H1, (uint32_t)i % H1)) = *reinterpret_cast<const float4*>(src + i);
@@ -606,10 +686,11 @@ static int actor_act_impl(const float* actor, const uint16_t* w2b, const float* 
                  float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream) {
     HX_REQUIRE(actor && obs && actions && rows > 0, "hx_actor_act: bad arguments");
     const Mlp mA{13, 4, (noise_mode & 16) ? 1 : 0};  // + 16: layerNorm = False
+    const int x9 = (w2b && (noise_mode & 32)) ? 1 : 0;  // + 32 (internal, the *_x9 entry points): w2b is the first of the hi | mid | lo images
     noise_mode &= 15;
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act: bad noise mode");
     ActFusedArgs H{actor, mA, const_cast<float*>(obs), (int)rows, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
-                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0, w2b, w2f};
+                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0, w2b, w2f, x9};
     launch_act<false>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_actor_act");
     return 0;
@@ -655,6 +736,7 @@ static int actor_act_step_impl(const float* actor, const uint16_t* w2b, const fl
     HX_REQUIRE(actor, "hx_actor_act_step: null actor");
     const int32_t mode_in = noise_mode;
     const Mlp mA{13, 4, (noise_mode & 16) ? 1 : 0};  // + 16: layerNorm = False
+    const int x9 = (w2b && (noise_mode & 32)) ? 1 : 0;  // + 32 (internal): see actor_act_impl
     noise_mode &= 15;
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act_step: bad noise mode");
     const HxStepOpts o = opts ? *opts : HxStepOpts{};
@@ -665,7 +747,7 @@ static int actor_act_step_impl(const float* actor, const uint16_t* w2b, const fl
     }
     ActFusedArgs H{actor, mA, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
                    noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
-                   o.cap > 0 ? 1.0 / (double)o.cap : 0.0, w2b, w2f};
+                   o.cap > 0 ? 1.0 / (double)o.cap : 0.0, w2b, w2f, x9};
     launch_act<false>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_actor_act_step");
     return 0;
@@ -682,6 +764,28 @@ int hx_actor_act_step_bf16(const float* actor, const uint16_t* w2_bf16, float* s
                            float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
     HX_REQUIRE(w2_bf16 && (reinterpret_cast<uintptr_t>(w2_bf16) & 15u) == 0, "hx_actor_act_step_bf16: w2_bf16 must be a 16-byte aligned bf16 image of W2");
     return actor_act_step_impl(actor, w2_bf16, nullptr, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed, row0, call, slope, reward, done,
+                               success, opts, stream);
+}
+
+/* The fp32 policy with the 256 -> 512 product as the exact 9-term bf16 split on the bf16 matrix cores (see the header). */
+int hx_pack_w2_x9(const float* net, int32_t in_dim, uint16_t* w2_x9, void* stream) {
+    HX_REQUIRE(net && w2_x9 && (in_dim == 13 || in_dim == 17) && (reinterpret_cast<uintptr_t>(w2_x9) & 15u) == 0, "hx_pack_w2_x9: bad arguments");
+    const Mlp m{in_dim, 1, 0};
+    const int n = H2 * H1;
+    hipLaunchKernelGGL(pack_x9_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, net + m.W2(), w2_x9, n);
+    HX_CHECK_LAUNCH("hx_pack_w2_x9");
+    return 0;
+}
+int hx_actor_act_x9(const float* actor, const uint16_t* w2_x9, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
+                    const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream) {
+    HX_REQUIRE(w2_x9 && (reinterpret_cast<uintptr_t>(w2_x9) & 15u) == 0 && (noise_mode & 32) == 0, "hx_actor_act_x9: w2_x9 must be the 16-byte aligned hi | mid | lo images of W2");
+    return actor_act_impl(actor, w2_x9, nullptr, obs, rows, actions, noise_mode | 32, noise, sigma, seed, row0, call, slope, stream);
+}
+int hx_actor_act_step_x9(const float* actor, const uint16_t* w2_x9, float* state, int64_t n, int64_t stride, float* obs_io, float* actions,
+                         int32_t noise_mode, const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope,
+                         float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts, void* stream) {
+    HX_REQUIRE(w2_x9 && (reinterpret_cast<uintptr_t>(w2_x9) & 15u) == 0 && (noise_mode & 32) == 0, "hx_actor_act_step_x9: w2_x9 must be the 16-byte aligned hi | mid | lo images of W2");
+    return actor_act_step_impl(actor, w2_x9, nullptr, state, n, stride, obs_io, actions, noise_mode | 32, noise, sigma, seed, row0, call, slope, reward, done,
                                success, opts, stream);
 }
 

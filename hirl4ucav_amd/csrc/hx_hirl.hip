@@ -258,6 +258,10 @@ static int actor_wgrad_impl(const HxNets* N, const HxHyper* Hy, int32_t batch, i
         J.target = polyak ? N->target_actor : nullptr;
         J.w2b = N->actor_w2_bf16;
         J.w2f = N->actor_w2_f32i;
+        if (N->actor_w2_x9) {
+            HX_REQUIRE(!N->actor_w2_bf16 && !N->w2_bf16_all, "hx_hirl_learn: actor_w2_x9 excludes the plain bf16 images (one acting format at a time)");
+            J.w2b = N->actor_w2_x9; J.w2b_x9 = 1;
+        }
         if (uint16_t* im = N->w2_bf16_all) {
             HX_REQUIRE(!N->actor_w2_bf16 || N->actor_w2_bf16 == im + IM_ACTOR * kImgElems, "hx_hirl_learn: with w2_bf16_all set, actor_w2_bf16 must be NULL or its first image");
             J.w2b = im + IM_ACTOR * kImgElems; J.w2tb = im + IM_ACTOR_T * kImgElems; J.tgt_w2b = im + IM_TA * kImgElems;

@@ -441,6 +441,15 @@ constexpr int LDB2 = H2 + 16;  // bf16 dz2 tile pitch = 264 dwords = 8 mod 64
 // forward images (w2_image_index) first, so that a FwdJobC's 3-bit field can name them, then the transposed ones (w2t_image_index)
 enum { IM_ACTOR = 0, IM_C1, IM_C2, IM_TA, IM_TC1, IM_TC2, IM_BC, IM_ACTOR_T, IM_C1_T, IM_C2_T, IM_COUNT };
 constexpr size_t kImgElems = (size_t)H2 * H1;
+// x = hi + mid + lo, exactly: three bf16 numbers (8 significand bits each, round to nearest even; the two remainders are exact in fp32)
+__device__ __forceinline__ void split3_bf16(float x, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    const __bf16 l = (__bf16)r2;
+    hi = __builtin_bit_cast(uint16_t, h); mid = __builtin_bit_cast(uint16_t, m); lo = __builtin_bit_cast(uint16_t, l);
+}
 __device__ __forceinline__ v8bf as_v8bf(const uint4& q) { return __builtin_bit_cast(v8bf, q); }
 __device__ __forceinline__ v4f mfma16_bf16(const uint4& a, const uint4& b, v4f c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_v8bf(a), as_v8bf(b), c, 0, 0, 0);
@@ -504,6 +513,7 @@ struct WgJob {
     float* w2f;                    // nullptr, or the fp32 image of W2 to refresh
     uint16_t* w2tb;                // nullptr, or the transposed bf16 image of W2 to refresh (bf16 update path)
     uint16_t* tgt_w2b;             // nullptr, or the bf16 image of the TARGET's W2: follows the Polyak step
+    int w2b_x9;                    // w2b is the FIRST of three images, hi | mid | lo (HxNets.actor_w2_x9): the exact split of every weight
 };
 struct WgAdam {
     float b1, b2, eps, step_size, bc2_sqrt, tau;
@@ -563,6 +573,7 @@ struct AdamArgs {
     // acting kernels read it; nullptr = none
     uint16_t* w2b;
     float* w2f;  // fp32 image of W2 to refresh (same range)
+    int w2b_x9;  // w2b is the first of three images hi | mid | lo (HxNets.actor_w2_x9)
     int w2_lo;
     // bf16 update path: up to two W2 ranges of p (the critic's two heads) with their forward / transposed images and the images of the
     // target's W2 (written when `target` is stepped here); nseg = 0: none

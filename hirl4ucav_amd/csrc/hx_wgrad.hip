@@ -17,7 +17,7 @@ struct WgJobC {
     const float* net; float* grad;
     float* ws0; float* ws1;
     float* mom; float* var; float* target; uint16_t* w2b; float* w2f;
-    uint32_t cfg;  // m:10 | nslots:2 | wmode0:2 | wmode1:2 | w_kind:2 | adam.finish_actor:1 | adam.use_bc:1
+    uint32_t cfg;  // m:10 | nslots:2 | wmode0:2 | wmode1:2 | w_kind:2 | adam.finish_actor:1 | adam.use_bc:1 | w2b_x9:1
     int32_t rows0, rows1;
     float slope, w_given, warm, inv_batch;
     float b1, b2, eps, step_size, bc2_sqrt, tau;
@@ -93,7 +93,7 @@ __device__ __forceinline__ void expand_wg(const WgJobC& c, WgJob& J, WgArgs& A) 
     J.ws[0] = carve_slot(c.ws0, c.rows0); J.ws[1] = carve_slot(c.ws1, c.rows1);
     J.rows[0] = c.rows0; J.rows[1] = c.rows1;
     J.p = const_cast<float*>(c.net); J.mom = c.mom; J.var = c.var; J.target = c.target; J.w2b = c.w2b; J.w2f = c.w2f;
-    J.w2tb = c.w2tb; J.tgt_w2b = c.tgt_w2b;
+    J.w2tb = c.w2tb; J.tgt_w2b = c.tgt_w2b; J.w2b_x9 = (int)((c.cfg >> 20) & 1u);
     A.slope = c.slope; A.w_kind = (int)((c.cfg >> 16) & 3u); A.w_given = c.w_given; A.warm = c.warm; A.inv_batch = c.inv_batch;
     A.soft_count = c.soft_count; A.wstate = c.wstate;
     A.ad.b1 = c.b1; A.ad.b2 = c.b2; A.ad.eps = c.eps; A.ad.step_size = c.step_size; A.ad.bc2_sqrt = c.bc2_sqrt; A.ad.tau = c.tau;
@@ -106,7 +106,7 @@ inline WgJobC pack_wg(const WgJob& J, const WgArgs& A) {
     c.net = J.net; c.grad = J.grad; c.ws0 = J.ws[0].x; c.ws1 = J.nslots > 1 ? J.ws[1].x : J.ws[0].x;
     c.mom = J.mom; c.var = J.var; c.target = J.target; c.w2b = J.w2b; c.w2f = J.w2f; c.w2tb = J.w2tb; c.tgt_w2b = J.tgt_w2b;
     c.cfg = mlp_bits(J.m) | ((uint32_t)J.nslots << 10) | ((uint32_t)J.wmode[0] << 12) | ((uint32_t)J.wmode[1] << 14) | ((uint32_t)A.w_kind << 16) |
-            ((uint32_t)(A.ad.finish_actor ? 1 : 0) << 18) | ((uint32_t)(A.ad.use_bc ? 1 : 0) << 19);
+            ((uint32_t)(A.ad.finish_actor ? 1 : 0) << 18) | ((uint32_t)(A.ad.use_bc ? 1 : 0) << 19) | ((uint32_t)(J.w2b_x9 ? 1 : 0) << 20);
     c.rows0 = J.rows[0]; c.rows1 = J.nslots > 1 ? J.rows[1] : J.rows[0];
     c.slope = A.slope; c.w_given = A.w_given; c.warm = A.warm; c.inv_batch = A.inv_batch;
     c.b1 = A.ad.b1; c.b2 = A.ad.b2; c.eps = A.ad.eps; c.step_size = A.ad.step_size; c.bc2_sqrt = A.ad.bc2_sqrt; c.tau = A.ad.tau;
@@ -232,8 +232,11 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                 const int idx = J.m.W2() + (n0 + 4 * g + q0 + q) * H1 + k0 + r;
                 ae[q].apply(J, A.ad, idx, fin[q]);
                 if (J.w2b) {
-                    const __bf16 bv = (__bf16)ae[q].p;
-                    J.w2b[w2_image_index((uint32_t)(n0 + 4 * g + q0 + q), (uint32_t)(k0 + r))] = __builtin_bit_cast(uint16_t, bv);
+                    const uint32_t ix = w2_image_index((uint32_t)(n0 + 4 * g + q0 + q), (uint32_t)(k0 + r));
+                    uint16_t hi, mid, lo;
+                    split3_bf16(ae[q].p, hi, mid, lo);  // hi = the weight rounded to bf16 (the plain image); mid | lo only for the x9 images
+                    J.w2b[ix] = hi;
+                    if (J.w2b_x9) { J.w2b[kImgElems + ix] = mid; J.w2b[2 * kImgElems + ix] = lo; }
                 }
                 if (J.w2f) J.w2f[w2f_image_index((uint32_t)(n0 + 4 * g + q0 + q), (uint32_t)(k0 + r))] = ae[q].p;
                 if (J.w2tb) {
@@ -563,7 +566,16 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
             typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
             const v4bf r = {(__bf16)p4.x, (__bf16)p4.y, (__bf16)p4.z, (__bf16)p4.w};
             const uint32_t e = (uint32_t)(i - A.w2_lo);  // four consecutive k of one column: adjacent in the image too
-            *reinterpret_cast<uint2*>(A.w2b + w2_image_index(e / H1, e % H1)) = __builtin_bit_cast(uint2, r);
+            const uint32_t ix = w2_image_index(e / H1, e % H1);
+            *reinterpret_cast<uint2*>(A.w2b + ix) = __builtin_bit_cast(uint2, r);
+            if (A.w2b_x9) {  // the other two parts of the exact split (split3_bf16)
+                const float pv[4] = {p4.x, p4.y, p4.z, p4.w};
+                uint16_t md[4], lw[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { uint16_t h; split3_bf16(pv[q], h, md[q], lw[q]); }
+                *reinterpret_cast<uint2*>(A.w2b + kImgElems + ix) = make_uint2((uint32_t)md[0] | ((uint32_t)md[1] << 16), (uint32_t)md[2] | ((uint32_t)md[3] << 16));
+                *reinterpret_cast<uint2*>(A.w2b + 2 * kImgElems + ix) = make_uint2((uint32_t)lw[0] | ((uint32_t)lw[1] << 16), (uint32_t)lw[2] | ((uint32_t)lw[3] << 16));
+            }
         }
         if (A.w2f && i >= A.w2_lo && i < A.w2_lo + H2 * H1) {
             const uint32_t e = (uint32_t)(i - A.w2_lo);
@@ -697,6 +709,12 @@ static int adam_impl(const HxNets* N, const HxHyper* Hy, int32_t which, int32_t 
     }
     if (which != 0 && N->actor_w2_bf16 && !N->w2_bf16_all) {
         A.w2b = N->actor_w2_bf16;
+        A.w2_lo = kActor.W2();
+    }
+    if (which != 0 && N->actor_w2_x9) {
+        HX_REQUIRE(!N->actor_w2_bf16 && !N->w2_bf16_all, "hx_adam: actor_w2_x9 excludes the plain bf16 images (one acting format at a time)");
+        A.w2b = N->actor_w2_x9;
+        A.w2b_x9 = 1;
         A.w2_lo = kActor.W2();
     }
     if (uint16_t* im = N->w2_bf16_all) {  // bf16 update path: the images of every W2 this step changes (and of the target it moves) follow it

@@ -191,6 +191,21 @@ int hx_actor_act_step_f32i(const float* actor, const float* w2_f32i, float* stat
                            float slope, float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts /* host, may be NULL */,
                            void* stream);
 
+/* fp32 policy inference with the 256 -> 512 product on the bf16 matrix cores, EXACTLY: every fp32 operand is the sum of three bf16 numbers
+ * (x = hi + mid + lo: 3 x 8 significand bits = fp32's 24, the split loses nothing), every one of the 9 partial products of a pair is exact in
+ * fp32, and v_mfma_f32_16x16x32_bf16 accumulates them in fp32 — the small ones in an accumulator of their own that joins hi x hi at the end.
+ * The same products as fp32 arithmetic, summed in another order: results within the fp32 kernels' own rounding noise (tests/test_x9_gpu.py
+ * measures both against an fp64 evaluation), NOT bit-identical to hx_actor_act.  9 bf16 MFMAs per 32 k cost 144 matrix-core cycles against
+ * 256 for fp32 MFMA (the bf16 units are 16 x faster).  w2_x9 = [3][512][256] bf16: hi | mid | lo images of W2 in the bf16 acting kernels'
+ * format; hx_pack_w2_x9 writes them, HxNets.actor_w2_x9 keeps them current through every Adam step of the actor.  Deterministic head only. */
+int hx_pack_w2_x9(const float* net, int32_t in_dim, uint16_t* w2_x9, void* stream);
+int hx_actor_act_x9(const float* actor, const uint16_t* w2_x9, const float* obs, int64_t rows, float* actions, int32_t noise_mode,
+                    const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, void* stream);
+int hx_actor_act_step_x9(const float* actor, const uint16_t* w2_x9, float* state, int64_t n, int64_t stride, float* obs_io,
+                         float* actions, int32_t noise_mode, const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call,
+                         float slope, float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts /* host, may be NULL */,
+                         void* stream);
+
 /* Minibatch of Agent.learn (HIRL.py:223-251), already assembled by hx_sample_batch into compact row tiles:
  * rows[batch][HX_ROW_WORDS] = s[13] a[4] s'[13] r done (buffer rows first, then expert rows, HIRL.py:229-233);
  * bc_rows[batch][HX_ROW_WORDS]: cols 0..12 state, 13..16 action of the BC minibatch (HIRL.py:248-251; NULL for TD3). */
@@ -217,6 +232,8 @@ typedef struct HxNets {
                                 the actor's image in the bf16 acting kernels' format: actor_w2_bf16 must then be NULL or point at them */
     const uint32_t* xchg_status; /* NULL, or the status word of hx_allreduce_oneshot: while it is non-zero (an exchange failed: the summed
                                 gradient is garbage) hx_adam / hx_adam_mixed change nothing — no parameter, moment, target or image */
+    uint16_t* actor_w2_x9;   /* NULL, or the [3][512][256] hi | mid | lo bf16 images of the actor's full2.weight (hx_pack_w2_x9): refreshed by
+                                every Adam step of the actor like the other two; hx_actor_act*_x9 read them */
 } HxNets;
 
 /* bf16 update path (BASELINE.json configs[4] "bf16 actor/critic + fp32 dynamics"; SURVEY.md 7 "bf16 config").  With HxNets.w2_bf16_all set,

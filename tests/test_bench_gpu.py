@@ -101,6 +101,10 @@ def test_bench_labels_follow_the_arguments():
     check(d, 1, 60, 10, envs=16384, dtype="bf16", fused=False)  # > 8,192 envs: act and env step are two launches
     assert "configs[4]" in d["config"]["workload"] and "bf16 actor/critic" in d["config"]["workload"]
     assert d["roofline_update"]["peak"] == 2500.0 and d["roofline_act"]["peak"] == 2500.0
+    d = run([sys.executable, "bench.py", "--dtype", "f32x9", "--no-cpu-baseline"] + common)  # opt-in: never labelled as the configs[1] line
+    check(d, 1, 60, 10, dtype="f32 (policy product: exact bf16 x 9 split)")
+    assert "configs[" not in d["config"]["workload"] and "9-term bf16 split" in d["config"]["workload"] and d["roofline"]["peak"] == 157.3
+    assert d["roofline"]["traffic"] is None  # (the committed PMC passes are of the fp32-MFMA kernel)
     d = run([sys.executable, "bench.py", "--agent", "sac", "--envs", "16384", "--scenario", "serpentine", "--cpu-seconds", "4"] + common)
     check(d, 1, 60, 10, envs=16384, fused=False)
     assert "configs[2]" in d["config"]["workload"] and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0

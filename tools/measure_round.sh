@@ -19,6 +19,8 @@ while read -r cfg; do
 done <<'CFGS'
 --dtype bf16
 --dtype bf16_policy
+--dtype f32x9
+--dtype f32x9 --envs 16384 --scenario mixed
 --agent sac --envs 16384 --scenario serpentine
 --envs 16384 --scenario mixed
 --envs 16384 --scenario mixed --dtype bf16
