@@ -296,7 +296,9 @@ def main(config):
         elif hirl and config.type == "soft" and rank == 0:
             print("WARNING: HIRL-soft without --bc_actor: the soft weight is estimated against a randomly initialised bc_actor", flush=True)
     dtype = getattr(config, "dtype", "f32")
-    if dtype != "f32" and not sac:  # bf16: actor AND critic (BASELINE.json configs[4]); bf16_policy: policy inference only
+    if dtype == "f32x9" and not sac:  # fp32, the acting kernel's 256 -> 512 product as the exact 9-term bf16 split (engine.set_act_dtype)
+        eng.set_act_dtype("f32x9")
+    elif dtype != "f32" and not sac:  # bf16: actor AND critic (BASELINE.json configs[4]); bf16_policy: policy inference only
         eng.set_act_dtype("bf16")
         if dtype == "bf16":
             eng.set_update_dtype("bf16")
@@ -447,7 +449,7 @@ def parser():
     p.add_argument("--snapshot_every", type=int, default=25, help="episodes between whole-run snapshots (0: never)")
     p.add_argument("--resume", type=str, default=None, help="run directory holding state_rank<r>.pt to continue from")
     p.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; without a launcher environment the driver starts them itself")
-    p.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "bf16_policy"],
+    p.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "bf16_policy", "f32x9"],
                    help="bf16: policy inference AND the 256<->512 products of learn() on bf16 MFMA (fp32 accumulate, fp32 master weights / Adam / "
                         "LayerNorm / dynamics); bf16_policy: policy inference only")
     p.add_argument("--synthetic_expert", action="store_true", help="uniform-random stand-in for the expert CSV (throughput runs and tests ONLY)")

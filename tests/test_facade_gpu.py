@@ -166,14 +166,15 @@ def test_checkpoints_round_trip(tmp_path):
     assert len(out) == 2 and np.isfinite(out[0]) and np.isfinite(out[1])
 
 
-def test_vectorised_driver_runs_and_learns_something(tmp_path, capsys):
+@pytest.mark.parametrize("dtype", ["f32", "f32x9"])
+def test_vectorised_driver_runs_and_learns_something(tmp_path, capsys, dtype):
     """Two short 'episodes' of the vectorised train_all on 256 envs: exploration, expert labelling, act/step/learn,
-    schedules, stats — end to end through the HIP path."""
+    schedules, stats — end to end through the HIP path (f32x9: with the acting kernel's product as the exact bf16 split)."""
     from hirl4ucav_amd import train_all as T
 
     T.MAX_STEP["straight_line"] = 40
     try:
-        cfg = T.parser().parse_args(["--agent", "HIRL", "--type", "soft", "--env", "straight_line", "--random", "--seed", "1",
+        cfg = T.parser().parse_args(["--agent", "HIRL", "--type", "soft", "--env", "straight_line", "--random", "--seed", "1", "--dtype", dtype,
                                      "--num_envs", "256", "--episodes", "2", "--result_dir", str(tmp_path), "--buffer_size", "65536", "--synthetic_expert"])
         T.main(cfg)
     finally:
