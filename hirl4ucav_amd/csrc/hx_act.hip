@@ -5,11 +5,12 @@
 //   SacAgent.explore / exploit                                          hirl/agents/SAC/agent.py:183-196    -> hx_sac_act*
 #include <hip/hip_ext.h>
 
-#include "hx_update.h"
+#include "hx_act.h"
 #include "hx_env_dev.h"
 
 using namespace hxnn;
 using namespace hxu;
+using namespace hxact;
 
 namespace {
 
@@ -20,45 +21,9 @@ namespace {
 // of z2.  No z2 round trip through HBM, no second launch.
 // chooseAction / chooseActionSmallNoise / chooseActionNoNoise, HIRL.py:192-212.
 // ---------------------------------------------------------------------------------------------------------------
-struct ActFusedArgs {
-    const float* net;
-    Mlp m;
-    float* obs;        // [rows][13]; written only by the ENV instantiations (next observation)
-    int rows;
-    float slope;
-    float* actions;      // [rows][4]
-    const float* noise;  // deterministic head: nullptr, [4] (shared) or [rows][4] additive noise; Gaussian head: eps [rows][4] or nullptr
-    int noise_per_row;
-    float sigma;
-    int mode;            // Gaussian head: 0 exploit tanh(mean), 1 sample with eps, 2 sample with Philox
-    uint64_t seed;
-    uint32_t row0, call;
-    // ENV instantiations: HarfangEnv.step for the same rows in the tail of this launch (obs is then in/out)
-    float* state;
-    int64_t stride;
-    float* reward;
-    uint8_t* done;
-    int8_t* success;
-    HxStepOpts o;
-    double inv_cap;  // 1 / o.cap
-    const uint16_t* w2b;  // BF16 instantiations: bf16 image of W2 [512][256] (hx_pack_w2_bf16 / the actor's Adam step keep it current)
-    const float* w2f;     // F32I instantiations: fp32 image of W2 (hx_pack_w2_f32i)
-    int x9;               // X3 instantiations: w2b is the first of THREE images hi | mid | lo (hx_pack_w2_x9): the exact bf16 split of W2
-};
-
-
 constexpr int ACT_KC = 16;            // k-chunk of W2 staged through LDS (64 B per column), double-buffered
 constexpr int ACT_LDW = ACT_KC + 8;   // pitch = 8 mod 16 dwords: conflict-free ds_read_b128 (see LDA1)
 constexpr int ACT_NCH = H1 / ACT_KC;  // 16 chunks
-
-// one standard-normal draw per (row, component j) of the acting kernels: Philox4x32-10(seed; row, call, tag) + Box-Muller
-__device__ __forceinline__ float philox_normal(uint32_t row, uint32_t call, uint32_t tag, uint64_t seed, int j) {
-    uint32_t u[4];
-    philox4x32_10(row, call, tag, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), u);
-    const float ua = u01(u[j & 2]), ub = u01(u[(j & 2) + 1]);
-    const float rad = sqrtf(-2.0f * logf(ua)), ang = 6.28318530717958647692f * ub;
-    return (j & 1) ? rad * sinf(ang) : rad * cosf(ang);
-}
 
 // NRT = 16-row tiles per workgroup: 1 keeps 256 workgroups busy at 4,096 rows; 2 (from 8,192 rows on) multiplies every W2
 // chunk against two row tiles, halving W2's L2 traffic and the barriers per MFMA.
@@ -575,10 +540,9 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
     SPAN_LOG(HX_SPAN_ACT);
 }
 
-// 16 rows per workgroup fill the chip up to 4,096 rows; from 8,192 rows on 32 rows per workgroup reuse every W2 chunk twice
-// The env tail pays while the launch is ONE round of workgroups (256 CUs x 16 or 32 rows): beyond that every extra round repeats
-// the ~8 us tail, and the env kernel on its own (thousands of envs per launch, 10-14 us) is the cheaper way.
-constexpr int64_t kFuseEnvMax = 8192;
+// 16 rows per workgroup fill the chip up to 4,096 rows; from 8,192 rows on 32 rows per workgroup reuse every W2 chunk twice.
+// The env tail on wave 0 pays while the launch is ONE round of workgroups (256 CUs x 16 or 32 rows: kFuseEnvMax, hx_act.h); beyond that the
+// persistent kernel of hx_actp.hip takes the launch (its env tail runs on all 16 waves, once per workgroup).
 
 // ENV launches carry HxStepOpts: with ev_start / ev_stop set the launch is stamped with the kernel's own begin / end (bench.py's live
 // roofline of the act + env launch, as hx_env_step does for the env kernel)
@@ -610,8 +574,15 @@ static void launch_act_t(const ActFusedArgs& H, hipStream_t st) {
         else launch_act_k(act_fused_kernel<1, GAUSS, false, BF16, RELU, F32I, X3>, grid, H, st);
     }
 }
+// HX_ACT_PERSIST=0 keeps act_fused_kernel at every size (A/B timing, bit-identity tests of the two kernels)
+static bool persist_enabled() {
+    const char* e = getenv("HX_ACT_PERSIST");
+    return !(e && e[0] == '0');
+}
 template <bool GAUSS>
 static void launch_act(const ActFusedArgs& H, hipStream_t st) {
+    // beyond one round of workgroups: persistent workgroups that fetch W2 once (hx_actp.hip)
+    if (H.rows > kFuseEnvMax && persist_enabled() && launch_act_persist(H, GAUSS, st)) return;
     // the activation is a compile-time ReLU when the slope is 0 (HIRL, SAC; the Gaussian policy is a Linear-ReLU stack by definition)
     if (!GAUSS && H.w2b && H.x9) {  // fp32 through the exact bf16 split (deterministic head only)
         if (H.slope == 0.0f) launch_act_t<false, false, true, false, true>(H, st);
@@ -741,13 +712,17 @@ static int actor_act_step_impl(const float* actor, const uint16_t* w2b, const fl
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_actor_act_step: bad noise mode");
     const HxStepOpts o = opts ? *opts : HxStepOpts{};
     if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_actor_act_step")) return rc;
-    if (n > kFuseEnvMax) {  // more than one round of workgroups: the env step is cheaper as a launch of its own
-        if (int rc = actor_act_impl(actor, w2b, w2f, obs_io, n, actions, mode_in, noise, sigma, seed, row0, call, slope, stream)) return rc;
-        return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
-    }
     ActFusedArgs H{actor, mA, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
                    noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
                    o.cap > 0 ? 1.0 / (double)o.cap : 0.0, w2b, w2f, x9};
+    if (n > kFuseEnvMax) {  // more than one round of 32-row workgroups: the persistent kernel (env tail on all waves), else two launches
+        if (persist_enabled() && launch_act_persist(H, false, (hipStream_t)stream)) {
+            HX_CHECK_LAUNCH("hx_actor_act_step");
+            return 0;
+        }
+        if (int rc = actor_act_impl(actor, w2b, w2f, obs_io, n, actions, mode_in, noise, sigma, seed, row0, call, slope, stream)) return rc;
+        return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
+    }
     launch_act<false>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_actor_act_step");
     return 0;
@@ -840,12 +815,16 @@ static int sac_act_step_impl(const float* policy, const float* w2f, float* state
     HX_REQUIRE(policy && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act_step: bad arguments");
     const HxStepOpts o = opts ? *opts : HxStepOpts{};
     if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_sac_act_step")) return rc;
+    ActFusedArgs H{policy, kPolicy, obs_io, (int)n, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
+                   state, stride, reward, done, success, o, o.cap > 0 ? 1.0 / (double)o.cap : 0.0, nullptr, w2f};
     if (n > kFuseEnvMax) {
+        if (persist_enabled() && launch_act_persist(H, true, (hipStream_t)stream)) {
+            HX_CHECK_LAUNCH("hx_sac_act_step");
+            return 0;
+        }
         if (int rc = sac_act_impl(policy, w2f, obs_io, n, actions, mode, eps, seed, row0, call, stream)) return rc;
         return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
     }
-    ActFusedArgs H{policy, kPolicy, obs_io, (int)n, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
-                   state, stride, reward, done, success, o, o.cap > 0 ? 1.0 / (double)o.cap : 0.0, nullptr, w2f};
     launch_act<true>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_sac_act_step");
     return 0;

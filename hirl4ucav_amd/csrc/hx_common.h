@@ -41,6 +41,7 @@ inline int fail(int code, const char* fmt, ...) {
 int dbg_stamps_fwdbwd(float* host80);
 int dbg_stamps_wgrad(float* host80);
 int dbg_stamps_act(float* host80);
+int dbg_stamps_actp(float* host80);
 int dbg_spans_fwdbwd(unsigned long long* spans, unsigned* tags, unsigned* n, unsigned cap);
 int dbg_spans_wgrad(unsigned long long* spans, unsigned* tags, unsigned* n, unsigned cap);
 int dbg_spans_act(unsigned long long* spans, unsigned* tags, unsigned* n, unsigned cap);
