@@ -44,6 +44,145 @@ __device__ __forceinline__ float philox_normal(uint32_t row, uint32_t call, uint
     return (j & 1) ? rad * sinf(ang) : rad * cosf(ang);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Row arithmetic of the acting kernels: SIXTEEN LANES PER ROW, four rows per wave.
+// Lane (q = lane >> 4, c = lane & 15) of a wave works on row q of the wave's four rows and owns that row's columns 64 i + 4 c .. + 3
+// (i < N / 64): one 16-byte LDS read per i, and a row sum is the lane's sequential sum followed by FOUR DPP adds inside the 16-lane row
+// (sum16u) — every lane of the row then holds it, bit for bit.  With a whole wave per row (round 1-3) each of the six sums of a head row cost 4 DPP adds
+// + 4 v_readlane + 3 adds + the hazard nops: 280 of the ~850 instructions two head rows took, on a phase that is VALU-issue bound
+// (131,072 rows x ~350 instructions = 75 us of the whole chip's vector issue).  Here the reductions of FOUR rows are 4 instructions.
+// Both acting kernels use these functions, with contraction off and every fused multiply-add spelled out, so a row's action does not depend
+// on the kernel, the row tiling or the wave that computed it (tests/test_actp_gpu.py, test_act_row_tilings_agree_bit_for_bit).
+// ---------------------------------------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+// Sum over the 16 lanes of a row that leaves the SAME BITS in every lane: two quad permutes, then half-mirror and mirror — a butterfly whose
+// partners add the same two numbers (a + b and b + a).  hx_nn.h's sum16 ends with two rotations instead: its quads 0 / 2 and 1 / 3 hold
+// (B0 + B1) + (B2 + B3) and (B1 + B2) + (B3 + B0) — one rounding apart now and then, which is fine for wave_sum (it reads quad 0) but not
+// for lanes that each go on with their own copy.  The value equals sum16's quad-0 value.
+__device__ __forceinline__ float sum16u(float v) {
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    v = dpp_add<0x140>(v);  // row_mirror
+    return v;
+}
+// The element arithmetic runs on PACKED fp32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two IEEE operations per lane and instruction —
+// the phase is bound by vector issue): every running sum is kept as an (even, odd) pair — elements 0, 1 of a 16-byte piece open / extend
+// the pair, elements 2, 3 extend it — and the two halves meet in one add before the cross-lane sum.
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// two-pass LayerNorm statistics of this lane's row from its PER elements (nn.LayerNorm: biased variance, eps inside the root)
+template <int PER>
+__device__ __forceinline__ void row_stats16(const float (&v)[PER], int n, float& mean, float& rstd) {
+    v2f s2 = v2f{v[0], v[1]} + v2f{v[2], v[3]};
+#pragma unroll
+    for (int i = 4; i < PER; i += 4) {
+        s2 = s2 + v2f{v[i], v[i + 1]};
+        s2 = s2 + v2f{v[i + 2], v[i + 3]};
+    }
+    mean = sum16u(s2.x + s2.y) / (float)n;
+    const v2f m2 = {mean, mean};
+    v2f q2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < PER; i += 2) {
+        const v2f d = v2f{v[i], v[i + 1]} - m2;
+        q2 = fma2(d, d, q2);
+    }
+    rstd = __builtin_amdgcn_rsqf(sum16u(q2.x + q2.y) / (float)n + LN_EPS);  // v_rsq_f32, as row_stats
+}
+// this lane's 16 (N = 256) or 32 (N = 512) elements of the LDS row `row`
+template <int N>
+__device__ __forceinline__ void load_row16(const float* row, int c, float (&v)[N / 16]) {
+#pragma unroll
+    for (int i = 0; i < N / 64; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(row + 64 * i + 4 * c);
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+}
+// LN1 + activation, elementwise (any layout): h1 = act(g1 (z1 - mean) rstd + be1)   Actor.forward, HIRL.py:128-131
+template <bool RELU>
+__device__ __forceinline__ float ln_act(float z, float mean, float rstd, float g, float be, float slope) {
+    return act_f<RELU>(__builtin_fmaf(g, (z - mean) * rstd, be), slope);
+}
+template <bool RELU>
+__device__ __forceinline__ v2f ln_act2(v2f z, v2f mean, v2f rstd, v2f g, v2f be, float slope) {  // the same, two elements
+    const v2f y = fma2(g, (z - mean) * rstd, be);
+    return v2f{act_f<RELU>(y.x, slope), act_f<RELU>(y.y, slope)};
+}
+// Head of this lane's row from the LDS copy of z2 and the LDS head image (HeadImage<IMG>: g2 | be2 | W3 rows | b3): LN2, activation, final
+// layer.  Every lane of the row's 16 ends up with all OUT pre-tanh outputs.  The row's 32 elements per lane are read from LDS in each of the
+// three passes (statistics twice, projection) instead of living in 32 registers: the reads of a later pass do not depend on the earlier
+// pass's result, so they cost LDS bandwidth (which this phase does not lack), not latency.
+template <int OUT, int IMG, bool RELU>
+__device__ __forceinline__ void head16(const float* zrow, const float* hp, int c, float slope, int no_ln, float (&o)[OUT]) {
+    float mean, rstd;
+    v2f s2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const v4f t = *reinterpret_cast<const v4f*>(zrow + 64 * i + 4 * c);
+        // (the association of row_stats16: the first piece opens the pair)
+        s2 = i == 0 ? v2f{t[0], t[1]} + v2f{t[2], t[3]} : (s2 + v2f{t[0], t[1]}) + v2f{t[2], t[3]};
+    }
+    mean = sum16u(s2.x + s2.y) / (float)H2;
+    v2f m2 = {mean, mean};
+    v2f q2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const v4f t = *reinterpret_cast<const v4f*>(zrow + 64 * i + 4 * c);
+        v2f d = v2f{t[0], t[1]} - m2;
+        q2 = fma2(d, d, q2);
+        d = v2f{t[2], t[3]} - m2;
+        q2 = fma2(d, d, q2);
+    }
+    rstd = __builtin_amdgcn_rsqf(sum16u(q2.x + q2.y) / (float)H2 + LN_EPS);
+    if (no_ln) { mean = 0.0f; rstd = 1.0f; }
+    m2 = v2f{mean, mean};
+    const v2f r2 = {rstd, rstd};
+    v2f acc[OUT];
+#pragma unroll
+    for (int j = 0; j < OUT; ++j) acc[j] = v2f{0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const v4f z = *reinterpret_cast<const v4f*>(zrow + 64 * i + 4 * c);
+        const v4f g = *reinterpret_cast<const v4f*>(hp + 64 * i + 4 * c);
+        const v4f be = *reinterpret_cast<const v4f*>(hp + H2 + 64 * i + 4 * c);
+        const v2f h01 = ln_act2<RELU>(v2f{z[0], z[1]}, m2, r2, v2f{g[0], g[1]}, v2f{be[0], be[1]}, slope);
+        const v2f h23 = ln_act2<RELU>(v2f{z[2], z[3]}, m2, r2, v2f{g[2], g[3]}, v2f{be[2], be[3]}, slope);
+#pragma unroll
+        for (int j = 0; j < OUT; ++j) {
+            const v4f w = *reinterpret_cast<const v4f*>(hp + (2 + j) * H2 + 64 * i + 4 * c);
+            acc[j] = fma2(h01, v2f{w[0], w[1]}, acc[j]);
+            acc[j] = fma2(h23, v2f{w[2], w[3]}, acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < OUT; ++j) o[j] = sum16u(acc[j].x + acc[j].y) + hp[(2 + IMG) * H2 + j];
+}
+#pragma clang fp contract(fast)
+
+// What follows the head for the row of lane (q, c), c < 4 = the action component: tanh, exploration noise, clamp (chooseAction*,
+// HIRL.py:192-212) or the tanh-Gaussian sample (GaussianPolicy.sample, SAC/model.py:63-82).  s_noise: the row's four standard-normal draws.
+template <bool GAUSS, int OUT>
+__device__ __forceinline__ float action_of(const ActFusedArgs& A, const float (&o)[OUT], int c, int r, const float* s_noise) {
+    if constexpr (!GAUSS) {
+        float a = fast_tanh(c == 0 ? o[0] : c == 1 ? o[1] : c == 2 ? o[2] : o[3]);  // no dynamic register index
+        if (A.noise) a = fminf(fmaxf(a + A.noise[(A.noise_per_row ? (size_t)r * 4 : 0) + c], -1.0f), 1.0f);
+        else if (A.sigma > 0.0f) a = fminf(fmaxf(a + A.sigma * s_noise[c], -1.0f), 1.0f);
+        return a;
+    } else {
+        // (selected from VALUES: a select chain over the elements of the array itself is folded back into a run-time index, which puts the
+        //  array in scratch or — promoted — in 32 KB of LDS)
+        const float o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3], o4 = o[4], o5 = o[5], o6 = o[6], o7 = o[7];
+        const float mu = c == 0 ? o0 : c == 1 ? o1 : c == 2 ? o2 : o3;
+        float a = mu;
+        if (A.mode != 0) {
+            const float ls = fminf(fmaxf(c == 0 ? o4 : c == 1 ? o5 : c == 2 ? o6 : o7, -20.0f), 2.0f);  // model.py:65-66
+            const float e = A.mode == 1 ? A.noise[(size_t)r * 4 + c] : s_noise[c];
+            a = mu + expf(ls) * e;
+        }
+        return tanhf(a);
+    }
+}
+
 // Rows beyond which the persistent kernel takes over (hx_actp.hip).  Up to here ONE round of 16- / 32-row workgroups covers the rows and
 // the env step rides in wave 0 of each; beyond, every further round of workgroups would fetch the whole W2 image again.
 constexpr int64_t kFuseEnvMax = 8192;

@@ -161,16 +161,18 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int t = 0; t < NRT; ++t) {  // LN1 statistics: wave w owns rows w, 16 + w
-        const int row = t * RT + wave;
-        float v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = h1s[row * LDA1 + i * 64 + lane];
+    // LN1 statistics, 16 lanes per row (hx_act.h): waves 0 .. 4 NRT - 1 take four rows each — wave w rows w, w + 4 NRT, ... (eight rows
+    // apart at NRT = 2: the pitch is 8 mod 64 dwords, so the four rows of a wave's 16-byte reads fall on disjoint banks)
+    constexpr int kRowWaves = 4 * NRT;
+    const int gq = lane >> 4, gc = lane & 15;
+    if (wave < kRowWaves) {
+        const int row = wave + kRowWaves * gq;
+        float v[16];
+        load_row16<H1>(h1s + row * LDA1, gc, v);
         float mean, rstd;
-        row_stats<4>(v, H1, mean, rstd);
+        row_stats16<16>(v, H1, mean, rstd);
         if (m.no_ln) { mean = 0.0f; rstd = 1.0f; }
-        if (lane == 0) {
+        if (gc == 0) {
             sts[row * 2] = mean;
             sts[row * 2 + 1] = rstd;
         }
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = t * RT + 4 * lg + r;
-            const float hv = act_f<RELU>(g1v * ((z1[t][r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
+            const float hv = ln_act<RELU>(z1[t][r], sts[row * 2], sts[row * 2 + 1], g1v, be1v, slope);
             if (BF16) h1b[row * LDB1 + u] = (__bf16)hv;  // v_cvt_pk_bf16_f32: round to nearest even
             else if (X3) split3_bf16(hv, h1x[row * LDB1 + u], h1x[(ROWS + row) * LDB1 + u], h1x[(2 * ROWS + row) * LDB1 + u]);
             else h1s[row * LDA1 + u] = hv;
@@ -361,44 +363,17 @@ __global__ __launch_bounds__(kWide) void act_fused_kernel(ActFusedArgs A) {
 #pragma unroll
         for (int j = 0; j < HX_OBS_DIM; ++j) envPrev[j] = (A.o.ring && env_opp) ? A.obs[((size_t)r0 + env_e) * HX_OBS_DIM + j] : 0.0f;
     }
-#pragma unroll
-    for (int t = 0; t < NRT; ++t) {  // head: wave w owns rows w, 16 + w
-        const int lr = t * RT + wave;
-        if (lr >= nrow) continue;
-        const int r = r0 + lr;
-        RowReg<H2> xh, y, z;
-        float mean, rstd;
-        z.load(z2s + lr * LDA2);
-        if (!GAUSS) {
-            float o[4];
-            head_regs<4, 4, RELU>(z, hps, m.out, slope, xh, y, mean, rstd, o, m.no_ln);
-            if (lane < 4) {
-                float a = fast_tanh(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // no dynamic register index
-                if (A.noise) {
-                    a = fminf(fmaxf(a + A.noise[(A.noise_per_row ? (size_t)r * 4 : 0) + lane], -1.0f), 1.0f);
-                } else if (A.sigma > 0.0f) {
-                    a = fminf(fmaxf(a + A.sigma * s_noise[lr * 4 + lane], -1.0f), 1.0f);
-                }
-                A.actions[(size_t)r * 4 + lane] = a;
-                if (ENV) s_act[lr * 4 + lane] = a;
-            }
-        } else {
-            float o[8];
-            head_regs<8, 8, RELU>(z, hps, m.out, slope, xh, y, mean, rstd, o, m.no_ln);
-            if (lane < 4) {
-                // (selected from VALUES: a select chain over the elements of the array itself is folded back into a run-time index, which
-                //  puts the array in scratch or — promoted — in 32 KB of LDS)
-                const float o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3], o4 = o[4], o5 = o[5], o6 = o[6], o7 = o[7];
-                const float mu = lane == 0 ? o0 : lane == 1 ? o1 : lane == 2 ? o2 : o3;
-                float a = mu;
-                if (A.mode != 0) {
-                    const float ls = fminf(fmaxf(lane == 0 ? o4 : lane == 1 ? o5 : lane == 2 ? o6 : o7, -20.0f), 2.0f);  // model.py:65-66
-                    const float e = A.mode == 1 ? A.noise[(size_t)r * 4 + lane] : s_noise[lr * 4 + lane];
-                    a = mu + expf(ls) * e;
-                }
-                a = tanhf(a);
-                A.actions[(size_t)r * 4 + lane] = a;
-                if (ENV) s_act[lr * 4 + lane] = a;
+    // head, 16 lanes per row (hx_act.h): waves 0 .. 4 NRT - 1, four rows each, the same rows as in the LN1 statistics
+    if (wave < kRowWaves) {
+        const int lrow = wave + kRowWaves * gq;
+        if (lrow < nrow) {
+            const int r = r0 + lrow;
+            float o[GAUSS ? 8 : 4];
+            head16<GAUSS ? 8 : 4, GAUSS ? 8 : 4, RELU>(z2s + lrow * LDA2, hps, gc, slope, m.no_ln, o);
+            if (gc < 4) {
+                const float a = action_of<GAUSS>(A, o, gc, r, s_noise + lrow * 4);
+                A.actions[(size_t)r * 4 + gc] = a;
+                if (ENV) s_act[lrow * 4 + gc] = a;
             }
         }
     }

@@ -30,12 +30,17 @@ using namespace hxact;
 
 namespace {
 
+// -DHX_PX=mask builds a timing experiment (tools/ubench/actp_variants.sh; wrong results): 1 no head, 2 no LayerNorm 1, 4 no product MFMAs,
+// 8 no layer 1, 16 no z2 stores, 32 no noise draw
+#ifndef HX_PX
+#define HX_PX 0
+#endif
 constexpr int kEnvPass = 512;  // envs per pass of the tail: pair layout = 1,024 lanes = the workgroup
 
 // layer 1 of NRT row tiles on the fp32 matrix cores, exactly as act_fused_kernel does it: wave w owns hidden units 16 w .. 16 w + 15,
-// lane (lr, lg) ends up with rows 4 lg .. 4 lg + 3 of unit u; the pre-activations also go to h1s for the LayerNorm statistics
+// lane (lr, lg) ends up with rows 4 lg .. 4 lg + 3 of unit u; the pre-activations go to h1s (LayerNorm 1 reads them row-wise)
 template <int NRT>
-__device__ __forceinline__ void layer1_tiles(const float* xs, const float* w1s, float bias1, int u, int lr, int lg, float (&z1)[NRT][4], float* h1s) {
+__device__ __forceinline__ void layer1_tiles(const float* xs, const float* w1s, float bias1, int u, int lr, int lg, float* h1s) {
 #pragma unroll
     for (int t = 0; t < NRT; ++t) {
         v4f acc = {bias1, bias1, bias1, bias1};
@@ -47,75 +52,19 @@ __device__ __forceinline__ void layer1_tiles(const float* xs, const float* w1s, 
             acc = mfma16(xrow[4 * mm], 4 * mm + lg < 13 ? wv : 0.0f, acc);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            z1[t][r] = acc[r];
-            h1s[(t * RT + 4 * lg + r) * LDA1 + u] = z1[t][r];
-        }
+        for (int r = 0; r < 4; ++r) h1s[(t * RT + 4 * lg + r) * LDA1 + u] = acc[r];
     }
 }
 
-// LN1 statistics: wave w owns rows w, 16 + w, ...
-template <int NRT>
-__device__ __forceinline__ void ln1_stats(const float* h1s, float* sts, int wave, int lane, int no_ln) {
-#pragma unroll
-    for (int t = 0; t < NRT; ++t) {
-        const int row = t * RT + wave;
-        float v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = h1s[row * LDA1 + i * 64 + lane];
-        float mean, rstd;
-        row_stats<4>(v, H1, mean, rstd);
-        if (no_ln) { mean = 0.0f; rstd = 1.0f; }
-        if (lane == 0) {
-            sts[row * 2] = mean;
-            sts[row * 2 + 1] = rstd;
-        }
-    }
-}
-
-// head of the rows of NRT tiles (one wave per row: LN2, final layer, tanh, exploration noise, clamp) from the LDS copy of z2
-template <int NRT, bool GAUSS, bool RELU>
-__device__ __forceinline__ void head_tiles(const ActFusedArgs& A, const float* z2s, const float* hps, const float* s_noise, int r0, int nrow, int wave, int lane,
-                                           int t_lo = 0, int t_hi = NRT) {
-    const Mlp m = A.m;
-#pragma unroll
-    for (int t = 0; t < NRT; ++t) {
-        if (t < t_lo || t >= t_hi) continue;
-        const int lrow = t * RT + wave;
-        if (lrow >= nrow) continue;
-        const int r = r0 + lrow;
-        RowReg<H2> xh, y, z;
-        float mean, rstd;
-        z.load(z2s + (lrow - t_lo * RT) * LDA2);
-        if (!GAUSS) {
-            float o[4];
-            head_regs<4, 4, RELU>(z, hps, m.out, A.slope, xh, y, mean, rstd, o, m.no_ln);
-            if (lane < 4) {
-                float a = fast_tanh(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // no dynamic register index
-                if (A.noise) {
-                    a = fminf(fmaxf(a + A.noise[(A.noise_per_row ? (size_t)r * 4 : 0) + lane], -1.0f), 1.0f);
-                } else if (A.sigma > 0.0f) {
-                    a = fminf(fmaxf(a + A.sigma * s_noise[lrow * 4 + lane], -1.0f), 1.0f);
-                }
-                A.actions[(size_t)r * 4 + lane] = a;
-            }
-        } else {
-            float o[8];
-            head_regs<8, 8, RELU>(z, hps, m.out, A.slope, xh, y, mean, rstd, o, m.no_ln);
-            if (lane < 4) {
-                const float o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3], o4 = o[4], o5 = o[5], o6 = o[6], o7 = o[7];  // (values, not a run-time index: hx_act.hip)
-                const float mu = lane == 0 ? o0 : lane == 1 ? o1 : lane == 2 ? o2 : o3;
-                float a = mu;
-                if (A.mode != 0) {
-                    const float ls = fminf(fmaxf(lane == 0 ? o4 : lane == 1 ? o5 : lane == 2 ? o6 : o7, -20.0f), 2.0f);  // model.py:65-66
-                    const float e = A.mode == 1 ? A.noise[(size_t)r * 4 + lane] : s_noise[lrow * 4 + lane];
-                    a = mu + expf(ls) * e;
-                }
-                a = tanhf(a);
-                A.actions[(size_t)r * 4 + lane] = a;
-            }
-        }
-    }
+// the four standard-normal draws of a row, two per lane: lane (row, pair p) -> components 2 p (cos) and 2 p + 1 (sin) of philox_normal's
+// Box-Muller pairs — one Philox evaluation, logarithm and root per PAIR instead of per component, the same bits
+__device__ __forceinline__ void philox_normal_pair(uint32_t row, uint32_t call, uint32_t tag, uint64_t seed, int p, float& n_cos, float& n_sin) {
+    uint32_t u[4];
+    philox4x32_10(row, call, tag, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), u);
+    const float ua = u01(p ? u[2] : u[0]), ub = u01(p ? u[3] : u[1]);
+    const float rad = sqrtf(-2.0f * logf(ua)), ang = 6.28318530717958647692f * ub;
+    n_cos = rad * cosf(ang);
+    n_sin = rad * sinf(ang);
 }
 
 // the env step of rows [row_begin, row_end) — whose actions this workgroup has written — kEnvPass at a time (HarfangEnv.step, train_all.py:345)
@@ -141,15 +90,15 @@ __global__ __launch_bounds__(kWide) void act_persist_bf16_kernel(ActFusedArgs A,
     constexpr int kLoop = TR * LDA1 + TR * LDA2 + TR * LDB1 / 2;  // h1s (fp32 pre-activations), z2s, h1b (bf16)
     constexpr int kTail = ENV ? hxenv::kEnvBlockLds<true, kEnvPass> : 0;
     constexpr int kUnion = kLoop > kTail ? kLoop : kTail;
-    __shared__ __attribute__((aligned(16))) float lds[kW1 + Img::kStride + TR * XP + TR * 2 + TR * 4 + kUnion];
+    __shared__ __attribute__((aligned(16))) float lds[kW1 + Img::kStride + TR * XP + 2 * H1 + 2 * TR * 4 + kUnion];
     __shared__ unsigned s_slot0;
     __shared__ int s_wcount[kWide / 64];
     float* w1s = lds;
     float* hps = w1s + kW1;
     float* xs = hps + Img::kStride;
-    float* sts = xs + TR * XP;
-    float* s_noise = sts + TR * 2;
-    float* h1s = s_noise + TR * 4;
+    float* g1s = xs + TR * XP;          // LayerNorm 1 weight | bias, read four columns at a time
+    float* s_noise = g1s + 2 * H1;      // [2][TR][4]: the draws of tile t live in half t & 1
+    float* h1s = s_noise + 2 * TR * 4;
     float* z2s = h1s + TR * LDA1;
     __bf16* h1b = reinterpret_cast<__bf16*>(z2s + TR * LDA2);
     const int tid0 = threadIdx.x;
@@ -167,38 +116,40 @@ __global__ __launch_bounds__(kWide) void act_persist_bf16_kernel(ActFusedArgs A,
         const int r0 = row_begin + tile * TR;
         return (tile < ntile && tid < TR * 13 && r0 + tid / 13 < row_end) ? A.obs[(size_t)r0 * 13 + tid] : 0.0f;
     };
-    float xv, bias1, g1v, be1v, bb0, bb1;
+    float xv, bias1, bb0, bb1;
     uint4 bq[2][8];  // B fragments of this wave's two column tiles, all of K: resident for every tile
     {
-    const int tid = tid0, wave = tid >> 6, lane = tid & 63, lr = lane & 15, u = wave * 16 + lr;
-    xv = obs_of(0, tid);
-    float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < kW1 / 4) wv = reinterpret_cast<const float4*>(net + m.W1())[tid];
-    bias1 = net[m.b1() + u]; g1v = net[m.g1() + u]; be1v = net[m.be1() + u];
-    Img himg;
-    himg.fetch(net, m, tid);
-    // which 32 columns this wave owns rotates with the workgroup: the workgroups of a launch do not all ask L2 for the same lines at once
-    const int cw = (wave + (int)blockIdx.x) & 15;
-    bb0 = net[m.b2() + cw * 16 + lr]; bb1 = net[m.b2() + 256 + cw * 16 + lr];
+        const int tid = tid0, wave = tid >> 6, lane = tid & 63, lr = lane & 15, u = wave * 16 + lr;
+        xv = obs_of(0, tid);
+        float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < kW1 / 4) wv = reinterpret_cast<const float4*>(net + m.W1())[tid];
+        bias1 = net[m.b1() + u];
+        const float gb = tid < 2 * H1 ? net[m.g1() + tid] : 0.0f;  // g1 | be1 are adjacent in the parameter block
+        Img himg;
+        himg.fetch(net, m, tid);
+        // which 32 columns this wave owns rotates with the workgroup: the workgroups of a launch do not all ask L2 for the same lines at once
+        const int cw = (wave + (int)blockIdx.x) & 15;
+        bb0 = net[m.b2() + cw * 16 + lr];
+        bb1 = net[m.b2() + 256 + cw * 16 + lr];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const uint16_t* blk = A.w2b + (size_t)((t * 16 + cw) * 8) * 512 + lane * 8;  // (lane = 16 g + r: w2_image_index's block order)
+        for (int t = 0; t < 2; ++t) {
+            const uint16_t* blk = A.w2b + (size_t)((t * 16 + cw) * 8) * 512 + lane * 8;  // (lane = 16 g + r: w2_image_index's block order)
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl) bq[t][sl] = *reinterpret_cast<const uint4*>(blk + sl * 512);
-    }
-    if (tid < kW1 / 4) reinterpret_cast<float4*>(w1s)[tid] = wv;
-    if (tid < TR * XP) xs[tid] = 0.0f;
-    himg.store(hps, net, m, tid);
-    __syncthreads();
-    if (tid < TR * 13) xs[(tid / 13) * XP + tid % 13] = xv;
-    xv = obs_of(1, tid);
-    __syncthreads();
+            for (int sl = 0; sl < 8; ++sl) bq[t][sl] = *reinterpret_cast<const uint4*>(blk + sl * 512);
+        }
+        if (tid < kW1 / 4) reinterpret_cast<float4*>(w1s)[tid] = wv;
+        if (tid < 2 * H1) g1s[tid] = gb;
+        if (tid < TR * XP) xs[tid] = 0.0f;
+        himg.store(hps, net, m, tid);
+        __syncthreads();
+        if (tid < TR * 13) xs[(tid / 13) * XP + tid % 13] = xv;
+        xv = obs_of(1, tid);
+        __syncthreads();
     }
     const bool draw_noise = !A.noise && A.sigma > 0.0f;
     STAMP();
-    // ---- the tile loop: iteration i runs tile i's layer 1 / LN1 and tile i - 1's product and head ----------------------------------
+    // ---- the tile loop: iteration i runs tile i's layer 1 / LayerNorm 1 and tile i - 1's product and head, two barriers per tile ------
     for (int i = 0; i <= ntile; ++i) {
-        if (i == 2) STAMP();
         // The lane's LDS addresses are loop invariants, and with 64 registers of weights resident the allocator spills them; behind this
         // opaque copy of the thread id they are recomputed per tile (a few VALU instructions) instead of living across the loop.
         int tid = tid0;
@@ -207,68 +158,85 @@ __global__ __launch_bounds__(kWide) void act_persist_bf16_kernel(ActFusedArgs A,
         const int lr = lane & 15, lg = lane >> 4, u = wave * 16 + lr;
         const int r0p = row_begin + (i - 1) * TR;  // first row of tile i - 1
         const int cw = (wave + (int)blockIdx.x) & 15;
-        float z1[NRT][4];
-        // P1
-        if (i < ntile) layer1_tiles<NRT>(xs, w1s, bias1, u, lr, lg, z1, h1s);
-        if (i == 2) STAMP();
+        // P1: z2(i - 1) = h1(i - 1) W2^T (bf16 matrix cores, weights from registers) | layer 1 of tile i (fp32 matrix cores)
         if (i >= 1) {
-            if (draw_noise && wave >= kWide / 64 - NRT) {
-                const int lrow = (kWide / 64 - 1 - wave) * RT + (lane >> 2);
-                s_noise[lrow * 4 + (lane & 3)] = philox_normal(A.row0 + (uint32_t)(r0p + lrow), A.call, 0x61637421u, A.seed, lane & 3);
-            }
             v4f acc[NRT][2];
 #pragma unroll
             for (int t = 0; t < NRT; ++t) acc[t][0] = acc[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
-            // K = 256 in 8 slabs of 32: lane (r, g) holds A[row r][32 sl + 8 g ..+7] and B[32 sl + 8 g ..+7][col r]
+            // K = 256 in 8 slabs of 32: lane (r, g) holds A[row r][32 sl + 8 g ..+7] and B[32 sl + 8 g ..+7][col r]; the A fragments of
+            // slab sl + 1 are requested before slab sl's four MFMAs
+            const __bf16* ap = h1b + lr * LDB1 + 8 * lg;
+            uint4 aq[2][NRT];
 #pragma unroll
-            for (int sl = 0; sl < 8; ++sl) {
+            for (int t = 0; t < NRT; ++t) aq[0][t] = *reinterpret_cast<const uint4*>(ap + t * RT * LDB1);
+            if (i < ntile && !(HX_PX & 8)) layer1_tiles<NRT>(xs, w1s, bias1, u, lr, lg, h1s);
+#pragma unroll
+            for (int sl = 0; sl < ((HX_PX & 4) ? 0 : 8); ++sl) {
+                if (sl + 1 < 8) {
+#pragma unroll
+                    for (int t = 0; t < NRT; ++t) aq[(sl + 1) & 1][t] = *reinterpret_cast<const uint4*>(ap + t * RT * LDB1 + 32 * (sl + 1));
+                }
 #pragma unroll
                 for (int t = 0; t < NRT; ++t) {
-                    const uint4 aq = *reinterpret_cast<const uint4*>(h1b + (t * RT + lr) * LDB1 + 32 * sl + 8 * lg);
-                    acc[t][0] = mfma16_bf16(aq, bq[0][sl], acc[t][0]);
-                    acc[t][1] = mfma16_bf16(aq, bq[1][sl], acc[t][1]);
+                    acc[t][0] = mfma16_bf16(aq[sl & 1][t], bq[0][sl], acc[t][0]);
+                    acc[t][1] = mfma16_bf16(aq[sl & 1][t], bq[1][sl], acc[t][1]);
                 }
             }
-            if (i == 2) STAMP();
-#pragma unroll
-            for (int t = 0; t < NRT; ++t)
+    #pragma unroll
+            for (int t = 0; t < ((HX_PX & 16) ? 0 : NRT); ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     z2s[(t * RT + 4 * lg + q) * LDA2 + cw * 16 + lr] = acc[t][0][q] + bb0;
                     z2s[(t * RT + 4 * lg + q) * LDA2 + 256 + cw * 16 + lr] = acc[t][1][q] + bb1;
                 }
+        } else if (!(HX_PX & 8)) {
+            layer1_tiles<NRT>(xs, w1s, bias1, u, lr, lg, h1s);
         }
-        if (i == 2) STAMP();
-        __syncthreads();  // A: z2 of tile i - 1 and the pre-activations of tile i are in LDS; xs is free
-        if (i == 2) STAMP();
-        // P2
-        if (i >= 1) head_tiles<NRT, false, RELU>(A, z2s, hps, s_noise, r0p, min(TR, row_end - r0p), wave, lane);
-        if (i == 2) STAMP();
-        if (i < ntile) ln1_stats<NRT>(h1s, sts, wave, lane, m.no_ln);
+        __syncthreads();  // A: z2 of tile i - 1 and the pre-activations of tile i are in LDS; xs and h1b are free
+        // P2 (16 lanes per row, hx_act.h): waves 0-7 the head of tile i - 1, waves 8-15 LayerNorm 1 + activation of tile i -> bf16 h1;
+        // a wave's four rows are eight apart (pitch = 8 mod 64 dwords: their 16-byte reads fall on disjoint banks)
+        const int gq = lane >> 4, gc = lane & 15;
+        if (wave < 8) {
+            const int lrow = wave + 8 * gq;
+            if (i >= 1 && r0p + lrow < row_end && !(HX_PX & 1)) {
+                float o[4];
+                head16<4, 4, RELU>(z2s + lrow * LDA2, hps, gc, slope, m.no_ln, o);
+                if (gc < 4) A.actions[(size_t)(r0p + lrow) * 4 + gc] = action_of<false>(A, o, gc, r0p + lrow, s_noise + ((i - 1) & 1) * TR * 4 + lrow * 4);
+            }
+        } else {
+            if (i < ntile && !(HX_PX & 2)) {
+                const int row = wave - 8 + 8 * gq;
+                float v[16];
+                load_row16<H1>(h1s + row * LDA1, gc, v);
+                float mean, rstd;
+                row_stats16<16>(v, H1, mean, rstd);
+                if (m.no_ln) { mean = 0.0f; rstd = 1.0f; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const v4f g = *reinterpret_cast<const v4f*>(g1s + 64 * k + 4 * gc);
+                    const v4f be = *reinterpret_cast<const v4f*>(g1s + H1 + 64 * k + 4 * gc);
+                    typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+                    v4bf hb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hb[e] = (__bf16)ln_act<RELU>(v[4 * k + e], mean, rstd, g[e], be[e], slope);  // round to nearest even
+                    *reinterpret_cast<v4bf*>(h1b + row * LDB1 + 64 * k + 4 * gc) = hb;
+                }
+                // the exploration noise of tile i (its head runs in the next iteration): one wave, a lane per (row, Box-Muller pair)
+                if (draw_noise && wave == kWide / 64 - 1 && !(HX_PX & 32)) {
+                    float nc, ns;
+                    philox_normal_pair(A.row0 + (uint32_t)(row_begin + i * TR + (lane >> 1)), A.call, 0x61637421u, A.seed, lane & 1, nc, ns);
+                    *reinterpret_cast<float2*>(s_noise + (i & 1) * TR * 4 + lane * 2) = make_float2(nc, ns);
+                }
+            }
+        }
         if (i + 1 < ntile) {
             if (tid < TR * 13) xs[(tid / 13) * XP + tid % 13] = xv;
             xv = obs_of(i + 2, tid);
         }
-        if (i == 2) STAMP();
-        __syncthreads();  // B: LN1 statistics of tile i; every read of z2 is done
-        if (i == 2) STAMP();
-        // P3
-        if (i < ntile) {
-#pragma unroll
-            for (int t = 0; t < NRT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = t * RT + 4 * lg + r;
-                    const float hv = act_f<RELU>(g1v * ((z1[t][r] - sts[row * 2]) * sts[row * 2 + 1]) + be1v, slope);
-                    h1b[row * LDB1 + u] = (__bf16)hv;  // v_cvt_pk_bf16_f32: round to nearest even
-                }
-        }
-        if (i == 2) STAMP();
-        __syncthreads();  // C: h1 of tile i (bf16) is in LDS
-        if (i == 2) STAMP();
+        __syncthreads();  // B: h1 of tile i (bf16) and the next observation tile are in LDS; every read of z2 is done
     }
     STAMP();
-    if (ENV) env_tail(A, row_begin, row_end, h1s, s_slot0, s_wcount);  // (barrier C: every action of the block is written)
+    if (ENV) env_tail(A, row_begin, row_end, h1s, s_slot0, s_wcount);  // (barrier B: every action of the block is written)
     STAMP();
     STAMP_FLUSH(0, (blockIdx.x == 0 || blockIdx.x == 200) && tid0 == 0);
     SPAN_LOG(HX_SPAN_ACT);

@@ -1,6 +1,6 @@
 """Phase stamps of one workgroup of the persistent acting kernel (csrc/hx_actp.hip), diagnostic build:
     make -C hirl4ucav_amd/csrc stamps && python tools/ubench/stamps_actp.py [dtype] [rows]
-Words: setup | (tiles 0, 1) | iteration 2: layer 1 | product | z2 -> LDS | barrier A | head | LN1 stats + obs | barrier B | P3 | barrier C | rest of the loop | env tail   (x 10 ns)"""
+Words: setup | tiles 0, 1 | iteration 2: product + layer 1 | z2 -> LDS | barrier A | head (waves 0-7) or LN1 (8-15) | obs -> LDS | barrier B | rest of the loop | env tail   (x 10 ns)"""
 import ctypes
 import os
 import sys
