@@ -112,28 +112,35 @@ __device__ __forceinline__ v2f ln_act2(v2f z, v2f mean, v2f rstd, v2f g, v2f be,
 // layer.  Every lane of the row's 16 ends up with all OUT pre-tanh outputs.  The row's 32 elements per lane are read from LDS in each of the
 // three passes (statistics twice, projection) instead of living in 32 registers: the reads of a later pass do not depend on the earlier
 // pass's result, so they cost LDS bandwidth (which this phase does not lack), not latency.
-template <int OUT, int IMG, bool RELU>
+template <int OUT, int IMG, bool RELU, bool ZREG = false>
 __device__ __forceinline__ void head16(const float* zrow, const float* hp, int c, float slope, int no_ln, float (&o)[OUT]) {
     float mean, rstd;
-    v2f s2 = {0.0f, 0.0f};
+    v2f m2;
+    if constexpr (ZREG) {  // both statistics passes from ONE batch of reads (32 registers): the same values, the same operations
+        float z[32];
+        load_row16<H2>(zrow, c, z);
+        row_stats16<32>(z, H2, mean, rstd);
+    } else {
+        v2f s2 = {0.0f, 0.0f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const v4f t = *reinterpret_cast<const v4f*>(zrow + 64 * i + 4 * c);
-        // (the association of row_stats16: the first piece opens the pair)
-        s2 = i == 0 ? v2f{t[0], t[1]} + v2f{t[2], t[3]} : (s2 + v2f{t[0], t[1]}) + v2f{t[2], t[3]};
-    }
-    mean = sum16u(s2.x + s2.y) / (float)H2;
-    v2f m2 = {mean, mean};
-    v2f q2 = {0.0f, 0.0f};
+        for (int i = 0; i < 8; ++i) {
+            const v4f t = *reinterpret_cast<const v4f*>(zrow + 64 * i + 4 * c);
+            // (the association of row_stats16: the first piece opens the pair)
+            s2 = i == 0 ? v2f{t[0], t[1]} + v2f{t[2], t[3]} : (s2 + v2f{t[0], t[1]}) + v2f{t[2], t[3]};
+        }
+        mean = sum16u(s2.x + s2.y) / (float)H2;
+        m2 = v2f{mean, mean};
+        v2f q2 = {0.0f, 0.0f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const v4f t = *reinterpret_cast<const v4f*>(zrow + 64 * i + 4 * c);
-        v2f d = v2f{t[0], t[1]} - m2;
-        q2 = fma2(d, d, q2);
-        d = v2f{t[2], t[3]} - m2;
-        q2 = fma2(d, d, q2);
+        for (int i = 0; i < 8; ++i) {
+            const v4f t = *reinterpret_cast<const v4f*>(zrow + 64 * i + 4 * c);
+            v2f d = v2f{t[0], t[1]} - m2;
+            q2 = fma2(d, d, q2);
+            d = v2f{t[2], t[3]} - m2;
+            q2 = fma2(d, d, q2);
+        }
+        rstd = __builtin_amdgcn_rsqf(sum16u(q2.x + q2.y) / (float)H2 + LN_EPS);
     }
-    rstd = __builtin_amdgcn_rsqf(sum16u(q2.x + q2.y) / (float)H2 + LN_EPS);
     if (no_ln) { mean = 0.0f; rstd = 1.0f; }
     m2 = v2f{mean, mean};
     const v2f r2 = {rstd, rstd};
@@ -147,12 +154,13 @@ __device__ __forceinline__ void head16(const float* zrow, const float* hp, int c
         const v4f be = *reinterpret_cast<const v4f*>(hp + H2 + 64 * i + 4 * c);
         const v2f h01 = ln_act2<RELU>(v2f{z[0], z[1]}, m2, r2, v2f{g[0], g[1]}, v2f{be[0], be[1]}, slope);
         const v2f h23 = ln_act2<RELU>(v2f{z[2], z[3]}, m2, r2, v2f{g[2], g[3]}, v2f{be[2], be[3]}, slope);
+        v4f w[OUT];
 #pragma unroll
-        for (int j = 0; j < OUT; ++j) {
-            const v4f w = *reinterpret_cast<const v4f*>(hp + (2 + j) * H2 + 64 * i + 4 * c);
-            acc[j] = fma2(h01, v2f{w[0], w[1]}, acc[j]);
-            acc[j] = fma2(h23, v2f{w[2], w[3]}, acc[j]);
-        }
+        for (int j = 0; j < OUT; ++j) w[j] = *reinterpret_cast<const v4f*>(hp + (2 + j) * H2 + 64 * i + 4 * c);
+#pragma unroll
+        for (int j = 0; j < OUT; ++j) acc[j] = fma2(h01, v2f{w[j][0], w[j][1]}, acc[j]);  // (OUT independent chains between a sum's two steps)
+#pragma unroll
+        for (int j = 0; j < OUT; ++j) acc[j] = fma2(h23, v2f{w[j][2], w[j][3]}, acc[j]);
     }
 #pragma unroll
     for (int j = 0; j < OUT; ++j) o[j] = sum16u(acc[j].x + acc[j].y) + hp[(2 + IMG) * H2 + j];

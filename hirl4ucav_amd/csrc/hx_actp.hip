@@ -37,22 +37,19 @@ namespace {
 #endif
 constexpr int kEnvPass = 512;  // envs per pass of the tail: pair layout = 1,024 lanes = the workgroup
 
-// layer 1 of NRT row tiles on the fp32 matrix cores, exactly as act_fused_kernel does it: wave w owns hidden units 16 w .. 16 w + 15,
-// lane (lr, lg) ends up with rows 4 lg .. 4 lg + 3 of unit u; the pre-activations go to h1s (LayerNorm 1 reads them row-wise)
+// Layer 1 of NRT row tiles on the fp32 matrix cores: the products and the k order of act_fused_kernel's layer 1, with the two MFMA operands
+// SWAPPED — A = W1 (wave w: hidden units 16 w .. + 15), B = the observation rows — so that lane (lr, lg) ends up with FOUR CONSECUTIVE units
+// 16 w + 4 lg .. + 3 of row lr: one 16-byte LDS store per row tile instead of four conflicting dword stores.  The W1 fragments (w1f) and
+// the biases of the lane's four units (b1f) are loop invariants held in registers.
 template <int NRT>
-__device__ __forceinline__ void layer1_tiles(const float* xs, const float* w1s, float bias1, int u, int lr, int lg, float* h1s) {
+__device__ __forceinline__ void layer1_tiles(const float* xs, const float (&w1f)[4], v4f b1f, int wave, int lr, int lg, float* h1s) {
 #pragma unroll
     for (int t = 0; t < NRT; ++t) {
-        v4f acc = {bias1, bias1, bias1, bias1};
-        const float* wrow = w1s + u * 13 + lg;  // columns 13.. of xs are zero; W1 is masked (the LDS words behind a row are not zeros)
-        const float* xrow = xs + (t * RT + lr) * XP + lg;
+        v4f acc = b1f;
+        const float* xrow = xs + (t * RT + lr) * XP + lg;  // (columns 13.. of xs are zero, and so are the W1 fragments there)
 #pragma unroll
-        for (int mm = 0; mm < 4; ++mm) {  // K = 16 covers the 13 inputs
-            const float wv = wrow[4 * mm];
-            acc = mfma16(xrow[4 * mm], 4 * mm + lg < 13 ? wv : 0.0f, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h1s[(t * RT + 4 * lg + r) * LDA1 + u] = acc[r];
+        for (int mm = 0; mm < 4; ++mm) acc = mfma16(w1f[mm], xrow[4 * mm], acc);  // K = 16 covers the 13 inputs
+        *reinterpret_cast<v4f*>(h1s + (t * RT + lr) * LDA1 + wave * 16 + 4 * lg) = acc;
     }
 }
 
@@ -86,18 +83,19 @@ template <bool ENV, bool RELU>
 __global__ __launch_bounds__(kWide) void act_persist_bf16_kernel(ActFusedArgs A, int tiles_per_wg) {
     constexpr int NRT = 2, TR = NRT * RT;
     typedef HeadImage<4> Img;
-    constexpr int kW1 = H1 * 13;
     constexpr int kLoop = TR * LDA1 + TR * LDA2 + TR * LDB1 / 2;  // h1s (fp32 pre-activations), z2s, h1b (bf16)
     constexpr int kTail = ENV ? hxenv::kEnvBlockLds<true, kEnvPass> : 0;
     constexpr int kUnion = kLoop > kTail ? kLoop : kTail;
-    __shared__ __attribute__((aligned(16))) float lds[kW1 + Img::kStride + TR * XP + 2 * H1 + 2 * TR * 4 + kUnion];
+    __shared__ __attribute__((aligned(16))) float lds[Img::kStride + TR * XP + 3 * H1 + H2 + kWide * 4 + 2 * TR * 4 + kUnion];
     __shared__ unsigned s_slot0;
     __shared__ int s_wcount[kWide / 64];
-    float* w1s = lds;
-    float* hps = w1s + kW1;
+    float* hps = lds;
     float* xs = hps + Img::kStride;
     float* g1s = xs + TR * XP;          // LayerNorm 1 weight | bias, read four columns at a time
-    float* s_noise = g1s + 2 * H1;      // [2][TR][4]: the draws of tile t live in half t & 1
+    float* b1s = g1s + 2 * H1;          // full1.bias
+    float* b2s = b1s + H1;              // full2.bias
+    float* w1t = b2s + H2;              // [1024][4]: every lane's four layer-1 A fragments of W1 (zero beyond the 13 inputs): one 16-byte read per tile
+    float* s_noise = w1t + kWide * 4;   // [2][TR][4]: the draws of tile t live in half t & 1
     float* h1s = s_noise + 2 * TR * 4;
     float* z2s = h1s + TR * LDA1;
     __bf16* h1b = reinterpret_cast<__bf16*>(z2s + TR * LDA2);
@@ -116,29 +114,31 @@ __global__ __launch_bounds__(kWide) void act_persist_bf16_kernel(ActFusedArgs A,
         const int r0 = row_begin + tile * TR;
         return (tile < ntile && tid < TR * 13 && r0 + tid / 13 < row_end) ? A.obs[(size_t)r0 * 13 + tid] : 0.0f;
     };
-    float xv, bias1, bb0, bb1;
+    float xv;
     uint4 bq[2][8];  // B fragments of this wave's two column tiles, all of K: resident for every tile
     {
-        const int tid = tid0, wave = tid >> 6, lane = tid & 63, lr = lane & 15, u = wave * 16 + lr;
+        const int tid = tid0, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
         xv = obs_of(0, tid);
-        float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < kW1 / 4) wv = reinterpret_cast<const float4*>(net + m.W1())[tid];
-        bias1 = net[m.b1() + u];
+        float w1f[4];  // layer 1: this lane's A fragments of W1 (unit 16 wave + lr, inputs 4 mm + lg)
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) w1f[mm] = net[m.W1() + (wave * 16 + lr) * 13 + min(4 * mm + lg, 12)];
+        const float b1v = tid < H1 ? net[m.b1() + tid] : 0.0f;
         const float gb = tid < 2 * H1 ? net[m.g1() + tid] : 0.0f;  // g1 | be1 are adjacent in the parameter block
+        const float b2v = tid < H2 ? net[m.b2() + tid] : 0.0f;
         Img himg;
         himg.fetch(net, m, tid);
         // which 32 columns this wave owns rotates with the workgroup: the workgroups of a launch do not all ask L2 for the same lines at once
         const int cw = (wave + (int)blockIdx.x) & 15;
-        bb0 = net[m.b2() + cw * 16 + lr];
-        bb1 = net[m.b2() + 256 + cw * 16 + lr];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const uint16_t* blk = A.w2b + (size_t)((t * 16 + cw) * 8) * 512 + lane * 8;  // (lane = 16 g + r: w2_image_index's block order)
 #pragma unroll
             for (int sl = 0; sl < 8; ++sl) bq[t][sl] = *reinterpret_cast<const uint4*>(blk + sl * 512);
         }
-        if (tid < kW1 / 4) reinterpret_cast<float4*>(w1s)[tid] = wv;
+        *reinterpret_cast<float4*>(w1t + tid * 4) = make_float4(w1f[0], w1f[1], w1f[2], 12 + lg < 13 ? w1f[3] : 0.0f);  // (only 4 mm + lg = 13..15 are beyond)
+        if (tid < H1) b1s[tid] = b1v;
         if (tid < 2 * H1) g1s[tid] = gb;
+        if (tid < H2) b2s[tid] = b2v;
         if (tid < TR * XP) xs[tid] = 0.0f;
         himg.store(hps, net, m, tid);
         __syncthreads();
@@ -155,42 +155,58 @@ __global__ __launch_bounds__(kWide) void act_persist_bf16_kernel(ActFusedArgs A,
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-        const int lr = lane & 15, lg = lane >> 4, u = wave * 16 + lr;
+        const int lr = lane & 15, lg = lane >> 4;
         const int r0p = row_begin + (i - 1) * TR;  // first row of tile i - 1
         const int cw = (wave + (int)blockIdx.x) & 15;
-        // P1: z2(i - 1) = h1(i - 1) W2^T (bf16 matrix cores, weights from registers) | layer 1 of tile i (fp32 matrix cores)
+        // P1: z2(i - 1) = h1(i - 1) W2^T (bf16 matrix cores, weights from registers) | layer 1 of tile i (fp32 matrix cores).
+        // Both products run with the MFMA operands swapped (weights as A, rows as B): the same products in the same k order, but lane
+        // (lr, lg) then holds FOUR CONSECUTIVE columns of row lr — 16-byte LDS stores instead of four conflicting dword stores each.
         if (i >= 1) {
             v4f acc[NRT][2];
 #pragma unroll
             for (int t = 0; t < NRT; ++t) acc[t][0] = acc[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
-            // K = 256 in 8 slabs of 32: lane (r, g) holds A[row r][32 sl + 8 g ..+7] and B[32 sl + 8 g ..+7][col r]; the A fragments of
-            // slab sl + 1 are requested before slab sl's four MFMAs
+            // K = 256 in 8 slabs of 32: lane (r, g) holds h1[row r][32 sl + 8 g ..+7] and W2[col r][32 sl + 8 g ..+7].  (One register set for
+            // the h1 fragments: the other three waves of the SIMD cover a wave's LDS round trip, and a second set costs spills of the weights.)
             const __bf16* ap = h1b + lr * LDB1 + 8 * lg;
-            uint4 aq[2][NRT];
+            // layer 1 of tile i rides BETWEEN the slabs: its eight dependent fp32 MFMAs (two chains of four) and their LDS operands would
+            // otherwise open the phase on every wave at once with the bf16 matrix work waiting behind them
+            const bool l1 = i < ntile && !(HX_PX & 8);
+            float xf[NRT][4];
+            v4f acc1[NRT];
+            const v4f w1f = *reinterpret_cast<const v4f*>(w1t + tid * 4), b1f = *reinterpret_cast<const v4f*>(b1s + wave * 16 + 4 * lg);
 #pragma unroll
-            for (int t = 0; t < NRT; ++t) aq[0][t] = *reinterpret_cast<const uint4*>(ap + t * RT * LDB1);
-            if (i < ntile && !(HX_PX & 8)) layer1_tiles<NRT>(xs, w1s, bias1, u, lr, lg, h1s);
+            for (int t = 0; t < NRT; ++t) {
+                acc1[t] = b1f;
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) xf[t][mm] = xs[(t * RT + lr) * XP + lg + 4 * mm];  // (read whether or not l1: a few dwords)
+            }
 #pragma unroll
             for (int sl = 0; sl < ((HX_PX & 4) ? 0 : 8); ++sl) {
-                if (sl + 1 < 8) {
+                uint4 aq[NRT];
 #pragma unroll
-                    for (int t = 0; t < NRT; ++t) aq[(sl + 1) & 1][t] = *reinterpret_cast<const uint4*>(ap + t * RT * LDB1 + 32 * (sl + 1));
-                }
+                for (int t = 0; t < NRT; ++t) aq[t] = *reinterpret_cast<const uint4*>(ap + t * RT * LDB1 + 32 * ((HX_PX & 128) ? 0 : sl));
 #pragma unroll
                 for (int t = 0; t < NRT; ++t) {
-                    acc[t][0] = mfma16_bf16(aq[sl & 1][t], bq[0][sl], acc[t][0]);
-                    acc[t][1] = mfma16_bf16(aq[sl & 1][t], bq[1][sl], acc[t][1]);
+                    acc[t][0] = mfma16_bf16(bq[0][sl], aq[t], acc[t][0]);
+                    acc[t][1] = mfma16_bf16(bq[1][sl], aq[t], acc[t][1]);
                 }
+                acc1[sl & 1] = mfma16(w1f[sl >> 1], xf[sl & 1][sl >> 1], acc1[sl & 1]);  // tile sl & 1, inputs 4 (sl >> 1) ..: k ascending per tile
+                if (!(HX_PX & 256)) __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise gathers the eight fp32 MFMAs at the head of the phase)
             }
-    #pragma unroll
-            for (int t = 0; t < ((HX_PX & 16) ? 0 : NRT); ++t)
+            if (l1) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    z2s[(t * RT + 4 * lg + q) * LDA2 + cw * 16 + lr] = acc[t][0][q] + bb0;
-                    z2s[(t * RT + 4 * lg + q) * LDA2 + 256 + cw * 16 + lr] = acc[t][1][q] + bb1;
-                }
+                for (int t = 0; t < NRT; ++t) *reinterpret_cast<v4f*>(h1s + (t * RT + lr) * LDA1 + wave * 16 + 4 * lg) = acc1[t];
+            }
+            const v4f bb0 = *reinterpret_cast<const v4f*>(b2s + cw * 16 + 4 * lg), bb1 = *reinterpret_cast<const v4f*>(b2s + 256 + cw * 16 + 4 * lg);
+#pragma unroll
+            for (int t = 0; t < ((HX_PX & 16) ? 0 : NRT); ++t) {
+                *reinterpret_cast<v4f*>(z2s + (t * RT + lr) * LDA2 + cw * 16 + 4 * lg) = acc[t][0] + bb0;
+                *reinterpret_cast<v4f*>(z2s + (t * RT + lr) * LDA2 + 256 + cw * 16 + 4 * lg) = acc[t][1] + bb1;
+            }
         } else if (!(HX_PX & 8)) {
-            layer1_tiles<NRT>(xs, w1s, bias1, u, lr, lg, h1s);
+            const v4f w1v = *reinterpret_cast<const v4f*>(w1t + tid * 4);
+            const float w1f[4] = {w1v[0], w1v[1], w1v[2], w1v[3]};
+            layer1_tiles<NRT>(xs, w1f, *reinterpret_cast<const v4f*>(b1s + wave * 16 + 4 * lg), wave, lr, lg, h1s);
         }
         __syncthreads();  // A: z2 of tile i - 1 and the pre-activations of tile i are in LDS; xs and h1b are free
         // P2 (16 lanes per row, hx_act.h): waves 0-7 the head of tile i - 1, waves 8-15 LayerNorm 1 + activation of tile i -> bf16 h1;
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(kWide) void act_persist_bf16_kernel(ActFusedArgs A,
             const int lrow = wave + 8 * gq;
             if (i >= 1 && r0p + lrow < row_end && !(HX_PX & 1)) {
                 float o[4];
-                head16<4, 4, RELU>(z2s + lrow * LDA2, hps, gc, slope, m.no_ln, o);
+                head16<4, 4, RELU, !(HX_PX & 64)>(z2s + lrow * LDA2, hps, gc, slope, m.no_ln, o);
                 if (gc < 4) A.actions[(size_t)(r0p + lrow) * 4 + gc] = action_of<false>(A, o, gc, r0p + lrow, s_noise + ((i - 1) & 1) * TR * 4 + lrow * 4);
             }
         } else {

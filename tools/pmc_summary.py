@@ -17,7 +17,7 @@ for d in sys.argv[1:]:
             a[1] += 1
 cols = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS",
         "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_MFMA", "SQ_INSTS_BRANCH", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS",
-        "SQ_INST_CYCLES_VMEM", "SQC_ICACHE_REQ", "SQC_ICACHE_MISSES", "SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"]
+        "SQ_INST_CYCLES_VMEM", "SQC_ICACHE_REQ", "SQC_ICACHE_MISSES", "SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_ADDR_CONFLICT"]
 print("%-44s %6s " % ("kernel (per wave; cycles in 4-clock units)", "waves") + " ".join("%9s" % c.replace("SQ_", "").replace("INSTS_", "n").replace("ACTIVE_INST", "ACT").replace("WAIT_INST", "WI")[:9] for c in cols))
 for k in sorted(acc):
     c = {n: v[0] / v[1] for n, v in acc[k].items()}
