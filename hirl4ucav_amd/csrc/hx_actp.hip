@@ -64,14 +64,25 @@ __device__ __forceinline__ void philox_normal_pair(uint32_t row, uint32_t call, 
     n_sin = rad * sinf(ang);
 }
 
-// the env step of rows [row_begin, row_end) — whose actions this workgroup has written — kEnvPass at a time (HarfangEnv.step, train_all.py:345)
-__device__ __forceinline__ void env_tail(const ActFusedArgs& A, int row_begin, int row_end, float* elds, unsigned& s_slot0, int* s_wcount) {
+// The env step of rows [row_begin, row_end) — whose actions this workgroup has written — kEnvPass at a time (HarfangEnv.step,
+// train_all.py:345).  It reads the launch description from the kernel-argument SEGMENT (uniform scalar loads, here, after the tile loop)
+// instead of from the kernel's parameter: as a parameter the env step's ~30 argument words stayed live in SGPRs across the tile loop, next to
+// the loop's own ~60, spilled into VGPR lanes, and pushed the loop's vector registers (64 of them resident weights) into scratch.
+typedef const __attribute__((address_space(4))) ActFusedArgs* KernArgs;
+__device__ __forceinline__ void env_tail(KernArgs Ap, int row_begin, int row_end, float* elds, unsigned* s_slot0, int* s_wcount) {
     using namespace hxenv;
-    const StepArgs S{A.state, (int64_t)A.rows, A.stride, A.actions, A.obs, A.reward, A.done, A.success, A.o, A.inv_cap};
+    StepArgs S;
+    S.state = Ap->state; S.n = (int64_t)Ap->rows; S.stride = Ap->stride; S.actions = Ap->actions; S.obs_io = Ap->obs; S.reward = Ap->reward;
+    S.done = Ap->done; S.success = Ap->success; S.inv_cap = Ap->inv_cap;
+    S.o.max_step = Ap->o.max_step; S.o.auto_reset = Ap->o.auto_reset; S.o.randomize = Ap->o.randomize; S.o.env_id0 = Ap->o.env_id0; S.o.seed = Ap->o.seed;
+    S.o.episode_ctr = Ap->o.episode_ctr; S.o.ring = Ap->o.ring; S.o.ring_success = Ap->o.ring_success; S.o.cap = Ap->o.cap; S.o.total = Ap->o.total;
+    S.o.stats = Ap->o.stats; S.o.ev_start = nullptr; S.o.ev_stop = nullptr; S.o.layout = 0;
     unsigned way = blockIdx.x;
     for (int i0 = row_begin; i0 < row_end; i0 += kEnvPass, way += gridDim.x) {
-        if (A.o.ring) env_block_step<true, true, kEnvPass>(S, i0, row_end, elds, s_slot0, s_wcount, way);
-        else env_block_step<true, false, kEnvPass>(S, i0, row_end, elds, s_slot0, s_wcount, way);
+        // (behind opaque copies of the base pointers nothing of a pass is invariant across passes: hoisted out of this loop, the 37 state
+        //  words' 64-bit addresses alone are 74 VGPRs and the pass spills ~170 bytes per lane)
+        asm volatile("" : "+s"(S.state), "+s"(S.obs_io), "+s"(S.actions), "+s"(S.stride));
+        env_block_step<true, true, kEnvPass>(S, i0, row_end, elds, *s_slot0, s_wcount, way);  // (launches without a replay ring take two launches)
         __syncthreads();  // the pass's LDS tiles and slot words are free again
     }
 }
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(kWide) void act_persist_bf16_kernel(ActFusedArgs A,
         __syncthreads();  // B: h1 of tile i (bf16) and the next observation tile are in LDS; every read of z2 is done
     }
     STAMP();
-    if (ENV) env_tail(A, row_begin, row_end, h1s, s_slot0, s_wcount);  // (barrier B: every action of the block is written)
+    if (ENV) env_tail((KernArgs)__builtin_amdgcn_kernarg_segment_ptr(), row_begin, row_end, h1s, &s_slot0, s_wcount);  // (barrier B: every action of the block is written)
     STAMP();
     STAMP_FLUSH(0, (blockIdx.x == 0 || blockIdx.x == 200) && tid0 == 0);
     SPAN_LOG(HX_SPAN_ACT);
@@ -284,6 +295,7 @@ namespace hxact {
 
 bool launch_act_persist(const ActFusedArgs& H, bool gauss, hipStream_t st) {
     const bool env = H.state != nullptr;
+    if (env && !H.o.ring) return false;  // the env tail is built with the fused replay insert only; without a ring: act (persistent) + hx_env_step
     const bool relu = gauss || H.slope == 0.0f;
     if (!gauss && H.w2b && !H.x9) {
         constexpr int TR = 32;
