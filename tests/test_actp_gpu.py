@@ -164,3 +164,49 @@ def test_config3_population_65536_circular_hirl_linear(mods):
     assert keep.sum() > 2000
     np.testing.assert_array_equal(env.state.cpu().numpy().T[sample][keep].view(np.uint32), s0[keep].view(np.uint32))
     np.testing.assert_array_equal(env.obs.cpu().numpy()[sample][keep].view(np.uint32), o_obs[keep].view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [8192 + 37, 16384, 65536 + 5])
+def test_persistent_sac_policy_equals_the_per_tile_kernel(mods, n):
+    """SacAgent.explore / exploit (SAC/agent.py:183-196) through the streaming persistent kernel (Gaussian head, fp32 image): exploit, explore
+    with given eps, explore with Philox draws — and explore + env step in one launch against two launches (BASELINE.json configs[2] is 16,384
+    serpentine envs)."""
+    E, Env, Replay = mods
+    from hirl4ucav_amd.agents import sac_engine as SE
+    from tests.test_oracle_sac import sac_params
+
+    p = sac_params()
+    e = SE.SacEngine(batch=128)
+    e.load_params(p["policy"], p["q1"], p["q2"])
+    rng = np.random.default_rng(n)
+    obs = torch.from_numpy(rng.uniform(-1, 1, (n, 13)).astype(np.float32)).cuda()
+    eps = torch.from_numpy(rng.normal(0, 1, (n, 4)).astype(np.float32)).cuda()
+    cases = [dict(explore=False), dict(eps=eps), dict(seed=5, row0=9)]
+    got = []
+    for kw in cases:
+        e.act_calls = 3
+        got.append(e.act(obs, **kw).clone())
+    with per_tile_kernel():
+        for kw, g in zip(cases, got):
+            e.act_calls = 3
+            assert torch.equal(g.view(torch.int32), e.act(obs, **kw).view(torch.int32)), kw.keys()
+    outs = []
+    for fused in (True, False):
+        e.act_calls = 0
+        rep = Replay(1 << 21, "cuda")
+        env = Env(n, scenario="serpentine", seed=5, max_step=9, auto_reset=True, random_reset=True, env_id0=40, replay=rep)
+        env.reset()
+        acts = torch.zeros((n, 4), device="cuda")
+        for t in range(12):
+            if fused:
+                e.act_step(env, seed=11, out=acts)
+            else:
+                e.act(env.obs, seed=11, row0=env.env_id0, out=acts)
+                env.step(acts)
+        torch.cuda.synchronize()
+        k = int(rep.total.item())
+        rows = rep.ring[:k].cpu().numpy().view(np.uint32)
+        outs.append((acts.cpu().numpy().view(np.uint32), env.state.cpu().numpy().view(np.uint32), env.obs.cpu().numpy().view(np.uint32),
+                     env.reward.cpu().numpy().view(np.uint32), rows[np.lexsort(rows.T[::-1])], np.asarray(list(env.stats_dict().values()))))
+    for x, y in zip(*outs):
+        np.testing.assert_array_equal(x, y)
