@@ -231,7 +231,9 @@ class Loop:
         self.separate = args.separate_launches
         self.rec = {"act": [], "env": [], "act+env": [], "learn": []}
         self.krec, self.krec_fused = [], []
-        self.fused = not (self.uniform or self.separate) and n <= 8192  # act + env step as ONE launch (hx_actor_act_step up to 8,192 envs)
+        # act + env step + replay insert as ONE launch at every size (hx_actor_act_step / hx_sac_act_step: up to 8,192 envs one 16- / 32-row
+        # workgroup per row tile with the env step on its first wave, beyond that the persistent kernel of csrc/hx_actp.hip)
+        self.fused = not (self.uniform or self.separate)
 
     # ---- the hot path ------------------------------------------------------------------------------------------------
     def _act_env(self, timed=None, split=False, stamp=None):
@@ -251,7 +253,7 @@ class Loop:
             if stamp is not None:
                 env.time_next_steps(None, None)
         else:
-            if stamp is not None:  # the launch's own begin / end (hipExtLaunchKernelGGL events): up to 8,192 envs that is the fused act + env kernel
+            if stamp is not None:  # the launch's own begin / end (hipExtLaunchKernelGGL events) of the fused act + env kernel
                 env.time_next_steps(*stamp)
                 self.krec_fused.append(stamp)
             if self.sac:   # explore + env.step in one launch
@@ -809,19 +811,34 @@ def run_rank(args):
         # the kernel the timed loop RUNS: policy inference + env step + replay insert in one launch.  Both roofs are quoted; `bound` names the nearer.
         us = float(np.mean(fused))
         fused_pmc = profile_traffic(f"fused_{args.envs}") if (args.agent == "hirl" and args.dtype == "f32") else None
-        flop = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
-        peak = FP32_MATRIX_PEAK_TFLOPS if (args.dtype in ("f32", "f32x9") or args.agent == "sac") else BF16_MATRIX_PEAK_TFLOPS
+        fp32_equiv = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
+        # which matrix-core instruction the 256 -> 512 product runs on: fp32 MFMA; bf16 MFMA; or — the fp32 HIRL policy from 16,384 rows on, and
+        # --dtype f32x9 at every size — NINE bf16 MFMAs per fp32 product (the exact hi | mid | lo split): priced as executed bf16 FLOPs against the bf16 peak
+        x9 = args.agent == "hirl" and (args.dtype == "f32x9" or (args.dtype == "f32" and args.envs >= 16384))
+        if x9:
+            flop, peak = fp32_equiv + 8 * 2 * 256 * 512 * args.envs, BF16_MATRIX_PEAK_TFLOPS
+        elif args.dtype in ("f32", "f32x9") or args.agent == "sac":
+            flop, peak = fp32_equiv, FP32_MATRIX_PEAK_TFLOPS
+        else:
+            flop, peak = fp32_equiv, BF16_MATRIX_PEAK_TFLOPS
         tf, gb = flop / us / 1e6, ENV_BYTES_FUSED * args.envs / us / 1e3
         mf, hf = tf / peak, gb / HBM_PEAK_GBPS
         hbm = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hf, 4), "bytes_per_launch": ENV_BYTES_FUSED * args.envs}
         mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(mf, 4), "flop_per_launch": flop}
+        if x9:
+            mfma["note"] = ("executed FLOPs: the fp32 product as 9 bf16 MFMAs per 32 k (exact split, fp32 accumulate); fp32-equivalent "
+                            f"{round(fp32_equiv / us / 1e6, 2)} TFLOP/s = {round(fp32_equiv / us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 3)} of the fp32-MFMA peak")
         first, second = (mfma, hbm) if mf >= hf else (hbm, mfma)
-        res["roofline"] = {"kernel": "act_fused_kernel<NRT, GAUSS, ENV = true, ...> (hx_act.hip): policy inference + env step + fused replay insert, the dominant "
-                                     "kernel of the timed loop", **first, "traffic": (fused_pmc or {}).get("bytes"), "other_roof": second,
+        persistent = args.envs > 8192
+        res["roofline"] = {"kernel": ("act_persist_*_kernel<..., ENV = true> (hx_actp.hip): persistent workgroups (one per CU) looping over their row tiles, env step + "
+                                      "fused replay insert in the launch's tail" if persistent else
+                                      "act_fused_kernel<NRT, GAUSS, ENV = true, ...> (hx_act.hip): policy inference + env step + fused replay insert") +
+                                     ", the dominant kernel of the timed loop", **first, "traffic": (fused_pmc or {}).get("bytes"), "other_roof": second,
                            "us_per_launch": round(us, 2), "launches_timed": len(fused),
                            "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the fused launches "
                                      "of the second pass (3 of every 4 steps)",
-                           "note": "latency-bound at this size: 256 workgroups, one round; neither roof is near (DESIGN.md section 4)",
+                           "note": ("vector-issue / LDS bound tile loop (LayerNorm + head per row), DESIGN.md section 4" if persistent else
+                                    "latency-bound at this size: 256 workgroups, one round; neither roof is near (DESIGN.md section 4)"),
                            "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes of the fp32 HIRL kernel at this size (FETCH_SIZE calibrated "
                                            "x2, WRITE_SIZE: tools/pmc_env_passes.sh); each of the 8 XCDs pulls the policy's 0.55 MB of weights into its own L2 "
                                            "once per launch, hence ~3.4 x the env's 550 B/env-step; null for other dtypes / agents / sizes",
@@ -838,7 +855,7 @@ def run_rank(args):
     if act_us and not loop.uniform:  # (with --actions uniform the 'act' stage is a torch uniform_ fill, not the policy)
         peak = FP32_MATRIX_PEAK_TFLOPS if (args.dtype in ("f32", "f32x9") or args.agent == "sac") else BF16_MATRIX_PEAK_TFLOPS
         flop = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
-        res["roofline_act"] = {"kernels": "act_fused_kernel<ENV = false> as its own launch (every 4th step of the second pass)", "bound": "mfma", "unit": "TFLOP/s",
+        res["roofline_act"] = {"kernels": "the acting kernel (ENV = false) as its own launch (every 4th step of the second pass); fp32-equivalent FLOPs", "bound": "mfma", "unit": "TFLOP/s",
                                "achieved": round(flop / act_us / 1e6, 3), "peak": peak,
                                "frac": round(flop / act_us / 1e6 / peak, 5), "us": round(act_us, 2), "timing": "torch events (median)"}
     if pg:

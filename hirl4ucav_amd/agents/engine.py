@@ -253,7 +253,13 @@ class HirlEngine:
         self.nets = HxNets(*(t.data_ptr() for t in (self.actor, self.critic, self.target_actor, self.target_critic, self.bc_actor,
                                                      self.grad_actor, self.grad_critic, self.m_actor, self.v_actor, self.m_critic,
                                                      self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None, None, None, None, None)
-        self.act_dtype, self.w2_bf16, self.w2_x9 = "f32", None, None
+        self.act_dtype, self.w2_bf16, self.w2_x9, self._x9_live = "f32", None, None, False
+        # act_dtype "f32" and at least this many rows: the 256 -> 512 product of the ACTING kernel runs as the exact 9-term bf16 split on the
+        # bf16 matrix cores (hx_actor_act_x9: fp32 operands, every partial product exact, fp32 accumulation — an fp32 result up to summation
+        # order, 1e-5 parity like the fp32-MFMA path) instead of fp32 MFMA: 121 against 163 us at 65,536 rows, 34 against 48 at 16,384
+        # (tools/ubench/actp_time.py).  None: never (fp32 MFMA at every size).  The three images are built at the first such call and kept
+        # current by the actor's Adam steps from then on.
+        self.x9_rows = 16384
         self.update_dtype, self.images = "f32", None
         # fp32 image of the actor's W2 in the acting kernel's operand order (hx_pack_w2_f32i): kept current by the actor's Adam steps
         self.w2_f32i = torch.zeros(H2 * H1, dtype=torch.float32, device=self.device)
@@ -319,7 +325,9 @@ class HirlEngine:
 
     def _bind_images(self):
         """which bf16 buffers the kernels see: in bf16 update mode ONE block holds every image (its first image is the acting kernel's);
-        with a bf16 policy only, the actor's image alone"""
+        with a bf16 policy only, the actor's image alone; with the exact-split format the hi | mid | lo images"""
+        self.nets.actor_w2_x9 = None
+        self._x9_live = False  # (an "f32" policy's large-population images are rebuilt and re-bound by the next large call: _x9_for)
         if self.update_dtype == "bf16":
             if self.images is None:
                 L = _lib.load()
@@ -330,7 +338,6 @@ class HirlEngine:
             self.nets.actor_w2_bf16 = self.w2_bf16.data_ptr() if self.act_dtype == "bf16" else None
             return
         self.nets.w2_bf16_all = None
-        self.nets.actor_w2_x9 = None
         if self.act_dtype == "f32x9":
             if self.w2_x9 is None:
                 self.w2_x9 = torch.zeros(3 * H2 * H1, dtype=torch.bfloat16, device=self.device)  # hi | mid | lo
@@ -353,8 +360,22 @@ class HirlEngine:
             _lib.call("hx_pack_update_images", ctypes.byref(self.nets), _lib.stream_ptr())
         elif self.act_dtype == "bf16":
             _lib.call("hx_pack_w2_bf16", self.actor.data_ptr(), 13, self.w2_bf16.data_ptr(), _lib.stream_ptr())
-        elif self.act_dtype == "f32x9":
+        elif self.act_dtype == "f32x9" or (self.act_dtype == "f32" and self._x9_live):
             _lib.call("hx_pack_w2_x9", self.actor.data_ptr(), 13, self.w2_x9.data_ptr(), _lib.stream_ptr())
+
+    def _x9_for(self, n):
+        """True when `n` rows of the fp32 policy take the exact-split format (set_act_dtype("f32x9"), or "f32" with n >= x9_rows)"""
+        if self.act_dtype == "f32x9":
+            return True
+        if self.act_dtype != "f32" or self.update_dtype != "f32" or self.x9_rows is None or n < self.x9_rows:
+            return False
+        if not self._x9_live:  # first large call: build the images; nets.actor_w2_x9 makes every later Adam step of the actor refresh them
+            if self.w2_x9 is None:
+                self.w2_x9 = torch.zeros(3 * H2 * H1, dtype=torch.bfloat16, device=self.device)  # hi | mid | lo
+            self.nets.actor_w2_x9 = self.w2_x9.data_ptr()
+            _lib.call("hx_pack_w2_x9", self.actor.data_ptr(), 13, self.w2_x9.data_ptr(), _lib.stream_ptr())
+            self._x9_live = True
+        return True
 
     refresh_images = refresh_bf16
 
@@ -399,7 +420,7 @@ class HirlEngine:
             _lib.call("hx_actor_act_bf16", self.actor.data_ptr(), self.w2_bf16.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise),
                       float(sigma), int(seed), int(row0), self.act_calls, self.slope, _lib.stream_ptr())
             return out
-        if self.act_dtype == "f32x9" and net is None:
+        if net is None and self._x9_for(n):
             _lib.call("hx_actor_act_x9", self.actor.data_ptr(), self.w2_x9.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise),
                       float(sigma), int(seed), int(row0), self.act_calls, self.slope, _lib.stream_ptr())
             return out
@@ -430,7 +451,7 @@ class HirlEngine:
                       out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
                       env.reward.data_ptr(), env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
             return out, env.obs, env.reward, env.done, env.success
-        if self.act_dtype == "f32x9":
+        if self._x9_for(n):
             _lib.call("hx_actor_act_step_x9", self.actor.data_ptr(), self.w2_x9.data_ptr(), env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(),
                       out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
                       env.reward.data_ptr(), env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())

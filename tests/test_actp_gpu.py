@@ -49,6 +49,8 @@ def engine(E, dtype, slope=0.0):
         e.set_act_dtype("bf16")
     elif dtype == "f32x9":
         e.set_act_dtype("f32x9")
+    else:
+        e.x9_rows = None  # "f32" here means the fp32-MFMA kernels at every size (the engine's default switches to the exact split at 16,384 rows)
     return e
 
 
@@ -131,6 +133,7 @@ def test_config3_population_65536_circular_hirl_linear(mods):
     E, Env, Replay = mods
     n = 65536
     e = engine(E, "f32")
+    e.x9_rows = 16384  # the engine's default: the population's fp32 policy runs through the exact 9-term split
     rep = Replay(1 << 22, "cuda")
     env = Env(n, scenario="circular", seed=7, max_step=40, auto_reset=True, random_reset=True, replay=rep)
     env.reset()

@@ -29,6 +29,8 @@ def make(E, dtype, params=None, **kw):
     e = E.HirlEngine(batch=128, **kw)
     e.load_params(params["actor"], params["critic"], params["bc_actor"])
     e.set_act_dtype(dtype)
+    if dtype == "f32":
+        e.x9_rows = None  # the fp32-MFMA kernels at every size (the engine's default takes the exact split from 16,384 rows on)
     return e
 
 
