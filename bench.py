@@ -84,9 +84,11 @@ def parse(argv=None):
     p.add_argument("--staged", action="store_true",
                    help="run EXACTLY the launch sequence of a sharded rank on one rank too (stage entry points, split actor message, hx_adam_mixed, "
                         "both exchange calls — through torch.distributed when launched by torch.distributed.run): the cost of the N > 1 step")
-    p.add_argument("--exchange", default="rccl", choices=["rccl", "oneshot"],
-                   help="gradient exchange at N > 1: RCCL all-reduce (torch.distributed) or — EXPERIMENTAL, never run on two physical GPUs — the "
-                        "one-shot peer-read kernel over hipIpc mappings")
+    p.add_argument("--exchange", default="rccl", choices=["rccl", "rccl-torch", "oneshot", "twostage", "twostage-bf16"],
+                   help="gradient exchange of the sharded step: rccl = ncclAllReduce enqueued by the library on the engine's stream (hx_rccl_allreduce; "
+                        "with the gloo test backend it falls back to torch.distributed); rccl-torch = torch.distributed.all_reduce; EXPERIMENTAL, never "
+                        "run on two physical GPUs: oneshot (every rank reads every peer's message over hipIpc mappings), twostage (reduce-scatter + "
+                        "all-gather over the same mappings), twostage-bf16 (its reduced slices as bf16)")
     p.add_argument("--exchange-timeout-ms", dest="exchange_timeout_ms", type=int, default=5000,
                    help="one-shot exchange: how long a rank waits for a peer's message before it raises (ranks that SHARE a GPU - tests - "
                         "only make progress through pre-emption and need far longer than ranks with a GPU each)")
@@ -206,8 +208,10 @@ class Loop:
                 self.eng.sharded_sequence = True
             self.eng.set_act_dtype({"f32": "f32", "f32x9": "f32x9"}.get(args.dtype, "bf16"))
             self.eng.set_update_dtype("bf16" if args.dtype == "bf16" else "f32")
-            if world > 1 and args.exchange == "oneshot":
-                self.eng.use_oneshot_exchange(timeout_ms=args.exchange_timeout_ms)
+            if world > 1 and args.exchange in ("oneshot", "twostage", "twostage-bf16"):
+                self.eng.use_oneshot_exchange(timeout_ms=args.exchange_timeout_ms, two_stage=args.exchange != "oneshot", bf16=args.exchange == "twostage-bf16")
+            elif args.exchange == "rccl" and getattr(args, "pg_backend", None) == "nccl" and (world > 1 or args.staged):
+                self.eng.use_rccl_direct()  # (one GPU per rank: RCCL refuses ranks that share a device — the gloo test backend keeps torch.distributed)
         es, ea = synthetic_expert(rng)
         # BC table rows (s, a) and the expert replay ring labelled on the GPU (train_all.py:289-306)
         bc_rows = np.zeros((es.shape[0], 32), np.float32)
@@ -686,6 +690,7 @@ def run_rank(args):
     if pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+    args.pg_backend = backend if pg else None
     loop = Loop(args, rank, world, device)
 
     def barrier():
@@ -788,7 +793,7 @@ def run_rank(args):
                    "actions": args.actions, "act_env": "one launch (hx_actor_act_step / hx_sac_act_step)" if loop.fused else "two launches",
                    "issue_order": "two streams" if loop.pipe.overlap else "serial",
                    "update_path": "staged (the sharded rank's launch sequence)" if (args.staged or world > 1) and args.agent == "hirl" else "one-call",
-                   "parallelism": f"dp{world}: env shards + replicated nets, {'one-shot peer-read' if (world > 1 and args.exchange == 'oneshot') else 'RCCL'} "
+                   "parallelism": f"dp{world}: env shards + replicated nets, {'peer-read ' + args.exchange if (world > 1 and args.exchange in ('oneshot', 'twostage', 'twostage-bf16')) else 'RCCL'} "
                                   f"all-reduce of the flat gradients; effective batch = {args.batch} x {world}"},
         "update_steps_per_s": round(args.steps / dt, 1),
         "timed_region": "R x [K x step() between two barrier + synchronize pairs]; no events, no stamped or split launches inside (those are the second pass)",
@@ -861,7 +866,9 @@ def run_rank(args):
     if pg:
         ids = [None] * world
         torch.distributed.all_gather_object(ids, (socket.gethostname(), str(getattr(torch.cuda.get_device_properties(local), "uuid", local))))
-        res["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(), "backend": backend, "distinct_gpus": len(set(ids)),
+        direct = getattr(loop.eng, "exchange_name", "") == "rccl-direct"
+        res["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(), "backend": "rccl-direct" if direct else backend, "process_group_backend": backend,
+                             "distinct_gpus": len(set(ids)),
                              "exchange": getattr(loop.eng, "exchange_name", "rccl"),
                              "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}
     if world > 1:  # the replicas must still be bit-identical after every sharded update so far

@@ -46,6 +46,20 @@ _SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 110  # HX_ABI_VERSION of include/hirl4ucav.h
+_ABI_STRUCTS = {}  # name -> (index in hx_abi_sizes, ctypes class): filled by the binding modules (check_struct)
+
+
+def check_struct(index, cls):
+    """Compare ctypes.sizeof(cls) with the library's sizeof of the same struct (hx_abi_sizes): a binding that has drifted from the header
+    would hand the kernels short buffers (a 9-word statistics buffer under a library that adds into 512 words)."""
+    sizes = (ctypes.c_int32 * 8)()
+    L = load()
+    L.hx_abi_sizes.argtypes = [ctypes.POINTER(ctypes.c_int32)]
+    if L.hx_abi_sizes(sizes) != 0 or sizes[index] != ctypes.sizeof(cls):
+        raise HxError(f"ABI mismatch: {cls.__name__} is {ctypes.sizeof(cls)} bytes here, {sizes[index]} in {SO_PATH}")
+    if sizes[7] != STAT_WAYS * STAT_PITCH:
+        raise HxError(f"ABI mismatch: a statistics buffer is {STAT_WAYS * STAT_PITCH} words here, {sizes[7]} in {SO_PATH}")
 
 
 def load():
@@ -64,6 +78,9 @@ def load():
     L = ctypes.CDLL(SO_PATH)
     L.hx_last_error.restype = ctypes.c_char_p
     L.hx_version.restype = ctypes.c_int
+    if L.hx_version() != ABI_VERSION:
+        raise HxError(f"{SO_PATH} implements ABI version {L.hx_version()}, this binding was written for {ABI_VERSION} (include/hirl4ucav.h "
+                      f"HX_ABI_VERSION): rebuild the library (make -C hirl4ucav_amd/csrc)")
     L.hx_event_create.restype = ctypes.c_void_p
     L.hx_event_create.argtypes = []
     for name, args in _SIGNATURES.items():

@@ -70,6 +70,41 @@ _lib.register("hx_ipc_export", [_vp, _vp])
 _lib.register("hx_ipc_import", [_vp, _P(_vp)])
 _lib.register("hx_ipc_close", [_vp])
 _lib.register("hx_allreduce_oneshot", [_vp, _P(_vp), _P(_vp), _vp, _i32, _i32, ctypes.c_int64, ctypes.c_uint32, _i32, _vp])
+_lib.register("hx_allreduce_twostage", [_vp, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _vp, _i32, _i32, ctypes.c_int64, ctypes.c_uint32, _i32, _i32, _vp])
+_lib.register("hx_rccl_unique_id", [_vp])
+_lib.register("hx_rccl_init", [_vp, _i32, _i32, _P(_vp)])
+_lib.register("hx_rccl_allreduce", [_vp, _vp, ctypes.c_int64, _i32, _vp])
+_lib.register("hx_rccl_destroy", [_vp])
+
+
+class RcclDirect:
+    """RCCL without torch.distributed in the loop (include/hirl4ucav.h hx_rccl_*): ncclAllReduce enqueued on the engine's stream by the
+    library.  The communicator's 128-byte id is made on rank 0 and travels once, at construction, through the existing process group
+    (torch.distributed.broadcast_object_list: the launcher's TCP store / gloo / nccl — any backend); one GPU per rank."""
+
+    def __init__(self, group=None):
+        dist = torch.distributed
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [None]
+        if self.rank == 0:
+            raw = ctypes.create_string_buffer(128)
+            _lib.call("hx_rccl_unique_id", raw)
+            box[0] = raw.raw
+        dist.broadcast_object_list(box, src=0, group=group)
+        comm = _vp()
+        _lib.call("hx_rccl_init", ctypes.create_string_buffer(box[0], 128), self.world, self.rank, ctypes.byref(comm))
+        self.comm = comm
+
+    def allreduce(self, t):
+        """t <- sum over the ranks of t (fp32), in place, on the current stream"""
+        _lib.call("hx_rccl_allreduce", self.comm, t.data_ptr(), t.numel(), 0, _lib.stream_ptr())
+        return t
+
+    def close(self):
+        if self.comm is not None:
+            torch.cuda.synchronize()
+            c, self.comm = self.comm, None
+            _lib.call("hx_rccl_destroy", c)
 
 
 class _DeviceWords:
@@ -84,13 +119,16 @@ class OneShotExchange:
     message buffers (epoch parity) that the peers map, and one fine-grained flag word.  Handles travel once, at construction, through
     torch.distributed.all_gather_object (any backend)."""
 
-    def __init__(self, sizes, device, group=None, timeout_ms=5000):
+    def __init__(self, sizes, device, group=None, timeout_ms=5000, two_stage=False, bf16=False):
+        """two_stage: reduce-scatter + all-gather (hx_allreduce_twostage: 2 (world - 1) / world x n floats per rank over xGMI instead of
+        world x n); bf16 (two_stage only): the reduced slices travel as bf16"""
         dist = torch.distributed
+        self.two_stage, self.bf16 = bool(two_stage), bool(bf16) and bool(two_stage)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.device, self.timeout_ms = device, int(timeout_ms)
         self.kinds = list(sizes)
         self.n = {k: (int(v) + 3) & ~3 for k, v in sizes.items()}
-        total = sum(2 * self.n[k] for k in self.kinds)
+        total = sum((3 if self.two_stage else 2) * self.n[k] for k in self.kinds)  # two message buffers (epoch parity) [+ the reduced slices]
         msg, flag = _vp(), _vp()
         _lib.call("hx_ipc_alloc", total * 4, 0, ctypes.byref(msg))
         _lib.call("hx_ipc_alloc", 256, 1, ctypes.byref(flag))  # word k: flag of kind k; word 32: status
@@ -124,7 +162,7 @@ class OneShotExchange:
             flags.append(pf.value)
         self.status_ptr = flag.value + 32 * 4
         self.epoch = {k: 0 for k in self.kinds}
-        self.own, self.bufs, self.flags, self.reduced = {}, {}, {}, {}
+        self.own, self.bufs, self.flags, self.reduced, self.reds, self.flags2 = {}, {}, {}, {}, {}, {}
         off = 0
         arr = _vp * self.world
         for ki, k in enumerate(self.kinds):
@@ -132,7 +170,11 @@ class OneShotExchange:
                 self.own[k, par] = torch.as_tensor(_DeviceWords(msg.value + off * 4, self.n[k]), device=device)
                 self.bufs[k, par] = arr(*[b + off * 4 for b in bases])
                 off += self.n[k]
+            if self.two_stage:
+                self.reds[k] = arr(*[b + off * 4 for b in bases])
+                off += self.n[k]
             self.flags[k] = arr(*[f + ki * 4 for f in flags])
+            self.flags2[k] = arr(*[f + (8 + ki) * 4 for f in flags])  # words 8..: the second stage's flags
             self.reduced[k] = torch.zeros(self.n[k], dtype=torch.float32, device=device)
         dist.barrier(group=group)  # every mapping exists before the first exchange
 
@@ -144,8 +186,12 @@ class OneShotExchange:
         """sum of every rank's message written into write_buffer(kind) -> a local tensor (the same bits on every rank)"""
         self.epoch[kind] += 1
         e = self.epoch[kind]
-        _lib.call("hx_allreduce_oneshot", self.reduced[kind].data_ptr(), self.bufs[kind, e & 1], self.flags[kind], self.status_ptr, self.world,
-                  self.rank, self.n[kind], e & 0xFFFFFFFF, self.timeout_ms, _lib.stream_ptr())
+        if self.two_stage:
+            _lib.call("hx_allreduce_twostage", self.reduced[kind].data_ptr(), self.bufs[kind, e & 1], self.reds[kind], self.flags[kind], self.flags2[kind],
+                      self.status_ptr, self.world, self.rank, self.n[kind], e & 0xFFFFFFFF, self.timeout_ms, int(self.bf16), _lib.stream_ptr())
+        else:
+            _lib.call("hx_allreduce_oneshot", self.reduced[kind].data_ptr(), self.bufs[kind, e & 1], self.flags[kind], self.status_ptr, self.world,
+                      self.rank, self.n[kind], e & 0xFFFFFFFF, self.timeout_ms, _lib.stream_ptr())
         return self.reduced[kind]
 
     def check(self):
@@ -228,6 +274,8 @@ class HirlEngine:
         if self.device.type != "cuda":
             raise _lib.HxError("HirlEngine runs on the GPU only (no CPU path in the product)")
         L = _lib.load()
+        for i, cls in ((0, _lib.HxStepOpts), (1, HxNets), (2, HxHyper), (3, HxBatch), (4, HxSample)):
+            _lib.check_struct(i, cls)  # this binding's structs against the loaded library's (include/hirl4ucav.h hx_abi_sizes)
         assert L.hx_actor_param_count() == ACTOR_SIZE and L.hx_critic_param_count() == CRITIC_SIZE
         L.hx_hirl_workspace_floats.restype = ctypes.c_int64
         self.batch = int(batch)
@@ -282,7 +330,7 @@ class HirlEngine:
         # True at world == 1: run EXACTLY the launch sequence of a sharded rank (split actor message, hx_adam_mixed, both exchange calls
         # — through torch.distributed when a process group exists) so that its cost can be measured on one GPU (bench.py --staged)
         self.sharded_sequence = False
-        self.exchange_name, self.xchg = "rccl", None
+        self.exchange_name, self.xchg, self.rccl = "rccl", None, None
 
     # ---- parameters ------------------------------------------------------------------------------------------
     def load_params(self, actor, critic, bc_actor=None, hard_update_targets=True):
@@ -388,7 +436,10 @@ class HirlEngine:
         return int(t.view(torch.int32).to(torch.int64).sum().item())
 
     def close(self):
-        """Release the one-shot exchange's peer mappings; raises if an exchange failed since the last check."""
+        """Release the one-shot exchange's peer mappings / the direct RCCL communicator; raises if an exchange failed since the last check."""
+        if self.rccl is not None:
+            r, self.rccl = self.rccl, None
+            r.close()
         if self.xchg is not None:
             x, self.xchg = self.xchg, None
             self.nets.xchg_status = None
@@ -462,13 +513,23 @@ class HirlEngine:
         return out, env.obs, env.reward, env.done, env.success
 
     # ---- learning --------------------------------------------------------------------------------------------
-    def use_oneshot_exchange(self, timeout_ms=5000):
-        """Exchange gradients with the one-shot peer-read kernel over hipIpc mappings instead of RCCL (hx_allreduce_oneshot)."""
+    def use_oneshot_exchange(self, timeout_ms=5000, two_stage=False, bf16=False):
+        """Exchange gradients with the peer-read kernels over hipIpc mappings instead of RCCL: hx_allreduce_oneshot, or with two_stage
+        hx_allreduce_twostage (reduce-scatter + all-gather; bf16: reduced slices as bf16)."""
         if self.world <= 1:
             return
-        self.xchg = OneShotExchange({"critic": CRITIC_SIZE, "actor": self.actor_msg.numel()}, self.device, self.group, timeout_ms)
+        self.xchg = OneShotExchange({"critic": CRITIC_SIZE, "actor": self.actor_msg.numel()}, self.device, self.group, timeout_ms, two_stage, bf16)
         self.nets.xchg_status = self.xchg.status_ptr  # a failed exchange freezes the optimizer steps (fail-stop), check() raises
-        self.exchange_name = "oneshot"
+        self.exchange_name = "oneshot" if not two_stage else ("twostage-bf16" if bf16 else "twostage")
+
+    def use_rccl_direct(self):
+        """Exchange gradients with ncclAllReduce enqueued by the library on the engine's stream (hx_rccl_allreduce) instead of
+        torch.distributed.all_reduce: no host-side collective call inside learn().  Needs an initialised process group (for the id) and one
+        GPU per rank (RCCL refuses two ranks on one device); works at world size 1 (the sharded rank's sequence, bench.py --staged)."""
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            raise _lib.HxError("use_rccl_direct needs an initialised torch.distributed process group (it carries the communicator id)")
+        self.rccl = RcclDirect(self.group)
+        self.exchange_name = "rccl-direct"
 
     def _allreduce(self, t, kind=None):
         """SUM over the ranks of `t` (a gradient message).  RCCL: in place.  One-shot: `t` is this rank's message buffer of `kind`, the
@@ -477,6 +538,8 @@ class HirlEngine:
             return t
         if self.xchg is not None and kind is not None:
             return self.xchg.allreduce(kind)
+        if self.rccl is not None:
+            return self.rccl.allreduce(t)
         torch.distributed.all_reduce(t, group=self.group)
         return t
 

@@ -80,5 +80,12 @@ int hx_event_elapsed_us(void* start, void* stop, float* us) {
     return 0;
 }
 const char* hx_last_error(void) { return hx::error_buffer(); }
-int hx_version(void) { return 100; }
+int hx_version(void) { return HX_ABI_VERSION; }
+int hx_abi_sizes(int32_t* sizes8) {
+    HX_REQUIRE(sizes8, "hx_abi_sizes: null");
+    const int32_t v[8] = {(int32_t)sizeof(HxStepOpts), (int32_t)sizeof(HxNets), (int32_t)sizeof(HxHyper), (int32_t)sizeof(HxBatch), (int32_t)sizeof(HxSample),
+                          (int32_t)sizeof(HxSacNets), (int32_t)sizeof(HxSacBatch), HX_STAT_WAYS * HX_STAT_PITCH};
+    for (int i = 0; i < 8; ++i) sizes8[i] = v[i];
+    return 0;
+}
 }

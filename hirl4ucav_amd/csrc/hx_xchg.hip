@@ -88,6 +88,90 @@ __global__ __launch_bounds__(kThreads) void oneshot_allreduce_kernel(OneShotArgs
     }
 }
 
+// ---- two stages: reduce-scatter + all-gather ---------------------------------------------------------------------------
+// The one-shot kernel reads world x n floats per rank (8.8 MB over xGMI for a 1.1 MB message at 8 ranks).  Here rank r first sums only ITS
+// slice [n r / world, n (r + 1) / world) of every rank's message into its peer-mapped `red` buffer (stage 1: (world - 1) / world x n floats
+// over xGMI), then copies the peers' reduced slices (stage 2: the same again): 2 (world - 1) / world x n per rank, every link busy in both
+// stages.  Two launches on the stream (the boundary is the grid-wide synchronisation), two flag words per rank and message kind.  `red`
+// needs no double buffer: a rank rewrites its slice at epoch e + 1 only after every peer has announced e + 1, which a peer does after its
+// stage-2 kernel of epoch e has finished (stream order).  bf16 != 0: the reduced slices travel as bf16 (round to nearest even, the rank's own
+// slice too: every replica sees the same bits) — half the bytes of stage 2, the sum itself is formed in fp32.
+struct TwoStageArgs {
+    float* dst;
+    const float* buf[kMaxWorld];
+    void* red[kMaxWorld];
+    unsigned* flag[kMaxWorld];
+    unsigned* status;
+    int world, rank, bf16, stage;
+    long long n;
+    unsigned epoch;
+    unsigned long long timeout_ticks;
+};
+
+// announce + bounded wait + acquire, shared by the two stages; returns false when the exchange has failed (status set, flag poisoned)
+__device__ __forceinline__ bool xchg_handshake(unsigned* const* flag, unsigned* status, int world, int rank, unsigned epoch, unsigned long long timeout_ticks, int* s_fail) {
+    if (threadIdx.x == 0) *s_fail = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u ? 1 : 0;  // sticky
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(flag[rank], *s_fail ? kPoison : epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (*s_fail) return false;
+    if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            const unsigned v = __hip_atomic_load(flag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v == kPoison) { *s_fail = 2; break; }
+            if ((int)(v - epoch) >= 0) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) { *s_fail = 1; break; }
+        }
+    }
+    __syncthreads();
+    if (*s_fail) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(status, (unsigned)*s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(flag[rank], kPoison, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return false;
+    }
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // ONE wave per workgroup (see oneshot_allreduce_kernel)
+    __syncthreads();
+    return true;
+}
+__device__ __forceinline__ uint2 pack4_bf16(float4 v) {
+    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+    return make_uint2(__builtin_bit_cast(unsigned, v2bf{(__bf16)v.x, (__bf16)v.y}), __builtin_bit_cast(unsigned, v2bf{(__bf16)v.z, (__bf16)v.w}));
+}
+__device__ __forceinline__ float4 unpack4_bf16(uint2 q) {
+    return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xFFFF0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xFFFF0000u));
+}
+
+__global__ __launch_bounds__(kThreads) void twostage_kernel(TwoStageArgs A) {
+    __shared__ int s_fail;
+    if (!xchg_handshake(A.flag, A.status, A.world, A.rank, A.epoch, A.timeout_ticks, &s_fail)) return;
+    const long long n4 = A.n / 4;
+    if (A.stage == 0) {  // this rank's slice of every message, summed in rank order -> red[rank]
+        const long long lo = n4 * A.rank / A.world, hi = n4 * (A.rank + 1) / A.world;
+        for (long long i = lo + (long long)blockIdx.x * kThreads + threadIdx.x; i < hi; i += (long long)gridDim.x * kThreads) {
+            float4 s = reinterpret_cast<const float4*>(A.buf[0])[i];
+            for (int r = 1; r < A.world; ++r) {
+                const float4 v = reinterpret_cast<const float4*>(A.buf[r])[i];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            if (A.bf16) reinterpret_cast<uint2*>(A.red[A.rank])[i] = pack4_bf16(s);
+            else reinterpret_cast<float4*>(A.red[A.rank])[i] = s;
+        }
+    } else {  // every rank's reduced slice -> dst
+        for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads) {
+            int r = (int)((i * A.world + A.world - 1) / n4);  // the owner of float4 i: the r with n4 r / world <= i < n4 (r + 1) / world
+            while (r > 0 && i < n4 * r / A.world) --r;
+            while (r + 1 < A.world && i >= n4 * (r + 1) / A.world) ++r;
+            reinterpret_cast<float4*>(A.dst)[i] = A.bf16 ? unpack4_bf16(reinterpret_cast<const uint2*>(A.red[r])[i]) : reinterpret_cast<const float4*>(A.red[r])[i];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -153,6 +237,38 @@ int hx_allreduce_oneshot(float* dst, const float* const* bufs, uint32_t* const* 
     const int blocks = (int)((n4 + kThreads - 1) / kThreads < max_blocks ? (n4 + kThreads - 1) / kThreads : max_blocks);
     hipLaunchKernelGGL(oneshot_allreduce_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, A);
     HX_CHECK_LAUNCH("hx_allreduce_oneshot");
+    return 0;
+}
+
+/* The same sum in two stages (reduce-scatter + all-gather: 2 (world - 1) / world x n floats per rank over xGMI instead of world x n), two
+ * launches on `stream`.  reds: HOST array of `world` device pointers to the ranks' peer-mapped reduced-slice buffers (n floats each; with
+ * bf16 != 0 they hold bf16 and the result is the fp32 sum rounded to bf16 — identical on every rank); flags2: a second flag word per rank
+ * (stage 2), same rules as flags.  Every other argument as hx_allreduce_oneshot; the same sticky fail-stop behaviour.  EXPERIMENTAL. */
+int hx_allreduce_twostage(float* dst, const float* const* bufs, void* const* reds, uint32_t* const* flags, uint32_t* const* flags2, uint32_t* status,
+                          int32_t world, int32_t rank, int64_t n, uint32_t epoch, int32_t timeout_ms, int32_t bf16, void* stream) {
+    HX_REQUIRE(dst && bufs && reds && flags && flags2 && status && world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world && n > 0 && n % 4 == 0,
+               "hx_allreduce_twostage: bad arguments (world <= 8, n a multiple of 4)");
+    HX_REQUIRE(epoch != kPoison, "hx_allreduce_twostage: epoch 0xFFFFFFFF is reserved");
+    TwoStageArgs A{};
+    A.dst = dst; A.status = status; A.world = world; A.rank = rank; A.n = n; A.epoch = epoch; A.bf16 = bf16 ? 1 : 0;
+    for (int r = 0; r < world; ++r) {
+        HX_REQUIRE(bufs[r] && reds[r] && flags[r] && flags2[r] && (reinterpret_cast<uintptr_t>(bufs[r]) & 15u) == 0 && (reinterpret_cast<uintptr_t>(reds[r]) & 15u) == 0,
+                   "hx_allreduce_twostage: null or misaligned peer pointer");
+        A.buf[r] = bufs[r];
+        A.red[r] = reds[r];
+    }
+    A.timeout_ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 2000) * 100000ull;
+    const long long n4 = n / 4;
+    static const int env_blocks = getenv("HX_ONESHOT_BLOCKS") ? atoi(getenv("HX_ONESHOT_BLOCKS")) : 256;
+    const int max_blocks = env_blocks < 1 ? 1 : env_blocks;
+    for (int stage = 0; stage < 2; ++stage) {
+        A.stage = stage;
+        for (int r = 0; r < world; ++r) A.flag[r] = stage == 0 ? flags[r] : flags2[r];
+        const long long work = stage == 0 ? (n4 + world - 1) / world : n4;
+        const int blocks = (int)((work + kThreads - 1) / kThreads < max_blocks ? (work + kThreads - 1) / kThreads : max_blocks);
+        hipLaunchKernelGGL(twostage_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(kThreads), 0, (hipStream_t)stream, A);
+    }
+    HX_CHECK_LAUNCH("hx_allreduce_twostage");
     return 0;
 }
 

@@ -69,7 +69,14 @@ enum { HX_STAT_EPISODES = 0, HX_STAT_KILLS, HX_STAT_FIRE_SUCCESS_EPISODES, HX_ST
 #define HX_STAT_PITCH 16
 
 const char* hx_last_error(void);
+/* HX_ABI_VERSION of the library that is loaded.  The structs below are part of the ABI: a caller built against another header version must
+ * not call in (round 3 widened HxStepOpts.stats from 9 to HX_STAT_WAYS * HX_STAT_PITCH words and appended fields to HxNets / HxHyper without
+ * bumping this: a 9-word stats buffer then took atomics up to word 504).  110: round 4 (hx_abi_sizes, hx_rccl_*, hx_allreduce_twostage). */
+#define HX_ABI_VERSION 110
 int hx_version(void);
+/* sizes[0..7] (host) <- sizeof HxStepOpts, HxNets, HxHyper, HxBatch, HxSample, HxSacNets, HxSacBatch, and the words of a statistics buffer
+ * (HX_STAT_WAYS * HX_STAT_PITCH): a binding checks these against its own declarations at load time (hirl4ucav_amd/_lib.py does). */
+int hx_abi_sizes(int32_t* sizes8);
 /* Kernel-duration events for HxStepOpts.ev_start / ev_stop (bench.py's live roofline measurement). */
 void* hx_event_create(void);
 int hx_event_destroy(void* ev);
@@ -410,6 +417,24 @@ int hx_ipc_close(void* dev_ptr);
  * reported failure (2) — sticky and global (fail-stop): see hx_xchg.hip.  EXPERIMENTAL until it has run on two physical GPUs. */
 int hx_allreduce_oneshot(float* dst, const float* const* bufs, uint32_t* const* flags, uint32_t* status, int32_t world, int32_t rank,
                          int64_t n, uint32_t epoch, int32_t timeout_ms, void* stream);
+
+/* The same sum in TWO stages — reduce-scatter, then all-gather: rank r sums its slice [n r / world, n (r + 1) / world) of every rank's
+ * message into reds[r] (its peer-mapped buffer of n floats), then copies the peers' reduced slices: 2 (world - 1) / world x n floats per rank
+ * over xGMI instead of world x n.  Two launches; flags2: a second flag word per rank; bf16 != 0: the reduced slices travel as
+ * bf16 (the fp32 sum rounded to nearest even, on every rank alike).  Otherwise as hx_allreduce_oneshot, the same fail-stop rules.  EXPERIMENTAL. */
+int hx_allreduce_twostage(float* dst, const float* const* bufs, void* const* reds, uint32_t* const* flags, uint32_t* const* flags2, uint32_t* status,
+                          int32_t world, int32_t rank, int64_t n, uint32_t epoch, int32_t timeout_ms, int32_t bf16, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The exchange on RCCL without torch.distributed in the loop (hx_rccl.hip): ncclAllReduce enqueued on the caller's stream.  librccl.so is
+ * opened at run time — the copy the process already holds when there is one.  hx_rccl_unique_id on ONE rank, its 128 bytes to every rank by
+ * any channel, hx_rccl_init on every rank (collective; one GPU per rank), then hx_rccl_allreduce per message: buf <- sum over ranks, in place
+ * (dtype 0 fp32, 1 bf16), the same bits on every rank.  SURVEY.md 8e: the flat critic gradient and the merged actor message.
+ * ------------------------------------------------------------------------------------------------------------ */
+int hx_rccl_unique_id(uint8_t* id128 /* host, out */);
+int hx_rccl_init(const uint8_t* id128 /* host */, int32_t world, int32_t rank, void** comm /* host, out */);
+int hx_rccl_allreduce(void* comm, void* buf, int64_t n, int32_t dtype, void* stream);
+int hx_rccl_destroy(void* comm);
 
 #ifdef __cplusplus
 }

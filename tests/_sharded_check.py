@@ -1,4 +1,4 @@
-"""Run under `python -m torch.distributed.run --nproc-per-node 2 ... tests/_sharded_check.py {rccl|oneshot}` (gloo, both ranks on the one GPU
+"""Run under `python -m torch.distributed.run --nproc-per-node 2 ... tests/_sharded_check.py {rccl|oneshot|twostage|twostage-bf16}` (gloo, both ranks on the one GPU
 of the box): K sharded learn() calls of the PRODUCT engine — each rank its own minibatch of 128, ONE exchange per phase — against a
 single engine of batch 256 fed the two minibatches concatenated (the same global batch).  Rank 0 prints SHARDED_OK."""
 import os
@@ -24,8 +24,8 @@ def main(exchange):
     e = E.HirlEngine(batch=128)
     assert e.world == world and e.staged
     e.load_params(params["actor"], params["critic"], params["bc_actor"])
-    if exchange == "oneshot":
-        e.use_oneshot_exchange(timeout_ms=20000)
+    if exchange in ("oneshot", "twostage", "twostage-bf16"):
+        e.use_oneshot_exchange(timeout_ms=20000, two_stage=exchange != "oneshot", bf16=exchange == "twostage-bf16")
     rng = np.random.default_rng(7)
     K = 6
     draws = [(rng.integers(0, D.N_REPLAY, (world, 128)).astype(np.int32), rng.integers(0, D.N_EXPERT, (world, 128)).astype(np.int32),

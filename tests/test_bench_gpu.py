@@ -118,18 +118,25 @@ def test_bench_labels_follow_the_arguments():
 def test_bench_one_rank_over_rccl_runs_the_sharded_sequence():
     """python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 --staged with the DEFAULT backend (nccl = RCCL on ROCm): the
     process group is created on the device, the engine runs the sharded rank's launch sequence and sends its two messages per actor
-    call through torch.distributed.all_reduce -> RCCL (world size 1).  RCCL loads, builds a communicator on an MI355X and accepts the
-    flat fp32 gradient tensors on the engine's stream; what this box cannot show is an exchange between two GPUs."""
+    call through RCCL at world size 1 — by default with ncclAllReduce enqueued by the library itself on the engine's stream (hx_rccl_*:
+    the communicator id travels over the process group once), with --exchange rccl-torch through torch.distributed.all_reduce.  RCCL
+    loads, builds a communicator on an MI355X and accepts the flat fp32 gradient messages; what this box cannot show is an exchange
+    between two GPUs.  The direct path must not be slower than torch.distributed's (it exists to take ~8 us of host time per message out)."""
     port = str(29100 + os.getpid() % 300)
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", port,
              "bench.py", "--gpus", "1", "--staged", "--steps", "60", "--warmup", "10", "--no-cpu-baseline", "--no-sweep", "--settle-s", "0.2"],
             env={k: v for k, v in {"HX_BENCH_BACKEND": "nccl"}.items()})
     check(d, 1, 60, 10)
     rr = d["rccl_ranks"]
-    assert rr["backend"] == "nccl" and rr["world_size"] == 1 and rr["exchange"] == "rccl" and rr["rccl_version"]
+    assert rr["backend"] == "rccl-direct" and rr["process_group_backend"] == "nccl" and rr["world_size"] == 1 and rr["exchange"] == "rccl-direct" and rr["rccl_version"]
     assert "staged" in d["config"]["update_path"]
     assert len(d["allreduce"]) == 2 and {a["bytes"] for a in d["allreduce"]} == {4 * 276488, 4 * (2 * 138756 + 64)}  # critic message, merged actor message
     assert "world size 1" in d["allreduce_note"]
+    t = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(int(port) + 1),
+             "bench.py", "--gpus", "1", "--staged", "--exchange", "rccl-torch", "--steps", "60", "--warmup", "10", "--no-cpu-baseline", "--no-sweep", "--settle-s", "0.2"],
+            env={"HX_BENCH_BACKEND": "nccl"})
+    assert t["rccl_ranks"]["backend"] == "nccl" and t["rccl_ranks"]["exchange"] == "rccl"
+    assert d["ms_per_step"] <= t["ms_per_step"] * 1.03, (d["ms_per_step"], t["ms_per_step"])
 
 
 def test_bench_refuses_more_gpus_than_visible():
@@ -165,22 +172,25 @@ def test_two_rank_launch_soak():
 # (OneShotExchange picks that when ranks share a device; 256 spinning workgroups keep the peer's 1024-thread workgroups from being placed
 # for seconds at a time) — a functional check with a long timeout; ranks with a GPU each never wait like that
 ONESHOT = ["--exchange", "oneshot", "--exchange-timeout-ms", "120000", "--measure-steps", "16"]
+TWOSTAGE = ["--exchange", "twostage", "--exchange-timeout-ms", "120000", "--measure-steps", "16"]
+TWOSTAGE_BF16 = ["--exchange", "twostage-bf16", "--exchange-timeout-ms", "120000", "--measure-steps", "16"]
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
-@pytest.mark.parametrize("extra", [[], ["--overlap"], ["--agent", "sac", "--scenario", "serpentine"], ONESHOT])
+@pytest.mark.parametrize("extra", [[], ["--overlap"], ["--agent", "sac", "--scenario", "serpentine"], ONESHOT, TWOSTAGE, TWOSTAGE_BF16])
 def test_bench_two_ranks_launch_form(extra):
     """python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ..."""
     port = str(29600 + (os.getpid() + len(extra)) % 300)
-    steps, warm = (("12", "2") if "oneshot" in extra else ("60", "10"))
+    peer = "--exchange" in extra
+    steps, warm = (("12", "2") if peer else ("60", "10"))
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
-             "bench.py", "--gpus", "2", "--steps", steps, "--warmup", warm, "--no-cpu-baseline", "--no-sweep", "--settle-s", "0" if "oneshot" in extra else "0.2"] + extra,
+             "bench.py", "--gpus", "2", "--steps", steps, "--warmup", warm, "--no-cpu-baseline", "--no-sweep", "--settle-s", "0" if peer else "0.2"] + extra,
             env={"HX_BENCH_BACKEND": "gloo"})
     check(d, 2, int(steps), int(warm))
     assert d["allreduce"] and all(a["median_us"] > 0 for a in d["allreduce"])
     assert d["env_stats"]["env_steps"] > 0
     assert d["replicas_identical"] is True  # 70 sharded updates later every rank holds the same networks and Adam moments, bit for bit
-    assert d["rccl_ranks"]["exchange"] == ("oneshot" if "oneshot" in extra else "rccl") and d["rccl_ranks"]["world_size"] == 2
+    assert d["rccl_ranks"]["exchange"] == (extra[1] if peer else "rccl") and d["rccl_ranks"]["world_size"] == 2
     if "sac" not in extra:  # HIRL: one message per phase = the critic's 1.1 MB and the merged actor message, nothing else
         assert len(d["allreduce"]) == 2, d["allreduce"]
 

@@ -36,12 +36,12 @@ def single_engine_reference():
     return {k: getattr(e, k).cpu().numpy() for k in ("actor", "critic", "target_actor", "target_critic")}, np.asarray(e.losses_host())
 
 
-@pytest.mark.parametrize("exchange", ["rccl", "oneshot"])
+@pytest.mark.parametrize("exchange", ["rccl", "oneshot", "twostage", "twostage-bf16"])
 def test_two_rank_update_equals_the_global_batch_update(exchange, tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     out = str(tmp_path / "sharded.npz")
-    port = str(29800 + os.getpid() % 150 + (50 if exchange == "oneshot" else 0))
+    port = str(29800 + os.getpid() % 150 + 40 * ["rccl", "oneshot", "twostage", "twostage-bf16"].index(exchange))
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", port, os.path.join(ROOT, "tests", "_sharded_check.py"), exchange], cwd=ROOT,
                        env={**os.environ, "SHARDED_OUT": out, "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -52,9 +52,12 @@ def test_two_rank_update_equals_the_global_batch_update(exchange, tmp_path):
     # same global batch, different summation tree (two shard sums added vs one 256-row reduction) and, in the sharded run, the two actor
     # losses combined AFTER the exchange: fp32 rounding only.  Adam turns a rounding-level gradient difference on a near-zero entry
     # into up to 2 lr of parameter difference, so: 99.9 % of the entries within 2e-5, none beyond 6 x 2 lr.
+    # twostage-bf16: the SUMMED gradient is rounded to bf16 before Adam (2^-9 relative per entry) — replicas stay bit-identical (asserted in
+    # the ranks), the parameters follow the fp32 run to Adam's resolution of such a perturbation: 99 % within 2e-4
+    frac, tol = (0.99, 2e-4) if exchange == "twostage-bf16" else (0.999, 2e-5)
     for k in ("actor", "critic", "target_actor", "target_critic"):
         d = np.abs(got[k] - ref[k])
-        assert (d <= 2e-5).mean() >= 0.999 and d.max() <= 1.2e-2, (k, (d <= 2e-5).mean(), d.max())
+        assert (d <= tol).mean() >= frac and d.max() <= 1.2e-2, (k, (d <= tol).mean(), d.max())
     # (rank 0's logged loss values are its own shard's means; only the weight is a global quantity)
     assert abs(got["losses"][5] - ref_losses[5]) < 1e-6  # the BC weight comes from the GLOBAL soft count: equal to the single engine's
 
