@@ -584,8 +584,8 @@ class HirlEngine:
         B = self.batch
         st = _lib.stream_ptr()
         pending, self._pending = self._pending, None
-        if pending is not None and before_exchange is not None and getattr(before_exchange, "__self__", None) is not None \
-                and getattr(before_exchange.__self__, "_armed", None) is not None:
+        pipe = getattr(before_exchange, "__self__", None) if before_exchange is not None else None
+        if pending is not None and pipe is not None and (getattr(pipe, "_armed", None) is not None or getattr(pipe, "issued", False)):
             # a deferred draw reads *total and the ring INSIDE learn()'s first launch; an env step released beside that launch inserts into the
             # ring and moves *total under it (workgroups would disagree about the live length).  Draw first, then overlap.
             raise _lib.HxError("sample(defer=True) cannot be combined with an armed VectorStepPipeline: use sample(defer=False) when the "

@@ -626,7 +626,8 @@ void launch_fwd(const FwdArgs& F, hipStream_t st);                          // h
 void launch_bwd(int grp, const BwdArgs& G, hipStream_t st);                 // hx_fwdbwd.hip: grp = bwd_l2_kernel's GRP (0..3)
 void launch_wg(const WgArgs& W, bool adam, hipStream_t st);                 // hx_wgrad.hip: adam = the optimizer step rides in the launch
 void launch_adam(const AdamArgs& A, hipStream_t st);                        // hx_wgrad.hip
-void launch_polyak(float* target, const float* source, int n, float tau, float* target2, const float* source2, int n2, hipStream_t st);
+void launch_polyak(float* target, const float* source, int n, float tau, float* target2, const float* source2, int n2, hipStream_t st,
+                   const uint32_t* guard = nullptr);  // guard: a word that must be 0 for the step to happen (a failed exchange)
 // bf16 image of the W2 [512][256] at `w2`: forward order (w2_image_index) or transposed (w2t_image_index)             hx_act.hip
 void launch_pack_bf16(const float* w2, uint16_t* image, bool transposed, hipStream_t st);
 

@@ -622,8 +622,10 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs A) {
 }
 
 // up to two (target, source) segments in one launch: blocks [0, nb1) walk the first, the rest the second
+// guard: nullptr, or a word that must be 0 for the step to happen (HxNets.xchg_status: after a failed exchange no target moves either)
 __global__ __launch_bounds__(kThreads) void polyak_kernel(float* target, const float* source, int n, float tau, float* target2 = nullptr,
-                                                          const float* source2 = nullptr, int n2 = 0) {
+                                                          const float* source2 = nullptr, int n2 = 0, const uint32_t* guard = nullptr) {
+    if (guard && *guard != 0u) return;
     const int nb1 = (n / 4 + kThreads) / kThreads;
     int blk = blockIdx.x;
     if (blk >= nb1) {
@@ -667,9 +669,9 @@ void launch_wg(const WgArgs& W, bool adam, hipStream_t st) {
 void launch_adam(const AdamArgs& A, hipStream_t st) {
     hipLaunchKernelGGL(adam_kernel, dim3((A.n / 4 + kThreads) / kThreads), dim3(kThreads), 0, st, A);
 }
-void launch_polyak(float* target, const float* source, int n, float tau, float* target2, const float* source2, int n2, hipStream_t st) {
+void launch_polyak(float* target, const float* source, int n, float tau, float* target2, const float* source2, int n2, hipStream_t st, const uint32_t* guard) {
     const int nb = (n / 4 + kThreads) / kThreads + (target2 ? (n2 / 4 + kThreads) / kThreads : 0);
-    hipLaunchKernelGGL(polyak_kernel, dim3(nb), dim3(kThreads), 0, st, target, source, n, tau, target2, source2, n2);
+    hipLaunchKernelGGL(polyak_kernel, dim3(nb), dim3(kThreads), 0, st, target, source, n, tau, target2, source2, n2, guard);
 }
 
 }  // namespace hxu
@@ -766,7 +768,9 @@ int hx_adam_mixed(const HxNets* N, const HxHyper* Hy, int32_t polyak, int32_t st
 int hx_polyak(const HxNets* N, const HxHyper* Hy, void* stream) {
     HX_REQUIRE(N && Hy, "hx_polyak: bad arguments");
     const int nc = 2 * kQ.padded(), na = kActor.size();
-    launch_polyak(N->target_critic, N->critic, nc, Hy->tau, N->target_actor, N->actor, na, (hipStream_t)stream);
+    // (HxNets.xchg_status non-zero — a failed one-shot exchange: the targets stay where they are, like everything hx_adam* guards; the image
+    //  refresh below then re-derives the same images from the unchanged targets)
+    launch_polyak(N->target_critic, N->critic, nc, Hy->tau, N->target_actor, N->actor, na, (hipStream_t)stream, N->xchg_status);
     if (uint16_t* im = N->w2_bf16_all) {  // bf16 update path: the targets' images follow
         launch_pack_bf16(N->target_actor + kActor.W2(), im + IM_TA * kImgElems, false, (hipStream_t)stream);
         for (int h = 0; h < 2; ++h)

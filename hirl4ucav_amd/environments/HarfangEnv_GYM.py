@@ -60,7 +60,8 @@ class HarfangEnv:
         self._h_action = torch.zeros((1, 4), dtype=torch.float32).pin_memory()
         self._h_row = torch.zeros(64, dtype=torch.float32).pin_memory()
         self._np_action, self._np_row = self._h_action.numpy(), self._h_row.numpy()
-        self._stream_sync = torch.cuda.current_stream(self._env.device).synchronize
+        # (the stream current AT THE CALL: hx_env_step / hx_env_pack_row are enqueued on _lib.stream_ptr(), which follows torch.cuda.stream(...))
+        self._stream_sync = lambda: torch.cuda.current_stream(self._env.device).synchronize()
         _lib.register("hx_env_pack_row", [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
         self.state = None

@@ -296,6 +296,17 @@ def main(config):
         elif hirl and config.type == "soft" and rank == 0:
             print("WARNING: HIRL-soft without --bc_actor: the soft weight is estimated against a randomly initialised bc_actor", flush=True)
     dtype = getattr(config, "dtype", "f32")
+    # the run's arithmetic is part of its state: a snapshot taken under one --dtype does not continue under another (the same flag changed
+    # meaning once already: round 2's "bf16" was policy inference only, since round 3 it is the policy AND learn()'s 256 <-> 512 products)
+    snap_dtype = snap["driver"].get("dtype") if snap is not None else None
+    if snap_dtype is not None and snap_dtype != dtype:
+        raise SystemExit(f"train_all: --resume {config.resume} was run with --dtype {snap_dtype}, --dtype {dtype} given")
+    if sac and dtype != "f32":
+        if rank == 0:
+            print(f"WARNING: --dtype {dtype} has no effect on the SAC / E-SAC agents (their kernels are fp32): running fp32", flush=True)
+        dtype = "f32"
+    if world > 1 and os.environ.get("HX_DIST_BACKEND", "nccl") == "nccl" and hasattr(eng, "use_rccl_direct"):
+        eng.use_rccl_direct()  # ncclAllReduce enqueued by the library on the engine's stream (hx_rccl_*): no torch.distributed call inside learn()
     if dtype == "f32x9" and not sac:  # fp32, the acting kernel's 256 -> 512 product as the exact 9-term bf16 split (engine.set_act_dtype)
         eng.set_act_dtype("f32x9")
     elif dtype != "f32" and not sac:  # bf16: actor AND critic (BASELINE.json configs[4]); bf16_policy: policy inference only
@@ -410,7 +421,7 @@ def main(config):
                 torch.distributed.barrier()  # every shard of a snapshot comes from the same episode ...
             CK.save_run(os.path.join(log_dir, f"state_rank{rank}.pt"), eng, env, replay,
                         {"episode": episode + 1, "expert_num": expert_num, "high_score": high_score, "success_rate": success_rate, "arttir": arttir,
-                         "seed": seed})
+                         "seed": seed, "dtype": dtype})
             if world > 1:
                 torch.distributed.barrier()  # ... and nobody runs ahead while a shard is still being written
     if writer is not None:
@@ -450,8 +461,10 @@ def parser():
     p.add_argument("--resume", type=str, default=None, help="run directory holding state_rank<r>.pt to continue from")
     p.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; without a launcher environment the driver starts them itself")
     p.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "bf16_policy", "f32x9"],
-                   help="bf16: policy inference AND the 256<->512 products of learn() on bf16 MFMA (fp32 accumulate, fp32 master weights / Adam / "
-                        "LayerNorm / dynamics); bf16_policy: policy inference only")
+                   help="f32 (default): fp32 everywhere — from 16,384 envs per GPU on, the ACTING kernel forms its fp32 256->512 product as the exact "
+                        "9-term bf16 split on the bf16 matrix cores (engine.x9_rows); f32x9: that format at every size; bf16: policy inference AND the "
+                        "256<->512 products of learn() on bf16 MFMA (fp32 accumulate, fp32 master weights / Adam / LayerNorm / dynamics); bf16_policy: "
+                        "policy inference only.  HIRL / TD3 only: the SAC agents run fp32.  Stored in the snapshot: --resume refuses another value")
     p.add_argument("--synthetic_expert", action="store_true", help="uniform-random stand-in for the expert CSV (throughput runs and tests ONLY)")
     p.add_argument("--load_dir", type=str, default=None, help="--load_model: directory of the checkpoint files (default: this run's model dir)")
     p.add_argument("--load_tag", type=str, default="Agent20_successRate0.64", help="--load_model: checkpoint tag (train_all.py:240 hard-codes this one)")

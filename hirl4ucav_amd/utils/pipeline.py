@@ -58,9 +58,10 @@ class VectorStepPipeline:
         self.stepped.record(self.side)
         self.issued = True
 
-    def prefetch(self, fn, acting_net_untouched):
-        """arm + fire at once: the side stream starts right behind the sampler."""
-        self.arm(fn, acting_net_untouched)
+    def prefetch(self, fn, acting_net_untouched, engine=None):
+        """arm + fire at once: the side stream starts right behind the sampler.  engine: as in arm() — pass the engine whose learn() follows,
+        so that a draw it deferred into that learn() is refused here too (once fired, nothing is armed any more for learn() to notice)."""
+        self.arm(fn, acting_net_untouched, engine=engine)
         self.fire()
 
     def join(self):
