@@ -32,6 +32,7 @@ _lib.register("hx_sac_act_step_f32i", [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_i
 _lib.register("hx_sac_critic_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _i32, _vp])
 _lib.register("hx_sac_critic_grads_sampled", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _P(E.HxSample), _i32, _vp])
 _lib.register("hx_sac_critic_step", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _P(E.HxSample), _i32, _i32, _vp])
+_lib.register("hx_sac_learn", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _P(E.HxSample), _i32, _i32, ctypes.c_float, _vp])
 _lib.register("hx_sac_policy_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _vp])
 _lib.register("hx_sac_adam", [_P(HxSacNets), _P(E.HxHyper), _i32, _i32, _f32, _f32, _vp])
 
@@ -220,6 +221,11 @@ class SacEngine:
         self.learning_steps += 1
         pending, self._pending = getattr(self, "_pending", None), None
         polyak_first = int(self.learning_steps % self.interval == 0)
+        if self.world == 1 and not getattr(self, "separate_critic_adam", False) and not getattr(self, "staged_policy", False):
+            # one GPU: the whole learn() in one call, 11 launches (hx_sac_learn: bit-identical to the staged sequence below, 14 launches)
+            _lib.call("hx_sac_learn", nets, ctypes.byref(batch), hyper, ctypes.byref(pending[0]) if pending is not None else None,
+                      polyak_first, self.learning_steps, self.target_entropy, st)
+            return
         if self.world == 1 and not getattr(self, "separate_critic_adam", False):
             # one GPU: the critics' optimizer steps ride in the weight-gradient launch (bit-identical to the two calls below, one launch less)
             _lib.call("hx_sac_critic_step", nets, ctypes.byref(batch), hyper, ctypes.byref(pending[0]) if pending is not None else None,

@@ -26,9 +26,37 @@ struct GaussArgs {
     uint64_t seed;
     uint32_t row0, call;
 };
-__global__ __launch_bounds__(kThreads) void gauss_head_kernel(GaussArgs A) {
+// One launch serves up to TWO evaluations (policy.sample(s') for the TD target and policy.sample(s) for the policy loss: both read z2 rows of
+// the first forward launch and the policy as it is before this learn()'s steps) and, behind them, the soft_update of the target critics
+// that SacAgent.learn does first on every target_update_interval-th call (agent.py:278-279): nothing reads the targets before the NEXT launch.
+struct GaussLaunch {
+    GaussArgs g[2];
+    int nb0;       // workgroups of g[0]; g[1] follows (rows 0: none)
+    int nb_gauss;  // workgroups of g[0] + g[1]; Polyak blocks follow
+    float* target; const float* source; int n; float tau;  // soft_update (n = 0: none)
+};
+__device__ __forceinline__ void gauss_head_rows(const GaussArgs& A, int block);
+__global__ __launch_bounds__(kThreads) void gauss_head_kernel(GaussLaunch L) {
+    const int b = blockIdx.x;
+    if (b >= L.nb_gauss) {  // target <- (1 - tau) target + tau source, 16 B per lane (the arithmetic of polyak_kernel)
+        const int i = ((b - L.nb_gauss) * kThreads + threadIdx.x) * 4;
+        if (i + 4 <= L.n) {
+            float4 t4 = *reinterpret_cast<const float4*>(L.target + i);
+            const float4 s4 = *reinterpret_cast<const float4*>(L.source + i);
+            t4.x = polyak_update(t4.x, s4.x, L.tau); t4.y = polyak_update(t4.y, s4.y, L.tau);
+            t4.z = polyak_update(t4.z, s4.z, L.tau); t4.w = polyak_update(t4.w, s4.w, L.tau);
+            *reinterpret_cast<float4*>(L.target + i) = t4;
+        } else {
+            for (int c = 0; i + c < L.n; ++c) L.target[i + c] = polyak_update(L.target[i + c], L.source[i + c], L.tau);
+        }
+        return;
+    }
+    if (b < L.nb0) gauss_head_rows(L.g[0], b);
+    else gauss_head_rows(L.g[1], b - L.nb0);
+}
+__device__ __forceinline__ void gauss_head_rows(const GaussArgs& A, int block) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + wave;
+    const int r = block * 4 + wave;
     if (r >= A.rows) return;
     RowReg<H2> xh, y;
     float mean_, rstd_, o[8];
@@ -171,6 +199,16 @@ static SacAux sac_aux(const HxSacNets* N, int B) {
     float* p = N->ws + (size_t)S_COUNT * kSlotFloats * B;
     return SacAux{p, p + 4 * B, p + 5 * B, p + 9 * B};  // [B][4], [B], [B][4], [B][16]
 }
+static void launch_gauss(const GaussArgs& g0, const GaussArgs* g1, float* target, const float* source, int n, float tau, hipStream_t st) {
+    GaussLaunch L{};
+    L.g[0] = g0;
+    L.nb0 = (g0.rows + 3) / 4;
+    L.nb_gauss = L.nb0;
+    if (g1) { L.g[1] = *g1; L.nb_gauss += (g1->rows + 3) / 4; }
+    L.target = target; L.source = source; L.n = n; L.tau = tau;
+    const int nbp = n > 0 ? (n / 4 + kThreads) / kThreads : 0;
+    hipLaunchKernelGGL(gauss_head_kernel, dim3((unsigned)(L.nb_gauss + nbp)), dim3(kThreads), 0, st, L);
+}
 static void sac_slots(const HxSacNets* N, int B, Slot* s) {
     for (int i = 0; i < S_COUNT; ++i) s[i] = carve_slot(N->ws + (size_t)i * kSlotFloats * B, B);
 }
@@ -178,8 +216,10 @@ static void sac_slots(const HxSacNets* N, int B, Slot* s) {
 /* Critic half of SacAgent.learn (SAC/agent.py:278-313): [Polyak of the target critics first when polyak_first], a', H' =
  * policy.sample(s') with eps_next, y = r + (1 - d) gamma (min Q_target(s', a') + alpha H'), q1_loss / q2_loss -> losses[0..1],
  * grad_critic.  Also evaluates policy(s) for the policy half.  Follow with hx_sac_adam(which = 0). */
+// one_call (hx_sac_learn): the Polyak step rides behind the Gaussian heads' workgroups instead of in a launch of its own, and policy.sample(s)
+// of the policy half is evaluated beside policy.sample(s') — the same arithmetic on the same values, two launches less
 static int sac_critic_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t polyak_first, void* stream,
-                                 int adam_step = 0) {
+                                 int adam_step = 0, bool one_call = false) {
     HX_REQUIRE(N && Bt && Hy && Bt->rows && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_sac_critic_grads: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int B = Bt->batch;
@@ -194,7 +234,7 @@ static int sac_critic_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const
     const SacAux X = sac_aux(N, B);
     const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
     const int nq = 2 * kQs.padded();
-    if (polyak_first)  // soft_update(critic_target, critic) BEFORE the update, agent.py:278-279
+    if (polyak_first && !one_call)  // soft_update(critic_target, critic) BEFORE the update, agent.py:278-279
         launch_polyak(N->target_critic, N->critic, nq, Hy->tau, nullptr, nullptr, 0, st);
     const float* q1 = N->critic; const float* q2 = N->critic + kQs.padded();
     const float* t1 = N->target_critic; const float* t2 = N->target_critic + kQs.padded();
@@ -210,8 +250,13 @@ static int sac_critic_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const
         launch_fwd(F, st);
     }
     {   // a', H' = policy.sample(s')
-        GaussArgs G{N->policy, kPolicy, s[SS_PN].z2, Bt->eps_next, B, Bt->eps_next ? 1 : 2, X.act_n, X.ent_n, nullptr, Bt->seed, 0x40000000u, Bt->call};
-        hipLaunchKernelGGL(gauss_head_kernel, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, st, G);
+        const GaussArgs G{N->policy, kPolicy, s[SS_PN].z2, Bt->eps_next, B, Bt->eps_next ? 1 : 2, X.act_n, X.ent_n, nullptr, Bt->seed, 0x40000000u, Bt->call};
+        if (one_call) {
+            const GaussArgs G2{N->policy, kPolicy, s[SS_PC].z2, Bt->eps_cur, B, Bt->eps_cur ? 1 : 2, X.act_c, nullptr, X.aux_c, Bt->seed, 0x80000000u, Bt->call};
+            launch_gauss(G, &G2, N->target_critic, N->critic, polyak_first ? nq : 0, Hy->tau, st);
+        } else {
+            launch_gauss(G, nullptr, nullptr, nullptr, 0, 0.0f, st);
+        }
     }
     {   // target Q1/Q2 (s', a')
         FwdArgs F{};
@@ -279,7 +324,9 @@ int hx_sac_critic_step(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* 
     HX_REQUIRE(step >= 1, "hx_sac_critic_step: step is 1-based");
     return sac_critic_grads_impl(N, Bt, Hy, S, polyak_first, stream, step);
 }
-int hx_sac_policy_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, void* stream) {
+// adam_step > 0 (hx_sac_learn): policy.sample(s) was evaluated in the critic half's launch, and policy_optim.step() + the log-alpha step ride in
+// the policy's weight-gradient launch (the thread that produced a gradient steps it; thread 0 of the launch steps log_alpha)
+static int sac_policy_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, void* stream, int adam_step, float target_entropy) {
     HX_REQUIRE(N && Bt && Hy && Bt->rows && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_sac_policy_grads: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int B = Bt->batch;
@@ -288,9 +335,9 @@ int hx_sac_policy_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
     const SacAux X = sac_aux(N, B);
     const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
     const float* q1 = N->critic; const float* q2 = N->critic + kQs.padded();
-    {
-        GaussArgs G{N->policy, kPolicy, s[SS_PC].z2, Bt->eps_cur, B, Bt->eps_cur ? 1 : 2, X.act_c, nullptr, X.aux_c, Bt->seed, 0x80000000u, Bt->call};
-        hipLaunchKernelGGL(gauss_head_kernel, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, st, G);
+    if (adam_step == 0) {
+        const GaussArgs G{N->policy, kPolicy, s[SS_PC].z2, Bt->eps_cur, B, Bt->eps_cur ? 1 : 2, X.act_c, nullptr, X.aux_c, Bt->seed, 0x80000000u, Bt->call};
+        launch_gauss(G, nullptr, nullptr, nullptr, 0, 0.0f, st);
     }
     {
         FwdArgs F{};
@@ -331,10 +378,36 @@ int hx_sac_policy_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper*
         WgJob& J = W.job[0];
         J = WgJob{};
         J.net = N->policy; J.grad = N->grad_policy; J.m = kPolicy; J.ws[0] = s[SS_PC]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
-        launch_wg(W, false, st);
+        if (adam_step > 0) {
+            const double b1 = 0.9, b2 = 0.999;
+            const double bc1 = 1.0 - pow(b1, adam_step), bc2 = 1.0 - pow(b2, adam_step);
+            J.p = N->policy; J.mom = N->m_policy; J.var = N->v_policy;
+            J.w2f = N->policy_w2_f32i;  // the acting kernel's image of the policy's W2 follows its optimizer step
+            W.ad = WgAdam{};
+            W.ad.b1 = (float)b1; W.ad.b2 = (float)b2; W.ad.eps = 1e-8f;
+            W.ad.step_size = (float)(Hy->lr_actor / bc1);
+            W.ad.bc2_sqrt = (float)sqrt(bc2);
+            W.ad.losses = N->losses;
+            W.ad.alpha_state = N->alpha_state; W.ad.target_entropy = target_entropy; W.ad.alpha_step_size = (float)(Hy->lr_actor / bc1);
+            launch_wg(W, true, st);
+        } else {
+            launch_wg(W, false, st);
+        }
     }
     HX_CHECK_LAUNCH("hx_sac_policy_grads");
     return 0;
+}
+int hx_sac_policy_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, void* stream) {
+    return sac_policy_grads_impl(N, Bt, Hy, stream, 0, 0.0f);
+}
+/* One GPU: the whole SacAgent.learn (SAC/agent.py:276-327) in ONE call and 11 launches (the staged sequence takes 14): the Polyak step and
+ * policy.sample(s) ride in the launch of policy.sample(s'), both optimizers' steps (and the log-alpha step) in their weight-gradient launches.
+ * Bit-identical to hx_sac_critic_step + hx_sac_policy_grads + hx_sac_adam(which = 1).  sample may be NULL; step is 1-based. */
+int hx_sac_learn(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t polyak_first, int32_t step, float target_entropy,
+                 void* stream) {
+    HX_REQUIRE(step >= 1, "hx_sac_learn: step is 1-based");
+    if (int rc = sac_critic_grads_impl(N, Bt, Hy, S, polyak_first, stream, step, true)) return rc;
+    return sac_policy_grads_impl(N, Bt, Hy, stream, step, target_entropy);
 }
 
 }  // extern "C"

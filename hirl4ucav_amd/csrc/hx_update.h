@@ -520,6 +520,9 @@ struct WgAdam {
     int finish_actor, use_bc;  // thread 0 of the launch finishes actor_loss / bc_weight (HIRL.py:321,334)
     float* losses;
     float* wstate;
+    // SAC policy step: thread 0 of the launch also steps log_alpha (SAC/agent.py:322-325, 408-414) with the mean entropy in losses[4]
+    float* alpha_state;  // [4]: log_alpha, m, v, alpha; nullptr = not a SAC policy step
+    float target_entropy, alpha_step_size;
 };
 struct WgArgs {
     WgJob job[2];

@@ -17,7 +17,8 @@ struct WgJobC {
     const float* net; float* grad;
     float* ws0; float* ws1;
     float* mom; float* var; float* target; uint16_t* w2b; float* w2f;
-    uint32_t cfg;  // m:10 | nslots:2 | wmode0:2 | wmode1:2 | w_kind:2 | adam.finish_actor:1 | adam.use_bc:1 | w2b_x9:1
+    uint32_t cfg;  // m:10 | nslots:2 | wmode0:2 | wmode1:2 | w_kind:2 | adam.finish_actor:1 | adam.use_bc:1 | w2b_x9:1 | sac_alpha:1
+                   // (sac_alpha: a SAC policy step — wstate holds alpha_state, w_given the target entropy, warm the log-alpha step size)
     int32_t rows0, rows1;
     float slope, w_given, warm, inv_batch;
     float b1, b2, eps, step_size, bc2_sqrt, tau;
@@ -100,17 +101,24 @@ __device__ __forceinline__ void expand_wg(const WgJobC& c, WgJob& J, WgArgs& A) 
     A.ad.finish_actor = (int)((c.cfg >> 18) & 1u); A.ad.use_bc = (int)((c.cfg >> 19) & 1u);
     A.ad.losses = c.losses; A.ad.wstate = c.wstate;
     A.count_out = c.count_out;
+    A.ad.alpha_state = nullptr; A.ad.target_entropy = 0.0f; A.ad.alpha_step_size = 0.0f;
+    if ((c.cfg >> 21) & 1u) {  // the three fields a SAC policy step does not use otherwise carry its log-alpha step
+        A.ad.alpha_state = c.wstate; A.ad.target_entropy = c.w_given; A.ad.alpha_step_size = c.warm;
+        A.ad.wstate = nullptr; A.wstate = nullptr; A.w_given = 0.0f; A.warm = 0.0f;
+    }
 }
 inline WgJobC pack_wg(const WgJob& J, const WgArgs& A) {
     WgJobC c{};
     c.net = J.net; c.grad = J.grad; c.ws0 = J.ws[0].x; c.ws1 = J.nslots > 1 ? J.ws[1].x : J.ws[0].x;
     c.mom = J.mom; c.var = J.var; c.target = J.target; c.w2b = J.w2b; c.w2f = J.w2f; c.w2tb = J.w2tb; c.tgt_w2b = J.tgt_w2b;
     c.cfg = mlp_bits(J.m) | ((uint32_t)J.nslots << 10) | ((uint32_t)J.wmode[0] << 12) | ((uint32_t)J.wmode[1] << 14) | ((uint32_t)A.w_kind << 16) |
-            ((uint32_t)(A.ad.finish_actor ? 1 : 0) << 18) | ((uint32_t)(A.ad.use_bc ? 1 : 0) << 19) | ((uint32_t)(J.w2b_x9 ? 1 : 0) << 20);
+            ((uint32_t)(A.ad.finish_actor ? 1 : 0) << 18) | ((uint32_t)(A.ad.use_bc ? 1 : 0) << 19) | ((uint32_t)(J.w2b_x9 ? 1 : 0) << 20) |
+            ((uint32_t)(A.ad.alpha_state ? 1 : 0) << 21);
     c.rows0 = J.rows[0]; c.rows1 = J.nslots > 1 ? J.rows[1] : J.rows[0];
     c.slope = A.slope; c.w_given = A.w_given; c.warm = A.warm; c.inv_batch = A.inv_batch;
     c.b1 = A.ad.b1; c.b2 = A.ad.b2; c.eps = A.ad.eps; c.step_size = A.ad.step_size; c.bc2_sqrt = A.ad.bc2_sqrt; c.tau = A.ad.tau;
     c.soft_count = A.soft_count; c.wstate = const_cast<float*>(A.wstate); c.losses = A.ad.losses; c.count_out = A.count_out;
+    if (A.ad.alpha_state) { c.wstate = A.ad.alpha_state; c.w_given = A.ad.target_entropy; c.warm = A.ad.alpha_step_size; }
     return c;
 }
 
@@ -150,6 +158,15 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         } else {
             A.ad.losses[1] = A.ad.losses[3];  // TD3.py:236
         }
+    }
+    if (ADAM && A.ad.alpha_state && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {  // what adam_kernel's thread 0 does on a SAC policy step
+        const float mean_h = A.ad.losses[4];
+        float la = A.ad.alpha_state[0], m = A.ad.alpha_state[1], v = A.ad.alpha_state[2];
+        A.ad.losses[3] = -(la * (A.ad.target_entropy - mean_h));  // entropy_loss with the log_alpha BEFORE its step
+        adam_update(la, m, v, mean_h - A.ad.target_entropy, A.ad.b1, A.ad.b2, A.ad.eps, A.ad.alpha_step_size, A.ad.bc2_sqrt);
+        A.ad.alpha_state[0] = la; A.ad.alpha_state[1] = m; A.ad.alpha_state[2] = v;
+        A.ad.alpha_state[3] = expf(la);  // self.alpha = self.log_alpha.exp()
+        A.ad.losses[5] = A.ad.alpha_state[3];
     }
 
     if (b < kWgTilesPerBlock) {

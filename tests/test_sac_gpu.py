@@ -153,6 +153,35 @@ def test_sac_deferred_draw_is_bit_identical_to_the_sampling_launch(SE, esac):
 
 
 @pytest.mark.parametrize("defer", [False, True])
+def test_sac_learn_in_one_call_is_bit_identical_to_the_staged_sequence(SE, defer):
+    """hx_sac_learn (one GPU, 11 launches: the soft_update and policy.sample(s) in the launch of policy.sample(s'), q1 / q2 / policy optimizer
+    steps and the log-alpha step inside their weight-gradient launches) against BOTH staged sequences — hx_sac_critic_step +
+    hx_sac_policy_grads + hx_sac_adam(1) and the fully separate hx_sac_critic_grads[_sampled] + hx_sac_adam(0) + ... (14 launches): after 7
+    calls (two of them with the Polyak step of the targets first) the same networks, moments, targets, alpha and W2 image, bit for bit."""
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    params = sac_params()
+    rng = np.random.default_rng(5)
+    rep = DeviceReplay(4096)
+    rep.ring.copy_(torch.from_numpy(rng.normal(size=(4096, 32)).astype(np.float32)))
+    rep.ring[:, 31] = (rep.ring[:, 31] > 1.0).float()
+    rep.total += 4096
+    a, b, c = (SE.SacEngine(batch=128) for _ in range(3))
+    b.staged_policy = True          # hx_sac_critic_step + hx_sac_policy_grads + hx_sac_adam(1)
+    c.separate_critic_adam = True   # every stage a call of its own
+    for e in (a, b, c):
+        e.load_params(params["policy"], params["q1"], params["q2"])
+    for k in range(7):
+        for e in (a, b, c):
+            e.sample(rep, None, seed=11, defer=defer)
+            e.learn()
+    for other in (b, c):
+        for name in ("policy", "critic", "target_critic", "m_policy", "v_policy", "m_critic", "v_critic", "alpha_state", "w2_f32i"):
+            assert torch.equal(getattr(a, name), getattr(other, name)), name
+        np.testing.assert_allclose(a.losses.cpu().numpy(), other.losses.cpu().numpy(), rtol=1e-6)  # (atomic accumulation order)
+
+
+@pytest.mark.parametrize("defer", [False, True])
 def test_sac_critic_step_in_the_wgrad_launch_is_bit_identical(SE, defer):
     """hx_sac_critic_step (one GPU: q1_optim / q2_optim step inside the weight-gradient launch) against hx_sac_critic_grads[_sampled] +
     hx_sac_adam(0): after 6 calls (two of them with the Polyak step of the targets first) the same networks, moments, targets and alpha."""
@@ -165,6 +194,7 @@ def test_sac_critic_step_in_the_wgrad_launch_is_bit_identical(SE, defer):
     rep.ring[:, 31] = (rep.ring[:, 31] > 1.0).float()
     rep.total += 4096
     a, b = (SE.SacEngine(batch=128) for _ in range(2))
+    a.staged_policy = True
     b.separate_critic_adam = True
     for e in (a, b):
         e.load_params(params["policy"], params["q1"], params["q2"])
