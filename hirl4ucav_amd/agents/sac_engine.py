@@ -16,7 +16,7 @@ _P = ctypes.POINTER
 
 class HxSacNets(ctypes.Structure):
     _fields_ = [(k, _vp) for k in ("policy", "critic", "target_critic", "grad_policy", "grad_critic", "m_policy", "v_policy", "m_critic",
-                                   "v_critic", "losses", "alpha_state", "ws", "policy_w2_f32i")]
+                                   "v_critic", "losses", "alpha_state", "ws", "policy_w2_f32i", "policy_w2_x9")]
 
 
 class HxSacBatch(ctypes.Structure):
@@ -29,6 +29,9 @@ _lib.register("hx_sac_act_step", [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp,
 _lib.register("hx_sac_act_f32i", [_vp, _vp, _vp, ctypes.c_int64, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp])
 _lib.register("hx_sac_act_step_f32i", [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32,
                                         ctypes.c_uint32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
+_lib.register("hx_sac_act_x9", [_vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp])
+_lib.register("hx_sac_act_step_x9", [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32,
+                                      ctypes.c_uint32, _vp, _vp, _vp, _P(_lib.HxStepOpts), _vp])
 _lib.register("hx_sac_critic_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _i32, _vp])
 _lib.register("hx_sac_critic_grads_sampled", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _P(E.HxSample), _i32, _vp])
 _lib.register("hx_sac_critic_step", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _P(E.HxSample), _i32, _i32, _vp])
@@ -101,10 +104,16 @@ class SacEngine:
         self.alpha_state[3] = 1.0  # log_alpha = 0 -> alpha = 1  (agent.py:106-107)
         self.nets = HxSacNets(*(t.data_ptr() for t in (self.policy, self.critic, self.target_critic, self.grad_policy, self.grad_critic,
                                                         self.m_policy, self.v_policy, self.m_critic, self.v_critic, self.losses,
-                                                        self.alpha_state, self.ws)), None)
+                                                        self.alpha_state, self.ws)), None, None)
+        for i, cls in ((5, HxSacNets), (6, HxSacBatch), (0, _lib.HxStepOpts), (2, E.HxHyper), (4, E.HxSample)):
+            _lib.check_struct(i, cls)  # this binding's structs against the loaded library's (hx_abi_sizes)
         # fp32 image of the policy's W2 in the acting kernel's operand order (hx_pack_w2_f32i): kept current by hx_sac_adam(which = 1)
         self.w2_f32i = torch.zeros(512 * 256, dtype=torch.float32, device=self.device)
         self.nets.policy_w2_f32i = self.w2_f32i.data_ptr()
+        # From this many rows on the policy's fp32 256 -> 512 product runs as the exact 9-term bf16 split on the bf16 matrix cores
+        # (hx_sac_act*_x9: every partial product exact, fp32 accumulation; 34 against 45 us at 16,384 rows, tools/ubench/actp_time.py);
+        # None: fp32 MFMA at every size.  The hi | mid | lo images are built at the first such call, the policy's optimizer step keeps them current.
+        self.x9_rows, self.w2_x9 = 16384, None
         self.hyper = E.HxHyper(gamma, tau, lr, lr, 0.0, 0.5, 0.0, 0)
         self.target_entropy, self.interval = float(target_entropy), int(target_update_interval)
         self.learning_steps = 0
@@ -124,6 +133,17 @@ class SacEngine:
         """Rebuild the acting kernel's image of the policy's W2 (after load_params / a checkpoint restore or any direct write to
         `self.policy`; the policy's Adam step maintains it otherwise)."""
         _lib.call("hx_pack_w2_f32i", self.policy.data_ptr(), 13, self.w2_f32i.data_ptr(), _lib.stream_ptr())
+        if self.w2_x9 is not None:
+            _lib.call("hx_pack_w2_x9", self.policy.data_ptr(), 13, self.w2_x9.data_ptr(), _lib.stream_ptr())
+
+    def _x9_for(self, n):
+        if self.x9_rows is None or n < self.x9_rows:
+            return False
+        if self.w2_x9 is None:  # first large call: build the images; nets.policy_w2_x9 makes every later policy step refresh them
+            self.w2_x9 = torch.zeros(3 * H2 * H1, dtype=torch.bfloat16, device=self.device)
+            self.nets.policy_w2_x9 = self.w2_x9.data_ptr()
+            _lib.call("hx_pack_w2_x9", self.policy.data_ptr(), 13, self.w2_x9.data_ptr(), _lib.stream_ptr())
+        return True
 
     refresh_bf16 = refresh_images  # (the name utils/checkpoint.py calls after a restore)
 
@@ -164,6 +184,10 @@ class SacEngine:
             out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         mode = 0 if not explore else (1 if eps is not None else 2)
         self.act_calls += 1
+        if self._x9_for(n):
+            _lib.call("hx_sac_act_x9", self.policy.data_ptr(), self.w2_x9.data_ptr(), self.w2_f32i.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode,
+                      _lib.ptr(eps), int(seed), int(row0), self.act_calls, _lib.stream_ptr())
+            return out
         _lib.call("hx_sac_act_f32i", self.policy.data_ptr(), self.w2_f32i.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode, _lib.ptr(eps),
                   int(seed), int(row0), self.act_calls, _lib.stream_ptr())
         return out
@@ -176,6 +200,11 @@ class SacEngine:
             out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         mode = 0 if not explore else (1 if eps is not None else 2)
         self.act_calls += 1
+        if self._x9_for(n):
+            _lib.call("hx_sac_act_step_x9", self.policy.data_ptr(), self.w2_x9.data_ptr(), self.w2_f32i.data_ptr(), env.state.data_ptr(), n, env.pitch,
+                      env.obs.data_ptr(), out.data_ptr(), mode, _lib.ptr(eps), int(seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(),
+                      env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())
+            return out, env.obs, env.reward, env.done, env.success
         _lib.call("hx_sac_act_step_f32i", self.policy.data_ptr(), self.w2_f32i.data_ptr(), env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(),
                   out.data_ptr(), mode, _lib.ptr(eps), int(seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(), env.done.data_ptr(),
                   env.success.data_ptr(), ctypes.byref(env._opts), _lib.stream_ptr())

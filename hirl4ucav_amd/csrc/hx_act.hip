@@ -764,10 +764,11 @@ int hx_actor_act_step_f32i(const float* actor, const float* w2_f32i, float* stat
 /* SacAgent.explore / exploit (SAC/agent.py:183-196) for `rows` observations.  mode 0: exploit = tanh(mean); 1: sample with the
  * standard-normal draws eps[rows][4]; 2: sample with Philox(seed; row0 + row, call).  ws: unused since the whole policy runs in one kernel (may be NULL). */
 static int sac_act_impl(const float* policy, const float* w2f, const float* obs, int64_t rows, float* actions, int32_t mode, const float* eps,
-                        uint64_t seed, uint32_t row0, uint32_t call, void* stream) {
+                        uint64_t seed, uint32_t row0, uint32_t call, void* stream, const uint16_t* w2x = nullptr) {
     HX_REQUIRE(policy && obs && actions && rows > 0 && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act: bad arguments");
+    const bool x9 = w2x && rows > kFuseEnvMax && persist_enabled();  // the exact split exists for the Gaussian head in the persistent kernel only
     ActFusedArgs H{policy, kPolicy, const_cast<float*>(obs), (int)rows, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
-                   nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0, nullptr, w2f};
+                   nullptr, 0, nullptr, nullptr, nullptr, HxStepOpts{}, 0.0, x9 ? w2x : nullptr, x9 ? nullptr : w2f, x9 ? 1 : 0};
     launch_act<true>(H, (hipStream_t)stream);
     HX_CHECK_LAUNCH("hx_sac_act");
     return 0;
@@ -786,18 +787,19 @@ int hx_sac_act_f32i(const float* policy, const float* w2_f32i, const float* obs,
 /* SacAgent.explore / exploit + HarfangEnv.step in one launch (train_sac.py:238-241): hx_sac_act, then hx_env_step in the kernel's tail. */
 static int sac_act_step_impl(const float* policy, const float* w2f, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t mode,
                              const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,
-                             const HxStepOpts* opts, void* stream) {
+                             const HxStepOpts* opts, void* stream, const uint16_t* w2x = nullptr) {
     HX_REQUIRE(policy && mode >= 0 && mode <= 2 && (mode != 1 || eps), "hx_sac_act_step: bad arguments");
     const HxStepOpts o = opts ? *opts : HxStepOpts{};
     if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_sac_act_step")) return rc;
+    const bool x9 = w2x && n > kFuseEnvMax && persist_enabled();
     ActFusedArgs H{policy, kPolicy, obs_io, (int)n, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
-                   state, stride, reward, done, success, o, o.cap > 0 ? 1.0 / (double)o.cap : 0.0, nullptr, w2f};
+                   state, stride, reward, done, success, o, o.cap > 0 ? 1.0 / (double)o.cap : 0.0, x9 ? w2x : nullptr, x9 ? nullptr : w2f, x9 ? 1 : 0};
     if (n > kFuseEnvMax) {
         if (persist_enabled() && launch_act_persist(H, true, (hipStream_t)stream)) {
             HX_CHECK_LAUNCH("hx_sac_act_step");
             return 0;
         }
-        if (int rc = sac_act_impl(policy, w2f, obs_io, n, actions, mode, eps, seed, row0, call, stream)) return rc;
+        if (int rc = sac_act_impl(policy, w2f, obs_io, n, actions, mode, eps, seed, row0, call, stream, w2x)) return rc;
         return hx_env_step(state, n, stride, actions, obs_io, reward, done, success, opts, stream);
     }
     launch_act<true>(H, (hipStream_t)stream);
@@ -814,6 +816,20 @@ int hx_sac_act_step_f32i(const float* policy, const float* w2_f32i, float* state
                          int8_t* success, const HxStepOpts* opts, void* stream) {
     HX_REQUIRE(w2_f32i && (reinterpret_cast<uintptr_t>(w2_f32i) & 15u) == 0, "hx_sac_act_step_f32i: w2_f32i must be a 16-byte aligned fp32 image of W2");
     return sac_act_step_impl(policy, w2_f32i, state, n, stride, obs_io, actions, mode, eps, seed, row0, call, reward, done, success, opts, stream);
+}
+
+int hx_sac_act_x9(const float* policy, const uint16_t* w2_x9, const float* w2_f32i, const float* obs, int64_t rows, float* actions, int32_t mode,
+                  const float* eps, uint64_t seed, uint32_t row0, uint32_t call, void* stream) {
+    HX_REQUIRE(w2_x9 && w2_f32i && (reinterpret_cast<uintptr_t>(w2_x9) & 15u) == 0 && (reinterpret_cast<uintptr_t>(w2_f32i) & 15u) == 0,
+               "hx_sac_act_x9: w2_x9 (hi | mid | lo images) and w2_f32i (the fallback up to 8,192 rows) must be 16-byte aligned images of W2");
+    return sac_act_impl(policy, w2_f32i, obs, rows, actions, mode, eps, seed, row0, call, stream, w2_x9);
+}
+int hx_sac_act_step_x9(const float* policy, const uint16_t* w2_x9, const float* w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io,
+                       float* actions, int32_t mode, const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done,
+                       int8_t* success, const HxStepOpts* opts, void* stream) {
+    HX_REQUIRE(w2_x9 && w2_f32i && (reinterpret_cast<uintptr_t>(w2_x9) & 15u) == 0 && (reinterpret_cast<uintptr_t>(w2_f32i) & 15u) == 0,
+               "hx_sac_act_step_x9: w2_x9 (hi | mid | lo images) and w2_f32i (the fallback up to 8,192 rows) must be 16-byte aligned images of W2");
+    return sac_act_step_impl(policy, w2_f32i, state, n, stride, obs_io, actions, mode, eps, seed, row0, call, reward, done, success, opts, stream, w2_x9);
 }
 
 }  // extern "C"

@@ -555,7 +555,7 @@ bool launch_act_persist(const ActFusedArgs& H, bool gauss, hipStream_t st) {
         }
         return true;
     }
-    const bool x9 = !gauss && H.w2b && H.x9;
+    const bool x9 = H.w2b && H.x9;
     if (x9 || H.w2f) {  // fp32 from an image: 64 rows per pass
         constexpr int TR = 64;
         const int ntiles = (H.rows + TR - 1) / TR;
@@ -563,7 +563,8 @@ bool launch_act_persist(const ActFusedArgs& H, bool gauss, hipStream_t st) {
         const dim3 grid((unsigned)((ntiles + per - 1) / per));
 #define HX_STREAM(MODE, G, R) \
         { if (env) launch_k(act_persist_stream_kernel<MODE, G, true, R>, grid, H, per, st); else launch_k(act_persist_stream_kernel<MODE, G, false, R>, grid, H, per, st); }
-        if (x9) { if (relu) HX_STREAM(1, false, true) else HX_STREAM(1, false, false) }
+        if (x9 && gauss) HX_STREAM(1, true, true)
+        else if (x9) { if (relu) HX_STREAM(1, false, true) else HX_STREAM(1, false, false) }
         else if (gauss) HX_STREAM(0, true, true)
         else if (relu) HX_STREAM(0, false, true)
         else HX_STREAM(0, false, false)

@@ -382,7 +382,8 @@ static int sac_policy_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const
             const double b1 = 0.9, b2 = 0.999;
             const double bc1 = 1.0 - pow(b1, adam_step), bc2 = 1.0 - pow(b2, adam_step);
             J.p = N->policy; J.mom = N->m_policy; J.var = N->v_policy;
-            J.w2f = N->policy_w2_f32i;  // the acting kernel's image of the policy's W2 follows its optimizer step
+            J.w2f = N->policy_w2_f32i;  // the acting kernels' images of the policy's W2 follow its optimizer step
+            if (N->policy_w2_x9) { J.w2b = N->policy_w2_x9; J.w2b_x9 = 1; }
             W.ad = WgAdam{};
             W.ad.b1 = (float)b1; W.ad.b2 = (float)b2; W.ad.eps = 1e-8f;
             W.ad.step_size = (float)(Hy->lr_actor / bc1);

@@ -819,6 +819,11 @@ int hx_sac_adam(const HxSacNets* N, const HxHyper* Hy, int32_t which, int32_t st
         A.w2f = N->policy_w2_f32i;
         A.w2_lo = kPolicy.W2();
     }
+    if (which == 1 && N->policy_w2_x9) {  // ... and the hi | mid | lo images of the large-population format
+        A.w2b = N->policy_w2_x9;
+        A.w2b_x9 = 1;
+        A.w2_lo = kPolicy.W2();
+    }
     if (which == 1) {
         A.alpha_state = N->alpha_state;
         A.target_entropy = target_entropy;

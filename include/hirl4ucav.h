@@ -354,6 +354,8 @@ typedef struct HxSacNets {
     float* ws;          /* hx_sac_workspace_floats(batch) */
     float* policy_w2_f32i; /* NULL, or the fp32 image of the policy's W2 (hx_pack_w2_f32i(policy, 13, ...)): hx_sac_adam(which = 1) keeps it
                               current, hx_sac_act*_f32i read it */
+    uint16_t* policy_w2_x9; /* NULL, or the hi | mid | lo bf16 images of the policy's W2 (hx_pack_w2_x9(policy, 13, ...), 3 x 512 x 256): the
+                               policy's optimizer step keeps them current, hx_sac_act*_x9 read them */
 } HxSacNets;
 
 typedef struct HxSacBatch {
@@ -378,6 +380,14 @@ int hx_sac_act_step_f32i(const float* policy, const float* w2_f32i, float* state
                          int32_t mode, const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done,
                          int8_t* success, const HxStepOpts* opts /* host, may be NULL */, void* stream);
 /* SacAgent.explore / exploit + HarfangEnv.step in one launch (train_sac.py:238-241). */
+/* The same from the exact 9-term bf16 split of the 256 -> 512 product (hx_actor_act_x9's format; w2_x9 = hx_pack_w2_x9(policy, 13, ...)):
+ * the large-population format of the fp32 policy — beyond 8,192 rows the persistent kernel streams the three images; up to 8,192 rows these
+ * entry points fall back to the fp32 image, which must then be given as well (w2_f32i). */
+int hx_sac_act_x9(const float* policy, const uint16_t* w2_x9, const float* w2_f32i, const float* obs, int64_t rows, float* actions, int32_t mode,
+                  const float* eps, uint64_t seed, uint32_t row0, uint32_t call, void* stream);
+int hx_sac_act_step_x9(const float* policy, const uint16_t* w2_x9, const float* w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io,
+                       float* actions, int32_t mode, const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done,
+                       int8_t* success, const HxStepOpts* opts, void* stream);
 int hx_sac_act_step(const float* policy, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t mode,
                     const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,
                     const HxStepOpts* opts /* host, may be NULL */, void* stream);

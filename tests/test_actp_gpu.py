@@ -181,6 +181,7 @@ def test_persistent_sac_policy_equals_the_per_tile_kernel(mods, n):
     p = sac_params()
     e = SE.SacEngine(batch=128)
     e.load_params(p["policy"], p["q1"], p["q2"])
+    e.x9_rows = None  # the fp32-MFMA kernels at every size (the engine's default takes the exact split from 16,384 rows on: next test)
     rng = np.random.default_rng(n)
     obs = torch.from_numpy(rng.uniform(-1, 1, (n, 13)).astype(np.float32)).cuda()
     eps = torch.from_numpy(rng.normal(0, 1, (n, 4)).astype(np.float32)).cuda()
@@ -213,3 +214,57 @@ def test_persistent_sac_policy_equals_the_per_tile_kernel(mods, n):
                      env.reward.cpu().numpy().view(np.uint32), rows[np.lexsort(rows.T[::-1])], np.asarray(list(env.stats_dict().values()))))
     for x, y in zip(*outs):
         np.testing.assert_array_equal(x, y)
+
+
+def test_sac_policy_exact_split_format_at_large_populations(mods):
+    """SacEngine's default from 16,384 rows on: the policy's fp32 256 -> 512 product as the exact 9-term bf16 split (hx_sac_act*_x9, the persistent
+    kernel's Gaussian-head instantiation).  Against the fp32-MFMA kernel: the same action within 2e-6 (exact products, another summation order;
+    the parity bar against the reference is 1e-5); act + env step in one launch == two launches bit for bit; and the hi | mid | lo images
+    follow the policy's optimizer step (hx_sac_learn) exactly: hi + mid + lo == W2."""
+    E, Env, Replay = mods
+    from hirl4ucav_amd.agents import sac_engine as SE
+    from tests.test_oracle_sac import sac_params
+
+    p = sac_params()
+    n = 16384
+    e, f = SE.SacEngine(batch=128), SE.SacEngine(batch=128)
+    f.x9_rows = None
+    for x in (e, f):
+        x.load_params(p["policy"], p["q1"], p["q2"])
+    rng = np.random.default_rng(3)
+    obs = torch.from_numpy(rng.uniform(-1, 1, (n, 13)).astype(np.float32)).cuda()
+    for kw in (dict(explore=False), dict(seed=5, row0=9)):
+        e.act_calls = f.act_calls = 3
+        d = (e.act(obs, **kw) - f.act(obs, **kw)).abs().max()
+        assert e.w2_x9 is not None and float(d) < 2e-6, float(d)
+    outs = []
+    for fused in (True, False):
+        e.act_calls = 0
+        rep = Replay(1 << 20, "cuda")
+        env = Env(n, scenario="serpentine", seed=5, max_step=9, auto_reset=True, random_reset=True, env_id0=40, replay=rep)
+        env.reset()
+        acts = torch.zeros((n, 4), device="cuda")
+        for t in range(12):
+            if fused:
+                e.act_step(env, seed=11, out=acts)
+            else:
+                e.act(env.obs, seed=11, row0=env.env_id0, out=acts)
+                env.step(acts)
+        torch.cuda.synchronize()
+        rows = rep.ring[:int(rep.total.item())].cpu().numpy().view(np.uint32)
+        outs.append((acts.cpu().numpy().view(np.uint32), env.state.cpu().numpy().view(np.uint32), env.obs.cpu().numpy().view(np.uint32),
+                     rows[np.lexsort(rows.T[::-1])]))
+    for x, y in zip(*outs):
+        np.testing.assert_array_equal(x, y)
+    # the images after optimizer steps
+    rep = Replay(4096, "cuda")
+    rep.ring.copy_(torch.from_numpy(rng.normal(size=(4096, 32)).astype(np.float32)))
+    rep.ring[:, 31] = (rep.ring[:, 31] > 1.0).float()
+    rep.total += 4096
+    for k in range(3):
+        e.sample(rep, None, seed=11, defer=True)
+        e.learn()
+    torch.cuda.synchronize()
+    w2 = SE.unpack_mlp(e.policy, SE.POLICY_BLOCK, 13, 8)["2.weight"].double().cpu().numpy()
+    img = e.w2_x9.view(3, -1).float().cpu().numpy().astype(np.float64)
+    np.testing.assert_array_equal(np.sort(img.sum(0)), np.sort(w2.reshape(-1)))  # (sorted: the image order is the kernels' own)

@@ -218,6 +218,7 @@ def test_sac_image_path_is_bit_identical_and_follows_adam(SE, n):
     params = sac_params()
     e = SE.SacEngine(batch=128)
     e.load_params(params["policy"], params["q1"], params["q2"])
+    e.x9_rows = None  # the fp32 image at every size (from 16,384 rows on the engine's default is the exact 9-term split: tests/test_actp_gpu.py)
     rng = np.random.default_rng(n)
     obs = torch.from_numpy(rng.uniform(-1, 1, (n, 13)).astype(np.float32)).cuda()
     rep = DeviceReplay(4096)
