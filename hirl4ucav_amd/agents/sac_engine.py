@@ -251,7 +251,7 @@ class SacEngine:
         pending, self._pending = getattr(self, "_pending", None), None
         polyak_first = int(self.learning_steps % self.interval == 0)
         if self.world == 1 and not getattr(self, "separate_critic_adam", False) and not getattr(self, "staged_policy", False):
-            # one GPU: the whole learn() in one call, 11 launches (hx_sac_learn: bit-identical to the staged sequence below, 14 launches)
+            # one GPU: the whole learn() in one call, 9 launches (hx_sac_learn: bit-identical to the staged sequence below, 14 launches)
             _lib.call("hx_sac_learn", nets, ctypes.byref(batch), hyper, ctypes.byref(pending[0]) if pending is not None else None,
                       polyak_first, self.learning_steps, self.target_entropy, st)
             return

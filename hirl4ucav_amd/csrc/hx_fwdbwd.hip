@@ -361,7 +361,7 @@ struct BwdArgsC {
 inline BwdJobC pack_bwd(const BwdJob& J, const BwdArgs& A) {
     BwdJobC c{};
     c.net = J.net; c.ws = J.ws.x;
-    const Head& h1 = J.mode == BM_CRITIC_TD ? J.t1 : (J.mode == BM_CRITIC_PI ? J.soft : J.crit);
+    const Head& h1 = (J.mode == BM_CRITIC_TD || J.mode == BM_SAC_QMIN || J.mode == BM_SAC_POLICY) ? J.t1 : (J.mode == BM_CRITIC_PI ? J.soft : J.crit);
     c.h1_net = h1.net; c.h1_ws = h1.ws.x;
     c.h2_net = J.t2.net; c.h2_ws = J.t2.ws.x;
     c.src = J.src.main; c.bonus = J.bonus; c.bonus_scale = J.bonus_scale;
@@ -397,7 +397,9 @@ __device__ __forceinline__ float lnp_sum(const float* lp) {
 
 // GRP 0: BM_CRITIC_TD jobs, 1: BM_CRITIC_PI, 2: BM_ACTOR_PI / BM_ACTOR_BC, 3: BM_GIVEN — the head gradient was written to ws.dout
 // by an earlier kernel, heads up to 8 wide (SAC) (one instantiation per launch keeps the register
-// footprint of each below 128 at 16 waves per workgroup).
+// footprint of each below 128 at 16 waves per workgroup); 4: BM_SAC_QMIN — SAC's min(Q1, Q2)(s, a~) selection in the prologue (role 1: the
+// other critic's head) instead of a launch of its own; 5: BM_SAC_POLICY — the policy's head gradient in the prologue (role 1: dL/da from
+// both critics' layer-1 backward), 8-wide head.
 // Latency structure (what matters at B = 128, one workgroup per CU): EVERY global load of the workgroup — the W2 fragment
 // of the MFMA phase, the z2 rows, labels, the other nets' rows, all head parameters, the epilogue's z1 — is issued at
 // entry; there is ONE wait; head parameters are shared through LDS; the rest runs out of registers and LDS.
@@ -409,15 +411,15 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     __shared__ __attribute__((aligned(16))) float dz2s[BF16 ? kCTB * RT * 2 : RT * LDA2];  // (BF16: only the epilogue's row-sum scratch)
     __shared__ __attribute__((aligned(16))) __bf16 dz2b[BF16 ? RT * LDB2 : 8];
     __shared__ __attribute__((aligned(16))) float kred[(kKSB - 1) * kCTB * 256];  // split-K partial tiles
-    constexpr int IMG = GRP == 3 ? 8 : 4;  // head width of this instantiation's LDS images
+    constexpr int IMG = (GRP == 3 || GRP == 5) ? 8 : 4;  // head width of this instantiation's LDS images
     // head width known at compile time: the critic jobs (GRP 0, 1) have ONE output, the actor jobs (GRP 2) four; GRP 3 (SAC: policy 8 wide,
     // Q heads 1) keeps the run-time width.  A run-time trip count over dout[] costs a select chain per step (no indexed registers).
-    constexpr int NOUT = GRP <= 1 ? 1 : (GRP == 2 ? 4 : 0);
+    constexpr int NOUT = (GRP <= 1 || GRP == 4) ? 1 : (GRP == 2 ? 4 : (GRP == 5 ? 8 : 0));
     constexpr int OUTW = NOUT ? NOUT : IMG;
     typedef HeadImage<IMG> Img;
     constexpr int kHpStride = Img::kStride;
-    __shared__ __attribute__((aligned(16))) float hps[(GRP == 0 ? 3 : 1) * kHpStride];
-    __shared__ __attribute__((aligned(16))) float c1s[GRP == 2 ? H1 * 6 : 4];  // critic layer 1: g1 be1 W1[:,13..16]
+    __shared__ __attribute__((aligned(16))) float hps[(GRP == 0 ? 3 : (GRP == 4 ? 2 : 1)) * kHpStride];
+    __shared__ __attribute__((aligned(16))) float c1s[GRP == 2 ? H1 * 6 : (GRP == 5 ? H1 * 8 : 4)];  // critic layer 1: g1 be1 W1[:,13..16]  (GRP 5: W1[:,13..16] of both critics)
     __shared__ float red[16][4];
     __shared__ float st1s[RT * 2];  // LN1 stats of the tile's rows (epilogue)
     // TD job (GRP 0): EIGHT rows per workgroup, a wave PAIR per row — wave w (role 0) owns the row's own head, loss gradient and LN2
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     // its 16 rows (8 of them zero): that phase is the short one.
     // The critic-PI job (GRP 1) pairs the same way (role 1: the soft head), the actor jobs (GRP 2) too (role 1: dL/da from the critic's
     // layer-1 backward, four dot products over 256 hidden units).
-    constexpr bool PAIRED = GRP <= 2;
+    constexpr bool PAIRED = GRP <= 2 || GRP >= 4;
     constexpr int RTB = PAIRED ? RT / 2 : RT;
     __shared__ float tq[PAIRED ? RTB * 4 : 1];
 
@@ -466,8 +468,9 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     // zero-fills the registers, loads under a branch and — where the two versions merge — WAITS for the loads in the middle of the issue phase.
     RowReg<H2> z, za, zb;
     float lab0 = 0.f, lab1 = 0.f, tgt[4] = {0.f, 0.f, 0.f, 0.f};
-    RowReg<H1> cdh, cz;
+    RowReg<H1> cdh, cz, cdh2, cz2;  // (cdh2 / cz2: GRP 5, the second critic)
     float cst0 = 0.f, cst1 = 0.f, cs1 = 0.f, cs2 = 0.f;
+    float paux[GRP == 5 ? 13 : 1] = {};  // GRP 5: a[4], sigma eps[4], clamp mask[4], entropy of the row (the Gaussian head's aux row)
     // PAIRED: role 0 asks for the row of its own net (z), role 1 for the two target nets' (za, zb); both behind one scalar branch each, the
     // skipped registers left unset (never used by that role)
     const bool role1 = PAIRED && __builtin_amdgcn_readfirstlane(wave) >= RTB;
@@ -497,7 +500,25 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
     if (GRP == 1) {
         if (role1 && J.soft.net) za.load(J.soft.ws.z2 + R * H2);  // same net as J.net: shares the LDS image
     }
+    if (GRP == 4) {  // the other critic on (s, a~): its own LDS image
+        if (role1) za.load(J.t1.ws.z2 + R * H2);
+        pv1.fetch(J.t1.net, J.t1.m, tid);
+    }
     float c1v[2] = {0.f, 0.f};
+    if (GRP == 5) {
+        if (role1) {  // the pair's second wave owns dL/da: both critics' dh1 and z1 rows
+            cdh.load(J.t1.ws.dh1 + R * H1);
+            cz.load(J.t1.ws.z1 + R * H1);
+            cdh2.load(J.t2.ws.dh1 + R * H1);
+            cz2.load(J.t2.ws.z1 + R * H1);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 13; ++jj) paux[jj] = J.bonus[R * 16 + jj];
+            bonus_scale = J.bonus_scale[threadIdx.x & 0];  // alpha
+        }
+        c1v[0] = J.t1.net[J.t1.m.W1() + (tid >> 2) * J.t1.m.in + 13 + (tid & 3)];  // W1[k][13..16] of each critic, one float per thread
+        c1v[1] = J.t2.net[J.t2.m.W1() + (tid >> 2) * J.t2.m.in + 13 + (tid & 3)];
+    }
     if (GRP == 2) {
         if (J.mode == BM_ACTOR_PI) {
             const Head& C = J.crit;
@@ -552,6 +573,11 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
         if (tid < 2 * H1) c1s[tid] = c1v[0];
         c1s[2 * H1 + tid] = c1v[1];
     }
+    if (GRP == 4) pv1.store(hps + kHpStride, J.t1.net, J.t1.m, tid);
+    if (GRP == 5) {
+        c1s[tid] = c1v[0];
+        c1s[4 * H1 + tid] = c1v[1];
+    }
     __syncthreads();
     STAMP();
 
@@ -585,6 +611,28 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
                     head_regs<1, IMG, RELU>(za, hps, 1, slope, xa, ya, m1, s1, qs, J.m.no_ln);
                     if (lane == 0) tq[prow] = qs[0];
                 }
+            } else if constexpr (GRP == 4) {
+                RowReg<H2> xa, ya;
+                float m1, s1, qo[1];
+                head_regs<1, IMG, RELU>(za, hps + kHpStride, 1, slope, xa, ya, m1, s1, qo, J.t1.m.no_ln);
+                if (lane == 0) tq[prow] = qo[0];
+            } else if constexpr (GRP == 5) {
+                // dL/da_j = sum over both critics and their 256 hidden units of dz1[k] W1[k][13 + j]; plain stacks: dz1 = dh1 relu'(z1)
+                // (policy_dout_kernel's order: critic 1's four units of the lane, then critic 2's, then the wave sums)
+                float da[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int hsel = 0; hsel < 2; ++hsel) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int k = lane * 4 + c;
+                        const float dz1 = act_bwd<true>(hsel ? cdh2.v[c] : cdh.v[c], hsel ? cz2.v[c] : cz.v[c], 0.0f);
+                        const float4 w4 = *reinterpret_cast<const float4*>(c1s + hsel * 4 * H1 + 4 * k);
+                        da[0] += dz1 * w4.x; da[1] += dz1 * w4.y; da[2] += dz1 * w4.z; da[3] += dz1 * w4.w;
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) da[jj] = wave_sum(da[jj]);
+                if (lane < 4) tq[prow * 4 + lane] = lane == 0 ? da[0] : lane == 1 ? da[1] : lane == 2 ? da[2] : da[3];
             } else if (J.mode == BM_ACTOR_PI) {
                 // dL/da_j = sum_k dz1_c[k] W1c[k][13 + j], dz1_c = LN1 backward of the critic's dh1 (row sums from lnp)
                 float da[4] = {0.f, 0.f, 0.f, 0.f};
@@ -627,6 +675,17 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
             const float diff = o[0] - target;
             dout[0] = 2.0f * diff * A.inv_batch;  // d mse / dq
             part[0] += diff * diff * A.inv_batch;
+        } else if constexpr (GRP == 4) {
+            // torch.min(Q1, Q2)'s subgradient: the smaller head takes -1 / B, a tie is shared (q_select_kernel)   SAC/agent.py:380-383
+            const float other = tq[prow];
+            const float w = o[0] < other ? 1.0f : (o[0] == other ? 0.5f : 0.0f);
+            dout[0] = -w * A.inv_batch;
+            if (J.loss_slot == 0) part[2] += -fminf(o[0], other) * A.inv_batch;  // the -min(Q) / B part of the policy loss (logged), once per row
+        } else if constexpr (GRP == 5) {
+            const float ab = bonus_scale * A.inv_batch;  // alpha / B
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) sac_policy_dout(tq[prow * 4 + jj], paux[jj], paux[4 + jj], paux[8 + jj], ab, dout[jj], dout[4 + jj]);
+            part[2] += -bonus_scale * paux[12] * A.inv_batch;  // -alpha H / B (logged)
         } else if constexpr (GRP == 1) {
             dout[0] = -A.inv_batch;            // rl_loss = -mean(Q1(s, pi(s)))  HIRL.py:297
             part[3] += -o[0] * A.inv_batch;
@@ -689,7 +748,10 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
                 J.ws.st2[R * 2] = mean;
                 J.ws.st2[R * 2 + 1] = rstd;
             }
-            if (GRP != 3 && lane < 4) {
+            if constexpr (GRP == 5) {  // eight head gradients; no outv (nothing reads the policy's pre-activations downstream)
+                const float d0 = dout[0], d1 = dout[1], d2 = dout[2], d3 = dout[3], d4 = dout[4], d5 = dout[5], d6 = dout[6], d7 = dout[7];
+                if (lane < 8) J.ws.dout[R * OW + lane] = lane == 0 ? d0 : lane == 1 ? d1 : lane == 2 ? d2 : lane == 3 ? d3 : lane == 4 ? d4 : lane == 5 ? d5 : lane == 6 ? d6 : d7;
+            } else if (GRP != 3 && lane < 4) {
                 J.ws.dout[R * OW + lane] = dout[lane < OUTW ? lane : 0];
                 if (J.mode != BM_ACTOR_PI) J.ws.outv[R * OW + lane] = (J.m.out == 4) ? fast_tanh(o[lane < OUTW ? lane : 0]) : o[lane < OUTW ? lane : 0];
             }
@@ -709,7 +771,16 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
             if (J.mode == BM_CRITIC_PI && c == 3) atomicAdd(&A.losses[3], p);
             if (J.mode == BM_ACTOR_BC && c == 2) atomicAdd(&A.losses[2], p);
             if (J.mode == BM_ACTOR_BC && c == 1) atomicAdd(&A.losses[4], p);
+            if ((GRP == 4 || GRP == 5) && c == 2 && p != 0.0f) atomicAdd(&A.losses[2], p);  // SAC: the policy loss's logged parts
         }
+    }
+    if (GRP == 5 && blockIdx.x == 0 && blockIdx.y == 0 && wave == 1) {
+        // The mean entropy feeds the log-alpha step, so it must not depend on arrival order: the per-row entropies were written by the
+        // Gaussian head's launch, one wave adds them in a fixed order (policy_dout_kernel's).
+        float s = 0.0f;
+        for (int rr = lane; rr < J.rows; rr += 64) s += J.bonus[(size_t)rr * 16 + 12];
+        s = wave_sum(s);
+        if (lane == 0) A.losses[4] = s * A.inv_batch;
     }
     // ---------------- dh1 tile on fp32 MFMA: wave = (column tile ct, K quarter kq), K = 512 ----------------
     {
@@ -790,7 +861,7 @@ void launch_bwd_t(const BwdArgs& G, hipStream_t st) {
     C.images = G.images;
     static const int rowmap = getenv("HX_XCD_ROWMAP") ? atoi(getenv("HX_XCD_ROWMAP")) : 3;  // bit 1: bwd_l2
     C.rowmap = (rowmap >> 1) & 1;
-    const dim3 grid(bwd_blocks(G, GRP <= 2 ? RT / 2 : RT), G.njobs);
+    const dim3 grid(bwd_blocks(G, (GRP <= 2 || GRP >= 4) ? RT / 2 : RT), G.njobs);
     if constexpr (GRP <= 2) {  // the bf16 update path covers the HIRL / TD3 / BC jobs (GRP 3 = SAC's given head gradients: fp32)
         static const int dbg_off = getenv("HX_DBG_BF16_OFF") ? atoi(getenv("HX_DBG_BF16_OFF")) : 0;
         if (G.images && !(dbg_off & 2)) {
@@ -848,6 +919,8 @@ void launch_bwd(int grp, const BwdArgs& G, hipStream_t st) {
         case 0: launch_bwd_t<0>(G, st); break;
         case 1: launch_bwd_t<1>(G, st); break;
         case 2: launch_bwd_t<2>(G, st); break;
+        case 4: launch_bwd_t<4>(G, st); break;
+        case 5: launch_bwd_t<5>(G, st); break;
         default: launch_bwd_t<3>(G, st); break;
     }
 }

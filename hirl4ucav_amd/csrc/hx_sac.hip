@@ -161,12 +161,10 @@ __global__ __launch_bounds__(kThreads) void policy_dout_kernel(PDoutArgs A) {
     const float alpha = A.alpha_state[3];
     if (lane < 4) {
         const float* x = A.aux + (size_t)r * 16;
-        const float a = x[lane], se = x[4 + lane], mask = x[8 + lane];
-        const float t = 1.0f - a * a;
-        const float dHdx = (-2.0f * a * t) / (t + 1e-6f);
-        const float dLdx = (lane == 0 ? da[0] : lane == 1 ? da[1] : lane == 2 ? da[2] : da[3]) * t - alpha * A.inv_batch * dHdx;
-        A.pol.dout[(size_t)r * OW + lane] = dLdx;
-        A.pol.dout[(size_t)r * OW + 4 + lane] = (dLdx * se - alpha * A.inv_batch) * mask;
+        float d_mean, d_logstd;
+        sac_policy_dout(lane == 0 ? da[0] : lane == 1 ? da[1] : lane == 2 ? da[2] : da[3], x[lane], x[4 + lane], x[8 + lane], alpha * A.inv_batch, d_mean, d_logstd);
+        A.pol.dout[(size_t)r * OW + lane] = d_mean;
+        A.pol.dout[(size_t)r * OW + 4 + lane] = d_logstd;
         if (lane == 0) atomicAdd(&A.losses[2], -alpha * x[12] * A.inv_batch);  // logged only
     }
     // The mean entropy feeds the log-alpha step, so it must not depend on arrival order: the per-row entropies were written by
@@ -346,21 +344,26 @@ static int sac_policy_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const
         F.job[1] = FwdJob{q2, kQs, src, 0, 3, Head{}, X.act_c, 0.f, s[SS_Q2P], B, 1};
         launch_fwd(F, st);
     }
-    {
+    // one call (adam_step > 0): min(Q1, Q2) is selected in the critics' backward prologue and the policy's head gradient is formed in the
+    // policy's backward prologue (bwd_l2<4> / <5>) — q_select_kernel and policy_dout_kernel as launches of their own are the staged form
+    static const bool fold_env = !(getenv("HX_SAC_FOLD") && getenv("HX_SAC_FOLD")[0] == '0');  // A/B knob
+    const bool fold = adam_step > 0 && fold_env;
+    if (!fold) {
         QSelArgs Q{q1, q2, kQs, s[SS_Q1P], s[SS_Q2P], B, 1.0f / B, N->losses};
         hipLaunchKernelGGL(q_select_kernel, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, st, Q);
     }
-    {   // both critics backward down to dh1 with the given head gradients
+    {   // both critics backward down to dh1
         BwdArgs G{};
         G.njobs = 2; G.slope = 0.0f; G.inv_batch = 1.0f / B; G.losses = N->losses;
         for (int h = 0; h < 2; ++h) {
             BwdJob& J = G.job[h];
             J = BwdJob{};
-            J.net = h ? q2 : q1; J.m = kQs; J.ws = s[SS_Q1P + h]; J.rows = B; J.mode = BM_GIVEN;
+            J.net = h ? q2 : q1; J.m = kQs; J.ws = s[SS_Q1P + h]; J.rows = B; J.mode = fold ? BM_SAC_QMIN : BM_GIVEN;
+            if (fold) { J.t1 = Head{h ? q1 : q2, kQs, s[SS_Q1P + (1 - h)]}; J.loss_slot = h; }
         }
-        launch_bwd(3, G, st);
+        launch_bwd(fold ? 4 : 3, G, st);
     }
-    {
+    if (!fold) {
         PDoutArgs P{q1, q2, kQs, s[SS_Q1P], s[SS_Q2P], s[SS_PC], X.aux_c, N->alpha_state, B, 1.0f / B, N->losses};
         hipLaunchKernelGGL(policy_dout_kernel, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, st, P);
     }
@@ -369,8 +372,12 @@ static int sac_policy_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const
         G.njobs = 1; G.slope = 0.0f; G.inv_batch = 1.0f / B; G.losses = N->losses;
         BwdJob& J = G.job[0];
         J = BwdJob{};
-        J.net = N->policy; J.m = kPolicy; J.ws = s[SS_PC]; J.rows = B; J.mode = BM_GIVEN;
-        launch_bwd(3, G, st);
+        J.net = N->policy; J.m = kPolicy; J.ws = s[SS_PC]; J.rows = B; J.mode = fold ? BM_SAC_POLICY : BM_GIVEN;
+        if (fold) {
+            J.t1 = Head{q1, kQs, s[SS_Q1P]}; J.t2 = Head{q2, kQs, s[SS_Q2P]};
+            J.bonus = X.aux_c; J.bonus_scale = N->alpha_state + 3;
+        }
+        launch_bwd(fold ? 5 : 3, G, st);
     }
     {
         WgArgs W{};
@@ -401,8 +408,9 @@ static int sac_policy_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const
 int hx_sac_policy_grads(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, void* stream) {
     return sac_policy_grads_impl(N, Bt, Hy, stream, 0, 0.0f);
 }
-/* One GPU: the whole SacAgent.learn (SAC/agent.py:276-327) in ONE call and 11 launches (the staged sequence takes 14): the Polyak step and
- * policy.sample(s) ride in the launch of policy.sample(s'), both optimizers' steps (and the log-alpha step) in their weight-gradient launches.
+/* One GPU: the whole SacAgent.learn (SAC/agent.py:276-327) in ONE call and 9 launches (the staged sequence takes 14): the Polyak step and
+ * policy.sample(s) ride in the launch of policy.sample(s'), both optimizers' steps (and the log-alpha step) in their weight-gradient launches,
+ * the min(Q1, Q2) selection and the policy's head gradient in the prologues of the backward launches that consume them.
  * Bit-identical to hx_sac_critic_step + hx_sac_policy_grads + hx_sac_adam(which = 1).  sample may be NULL; step is 1-based. */
 int hx_sac_learn(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t polyak_first, int32_t step, float target_entropy,
                  void* stream) {

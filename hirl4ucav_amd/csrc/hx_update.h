@@ -465,7 +465,22 @@ __device__ __forceinline__ uint4 pack8_bf16(const float (&v)[8]) {
     return q;
 }
 
-enum { BM_CRITIC_TD = 0, BM_CRITIC_PI = 1, BM_ACTOR_PI = 2, BM_ACTOR_BC = 3, BM_GIVEN = 4 };
+enum { BM_CRITIC_TD = 0, BM_CRITIC_PI = 1, BM_ACTOR_PI = 2, BM_ACTOR_BC = 3, BM_GIVEN = 4,
+       BM_SAC_QMIN = 5,     // SAC policy loss, a critic's side: dq = -w / B, w = 1 for the smaller of Q1 / Q2 (s, a~), 1/2 each on a tie  (SAC/agent.py:380-383)
+       BM_SAC_POLICY = 6 }; // ... the policy's side: the critics' dL/da chained through a = tanh(mean + sigma eps), plus the entropy term (:404-406)
+
+// The gradient of SAC's policy loss wrt the policy head's pre-activations (mean_j, log_std_j) of one action component, shared by
+// policy_dout_kernel and bwd_l2<5> so that both round alike (contraction off, the multiply-adds spelled out):
+//   da = dL/da_j from the critics, a = tanh(x), se = sigma eps, mask = log_std clamp pass-through, ab = alpha / B
+#pragma clang fp contract(off)
+__device__ __forceinline__ void sac_policy_dout(float da, float a, float se, float mask, float ab, float& d_mean, float& d_logstd) {
+    const float t = 1.0f - a * a;
+    const float dHdx = (-2.0f * a * t) / (t + 1e-6f);
+    const float dLdx = da * t - ab * dHdx;
+    d_mean = dLdx;
+    d_logstd = (dLdx * se - ab) * mask;
+}
+#pragma clang fp contract(fast)
 
 struct BwdJob {
     const float* net;
@@ -487,6 +502,9 @@ struct BwdJob {
     const float* bonus_scale;
     int loss_slot;
     int img_t;  // bf16 update path: which image of BwdArgs::images holds this net's TRANSPOSED W2 (IM_*_T)
+    // BM_SAC_QMIN: t1 = the OTHER critic evaluated on (s, a~) (its z2 rows); loss_slot 0: this job also logs -min(Q1, Q2) / B into losses[2]
+    // BM_SAC_POLICY: t1 / t2 = the two critics' slots on (s, a~) (dh1, z1 read), bonus = the Gaussian head's aux rows [rows][16]
+    //                (a[4], sigma eps[4], clamp mask[4], entropy), bonus_scale = &alpha
 };
 struct BwdArgs {
     BwdJob job[2];

@@ -407,8 +407,9 @@ int hx_sac_critic_grads_sampled(const HxSacNets* nets, const HxSacBatch* batch, 
 int hx_sac_critic_step(const HxSacNets* nets, const HxSacBatch* batch, const HxHyper* hyper, const HxSample* sample, int32_t polyak_first,
                        int32_t step, void* stream);
 int hx_sac_policy_grads(const HxSacNets* nets, const HxSacBatch* batch, const HxHyper* hyper, void* stream);
-/* One GPU: the whole SacAgent.learn (SAC/agent.py:276-327) in one call — the soft_update and policy.sample(s) in the launch of
- * policy.sample(s'), every optimizer step (log-alpha included) in its weight-gradient launch.  Bit-identical to hx_sac_critic_step +
+/* One GPU: the whole SacAgent.learn (SAC/agent.py:276-327) in one call and 9 launches — the soft_update and policy.sample(s) in the launch of
+ * policy.sample(s'), every optimizer step (log-alpha included) in its weight-gradient launch, the min(Q1, Q2) selection and the policy's head
+ * gradient in the prologues of the backward launches that consume them.  Bit-identical to hx_sac_critic_step +
  * hx_sac_policy_grads + hx_sac_adam(which = 1); sample may be NULL (minibatch already assembled); step is 1-based. */
 int hx_sac_learn(const HxSacNets* nets, const HxSacBatch* batch, const HxHyper* hyper, const HxSample* sample, int32_t polyak_first, int32_t step,
                  float target_entropy, void* stream);

@@ -154,7 +154,8 @@ def test_sac_deferred_draw_is_bit_identical_to_the_sampling_launch(SE, esac):
 
 @pytest.mark.parametrize("defer", [False, True])
 def test_sac_learn_in_one_call_is_bit_identical_to_the_staged_sequence(SE, defer):
-    """hx_sac_learn (one GPU, 11 launches: the soft_update and policy.sample(s) in the launch of policy.sample(s'), q1 / q2 / policy optimizer
+    """hx_sac_learn (one GPU, 9 launches: the soft_update and policy.sample(s) in the launch of policy.sample(s'), the min(Q1, Q2) selection and the
+    policy head gradient in the backward prologues, q1 / q2 / policy optimizer
     steps and the log-alpha step inside their weight-gradient launches) against BOTH staged sequences — hx_sac_critic_step +
     hx_sac_policy_grads + hx_sac_adam(1) and the fully separate hx_sac_critic_grads[_sampled] + hx_sac_adam(0) + ... (14 launches): after 7
     calls (two of them with the Polyak step of the targets first) the same networks, moments, targets, alpha and W2 image, bit for bit."""
