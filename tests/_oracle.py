@@ -6,7 +6,8 @@ import subprocess
 import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(REPO, "oracle", "libhx_oracle.so")
+# HX_ORACLE_LIBRARY selects another build of the same restatement (oracle/Makefile `asan`: tools/asan_oracle.sh)
+_SO = os.environ.get("HX_ORACLE_LIBRARY") or os.path.join(REPO, "oracle", "libhx_oracle.so")
 
 F_LOCKED_PREV, F_LOCKED, F_SLOT_PREV, F_SLOT, F_FIRED, F_FIRE_SUCCESS, F_EPISODE_SUCCESS, F_DONE = (1 << i for i in range(8))
 F_SCEN_SHIFT = 8
