@@ -335,6 +335,25 @@ def host_cpu():
     return model, os.cpu_count() or 1
 
 
+def best_torch_threads(step, cores):
+    """torch's intra-op thread count that makes `step()` (one actor forward for all envs + one learn at B = 128) fastest on this host: the
+    default (one thread per physical core: 128 on the GPU boxes) is thread-oversubscribed for a 128-row MLP and reads 3-10x too slow — the CPU
+    figure is reported at its best, not at its worst.  -> (threads, {threads: seconds per step})"""
+    import torch
+
+    tried = {}
+    for t in [c for c in (1, 2, 4, 8, 16, 32, 64) if c <= cores] or [1]:
+        torch.set_num_threads(t)
+        step()  # warm
+        t0 = time.perf_counter()
+        step()
+        step()
+        tried[t] = round((time.perf_counter() - t0) / 2, 5)
+    best = min(tried, key=tried.get)
+    torch.set_num_threads(best)
+    return best, tried
+
+
 def baseline_port(args, seconds):
     """The oracle timed on a BOUNDED sample of the same workload: the same loop (actor forward for all envs, env step for all
     envs with insert — the envs split over host threads, >= 256 envs each —, one HIRL learn at B = 128) for as many vector steps as fit."""
@@ -364,6 +383,13 @@ def baseline_port(args, seconds):
         ox.step_batch(envs[lo:hi], a[lo:hi], obs[lo:hi], max_step=1500, auto_reset=1, randomize=1, seed=0, env_id0=lo, episode_ctr=epi[lo:hi],
                       ring=rings[k], total=totals[k])
 
+    def torch_part():  # what runs on torch's threads in one vector step (the env step runs on the worker threads)
+        o.choose_action(obs, rng.normal(0, 0.1, (n, 4)).astype(np.float32))
+        rows = rings[0][rng.integers(0, 1, args.batch)]
+        ibc = rng.integers(0, es.shape[0], args.batch)
+        o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), (es[ibc], ea[ibc]), rng.normal(0, 0.2, 4).astype(np.float32), 0.5, 0.0)
+
+    torch_threads, tried = best_torch_threads(torch_part, cores)
     steps, t0 = 0, time.perf_counter()
     while True:
         a = o.choose_action(obs, rng.normal(0, 0.1, (n, 4)).astype(np.float32))
@@ -381,7 +407,8 @@ def baseline_port(args, seconds):
     pool.shutdown()
     return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": cores, "kind": "port",
             "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s: oracle C env step on {len(chunks)} threads + torch-CPU actor forward and "
-                      f"HIRL learn on {torch.get_num_threads()} threads",
+                      f"HIRL learn on {torch_threads} threads (the fastest of {sorted(tried)}: seconds per torch part {tried})",
+            "threads": {"env_step": len(chunks), "torch": torch_threads, "torch_tried_s_per_step": tried, "logical_cores": cores},
             "update_steps_per_s": round(steps / dt, 2)}
 
 
@@ -413,6 +440,13 @@ def baseline_port_sac(args, seconds):
         ox.step_batch(envs[lo:hi], a[lo:hi], obs[lo:hi], max_step=1500, auto_reset=1, randomize=1, seed=0, env_id0=lo, episode_ctr=epi[lo:hi],
                       ring=rings[k], total=totals[k])
 
+    def torch_part():
+        o.explore(obs, rng.normal(0, 1, (n, 4)).astype(np.float32))
+        rows = rings[0][rng.integers(0, 1, args.batch)]
+        o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 30], rows[:, 17:30], rows[:, 31]), rng.normal(0, 1, (args.batch, 4)).astype(np.float32),
+                rng.normal(0, 1, (args.batch, 4)).astype(np.float32))
+
+    torch_threads, tried = best_torch_threads(torch_part, cores)
     steps, t0 = 0, time.perf_counter()
     while True:
         a = o.explore(obs, rng.normal(0, 1, (n, 4)).astype(np.float32)).astype(np.float32)
@@ -429,7 +463,8 @@ def baseline_port_sac(args, seconds):
     pool.shutdown()
     return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": cores, "kind": "port",
             "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s: oracle C env step on {len(chunks)} threads + torch-CPU SAC explore and "
-                      f"learn on {torch.get_num_threads()} threads",
+                      f"learn on {torch_threads} threads (the fastest of {sorted(tried)}: seconds per torch part {tried})",
+            "threads": {"env_step": len(chunks), "torch": torch_threads, "torch_tried_s_per_step": tried, "logical_cores": cores},
             "update_steps_per_s": round(steps / dt, 2)}
 
 
@@ -815,7 +850,8 @@ def run_rank(args):
     if fused:
         # the kernel the timed loop RUNS: policy inference + env step + replay insert in one launch.  Both roofs are quoted; `bound` names the nearer.
         us = float(np.mean(fused))
-        fused_pmc = profile_traffic(f"fused_{args.envs}") if (args.agent == "hirl" and args.dtype == "f32") else None
+        fused_pmc = (profile_traffic(f"fused_{args.envs}") if args.dtype == "f32" else profile_traffic(f"fused_bf16_{args.envs}") if args.dtype == "bf16" else None) \
+            if args.agent == "hirl" else None
         fp32_equiv = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
         # which matrix-core instruction the 256 -> 512 product runs on: fp32 MFMA; bf16 MFMA; or — the fp32 HIRL policy from 16,384 rows on, and
         # --dtype f32x9 at every size — NINE bf16 MFMAs per fp32 product (the exact hi | mid | lo split): priced as executed bf16 FLOPs against the bf16 peak
@@ -844,9 +880,9 @@ def run_rank(args):
                                      "of the second pass (3 of every 4 steps)",
                            "note": ("vector-issue / LDS bound tile loop (LayerNorm + head per row), DESIGN.md section 4" if persistent else
                                     "latency-bound at this size: 256 workgroups, one round; neither roof is near (DESIGN.md section 4)"),
-                           "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes of the fp32 HIRL kernel at this size (FETCH_SIZE calibrated "
-                                           "x2, WRITE_SIZE: tools/pmc_env_passes.sh); each of the 8 XCDs pulls the policy's 0.55 MB of weights into its own L2 "
-                                           "once per launch, hence ~3.4 x the env's 550 B/env-step; null for other dtypes / agents / sizes",
+                           "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes of this launch (HIRL, this policy format, this size; FETCH_SIZE "
+                                           "calibrated x2, WRITE_SIZE: tools/pmc_env_passes.sh); each of the 8 XCDs pulls the policy's weights into its own L2 once "
+                                           "per launch, hence a few x the env's 550 B/env-step at small sizes; null where no pass exists",
                            "traffic_from_profiles": fused_pmc}
         res["roofline_env_kernel"] = env_roof
     else:

@@ -1,6 +1,6 @@
 """Workload for the HBM-traffic counters of the env-step kernel (run under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one
 counter per pass): a calibration copy with the same access shape over a known byte count, then env steps at HX_PMC_ENVS envs
-(default 1,048,576); HX_PMC_FUSED=1 adds six launches of the fused act + env kernel at that size (<= 8,192 envs).  tools/pmc_traffic_json.py turns
+(default 1,048,576); HX_PMC_FUSED=1 adds six launches of the fused act + env kernel at that size (HX_PMC_DTYPE f32 | bf16: the policy's format).  tools/pmc_traffic_json.py turns
 the passes' CSV files into profiles/pmc_env_traffic.json."""
 import os
 import sys
@@ -25,6 +25,8 @@ for _ in range(6):
 if os.environ.get("HX_PMC_FUSED"):  # the kernel of bench.py's timed loop: policy inference + env step + insert in ONE launch (act_fused_kernel<..., ENV>)
     from hirl4ucav_amd.agents.engine import HirlEngine
     eng = HirlEngine(batch=128)
+    if os.environ.get("HX_PMC_DTYPE", "f32") == "bf16":  # (beyond 8,192 envs the launch is the persistent kernel of hx_actp.hip: bf16 weight-stationary,
+        eng.set_act_dtype("bf16")                          #  fp32 through the exact 9-term split from 16,384 rows on)
     out = torch.empty((n, 4), device="cuda")
     for _ in range(6):
         eng.act_step(env, sigma=0.1, seed=1, out=out)

@@ -11,7 +11,7 @@ import re
 import sys
 
 d, commit = sys.argv[1], sys.argv[2]
-ALGO = {"env_step_kernel": 550, "act_fused_kernel": 550}  # algorithmic bytes per env-step with the fused insert
+ALGO = {"env_step_kernel": 550, "act_fused_kernel": 550, "act_persist": 550}  # algorithmic bytes per env-step with the fused insert
 
 
 def rows(path):
@@ -21,18 +21,22 @@ def rows(path):
 
 out = {"_comment": "HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_env.py; FETCH_SIZE calibrated with the "
                    "512 MiB dword copy of the same run, WRITE_SIZE as reported). Keys: envs per launch -> the stand-alone env_step_kernel; 'fused_<n>' -> "
-                   "act_fused_kernel<..., ENV> (policy inference + env step + insert, the kernel of bench.py's timed loop; its reads include the policy's W2 per workgroup "
-                   "out of L2, which the counter does not see).",
-       "kernel_build": "round 3: one lane per env from 32,768 envs on, non-temporal row / observation stores", "measured_at_commit": commit}
+                   "the fused act + env launch (policy inference + env step + insert, the kernel of bench.py's timed loop: act_fused_kernel<..., ENV> up to 8,192 envs, "
+                   "the persistent act_persist_*_kernel<..., ENV> beyond), 'fused_bf16_<n>' the same with the bf16 policy; their reads include the policy's W2 per "
+                   "workgroup out of L2, which the counter does not see.",
+       "kernel_build": "round 4: persistent acting kernels beyond 8,192 envs (hx_actp.hip); env kernel as in round 3", "measured_at_commit": commit}
 for f in sorted(glob.glob(os.path.join(d, "pmc_FETCH_SIZE_env_*.csv"))):
-    n = int(re.search(r"env_(\d+)\.csv", f).group(1))
+    mt = re.search(r"env_(\d+)(_bf16)?\.csv", f)
+    n, dt = int(mt.group(1)), (mt.group(2) or "")
     w = f.replace("FETCH_SIZE", "WRITE_SIZE")
     fr, wr = rows(f), rows(w)
     cal_f = [float(r["Counter_Value"]) for r in fr if "calib_copy_dword" in r["Kernel_Name"]]
     cal_w = [float(r["Counter_Value"]) for r in wr if "calib_copy_dword" in r["Kernel_Name"]]
     kib = 128 * 1024 * 1024 * 4 / 1024  # the copy reads and writes 512 MiB
     ff, wf = kib / (sum(cal_f) / len(cal_f)), kib / (sum(cal_w) / len(cal_w))
-    for kern, key in (("env_step_kernel", str(n)), ("act_fused_kernel", f"fused_{n}")):
+    for kern, key in (("env_step_kernel", str(n)), ("act_fused_kernel", f"fused{dt}_{n}"), ("act_persist", f"fused{dt}_{n}")):
+        if kern == "env_step_kernel" and (dt or str(n) in out):
+            continue
         fv = [float(r["Counter_Value"]) for r in fr if kern in r["Kernel_Name"]]
         wv = [float(r["Counter_Value"]) for r in wr if kern in r["Kernel_Name"]]
         if not fv or not wv:
