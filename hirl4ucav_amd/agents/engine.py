@@ -525,11 +525,38 @@ class HirlEngine:
     def use_rccl_direct(self):
         """Exchange gradients with ncclAllReduce enqueued by the library on the engine's stream (hx_rccl_allreduce) instead of
         torch.distributed.all_reduce: no host-side collective call inside learn().  Needs an initialised process group (for the id) and one
-        GPU per rank (RCCL refuses two ranks on one device); works at world size 1 (the sharded rank's sequence, bench.py --staged)."""
-        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        GPU per rank (RCCL refuses two ranks on one device); works at world size 1 (the sharded rank's sequence, bench.py --staged).
+        The communicator is checked with one all-reduce of ones before it is used, and EVERY rank takes the same decision: if any rank could
+        not build or verify it (a second RCCL instance in the process, a launcher without device binding, ...) all ranks keep
+        torch.distributed.all_reduce and say so on stderr — `exchange_name` (bench.py: `rccl_ranks.backend`) tells which transport runs."""
+        dist = torch.distributed
+        if not (dist.is_available() and dist.is_initialized()):
             raise _lib.HxError("use_rccl_direct needs an initialised torch.distributed process group (it carries the communicator id)")
-        self.rccl = RcclDirect(self.group)
+        import sys
+        ok, why, r = 1, "", None
+        try:
+            r = RcclDirect(self.group)
+            probe = torch.ones(64, dtype=torch.float32, device=self.device)
+            r.allreduce(probe)
+            torch.cuda.synchronize()
+            if not bool((probe == float(r.world)).all()):
+                ok, why = 0, f"the probe all-reduce returned {float(probe[0])} instead of {r.world}"
+        except Exception as e:  # noqa: BLE001 — any failure here means "use the other transport", on every rank
+            ok, why = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) != 1:
+            if r is not None:
+                try:
+                    r.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            print(f"hirl4ucav_amd: RCCL direct not available on rank {dist.get_rank(self.group)} ({why or 'another rank failed'}): "
+                  f"the gradient exchange stays on torch.distributed.all_reduce", file=sys.stderr, flush=True)
+            return False
+        self.rccl = r
         self.exchange_name = "rccl-direct"
+        return True
 
     def _allreduce(self, t, kind=None):
         """SUM over the ranks of `t` (a gradient message).  RCCL: in place.  One-shot: `t` is this rank's message buffer of `kind`, the
