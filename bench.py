@@ -89,6 +89,9 @@ def parse(argv=None):
                         "with the gloo test backend it falls back to torch.distributed); rccl-torch = torch.distributed.all_reduce; EXPERIMENTAL, never "
                         "run on two physical GPUs: oneshot (every rank reads every peer's message over hipIpc mappings), twostage (reduce-scatter + "
                         "all-gather over the same mappings), twostage-bf16 (its reduced slices as bf16)")
+    p.add_argument("--b0-episodes", dest="b0_episodes", type=int, default=0,
+                   help="B0 (reference plumbing) in SURVEY.md 8(d)'s form: this many episodes of 1,500 steps (3 = ~4 minutes on the GPU box's host); "
+                        "0 (default): a few-second sample, so that the default run stays within minutes")
     p.add_argument("--exchange-timeout-ms", dest="exchange_timeout_ms", type=int, default=5000,
                    help="one-shot exchange: how long a rank waits for a peer's message before it raises (ranks that SHARE a GPU - tests - "
                         "only make progress through pre-emption and need far longer than ranks with a GPU each)")
@@ -501,8 +504,10 @@ def baseline_batched_cpu(seconds):
             "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s"}
 
 
-def baseline_reference_plumbing(seconds):
-    """B0 (configs[0]): ONE env behind the reference's loopback framing — 4-byte big-endian length + JSON (socket_lib.py:86-143), the
+def baseline_reference_plumbing(seconds, episodes=0, episode_steps=1500):
+    """episodes > 0: SURVEY.md 8(d)'s form of B0 — that many episodes of `episode_steps` steps (straight_line's maxStep), each opened with
+    random_reset's message sequence (HarfangEnv_GYM.py:51-81), however long it takes (--b0-episodes: minutes; the default run takes a few-second sample).
+    B0 (configs[0]): ONE env behind the reference's loopback framing — 4-byte big-endian length + JSON (socket_lib.py:86-143), the
     wrapper's message sequence per step (HarfangEnv_GYM.py:139-158: 6 level setters [+ FIRE_MISSILE] + UPDATE_SCENE; :193-251: 4
     request/reply read-backs), no TCP_NODELAY on the client (the reference sets none) — with the oracle simulator as the server and
     the oracle's eager CPU HIRL agent doing chooseAction + learn every step, as train_all.py:341-361 does."""
@@ -543,11 +548,28 @@ def baseline_reference_plumbing(seconds):
         return np.concatenate([d, np.asarray(pa["Euler_angles"]) / np.pi, [pa["target_angle"] / 180.0, 1.0 if pa["target_locked"] else -1.0,
                                1.0 if slot else -1.0], np.asarray(po["Euler_angles"]) / np.pi, [h]]), float(np.linalg.norm(d) * 10000.0)
 
+    def random_reset():  # _random_reset_machine + _reset_missile + the first observation (HarfangEnv_GYM.py:51-81, :171-188)
+        send("RESET_MACHINE", machine_id=ALLY)
+        send("RESET_MACHINE", machine_id=OPPO)
+        send("SET_HEALTH", machine_id=OPPO, health_level=0.2)
+        send("RESET_MACHINE_MATRIX", machine_id=OPPO, position=[0, 4200, 0], rotation=[0, 0, 0])
+        send("RESET_MACHINE_MATRIX", machine_id=ALLY, position=[int(rng.integers(-100, 101)), 3500 + int(rng.integers(-100, 101)), -4000 + int(rng.integers(-100, 101))],
+             rotation=[0, 0, 0])
+        send("SET_PLANE_THRUST", plane_id=ALLY, thrust_level=1.0)
+        send("SET_PLANE_THRUST", plane_id=OPPO, thrust_level=0.6)
+        send("SET_PLANE_LINEAR_SPEED", plane_id=ALLY, linear_speed=300.0)
+        send("SET_PLANE_LINEAR_SPEED", plane_id=OPPO, linear_speed=200.0)
+        send("REARM_MACHINE", machine_id=ALLY)
+        return observe()[0]
+
     obs, _ = observe()
     # the replay memory starts with 128 rows, as after the reference's exploration episodes (train_all.py:266-282): learn() runs from step 1
     mem = [rng.uniform(-1, 1, 32).astype(np.float32) for _ in range(128)]
     steps, t0 = 0, time.perf_counter()
+    limit = episodes * episode_steps if episodes > 0 else 5000
     while True:
+        if episodes > 0 and steps % episode_steps == 0:
+            obs = random_reset()
         a = agent.choose_action(obs.astype(np.float32)[None], rng.normal(0, 0.1, 4).astype(np.float32))[0]
         send("SET_PLANE_PITCH", plane_id=ALLY, pitch_level=float(a[0]))
         send("SET_PLANE_ROLL", plane_id=ALLY, roll_level=float(a[1]))
@@ -569,13 +591,16 @@ def baseline_reference_plumbing(seconds):
                         rng.normal(0, 0.2, 4).astype(np.float32), 100 if len(mem) == 128 else agent.bc_weight, 0.0)
         steps += 1
         dt = time.perf_counter() - t0
-        if dt > seconds or steps >= 5000:
+        if (episodes <= 0 and dt > seconds) or steps >= limit:
             break
+        if len(mem) > 20000:  # (the sample is uniform over the memory: keep the full form's host memory bounded)
+            del mem[:10000]
     sock.close()
     srv.close()
     return {"value": round(steps / dt, 2), "unit": "env steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "what": "configs[0]: 1 env behind the reference's socket framing (loopback TCP + JSON), eager CPU HIRL chooseAction + learn per step",
-            "sample": f"{steps} env steps in {dt:.1f} s, {sent[0] / max(steps, 1):.1f} messages per step, one learn(B=128) per step"}
+            "sample": (f"{episodes} episodes x {episode_steps} steps = " if episodes > 0 else "") +
+                      f"{steps} env steps in {dt:.1f} s, {sent[0] / max(steps, 1):.1f} messages per step, one learn(B=128) per step"}
 
 
 def baseline_eager_rocm_learn(args, seconds, device):
@@ -931,7 +956,7 @@ def run_rank(args):
             if args.agent == "hirl":
                 res["cpu_baseline"] = baseline_port(args, 0.4 * budget)
                 res["cpu_baseline"]["host"] = f"{model}, {cores} logical cores"
-                res["cpu_baseline"]["b0_reference_plumbing"] = baseline_reference_plumbing(0.3 * budget)
+                res["cpu_baseline"]["b0_reference_plumbing"] = baseline_reference_plumbing(0.3 * budget, episodes=args.b0_episodes)
                 res["cpu_baseline"]["b1_batched_cpu"] = baseline_batched_cpu(0.15 * budget)
                 res["cpu_baseline"]["b2_eager_rocm_learn"] = baseline_eager_rocm_learn(args, 0.15 * budget, device)
             else:
