@@ -60,3 +60,32 @@ def test_product_does_not_import_the_oracle():
                 if "oracle" in open(os.path.join(root, f), errors="ignore").read().replace("the scalar oracle", ""):
                     bad.append(os.path.join(root, f))
     assert not bad, bad
+
+
+def test_abi_version_and_struct_sizes_match_the_binding():
+    """HX_ABI_VERSION of the header == hx_version() of the library == the binding's, and every struct that crosses the boundary has the size
+    the library was compiled with (hx_abi_sizes) — the check _lib.load() / the engines run at construction (a binding that had
+    drifted from the header handed the kernels a 9-word statistics buffer under a library that adds into 512 words)."""
+    import re
+
+    from hirl4ucav_amd import _lib
+    from hirl4ucav_amd.agents import engine as E
+    from hirl4ucav_amd.agents import sac_engine as SE
+
+    hdr = open(os.path.join(REPO, "include", "hirl4ucav.h")).read()
+    declared = int(re.search(r"#define HX_ABI_VERSION (\d+)", hdr).group(1))
+    L = _lib.load()
+    assert declared == _lib.ABI_VERSION == L.hx_version()
+    sizes = (ctypes.c_int32 * 8)()
+    L.hx_abi_sizes.argtypes = [ctypes.POINTER(ctypes.c_int32)]
+    assert L.hx_abi_sizes(sizes) == 0
+    for i, cls in enumerate((_lib.HxStepOpts, E.HxNets, E.HxHyper, E.HxBatch, E.HxSample, SE.HxSacNets, SE.HxSacBatch)):
+        assert sizes[i] == ctypes.sizeof(cls), (cls.__name__, sizes[i], ctypes.sizeof(cls))
+        _lib.check_struct(i, cls)
+    assert sizes[7] == _lib.STAT_WAYS * _lib.STAT_PITCH
+
+    class Short(ctypes.Structure):
+        _fields_ = [("a", ctypes.c_void_p)]
+
+    with pytest.raises(_lib.HxError, match="ABI mismatch"):
+        _lib.check_struct(1, Short)
