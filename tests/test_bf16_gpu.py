@@ -156,7 +156,7 @@ def test_f32_image_path_is_bit_identical_and_follows_adam(mods, staged, n):
 
 @pytest.mark.parametrize("n,scenario", [(4096, "straight_line"), (131072, "mixed")])
 def test_bf16_act_step_is_act_then_step(mods, n, scenario):
-    """hx_actor_act_step_bf16 (one launch up to 8,192 envs, two beyond) == hx_actor_act_bf16 followed by hx_env_step, bit for bit:
+    """hx_actor_act_step_bf16 (ONE launch at every size: the per-tile kernel up to 8,192 envs, the persistent kernel of hx_actp.hip beyond) == hx_actor_act_bf16 followed by hx_env_step, bit for bit:
     actions, every state word, observations, rewards, masks, statistics, the replay rows as a multiset.  The large case is the
     configured size of BASELINE.json configs[4] (131,072 mixed envs: scenario = id mod 3, sorted) — and its dynamics agree
     with the oracle on a sample, from the actions the bf16 policy produced."""

@@ -597,7 +597,7 @@ def test_two_stream_issue_order_is_bit_identical_to_serial(staged):
         assert torch.equal(x.view(torch.int32), y.view(torch.int32)), name
 
 
-@pytest.mark.parametrize("n", [83, 4096, 8192, 8192 + 40])  # 16-row tail, one round of 16-row / 32-row workgroups, two-launch fallback
+@pytest.mark.parametrize("n", [83, 4096, 8192, 8192 + 40])  # 16-row tail, one round of 16-row / 32-row workgroups, the persistent kernel (hx_actp.hip)
 def test_act_step_in_one_launch_equals_act_then_step(eng_mod, n):
     """hx_actor_act_step = hx_actor_act followed by hx_env_step, in the tail of the same kernel (16 or 32 envs per workgroup on
     the lanes of one wave): actions, state words, observations, rewards, masks, statistics and the replay rows must be

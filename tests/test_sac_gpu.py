@@ -244,7 +244,7 @@ def test_sac_image_path_is_bit_identical_and_follows_adam(SE, n):
             e.learn()
 
 
-@pytest.mark.parametrize("n", [4096 + 17, 8192, 16384])  # 16-row / 32-row workgroups with the env tail; 16,384: the two-launch fallback
+@pytest.mark.parametrize("n", [4096 + 17, 8192, 16384])  # 16-row / 32-row workgroups with the env tail; 16,384: the persistent kernel (hx_actp.hip)
 def test_sac_act_step_in_one_launch_equals_act_then_step(SE, n):
     """hx_sac_act_step = hx_sac_act followed by hx_env_step (explore with given draws, with Philox, and exploit).  16,384 serpentine
     envs is BASELINE.json configs[2] at its own size: beyond 8,192 envs the entry point issues the two launches itself, and the
