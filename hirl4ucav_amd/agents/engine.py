@@ -27,7 +27,12 @@ class HxSample(ctypes.Structure):
     """the minibatch draw as a description (include/hirl4ucav.h HxSample): launch A of the update draws and gathers"""
     _fields_ = [("total", _vp), ("cap", ctypes.c_int64), ("ring", _vp), ("expert_ring", _vp), ("expert_len", ctypes.c_int64),
                 ("bc_table", _vp), ("bc_len", ctypes.c_int64), ("n_main", _i32), ("seed", ctypes.c_uint64), ("call", ctypes.c_uint32),
-                ("sigma", _f32), ("idx", _vp), ("idx_bc", _vp)]
+                ("sigma", _f32), ("idx", _vp), ("idx_bc", _vp), ("guard", ctypes.c_uint32)]
+
+
+class HxFront(ctypes.Structure):
+    """in-launch hand-off state of the front launch (include/hirl4ucav.h HxFront)"""
+    _fields_ = [("total_snap", _vp), ("flags", _vp), ("status", _vp), ("epoch", ctypes.c_uint32)]
 
 
 class HxNets(ctypes.Structure):
@@ -213,6 +218,9 @@ class OneShotExchange:
 _lib.register("hx_bc_train_actor", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _vp])
 _lib.register("hx_hirl_learn", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp])
 _lib.register("hx_hirl_learn_sampled", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp])
+_lib.register("hx_hirl_front", [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, _vp,
+                                 _P(_lib.HxStepOpts), _P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _i32, _i32, _P(HxFront), _vp])
+_lib.register("hx_hirl_learn_back", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _P(HxFront), _vp])
 _lib.register("hx_hirl_critic_grads_sampled", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _i32, _vp])
 _lib.register("hx_sample_batch", [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _i32, _i32, _i32, ctypes.c_uint64,
                                    ctypes.c_uint32, _f32, _vp, _vp, _vp, _vp, _vp, _vp])
@@ -298,6 +306,9 @@ class HirlEngine:
         self.soft_count = self.soft_count[:1]
         self.sample_calls = 0
         self._pending = None  # a draw sample(defer=True) recorded for the next learn()
+        self._front = None     # step_learn: (total_snap int64[1], flags int32[16], status int32[1]) + the epoch counter
+        self._front_epoch = 0
+        self._front_mark = None  # (env, env.steps_issued) at which total_snap was taken
         self.nets = HxNets(*(t.data_ptr() for t in (self.actor, self.critic, self.target_actor, self.target_critic, self.bc_actor,
                                                      self.grad_actor, self.grad_critic, self.m_actor, self.v_actor, self.m_critic,
                                                      self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None, None, None, None, None)
@@ -497,6 +508,7 @@ class HirlEngine:
         elif sigma > 0:
             mode = 3
         self.act_calls += 1
+        env.steps_issued += 1
         if self.act_dtype == "bf16":
             _lib.call("hx_actor_act_step_bf16", self.actor.data_ptr(), self.w2_bf16.data_ptr(), env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(),
                       out.data_ptr(), mode | self._mode_bits, _lib.ptr(noise), float(sigma), int(seed), int(env.env_id0), self.act_calls, self.slope,
@@ -668,6 +680,70 @@ class HirlEngine:
                     _lib.call("hx_hirl_actor_wgrad", nets, hyper, B, B, w_kind, w_given, float(bc_warm_up_weight), st)
                     _lib.call("hx_adam", nets, hyper, 1 | pk, self.actor_step, gs, w_kind, w_given, float(bc_warm_up_weight), B, st)
         self.actor_trainable = not self.actor_trainable  # HIRL.py:332
+
+    def step_learn(self, env, expert=None, bc_table=None, n_main=None, act_noise=None, act_sigma=0.0, act_seed=0, out=None, sample_seed=0,
+                   smooth_sigma=0.2, bc_weight_now=0.0, bc_warm_up_weight=0.0):
+        """One iteration of the vector loop — act_step(env) then sample(env.replay, ..., defer=True) then learn() — in FRONT form
+        (include/hirl4ucav.h hx_hirl_front): the env step and the first two launches of learn() are ONE launch, the acting workgroups on half of
+        the CUs, the update's on the other half.  The one change of meaning: the minibatch is drawn from the ring as it stood BEFORE this env
+        step, without the env.n slots the step may overwrite (uniform over every transition that is in the buffer before and after the step).
+        fp32 networks on one GPU, at most 8,192 envs, batch <= 256.  -> (actions, obs, reward, done, success) as act_step."""
+        replay, n, B = env.replay, env.n, self.batch
+        if self.staged or self.world > 1 or self.act_dtype != "f32" or self.nets.w2_bf16_all or self._x9_for(n) or replay is None:
+            raise _lib.HxError("step_learn: the front launch exists for the one-call fp32 path on one GPU with a replay ring attached to the env "
+                               "(set_act_dtype('f32'), x9_rows = None / n below it)")
+        if self._pending is not None:
+            raise _lib.HxError("step_learn draws its own minibatch: a sample(defer=True) is still pending")
+        if self._front is None:
+            buf = torch.zeros(24, dtype=torch.int64, device=self.device)
+            self._front = (buf[0:1], buf[8:16].view(torch.int32), buf[16:17].view(torch.int32)[:1])
+        snap, flags, status = self._front
+        if self._front_mark != (env, env.steps_issued):  # the ring moved since the snapshot (or there is none yet): take it now
+            snap.copy_(replay.total)
+        if out is None:
+            out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        mode = 0
+        if act_noise is not None:
+            mode = 1 if act_noise.numel() == 4 else 2
+        elif act_sigma > 0:
+            mode = 3
+        self.act_calls += 1
+        self.sample_calls += 1
+        self._front_epoch += 1
+        smp = HxSample(replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(), expert.ring.data_ptr() if expert is not None else None,
+                       len_of(expert), _lib.ptr(bc_table), bc_table.shape[0] if bc_table is not None else 0, B if n_main is None else int(n_main),
+                       int(sample_seed), self.sample_calls, float(smooth_sigma), self._idx.data_ptr(),
+                       self._idx_bc.data_ptr() if bc_table is not None else None, 0)
+        front = HxFront(snap.data_ptr(), flags.data_ptr(), status.data_ptr(), self._front_epoch)
+        batch = HxBatch(self.rows.data_ptr(), self.bc_rows.data_ptr() if self.use_bc else None, B, self._noise.data_ptr())
+        nets, hyper, st = ctypes.byref(self.nets), ctypes.byref(self.hyper), _lib.stream_ptr()
+        if bc_weight_now is None:
+            w_kind, w_given = 2, 0.0
+        elif bc_weight_now == 100:
+            w_kind, w_given = 1, 0.0
+        else:
+            w_kind, w_given = 0, float(bc_weight_now)
+        actor_phase = self.actor_trainable  # HIRL.py:291
+        self.critic_step += 1
+        if actor_phase:
+            self.actor_step += 1
+            self.update_count += 1
+        do_polyak = actor_phase and self.update_count % self.target_update_freq == 0  # HIRL.py:327-330
+        _lib.call("hx_hirl_front", self.w2_f32i.data_ptr(), env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(), out.data_ptr(), mode | self._mode_bits,
+                  _lib.ptr(act_noise), float(act_sigma), int(act_seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(), env.done.data_ptr(),
+                  env.success.data_ptr(), ctypes.byref(env._opts), nets, ctypes.byref(batch), hyper, ctypes.byref(smp), int(actor_phase), w_kind,
+                  ctypes.byref(front), st)
+        env.steps_issued += 1
+        _lib.call("hx_hirl_learn_back", nets, ctypes.byref(batch), hyper, self.critic_step, int(actor_phase), self.actor_step, int(do_polyak), w_kind, w_given,
+                  float(bc_warm_up_weight), replay.total.data_ptr(), ctypes.byref(front), st)
+        self._front_mark = (env, env.steps_issued)
+        self.actor_trainable = not self.actor_trainable  # HIRL.py:332
+        return out, env.obs, env.reward, env.done, env.success
+
+    def front_check(self):
+        """Raise if a workgroup of a front launch ever gave up waiting for its producers (synchronises)."""
+        if self._front is not None and int(self._front[2].item()) != 0:
+            raise _lib.HxError("front launch: an in-launch wait for the target actor's rows timed out (status word set)")
 
     def bc_train_actor(self):
         """BC.Agent.train_actor (BC.py:160-185) on the BC minibatch last assembled: mse, backward, Adam on the actor."""

@@ -199,4 +199,16 @@ constexpr int64_t kFuseEnvMax = 8192;
 // Returns false when no persistent instantiation covers the request (the caller falls back to act_fused_kernel).
 bool launch_act_persist(const ActFusedArgs& H, bool gauss, hipStream_t st);
 
+// the buffers and options of an env step that rides in an acting launch (hx_*_act_step*, hx_hirl_front)
+inline int check_step_args(const float* state, int64_t n, int64_t stride, const float* obs_io, const float* actions, const float* reward,
+                           const uint8_t* done, const int8_t* success, const HxStepOpts& o, const char* who) {
+    HX_REQUIRE(state && obs_io && actions && reward && done && success && n > 0 && stride >= n, "%s: bad buffers", who);
+    HX_REQUIRE(n < (int64_t)1 << 31, "%s: at most 2^31 - 1 envs per launch", who);
+    HX_REQUIRE(!o.auto_reset || o.episode_ctr, "%s: auto_reset needs episode_ctr", who);
+    HX_REQUIRE(stride < ((int64_t)1 << 25), "%s: stride must be below 2^25 envs", who);
+    HX_REQUIRE(!o.ring || (o.cap >= 512 && o.cap < ((int64_t)1 << 31) && o.total && (reinterpret_cast<uintptr_t>(o.ring) & 15u) == 0),
+               "%s: ring needs 512 <= cap < 2^31, total and 16-byte alignment", who);
+    return 0;
+}
+
 }  // namespace hxact

@@ -1,0 +1,101 @@
+// hx_front.hip — the FRONT launch (gfx950): the env step of a vector loop and the first two launches of the learn() call that follows it, as ONE launch.
+//   chooseAction + HarfangEnv.step + memory.store   hirl/train_all.py:343-348   -> the acting workgroups (act_fused_body, hx_act_body.h: 32 rows each)
+//   Agent.learn up to the TD target's inputs        hirl/agents/HIRL.py:259-272 -> launch A (draw + gather, targetActor(s'), Q1/Q2(s, a)) and launch B
+//                                                                                  (targetCritic Q1/Q2) as further workgroups (fwd_l2_body, hx_fwd_body.h)
+// Why: every kernel of the step is 1,024 threads x up to 128 registers — one workgroup per CU — so a launch is as long as its longest workgroup
+// chain.  At 4,096 envs the acting launch is 256 workgroups x 16 rows (20.5 us) and launches A + B another 17 us behind it, although they need
+// nothing the env step computes (the draw aside).  With 32 rows per acting workgroup the step takes 128 CUs for ~26 us (tools/ubench/merge_probe.sh)
+// and launches A (192-256 workgroups) and B (128-256) run on the other 128 CUs in that shadow.  B needs A's target-actor rows: it waits for them
+// IN the launch, per row tile (FrontSync, hx_fwd_body.h) — off the critical path here, because A is through long before the acting workgroups are.
+// Workgroups are dispatched in index order: acting first (the longest), then A (job 0 = the target actor first), then B.
+// The draw's meaning changes (it cannot see this step's inserts and must not read the slots they overwrite): include/hirl4ucav.h hx_hirl_front.
+#include <hip/hip_ext.h>
+
+#include "hx_act_body.h"
+#include "hx_fwd_body.h"
+
+using namespace hxnn;
+using namespace hxu;
+using namespace hxact;
+
+namespace {
+
+struct FrontCtl {
+    int n_act;         // acting workgroups (32 rows each)
+    int n_a, per_a;    // launch A: workgroups, workgroups per job (row tiles x column workgroups)
+    int per_b;         // launch B: workgroups per job
+    FrontSync sync;
+};
+
+// BNT: launch B's column tiling, chosen as launch_fwd chooses it (32 columns per workgroup for two nets, 64 beyond): same K-split, same bits
+template <bool RELU, int BNT>
+__global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArgsC FA, SampleDev SA, FwdArgsC FB, FrontCtl C) {
+    typedef ActLds<2, true, false, true, false> LdsAct;
+    typedef FwdLds<kNT, true, false> LdsA;
+    typedef FwdLds<BNT, false, false> LdsB;
+    __shared__ union {
+        LdsAct act;
+        LdsA a;
+        LdsB b;
+    } u;
+    int b = (int)blockIdx.x;
+    if (b < C.n_act) {
+        act_fused_body<2, false, true, false, RELU, true, false>(H, b, u.act);
+        return;
+    }
+    b -= C.n_act;
+    if (b < C.n_a) {
+        fwd_l2_body<kNT, RELU, true, false, 1>(FA, SA, b % C.per_a, b / C.per_a, u.a, C.sync);
+        return;
+    }
+    b -= C.n_a;
+    fwd_l2_body<BNT, RELU, false, false, 2>(FB, SA, b % C.per_b, b / C.per_b, u.b, C.sync);
+}
+
+}  // namespace
+
+namespace hxu {
+
+int launch_front(const float* actor, const float* w2f, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+                 const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward, uint8_t* done, int8_t* success,
+                 const HxStepOpts& o, const FwdArgs& FA, const FwdArgs& FB, const HxFront& front, hipStream_t st) {
+    HX_REQUIRE(actor && w2f && (reinterpret_cast<uintptr_t>(w2f) & 15u) == 0, "hx_hirl_front: the actor and the 16-byte aligned fp32 image of its W2");
+    const Mlp mA{13, 4, (noise_mode & 16) ? 1 : 0};  // + 16: layerNorm = False (as hx_actor_act_step)
+    noise_mode &= 15;
+    HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_hirl_front: bad noise mode");
+    if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_hirl_front")) return rc;
+    HX_REQUIRE(n <= kFuseEnvMax, "hx_hirl_front: at most 8,192 envs (one round of 32-row acting workgroups)");
+    HX_REQUIRE(FA.sample && FA.njobs >= 3 && FB.njobs >= 2, "hx_hirl_front: launch A draws the minibatch");
+    ActFusedArgs H{actor, mA, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
+                   noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
+                   o.cap > 0 ? 1.0 / (double)o.cap : 0.0, nullptr, w2f, 0};
+    FwdArgsC CA{}, CB{};
+    for (int j = 0; j < FA.njobs; ++j) { CA.job[j] = pack_fwd(FA.job[j]); CA.job[j].slope = FA.slope; }
+    for (int j = 0; j < FB.njobs; ++j) { CB.job[j] = pack_fwd(FB.job[j]); CB.job[j].slope = FB.slope; }
+    CA.slope = FA.slope; CA.zero_nf = FA.zero_nf; CA.zero_f = FA.zero_f; CA.zero_i = FA.zero_i; CA.images = nullptr; CA.rowmap = 1;
+    CB.slope = FB.slope; CB.zero_nf = FB.zero_nf; CB.zero_f = FB.zero_f; CB.zero_i = FB.zero_i; CB.images = nullptr; CB.rowmap = 1;
+    const int rows = FA.job[0].rows, tiles = (rows + RT - 1) / RT;
+    // launch B's tiling as launch_fwd picks it for the same job list (one or two nets at B = 128: 32-column workgroups)
+    const int b_tiles = tiles * FB.njobs;
+    HX_REQUIRE(b_tiles < 128, "hx_hirl_front: minibatches of at most 256 rows");
+    const bool b32 = b_tiles * (H2 / 32) <= 256;
+    const int bnt = b32 ? 32 : kNT;
+    FrontCtl C{};
+    C.n_act = (int)((n + 2 * RT - 1) / (2 * RT));
+    C.per_a = tiles * (H2 / kNT); C.n_a = C.per_a * FA.njobs;
+    C.per_b = tiles * (H2 / bnt);
+    C.sync = FrontSync{front.flags, front.epoch * (uint32_t)(H2 / kNT), front.status};
+    HX_REQUIRE(tiles <= 16, "hx_hirl_front: at most 16 row tiles (HxFront.flags)");
+    const dim3 grid((unsigned)(C.n_act + C.n_a + C.per_b * FB.njobs));
+    const bool relu = slope == 0.0f;
+#define HX_FRONT(RELU_, BNT_) do { \
+        if (o.ev_start && o.ev_stop) hipExtLaunchKernelGGL((act_front_kernel<RELU_, BNT_>), grid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, *FA.sample, CB, C); \
+        else hipLaunchKernelGGL((act_front_kernel<RELU_, BNT_>), grid, dim3(kWide), 0, st, H, CA, *FA.sample, CB, C); } while (0)
+    if (relu) { if (b32) HX_FRONT(true, 32); else HX_FRONT(true, kNT); }
+    else { if (b32) HX_FRONT(false, 32); else HX_FRONT(false, kNT); }
+#undef HX_FRONT
+    HX_CHECK_LAUNCH("hx_hirl_front");
+    return 0;
+}
+
+}  // namespace hxu

@@ -59,57 +59,61 @@ static WgAdam make_adam(const HxNets* N, const HxHyper* Hy, float lr, int step, 
     return a;
 }
 
-// adam_step > 0: the critic's optimizer step (and, with polyak, the soft_update of its target) rides in the wgrad launch
-static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, void* stream, int adam_step, bool polyak,
-                             const HxSample* S = nullptr) {
-    HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_critic_grads: batch must be a positive multiple of 16");
-    hipStream_t st = (hipStream_t)stream;
+// launch A: targetActor(s'), critic Q1/Q2 (s, a)  [+ actor(s) on an actor call]
+static void make_launch_a(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, FwdArgs& F) {
     const Mlp mA{13, 4, Hy->no_layernorm ? 1 : 0}, mQ{17, 1, Hy->no_layernorm ? 1 : 0};  // layerNorm = False: HIRL.py:70-80,92-97,135-138
-    (void)mA; (void)mQ;
     const int B = Bt->batch;
-    SampleDev SD{};
-    bool fused = false;
-    if (S) {  // the minibatch is drawn by this call: inside launch A (batch <= 256) or by the sampling launch first
-        HX_REQUIRE(Bt->noise, "hx_hirl_*_sampled: the draw needs the output word noise[4]");
-        if (int rc = prepare_draw(S, B, const_cast<float*>(Bt->rows), const_cast<float*>(Bt->bc_rows), const_cast<float*>(Bt->noise), stream, &SD, &fused)) return rc;
+    Slot s[S_COUNT];
+    make_slots(N, B, s);
+    const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
+    F = FwdArgs{};
+    F.njobs = 3; F.slope = Hy->slope;
+    F.zero_f = N->losses; F.zero_nf = 1;  // critic_loss accumulator
+    F.job[0] = FwdJob{N->target_actor, mA, src, 17, 0, Head{}, nullptr, 0.f, s[S_TA], B, 0, IM_TA};
+    F.job[1] = FwdJob{N->critic, mQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C1], B, 1, IM_C1};
+    F.job[2] = FwdJob{N->critic + mQ.padded(), mQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C2], B, 1, IM_C2};
+    if (actor_fwd) {  // the delayed actor step's forwards ride along, split so that NEITHER launch exceeds 256 workgroups
+        F.zero_nf = 5; F.zero_i = N->soft_count;  // + actor / bc / rl / bc_fire accumulators and the soft count
+        F.job[3] = FwdJob{N->actor, mA, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1, IM_ACTOR};
+        F.njobs = 4;
     }
+    F.images = N->w2_bf16_all;
+}
+// launch B: targetCritic Q1/Q2 (s', clamp(targetActor(s') + clamp(noise)))  [+ actor(s_bc), bc_actor(s)]
+static void make_launch_b(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, FwdArgs& F) {
+    const Mlp mA{13, 4, Hy->no_layernorm ? 1 : 0}, mQ{17, 1, Hy->no_layernorm ? 1 : 0};
+    const int B = Bt->batch;
     Slot s[S_COUNT];
     make_slots(N, B, s);
     const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
     const float* tc1 = N->target_critic;
     const float* tc2 = N->target_critic + mQ.padded();
-    {   // launch A: targetActor(s'), critic Q1/Q2 (s, a)
-        FwdArgs F{};
-        F.njobs = 3; F.slope = Hy->slope;
-        F.zero_f = N->losses; F.zero_nf = 1;  // critic_loss accumulator
-        F.job[0] = FwdJob{N->target_actor, mA, src, 17, 0, Head{}, nullptr, 0.f, s[S_TA], B, 0, IM_TA};
-        F.job[1] = FwdJob{N->critic, mQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C1], B, 1, IM_C1};
-        F.job[2] = FwdJob{N->critic + mQ.padded(), mQ, src, 0, 0, Head{}, nullptr, 0.f, s[S_C2], B, 1, IM_C2};
-        if (actor_fwd) {  // the delayed actor step's forwards ride along, split so that NEITHER launch exceeds 256 workgroups
-            F.zero_nf = 5; F.zero_i = N->soft_count;  // + actor / bc / rl / bc_fire accumulators and the soft count
-            F.job[3] = FwdJob{N->actor, mA, src, 0, 0, Head{}, nullptr, 0.f, s[S_API], B, 1, IM_ACTOR};
-            F.njobs = 4;
-        }
-        F.sample = fused ? &SD : nullptr;
-        F.images = N->w2_bf16_all;
-        launch_fwd(F, st);
+    F = FwdArgs{};
+    F.njobs = 2; F.slope = Hy->slope;
+    const Head prev{N->target_actor, mA, s[S_TA]};
+    F.job[0] = FwdJob{tc1, mQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC1], B, 0, IM_TC1};
+    F.job[1] = FwdJob{tc2, mQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC2], B, 0, IM_TC2};
+    if (actor_fwd && Hy->use_bc) {
+        const RowSrc bcsrc{Bt->bc_rows ? Bt->bc_rows : Bt->rows, nullptr, nullptr, 0, 32};
+        int n = 2;
+        F.job[n++] = FwdJob{N->actor, mA, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1, IM_ACTOR};
+        if (actor_fwd == 2) F.job[n++] = FwdJob{N->bc_actor, mA, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0, IM_BC};
+        F.njobs = n;
     }
-    {   // launch B: targetCritic Q1/Q2 (s', clamp(targetActor(s') + clamp(noise)))  [+ actor(s_bc), bc_actor(s)]
-        FwdArgs F{};
-        F.njobs = 2; F.slope = Hy->slope;
-        const Head prev{N->target_actor, mA, s[S_TA]};
-        F.job[0] = FwdJob{tc1, mQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC1], B, 0, IM_TC1};
-        F.job[1] = FwdJob{tc2, mQ, src, 17, 1, prev, Bt->noise, Hy->noise_clamp, s[S_TC2], B, 0, IM_TC2};
-        if (actor_fwd && Hy->use_bc) {
-            const RowSrc bcsrc{Bt->bc_rows ? Bt->bc_rows : Bt->rows, nullptr, nullptr, 0, 32};
-            int n = 2;
-            F.job[n++] = FwdJob{N->actor, mA, bcsrc, 0, 0, Head{}, nullptr, 0.f, s[S_ABC], B, 1, IM_ACTOR};
-            if (actor_fwd == 2) F.job[n++] = FwdJob{N->bc_actor, mA, src, 0, 0, Head{}, nullptr, 0.f, s[S_BCS], B, 0, IM_BC};
-            F.njobs = n;
-        }
-        F.images = N->w2_bf16_all;
-        launch_fwd(F, st);
-    }
+    F.images = N->w2_bf16_all;
+}
+// launches C and D: y, loss, dq, LN2 backward, dh1 for both heads; all critic parameter gradients.
+// adam_step > 0: the critic's optimizer step (and, with polyak, the soft_update of its target) rides in the wgrad launch
+static int critic_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, void* stream, int adam_step, bool polyak, const uint64_t* snap_src = nullptr,
+                       uint64_t* snap_dst = nullptr) {
+    hipStream_t st = (hipStream_t)stream;
+    const Mlp mQ{17, 1, Hy->no_layernorm ? 1 : 0};
+    const int B = Bt->batch;
+    Slot s[S_COUNT];
+    make_slots(N, B, s);
+    const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
+    const float* tc1 = N->target_critic;
+    const float* tc2 = N->target_critic + mQ.padded();
     {   // launch C: y, loss, dq, LN2 backward, dh1 for both heads
         BwdArgs G{};
         G.njobs = 2; G.slope = Hy->slope; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = N->soft_count;
@@ -121,6 +125,7 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
             J.img_t = IM_C1_T + h;
         }
         G.images = N->w2_bf16_all;
+        G.snap_src = (const unsigned long long*)snap_src; G.snap_dst = (unsigned long long*)snap_dst;
         launch_bwd(0, G, st);
     }
     {   // launch D: all critic parameter gradients
@@ -151,6 +156,25 @@ static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* 
     }
     HX_CHECK_LAUNCH("hx_hirl_critic_grads");
     return 0;
+}
+static int critic_grads_impl(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, void* stream, int adam_step, bool polyak,
+                             const HxSample* S = nullptr) {
+    HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_critic_grads: batch must be a positive multiple of 16");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = Bt->batch;
+    SampleDev SD{};
+    bool fused = false;
+    if (S) {  // the minibatch is drawn by this call: inside launch A (batch <= 256) or by the sampling launch first
+        HX_REQUIRE(Bt->noise, "hx_hirl_*_sampled: the draw needs the output word noise[4]");
+        if (int rc = prepare_draw(S, B, const_cast<float*>(Bt->rows), const_cast<float*>(Bt->bc_rows), const_cast<float*>(Bt->noise), stream, &SD, &fused)) return rc;
+    }
+    FwdArgs F;
+    make_launch_a(N, Bt, Hy, actor_fwd, F);
+    F.sample = fused ? &SD : nullptr;
+    launch_fwd(F, st);
+    make_launch_b(N, Bt, Hy, actor_fwd, F);
+    launch_fwd(F, st);
+    return critic_back(N, Bt, Hy, stream, adam_step, polyak);
 }
 int hx_hirl_critic_grads(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_fwd, void* stream) {
     return critic_grads_impl(N, Bt, Hy, actor_fwd, stream, 0, false);
@@ -320,6 +344,44 @@ int hx_hirl_learn_sampled(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy,
                           int32_t actor_step, int32_t do_polyak, int32_t w_kind, float w_given, float warm, void* stream) {
     HX_REQUIRE(critic_step >= 1 && (!actor_phase || actor_step >= 1), "hx_hirl_learn: Adam steps are 1-based");
     int rc = critic_grads_impl(N, Bt, Hy, actor_phase ? (w_kind == 1 ? 2 : 1) : 0, stream, critic_step, do_polyak != 0, S);
+    if (rc || !actor_phase) return rc;
+    if ((rc = hx_hirl_actor_backward(N, Bt, Hy, w_kind == 1, 1, stream))) return rc;
+    return actor_wgrad_impl(N, Hy, Bt->batch, Bt->batch, w_kind, w_given, warm, stream, actor_step, do_polyak != 0);
+}
+
+/* hx_hirl_learn_sampled in two parts around an env step (include/hirl4ucav.h "front launch"): hx_hirl_front = chooseAction + env step + replay insert of
+ * n envs AND launches A and B of the learn() call that follows, as workgroups of ONE launch (hx_front.hip); hx_hirl_learn_back = the rest of that call. */
+int hx_hirl_front(const float* actor_w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode, const float* noise,
+                  float sigma, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts,
+                  const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t actor_phase, int32_t w_kind, const HxFront* front,
+                  void* stream) {
+    HX_REQUIRE(N && Bt && Hy && S && front && opts && Bt->batch > 0 && Bt->batch % 16 == 0 && Bt->batch <= kFusedBatchMax,
+               "hx_hirl_front: the minibatch is a positive multiple of 16 rows, at most 256, drawn inside the launch");
+    HX_REQUIRE(Bt->noise && front->total_snap && front->flags && front->status && front->epoch >= 1, "hx_hirl_front: noise[4], total_snap, flags, status and a 1-based epoch are required");
+    HX_REQUIRE(!N->w2_bf16_all && actor_w2_f32i, "hx_hirl_front: fp32 networks with the fp32 image of the actor's W2 (the bf16 update path runs its launches one by one)");
+    HX_REQUIRE(opts->ring && S->ring == opts->ring && S->cap == opts->cap && S->total == opts->total,
+               "hx_hirl_front: the draw and the env step's insert must name the same replay ring");
+    HX_REQUIRE(n > 0 && 2 * n <= S->cap, "hx_hirl_front: the ring must hold at least 2 n rows");
+    const int actor_fwd = actor_phase ? (w_kind == 1 ? 2 : 1) : 0;
+    SampleDev SD{};
+    bool fused = false;
+    HxSample Sg = *S;
+    Sg.total = front->total_snap;  // the draw reads the ring as it stood BEFORE this launch's env step ...
+    if (int rc = prepare_draw(&Sg, Bt->batch, const_cast<float*>(Bt->rows), const_cast<float*>(Bt->bc_rows), const_cast<float*>(Bt->noise), stream, &SD, &fused)) return rc;
+    SD.guard = (uint32_t)n;        // ... and leaves out the slots that step may overwrite
+    FwdArgs FA, FB;
+    make_launch_a(N, Bt, Hy, actor_fwd, FA);
+    FA.sample = &SD;
+    make_launch_b(N, Bt, Hy, actor_fwd, FB);
+    return launch_front(N->actor, actor_w2_f32i, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed, row0, call, Hy->slope, reward, done, success,
+                        *opts, FA, FB, *front, (hipStream_t)stream);
+}
+int hx_hirl_learn_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t critic_step, int32_t actor_phase, int32_t actor_step, int32_t do_polyak,
+                       int32_t w_kind, float w_given, float warm, const uint64_t* total, const HxFront* front, void* stream) {
+    HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_learn_back: batch must be a positive multiple of 16");
+    HX_REQUIRE(critic_step >= 1 && (!actor_phase || actor_step >= 1), "hx_hirl_learn_back: Adam steps are 1-based");
+    HX_REQUIRE(!front || (front->total_snap && total), "hx_hirl_learn_back: the snapshot needs the ring's total and total_snap");
+    int rc = critic_back(N, Bt, Hy, stream, critic_step, do_polyak != 0, front ? total : nullptr, front ? front->total_snap : nullptr);
     if (rc || !actor_phase) return rc;
     if ((rc = hx_hirl_actor_backward(N, Bt, Hy, w_kind == 1, 1, stream))) return rc;
     return actor_wgrad_impl(N, Hy, Bt->batch, Bt->batch, w_kind, w_given, warm, stream, actor_step, do_polyak != 0);

@@ -158,6 +158,11 @@ struct Head {  // a previous net whose output is (part of) this net's input
 // ---------------------------------------------------------------------------------------------------------------
 // row helpers: a wave owns one row; lane holds n = (i*64 + lane)*4 + c  (i < PER4, c < 4): 16-B coalesced loads
 // ---------------------------------------------------------------------------------------------------------------
+// agent-scope relaxed accesses: data handed from one workgroup to another INSIDE a launch (hx_front.hip) goes past the non-coherent levels with
+// these and needs no fence (tools/ubench/handoff_probe.hip: a release / acquire fence costs a cache write-back / invalidate on this machine)
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <int N>
 struct RowReg {
     static constexpr int PER4 = N / 256;
@@ -170,6 +175,13 @@ struct RowReg {
             v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
         }
     }
+    __device__ __forceinline__ void load_agent(const float* p) {  // the same elements through agent-scope loads
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < PER4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[4 * i + c] = ld_agent(p + (i * 64 + lane) * 4 + c);
+    }
     __device__ __forceinline__ void store(float* __restrict__ p) const {
         const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -181,11 +193,12 @@ struct RowReg {
 
 // head of an MLP block for ONE row held by a wave: LN2 stats of z2, h2 = act(LN2(z2)), o[j] = h2 . W3[j] + b3[j].
 // Leaves xhat and y (pre-activation) in registers for the backward prologue.
-template <int OUTMAX, bool RELU>
+template <int OUTMAX, bool RELU, bool AGENT = false>
 __device__ __forceinline__ void head_row(const float* __restrict__ z2row, const float* __restrict__ net, const Mlp m, float slope,
                                          RowReg<H2>& xhat, RowReg<H2>& y, float& mean, float& rstd, float (&o)[OUTMAX]) {
     RowReg<H2> z, g, be;
-    z.load(z2row);
+    if (AGENT) z.load_agent(z2row);
+    else z.load(z2row);
     row_stats<8>(z.v, H2, mean, rstd);
     if (m.no_ln) { mean = 0.0f; rstd = 1.0f; }
     g.load(net + m.g2());
@@ -213,11 +226,12 @@ __device__ __forceinline__ void head_row(const float* __restrict__ z2row, const 
 // rows one at a time under `if (j < m.out)`: dependent round trips to L2 on the critical path of a forward workgroup whose input action
 // is another net's output (-0.2 us per step; staging the 12 KB through LDS as bwd_l2 does costs a barrier more than it saves: +0.35 us).
 // Same arithmetic in the same order: same bits.
-template <bool RELU>
+template <bool RELU, bool AGENT = false>
 __device__ __forceinline__ void head_row4(const float* __restrict__ z2row, const float* __restrict__ net, const Mlp m, float slope,
                                           RowReg<H2>& xhat, RowReg<H2>& y, float& mean, float& rstd, float (&o)[4]) {
     RowReg<H2> z, g, be, w0, w1, w2, w3;
-    z.load(z2row);
+    if (AGENT) z.load_agent(z2row);
+    else z.load(z2row);
     g.load(net + m.g2());
     be.load(net + m.be2());
     w0.load(net + m.W3());
@@ -277,7 +291,48 @@ struct SampleDev {
     uint32_t call;
     uint64_t seed;
     float sigma;
+    // guard > 0 (hx_front.hip: the draw runs BESIDE the env step of the same launch): `total` points at a snapshot taken before that env step and the
+    // `guard` ring slots the step may overwrite are not drawn — the population is every transition that is in the ring before AND after the step
+    // (slot_of_draw below); 0: UniformMemory.sample over the whole buffer (buffer.py:45)
+    uint32_t guard;
 };
+// draw k of `live` -> ring slot.  Without a guard the slot IS the draw.  With one, the window [h, h + guard) mod cap behind the ring head h is left out:
+// its wrapped part [0, e0) shifts every draw up, and a draw at or beyond h jumps the rest of the window.
+struct DrawMap {
+    uint32_t live, e0, h, jump;
+};
+__device__ __forceinline__ DrawMap draw_map(unsigned long long tot, unsigned long long cap, uint32_t guard) {
+    DrawMap m;
+    if (tot < cap) {
+        const unsigned long long over = tot + guard > cap ? tot + guard - cap : 0ull;
+        m.e0 = (uint32_t)(over < tot ? over : tot);
+        m.live = (uint32_t)tot - m.e0;
+        m.h = 0xFFFFFFFFu; m.jump = 0u;
+    } else {
+        const uint32_t g = guard < cap ? guard : (uint32_t)cap;
+        m.h = (uint32_t)(tot % cap);
+        const unsigned long long over = (unsigned long long)m.h + g > cap ? (unsigned long long)m.h + g - cap : 0ull;
+        m.e0 = (uint32_t)over;
+        m.live = (uint32_t)cap - g;
+        m.jump = g - m.e0;
+        if (g == 0u) m.h = 0xFFFFFFFFu;
+    }
+    return m;
+}
+__device__ __forceinline__ uint32_t slot_of_draw(const DrawMap& m, uint32_t k) {
+    uint32_t s = k + m.e0;
+    if (s >= m.h) s += m.jump;
+    return s;
+}
+// the (4,) target-smoothing draw of a learn() call, HIRL.py:265 (sample_kernel's arithmetic): component k
+template <typename S>
+__device__ __forceinline__ float smoothing_noise(const S& SA, int k) {
+    uint32_t uu[4];
+    philox4x32_10(0xFFFFFFF0u, SA.call, 2u, 0u, (uint32_t)SA.seed, (uint32_t)(SA.seed >> 32), uu);
+    const float ua = u01(uu[k & 2]), ub = u01(uu[(k & 2) + 1]);
+    const float rad = sqrtf(-2.0f * __logf(ua)), ang = 6.28318530717958647692f * ub;
+    return SA.sigma * ((k & 1) ? rad * __sinf(ang) : rad * __cosf(ang));
+}
 constexpr int kFusedSlots = 1024, kFusedBatchMax = 256;
 __device__ __forceinline__ uint32_t fused_hash(uint32_t k) { return (k * 2654435761u) >> 22; }  // top 10 bits
 
@@ -285,7 +340,8 @@ __device__ __forceinline__ void draw_fused(const SampleDev& S, int B, uint32_t (
     const int tid = threadIdx.x;
     const int t = tid & 511, stream = tid >> 9;  // 0: replay / expert rows, 1: BC rows
     const unsigned long long tot = *S.total;
-    const uint32_t len_main = (uint32_t)(tot < (unsigned long long)S.cap ? tot : (unsigned long long)S.cap);
+    const DrawMap dm = draw_map(tot, (unsigned long long)S.cap, S.guard);
+    const uint32_t len_main = dm.live;
     const uint32_t k0 = (uint32_t)S.seed, k1 = (uint32_t)(S.seed >> 32);
     const bool live = (stream == 0 || S.idx_bc != nullptr) && t < B;
     const bool main_grp = t < S.n_main;
@@ -321,7 +377,7 @@ __device__ __forceinline__ void draw_fused(const SampleDev& S, int B, uint32_t (
         }
         if (!__syncthreads_or(dup)) break;
     }
-    if (live) fin[stream][t] = (int)(key & 0x7FFFFFFFu);
+    if (live) fin[stream][t] = (stream == 0 && main_grp) ? (int)slot_of_draw(dm, key & 0x7FFFFFFFu) : (int)(key & 0x7FFFFFFFu);
     __syncthreads();
 }
 
@@ -514,6 +570,8 @@ struct BwdArgs {
     float* losses;    // [8]: critic, actor, bc, rl, bc_fire, bc_weight, -, -
     int* soft_count;
     const uint16_t* images;  // nullptr: dh1 = dz2 W2 on fp32 MFMA; else the bf16 images: dz2 rounded to bf16, W2^T from its image
+    const unsigned long long* snap_src;  // hx_front.hip: *snap_dst = *snap_src (the ring's total between two env steps), or null
+    unsigned long long* snap_dst;
 };
 
 struct WgJob {
@@ -631,10 +689,11 @@ inline int prepare_draw(const HxSample* S, int B, float* rows, float* bc_rows, f
     HX_REQUIRE(S->n_main == B || S->expert_ring, "hx_*_sampled: expert rows requested without an expert ring");
     HX_REQUIRE(!S->bc_table == !S->idx_bc && (!S->bc_table || bc_rows), "hx_*_sampled: bc_table, idx_bc and bc_rows go together");
     *fused = B <= kFusedBatchMax;
+    HX_REQUIRE(!S->guard || *fused, "hx_*_sampled: HxSample.guard is honoured by the fused draw only (batch <= 256)");
     if (*fused) {
         *SD = SampleDev{(const unsigned long long*)S->total, S->ring, S->expert_ring ? S->expert_ring : S->ring, S->bc_table, rows,
                         S->bc_table ? bc_rows : nullptr, noise, S->idx, S->idx_bc, (long long)S->cap, (uint32_t)S->expert_len, (uint32_t)S->bc_len,
-                        S->n_main, S->call, S->seed, S->sigma};
+                        S->n_main, S->call, S->seed, S->sigma, S->guard};
         return 0;
     }
     return hx_sample_batch(S->total, S->cap, S->ring, S->expert_ring, S->expert_len, S->bc_table, S->bc_len, B, S->n_main, 1, S->seed, S->call,
@@ -645,6 +704,10 @@ inline int prepare_draw(const HxSample* S, int B, float* rows, float* bc_rows, f
 // launchers (defined beside their kernels)
 void launch_fwd(const FwdArgs& F, hipStream_t st);                          // hx_fwdbwd.hip
 void launch_bwd(int grp, const BwdArgs& G, hipStream_t st);                 // hx_fwdbwd.hip: grp = bwd_l2_kernel's GRP (0..3)
+// hx_front.hip: the act + env + insert workgroups of hx_actor_act_step_f32i (32 rows each) and the workgroups of launches A and B as ONE launch
+int launch_front(const float* actor, const float* w2f, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+                 const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward, uint8_t* done, int8_t* success,
+                 const HxStepOpts& o, const FwdArgs& FA, const FwdArgs& FB, const HxFront& front, hipStream_t st);
 void launch_wg(const WgArgs& W, bool adam, hipStream_t st);                 // hx_wgrad.hip: adam = the optimizer step rides in the launch
 void launch_adam(const AdamArgs& A, hipStream_t st);                        // hx_wgrad.hip
 void launch_polyak(float* target, const float* source, int n, float tau, float* target2, const float* source2, int n2, hipStream_t st,

@@ -46,6 +46,7 @@ class BatchedHarfangEnv:
         self.episode_ctr = torch.zeros(self.n, dtype=torch.int32, device=d)
         self.stats = torch.zeros((_lib.STAT_WAYS, _lib.STAT_PITCH), dtype=torch.int64, device=d) if collect_stats else None  # sum over dim 0: stats_dict()
         self.replay = replay
+        self.steps_issued = 0  # step launches so far (every path that may insert into `replay`): HirlEngine.step_learn checks its ring snapshot against it
         self.layout = int(layout)  # 0: the library picks the launch shape; _lib.layout(pair, envs_per_block) forces one (tests, tuning)
         self._opts = _lib.HxStepOpts()
         self._refresh_opts()
@@ -74,6 +75,7 @@ class BatchedHarfangEnv:
         """actions [N, 4] fp32 on the device -> (obs [N,13], reward [N], done [N] u8, success [N] i8)."""
         if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(self.device, torch.float32).contiguous()
+        self.steps_issued += 1
         _lib.call("hx_env_step", _lib.ptr(self.state), self.n, self.pitch, _lib.ptr(actions), _lib.ptr(self.obs),
                   _lib.ptr(self.reward), _lib.ptr(self.done), _lib.ptr(self.success), ctypes.byref(self._opts),
                   _lib.stream_ptr())
@@ -82,6 +84,7 @@ class BatchedHarfangEnv:
     def step_from(self, actions_ptr):
         """step() with the actions at a raw address the DEVICE can read — device memory, or pinned host memory it maps (the N = 1 facade
         passes its pinned action buffer: no upload call)."""
+        self.steps_issued += 1
         _lib.call("hx_env_step", _lib.ptr(self.state), self.n, self.pitch, actions_ptr, _lib.ptr(self.obs),
                   _lib.ptr(self.reward), _lib.ptr(self.done), _lib.ptr(self.success), ctypes.byref(self._opts),
                   _lib.stream_ptr())

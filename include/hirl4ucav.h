@@ -72,7 +72,7 @@ const char* hx_last_error(void);
 /* HX_ABI_VERSION of the library that is loaded.  The structs below are part of the ABI: a caller built against another header version must
  * not call in (round 3 widened HxStepOpts.stats from 9 to HX_STAT_WAYS * HX_STAT_PITCH words and appended fields to HxNets / HxHyper without
  * bumping this: a 9-word stats buffer then took atomics up to word 504).  110: round 4 (hx_abi_sizes, hx_rccl_*, hx_allreduce_twostage). */
-#define HX_ABI_VERSION 110
+#define HX_ABI_VERSION 111
 int hx_version(void);
 /* sizes[0..7] (host) <- sizeof HxStepOpts, HxNets, HxHyper, HxBatch, HxSample, HxSacNets, HxSacBatch, and the words of a statistics buffer
  * (HX_STAT_WAYS * HX_STAT_PITCH): a binding checks these against its own declarations at load time (hirl4ucav_amd/_lib.py does). */
@@ -331,12 +331,40 @@ typedef struct HxSample {
     int32_t n_main;                                          /* rows [0, n_main) from the main ring, the rest from the expert ring */
     uint64_t seed; uint32_t call; float sigma;               /* Philox4x32-10(seed; row, call); noise[4] = sigma N(0, 1) */
     int32_t* idx; int32_t* idx_bc;                           /* [batch] out (idx_bc NULL without a BC table) */
+    uint32_t guard;                                          /* 0: UniformMemory.sample over the whole buffer.  > 0 (fused draws only): the `guard`
+                                                              * slots behind the ring head *total are not drawn — see hx_hirl_front */
 } HxSample;
 /* hx_hirl_critic_grads / hx_hirl_learn with the minibatch drawn and gathered in their first launch (arguments as theirs + the draw). */
 int hx_hirl_critic_grads_sampled(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, const HxSample* sample, int32_t actor_fwd,
                                  void* stream);
 int hx_hirl_learn_sampled(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, const HxSample* sample, int32_t critic_step,
                           int32_t actor_phase, int32_t actor_step, int32_t do_polyak, int32_t w_kind, float w_given, float warm, void* stream);
+
+/* The FRONT launch (opt-in; fp32 networks): hx_actor_act_step_f32i for n envs (chooseAction + HarfangEnv.step + replay insert, train_all.py:343-345)
+ * AND the first two launches of the hx_hirl_learn_sampled call that follows it (minibatch draw + gather, targetActor(s'), Q1/Q2(s, a) [+ the actor
+ * call's forwards]; then targetCritic Q1/Q2 — HIRL.py:259-272) as workgroups of ONE launch: the acting workgroups take 32 rows each and so leave
+ * half of the CUs to the update's workgroups, which would otherwise wait for the env step to finish although they depend on nothing it computes
+ * EXCEPT the ring it inserts into.  Hence the one change of meaning: the minibatch is drawn from the ring as it stood BEFORE this env step
+ * (*total_snap), leaving out the n slots the step may overwrite — i.e. uniformly from every transition that is in the buffer both before and
+ * after the step (the reference draws after its one-transition append, buffer.py:45; at n envs per step the population differs by the newest
+ * and, once the ring is full, the oldest n transitions).  Bit-identical to hx_actor_act_step_f32i followed by hx_hirl_learn_sampled with
+ * HxSample.total = the snapshot and HxSample.guard = n.  The target critics wait IN the launch for the target actor's rows (per-row-tile
+ * counters `flags`, agent-scope relaxed accesses, bounded wait: bit 0 of *status is set if a wait gives up — workgroups are dispatched in
+ * index order and the producers come first, so that is a fault, not a schedule).
+ * hx_hirl_learn_back = the rest of the call (critic backward + gradients + Adam [+ the delayed actor step]); with `front` it also leaves
+ * *front->total_snap = *total for the next front launch (which must follow with no env step in between; otherwise copy it yourself). */
+typedef struct HxFront {
+    uint64_t* total_snap;  /* device word */
+    uint32_t* flags;       /* [16] device words, zero before the first use */
+    uint32_t* status;      /* device word, sticky */
+    uint32_t epoch;        /* 1, 2, 3, ... : one per front launch on these flags */
+} HxFront;
+int hx_hirl_front(const float* actor_w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+                  const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,
+                  const HxStepOpts* opts, const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, const HxSample* sample,
+                  int32_t actor_phase, int32_t w_kind, const HxFront* front, void* stream);
+int hx_hirl_learn_back(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, int32_t critic_step, int32_t actor_phase, int32_t actor_step,
+                       int32_t do_polyak, int32_t w_kind, float w_given, float warm, const uint64_t* total, const HxFront* front, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------------------------

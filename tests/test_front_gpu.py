@@ -1,0 +1,169 @@
+"""The FRONT launch (hx_hirl_front + hx_hirl_learn_back, HirlEngine.step_learn): the env step of a vector loop and the first two launches of the
+learn() call behind it as ONE launch, the target critics waiting in-launch for the target actor's rows.
+
+Parity statement: one step_learn == act_step, then learn() on a minibatch drawn with HxSample.total = the ring's total BEFORE the env step and
+HxSample.guard = n (the slots the step may overwrite left out) — bit for bit in everything both leave behind: actions, env state words,
+observations, rewards, episode counters, the replay rows (as a multiset: ring slots are handed out by an atomic), drawn indices, smoothing noise,
+row tiles, networks, Adam moments; loss sums to 1e-6 (they are accumulated with atomics).  Checked step by step from shared states over rings that
+fill up and wrap, HIRL (soft / fixed weights, BC minibatch, expert rows) and TD3, ReLU and leaky networks.  The draw rule itself is checked against
+a restatement on the host (allowed slots, no replacement)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from tests import _hirl_data as D  # noqa: E402
+
+NETS = ("actor", "critic", "target_actor", "target_critic", "m_actor", "v_actor", "m_critic", "v_critic")
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from hirl4ucav_amd.agents import engine
+
+    return engine
+
+
+def allowed_slots(tot, cap, guard):
+    """The population of a guarded draw, restated: every slot that holds a transition before the env step (slots < min(tot, cap)) and is not one of
+    the `guard` slots behind the ring head tot % cap."""
+    live = np.arange(min(tot, cap))
+    window = (tot + np.arange(guard)) % cap
+    return np.setdiff1d(live, window)
+
+
+def make_pair(eng_mod, n, cap, use_bc, slope, seed):
+    from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    params = D.make_params(31)
+    rng = np.random.default_rng(seed)
+    exp = DeviceReplay(64)
+    exp.store_rows(torch.from_numpy(rng.normal(size=(40, 32)).astype(np.float32)))
+    bc = torch.from_numpy(rng.normal(size=(150, 32)).astype(np.float32)).cuda() if use_bc else None
+    scen = (np.arange(n) % 3).astype(np.int32)
+    side = []
+    for _ in range(2):
+        e = eng_mod.HirlEngine(batch=128, use_bc=use_bc, slope=slope)
+        e.x9_rows = None
+        e.load_params(params["actor"], params["critic"], params["bc_actor"] if use_bc else None)
+        rep = DeviceReplay(cap)
+        env = BatchedHarfangEnv(n, scenario=scen, seed=5, max_step=6, auto_reset=True, random_reset=True, replay=rep)  # (max_step 6: time-limit steps are not stored, so a step inserts fewer than n rows)
+        env.reset()
+        side.append((e, env, rep))
+    return side, exp, bc
+
+
+def sync(dst, src):
+    (e1, env1, rep1), (e0, env0, rep0) = dst, src
+    e1.arena.copy_(e0.arena)
+    for k in ("critic_step", "actor_step", "update_count", "actor_trainable", "sample_calls", "act_calls"):
+        setattr(e1, k, getattr(e0, k))
+    env1._state_store.copy_(env0._state_store)
+    for k in ("obs", "reward", "done", "success", "episode_ctr"):
+        getattr(env1, k).copy_(getattr(env0, k))
+    if env0.stats is not None:
+        env1.stats.copy_(env0.stats)
+    rep1.ring.copy_(rep0.ring); rep1.success.copy_(rep0.success); rep1.total.copy_(rep0.total)
+
+
+def sorted_rows(rep):
+    r = rep.ring.cpu().numpy()
+    return r[np.lexsort(r.T[::-1])]
+
+
+@pytest.mark.parametrize("use_bc,slope,n,cap", [(True, 0.0, 1024, 2600), (False, 0.01, 576, 1400), (True, 0.0, 4096, 10000)])
+def test_front_launch_equals_act_step_then_guarded_learn(eng_mod, use_bc, slope, n, cap):
+    side, exp, bc = make_pair(eng_mod, n, cap, use_bc, slope, seed=n)
+    (a, env_a, rep_a), (b, env_b, rep_b) = side
+    a.act_step(env_a, sigma=0.1, seed=3)  # some rows in the ring before the first draw
+    snap = torch.zeros(1, dtype=torch.int64, device="cuda")
+    seen_wrapped_window = False
+    for k in range(16):
+        sync(side[1], side[0])
+        w = ((100 if k % 4 == 0 else (None if k % 4 < 3 else 0.3)) if use_bc else 0.0)
+        tot0 = int(rep_a.total.item())
+        out_a = a.step_learn(env_a, exp, bc, n_main=96, act_sigma=0.1, act_seed=3, sample_seed=11, bc_weight_now=w, bc_warm_up_weight=0.05)
+        # the same step as separate launches: total before the step, guard = n
+        snap.copy_(rep_b.total)
+        out_b = b.act_step(env_b, sigma=0.1, seed=3)
+        b.sample(rep_b, exp, bc, n_main=96, seed=11, defer=True)
+        b._pending[0].total, b._pending[0].guard = snap.data_ptr(), n
+        b.learn(bc_weight_now=w, bc_warm_up_weight=0.05)
+        a.front_check()
+        for x, y, name in zip(out_a, out_b, ("actions", "obs", "reward", "done", "success")):
+            assert torch.equal(x, y), (k, name)
+        assert torch.equal(env_a._state_store, env_b._state_store) and torch.equal(env_a.episode_ctr, env_b.episode_ctr), k
+        assert torch.equal(rep_a.total, rep_b.total), k
+        np.testing.assert_array_equal(sorted_rows(rep_a), sorted_rows(rep_b), err_msg=f"step {k}: replay rows")
+        for name in ("_idx", "_noise", "rows") + (("_idx_bc", "bc_rows") if use_bc else ()):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (k, name)
+        np.testing.assert_allclose(a.losses_host(), b.losses_host(), rtol=1e-6, atol=1e-7, err_msg=f"step {k}")
+        for name in NETS:
+            assert torch.equal(getattr(a, name), getattr(b, name)), (k, name)
+        # the draw rule on the host
+        i = a._idx.cpu().numpy()
+        ok = allowed_slots(tot0, cap, n)
+        assert len(set(i[:96])) == 96 and np.isin(i[:96], ok).all(), (k, tot0)
+        assert len(set(i[96:])) == 32 and i[96:].max() < 40
+        if tot0 >= cap and tot0 % cap + n > cap:
+            seen_wrapped_window = True
+        # the snapshot hx_hirl_learn_back left is the ring's total now
+        assert int(a._front[0].item()) == int(rep_a.total.item())
+    assert int(rep_a.total.item()) > cap, "the ring was meant to wrap"
+    assert seen_wrapped_window, "no step had its guard window across the ring's end"
+    assert a.update_count == 8
+
+
+def test_guarded_draw_covers_its_population(eng_mod):
+    """Every allowed slot is drawn and no other: 200 guarded draws of 128 from a small ring, full and not, with the window wrapped and not."""
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    params = D.make_params(31)
+    rng = np.random.default_rng(3)
+    cap, guard = 700, 150
+    rep = DeviceReplay(cap)
+    rep.ring.copy_(torch.from_numpy(rng.normal(size=(cap, 32)).astype(np.float32)))
+    e = eng_mod.HirlEngine(batch=128, use_bc=False)
+    e.load_params(params["actor"], params["critic"], None)
+    for tot in (400, 650, 700, 2 * 700 + 10, 3 * 700 + 620):  # not full; window past the end; just full; full; full with the window wrapped
+        rep.total.fill_(tot)
+        seen = set()
+        ok = allowed_slots(tot, cap, guard)
+        for k in range(200):
+            e.sample(rep, n_main=128, seed=7, defer=True)
+            e._pending[0].guard = guard
+            e.learn()
+            i = e._idx.cpu().numpy()
+            assert len(set(i)) == 128 and np.isin(i, ok).all(), (tot, k)
+            seen.update(i.tolist())
+        assert seen == set(ok.tolist()), (tot, len(seen), len(ok))
+
+
+def test_step_learn_refuses_what_it_does_not_cover(eng_mod):
+    side, exp, bc = make_pair(eng_mod, 64, 1024, True, 0.0, seed=1)
+    e, env, rep = side[0]
+    e.set_act_dtype("bf16")
+    with pytest.raises(Exception, match="front launch"):
+        e.step_learn(env, exp, bc, n_main=96)
+    e.set_act_dtype("f32")
+    e.sample(rep, exp, bc, n_main=96, defer=True)
+    with pytest.raises(Exception, match="pending"):
+        e.step_learn(env, exp, bc, n_main=96)
+
+
+def test_front_loop_free_running(eng_mod):
+    """40 free-running steps of the front loop (no re-synchronisation, the snapshot kept by hx_hirl_learn_back alone): finite losses, every Adam
+    step counted, the ring wrapped, the hand-off status word clear."""
+    side, exp, bc = make_pair(eng_mod, 512, 8192, True, 0.0, seed=9)
+    (a, env_a, rep_a), _ = side
+    a.act_step(env_a, sigma=0.1, seed=3)
+    for k in range(40):
+        a.step_learn(env_a, exp, bc, n_main=96, act_sigma=0.1, act_seed=3, sample_seed=11, bc_weight_now=100 if k % 4 == 0 else None, bc_warm_up_weight=0.05)
+        assert a._front_mark == (env_a, env_a.steps_issued)
+    a.front_check()
+    assert np.isfinite(a.losses_host()).all() and a.critic_step == 40 and a.update_count == 20
+    assert int(rep_a.total.item()) > 8192 and int(a._front[0].item()) == int(rep_a.total.item())
