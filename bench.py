@@ -78,6 +78,10 @@ def parse(argv=None):
                    help="issue the next act + env.step on a second stream beside critic-only learns (bit-identical results); measured on one "
                         "GPU it does not pay (every cross-stream event hand-off costs ~10 us on this runtime), so the default, at any N, is "
                         "the reference's strict act -> step -> sample -> learn order on one stream")
+    p.add_argument("--front", action="store_true",
+                   help="the FRONT launch (HirlEngine.step_learn, include/hirl4ucav.h hx_hirl_front): env step + the first two launches of learn() as ONE "
+                        "launch; the minibatch is then drawn from the ring as it stood before this step's insert, without the slots it may overwrite "
+                        "(fp32 HIRL on one GPU, <= 8,192 envs)")
     p.add_argument("--serial", action="store_true", help="(default) one stream")
     p.add_argument("--separate-launches", dest="separate_launches", action="store_true",
                    help="act and env step as two launches on every step (default: one fused launch, hx_actor_act_step)")
@@ -236,11 +240,14 @@ class Loop:
         from hirl4ucav_amd.utils.pipeline import VectorStepPipeline
         self.pipe = VectorStepPipeline(device, overlap=args.overlap and not args.serial and not self.sac)
         self.separate = args.separate_launches
-        self.rec = {"act": [], "env": [], "act+env": [], "learn": []}
+        self.rec = {"act": [], "env": [], "act+env": [], "learn": [], "front+back": []}
         self.krec, self.krec_fused = [], []
         # act + env step + replay insert as ONE launch at every size (hx_actor_act_step / hx_sac_act_step: up to 8,192 envs one 16- / 32-row
         # workgroup per row tile with the env step on its first wave, beyond that the persistent kernel of csrc/hx_actp.hip)
         self.fused = not (self.uniform or self.separate)
+        self.front = bool(getattr(args, "front", False))
+        if self.front and (self.sac or self.uniform or self.separate or args.overlap or args.staged or self.world > 1 or args.dtype != "f32" or n > 8192 or args.batch > 256):
+            raise SystemExit("--front: fp32 HIRL, one-call update path on one GPU, policy actions in one launch, at most 8,192 envs and batch 256")
 
     # ---- the hot path ------------------------------------------------------------------------------------------------
     def _act_env(self, timed=None, split=False, stamp=None):
@@ -280,21 +287,33 @@ class Loop:
         e.sample(self.replay, self.expert, self.bc_table, n_main=e.batch - self.expert_num, seed=2 + self.rank, defer=not (self.args.sample_launch or self.args.overlap))  # --overlap: the next env step may run beside learn(): draw first
         # a critic-only learn() leaves the acting network alone: the next act + env.step go out on the side stream now
         self.pipe.arm(act_env, acting_net_untouched=not e.actor_trainable, engine=e)
-        # soft weight: estimated at the start of every max_step-long "episode" of vector steps, kept in between
-        # (the reference re-estimates at most once per episode, SURVEY.md quirk 2)
-        kind = self.args.type
-        if kind == "soft":
-            w = 100 if (self.t % self.max_step == 0) else None
-        elif kind == "linear":  # bc_weight - episode / 5000, floored at 0 (train_all.py:328-331); episode = max_step vector steps
-            w = max(self.args.bc_weight - (self.t // self.max_step) / 5000.0, 0.0)
-        else:
-            w = self.args.bc_weight
+        w = self._bc_weight()
         # sharded path: the side stream is released at the gradient all-reduce; one-call path: right away
         if not e.staged:
             self.pipe.fire()
         e.learn(bc_weight_now=w, bc_warm_up_weight=0.0, before_exchange=self.pipe.fire)
 
+    def _bc_weight(self):
+        # soft weight: estimated at the start of every max_step-long "episode" of vector steps, kept in between
+        # (the reference re-estimates at most once per episode, SURVEY.md quirk 2)
+        kind = self.args.type
+        if kind == "soft":
+            return 100 if (self.t % self.max_step == 0) else None
+        if kind == "linear":  # bc_weight - episode / 5000, floored at 0 (train_all.py:328-331); episode = max_step vector steps
+            return max(self.args.bc_weight - (self.t // self.max_step) / 5000.0, 0.0)
+        return self.args.bc_weight
+
+    def _front_step(self):
+        """act + env step + replay insert AND launches A, B of learn() in one launch, then the rest of learn() (HirlEngine.step_learn)"""
+        e = self.eng
+        e.step_learn(self.env, self.expert, self.bc_table, n_main=e.batch - self.expert_num, act_sigma=0.1, act_seed=1, out=self.actions,
+                     sample_seed=2 + self.rank, bc_weight_now=self._bc_weight(), bc_warm_up_weight=0.0)
+
     def step(self):
+        if self.front:
+            self._front_step()
+            self.t += 1
+            return
         self.pipe.act_and_step(self._act_env)
         self._learn(self._act_env)
         self.pipe.join()
@@ -314,6 +333,14 @@ class Loop:
         stamp = None
         if not self.uniform and len(kpool) >= 2 and (split or not self.separate):
             stamp = (kpool.pop(), kpool.pop())  # split: the env launch, else the fused act + env launch (filed by _act_env when it runs)
+        if self.front and not split:  # the front launch stamped with its own begin / end; the whole step under one pair of stream events
+            if stamp is not None:
+                self.env.time_next_steps(*stamp)
+                self.krec_fused.append(stamp)
+            timed("front+back", self._front_step)
+            self.env.time_next_steps(None, None)
+            self.t += 1
+            return
         act_env = lambda: self._act_env(timed, split, stamp)  # noqa: E731
         self.pipe.act_and_step(act_env)
         timed("learn", lambda: self._learn(act_env))
@@ -819,6 +846,8 @@ def run_rank(args):
     for k in range(m_steps):
         loop.step_measured(split=(k % 4 == 3), pool=pool, kpool=kpool)
     barrier()
+    if loop.front:
+        loop.eng.front_check()  # an in-launch wait that gave up leaves a minibatch half read: fail loudly instead of printing a number
     if exchanging:
         loop.eng._allreduce = inner
         if getattr(loop.eng, "xchg", None) is not None:
@@ -863,6 +892,12 @@ def run_rank(args):
                      "env_step(own launch, every 4th step)": None if med["env"] is None else round(med["env"], 2),
                      "sample+learn": None if learn_us is None else round(learn_us, 2)},
     }
+    if loop.front:
+        res["config"]["act_env"] = "FRONT launch (hx_hirl_front): act + env step + replay insert + launches A and B of learn() in one launch"
+        res["config"]["draw"] = ("from the ring as it stood before this step's insert, without the n slots the step may overwrite "
+                                 "(HxSample.guard; the default loop draws after the insert, like the reference)")
+        res["stage_us"]["front launch + rest of learn() (3 of every 4 steps)"] = None if med["front+back"] is None else round(med["front+back"], 2)
+
     env_roof = {"kernel": "env_step_kernel<PAIR, INSERT, EPB> (hx_env.hip)", "bound": "hbm",
                 "achieved": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": (profile_traffic(args.envs) or {}).get("bytes"),
@@ -896,10 +931,14 @@ def run_rank(args):
                             f"{round(fp32_equiv / us / 1e6, 2)} TFLOP/s = {round(fp32_equiv / us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 3)} of the fp32-MFMA peak")
         first, second = (mfma, hbm) if mf >= hf else (hbm, mfma)
         persistent = args.envs > 8192
-        res["roofline"] = {"kernel": ("act_persist_*_kernel<..., ENV = true> (hx_actp.hip): persistent workgroups (one per CU) looping over their row tiles, env step + "
-                                      "fused replay insert in the launch's tail" if persistent else
-                                      "act_fused_kernel<NRT, GAUSS, ENV = true, ...> (hx_act.hip): policy inference + env step + fused replay insert") +
-                                     ", the dominant kernel of the timed loop", **first, "traffic": (fused_pmc or {}).get("bytes"), "other_roof": second,
+        front_name = None
+        if loop.front:  # + the forward passes of launches A (3.5 nets on average) and B (3 on average) over the minibatch
+            front_name = ("act_front_kernel<RELU, BNT> (hx_front.hip): the acting workgroups (32 rows each: policy inference + env step + fused replay insert) on half "
+                          "of the CUs, launches A and B of learn() (draw + gather, target actor, critics; target critics) on the other half")
+        plain_name = (("act_persist_*_kernel<..., ENV = true> (hx_actp.hip): persistent workgroups (one per CU) looping over their row tiles, env step + "
+                       "fused replay insert in the launch's tail") if persistent else
+                      "act_fused_kernel<NRT, GAUSS, ENV = true, ...> (hx_act.hip): policy inference + env step + fused replay insert")
+        res["roofline"] = {"kernel": ((front_name + "; FLOPs: the policy's only") if front_name else plain_name) + ", the dominant kernel of the timed loop", **first, "traffic": (fused_pmc or {}).get("bytes"), "other_roof": second,
                            "us_per_launch": round(us, 2), "launches_timed": len(fused),
                            "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the fused launches "
                                      "of the second pass (3 of every 4 steps)",

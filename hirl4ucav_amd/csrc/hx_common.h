@@ -45,5 +45,7 @@ int dbg_stamps_actp(float* host80);
 int dbg_spans_fwdbwd(unsigned long long* spans, unsigned* tags, unsigned* n, unsigned cap);
 int dbg_spans_wgrad(unsigned long long* spans, unsigned* tags, unsigned* n, unsigned cap);
 int dbg_spans_act(unsigned long long* spans, unsigned* tags, unsigned* n, unsigned cap);
+int dbg_spans_front(unsigned long long* spans, unsigned* tags, unsigned* n, unsigned cap);
+int dbg_stamps_front(float* host80);
 
 }  // namespace hx

@@ -47,6 +47,7 @@ int hx_debug_spans(unsigned long long* host_spans /* [8192][2] */, unsigned* hos
     *host_n = 0;
     if (int rc = hx::dbg_spans_fwdbwd(host_spans, host_tags, host_n, 8192u)) return rc;
     if (int rc = hx::dbg_spans_wgrad(host_spans, host_tags, host_n, 8192u)) return rc;
+    if (int rc = hx::dbg_spans_front(host_spans, host_tags, host_n, 8192u)) return rc;
     return hx::dbg_spans_act(host_spans, host_tags, host_n, 8192u);
 #else
     (void)host_spans; (void)host_tags; (void)host_n;

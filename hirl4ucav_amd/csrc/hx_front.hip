@@ -27,9 +27,13 @@ struct FrontCtl {
     FrontSync sync;
 };
 
-// BNT: launch B's column tiling, chosen as launch_fwd chooses it (32 columns per workgroup for two nets, 64 beyond): same K-split, same bits
-template <bool RELU, int BNT>
+// Launch B runs in 64-column workgroups whatever its job count (a launch of its own takes 32-column workgroups for two nets: twice the workgroups,
+// each with half the MFMA work — right for an empty chip, wrong in the shadow of the acting workgroups, where CU time is what runs out:
+// tools/ubench/front_spans.py).  The K-split of a column tile differs between the two tilings (4 against 8 partial sums), hence the last bits of the
+// target critics' z2: hx_debug_set_fwd_nt(64) gives the separate launches the same tiling (tests/test_front_gpu.py).
+template <bool RELU>
 __global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArgsC FA, SampleDev SA, FwdArgsC FB, FrontCtl C) {
+    constexpr int BNT = kNT;
     typedef ActLds<2, true, false, true, false> LdsAct;
     typedef FwdLds<kNT, true, false> LdsA;
     typedef FwdLds<BNT, false, false> LdsB;
@@ -75,11 +79,8 @@ int launch_front(const float* actor, const float* w2f, float* state, int64_t n, 
     CA.slope = FA.slope; CA.zero_nf = FA.zero_nf; CA.zero_f = FA.zero_f; CA.zero_i = FA.zero_i; CA.images = nullptr; CA.rowmap = 1;
     CB.slope = FB.slope; CB.zero_nf = FB.zero_nf; CB.zero_f = FB.zero_f; CB.zero_i = FB.zero_i; CB.images = nullptr; CB.rowmap = 1;
     const int rows = FA.job[0].rows, tiles = (rows + RT - 1) / RT;
-    // launch B's tiling as launch_fwd picks it for the same job list (one or two nets at B = 128: 32-column workgroups)
-    const int b_tiles = tiles * FB.njobs;
-    HX_REQUIRE(b_tiles < 128, "hx_hirl_front: minibatches of at most 256 rows");
-    const bool b32 = b_tiles * (H2 / 32) <= 256;
-    const int bnt = b32 ? 32 : kNT;
+    HX_REQUIRE(tiles * FB.njobs < 128, "hx_hirl_front: minibatches of at most 256 rows");
+    const int bnt = kNT;
     FrontCtl C{};
     C.n_act = (int)((n + 2 * RT - 1) / (2 * RT));
     C.per_a = tiles * (H2 / kNT); C.n_a = C.per_a * FA.njobs;
@@ -88,14 +89,16 @@ int launch_front(const float* actor, const float* w2f, float* state, int64_t n, 
     HX_REQUIRE(tiles <= 16, "hx_hirl_front: at most 16 row tiles (HxFront.flags)");
     const dim3 grid((unsigned)(C.n_act + C.n_a + C.per_b * FB.njobs));
     const bool relu = slope == 0.0f;
-#define HX_FRONT(RELU_, BNT_) do { \
-        if (o.ev_start && o.ev_stop) hipExtLaunchKernelGGL((act_front_kernel<RELU_, BNT_>), grid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, *FA.sample, CB, C); \
-        else hipLaunchKernelGGL((act_front_kernel<RELU_, BNT_>), grid, dim3(kWide), 0, st, H, CA, *FA.sample, CB, C); } while (0)
-    if (relu) { if (b32) HX_FRONT(true, 32); else HX_FRONT(true, kNT); }
-    else { if (b32) HX_FRONT(false, 32); else HX_FRONT(false, kNT); }
+#define HX_FRONT(RELU_) do { \
+        if (o.ev_start && o.ev_stop) hipExtLaunchKernelGGL((act_front_kernel<RELU_>), grid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, *FA.sample, CB, C); \
+        else hipLaunchKernelGGL((act_front_kernel<RELU_>), grid, dim3(kWide), 0, st, H, CA, *FA.sample, CB, C); } while (0)
+    if (relu) HX_FRONT(true);
+    else HX_FRONT(false);
 #undef HX_FRONT
     HX_CHECK_LAUNCH("hx_hirl_front");
     return 0;
 }
 
 }  // namespace hxu
+
+HX_DEFINE_DEBUG_COLLECTORS(front, 0, 0)

@@ -351,7 +351,7 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
         STAMP();
         STAMP_FLUSH(SAMPLE ? 8 : 0, bx == 5 && tid == 0);
     }
-    SPAN_LOG(HX_SPAN_FWD);
+    SPAN_LOG(FRONT == 1 ? HX_SPAN_FRONT_A : (FRONT == 2 ? HX_SPAN_FRONT_B : HX_SPAN_FWD));
     if constexpr (SAMPLE) {
         if (by == 0) {  // what hx_sample_batch leaves behind: row tiles, indices, noise — read by the launches after this one
             if (FRONT == 1) {

@@ -562,7 +562,16 @@ void launch_bwd_t(const BwdArgs& G, hipStream_t st) {
 namespace hxu {
 
 // column tiling by size: enough row tiles to fill the chip -> wide workgroups (less prologue recomputation)
+// hx_debug_set_fwd_nt: 64 = latency-mode launches keep 64-column workgroups whatever their job count (the tiling the front launch gives launch B)
+static int g_force_fwd_nt = 0, g_force_skip = 0, g_force_count = 0;
+void set_fwd_nt(int nt, int skip, int count) { g_force_fwd_nt = nt; g_force_skip = skip; g_force_count = count; }
+
 void launch_fwd(const FwdArgs& F, hipStream_t st) {
+    bool force64 = false;
+    if (g_force_fwd_nt == kNT) {  // (tests only) the launches [skip, skip + count) after the setter
+        if (g_force_skip > 0) --g_force_skip;
+        else if (g_force_count > 0) { --g_force_count; force64 = true; }
+    }
     FwdArgsC C{};
     for (int j = 0; j < F.njobs; ++j) {  // every job of a launch has the same row count (the minibatch)
         C.job[j] = pack_fwd(F.job[j]);
@@ -591,7 +600,7 @@ void launch_fwd(const FwdArgs& F, hipStream_t st) {
         return;
     }
     if (tiles >= 128) HX_FWD(256);
-    else if (tiles * (H2 / 32) <= 256) HX_FWD(32);  // one or two nets at B = 128: 32-column workgroups still fit the chip in one round
+    else if (tiles * (H2 / 32) <= 256 && !force64) HX_FWD(32);  // one or two nets at B = 128: 32-column workgroups still fit the chip in one round
     else HX_FWD(kNT);
 #undef HX_FWD_T
 #undef HX_FWD
@@ -611,3 +620,11 @@ void launch_bwd(int grp, const BwdArgs& G, hipStream_t st) {
 }  // namespace hxu
 
 HX_DEFINE_DEBUG_COLLECTORS(fwdbwd, 0, 32)
+
+/* tests (include/hirl4ucav_debug.h): of the forward launches that follow, numbers [skip, skip + count) keep 64-column workgroups whatever their job
+ * count (the tiling hx_hirl_front gives launch B) */
+extern "C" int hx_debug_set_fwd_nt(int32_t nt, int32_t skip, int32_t count) {
+    HX_REQUIRE((nt == 0 || nt == 64) && skip >= 0 && count >= 0, "hx_debug_set_fwd_nt: nt 0 or 64, skip and count >= 0");
+    hxu::set_fwd_nt(nt, skip, count);
+    return 0;
+}

@@ -83,7 +83,7 @@ static __device__ unsigned hx_span_n;
 #define SPAN_LOG(tag)
 #define HX_DEFINE_DEBUG_COLLECTORS(name, lo, hi)
 #endif
-enum { HX_SPAN_FWD = 1, HX_SPAN_ACT = 2, HX_SPAN_BWD = 3, HX_SPAN_WGRAD = 4 };
+enum { HX_SPAN_FWD = 1, HX_SPAN_ACT = 2, HX_SPAN_BWD = 3, HX_SPAN_WGRAD = 4, HX_SPAN_FRONT_A = 5, HX_SPAN_FRONT_B = 6 };
 
 namespace hxu {
 using namespace hxnn;
@@ -703,6 +703,7 @@ inline int prepare_draw(const HxSample* S, int B, float* rows, float* bc_rows, f
 
 // launchers (defined beside their kernels)
 void launch_fwd(const FwdArgs& F, hipStream_t st);                          // hx_fwdbwd.hip
+void set_fwd_nt(int nt, int skip, int count);                                                  // hx_fwdbwd.hip (hx_debug_set_fwd_nt)
 void launch_bwd(int grp, const BwdArgs& G, hipStream_t st);                 // hx_fwdbwd.hip: grp = bwd_l2_kernel's GRP (0..3)
 // hx_front.hip: the act + env + insert workgroups of hx_actor_act_step_f32i (32 rows each) and the workgroups of launches A and B as ONE launch
 int launch_front(const float* actor, const float* w2f, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,

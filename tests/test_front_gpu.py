@@ -2,7 +2,7 @@
 learn() call behind it as ONE launch, the target critics waiting in-launch for the target actor's rows.
 
 Parity statement: one step_learn == act_step, then learn() on a minibatch drawn with HxSample.total = the ring's total BEFORE the env step and
-HxSample.guard = n (the slots the step may overwrite left out) — bit for bit in everything both leave behind: actions, env state words,
+HxSample.guard = n (the slots the step may overwrite left out), launch B in the front launch's tiling (hx_debug_set_fwd_nt) — bit for bit in everything both leave behind: actions, env state words,
 observations, rewards, episode counters, the replay rows (as a multiset: ring slots are handed out by an atomic), drawn indices, smoothing noise,
 row tiles, networks, Adam moments; loss sums to 1e-6 (they are accumulated with atomics).  Checked step by step from shared states over rings that
 fill up and wrap, HIRL (soft / fixed weights, BC minibatch, expert rows) and TD3, ReLU and leaky networks.  The draw rule itself is checked against
@@ -77,6 +77,8 @@ def sorted_rows(rep):
 
 @pytest.mark.parametrize("use_bc,slope,n,cap", [(True, 0.0, 1024, 2600), (False, 0.01, 576, 1400), (True, 0.0, 4096, 10000)])
 def test_front_launch_equals_act_step_then_guarded_learn(eng_mod, use_bc, slope, n, cap):
+    from hirl4ucav_amd import _lib
+    L = _lib.load()
     side, exp, bc = make_pair(eng_mod, n, cap, use_bc, slope, seed=n)
     (a, env_a, rep_a), (b, env_b, rep_b) = side
     a.act_step(env_a, sigma=0.1, seed=3)  # some rows in the ring before the first draw
@@ -92,7 +94,11 @@ def test_front_launch_equals_act_step_then_guarded_learn(eng_mod, use_bc, slope,
         out_b = b.act_step(env_b, sigma=0.1, seed=3)
         b.sample(rep_b, exp, bc, n_main=96, seed=11, defer=True)
         b._pending[0].total, b._pending[0].guard = snap.data_ptr(), n
-        b.learn(bc_weight_now=w, bc_warm_up_weight=0.05)
+        L.hx_debug_set_fwd_nt(64, 1, 1)  # launch B (the second forward launch of learn()) in the front launch's tiling of launch B (64-column workgroups whatever the job count: same K-split, same bits)
+        try:
+            b.learn(bc_weight_now=w, bc_warm_up_weight=0.05)
+        finally:
+            L.hx_debug_set_fwd_nt(0, 0, 0)
         a.front_check()
         for x, y, name in zip(out_a, out_b, ("actions", "obs", "reward", "done", "success")):
             assert torch.equal(x, y), (k, name)
