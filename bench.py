@@ -246,7 +246,7 @@ class Loop:
         # workgroup per row tile with the env step on its first wave, beyond that the persistent kernel of csrc/hx_actp.hip)
         self.fused = not (self.uniform or self.separate)
         self.front = bool(getattr(args, "front", False))
-        if self.front and (self.sac or self.uniform or self.separate or args.overlap or args.staged or self.world > 1 or args.dtype != "f32" or n > 8192 or args.batch > 256):
+        if self.front and (self.sac or self.uniform or self.separate or args.overlap or args.staged or self.world > 1 or args.dtype not in ("f32", "f32x9") or n > 8192 or args.batch > 256):
             raise SystemExit("--front: fp32 HIRL, one-call update path on one GPU, policy actions in one launch, at most 8,192 envs and batch 256")
 
     # ---- the hot path ------------------------------------------------------------------------------------------------

@@ -32,7 +32,7 @@ class HxSample(ctypes.Structure):
 
 class HxFront(ctypes.Structure):
     """in-launch hand-off state of the front launch (include/hirl4ucav.h HxFront)"""
-    _fields_ = [("total_snap", _vp), ("flags", _vp), ("status", _vp), ("epoch", ctypes.c_uint32)]
+    _fields_ = [("flags", _vp), ("status", _vp), ("epoch", ctypes.c_uint32)]
 
 
 class HxNets(ctypes.Structure):
@@ -218,9 +218,11 @@ class OneShotExchange:
 _lib.register("hx_bc_train_actor", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _vp])
 _lib.register("hx_hirl_learn", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp])
 _lib.register("hx_hirl_learn_sampled", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp])
-_lib.register("hx_hirl_front", [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, _vp,
-                                 _P(_lib.HxStepOpts), _P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _i32, _i32, _P(HxFront), _vp])
-_lib.register("hx_hirl_learn_back", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _P(HxFront), _vp])
+_lib.register("hx_hirl_front", [_vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, _vp,
+                                 _P(_lib.HxStepOpts), _P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _P(HxFront), _vp])
+_lib.register("hx_hirl_learn_back", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _P(HxSample), _P(HxBatch), _vp])
+_lib.register("hx_sample_batch_guarded", [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _i32, _i32, _i32, ctypes.c_uint64,
+                                           ctypes.c_uint32, _f32, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint32, _vp])
 _lib.register("hx_hirl_critic_grads_sampled", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _i32, _vp])
 _lib.register("hx_sample_batch", [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _i32, _i32, _i32, ctypes.c_uint64,
                                    ctypes.c_uint32, _f32, _vp, _vp, _vp, _vp, _vp, _vp])
@@ -306,9 +308,12 @@ class HirlEngine:
         self.soft_count = self.soft_count[:1]
         self.sample_calls = 0
         self._pending = None  # a draw sample(defer=True) recorded for the next learn()
-        self._front = None     # step_learn: (total_snap int64[1], flags int32[16], status int32[1]) + the epoch counter
+        # step_learn: hand-off words (flags int32[16], status int32[1]) + the epoch counter; two sets of minibatch tiles (the rest of learn() k still
+        # reads set k while its first launch fills set k + 1 for the next front launch) and what the set in waiting was drawn for
+        self._front = None
         self._front_epoch = 0
-        self._front_mark = None  # (env, env.steps_issued) at which total_snap was taken
+        self._front_tiles = None
+        self._front_drawn = None
         self.nets = HxNets(*(t.data_ptr() for t in (self.actor, self.critic, self.target_actor, self.target_critic, self.bc_actor,
                                                      self.grad_actor, self.grad_critic, self.m_actor, self.v_actor, self.m_critic,
                                                      self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None, None, None, None, None)
@@ -687,19 +692,41 @@ class HirlEngine:
         (include/hirl4ucav.h hx_hirl_front): the env step and the first two launches of learn() are ONE launch, the acting workgroups on half of
         the CUs, the update's on the other half.  The one change of meaning: the minibatch is drawn from the ring as it stood BEFORE this env
         step, without the env.n slots the step may overwrite (uniform over every transition that is in the buffer before and after the step).
+        Each call also draws the NEXT call's minibatch (inside its learn() part, after this step's inserts): a next call with the same tables,
+        n_main, seed and sigma finds its tiles ready, any other draws them with a launch of its own first.
         fp32 networks on one GPU, at most 8,192 envs, batch <= 256.  -> (actions, obs, reward, done, success) as act_step."""
         replay, n, B = env.replay, env.n, self.batch
-        if self.staged or self.world > 1 or self.act_dtype != "f32" or self.nets.w2_bf16_all or self._x9_for(n) or replay is None:
+        if self.staged or self.world > 1 or self.act_dtype not in ("f32", "f32x9") or self.nets.w2_bf16_all or replay is None:
             raise _lib.HxError("step_learn: the front launch exists for the one-call fp32 path on one GPU with a replay ring attached to the env "
-                               "(set_act_dtype('f32'), x9_rows = None / n below it)")
+                               "(acting format 'f32' or 'f32x9')")
         if self._pending is not None:
             raise _lib.HxError("step_learn draws its own minibatch: a sample(defer=True) is still pending")
         if self._front is None:
-            buf = torch.zeros(24, dtype=torch.int64, device=self.device)
-            self._front = (buf[0:1], buf[8:16].view(torch.int32), buf[16:17].view(torch.int32)[:1])
-        snap, flags, status = self._front
-        if self._front_mark != (env, env.steps_issued):  # the ring moved since the snapshot (or there is none yet): take it now
-            snap.copy_(replay.total)
+            buf = torch.zeros(32, dtype=torch.int32, device=self.device)
+            self._front = (buf[0:16], buf[16:17])
+            second = torch.zeros(2 * B * 32 + 2 * B + 64, dtype=torch.float32, device=self.device)
+            t2 = (second[:B * 32], second[B * 32:2 * B * 32], second[2 * B * 32:2 * B * 32 + B].view(torch.int32),
+                  second[2 * B * 32 + B:2 * B * 32 + 2 * B].view(torch.int32), second[2 * B * 32 + 2 * B:2 * B * 32 + 2 * B + 4])
+            self._front_tiles = [(self.rows, self.bc_rows, self._idx, self._idx_bc, self._noise), t2]
+        flags, status = self._front
+        cur, nxt = self._front_tiles
+        n_main = B if n_main is None else int(n_main)
+        self.sample_calls += 1
+
+        def draw(tiles, call):
+            return HxSample(replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(), expert.ring.data_ptr() if expert is not None else None,
+                            len_of(expert), _lib.ptr(bc_table), bc_table.shape[0] if bc_table is not None else 0, n_main, int(sample_seed), call,
+                            float(smooth_sigma), tiles[2].data_ptr(), tiles[3].data_ptr() if bc_table is not None else None, n)
+
+        def tiles_of(t):
+            return HxBatch(t[0].data_ptr(), t[1].data_ptr() if self.use_bc else None, B, t[4].data_ptr())
+
+        want = (env, env.steps_issued, replay, expert, bc_table, n_main, int(sample_seed), float(smooth_sigma), self.sample_calls, n)
+        if self._front_drawn != want:  # no tiles in waiting for THIS draw (first call, another env step since, other tables): draw now, as a launch of its own
+            _lib.call("hx_sample_batch_guarded", replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(), expert.ring.data_ptr() if expert is not None else None,
+                      len_of(expert), _lib.ptr(bc_table), bc_table.shape[0] if bc_table is not None else 0, B, n_main, 1, int(sample_seed), self.sample_calls,
+                      float(smooth_sigma), cur[2].data_ptr(), cur[3].data_ptr() if bc_table is not None else None, cur[4].data_ptr(), cur[0].data_ptr(),
+                      cur[1].data_ptr() if bc_table is not None else None, n, _lib.stream_ptr())
         if out is None:
             out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         mode = 0
@@ -708,15 +735,9 @@ class HirlEngine:
         elif act_sigma > 0:
             mode = 3
         self.act_calls += 1
-        self.sample_calls += 1
         self._front_epoch += 1
-        smp = HxSample(replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(), expert.ring.data_ptr() if expert is not None else None,
-                       len_of(expert), _lib.ptr(bc_table), bc_table.shape[0] if bc_table is not None else 0, B if n_main is None else int(n_main),
-                       int(sample_seed), self.sample_calls, float(smooth_sigma), self._idx.data_ptr(),
-                       self._idx_bc.data_ptr() if bc_table is not None else None, 0)
-        front = HxFront(snap.data_ptr(), flags.data_ptr(), status.data_ptr(), self._front_epoch)
-        batch = HxBatch(self.rows.data_ptr(), self.bc_rows.data_ptr() if self.use_bc else None, B, self._noise.data_ptr())
-        nets, hyper, st = ctypes.byref(self.nets), ctypes.byref(self.hyper), _lib.stream_ptr()
+        front = HxFront(flags.data_ptr(), status.data_ptr(), self._front_epoch)
+        batch, nets, hyper, st = tiles_of(cur), ctypes.byref(self.nets), ctypes.byref(self.hyper), _lib.stream_ptr()
         if bc_weight_now is None:
             w_kind, w_given = 2, 0.0
         elif bc_weight_now == 100:
@@ -729,20 +750,22 @@ class HirlEngine:
             self.actor_step += 1
             self.update_count += 1
         do_polyak = actor_phase and self.update_count % self.target_update_freq == 0  # HIRL.py:327-330
-        _lib.call("hx_hirl_front", self.w2_f32i.data_ptr(), env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(), out.data_ptr(), mode | self._mode_bits,
+        _lib.call("hx_hirl_front", env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(), out.data_ptr(), mode | self._mode_bits | (32 if self._x9_for(n) else 0),
                   _lib.ptr(act_noise), float(act_sigma), int(act_seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(), env.done.data_ptr(),
-                  env.success.data_ptr(), ctypes.byref(env._opts), nets, ctypes.byref(batch), hyper, ctypes.byref(smp), int(actor_phase), w_kind,
-                  ctypes.byref(front), st)
+                  env.success.data_ptr(), ctypes.byref(env._opts), nets, ctypes.byref(batch), hyper, int(actor_phase), w_kind, ctypes.byref(front), st)
         env.steps_issued += 1
+        nxt_draw, nxt_tiles = draw(nxt, self.sample_calls + 1), tiles_of(nxt)
         _lib.call("hx_hirl_learn_back", nets, ctypes.byref(batch), hyper, self.critic_step, int(actor_phase), self.actor_step, int(do_polyak), w_kind, w_given,
-                  float(bc_warm_up_weight), replay.total.data_ptr(), ctypes.byref(front), st)
-        self._front_mark = (env, env.steps_issued)
+                  float(bc_warm_up_weight), ctypes.byref(nxt_draw), ctypes.byref(nxt_tiles), st)
+        self._front_drawn = (env, env.steps_issued, replay, expert, bc_table, n_main, int(sample_seed), float(smooth_sigma), self.sample_calls + 1, n)
+        self._front_tiles = [nxt, cur]
+        self.rows, self.bc_rows, self._idx, self._idx_bc, self._noise = cur  # what this call's learn() read (the attribute names sample() / learn() use)
         self.actor_trainable = not self.actor_trainable  # HIRL.py:332
         return out, env.obs, env.reward, env.done, env.success
 
     def front_check(self):
         """Raise if a workgroup of a front launch ever gave up waiting for its producers (synchronises)."""
-        if self._front is not None and int(self._front[2].item()) != 0:
+        if self._front is not None and int(self._front[1].item()) != 0:
             raise _lib.HxError("front launch: an in-launch wait for the target actor's rows timed out (status word set)")
 
     def bc_train_actor(self):

@@ -41,8 +41,9 @@ static void launch_act_t(const ActFusedArgs& H, hipStream_t st) {
     // W2 through L2, not by MFMA)
     static const int nrt2_bf16 = getenv("HX_ACT_BF16_NRT2_ROWS") ? atoi(getenv("HX_ACT_BF16_NRT2_ROWS")) : 8192;  // tuning knob
     static const int nrt2_f32 = getenv("HX_ACT_F32_NRT2_ROWS") ? atoi(getenv("HX_ACT_F32_NRT2_ROWS")) : 8192;     // tuning knob (tools/ubench/merge_probe.sh)
-    if constexpr (!X3) {  // (X3: 16-row workgroups at every size — three bf16 tiles of 32 rows of h1 do not fit the LDS beside the rest)
-        if (H.rows >= (BF16 ? nrt2_bf16 : nrt2_f32)) {
+    static const int nrt2_x9 = getenv("HX_ACT_X9_NRT2_ROWS") ? atoi(getenv("HX_ACT_X9_NRT2_ROWS")) : (1 << 30);  // tuning knob; default: 16-row workgroups (256 of them fill the chip up to 4,096 rows; beyond 8,192 the persistent kernel runs)
+    {
+        if (H.rows >= (X3 ? nrt2_x9 : BF16 ? nrt2_bf16 : nrt2_f32)) {
             const dim3 grid((unsigned)((H.rows + 2 * RT - 1) / (2 * RT)));
             if (env) launch_act_k(act_fused_kernel<2, GAUSS, true, BF16, RELU, F32I, X3>, grid, H, st);
             else launch_act_k(act_fused_kernel<2, GAUSS, false, BF16, RELU, F32I, X3>, grid, H, st);

@@ -48,7 +48,11 @@ struct ActLds {
     static constexpr int kPrologue = ROWS * LDA1 + ROWS * XP + ROWS * 2 + H1 * 13;
     __attribute__((aligned(16))) float lds[kPrologue + kTileA + kTileB];
     __attribute__((aligned(16))) __bf16 h1b[BF16 ? ROWS * LDB1 : 8];
-    __attribute__((aligned(16))) uint16_t h1x[X3 ? 3 * ROWS * LDB1 : 8];  // X3: the hi | mid | lo tiles of h1
+    // X3: the hi | mid | lo tiles of h1.  With 32 rows they do not fit beside the z2 tile (52 + 67 KB + the prologue's 49): they LIE IN the z2 tile's
+    // LDS, which is written only once the product is through (one more barrier)
+    static constexpr bool kX3InZ2 = X3 && NRT == 2;
+    __attribute__((aligned(16))) uint16_t h1x[(X3 && !kX3InZ2) ? 3 * ROWS * LDB1 : 8];
+    static_assert(!kX3InZ2 || 3 * ROWS * LDB1 * 2 <= kTileA * 4, "the three bf16 tiles of h1 fit in the z2 tile");
     float s_act[ENV ? ROWS * 4 : 4];
     float s_noise[ROWS * 4];  // exploration noise of the workgroup's rows, drawn by the last wave(s) under the prologue's loads
     unsigned s_base;          // ring slot of the workgroup's first row
@@ -64,7 +68,7 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
     constexpr int kTileA = Lds::kTileA;
     float* const lds = SL.lds;
     __bf16* const h1b = SL.h1b;
-    uint16_t* const h1x = SL.h1x;
+    uint16_t* const h1x = Lds::kX3InZ2 ? reinterpret_cast<uint16_t*>(SL.lds + Lds::kPrologue) : SL.h1x;
     float* const s_act = SL.s_act;
     float* const s_noise = SL.s_noise;
     unsigned& s_base = SL.s_base;
@@ -282,6 +286,7 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
             for (int t = 0; t < NRT; ++t)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) acc[t][ct] = acc[t][ct] + rest[t][ct];
+            if constexpr (Lds::kX3InZ2) __syncthreads();  // every wave has read its last h1 fragments: their LDS takes z2 now
         }
         const float* ap = h1s + r * LDA1 + 4 * g;
         const int boff = (wave * 16 + r) * ACT_LDW + 4 * g;

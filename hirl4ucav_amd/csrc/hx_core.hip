@@ -40,6 +40,17 @@ int hx_debug_stamps_actp(float* host_out) {
     return -1;
 #endif
 }
+/* diagnostic builds only: the 80 stamp words of the front launch (hx_front.hip: [0..7] a launch-B workgroup, [8..15] a launch-A workgroup, [56..] an acting one) */
+int hx_debug_stamps_front(float* host_out) {
+#ifdef HX_STAMPS
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    for (int i = 0; i < 80; ++i) host_out[i] = 0.0f;
+    return hx::dbg_stamps_front(host_out);
+#else
+    (void)host_out;
+    return -1;
+#endif
+}
 /* diagnostic builds only: the workgroup life-span logs (start, end in 10 ns ticks; tag = HX_SPAN_* kernel id) -> host, then cleared */
 int hx_debug_spans(unsigned long long* host_spans /* [8192][2] */, unsigned* host_tags /* [8192] */, unsigned* host_n) {
 #ifdef HX_STAMPS

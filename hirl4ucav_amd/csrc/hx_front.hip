@@ -1,13 +1,15 @@
 // hx_front.hip — the FRONT launch (gfx950): the env step of a vector loop and the first two launches of the learn() call that follows it, as ONE launch.
 //   chooseAction + HarfangEnv.step + memory.store   hirl/train_all.py:343-348   -> the acting workgroups (act_fused_body, hx_act_body.h: 32 rows each)
-//   Agent.learn up to the TD target's inputs        hirl/agents/HIRL.py:259-272 -> launch A (draw + gather, targetActor(s'), Q1/Q2(s, a)) and launch B
-//                                                                                  (targetCritic Q1/Q2) as further workgroups (fwd_l2_body, hx_fwd_body.h)
+//   Agent.learn up to the TD target's inputs        hirl/agents/HIRL.py:259-272 -> launch A (targetActor(s'), Q1/Q2(s, a)) and launch B (targetCritic
+//                                                                                  Q1/Q2) as further workgroups (fwd_l2_body, hx_fwd_body.h)
 // Why: every kernel of the step is 1,024 threads x up to 128 registers — one workgroup per CU — so a launch is as long as its longest workgroup
 // chain.  At 4,096 envs the acting launch is 256 workgroups x 16 rows (20.5 us) and launches A + B another 17 us behind it, although they need
-// nothing the env step computes (the draw aside).  With 32 rows per acting workgroup the step takes 128 CUs for ~26 us (tools/ubench/merge_probe.sh)
-// and launches A (192-256 workgroups) and B (128-256) run on the other 128 CUs in that shadow.  B needs A's target-actor rows: it waits for them
-// IN the launch, per row tile (FrontSync, hx_fwd_body.h) — off the critical path here, because A is through long before the acting workgroups are.
-// Workgroups are dispatched in index order: acting first (the longest), then A (job 0 = the target actor first), then B.
+// nothing the env step computes (the draw aside).  With 32 rows per acting workgroup the step takes 128 CUs for 22-27 us (tools/ubench/merge_probe.sh,
+// x9_32row.sh) and launches A (192-256 workgroups) and B (128-192) run on the other 128 CUs in that shadow.  B needs A's target-actor rows: it waits
+// for them IN the launch, per row tile (FrontSync, hx_fwd_body.h) — off the critical path here, because A is through long before the acting
+// workgroups are.  Workgroups are dispatched in index order: acting first (the longest), then A (job 0 = the target actor first), then B.
+// CU time is what runs out in the shadow (tools/ubench/front_spans.py), so the minibatch is NOT drawn here: the previous hx_hirl_learn_back left its
+// tiles behind (predraw_wg in its first launch), and launch B runs in 64-column workgroups whatever its job count.
 // The draw's meaning changes (it cannot see this step's inserts and must not read the slots they overwrite): include/hirl4ucav.h hx_hirl_front.
 #include <hip/hip_ext.h>
 
@@ -31,11 +33,14 @@ struct FrontCtl {
 // each with half the MFMA work — right for an empty chip, wrong in the shadow of the acting workgroups, where CU time is what runs out:
 // tools/ubench/front_spans.py).  The K-split of a column tile differs between the two tilings (4 against 8 partial sums), hence the last bits of the
 // target critics' z2: hx_debug_set_fwd_nt(64) gives the separate launches the same tiling (tests/test_front_gpu.py).
-template <bool RELU>
-__global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArgsC FA, SampleDev SA, FwdArgsC FB, FrontCtl C) {
+// X3: the acting workgroups multiply in the exact 9-term bf16 split (the engine's "f32x9" acting format, H.w2b = the hi | mid | lo images) instead of
+// fp32 MFMA from the fp32 image: 22.2 against 26.8 us for the 128 workgroups of 4,096 envs (tools/ubench/x9_32row.sh) — a shorter shadow, but the
+// acting workgroups are the launch's longest
+template <bool RELU, bool X3>
+__global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArgsC FA, FwdArgsC FB, FrontCtl C) {
     constexpr int BNT = kNT;
-    typedef ActLds<2, true, false, true, false> LdsAct;
-    typedef FwdLds<kNT, true, false> LdsA;
+    typedef ActLds<2, true, false, !X3, X3> LdsAct;
+    typedef FwdLds<kNT, false, false> LdsA;
     typedef FwdLds<BNT, false, false> LdsB;
     __shared__ union {
         LdsAct act;
@@ -44,35 +49,36 @@ __global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArg
     } u;
     int b = (int)blockIdx.x;
     if (b < C.n_act) {
-        act_fused_body<2, false, true, false, RELU, true, false>(H, b, u.act);
+        act_fused_body<2, false, true, false, RELU, !X3, X3>(H, b, u.act);
         return;
     }
     b -= C.n_act;
     if (b < C.n_a) {
-        fwd_l2_body<kNT, RELU, true, false, 1>(FA, SA, b % C.per_a, b / C.per_a, u.a, C.sync);
+        fwd_l2_body<kNT, RELU, false, false, 1>(FA, NoSample{}, b % C.per_a, b / C.per_a, u.a, C.sync);
         return;
     }
     b -= C.n_a;
-    fwd_l2_body<BNT, RELU, false, false, 2>(FB, SA, b % C.per_b, b / C.per_b, u.b, C.sync);
+    fwd_l2_body<BNT, RELU, false, false, 2>(FB, NoSample{}, b % C.per_b, b / C.per_b, u.b, C.sync);
 }
 
 }  // namespace
 
 namespace hxu {
 
-int launch_front(const float* actor, const float* w2f, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
                  const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward, uint8_t* done, int8_t* success,
                  const HxStepOpts& o, const FwdArgs& FA, const FwdArgs& FB, const HxFront& front, hipStream_t st) {
-    HX_REQUIRE(actor && w2f && (reinterpret_cast<uintptr_t>(w2f) & 15u) == 0, "hx_hirl_front: the actor and the 16-byte aligned fp32 image of its W2");
+    HX_REQUIRE(actor && (w2f || w2x) && ((reinterpret_cast<uintptr_t>(w2f) | reinterpret_cast<uintptr_t>(w2x)) & 15u) == 0,
+               "hx_hirl_front: the actor and a 16-byte aligned image of its W2 (HxNets.actor_w2_x9 or actor_w2_f32i)");
     const Mlp mA{13, 4, (noise_mode & 16) ? 1 : 0};  // + 16: layerNorm = False (as hx_actor_act_step)
     noise_mode &= 15;
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_hirl_front: bad noise mode");
     if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_hirl_front")) return rc;
     HX_REQUIRE(n <= kFuseEnvMax, "hx_hirl_front: at most 8,192 envs (one round of 32-row acting workgroups)");
-    HX_REQUIRE(FA.sample && FA.njobs >= 3 && FB.njobs >= 2, "hx_hirl_front: launch A draws the minibatch");
+    HX_REQUIRE(!FA.sample && FA.njobs >= 3 && FB.njobs >= 2, "hx_hirl_front: launch A reads finished minibatch tiles");
     ActFusedArgs H{actor, mA, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
                    noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
-                   o.cap > 0 ? 1.0 / (double)o.cap : 0.0, nullptr, w2f, 0};
+                   o.cap > 0 ? 1.0 / (double)o.cap : 0.0, w2x, w2x ? nullptr : w2f, w2x ? 1 : 0};
     FwdArgsC CA{}, CB{};
     for (int j = 0; j < FA.njobs; ++j) { CA.job[j] = pack_fwd(FA.job[j]); CA.job[j].slope = FA.slope; }
     for (int j = 0; j < FB.njobs; ++j) { CB.job[j] = pack_fwd(FB.job[j]); CB.job[j].slope = FB.slope; }
@@ -89,11 +95,11 @@ int launch_front(const float* actor, const float* w2f, float* state, int64_t n, 
     HX_REQUIRE(tiles <= 16, "hx_hirl_front: at most 16 row tiles (HxFront.flags)");
     const dim3 grid((unsigned)(C.n_act + C.n_a + C.per_b * FB.njobs));
     const bool relu = slope == 0.0f;
-#define HX_FRONT(RELU_) do { \
-        if (o.ev_start && o.ev_stop) hipExtLaunchKernelGGL((act_front_kernel<RELU_>), grid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, *FA.sample, CB, C); \
-        else hipLaunchKernelGGL((act_front_kernel<RELU_>), grid, dim3(kWide), 0, st, H, CA, *FA.sample, CB, C); } while (0)
-    if (relu) HX_FRONT(true);
-    else HX_FRONT(false);
+#define HX_FRONT(RELU_, X3_) do { \
+        if (o.ev_start && o.ev_stop) hipExtLaunchKernelGGL((act_front_kernel<RELU_, X3_>), grid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C); \
+        else hipLaunchKernelGGL((act_front_kernel<RELU_, X3_>), grid, dim3(kWide), 0, st, H, CA, CB, C); } while (0)
+    if (relu) { if (w2x) HX_FRONT(true, true); else HX_FRONT(true, false); }
+    else { if (w2x) HX_FRONT(false, true); else HX_FRONT(false, false); }
 #undef HX_FRONT
     HX_CHECK_LAUNCH("hx_hirl_front");
     return 0;
@@ -101,4 +107,4 @@ int launch_front(const float* actor, const float* w2f, float* state, int64_t n, 
 
 }  // namespace hxu
 
-HX_DEFINE_DEBUG_COLLECTORS(front, 0, 0)
+HX_DEFINE_DEBUG_COLLECTORS(front, 0, 80)

@@ -80,11 +80,10 @@ struct FwdLds {
 };
 
 // FRONT (hx_front.hip: launches A and B of learn() as workgroups of the act + env launch, B waiting for A in-launch):
-//   0  a launch of its own (fwd_l2_kernel below)
-//   1  producer: job 0 (the target actor) publishes its z2 tile and the minibatch row tiles with agent-scope relaxed stores and then bumps its
-//      row tile's counter X.flags[rt] (tools/ubench/handoff_probe.hip: the only hand-off form that does not cost a cache flush on this machine)
-//   2  consumer: waits (bounded) for the counter of its row tile, reads the published rows and the previous net's z2 with agent-scope loads and
-//      forms the smoothing noise itself (the producer's copy in SA.noise is for the launches after this one)
+//   0  a launch of its own (fwd_l2_kernel)
+//   1  producer: job 0 (the target actor) writes its z2 tile with agent-scope relaxed stores and then bumps its row tile's counter X.flags[rt]
+//      (tools/ubench/handoff_probe.hip: the only hand-off form that does not cost a cache flush on this machine)
+//   2  consumer: a job that feeds on the previous net's head waits (bounded) for the counter of its row tile and reads that z2 with agent-scope loads
 struct FrontSync {
     unsigned* flags;   // [row tiles] monotonic counters
     unsigned target;   // value a row tile's counter reaches once this launch's producers are through
@@ -160,20 +159,6 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
             if (nt == 0) tile_piece = reinterpret_cast<const float4*>((r < SA.n_main ? SA.ring : SA.expert_ring) + (size_t)s_fin[0][r] * 32)[tid & 7];
             else if (SA.bc_rows) tile_piece = reinterpret_cast<const float4*>(SA.bc_table + (size_t)s_fin[1][r] * 32)[tid & 7];
         }
-    } else if constexpr (FRONT == 2) {
-        // (W1 and the layer-1 vectors are on their way.)  The rows of this tile and the previous net's z2 come from workgroups of THIS launch:
-        if (tid == 0) {
-            int spins = 0;
-            while ((int)(__hip_atomic_load(&X.flags[rt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - X.target) < 0) {
-                if (++spins > 4000000) { atomicOr(X.status, 1u); break; }  // (~1 s: the producers have lower workgroup ids and were dispatched first)
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        __syncthreads();
-        if (tid < RT * XP && xr < nrow) {
-            if (xc < 13) xv = ld_agent(src_row(J.src, r0 + xr) + J.col0 + xc);
-            else if (in == 17 && xc < 17 && J.act_mode == 0) xv = ld_agent(src_row(J.src, r0 + xr) + xc);
-        }
     } else if (tid < RT * XP && xr < nrow) {
         if (xc < 13) xv = src_row(J.src, r0 + xr)[J.col0 + xc];
         else if (in == 17 && xc < 17) {
@@ -196,6 +181,18 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
         for (int i = 0; i < NW2; ++i) w2v[i] = *reinterpret_cast<const v4f*>(wcol + i * TPC * 4);
     }
     STAMP();
+    if constexpr (FRONT == 2) {
+        if (head_mode) {  // the previous net's z2 comes from workgroups of THIS launch (everything else this workgroup reads is older: already requested)
+            if (tid == 0) {
+                int spins = 0;
+                while ((int)(__hip_atomic_load(&X.flags[rt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - X.target) < 0) {
+                    if (++spins > 4000000) { atomicOr(X.status, 1u); break; }  // (~1 s: the producers have lower workgroup ids and were dispatched first)
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+        }
+    }
     if (head_mode && wave < nrow) {
         // head of the previous net: wave w owns row w (its loads go out right behind the ones above, nothing waited on yet)
         const int r = wave;
@@ -206,10 +203,7 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
         if (lane < 4) {
             float a = fast_tanh(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // Actor.forward's tanh, HIRL.py:140
             if (J.noise) {              // target smoothing, HIRL.py:264-267
-                float nz;
-                if constexpr (FRONT == 2) nz = smoothing_noise(SA, lane);  // (J.noise is being written by a producer of this launch)
-                else nz = J.noise[lane];
-                const float e = fminf(fmaxf(nz, -J.noise_clamp), J.noise_clamp);
+                const float e = fminf(fmaxf(J.noise[lane], -J.noise_clamp), J.noise_clamp);
                 a = fminf(fmaxf(a + e, -1.0f), 1.0f);
             }
             xs[r * XP + 13 + lane] = a;

@@ -34,10 +34,6 @@ struct BwdArgsC {
     BwdJobC job[2];
     const uint16_t* images;  // BF16 instantiations: base of the bf16 W2 images
     int rowmap;              // 1: row tiles -> XCDs as in fwd_l2 (see there)
-    // hx_front.hip: *snap_dst = *snap_src once per launch — the replay ring's `total` as it stands between two env steps, for the draw that
-    // runs BESIDE the next env step (off every workgroup's critical path: read by one thread at the end)
-    const unsigned long long* snap_src;
-    unsigned long long* snap_dst;
 };
 inline BwdJobC pack_bwd(const BwdJob& J, const BwdArgs& A) {
     BwdJobC c{};
@@ -525,7 +521,6 @@ __global__ __launch_bounds__(kWide) void bwd_l2_kernel(BwdArgsC AC) {
         STAMP_FLUSH(16, blockIdx.x == 3 && tid == 0);
         SPAN_LOG(HX_SPAN_BWD);
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && AC.snap_dst) *AC.snap_dst = *AC.snap_src;
 }
 
 int fwd_row_tiles(const FwdArgs& a) {
@@ -541,10 +536,9 @@ void launch_bwd_t(const BwdArgs& G, hipStream_t st) {
     BwdArgsC C{};
     for (int j = 0; j < G.njobs; ++j) C.job[j] = pack_bwd(G.job[j], G);
     C.images = G.images;
-    C.snap_src = G.snap_src; C.snap_dst = G.snap_dst;
     static const int rowmap = getenv("HX_XCD_ROWMAP") ? atoi(getenv("HX_XCD_ROWMAP")) : 3;  // bit 1: bwd_l2
     C.rowmap = (rowmap >> 1) & 1;
-    const dim3 grid(bwd_blocks(G, (GRP <= 2 || GRP >= 4) ? RT / 2 : RT), G.njobs);
+    const dim3 grid(bwd_blocks(G, (GRP <= 2 || GRP >= 4) ? RT / 2 : RT) , G.njobs);
     if constexpr (GRP <= 2) {  // the bf16 update path covers the HIRL / TD3 / BC jobs (GRP 3 = SAC's given head gradients: fp32)
         static const int dbg_off = getenv("HX_DBG_BF16_OFF") ? atoi(getenv("HX_DBG_BF16_OFF")) : 0;
         if (G.images && !(dbg_off & 2)) {

@@ -104,8 +104,7 @@ static void make_launch_b(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy,
 }
 // launches C and D: y, loss, dq, LN2 backward, dh1 for both heads; all critic parameter gradients.
 // adam_step > 0: the critic's optimizer step (and, with polyak, the soft_update of its target) rides in the wgrad launch
-static int critic_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, void* stream, int adam_step, bool polyak, const uint64_t* snap_src = nullptr,
-                       uint64_t* snap_dst = nullptr) {
+static int critic_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, void* stream, int adam_step, bool polyak, const SampleDev* predraw = nullptr) {
     hipStream_t st = (hipStream_t)stream;
     const Mlp mQ{17, 1, Hy->no_layernorm ? 1 : 0};
     const int B = Bt->batch;
@@ -125,7 +124,6 @@ static int critic_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, vo
             J.img_t = IM_C1_T + h;
         }
         G.images = N->w2_bf16_all;
-        G.snap_src = (const unsigned long long*)snap_src; G.snap_dst = (unsigned long long*)snap_dst;
         launch_bwd(0, G, st);
     }
     {   // launch D: all critic parameter gradients
@@ -147,6 +145,7 @@ static int critic_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, vo
             }
         }
         W.bf16 = N->w2_bf16_all != nullptr;
+        W.predraw = predraw; W.predraw_batch = B;
         if (adam_step > 0) {
             W.ad = make_adam(N, Hy, Hy->lr_critic, adam_step, false);
             launch_wg(W, true, st);
@@ -350,38 +349,40 @@ int hx_hirl_learn_sampled(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy,
 }
 
 /* hx_hirl_learn_sampled in two parts around an env step (include/hirl4ucav.h "front launch"): hx_hirl_front = chooseAction + env step + replay insert of
- * n envs AND launches A and B of the learn() call that follows, as workgroups of ONE launch (hx_front.hip); hx_hirl_learn_back = the rest of that call. */
-int hx_hirl_front(const float* actor_w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode, const float* noise,
+ * n envs AND launches A and B of the learn() call that follows, as workgroups of ONE launch (hx_front.hip), on the minibatch tiles a predraw left in
+ * `batch`; hx_hirl_learn_back = the rest of that call, and (with `next`) the draw + gather of the NEXT front launch's minibatch in its first launch. */
+int hx_hirl_front(float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode, const float* noise,
                   float sigma, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts,
-                  const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t actor_phase, int32_t w_kind, const HxFront* front,
-                  void* stream) {
-    HX_REQUIRE(N && Bt && Hy && S && front && opts && Bt->batch > 0 && Bt->batch % 16 == 0 && Bt->batch <= kFusedBatchMax,
-               "hx_hirl_front: the minibatch is a positive multiple of 16 rows, at most 256, drawn inside the launch");
-    HX_REQUIRE(Bt->noise && front->total_snap && front->flags && front->status && front->epoch >= 1, "hx_hirl_front: noise[4], total_snap, flags, status and a 1-based epoch are required");
-    HX_REQUIRE(!N->w2_bf16_all && actor_w2_f32i, "hx_hirl_front: fp32 networks with the fp32 image of the actor's W2 (the bf16 update path runs its launches one by one)");
-    HX_REQUIRE(opts->ring && S->ring == opts->ring && S->cap == opts->cap && S->total == opts->total,
-               "hx_hirl_front: the draw and the env step's insert must name the same replay ring");
-    HX_REQUIRE(n > 0 && 2 * n <= S->cap, "hx_hirl_front: the ring must hold at least 2 n rows");
+                  const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t actor_phase, int32_t w_kind, const HxFront* front, void* stream) {
+    HX_REQUIRE(N && Bt && Hy && front && opts && Bt->batch > 0 && Bt->batch % 16 == 0 && Bt->batch <= kFusedBatchMax && Bt->rows && Bt->noise,
+               "hx_hirl_front: the minibatch tiles (a positive multiple of 16 rows, at most 256) and noise[4] must be there");
+    HX_REQUIRE(front->flags && front->status && front->epoch >= 1, "hx_hirl_front: flags, status and a 1-based epoch are required");
+    HX_REQUIRE(!N->w2_bf16_all && !N->actor_w2_bf16 && (N->actor_w2_f32i || N->actor_w2_x9),
+               "hx_hirl_front: fp32 networks with HxNets.actor_w2_f32i or actor_w2_x9 (the bf16 paths run their launches one by one)");
     const int actor_fwd = actor_phase ? (w_kind == 1 ? 2 : 1) : 0;
-    SampleDev SD{};
-    bool fused = false;
-    HxSample Sg = *S;
-    Sg.total = front->total_snap;  // the draw reads the ring as it stood BEFORE this launch's env step ...
-    if (int rc = prepare_draw(&Sg, Bt->batch, const_cast<float*>(Bt->rows), const_cast<float*>(Bt->bc_rows), const_cast<float*>(Bt->noise), stream, &SD, &fused)) return rc;
-    SD.guard = (uint32_t)n;        // ... and leaves out the slots that step may overwrite
     FwdArgs FA, FB;
     make_launch_a(N, Bt, Hy, actor_fwd, FA);
-    FA.sample = &SD;
     make_launch_b(N, Bt, Hy, actor_fwd, FB);
-    return launch_front(N->actor, actor_w2_f32i, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed, row0, call, Hy->slope, reward, done, success,
-                        *opts, FA, FB, *front, (hipStream_t)stream);
+    const bool x9 = (noise_mode & 32) != 0;  // + 32: the exact-split acting format (HxNets.actor_w2_x9), else fp32 MFMA from HxNets.actor_w2_f32i
+    HX_REQUIRE(x9 ? N->actor_w2_x9 != nullptr : N->actor_w2_f32i != nullptr, "hx_hirl_front: the image of the chosen acting format is missing from HxNets");
+    noise_mode &= ~32;
+    return launch_front(N->actor, x9 ? nullptr : N->actor_w2_f32i, x9 ? N->actor_w2_x9 : nullptr, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed,
+                        row0, call, Hy->slope, reward, done, success, *opts, FA, FB, *front, (hipStream_t)stream);
 }
 int hx_hirl_learn_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t critic_step, int32_t actor_phase, int32_t actor_step, int32_t do_polyak,
-                       int32_t w_kind, float w_given, float warm, const uint64_t* total, const HxFront* front, void* stream) {
+                       int32_t w_kind, float w_given, float warm, const HxSample* next, const HxBatch* next_tiles, void* stream) {
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_learn_back: batch must be a positive multiple of 16");
     HX_REQUIRE(critic_step >= 1 && (!actor_phase || actor_step >= 1), "hx_hirl_learn_back: Adam steps are 1-based");
-    HX_REQUIRE(!front || (front->total_snap && total), "hx_hirl_learn_back: the snapshot needs the ring's total and total_snap");
-    int rc = critic_back(N, Bt, Hy, stream, critic_step, do_polyak != 0, front ? total : nullptr, front ? front->total_snap : nullptr);
+    SampleDev SD{};
+    if (next) {
+        HX_REQUIRE(next_tiles && next_tiles->batch == Bt->batch && next_tiles->rows && next_tiles->noise && next_tiles->rows != Bt->rows && next_tiles->noise != Bt->noise &&
+                   !N->w2_bf16_all, "hx_hirl_learn_back: the next minibatch needs tiles of its own (this call still reads the current ones); fp32 update path");
+        bool fused = false;
+        if (int rc = prepare_draw(next, Bt->batch, const_cast<float*>(next_tiles->rows), const_cast<float*>(next_tiles->bc_rows), const_cast<float*>(next_tiles->noise),
+                                  stream, &SD, &fused, /*launch_now=*/false)) return rc;
+        HX_REQUIRE(fused, "hx_hirl_learn_back: the predraw covers minibatches of at most 256 rows");
+    }
+    int rc = critic_back(N, Bt, Hy, stream, critic_step, do_polyak != 0, next ? &SD : nullptr);
     if (rc || !actor_phase) return rc;
     if ((rc = hx_hirl_actor_backward(N, Bt, Hy, w_kind == 1, 1, stream))) return rc;
     return actor_wgrad_impl(N, Hy, Bt->batch, Bt->batch, w_kind, w_given, warm, stream, actor_step, do_polyak != 0);

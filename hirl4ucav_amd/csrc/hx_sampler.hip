@@ -31,6 +31,7 @@ struct SampleArgs {
     float* rows;
     float* bc_rows;
     int do_sample;  // 0: idx / idx_bc are inputs (parity tests, the N = 1 facade), only gather
+    uint32_t guard; // > 0: the `guard` slots behind the ring head are not drawn (hx_update.h draw_map)
 };
 
 // 1024 threads.  With B <= 512 the two index streams (replay / expert rows, BC rows) are drawn side by side by the two halves
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
     const int t = tid % width, tab = tid / width;
     if (A.do_sample) {
         const unsigned long long tot = *A.total;
-        const uint32_t len_main = (uint32_t)(tot < (unsigned long long)A.cap ? tot : (unsigned long long)A.cap);
+        const DrawMap dm = draw_map(tot, (unsigned long long)A.cap, A.guard);
+        const uint32_t len_main = dm.live;
         const uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
         for (int pass = 0; pass < 2 / np; ++pass) {
             const int stream = np == 2 ? tab : pass;  // 0: replay / expert rows, 1: BC rows
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs A) {
                 if (!__syncthreads_or(dup)) break;  // nobody redraws: done (the common case after the first round)
             }
             if (live) {
-                const int v = (int)(key & 0x7FFFFFFFu);
+                const int v = (stream == 0 && main_grp) ? (int)slot_of_draw(dm, key & 0x7FFFFFFFu) : (int)(key & 0x7FFFFFFFu);
                 out[t] = v;
                 fin[stream][t] = v;
             }
@@ -138,11 +140,20 @@ int hx_sample_batch(const uint64_t* total, int64_t cap, const float* ring, const
                     const float* bc_table, int64_t bc_len, int32_t batch, int32_t n_main, int32_t do_sample, uint64_t seed,
                     uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc, float* noise, float* rows, float* bc_rows,
                     void* stream) {
+    return hx_sample_batch_guarded(total, cap, ring, expert_ring, expert_len, bc_table, bc_len, batch, n_main, do_sample, seed, call, sigma, idx, idx_bc, noise,
+                                   rows, bc_rows, 0u, stream);
+}
+/* The same with HxSample.guard: the `guard` ring slots behind the head *total are not drawn (hx_hirl_front's population, as a launch of its own). */
+int hx_sample_batch_guarded(const uint64_t* total, int64_t cap, const float* ring, const float* expert_ring, int64_t expert_len,
+                            const float* bc_table, int64_t bc_len, int32_t batch, int32_t n_main, int32_t do_sample, uint64_t seed,
+                            uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc, float* noise, float* rows, float* bc_rows,
+                            uint32_t guard, void* stream) {
     HX_REQUIRE(idx && ring && rows && batch > 0 && batch <= 1024 && n_main >= 0 && n_main <= batch, "hx_sample_batch: bad arguments");
+    HX_REQUIRE(guard == 0 || (do_sample && (int64_t)guard < cap), "hx_sample_batch_guarded: the guard must leave slots to draw from");
     HX_REQUIRE(!do_sample || (total && cap > 0), "hx_sample_batch: sampling needs total and cap");
     HX_REQUIRE(n_main == batch || expert_ring, "hx_sample_batch: expert rows requested without an expert ring");
     SampleArgs A{(const unsigned long long*)total, cap, expert_len, bc_len, batch, n_main, seed, call, sigma, idx, idx_bc, noise,
-                 ring, expert_ring ? expert_ring : ring, bc_table, rows, bc_rows, do_sample};
+                 ring, expert_ring ? expert_ring : ring, bc_table, rows, bc_rows, do_sample, guard};
     hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
     HX_CHECK_LAUNCH("hx_sample_batch");
     return 0;

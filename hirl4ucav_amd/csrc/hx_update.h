@@ -381,6 +381,32 @@ __device__ __forceinline__ void draw_fused(const SampleDev& S, int B, uint32_t (
     __syncthreads();
 }
 
+// One workgroup = one whole minibatch assembly (what hx_sample_batch does as a launch of its own): draw, indices, smoothing noise, row tiles.
+// hx_hirl_learn_back runs it as an extra workgroup of the critics' wgrad launch (224 workgroups: CUs to spare) for the NEXT front launch (hx_front.hip), whose workgroups then start from
+// finished tiles instead of each repeating the draw (3-4 us of every launch-A workgroup, tools/ubench/front_spans.py) and chasing an index into
+// the ring.  scratch: 18 KB of LDS.
+__device__ __forceinline__ void predraw_wg(const SampleDev& S, int B, float* scratch) {
+    auto hkey = reinterpret_cast<uint32_t (*)[kFusedSlots]>(scratch);
+    auto hown = reinterpret_cast<int (*)[kFusedSlots]>(scratch + 2 * kFusedSlots);
+    auto fin = reinterpret_cast<int (*)[kFusedBatchMax]>(scratch + 4 * kFusedSlots);
+    draw_fused(S, B, hkey, hown, fin);
+    const int tid = threadIdx.x;
+    if (tid < B) {
+        S.idx[tid] = fin[0][tid];
+        if (S.idx_bc) S.idx_bc[tid] = fin[1][tid];
+    }
+    if (tid < 4 && S.noise) S.noise[tid] = smoothing_noise(S, tid);
+    const bool bc = S.bc_rows && S.bc_table && S.idx_bc;
+    for (int e = tid; e < B * 8; e += kWide) {  // 8 lanes per row, one 16-byte piece each; both tiles' loads in flight together
+        const int r = e >> 3, c = e & 7;
+        const float4 m = reinterpret_cast<const float4*>((r < S.n_main ? S.ring : S.expert_ring) + (size_t)fin[0][r] * 32)[c];
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bc) q = reinterpret_cast<const float4*>(S.bc_table + (size_t)fin[1][r] * 32)[c];
+        reinterpret_cast<float4*>(S.rows)[e] = m;
+        if (bc) reinterpret_cast<float4*>(S.bc_rows)[e] = q;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // job descriptions: what the host sequencing hands to launch_fwd / launch_bwd / launch_wg
 // ---------------------------------------------------------------------------------------------------------------
@@ -570,8 +596,6 @@ struct BwdArgs {
     float* losses;    // [8]: critic, actor, bc, rl, bc_fire, bc_weight, -, -
     int* soft_count;
     const uint16_t* images;  // nullptr: dh1 = dz2 W2 on fp32 MFMA; else the bf16 images: dz2 rounded to bf16, W2^T from its image
-    const unsigned long long* snap_src;  // hx_front.hip: *snap_dst = *snap_src (the ring's total between two env steps), or null
-    unsigned long long* snap_dst;
 };
 
 struct WgJob {
@@ -612,6 +636,8 @@ struct WgArgs {
     const float* wstate;
     int bf16;  // dW2 = dz2^T h1 with both operands rounded to bf16 (fp32 accumulate): the bf16 update path
     float* count_out;  // nullptr, or where thread 0 of the launch leaves (float)*soft_count: the merged actor message's count word
+    const SampleDev* predraw;  // hx_hirl_learn_back: one more workgroup draws and gathers the NEXT front launch's minibatch (predraw_wg), or null
+    int predraw_batch;
 };
 
 // torch.optim.Adam (defaults) on one element, and soft_update.  Contraction is OFF in these two: HIP's __fmul_rn / __fsub_rn are plain
@@ -683,7 +709,7 @@ __device__ __forceinline__ float pick8(const float (&o)[8], int i) {
 
 // An HxSample for a launch-A draw: validated, then either the device-side description (batch <= 256: *fused = true, launch A draws and
 // gathers) or the sampling launch right here (larger batches).  rows / bc_rows / noise: the tiles the later launches read.
-inline int prepare_draw(const HxSample* S, int B, float* rows, float* bc_rows, float* noise, void* stream, SampleDev* SD, bool* fused) {
+inline int prepare_draw(const HxSample* S, int B, float* rows, float* bc_rows, float* noise, void* stream, SampleDev* SD, bool* fused, bool launch_now = true) {
     HX_REQUIRE(S->total && S->cap > 0 && S->ring && S->idx && rows && S->n_main >= 0 && S->n_main <= B,
                "hx_*_sampled: the draw needs total, cap, ring, idx and the output tile rows");
     HX_REQUIRE(S->n_main == B || S->expert_ring, "hx_*_sampled: expert rows requested without an expert ring");
@@ -696,6 +722,7 @@ inline int prepare_draw(const HxSample* S, int B, float* rows, float* bc_rows, f
                         S->n_main, S->call, S->seed, S->sigma, S->guard};
         return 0;
     }
+    if (!launch_now) return 0;
     return hx_sample_batch(S->total, S->cap, S->ring, S->expert_ring, S->expert_len, S->bc_table, S->bc_len, B, S->n_main, 1, S->seed, S->call,
                            S->sigma, S->idx, S->idx_bc, noise, rows, S->bc_table ? bc_rows : nullptr, stream);
 }
@@ -706,7 +733,7 @@ void launch_fwd(const FwdArgs& F, hipStream_t st);                          // h
 void set_fwd_nt(int nt, int skip, int count);                                                  // hx_fwdbwd.hip (hx_debug_set_fwd_nt)
 void launch_bwd(int grp, const BwdArgs& G, hipStream_t st);                 // hx_fwdbwd.hip: grp = bwd_l2_kernel's GRP (0..3)
 // hx_front.hip: the act + env + insert workgroups of hx_actor_act_step_f32i (32 rows each) and the workgroups of launches A and B as ONE launch
-int launch_front(const float* actor, const float* w2f, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
                  const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward, uint8_t* done, int8_t* success,
                  const HxStepOpts& o, const FwdArgs& FA, const FwdArgs& FB, const HxFront& front, hipStream_t st);
 void launch_wg(const WgArgs& W, bool adam, hipStream_t st);                 // hx_wgrad.hip: adam = the optimizer step rides in the launch

@@ -30,6 +30,9 @@ struct WgJobC {
 static_assert(sizeof(WgJobC) == 176, "WgJobC layout");
 struct WgArgsC {
     WgJobC job[2];
+    // hx_hirl_learn_back: workgroup (kWgPerJob, 0) — one beyond the jobs' own, on a CU this launch leaves idle — assembles the next front launch's minibatch
+    int has_pre, pre_batch;
+    SampleDev pre;
 };
 
 // One parameter of the fused step: Adam with the gradient just produced, then (optionally) Polyak of the target and the bf16 image.
@@ -133,6 +136,13 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
     float* rinfo = lds + kWgRowChunk * XP;    // [chunk][<=12] per-row scalars
     float* red = rinfo + kWgRowChunk * 12;    // [16][64][kRedP]  cross-row-group reduction
 
+    if constexpr (!BF16) {
+        static_assert(sizeof(lds) >= (4 * kFusedSlots + 2 * kFusedBatchMax) * 4, "predraw_wg's tables fit");
+        if (AC.has_pre && blockIdx.x >= kWgPerJob) {  // (eight columns beyond the jobs' own: the XCD of every other workgroup stays what it was)
+            if (blockIdx.x == kWgPerJob && blockIdx.y == 0) predraw_wg(AC.pre, AC.pre_batch, lds);
+            return;
+        }
+    }
     const int j = blockIdx.y, b = blockIdx.x;
     WgJob J;
     WgArgs A;
@@ -670,7 +680,10 @@ namespace hxu {
 void launch_wg(const WgArgs& W, bool adam, hipStream_t st) {
     WgArgsC C{};
     for (int j = 0; j < W.njobs; ++j) C.job[j] = pack_wg(W.job[j], W);
-    const dim3 grid(kWgPerJob, W.njobs);
+    const bool pre = W.predraw && !W.bf16;
+    C.has_pre = pre ? 1 : 0;
+    if (pre) { C.pre = *W.predraw; C.pre_batch = W.predraw_batch; }
+    const dim3 grid(kWgPerJob + (pre ? 8 : 0), W.njobs);
     const bool relu = W.slope == 0.0f;
 #define HX_WG(ADAM_, RELU_, BF16_) hipLaunchKernelGGL((wgrad_kernel<ADAM_, RELU_, BF16_>), grid, dim3(kWide), 0, st, C)
     static const int dbg_off = getenv("HX_DBG_BF16_OFF") ? atoi(getenv("HX_DBG_BF16_OFF")) : 0;

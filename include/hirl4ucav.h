@@ -316,6 +316,11 @@ int hx_sample_batch(const uint64_t* total, int64_t cap, const float* ring, const
                     const float* bc_table, int64_t bc_len, int32_t batch, int32_t n_main, int32_t do_sample, uint64_t seed,
                     uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc, float* noise, float* rows, float* bc_rows,
                     void* stream);
+/* The same with the `guard` ring slots behind the head *total left out of the draw (see HxSample.guard / hx_hirl_front). */
+int hx_sample_batch_guarded(const uint64_t* total, int64_t cap, const float* ring, const float* expert_ring, int64_t expert_len,
+                            const float* bc_table, int64_t bc_len, int32_t batch, int32_t n_main, int32_t do_sample, uint64_t seed,
+                            uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc, float* noise, float* rows, float* bc_rows,
+                            uint32_t guard, void* stream);
 
 /* The draw of hx_sample_batch(do_sample = 1) as a description instead of a launch: hx_hirl_learn_sampled / hx_hirl_critic_grads_sampled
  * draw the indices and gather the rows inside the FIRST launch of the update (every workgroup repeats the cheap draw, each gathers
@@ -340,31 +345,34 @@ int hx_hirl_critic_grads_sampled(const HxNets* nets, const HxBatch* batch, const
 int hx_hirl_learn_sampled(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, const HxSample* sample, int32_t critic_step,
                           int32_t actor_phase, int32_t actor_step, int32_t do_polyak, int32_t w_kind, float w_given, float warm, void* stream);
 
-/* The FRONT launch (opt-in; fp32 networks): hx_actor_act_step_f32i for n envs (chooseAction + HarfangEnv.step + replay insert, train_all.py:343-345)
- * AND the first two launches of the hx_hirl_learn_sampled call that follows it (minibatch draw + gather, targetActor(s'), Q1/Q2(s, a) [+ the actor
- * call's forwards]; then targetCritic Q1/Q2 — HIRL.py:259-272) as workgroups of ONE launch: the acting workgroups take 32 rows each and so leave
- * half of the CUs to the update's workgroups, which would otherwise wait for the env step to finish although they depend on nothing it computes
- * EXCEPT the ring it inserts into.  Hence the one change of meaning: the minibatch is drawn from the ring as it stood BEFORE this env step
- * (*total_snap), leaving out the n slots the step may overwrite — i.e. uniformly from every transition that is in the buffer both before and
- * after the step (the reference draws after its one-transition append, buffer.py:45; at n envs per step the population differs by the newest
- * and, once the ring is full, the oldest n transitions).  Bit-identical to hx_actor_act_step_f32i followed by hx_hirl_learn_sampled with
- * HxSample.total = the snapshot and HxSample.guard = n.  The target critics wait IN the launch for the target actor's rows (per-row-tile
+/* The FRONT launch (opt-in; fp32 networks; noise_mode + 32: the policy's W2 from HxNets.actor_w2_x9 — the exact 9-term bf16 split, as
+ * hx_actor_act_step_x9 — else from HxNets.actor_w2_f32i): hx_actor_act_step_f32i / _x9 for n envs (chooseAction + HarfangEnv.step + replay insert,
+ * train_all.py:343-345) AND the first two launches of the learn() call that follows it (targetActor(s'), Q1/Q2(s, a) [+ the actor call's forwards];
+ * then targetCritic Q1/Q2 — HIRL.py:259-272) as workgroups of ONE launch: the acting workgroups take 32 rows each and so leave half of the CUs to
+ * the update's workgroups, which would otherwise wait for the env step to finish although they depend on nothing it computes EXCEPT the ring it
+ * inserts into.  Hence the one change of meaning: the minibatch (`batch`'s tiles, filled before this launch) is drawn from the ring as it stood
+ * BEFORE this env step, leaving out the n slots the step may overwrite (HxSample.guard = n) — i.e. uniformly from every transition that is in the
+ * buffer both before and after the step (the reference draws after its one-transition append, buffer.py:45; at n envs per step the population
+ * differs by the newest and, once the ring is full, the oldest n transitions).  Who fills the tiles: the previous hx_hirl_learn_back (its `next`:
+ * one more workgroup of the critics' gradient launch draws and gathers, on a CU that launch leaves idle), or hx_sample_batch_guarded as a launch of its own.
+ * Bit-identical to hx_actor_act_step_f32i / _x9 followed by hx_hirl_learn_sampled with HxSample.total read before the step and HxSample.guard = n
+ * (and launch B in 64-column workgroups: hx_debug_set_fwd_nt).  The target critics wait IN the launch for the target actor's rows (per-row-tile
  * counters `flags`, agent-scope relaxed accesses, bounded wait: bit 0 of *status is set if a wait gives up — workgroups are dispatched in
  * index order and the producers come first, so that is a fault, not a schedule).
- * hx_hirl_learn_back = the rest of the call (critic backward + gradients + Adam [+ the delayed actor step]); with `front` it also leaves
- * *front->total_snap = *total for the next front launch (which must follow with no env step in between; otherwise copy it yourself). */
+ * hx_hirl_learn_back = the rest of the call (critic backward + gradients + Adam [+ the delayed actor step]) on the same `batch`; next / next_tiles
+ * (or NULL): the draw of the NEXT front launch (guard = its n; *next->total is read inside this call's second launch, i.e. after this step's
+ * inserts and before the next step's) into tiles of their own. */
 typedef struct HxFront {
-    uint64_t* total_snap;  /* device word */
     uint32_t* flags;       /* [16] device words, zero before the first use */
     uint32_t* status;      /* device word, sticky */
     uint32_t epoch;        /* 1, 2, 3, ... : one per front launch on these flags */
 } HxFront;
-int hx_hirl_front(const float* actor_w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+int hx_hirl_front(float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
                   const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,
-                  const HxStepOpts* opts, const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, const HxSample* sample,
-                  int32_t actor_phase, int32_t w_kind, const HxFront* front, void* stream);
+                  const HxStepOpts* opts, const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, int32_t actor_phase, int32_t w_kind,
+                  const HxFront* front, void* stream);
 int hx_hirl_learn_back(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, int32_t critic_step, int32_t actor_phase, int32_t actor_step,
-                       int32_t do_polyak, int32_t w_kind, float w_given, float warm, const uint64_t* total, const HxFront* front, void* stream);
+                       int32_t do_polyak, int32_t w_kind, float w_given, float warm, const HxSample* next, const HxBatch* next_tiles, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -19,6 +19,7 @@ int hx_debug_set_fwd_nt(int32_t nt, int32_t skip, int32_t count);
 /* diagnostic builds only (make -C hirl4ucav_amd/csrc stamps); all return -1 in the shipped build */
 int hx_debug_stamps(float* host_out /* host, 80 floats: in-kernel phase stamps, 10 ns ticks */);
 int hx_debug_stamps_actp(float* host_out /* host, 80 floats: the persistent acting kernel's stamps (csrc/hx_actp.hip) */);
+int hx_debug_stamps_front(float* host_out /* host, 80 floats: the front launch's stamps (csrc/hx_front.hip): [0..7] launch B, [8..15] launch A, [56..] acting */);
 int hx_debug_spans(unsigned long long* host_spans /* host [8192][2] */, unsigned* host_tags /* host [8192]: 1 fwd_l2, 2 act_fused, 3 bwd_l2, 4 wgrad, 5 / 6 launch A / B inside the front launch */,
                    unsigned* host_n /* host */); /* life span of every workgroup since the last call */
 

@@ -35,7 +35,7 @@ def allowed_slots(tot, cap, guard):
     return np.setdiff1d(live, window)
 
 
-def make_pair(eng_mod, n, cap, use_bc, slope, seed):
+def make_pair(eng_mod, n, cap, use_bc, slope, seed, act="f32"):
     from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
     from hirl4ucav_amd.utils.buffer import DeviceReplay
 
@@ -50,6 +50,8 @@ def make_pair(eng_mod, n, cap, use_bc, slope, seed):
         e = eng_mod.HirlEngine(batch=128, use_bc=use_bc, slope=slope)
         e.x9_rows = None
         e.load_params(params["actor"], params["critic"], params["bc_actor"] if use_bc else None)
+        if act != "f32":
+            e.set_act_dtype(act)
         rep = DeviceReplay(cap)
         env = BatchedHarfangEnv(n, scenario=scen, seed=5, max_step=6, auto_reset=True, random_reset=True, replay=rep)  # (max_step 6: time-limit steps are not stored, so a step inserts fewer than n rows)
         env.reset()
@@ -75,11 +77,12 @@ def sorted_rows(rep):
     return r[np.lexsort(r.T[::-1])]
 
 
-@pytest.mark.parametrize("use_bc,slope,n,cap", [(True, 0.0, 1024, 2600), (False, 0.01, 576, 1400), (True, 0.0, 4096, 10000)])
-def test_front_launch_equals_act_step_then_guarded_learn(eng_mod, use_bc, slope, n, cap):
+@pytest.mark.parametrize("use_bc,slope,n,cap,act", [(True, 0.0, 1024, 2600, "f32"), (False, 0.01, 576, 1400, "f32"), (True, 0.0, 4096, 10000, "f32"),
+                                                    (True, 0.0, 4096, 10000, "f32x9"), (False, 0.01, 1000, 2400, "f32x9")])
+def test_front_launch_equals_act_step_then_guarded_learn(eng_mod, use_bc, slope, n, cap, act):
     from hirl4ucav_amd import _lib
     L = _lib.load()
-    side, exp, bc = make_pair(eng_mod, n, cap, use_bc, slope, seed=n)
+    side, exp, bc = make_pair(eng_mod, n, cap, use_bc, slope, seed=n, act=act)
     (a, env_a, rep_a), (b, env_b, rep_b) = side
     a.act_step(env_a, sigma=0.1, seed=3)  # some rows in the ring before the first draw
     snap = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -117,8 +120,8 @@ def test_front_launch_equals_act_step_then_guarded_learn(eng_mod, use_bc, slope,
         assert len(set(i[96:])) == 32 and i[96:].max() < 40
         if tot0 >= cap and tot0 % cap + n > cap:
             seen_wrapped_window = True
-        # the snapshot hx_hirl_learn_back left is the ring's total now
-        assert int(a._front[0].item()) == int(rep_a.total.item())
+        # the next call's minibatch is in waiting (drawn inside this call's learn() part), and only the first call drew with a launch of its own
+        assert a._front_drawn[:2] == (env_a, env_a.steps_issued) and a._front_drawn[8] == a.sample_calls + 1
     assert int(rep_a.total.item()) > cap, "the ring was meant to wrap"
     assert seen_wrapped_window, "no step had its guard window across the ring's end"
     assert a.update_count == 8
@@ -162,14 +165,16 @@ def test_step_learn_refuses_what_it_does_not_cover(eng_mod):
 
 
 def test_front_loop_free_running(eng_mod):
-    """40 free-running steps of the front loop (no re-synchronisation, the snapshot kept by hx_hirl_learn_back alone): finite losses, every Adam
-    step counted, the ring wrapped, the hand-off status word clear."""
+    """40 free-running steps of the front loop (no re-synchronisation, every minibatch but the first drawn by the previous call's learn() part): finite
+    losses, every Adam step counted, the ring wrapped, the hand-off status word clear."""
     side, exp, bc = make_pair(eng_mod, 512, 8192, True, 0.0, seed=9)
     (a, env_a, rep_a), _ = side
     a.act_step(env_a, sigma=0.1, seed=3)
     for k in range(40):
         a.step_learn(env_a, exp, bc, n_main=96, act_sigma=0.1, act_seed=3, sample_seed=11, bc_weight_now=100 if k % 4 == 0 else None, bc_warm_up_weight=0.05)
-        assert a._front_mark == (env_a, env_a.steps_issued)
+        assert a._front_drawn[:2] == (env_a, env_a.steps_issued)
+        if k == 20:  # an env step from outside: the tiles in waiting no longer fit, the next call draws afresh (a launch of its own) — and goes on
+            a.act_step(env_a, sigma=0.1, seed=3)
     a.front_check()
     assert np.isfinite(a.losses_host()).all() and a.critic_step == 40 and a.update_count == 20
-    assert int(rep_a.total.item()) > 8192 and int(a._front[0].item()) == int(rep_a.total.item())
+    assert int(rep_a.total.item()) > 8192

@@ -55,6 +55,20 @@ def main():
             hist = np.bincount((st // 2).astype(int))
             print("%-22s %5d | %8.2f %8.2f %8.2f %8.2f | %8.2f | %s" % (NAMES[tag], m.sum(), st.min(), st.max(), en.min(), en.max(), (en - st).mean(),
                                                                       " ".join("%d:%d" % (2 * i, c) for i, c in enumerate(hist) if c)))
+    stamps(loop, L)
+
+
+def stamps(loop, L):
+    """phase stamps (x 10 ns) of one workgroup of each role inside the front launch, critic-only and actor step"""
+    out = np.zeros(80, np.float32)
+    for k in range(4):
+        loop.step()
+        torch.cuda.synchronize()
+        assert L.hx_debug_stamps_front(out.ctypes.data_as(ctypes.c_void_p)) == 0
+        print("front launch, step kind %s (x10ns)" % ("actor" if not loop.eng.actor_trainable else "critic-only"))
+        print("  launch A wg: draw + all requests issued %d | (head) %d | staging + sync (loads waited) %d | z1 %d | stats %d | norm %d | mfma+store %d" % tuple(out[9:16].tolist()))
+        print("  launch B wg: requests issued + wait + x tile %d | previous net's head %d | staging + sync %d | z1 %d | stats %d | norm %d | mfma+store %d" % tuple(out[1:8].tolist()))
+        print("  acting wg:   prologue %d | mfma %d | head+sync %d | env step %d | reset/store/obs %d | stats %d | sync %d | ring+obs out %d" % tuple(out[57:65].tolist()))
 
 
 if __name__ == "__main__":
