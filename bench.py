@@ -78,10 +78,12 @@ def parse(argv=None):
                    help="issue the next act + env.step on a second stream beside critic-only learns (bit-identical results); measured on one "
                         "GPU it does not pay (every cross-stream event hand-off costs ~10 us on this runtime), so the default, at any N, is "
                         "the reference's strict act -> step -> sample -> learn order on one stream")
-    p.add_argument("--front", action="store_true",
-                   help="the FRONT launch (HirlEngine.step_learn, include/hirl4ucav.h hx_hirl_front): env step + the first two launches of learn() as ONE "
-                        "launch; the minibatch is then drawn from the ring as it stood before this step's insert, without the slots it may overwrite "
-                        "(fp32 HIRL on one GPU, <= 8,192 envs)")
+    p.add_argument("--front", dest="front", action="store_true", default=None,
+                   help="(default where it applies: fp32 HIRL with the policy's actions in one launch, <= 8,192 envs per GPU, batch <= 256) the FRONT launch "
+                        "(HirlEngine.step_learn, include/hirl4ucav.h hx_hirl_front): env step + the first two launches of learn() as ONE launch; the minibatch is "
+                        "then drawn from the ring as it stood before this step's insert, without the slots it may overwrite")
+    p.add_argument("--no-front", dest="front", action="store_false",
+                   help="the reference's order on every step: act -> env step -> insert -> draw -> learn, each launch after the other (the minibatch sees this step's transitions)")
     p.add_argument("--serial", action="store_true", help="(default) one stream")
     p.add_argument("--separate-launches", dest="separate_launches", action="store_true",
                    help="act and env step as two launches on every step (default: one fused launch, hx_actor_act_step)")
@@ -245,9 +247,10 @@ class Loop:
         # act + env step + replay insert as ONE launch at every size (hx_actor_act_step / hx_sac_act_step: up to 8,192 envs one 16- / 32-row
         # workgroup per row tile with the env step on its first wave, beyond that the persistent kernel of csrc/hx_actp.hip)
         self.fused = not (self.uniform or self.separate)
-        self.front = bool(getattr(args, "front", False))
-        if self.front and (self.sac or self.uniform or self.separate or args.overlap or args.staged or self.world > 1 or args.dtype not in ("f32", "f32x9") or n > 8192 or args.batch > 256):
-            raise SystemExit("--front: fp32 HIRL, one-call update path on one GPU, policy actions in one launch, at most 8,192 envs and batch 256")
+        front_ok = not (self.sac or self.uniform or self.separate or args.overlap or args.sample_launch or args.dtype not in ("f32", "f32x9") or n > 8192 or args.batch > 256)
+        if getattr(args, "front", None) and not front_ok:
+            raise SystemExit("--front: fp32 HIRL, policy actions in one launch, one stream, at most 8,192 envs per GPU and batch 256")
+        self.front = front_ok if getattr(args, "front", None) is None else bool(args.front)
 
     # ---- the hot path ------------------------------------------------------------------------------------------------
     def _act_env(self, timed=None, split=False, stamp=None):
@@ -892,10 +895,33 @@ def run_rank(args):
                      "env_step(own launch, every 4th step)": None if med["env"] is None else round(med["env"], 2),
                      "sample+learn": None if learn_us is None else round(learn_us, 2)},
     }
+    if loop.front and world == 1 and not pg:
+        # the SAME workload with every launch in the reference's order (act -> env step -> insert -> draw -> learn), timed the same way in the same process:
+        # what the front launch buys, and the figure to quote if the draw must see the current step's transitions
+        import copy
+        ref_args = copy.copy(args)
+        ref_args.front = False
+        ref_loop = Loop(ref_args, rank, world, device)
+        for _ in range(max(args.warmup, 64)):
+            ref_loop.step()
+        ref_reps = []
+        for _ in range(max(int(args.reps), 1)):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                ref_loop.step()
+            barrier()
+            ref_reps.append(time.perf_counter() - t0)
+        ref_dt = float(np.median(ref_reps))
+        res["reference_order"] = {"loop": "reference order (--no-front): the minibatch is drawn after this step's insert", "value": round(n_total * args.steps / ref_dt, 1),
+                                  "unit": "env steps/s", "ms_per_step": round(ref_dt / args.steps * 1e3, 5), "update_steps_per_s": round(args.steps / ref_dt, 1),
+                                  "repetitions": {"count": len(ref_reps), "statistic": "median", "ms_per_step": [round(t / args.steps * 1e3, 5) for t in ref_reps]}}
+        del ref_loop
+    res["config"]["loop"] = "front" if loop.front else "reference order"
     if loop.front:
         res["config"]["act_env"] = "FRONT launch (hx_hirl_front): act + env step + replay insert + launches A and B of learn() in one launch"
-        res["config"]["draw"] = ("from the ring as it stood before this step's insert, without the n slots the step may overwrite "
-                                 "(HxSample.guard; the default loop draws after the insert, like the reference)")
+        res["config"]["draw"] = ("uniform without replacement over the transitions that are in the ring before AND after this step's insert (drawn from the ring as it stood "
+                                 "before the step, without the n slots the step may overwrite: HxSample.guard); --no-front draws after the insert, like the reference")
         res["stage_us"]["front launch + rest of learn() (3 of every 4 steps)"] = None if med["front+back"] is None else round(med["front+back"], 2)
 
     env_roof = {"kernel": "env_step_kernel<PAIR, INSERT, EPB> (hx_env.hip)", "bound": "hbm",
@@ -912,6 +938,8 @@ def run_rank(args):
         us = float(np.mean(fused))
         fused_pmc = (profile_traffic(f"fused_{args.envs}") if args.dtype == "f32" else profile_traffic(f"fused_bf16_{args.envs}") if args.dtype == "bf16" else None) \
             if args.agent == "hirl" else None
+        if loop.front:  # (the front launch has PMC passes of its own)
+            fused_pmc = profile_traffic(f"front_{args.envs}") if args.dtype == "f32" else None
         fp32_equiv = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
         # which matrix-core instruction the 256 -> 512 product runs on: fp32 MFMA; bf16 MFMA; or — the fp32 HIRL policy from 16,384 rows on, and
         # --dtype f32x9 at every size — NINE bf16 MFMAs per fp32 product (the exact hi | mid | lo split): priced as executed bf16 FLOPs against the bf16 peak
@@ -922,6 +950,8 @@ def run_rank(args):
             flop, peak = fp32_equiv, FP32_MATRIX_PEAK_TFLOPS
         else:
             flop, peak = fp32_equiv, BF16_MATRIX_PEAK_TFLOPS
+        if loop.front:  # + the forward passes of launches A and B over the minibatch: 3 + 2 nets on a critic-only call, 4 + 4 on an actor call (every 2nd)
+            flop += int(6.5 * args.batch * ACTOR_FLOP)
         tf, gb = flop / us / 1e6, ENV_BYTES_FUSED * args.envs / us / 1e3
         mf, hf = tf / peak, gb / HBM_PEAK_GBPS
         hbm = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hf, 4), "bytes_per_launch": ENV_BYTES_FUSED * args.envs}
@@ -933,12 +963,12 @@ def run_rank(args):
         persistent = args.envs > 8192
         front_name = None
         if loop.front:  # + the forward passes of launches A (3.5 nets on average) and B (3 on average) over the minibatch
-            front_name = ("act_front_kernel<RELU, BNT> (hx_front.hip): the acting workgroups (32 rows each: policy inference + env step + fused replay insert) on half "
+            front_name = ("act_front_kernel<RELU, X3> (hx_front.hip): the acting workgroups (32 rows each: policy inference + env step + fused replay insert) on half "
                           "of the CUs, launches A and B of learn() (draw + gather, target actor, critics; target critics) on the other half")
         plain_name = (("act_persist_*_kernel<..., ENV = true> (hx_actp.hip): persistent workgroups (one per CU) looping over their row tiles, env step + "
                        "fused replay insert in the launch's tail") if persistent else
                       "act_fused_kernel<NRT, GAUSS, ENV = true, ...> (hx_act.hip): policy inference + env step + fused replay insert")
-        res["roofline"] = {"kernel": ((front_name + "; FLOPs: the policy's only") if front_name else plain_name) + ", the dominant kernel of the timed loop", **first, "traffic": (fused_pmc or {}).get("bytes"), "other_roof": second,
+        res["roofline"] = {"kernel": ((front_name + "; FLOPs: the policy's over the envs + the 6.5 forward passes (average) of launches A and B over the minibatch") if front_name else plain_name) + ", the dominant kernel of the timed loop", **first, "traffic": (fused_pmc or {}).get("bytes"), "other_roof": second,
                            "us_per_launch": round(us, 2), "launches_timed": len(fused),
                            "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the fused launches "
                                      "of the second pass (3 of every 4 steps)",

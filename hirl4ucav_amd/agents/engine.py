@@ -221,6 +221,7 @@ _lib.register("hx_hirl_learn_sampled", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P
 _lib.register("hx_hirl_front", [_vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, _vp,
                                  _P(_lib.HxStepOpts), _P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _P(HxFront), _vp])
 _lib.register("hx_hirl_learn_back", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _P(HxSample), _P(HxBatch), _vp])
+_lib.register("hx_hirl_critic_grads_back", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _P(HxBatch), _vp])
 _lib.register("hx_sample_batch_guarded", [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _i32, _i32, _i32, ctypes.c_uint64,
                                            ctypes.c_uint32, _f32, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint32, _vp])
 _lib.register("hx_hirl_critic_grads_sampled", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _i32, _vp])
@@ -655,36 +656,45 @@ class HirlEngine:
         if not self.staged:
             _lib.call("hx_hirl_learn_sampled", nets, ctypes.byref(batch), hyper, smp, self.critic_step, int(actor_phase), self.actor_step,
                       int(do_polyak), w_kind, w_given, float(bc_warm_up_weight), st)
-        else:  # sharded: the same stages with the exchanges of SURVEY.md 8e in between — ONE message per phase
-            gs = 1.0 / self.world
-            own_critic = self.grad_critic.data_ptr()
-            if self.xchg is not None:  # peers read this rank's gradient straight out of its message buffer: wgrad writes there
-                self.nets.grad_critic = self.xchg.write_buffer("critic").data_ptr()
+        else:
+            actor_fwd = (2 if w_kind == 1 else 1) if actor_phase else 0
             if smp is not None:
-                _lib.call("hx_hirl_critic_grads_sampled", nets, ctypes.byref(batch), hyper, smp, (2 if w_kind == 1 else 1) if actor_phase else 0, st)
+                grads = lambda: _lib.call("hx_hirl_critic_grads_sampled", nets, ctypes.byref(batch), hyper, smp, actor_fwd, st)  # noqa: E731
             else:
-                _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, (2 if w_kind == 1 else 1) if actor_phase else 0, st)
-            if before_exchange is not None:
-                before_exchange()
-            summed = self._allreduce(self.grad_critic, "critic")
-            self.nets.grad_critic = summed.data_ptr()
-            pk = 16 if do_polyak else 0  # + 16: soft_update of the target in the same launch (nothing reads it in between)
-            _lib.call("hx_adam", nets, hyper, 0 | pk, self.critic_step, gs, 0, 0.0, 0.0, B, st)
-            self.nets.grad_critic = own_critic
-            if actor_phase:
-                _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, int(w_kind == 1), 1, st)
-                if self.world > 1 or self.sharded_sequence:   # [dL_rl | dL_bc | count] in one message, w formed from the global count after the exchange
-                    if self.actor_msg is None:
-                        self.actor_msg = torch.zeros(int(_lib.load().hx_actor_message_floats()), dtype=torch.float32, device=self.device)
-                    msg = self.xchg.write_buffer("actor") if self.xchg is not None else self.actor_msg
-                    _lib.call("hx_hirl_actor_wgrad_split", nets, hyper, B, msg.data_ptr(), st)
-                    summed = self._allreduce(msg, "actor")
-                    _lib.call("hx_adam_mixed", nets, hyper, int(do_polyak), self.actor_step, gs, w_kind, w_given, float(bc_warm_up_weight),
-                              B * self.world, summed.data_ptr(), st)
-                else:                # one rank running the staged sequence (tests): the weight is known locally, bit-identical to the one-call path
-                    _lib.call("hx_hirl_actor_wgrad", nets, hyper, B, B, w_kind, w_given, float(bc_warm_up_weight), st)
-                    _lib.call("hx_adam", nets, hyper, 1 | pk, self.actor_step, gs, w_kind, w_given, float(bc_warm_up_weight), B, st)
+                grads = lambda: _lib.call("hx_hirl_critic_grads", nets, ctypes.byref(batch), hyper, actor_fwd, st)  # noqa: E731
+            self._learn_staged(grads, batch, actor_phase, do_polyak, w_kind, w_given, bc_warm_up_weight, before_exchange)
         self.actor_trainable = not self.actor_trainable  # HIRL.py:332
+
+    def _learn_staged(self, critic_grads, batch, actor_phase, do_polyak, w_kind, w_given, bc_warm_up_weight, before_exchange=None):
+        """sharded: the stages of learn() with the exchanges of SURVEY.md 8e in between — ONE message per phase.  critic_grads() issues the launches
+        that leave the critics' gradient behind (all of them, or — after a front launch — the rest of them)."""
+        B, st = self.batch, _lib.stream_ptr()
+        nets, hyper = ctypes.byref(self.nets), ctypes.byref(self.hyper)
+        gs = 1.0 / self.world
+        own_critic = self.grad_critic.data_ptr()
+        if self.xchg is not None:  # peers read this rank's gradient straight out of its message buffer: wgrad writes there
+            self.nets.grad_critic = self.xchg.write_buffer("critic").data_ptr()
+        critic_grads()
+        if before_exchange is not None:
+            before_exchange()
+        summed = self._allreduce(self.grad_critic, "critic")
+        self.nets.grad_critic = summed.data_ptr()
+        pk = 16 if do_polyak else 0  # + 16: soft_update of the target in the same launch (nothing reads it in between)
+        _lib.call("hx_adam", nets, hyper, 0 | pk, self.critic_step, gs, 0, 0.0, 0.0, B, st)
+        self.nets.grad_critic = own_critic
+        if actor_phase:
+            _lib.call("hx_hirl_actor_backward", nets, ctypes.byref(batch), hyper, int(w_kind == 1), 1, st)
+            if self.world > 1 or self.sharded_sequence:   # [dL_rl | dL_bc | count] in one message, w formed from the global count after the exchange
+                if self.actor_msg is None:
+                    self.actor_msg = torch.zeros(int(_lib.load().hx_actor_message_floats()), dtype=torch.float32, device=self.device)
+                msg = self.xchg.write_buffer("actor") if self.xchg is not None else self.actor_msg
+                _lib.call("hx_hirl_actor_wgrad_split", nets, hyper, B, msg.data_ptr(), st)
+                summed = self._allreduce(msg, "actor")
+                _lib.call("hx_adam_mixed", nets, hyper, int(do_polyak), self.actor_step, gs, w_kind, w_given, float(bc_warm_up_weight),
+                          B * self.world, summed.data_ptr(), st)
+            else:                # one rank running the staged sequence (tests): the weight is known locally, bit-identical to the one-call path
+                _lib.call("hx_hirl_actor_wgrad", nets, hyper, B, B, w_kind, w_given, float(bc_warm_up_weight), st)
+                _lib.call("hx_adam", nets, hyper, 1 | pk, self.actor_step, gs, w_kind, w_given, float(bc_warm_up_weight), B, st)
 
     def step_learn(self, env, expert=None, bc_table=None, n_main=None, act_noise=None, act_sigma=0.0, act_seed=0, out=None, sample_seed=0,
                    smooth_sigma=0.2, bc_weight_now=0.0, bc_warm_up_weight=0.0):
@@ -694,11 +704,10 @@ class HirlEngine:
         step, without the env.n slots the step may overwrite (uniform over every transition that is in the buffer before and after the step).
         Each call also draws the NEXT call's minibatch (inside its learn() part, after this step's inserts): a next call with the same tables,
         n_main, seed and sigma finds its tiles ready, any other draws them with a launch of its own first.
-        fp32 networks on one GPU, at most 8,192 envs, batch <= 256.  -> (actions, obs, reward, done, success) as act_step."""
+        fp32 networks, at most 8,192 envs per GPU, batch <= 256; one-call and sharded (staged) update paths.  -> (actions, obs, reward, done, success) as act_step."""
         replay, n, B = env.replay, env.n, self.batch
-        if self.staged or self.world > 1 or self.act_dtype not in ("f32", "f32x9") or self.nets.w2_bf16_all or replay is None:
-            raise _lib.HxError("step_learn: the front launch exists for the one-call fp32 path on one GPU with a replay ring attached to the env "
-                               "(acting format 'f32' or 'f32x9')")
+        if self.act_dtype not in ("f32", "f32x9") or self.nets.w2_bf16_all or replay is None:
+            raise _lib.HxError("step_learn: the front launch exists for the fp32 networks (acting format 'f32' or 'f32x9') with a replay ring attached to the env")
         if self._pending is not None:
             raise _lib.HxError("step_learn draws its own minibatch: a sample(defer=True) is still pending")
         if self._front is None:
@@ -755,8 +764,12 @@ class HirlEngine:
                   env.success.data_ptr(), ctypes.byref(env._opts), nets, ctypes.byref(batch), hyper, int(actor_phase), w_kind, ctypes.byref(front), st)
         env.steps_issued += 1
         nxt_draw, nxt_tiles = draw(nxt, self.sample_calls + 1), tiles_of(nxt)
-        _lib.call("hx_hirl_learn_back", nets, ctypes.byref(batch), hyper, self.critic_step, int(actor_phase), self.actor_step, int(do_polyak), w_kind, w_given,
-                  float(bc_warm_up_weight), ctypes.byref(nxt_draw), ctypes.byref(nxt_tiles), st)
+        if not self.staged:
+            _lib.call("hx_hirl_learn_back", nets, ctypes.byref(batch), hyper, self.critic_step, int(actor_phase), self.actor_step, int(do_polyak), w_kind, w_given,
+                      float(bc_warm_up_weight), ctypes.byref(nxt_draw), ctypes.byref(nxt_tiles), st)
+        else:  # a sharded rank: the same front launch (every rank draws from its own ring), then the stages with the exchanges in between
+            self._learn_staged(lambda: _lib.call("hx_hirl_critic_grads_back", nets, ctypes.byref(batch), hyper, ctypes.byref(nxt_draw), ctypes.byref(nxt_tiles), st),
+                               batch, actor_phase, do_polyak, w_kind, w_given, bc_warm_up_weight)
         self._front_drawn = (env, env.steps_issued, replay, expert, bc_table, n_main, int(sample_seed), float(smooth_sigma), self.sample_calls + 1, n)
         self._front_tiles = [nxt, cur]
         self.rows, self.bc_rows, self._idx, self._idx_bc, self._noise = cur  # what this call's learn() read (the attribute names sample() / learn() use)

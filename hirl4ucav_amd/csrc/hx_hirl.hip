@@ -369,19 +369,29 @@ int hx_hirl_front(float* state, int64_t n, int64_t stride, float* obs_io, float*
     return launch_front(N->actor, x9 ? nullptr : N->actor_w2_f32i, x9 ? N->actor_w2_x9 : nullptr, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed,
                         row0, call, Hy->slope, reward, done, success, *opts, FA, FB, *front, (hipStream_t)stream);
 }
+// the predraw of hx_hirl_learn_back / hx_hirl_critic_grads_back as a device-side description (nothing is launched here)
+static int make_predraw(const HxNets* N, const HxBatch* Bt, const HxSample* next, const HxBatch* next_tiles, void* stream, SampleDev* SD) {
+    HX_REQUIRE(next_tiles && next_tiles->batch == Bt->batch && next_tiles->rows && next_tiles->noise && next_tiles->rows != Bt->rows && next_tiles->noise != Bt->noise &&
+               !N->w2_bf16_all, "hx_hirl_learn_back: the next minibatch needs tiles of its own (this call still reads the current ones); fp32 update path");
+    bool fused = false;
+    if (int rc = prepare_draw(next, Bt->batch, const_cast<float*>(next_tiles->rows), const_cast<float*>(next_tiles->bc_rows), const_cast<float*>(next_tiles->noise),
+                              stream, SD, &fused, /*launch_now=*/false)) return rc;
+    HX_REQUIRE(fused, "hx_hirl_learn_back: the predraw covers minibatches of at most 256 rows");
+    return 0;
+}
+/* The sharded rank's form (as hx_hirl_critic_grads after a front launch): launches C and D without the optimizer step; grad_critic is ready for the exchange. */
+int hx_hirl_critic_grads_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, const HxSample* next, const HxBatch* next_tiles, void* stream) {
+    HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_critic_grads_back: batch must be a positive multiple of 16");
+    SampleDev SD{};
+    if (next) if (int rc = make_predraw(N, Bt, next, next_tiles, stream, &SD)) return rc;
+    return critic_back(N, Bt, Hy, stream, 0, false, next ? &SD : nullptr);
+}
 int hx_hirl_learn_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t critic_step, int32_t actor_phase, int32_t actor_step, int32_t do_polyak,
                        int32_t w_kind, float w_given, float warm, const HxSample* next, const HxBatch* next_tiles, void* stream) {
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_learn_back: batch must be a positive multiple of 16");
     HX_REQUIRE(critic_step >= 1 && (!actor_phase || actor_step >= 1), "hx_hirl_learn_back: Adam steps are 1-based");
     SampleDev SD{};
-    if (next) {
-        HX_REQUIRE(next_tiles && next_tiles->batch == Bt->batch && next_tiles->rows && next_tiles->noise && next_tiles->rows != Bt->rows && next_tiles->noise != Bt->noise &&
-                   !N->w2_bf16_all, "hx_hirl_learn_back: the next minibatch needs tiles of its own (this call still reads the current ones); fp32 update path");
-        bool fused = false;
-        if (int rc = prepare_draw(next, Bt->batch, const_cast<float*>(next_tiles->rows), const_cast<float*>(next_tiles->bc_rows), const_cast<float*>(next_tiles->noise),
-                                  stream, &SD, &fused, /*launch_now=*/false)) return rc;
-        HX_REQUIRE(fused, "hx_hirl_learn_back: the predraw covers minibatches of at most 256 rows");
-    }
+    if (next) if (int rc = make_predraw(N, Bt, next, next_tiles, stream, &SD)) return rc;
     int rc = critic_back(N, Bt, Hy, stream, critic_step, do_polyak != 0, next ? &SD : nullptr);
     if (rc || !actor_phase) return rc;
     if ((rc = hx_hirl_actor_backward(N, Bt, Hy, w_kind == 1, 1, stream))) return rc;

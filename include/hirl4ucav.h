@@ -373,6 +373,8 @@ int hx_hirl_front(float* state, int64_t n, int64_t stride, float* obs_io, float*
                   const HxFront* front, void* stream);
 int hx_hirl_learn_back(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, int32_t critic_step, int32_t actor_phase, int32_t actor_step,
                        int32_t do_polyak, int32_t w_kind, float w_given, float warm, const HxSample* next, const HxBatch* next_tiles, void* stream);
+/* A sharded rank's form: what hx_hirl_critic_grads leaves behind (grad_critic, ready for the exchange; no optimizer step) after a front launch, + the predraw. */
+int hx_hirl_critic_grads_back(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, const HxSample* next, const HxBatch* next_tiles, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -55,8 +55,15 @@ def check(d, n_gpus, steps, warmup, envs=4096, dtype="f32", fused=True):
     r = d["roofline"]
     check_roof(r)
     assert r["launches_timed"] > 0 and (r["traffic"] is None or r["traffic"] > 0) and r["us_per_launch"] > 0
+    front = d["config"].get("loop") == "front"
+    if front:  # the default loop where it applies: fp32 HIRL, <= 8,192 envs per GPU — env step + launches A and B of learn() in ONE launch
+        assert fused and envs <= 8192 and "act_front_kernel" in r["kernel"] and "draw" in d["config"]
+        assert d["stage_us"]["front launch + rest of learn() (3 of every 4 steps)"] >= r["us_per_launch"]
+        if n_gpus == 1 and "rccl_ranks" not in d:  # the same workload in the reference's order, timed in the same process
+            ro = d["reference_order"]
+            assert ro["value"] > 0 and abs(ro["value"] - envs * 1e3 / ro["ms_per_step"]) < 1e-3 * ro["value"] and ro["repetitions"]["count"] == 3
     if fused:  # the record describes the kernel the timed loop RUNS: act + env step in one launch, both roofs quoted
-        assert ("act_persist_" if envs > 8192 else "act_fused_kernel") in r["kernel"] and "ENV" in r["kernel"]
+        assert front or (("act_persist_" if envs > 8192 else "act_fused_kernel") in r["kernel"] and "ENV" in r["kernel"])
         # ... and it is the DOMINANT kernel of the step: no other stage's launch outlasts it
         st = d["stage_us"]
         assert all(v is None or r["us_per_launch"] >= 0.8 * v for k, v in st.items() if k.startswith(("act(", "env_step(")))
@@ -65,7 +72,7 @@ def check(d, n_gpus, steps, warmup, envs=4096, dtype="f32", fused=True):
         e = d["roofline_env_kernel"]
         assert e["bound"] == "hbm" and "env_step_kernel" in e["kernel"] and 0 < e["frac"] < 1 and "traffic_from_profiles" in e
         assert r["us_per_launch"] > e["us_per_launch"] * 0.8  # the fused launch contains the env step
-        assert d["stage_us"]["act+env_step(1 kernel)"] >= r["us_per_launch"] * 0.8  # events around the launch >= the kernel's own stamps
+        assert front or d["stage_us"]["act+env_step(1 kernel)"] >= r["us_per_launch"] * 0.8  # events around the launch >= the kernel's own stamps
     else:
         assert r["bound"] == "hbm" and "env_step_kernel" in r["kernel"] and "roofline_env_kernel" not in d
     assert "settle_s" in d and "timed_region" in d and d["stage_us"]["sample+learn"] > 0
@@ -83,6 +90,7 @@ def test_bench_single_gpu_line():
     sw = d["roofline_env_sweep"]
     assert [r["envs_per_launch"] for r in sw] == [4096, 65536, 1 << 20, 1 << 22] and sw[2]["frac"] > 0.4  # the >= 40 % HBM evidence
     # traffic: the committed PMC passes of THIS kernel at THIS size (fp32 HIRL, 4,096 envs), labelled as a profile artefact; never invented
+    assert d["config"]["loop"] == "front"
     tp = d["roofline"]["traffic_from_profiles"]
     assert d["roofline"]["traffic"] == tp["bytes"] == tp["fetch_bytes"] + tp["write_bytes"] and tp["source"] == "profiles/pmc_env_traffic.json"
     assert d["roofline_env_kernel"]["traffic"] == d["roofline_env_kernel"]["traffic_from_profiles"]["bytes"]
@@ -97,6 +105,9 @@ def test_bench_labels_follow_the_arguments():
     check(d, 1, 60, 10, envs=8192)
     w = d["config"]["workload"]
     assert "configs[3]" in w and "configs[1]" not in w and "HIRL-linear" in w and "8192 parallel circular" in w
+    d = run([sys.executable, "bench.py", "--no-front", "--no-cpu-baseline"] + common)  # the reference's order on every step: act + env step as a launch of their own
+    check(d, 1, 60, 10)
+    assert d["config"]["loop"] == "reference order" and "act_fused_kernel" in d["roofline"]["kernel"] and "reference_order" not in d
     d = run([sys.executable, "bench.py", "--actions", "uniform", "--no-cpu-baseline"] + common)
     check(d, 1, 60, 10, fused=False)
     assert "roofline_act" not in d and "configs[" not in d["config"]["workload"]

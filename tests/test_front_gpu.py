@@ -35,7 +35,7 @@ def allowed_slots(tot, cap, guard):
     return np.setdiff1d(live, window)
 
 
-def make_pair(eng_mod, n, cap, use_bc, slope, seed, act="f32"):
+def make_pair(eng_mod, n, cap, use_bc, slope, seed, act="f32", staged=False):
     from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
     from hirl4ucav_amd.utils.buffer import DeviceReplay
 
@@ -49,6 +49,7 @@ def make_pair(eng_mod, n, cap, use_bc, slope, seed, act="f32"):
     for _ in range(2):
         e = eng_mod.HirlEngine(batch=128, use_bc=use_bc, slope=slope)
         e.x9_rows = None
+        e.staged = staged  # the sharded rank's launch sequence (one rank: the exchanges are no-ops)
         e.load_params(params["actor"], params["critic"], params["bc_actor"] if use_bc else None)
         if act != "f32":
             e.set_act_dtype(act)
@@ -77,12 +78,13 @@ def sorted_rows(rep):
     return r[np.lexsort(r.T[::-1])]
 
 
-@pytest.mark.parametrize("use_bc,slope,n,cap,act", [(True, 0.0, 1024, 2600, "f32"), (False, 0.01, 576, 1400, "f32"), (True, 0.0, 4096, 10000, "f32"),
-                                                    (True, 0.0, 4096, 10000, "f32x9"), (False, 0.01, 1000, 2400, "f32x9")])
-def test_front_launch_equals_act_step_then_guarded_learn(eng_mod, use_bc, slope, n, cap, act):
+@pytest.mark.parametrize("use_bc,slope,n,cap,act,staged", [(True, 0.0, 1024, 2600, "f32", False), (False, 0.01, 576, 1400, "f32", False), (True, 0.0, 4096, 10000, "f32", False),
+                                                           (True, 0.0, 4096, 10000, "f32x9", False), (False, 0.01, 1000, 2400, "f32x9", False),
+                                                           (True, 0.0, 1024, 2600, "f32", True), (False, 0.0, 2048, 5000, "f32x9", True)])
+def test_front_launch_equals_act_step_then_guarded_learn(eng_mod, use_bc, slope, n, cap, act, staged):
     from hirl4ucav_amd import _lib
     L = _lib.load()
-    side, exp, bc = make_pair(eng_mod, n, cap, use_bc, slope, seed=n, act=act)
+    side, exp, bc = make_pair(eng_mod, n, cap, use_bc, slope, seed=n, act=act, staged=staged)
     (a, env_a, rep_a), (b, env_b, rep_b) = side
     a.act_step(env_a, sigma=0.1, seed=3)  # some rows in the ring before the first draw
     snap = torch.zeros(1, dtype=torch.int64, device="cuda")
