@@ -184,7 +184,6 @@ class SacEngine:
             out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         mode = 0 if not explore else (1 if eps is not None else 2)
         self.act_calls += 1
-        env.steps_issued += 1
         if self._x9_for(n):
             _lib.call("hx_sac_act_x9", self.policy.data_ptr(), self.w2_x9.data_ptr(), self.w2_f32i.data_ptr(), obs.data_ptr(), n, out.data_ptr(), mode,
                       _lib.ptr(eps), int(seed), int(row0), self.act_calls, _lib.stream_ptr())
@@ -201,6 +200,7 @@ class SacEngine:
             out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         mode = 0 if not explore else (1 if eps is not None else 2)
         self.act_calls += 1
+        env.steps_issued += 1
         if self._x9_for(n):
             _lib.call("hx_sac_act_step_x9", self.policy.data_ptr(), self.w2_x9.data_ptr(), self.w2_f32i.data_ptr(), env.state.data_ptr(), n, env.pitch,
                       env.obs.data_ptr(), out.data_ptr(), mode, _lib.ptr(eps), int(seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(),
