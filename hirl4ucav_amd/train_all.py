@@ -349,9 +349,28 @@ def main(config):
     log_rate = 300  # train_all.py:208
     ret = torch.zeros(n, device=device) if config.log_rewards else None
     last_stats = env.stats_dict()
+    # --loop front (default where it applies: the fp32 HIRL / TD3 agents, <= 8,192 envs per GPU, batch <= 256, one update per step): the env
+    # step and the first two launches of learn() as ONE launch (HirlEngine.step_learn) — the minibatch is then drawn from the ring as it stood before
+    # this step's insert.  --loop reference: the reference's order on every step (act -> env step -> insert -> draw -> learn)
+    front = (config.loop == "front" and not sac and not config.separate_launches and config.updates_per_step == 1 and n <= 8192 and batch <= 256
+             and getattr(config, "dtype", "f32") in ("f32", "f32x9"))
+    if rank == 0:
+        print(f"vector loop: {'front launch (env step + first launches of learn() in one launch; draw before the insert)' if front else 'reference order'}", flush=True)
     for episode in range(episode0, config.episodes):
         w_now, warm = bc_weight_schedule(config.type, episode, config.bc_weight) if hirl else (0.0, 0.0)
         for step in range(max_step):
+            if front and step < max_step - 1:  # (the last step of an episode has no learn() behind it, train_all.py:346-347)
+                expert_num = expert_num_after(expert_num, step, warm_up_rate)
+                eng.step_learn(env, expert, bc_table, n_main=batch - expert_num, act_sigma=0.1, act_seed=seed + 1, out=actions, sample_seed=seed + 2 + rank,
+                               bc_weight_now=w_now, bc_warm_up_weight=warm)
+                w_now = None  # afterwards learn()'s own returned weight is fed back (train_all.py:361): the stored device value
+                if ret is not None:
+                    ret += env.reward
+                if writer is not None and step % log_rate == 0:  # Loss/* every 300 steps, train_all.py:362-367
+                    c_, a_, b_, r__, f_, _w = eng.losses_host()
+                    for tag, v in (("Loss/Critic_Loss", c_), ("Loss/Actor_Loss", a_), ("Loss/BC_Loss", b_), ("Loss/RL_Loss", r__), ("Loss/BC_Fire_Loss", f_)):
+                        writer.add_scalar(tag, v, step + episode * max_step)
+                continue
             if config.separate_launches:  # chooseAction, then env.step: two launches
                 eng.act(env.obs, seed=seed + 1, row0=env.env_id0, out=actions) if sac else eng.act(env.obs, sigma=0.1, seed=seed + 1, row0=env.env_id0, out=actions)
                 env.step(actions)
@@ -454,6 +473,10 @@ def parser():
     p.add_argument("--result_dir", type=str, default="results")
     p.add_argument("--checkpoint_rate", type=int, default=25, help="episodes between validations (train_all.py:206)")
     p.add_argument("--bc_validate_from", type=int, default=1000, help="BC: first episode with validation (train_all.py:259)")
+    p.add_argument("--loop", type=str, default="front", choices=["front", "reference"],
+                   help="front (default where it applies: fp32 HIRL / TD3, <= 8,192 envs per GPU, batch <= 256, one update per step): env step + the first two "
+                        "launches of learn() as one launch; the minibatch is drawn from the ring as it stood before the step's insert, without the slots it may "
+                        "overwrite.  reference: act -> env step -> insert -> draw -> learn on every step (the minibatch sees this step's transitions)")
     p.add_argument("--separate_launches", action="store_true",
                    help="chooseAction and env.step as two launches (default: one fused launch). With <= 256 envs this keeps the replay "
                         "insert order, and so the whole run, reproducible bit for bit")
