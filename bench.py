@@ -918,6 +918,9 @@ def run_rank(args):
                                   "repetitions": {"count": len(ref_reps), "statistic": "median", "ms_per_step": [round(t / args.steps * 1e3, 5) for t in ref_reps]}}
         del ref_loop
     res["config"]["loop"] = "front" if loop.front else "reference order"
+    if loop.front and args.dtype == "f32" and loop.eng.front_x9:
+        res["config"]["acting_product"] = ("fp32 operands, the 256 -> 512 product as the exact 9-term bf16 split on bf16 MFMA with fp32 accumulation (the engine's fp32 acting "
+                                           "format wherever it is the faster one: from 16,384 rows on, and in the front launch); max error vs fp64 4.0e-7 against 5.4e-7 for fp32 MFMA")
     if loop.front:
         res["config"]["act_env"] = "FRONT launch (hx_hirl_front): act + env step + replay insert + launches A and B of learn() in one launch"
         res["config"]["draw"] = ("uniform without replacement over the transitions that are in the ring before AND after this step's insert (drawn from the ring as it stood "
@@ -943,7 +946,7 @@ def run_rank(args):
         fp32_equiv = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
         # which matrix-core instruction the 256 -> 512 product runs on: fp32 MFMA; bf16 MFMA; or — the fp32 HIRL policy from 16,384 rows on, and
         # --dtype f32x9 at every size — NINE bf16 MFMAs per fp32 product (the exact hi | mid | lo split): priced as executed bf16 FLOPs against the bf16 peak
-        x9 = args.agent == "hirl" and (args.dtype == "f32x9" or (args.dtype == "f32" and args.envs >= 16384))
+        x9 = args.agent == "hirl" and (args.dtype == "f32x9" or (args.dtype == "f32" and (args.envs >= 16384 or (loop.front and loop.eng.front_x9))))
         if x9:
             flop, peak = fp32_equiv + 8 * 2 * 256 * 512 * args.envs, BF16_MATRIX_PEAK_TFLOPS
         elif args.dtype in ("f32", "f32x9") or args.agent == "sac":

@@ -325,6 +325,9 @@ class HirlEngine:
         # (tools/ubench/actp_time.py).  None: never (fp32 MFMA at every size).  The three images are built at the first such call and kept
         # current by the actor's Adam steps from then on.
         self.x9_rows = 16384
+        # ... and in the FRONT launch (step_learn) at every size: there the acting workgroups take 32 rows each on half of the CUs and are the launch's
+        # longest — 22.2 against 26.8 us for 4,096 envs (tools/ubench/x9_32row.sh), 53.9 against 56.6 us per step.  False: fp32 MFMA there too.
+        self.front_x9 = True
         self.update_dtype, self.images = "f32", None
         # fp32 image of the actor's W2 in the acting kernel's operand order (hx_pack_w2_f32i): kept current by the actor's Adam steps
         self.w2_f32i = torch.zeros(H2 * H1, dtype=torch.float32, device=self.device)
@@ -428,11 +431,14 @@ class HirlEngine:
         elif self.act_dtype == "f32x9" or (self.act_dtype == "f32" and self._x9_live):
             _lib.call("hx_pack_w2_x9", self.actor.data_ptr(), 13, self.w2_x9.data_ptr(), _lib.stream_ptr())
 
-    def _x9_for(self, n):
-        """True when `n` rows of the fp32 policy take the exact-split format (set_act_dtype("f32x9"), or "f32" with n >= x9_rows)"""
+    def _x9_for(self, n, front=False):
+        """True when `n` rows of the fp32 policy take the exact-split format (set_act_dtype("f32x9"), or "f32" with n >= x9_rows, or "f32" in the
+        front launch with front_x9)"""
         if self.act_dtype == "f32x9":
             return True
-        if self.act_dtype != "f32" or self.update_dtype != "f32" or self.x9_rows is None or n < self.x9_rows:
+        if self.act_dtype != "f32" or self.update_dtype != "f32":
+            return False
+        if not (front and self.front_x9) and (self.x9_rows is None or n < self.x9_rows):
             return False
         if not self._x9_live:  # first large call: build the images; nets.actor_w2_x9 makes every later Adam step of the actor refresh them
             if self.w2_x9 is None:
@@ -759,7 +765,7 @@ class HirlEngine:
             self.actor_step += 1
             self.update_count += 1
         do_polyak = actor_phase and self.update_count % self.target_update_freq == 0  # HIRL.py:327-330
-        _lib.call("hx_hirl_front", env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(), out.data_ptr(), mode | self._mode_bits | (32 if self._x9_for(n) else 0),
+        _lib.call("hx_hirl_front", env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(), out.data_ptr(), mode | self._mode_bits | (32 if self._x9_for(n, front=True) else 0),
                   _lib.ptr(act_noise), float(act_sigma), int(act_seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(), env.done.data_ptr(),
                   env.success.data_ptr(), ctypes.byref(env._opts), nets, ctypes.byref(batch), hyper, int(actor_phase), w_kind, ctypes.byref(front), st)
         env.steps_issued += 1

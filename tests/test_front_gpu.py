@@ -48,7 +48,7 @@ def make_pair(eng_mod, n, cap, use_bc, slope, seed, act="f32", staged=False):
     side = []
     for _ in range(2):
         e = eng_mod.HirlEngine(batch=128, use_bc=use_bc, slope=slope)
-        e.x9_rows = None
+        e.x9_rows, e.front_x9 = None, False  # "f32" = fp32 MFMA in the front launch too, so that act_step (16-row workgroups, fp32 MFMA below x9_rows) is its reference
         e.staged = staged  # the sharded rank's launch sequence (one rank: the exchanges are no-ops)
         e.load_params(params["actor"], params["critic"], params["bc_actor"] if use_bc else None)
         if act != "f32":
@@ -164,6 +164,22 @@ def test_step_learn_refuses_what_it_does_not_cover(eng_mod):
     e.sample(rep, exp, bc, n_main=96, defer=True)
     with pytest.raises(Exception, match="pending"):
         e.step_learn(env, exp, bc, n_main=96)
+
+
+def test_front_launch_default_acting_format_is_the_exact_split(eng_mod):
+    """act_dtype "f32" with the engine's defaults: the front launch multiplies in the exact 9-term bf16 split (front_x9), i.e. it equals the front launch
+    of an engine set to "f32x9" bit for bit, and its actions stay within 2e-6 of the fp32-MFMA front launch."""
+    outs = []
+    for cfg in ("default", "f32x9", "mfma"):
+        side, exp, bc = make_pair(eng_mod, 1024, 4096, True, 0.0, seed=4, act="f32x9" if cfg == "f32x9" else "f32")
+        e, env, rep = side[0]
+        if cfg == "default":
+            e.front_x9 = True
+        env.step(torch.from_numpy(np.random.default_rng(2).uniform(-1, 1, (1024, 4)).astype(np.float32)).cuda())  # the same first step for all three
+        out = e.step_learn(env, exp, bc, n_main=96, act_sigma=0.1, act_seed=3, sample_seed=11, bc_weight_now=100)[0]
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0] - outs[2]).abs().max()) < 2e-6 and not torch.equal(outs[0], outs[2])
 
 
 def test_front_loop_free_running(eng_mod):
