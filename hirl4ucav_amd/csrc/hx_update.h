@@ -303,6 +303,11 @@ struct DrawMap {
 };
 __device__ __forceinline__ DrawMap draw_map(unsigned long long tot, unsigned long long cap, uint32_t guard) {
     DrawMap m;
+    if (guard == 0u) {  // (the default: no 64-bit division on the path of every launch-A workgroup)
+        m.live = (uint32_t)(tot < cap ? tot : cap);
+        m.e0 = 0u; m.h = 0xFFFFFFFFu; m.jump = 0u;
+        return m;
+    }
     if (tot < cap) {
         const unsigned long long over = tot + guard > cap ? tot + guard - cap : 0ull;
         m.e0 = (uint32_t)(over < tot ? over : tot);

@@ -1,7 +1,8 @@
 #!/bin/bash
 # One round's measurement set in ONE gpurun call -> gpurun_out/<tag>/ (copy what is to be judged into profiles/).
 #   tools/measure_round.sh <tag> [quick]
-# default line (sweep + CPU baselines), driver form, the other BASELINE configs, kernel stats under rocprofv3 for fp32 / bf16 / the sharded
+# default line (sweep + CPU baselines; the front loop where it applies, the reference order timed in the same run), driver form, the other BASELINE configs
+# (+ --no-front twins), kernel stats under rocprofv3 for fp32 (front and reference order) / bf16 / the sharded
 # rank's launch sequence over RCCL at world size 1 (program directly after `--`: python3 <script>).
 set -uo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}
@@ -17,9 +18,11 @@ while read -r cfg; do
   # shellcheck disable=SC2086
   python3 bench.py $cfg --no-cpu-baseline --no-sweep 2>/dev/null | tail -1 >> "$O/bench_other_configs.jsonl"
 done <<'CFGS'
+--no-front
 --dtype bf16
 --dtype bf16_policy
 --dtype f32x9
+--no-front --dtype f32x9
 --agent sac --envs 16384 --scenario serpentine
 --envs 16384 --scenario mixed
 --envs 16384 --scenario mixed --dtype bf16
@@ -27,8 +30,10 @@ done <<'CFGS'
 --envs 65536 --scenario circular --type linear --bc_weight 0.5
 --envs 131072 --scenario mixed --dtype bf16
 --envs 131072 --scenario mixed
+--envs 8192 --scenario circular --type linear --bc_weight 0.5 --no-front
 --actions uniform
 --staged
+--staged --no-front
 CFGS
 STEPS=4000
 stats() {  # stats <name> <bench flags...>: per-kernel stats of a $STEPS-step run under rocprofv3
@@ -38,6 +43,7 @@ stats() {  # stats <name> <bench flags...>: per-kernel stats of a $STEPS-step ru
   rm -rf "$O/prof_$name"
 }
 stats f32
+stats f32_reference_order --no-front
 stats bf16 --dtype bf16
 stats staged_f32 --staged
 if [ -z "$QUICK" ]; then

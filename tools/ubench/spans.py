@@ -67,7 +67,7 @@ def report(spans, tags, names):
 
 
 def main():
-    loop = B.Loop(B.parse([]), 0, 1, torch.device("cuda", 0))
+    loop = B.Loop(B.parse(["--no-front"]), 0, 1, torch.device("cuda", 0))  # the launches one by one (the front launch: tools/ubench/front_spans.py)
     L = _lib.load()
     L.hx_debug_spans.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]
     # tags are kernel ids (hx_update.h HX_SPAN_*)

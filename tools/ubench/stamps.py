@@ -15,7 +15,7 @@ _lib.SO_PATH = os.path.join(os.path.dirname(_lib.SO_PATH), "libhx_mi355_stamps.s
 import bench as B  # noqa: E402
 from hirl4ucav_amd.agents.engine import HxBatch  # noqa: E402
 
-loop = B.Loop(B.parse([]), 0, 1, torch.device("cuda", 0))
+loop = B.Loop(B.parse(["--no-front"]), 0, 1, torch.device("cuda", 0))  # the launches one by one (the front launch: tools/ubench/front_spans.py)
 for _ in range(20):
     loop.step()
 e = loop.eng
