@@ -925,7 +925,7 @@ def run_rank(args):
         res["config"]["act_env"] = "FRONT launch (hx_hirl_front): act + env step + replay insert + launches A and B of learn() in one launch"
         res["config"]["draw"] = ("uniform without replacement over the transitions that are in the ring before AND after this step's insert (drawn from the ring as it stood "
                                  "before the step, without the n slots the step may overwrite: HxSample.guard); --no-front draws after the insert, like the reference")
-        res["stage_us"]["front launch + rest of learn() (3 of every 4 steps)"] = None if med["front+back"] is None else round(med["front+back"], 2)
+        res["stage_us"]["front launch + rest of learn() (3 of every 4 steps; the front launch stamped: + ~25 us of instruments)"] = None if med["front+back"] is None else round(med["front+back"], 2)
 
     env_roof = {"kernel": "env_step_kernel<PAIR, INSERT, EPB> (hx_env.hip)", "bound": "hbm",
                 "achieved": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -975,7 +975,8 @@ def run_rank(args):
                            "us_per_launch": round(us, 2), "launches_timed": len(fused),
                            "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the fused launches "
                                      "of the second pass (3 of every 4 steps)",
-                           "note": ("vector-issue / LDS bound tile loop (LayerNorm + head per row), DESIGN.md section 4" if persistent else
+                           "note": ("bound by CU time: 128 acting workgroups of 32 rows beside 320-448 update workgroups on the other 128 CUs; neither roof is near (DESIGN.md section 4 K5)" if loop.front else
+                                    "vector-issue / LDS bound tile loop (LayerNorm + head per row), DESIGN.md section 4" if persistent else
                                     "latency-bound at this size: 256 workgroups, one round; neither roof is near (DESIGN.md section 4)"),
                            "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes of this launch (HIRL, this policy format, this size; FETCH_SIZE "
                                            "calibrated x2, WRITE_SIZE: tools/pmc_env_passes.sh); each of the 8 XCDs pulls the policy's weights into its own L2 once "
