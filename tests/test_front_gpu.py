@@ -196,3 +196,50 @@ def test_front_loop_free_running(eng_mod):
     a.front_check()
     assert np.isfinite(a.losses_host()).all() and a.critic_step == 40 and a.update_count == 20
     assert int(rep_a.total.item()) > 8192
+
+
+def test_front_loop_against_the_oracles(eng_mod):
+    """The front loop checked against the CHECKERS directly, step by step (not only against the separate launches): its env step == the C env oracle
+    stepped with the actions the launch chose (done / success flags exact, observations and rewards 1e-5); its learn() == the update oracle (pinned to
+    the reference's Agent.learn) on the minibatch the loop drew, from synchronised states: losses 2e-5 and every parameter within check_params' bars."""
+    from oracle import hirl_oracle as H
+    from tests import _oracle as ox
+    from tests.test_hirl_gpu import assert_losses, check_params, sync_oracle
+    from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    params, data = D.make_params(D.PARAM_SEED), D.make_data(D.DATA_SEED)
+    n = 768
+    e = eng_mod.HirlEngine(batch=128)
+    e.load_params(params["actor"], params["critic"], params["bc_actor"])
+    o = H.HirlOracle(params["actor"], params["critic"], params["bc_actor"])
+    bc = np.zeros((data["expert_s"].shape[0], 32), np.float32)
+    bc[:, 0:13], bc[:, 13:17] = data["expert_s"], data["expert_a"]
+    bc_t = torch.from_numpy(bc).cuda()
+    exp = DeviceReplay(D.N_EXPERT)
+    exp.store_rows(torch.from_numpy(data["expert_rows"]))
+    rep = DeviceReplay(4096)
+    env = BatchedHarfangEnv(n, scenario="straight_line", seed=1, auto_reset=False, replay=rep)
+    env.reset()
+    envs, oobs = ox.reset_batch(n, 0, 1, seed=1)
+    a0 = np.random.default_rng(0).uniform(-1, 1, (n, 4)).astype(np.float32)
+    env.step(torch.from_numpy(a0).cuda())
+    ox.step_batch(envs, a0, oobs)
+    for k in range(8):
+        sync_oracle(o, e, eng_mod)
+        was_actor = e.actor_trainable
+        w = 100 if k % 4 == 0 else (None if k % 4 < 3 else 0.3)
+        if w is None:
+            o.bc_weight = float(e.wstate.item())  # "keep the stored weight": the oracle keeps its own copy of it
+        acts, obs, r, d, sc = e.step_learn(env, exp, bc_t, n_main=96, act_sigma=0.1, act_seed=3, sample_seed=11, bc_weight_now=w, bc_warm_up_weight=0.05)
+        ro, do, so = ox.step_batch(envs, acts.cpu().numpy(), oobs)
+        np.testing.assert_array_equal(d.cpu().numpy(), do)
+        np.testing.assert_array_equal(sc.cpu().numpy(), so)
+        np.testing.assert_allclose(obs.cpu().numpy(), oobs, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r.cpu().numpy(), ro, rtol=1e-5, atol=1e-6)
+        rows, bcr = e.rows.cpu().numpy().reshape(128, 32), e.bc_rows.cpu().numpy().reshape(128, 32)
+        ref = o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), (bcr[:, 0:13], bcr[:, 13:17]), e._noise.cpu().numpy(),
+                      w if w is not None else o.bc_weight, 0.05)
+        assert_losses(e.losses_host(), ref, f"front step {k}")
+        check_params(e, o, eng_mod, f"front step {k}", was_actor_call=was_actor)
+    e.front_check()
