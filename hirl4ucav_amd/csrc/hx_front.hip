@@ -7,7 +7,7 @@
 // nothing the env step computes (the draw aside).  With 32 rows per acting workgroup the step takes 128 CUs for 22-27 us (tools/ubench/merge_probe.sh,
 // x9_32row.sh) and launches A (192-256 workgroups) and B (128-192) run on the other 128 CUs in that shadow.  B needs A's target-actor rows: it waits
 // for them IN the launch, per row tile (FrontSync, hx_fwd_body.h) — off the critical path here, because A is through long before the acting
-// workgroups are.  Workgroups are dispatched in index order: acting first (the longest), then A (job 0 = the target actor first), then B.
+// workgroups are.  Workgroups are dispatched in index order: acting first (the longest), then the update's jobs in FrontCtl::order.
 // CU time is what runs out in the shadow (tools/ubench/front_spans.py), so the minibatch is NOT drawn here: the previous hx_hirl_learn_back left its
 // tiles behind (predraw_wg in its first launch), and launch B runs in 64-column workgroups whatever its job count.
 // The draw's meaning changes (it cannot see this step's inserts and must not read the slots they overwrite): include/hirl4ucav.h hx_hirl_front.
@@ -24,8 +24,10 @@ namespace {
 
 struct FrontCtl {
     int n_act;         // acting workgroups (32 rows each)
-    int n_a, per_a;    // launch A: workgroups, workgroups per job (row tiles x column workgroups)
-    int per_b;         // launch B: workgroups per job
+    int per;           // workgroups per job of launches A and B (row tiles x column workgroups; both in 64-column workgroups)
+    // dispatch order of the update's jobs behind the acting workgroups: job of launch A (0..3) or 16 + job of launch B.  The 128 CUs of the shadow take
+    // them round by round (two jobs per round at B = 128); the launches' own order (A's jobs, then B's) is as good as any (tools/ubench/front_order.sh)
+    unsigned char order[8];
     FrontSync sync;
 };
 
@@ -53,12 +55,9 @@ __global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArg
         return;
     }
     b -= C.n_act;
-    if (b < C.n_a) {
-        fwd_l2_body<kNT, RELU, false, false, 1>(FA, NoSample{}, b % C.per_a, b / C.per_a, u.a, C.sync);
-        return;
-    }
-    b -= C.n_a;
-    fwd_l2_body<BNT, RELU, false, false, 2>(FB, NoSample{}, b % C.per_b, b / C.per_b, u.b, C.sync);
+    const int k = b / C.per, bx = b - k * C.per, job = C.order[k];
+    if (job < 16) fwd_l2_body<kNT, RELU, false, false, 1>(FA, NoSample{}, bx, job, u.a, C.sync);
+    else fwd_l2_body<BNT, RELU, false, false, 2>(FB, NoSample{}, bx, job - 16, u.b, C.sync);
 }
 
 }  // namespace
@@ -85,15 +84,32 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, floa
     CA.slope = FA.slope; CA.zero_nf = FA.zero_nf; CA.zero_f = FA.zero_f; CA.zero_i = FA.zero_i; CA.images = nullptr; CA.rowmap = 1;
     CB.slope = FB.slope; CB.zero_nf = FB.zero_nf; CB.zero_f = FB.zero_f; CB.zero_i = FB.zero_i; CB.images = nullptr; CB.rowmap = 1;
     const int rows = FA.job[0].rows, tiles = (rows + RT - 1) / RT;
-    HX_REQUIRE(tiles * FB.njobs < 128, "hx_hirl_front: minibatches of at most 256 rows");
-    const int bnt = kNT;
+    HX_REQUIRE(tiles * FB.njobs < 128 && FA.njobs + FB.njobs <= 8, "hx_hirl_front: minibatches of at most 256 rows, at most 8 forward jobs");
     FrontCtl C{};
     C.n_act = (int)((n + 2 * RT - 1) / (2 * RT));
-    C.per_a = tiles * (H2 / kNT); C.n_a = C.per_a * FA.njobs;
-    C.per_b = tiles * (H2 / bnt);
+    C.per = tiles * (H2 / kNT);
+    {   // launch A's job 0 is the target actor, launch B's jobs 0 and 1 the target critics that feed on it (make_launch_a / make_launch_b)
+        int k = 0;
+        // HX_FRONT_ORDER (tuning knob, tools/ubench/front_order.sh): 0 = launch A's jobs, then launch B's (default); 1 = the target critics right behind the
+        // target actor and Q1, the rest last (+1.1 us per step: measured); 2 = the critic call's five jobs, then the actor call's extras (no difference)
+        static const int variant = getenv("HX_FRONT_ORDER") ? atoi(getenv("HX_FRONT_ORDER")) : 0;
+        if (variant == 1) {
+            C.order[k++] = 0; C.order[k++] = 1;
+            for (int j = 0; j < FB.njobs; ++j) C.order[k++] = (unsigned char)(16 + j);
+            for (int j = 2; j < FA.njobs; ++j) C.order[k++] = (unsigned char)j;
+        } else if (variant == 2) {
+            C.order[k++] = 0; C.order[k++] = 1; C.order[k++] = 2; C.order[k++] = 16; C.order[k++] = 17;
+            for (int j = 3; j < FA.njobs; ++j) C.order[k++] = (unsigned char)j;
+            for (int j = 2; j < FB.njobs; ++j) C.order[k++] = (unsigned char)(16 + j);
+        } else {
+            for (int j = 0; j < FA.njobs; ++j) C.order[k++] = (unsigned char)j;
+            for (int j = 0; j < FB.njobs; ++j) C.order[k++] = (unsigned char)(16 + j);
+        }
+    }
+    static_assert(kNT == 64, "launch B in launch A's tiling");
     C.sync = FrontSync{front.flags, front.epoch * (uint32_t)(H2 / kNT), front.status};
     HX_REQUIRE(tiles <= 16, "hx_hirl_front: at most 16 row tiles (HxFront.flags)");
-    const dim3 grid((unsigned)(C.n_act + C.n_a + C.per_b * FB.njobs));
+    const dim3 grid((unsigned)(C.n_act + C.per * (FA.njobs + FB.njobs)));
     const bool relu = slope == 0.0f;
 #define HX_FRONT(RELU_, X3_) do { \
         if (o.ev_start && o.ev_stop) hipExtLaunchKernelGGL((act_front_kernel<RELU_, X3_>), grid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C); \
