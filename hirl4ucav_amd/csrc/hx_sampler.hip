@@ -149,7 +149,7 @@ int hx_sample_batch_guarded(const uint64_t* total, int64_t cap, const float* rin
                             uint32_t call, float sigma, int32_t* idx, int32_t* idx_bc, float* noise, float* rows, float* bc_rows,
                             uint32_t guard, void* stream) {
     HX_REQUIRE(idx && ring && rows && batch > 0 && batch <= 1024 && n_main >= 0 && n_main <= batch, "hx_sample_batch: bad arguments");
-    HX_REQUIRE(guard == 0 || (do_sample && (int64_t)guard < cap), "hx_sample_batch_guarded: the guard must leave slots to draw from");
+    HX_REQUIRE(guard == 0 || (do_sample && 2 * (int64_t)guard <= cap), "hx_sample_batch_guarded: a guard of more than half the ring leaves too little to draw from (cap >= 2 n)");
     HX_REQUIRE(!do_sample || (total && cap > 0), "hx_sample_batch: sampling needs total and cap");
     HX_REQUIRE(n_main == batch || expert_ring, "hx_sample_batch: expert rows requested without an expert ring");
     SampleArgs A{(const unsigned long long*)total, cap, expert_len, bc_len, batch, n_main, seed, call, sigma, idx, idx_bc, noise,

@@ -721,6 +721,7 @@ inline int prepare_draw(const HxSample* S, int B, float* rows, float* bc_rows, f
     HX_REQUIRE(!S->bc_table == !S->idx_bc && (!S->bc_table || bc_rows), "hx_*_sampled: bc_table, idx_bc and bc_rows go together");
     *fused = B <= kFusedBatchMax;
     HX_REQUIRE(!S->guard || *fused, "hx_*_sampled: HxSample.guard is honoured by the fused draw only (batch <= 256)");
+    HX_REQUIRE(!S->guard || 2 * (int64_t)S->guard <= S->cap, "hx_*_sampled: a guard of more than half the ring leaves too little to draw from (cap >= 2 n)");
     if (*fused) {
         *SD = SampleDev{(const unsigned long long*)S->total, S->ring, S->expert_ring ? S->expert_ring : S->ring, S->bc_table, rows,
                         S->bc_table ? bc_rows : nullptr, noise, S->idx, S->idx_bc, (long long)S->cap, (uint32_t)S->expert_len, (uint32_t)S->bc_len,

@@ -395,6 +395,8 @@ def main(config):
                 c_, a_, b_, r__, f_, _w = eng.losses_host()
                 for tag, v in (("Loss/Critic_Loss", c_), ("Loss/Actor_Loss", a_), ("Loss/BC_Loss", b_), ("Loss/RL_Loss", r__), ("Loss/BC_Fire_Loss", f_)):
                     writer.add_scalar(tag, v, step + episode * max_step)
+        if front:
+            eng.front_check()  # a front launch whose in-launch wait gave up read a half-written minibatch: stop here, not at the next validation
         if rank == 0:
             c, a, b, r_, f, w = eng.losses_host()
             st = env.stats_dict()

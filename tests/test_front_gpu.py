@@ -164,6 +164,14 @@ def test_step_learn_refuses_what_it_does_not_cover(eng_mod):
     e.sample(rep, exp, bc, n_main=96, defer=True)
     with pytest.raises(Exception, match="pending"):
         e.step_learn(env, exp, bc, n_main=96)
+    e._pending = None
+    from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+    small = DeviceReplay(600)  # fewer than 2 n slots: nothing would be left to draw from once the ring is full
+    env2 = BatchedHarfangEnv(512, scenario="straight_line", seed=1, replay=small)
+    env2.reset()
+    with pytest.raises(Exception, match="half the ring"):
+        e.step_learn(env2, exp, bc, n_main=96)
 
 
 def test_front_launch_default_acting_format_is_the_exact_split(eng_mod):
