@@ -49,13 +49,13 @@ static __device__ float hx_dbg[80];
 #define STAMP() TS_[tsn_++] = __builtin_amdgcn_s_memrealtime()
 #define STAMP_FLUSH(base, cond) do { if (cond) { for (int i_ = 1; i_ < tsn_; ++i_) hx_dbg[(base) + i_] = (float)(TS_[i_] - TS_[i_ - 1]); hx_dbg[(base)] = (float)tsn_; } } while (0)
 // life span of EVERY workgroup of every launch (first stamp .. now), appended to the file's log: where a learn() spends its time BETWEEN
-// workgroups.  tag = HX_SPAN_* (which kernel)
+// workgroups.  tag = HX_SPAN_* (which kernel) | blockIdx.x << 8 | blockIdx.y << 24
 constexpr int kSpanCap = 8192;
 static __device__ unsigned long long hx_span[kSpanCap][2];
 static __device__ unsigned hx_span_tag[kSpanCap];
 static __device__ unsigned hx_span_n;
 #define SPAN_LOG(tag) do { if (threadIdx.x == 0) { const unsigned long long e_ = __builtin_amdgcn_s_memrealtime(); const unsigned i_ = atomicAdd(&hx_span_n, 1u); \
-    if (i_ < (unsigned)kSpanCap) { hx_span[i_][0] = TS_[0]; hx_span[i_][1] = e_; hx_span_tag[i_] = (unsigned)(tag); } } } while (0)
+    if (i_ < (unsigned)kSpanCap) { hx_span[i_][0] = TS_[0]; hx_span[i_][1] = e_; hx_span_tag[i_] = (unsigned)(tag) | (blockIdx.x << 8) | (blockIdx.y << 24); } } } while (0)
 // the file's share of hx_debug_stamps / hx_debug_spans (hx_core.hip): stamp words [lo, hi) and the span log, which is cleared
 #define HX_DEFINE_DEBUG_COLLECTORS(name, lo, hi) \
     namespace hx { \

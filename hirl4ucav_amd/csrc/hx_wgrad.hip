@@ -129,6 +129,13 @@ inline WgJobC pack_wg(const WgJob& J, const WgArgs& A) {
 // per MFMA instead of 4), fp32 accumulation per slot, the slot's BC weight applied to the fp32 sum; every other gradient (biases, LayerNorm,
 // layer 1, the head) is fp32 arithmetic on fp32 values.  With ADAM the step also refreshes the bf16 images of W2 (forward, transposed,
 // target).
+// the layer-1 workgroups' inner stamps (a dozen, each an s_waitcnt lgkmcnt(0)) lengthen that path: only with -DHX_STAMPS_L1 (tools/ubench/stamps.py's
+// layer-1 line); the default stamps build keeps the workgroup's life span alone, so that tools/ubench/wgrad_blocks.py compares like with like
+#ifdef HX_STAMPS_L1
+#define STAMP_L1() STAMP()
+#else
+#define STAMP_L1()
+#endif
 template <bool ADAM, bool RELU, bool BF16 = false>
 __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
     __shared__ __attribute__((aligned(16))) float lds[kWgRowChunk * XP + kWgRowChunk * 12 + kWgRG * kWgCols * kRedP];
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
         const int k = kb + cl;
         const int in = J.m.in;
         const float g1 = J.net[J.m.g1() + k], be1 = J.net[J.m.be1() + k];
-        STAMP();
+        STAMP_L1();
         float db1 = 0.f, dg = 0.f, dbe = 0.f, dw1[17];
 #pragma unroll
         for (int i = 0; i < 17; ++i) dw1[i] = 0.f;
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                     zv[i] = S.z1[o];
                     dv[i] = S.dh1[o];
                 }
-                STAMP();
+                STAMP_L1();
                 // the chunk's shared operands are requested BEFORE the barrier that frees the LDS tiles: one round trip with the loads above
                 static_assert(kWgRowChunk * XP <= 5 * kWide && kWgRowChunk <= kWide && kColWgB == 8, "staging: five words + one row per thread");
                 // (whole waves past the end of a tile skip their loads behind a scalar branch: at B = 128 the input tile is 2.5 of the 5
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                     const int e = tid + q * kWide;
                     if (w0 + q * kWide < nr * XP) xst[q] = S.x[(size_t)c0 * XP + (e < nr * XP ? e : 0)];
                 }
-                STAMP();
+                STAMP_L1();
                 const int er = tid < nr ? tid : 0;
                 v2f st1v;  // (unset in a skipping wave, which never stores it)
                 v4f l0, l1, l2, l3;
@@ -458,14 +465,14 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                     const v4f* lp4 = reinterpret_cast<const v4f*>(S.lnp + (size_t)(c0 + er) * (2 * kColWgB));  // [8 column workgroups][2]
                     l0 = lp4[0]; l1 = lp4[1]; l2 = lp4[2]; l3 = lp4[3];
                 }
-                STAMP();
+                STAMP_L1();
                 if (lae_pending) {
                     lae.fetch(J, lidx);
                     lae_pending = false;
                 }
-                STAMP();
+                STAMP_L1();
                 __syncthreads();
-                STAMP();
+                STAMP_L1();
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
                     const int e = tid + q * kWide;
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                     *reinterpret_cast<float4*>(rinfo + tid * 8) = make_float4(st1v[0], st1v[1], s1 * (1.0f / H1), s2 * (1.0f / H1));
                 }
                 __syncthreads();
-                STAMP();
+                STAMP_L1();
                 for (int rb0 = 0; rb0 < nr; rb0 += kWgRG * 4) {
                     const int rb = rg + rb0;
                     if (rb0 != 0) {
@@ -513,27 +520,27 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
                 }
             }
         }
-        STAMP();
+        STAMP_L1();
         float* my = red + (rg * kWgCols + cl) * kRedP;
         my[0] = db1; my[1] = dg; my[2] = dbe;
 #pragma unroll
         for (int i = 0; i < 17; ++i) my[3 + i] = dw1[i];
-        STAMP();
+        STAMP_L1();
         __syncthreads();
-        STAMP();
+        STAMP_L1();
         if (llive) {
             float v = sum_groups(red + ocol * kRedP + oitem, ohalf);
             if ((oitem == 1 || oitem == 2) && J.m.no_ln) v = 0.0f;
 #ifdef HX_STAMPS
             asm volatile("" ::"v"(v));
-            STAMP();
+            STAMP_L1();
 #endif
             if (ohalf == 0) {
                 J.grad[lidx] = v;
                 if (ADAM) lae.apply(J, A.ad, lidx, v);
             }
         }
-        STAMP();
+        STAMP_L1();
         STAMP_FLUSH(48, b == kWgTilesPerBlock + kWgVecWgs && j == 0 && tid == 0);
         SPAN_LOG(HX_SPAN_WGRAD);
     }

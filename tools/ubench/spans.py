@@ -31,7 +31,17 @@ def fetch(L):
     rc = L.hx_debug_spans(spans.ctypes.data_as(ctypes.c_void_p), tags.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n))
     assert rc == 0, rc
     k = min(int(n.value), CAP)
-    return spans[:k].astype(np.int64), tags[:k]
+    return spans[:k].astype(np.int64), tags[:k] & 0xFF  # (bits 8..: the workgroup's blockIdx — fetch_blocks)
+
+
+def fetch_blocks(L):
+    """as fetch(), with the workgroups' blockIdx.x / blockIdx.y"""
+    spans = np.zeros((CAP, 2), np.uint64)
+    tags = np.zeros(CAP, np.uint32)
+    n = ctypes.c_uint(0)
+    assert L.hx_debug_spans(spans.ctypes.data_as(ctypes.c_void_p), tags.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)) == 0
+    k = min(int(n.value), CAP)
+    return spans[:k].astype(np.int64), tags[:k] & 0xFF, (tags[:k] >> 8) & 0xFFFF, tags[:k] >> 24
 
 
 def report(spans, tags, names):

@@ -1,5 +1,7 @@
 """Phase stamps of one fwd_l2 / bwd_l2 / wgrad / act_fused workgroup.  Diagnostic build (never the product .so):
     make -C hirl4ucav_amd/csrc stamps      (-> hirl4ucav_amd/libhx_mi355_stamps.so)
+The layer-1 fields of the wgrad line are filled only by a build with -DHX_STAMPS_L1 (a dozen stamps inside that path double its length: the default stamps
+build leaves them out so that workgroup life spans stay comparable, tools/ubench/wgrad_blocks.py).
 """
 import ctypes
 import os
