@@ -107,7 +107,11 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, floa
         }
     }
     static_assert(kNT == 64, "launch B in launch A's tiling");
-    C.sync = FrontSync{front.flags, front.epoch * (uint32_t)(H2 / kNT), front.status};
+    {   // a row tile's counter advances by (column workgroups of the target actor's job) + 1 per front launch
+        const uint32_t per = (uint32_t)(H2 / kNT) + 1u;
+        HX_REQUIRE(FB.job[0].act_mode == 1 && FB.job[0].prev.net == FA.job[0].net, "hx_hirl_front: launch B's first job feeds on launch A's first");
+        C.sync = FrontSync{front.flags, (front.epoch - 1u) * per + (per - 1u), front.epoch * per, front.status, FB.job[0].noise, FB.job[0].noise_clamp};
+    }
     HX_REQUIRE(tiles <= 16, "hx_hirl_front: at most 16 row tiles (HxFront.flags)");
     const dim3 grid((unsigned)(C.n_act + C.per * (FA.njobs + FB.njobs)));
     const bool relu = slope == 0.0f;

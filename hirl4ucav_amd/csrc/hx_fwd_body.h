@@ -81,13 +81,18 @@ struct FwdLds {
 
 // FRONT (hx_front.hip: launches A and B of learn() as workgroups of the act + env launch, B waiting for A in-launch):
 //   0  a launch of its own (fwd_l2_kernel)
-//   1  producer: job 0 (the target actor) writes its z2 tile with agent-scope relaxed stores and then bumps its row tile's counter X.flags[rt]
-//      (tools/ubench/handoff_probe.hip: the only hand-off form that does not cost a cache flush on this machine)
-//   2  consumer: a job that feeds on the previous net's head waits (bounded) for the counter of its row tile and reads that z2 with agent-scope loads
+//   1  producer: job 0 (the target actor) writes its z2 tile with agent-scope relaxed stores and counts itself in on its row tile's counter X.flags[rt]
+//      (tools/ubench/handoff_probe.hip: the only hand-off form that does not cost a cache flush on this machine); the LAST of the tile's column
+//      workgroups then evaluates the net's head for the tile's 16 rows — tanh, smoothing noise, clamp: what every consumer workgroup of a launch of its own
+//      repeats for itself, 2.7 us of CU time each — writes the action rows and counts once more
+//   2  consumer: a job that feeds on the previous net's head waits (bounded) for the counter of its row tile and reads the action rows with agent-scope loads
 struct FrontSync {
-    unsigned* flags;   // [row tiles] monotonic counters
-    unsigned target;   // value a row tile's counter reaches once this launch's producers are through
+    unsigned* flags;   // [row tiles] monotonic counters: + 1 per column workgroup of the producer job, + 1 once the tile's action rows are written
+    unsigned arrive;   // value a row tile's counter shows when the LAST column workgroup of the producer job has counted itself in
+    unsigned target;   // value it reaches once the tile's action rows are there: what the consumers wait for
     unsigned* status;  // sticky: bit 0 = a consumer gave up waiting
+    const float* noise;  // [4] the call's target-smoothing draw (or null) and its clamp: applied by the producer's last column workgroup
+    float noise_clamp;
 };
 template <int NT, bool RELU, bool SAMPLE, bool BF16, int FRONT, typename SAT>
 __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, const int bx, const int by, FwdLds<NT, SAMPLE, BF16>& SL, const FrontSync& X) {
@@ -191,15 +196,16 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
                 }
             }
             __syncthreads();
+            if (tid < nrow * 4) xs[(tid >> 2) * XP + 13 + (tid & 3)] = ld_agent(J.prev.ws.outv + (size_t)(r0 + (tid >> 2)) * OW + (tid & 3));
         }
     }
-    if (head_mode && wave < nrow) {
+    if (FRONT != 2 && head_mode && wave < nrow) {
         // head of the previous net: wave w owns row w (its loads go out right behind the ones above, nothing waited on yet)
         const int r = wave;
         RowReg<H2> xh, y;
         float mean, rstd, o[4];
-        if (J.prev.m.out == 4) head_row4<RELU, FRONT == 2>(J.prev.ws.z2 + (size_t)(r0 + r) * H2, J.prev.net, J.prev.m, slope, xh, y, mean, rstd, o);
-        else head_row<4, RELU, FRONT == 2>(J.prev.ws.z2 + (size_t)(r0 + r) * H2, J.prev.net, J.prev.m, slope, xh, y, mean, rstd, o);
+        if (J.prev.m.out == 4) head_row4<RELU>(J.prev.ws.z2 + (size_t)(r0 + r) * H2, J.prev.net, J.prev.m, slope, xh, y, mean, rstd, o);
+        else head_row<4, RELU>(J.prev.ws.z2 + (size_t)(r0 + r) * H2, J.prev.net, J.prev.m, slope, xh, y, mean, rstd, o);
         if (lane < 4) {
             float a = fast_tanh(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // Actor.forward's tanh, HIRL.py:140
             if (J.noise) {              // target smoothing, HIRL.py:264-267
@@ -368,10 +374,36 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
         }
     }
     if constexpr (FRONT == 1) {
-        if (by == 0) {  // everything this workgroup published has left the CU: count it in for the consumers of the row tile
+        if (by == 0) {  // everything this workgroup published has left the CU: count it in
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(&X.flags[rt], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int* last = reinterpret_cast<int*>(lds);  // (every wave is past its last LDS access)
+            if (tid == 0) *last = __hip_atomic_fetch_add(&X.flags[rt], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == X.arrive;
+            __syncthreads();
+            if (*last) {  // the tile's last column workgroup: all 512 columns of its 16 rows are there — the head once, for every consumer
+                if (wave < nrow) {
+                    const int r = wave;
+                    RowReg<H2> xh, y;
+                    float mean, rstd, o[4];
+                    if (J.m.out == 4) head_row4<RELU, true>(J.ws.z2 + (size_t)(r0 + r) * H2, J.net, J.m, slope, xh, y, mean, rstd, o);
+                    else head_row<4, RELU, true>(J.ws.z2 + (size_t)(r0 + r) * H2, J.net, J.m, slope, xh, y, mean, rstd, o);
+                    if (lane < 4) {
+                        float a = fast_tanh(lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3]);  // Actor.forward's tanh, HIRL.py:140
+                        if (X.noise) {          // target smoothing, HIRL.py:264-267
+                            const float e = fminf(fmaxf(X.noise[lane], -X.noise_clamp), X.noise_clamp);
+                            a = fminf(fmaxf(a + e, -1.0f), 1.0f);
+                        }
+                        st_agent(&J.ws.outv[(size_t)(r0 + r) * OW + lane], a);
+                    }
+                    if (lane == 0) {
+                        J.ws.st2[(size_t)(r0 + r) * 2] = mean;
+                        J.ws.st2[(size_t)(r0 + r) * 2 + 1] = rstd;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(&X.flags[rt], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     // accumulators of LATER launches are cleared here, at the end: their kernel-argument words are off every workgroup's critical path
