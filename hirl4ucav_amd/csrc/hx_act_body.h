@@ -156,6 +156,16 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
             for (int sl = 0; sl < 8; ++sl) bq[t][sl] = *reinterpret_cast<const uint4*>(blk + sl * 512);
         }
     }
+    // X3: the first slab of this wave's B fragments (three images x two column tiles) is requested HERE, under layer 1 and LayerNorm 1, instead of in front of
+    // the product loop (where its L2 round trip was the loop's first wait)
+    uint4 bb0[X3 ? 3 : 1][2];
+    if constexpr (X3) {
+        const uint16_t* img = A.w2b + (size_t)(cw * 8) * 512 + lane * 8;
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) bb0[sx][ct] = *reinterpret_cast<const uint4*>(img + (size_t)sx * kImgElems + (size_t)ct * (16 * 8 * 512));
+    }
     if (tid < ROWS * 13) xs[(tid / 13) * XP + tid % 13] = xv;
     __syncthreads();
     float z1[NRT][4];
@@ -244,7 +254,7 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
 #pragma unroll
             for (int sx = 0; sx < 3; ++sx)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) bb[0][sx][ct] = *reinterpret_cast<const uint4*>(img + (size_t)sx * kImgElems + (size_t)ct * (16 * 8 * 512));
+                for (int ct = 0; ct < 2; ++ct) bb[0][sx][ct] = bb0[sx][ct];
 #pragma unroll
             for (int sl = 0; sl < 8; ++sl) {
                 if (sl + 1 < 8) {
