@@ -82,6 +82,8 @@ def parse(argv=None):
                    help="(default where it applies: fp32 HIRL with the policy's actions in one launch, <= 8,192 envs per GPU, batch <= 256) the FRONT launch "
                         "(HirlEngine.step_learn, include/hirl4ucav.h hx_hirl_front): env step + the first two launches of learn() as ONE launch; the minibatch is "
                         "then drawn from the ring as it stood before this step's insert, without the slots it may overwrite")
+    p.add_argument("--front-acting", dest="front_acting", default="x9", choices=["x9", "mfma"],
+                   help="--dtype f32 in the front loop: x9 (default, engine.front_x9) = the acting workgroups' 256 -> 512 product as the exact 9-term bf16 split; mfma = fp32 MFMA")
     p.add_argument("--no-front", dest="front", action="store_false",
                    help="the reference's order on every step: act -> env step -> insert -> draw -> learn, each launch after the other (the minibatch sees this step's transitions)")
     p.add_argument("--serial", action="store_true", help="(default) one stream")
@@ -247,6 +249,8 @@ class Loop:
         # act + env step + replay insert as ONE launch at every size (hx_actor_act_step / hx_sac_act_step: up to 8,192 envs one 16- / 32-row
         # workgroup per row tile with the env step on its first wave, beyond that the persistent kernel of csrc/hx_actp.hip)
         self.fused = not (self.uniform or self.separate)
+        if not self.sac and getattr(args, "front_acting", "x9") == "mfma":
+            self.eng.front_x9 = False
         front_ok = not (self.sac or self.uniform or self.separate or args.overlap or args.sample_launch or args.dtype not in ("f32", "f32x9") or n > 8192 or args.batch > 256)
         if getattr(args, "front", None) and not front_ok:
             raise SystemExit("--front: fp32 HIRL, policy actions in one launch, one stream, at most 8,192 envs per GPU and batch 256")
