@@ -326,7 +326,7 @@ class HirlEngine:
         # current by the actor's Adam steps from then on.
         self.x9_rows = 16384
         # ... and in the FRONT launch (step_learn) at every size: there the acting workgroups take 32 rows each on half of the CUs and are the launch's
-        # longest — 22.2 against 26.8 us for 4,096 envs (tools/ubench/x9_32row.sh), 53.9 against 56.6 us per step.  False: fp32 MFMA there too.
+        # longest — 21.7 against 26.8 us for 4,096 envs (tools/ubench/x9_32row.sh), 52.5 against 56.9 us per step.  False: fp32 MFMA there too.
         self.front_x9 = True
         self.update_dtype, self.images = "f32", None
         # fp32 image of the actor's W2 in the acting kernel's operand order (hx_pack_w2_f32i): kept current by the actor's Adam steps
