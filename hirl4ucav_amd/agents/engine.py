@@ -750,6 +750,9 @@ class HirlEngine:
         elif act_sigma > 0:
             mode = 3
         self.act_calls += 1
+        if self._front_epoch >= 400_000_000:  # the tiles' counters advance by 9 per launch: start over long before 32 bits run out (stream-ordered reset)
+            flags.zero_()
+            self._front_epoch = 0
         self._front_epoch += 1
         front = HxFront(flags.data_ptr(), status.data_ptr(), self._front_epoch)
         batch, nets, hyper, st = tiles_of(cur), ctypes.byref(self.nets), ctypes.byref(self.hyper), _lib.stream_ptr()

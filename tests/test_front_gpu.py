@@ -199,10 +199,12 @@ def test_front_loop_free_running(eng_mod):
     for k in range(40):
         a.step_learn(env_a, exp, bc, n_main=96, act_sigma=0.1, act_seed=3, sample_seed=11, bc_weight_now=100 if k % 4 == 0 else None, bc_warm_up_weight=0.05)
         assert a._front_drawn[:2] == (env_a, env_a.steps_issued)
+        if k == 10:  # the hand-off counters start over long before 32 bits run out: a reset between two launches changes nothing
+            a._front_epoch = 400_000_000
         if k == 20:  # an env step from outside: the tiles in waiting no longer fit, the next call draws afresh (a launch of its own) — and goes on
             a.act_step(env_a, sigma=0.1, seed=3)
     a.front_check()
-    assert np.isfinite(a.losses_host()).all() and a.critic_step == 40 and a.update_count == 20
+    assert np.isfinite(a.losses_host()).all() and a.critic_step == 40 and a.update_count == 20 and a._front_epoch == 29
     assert int(rep_a.total.item()) > 8192
 
 
