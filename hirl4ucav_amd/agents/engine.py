@@ -710,10 +710,13 @@ class HirlEngine:
         step, without the env.n slots the step may overwrite (uniform over every transition that is in the buffer before and after the step).
         Each call also draws the NEXT call's minibatch (inside its learn() part, after this step's inserts): a next call with the same tables,
         n_main, seed and sigma finds its tiles ready, any other draws them with a launch of its own first.
-        fp32 networks, at most 8,192 envs per GPU, batch <= 256; one-call and sharded (staged) update paths.  -> (actions, obs, reward, done, success) as act_step."""
+        fp32 networks, or bf16 acting + bf16 update; at most 8,192 envs per GPU, batch <= 256; one-call and sharded (staged) update paths.
+        -> (actions, obs, reward, done, success) as act_step."""
         replay, n, B = env.replay, env.n, self.batch
-        if self.act_dtype not in ("f32", "f32x9") or self.nets.w2_bf16_all or replay is None:
-            raise _lib.HxError("step_learn: the front launch exists for the fp32 networks (acting format 'f32' or 'f32x9') with a replay ring attached to the env")
+        bf16 = self.update_dtype == "bf16"
+        if replay is None or (self.act_dtype != "bf16" if bf16 else self.act_dtype not in ("f32", "f32x9")):
+            raise _lib.HxError("step_learn: the front launch exists for the fp32 networks (acting format 'f32' or 'f32x9') and for the bf16 update path with "
+                               "the bf16 acting format, with a replay ring attached to the env")
         if self._pending is not None:
             raise _lib.HxError("step_learn draws its own minibatch: a sample(defer=True) is still pending")
         if self._front is None:
@@ -768,7 +771,7 @@ class HirlEngine:
             self.actor_step += 1
             self.update_count += 1
         do_polyak = actor_phase and self.update_count % self.target_update_freq == 0  # HIRL.py:327-330
-        _lib.call("hx_hirl_front", env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(), out.data_ptr(), mode | self._mode_bits | (32 if self._x9_for(n, front=True) else 0),
+        _lib.call("hx_hirl_front", env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(), out.data_ptr(), mode | self._mode_bits | (32 if (not bf16 and self._x9_for(n, front=True)) else 0),
                   _lib.ptr(act_noise), float(act_sigma), int(act_seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(), env.done.data_ptr(),
                   env.success.data_ptr(), ctypes.byref(env._opts), nets, ctypes.byref(batch), hyper, int(actor_phase), w_kind, ctypes.byref(front), st)
         env.steps_issued += 1

@@ -38,12 +38,14 @@ struct FrontCtl {
 // X3: the acting workgroups multiply in the exact 9-term bf16 split (the engine's "f32x9" acting format, H.w2b = the hi | mid | lo images) instead of
 // fp32 MFMA from the fp32 image: 22.2 against 26.8 us for the 128 workgroups of 4,096 envs (tools/ubench/x9_32row.sh) — a shorter shadow, but the
 // acting workgroups are the launch's longest
-template <bool RELU, bool X3>
+// BF16: the bf16 update path (HxNets.w2_bf16_all) with the bf16 acting kernel — both on v_mfma_f32_16x16x32_bf16, as their launches of their own
+template <bool RELU, bool X3, bool BF16 = false>
 __global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArgsC FA, FwdArgsC FB, FrontCtl C) {
+    static_assert(!(X3 && BF16), "one acting format");
     constexpr int BNT = kNT;
-    typedef ActLds<2, true, false, !X3, X3> LdsAct;
-    typedef FwdLds<kNT, false, false> LdsA;
-    typedef FwdLds<BNT, false, false> LdsB;
+    typedef ActLds<2, true, BF16, !X3 && !BF16, X3> LdsAct;
+    typedef FwdLds<kNT, false, BF16> LdsA;
+    typedef FwdLds<BNT, false, BF16> LdsB;
     __shared__ union {
         LdsAct act;
         LdsA a;
@@ -51,24 +53,25 @@ __global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArg
     } u;
     int b = (int)blockIdx.x;
     if (b < C.n_act) {
-        act_fused_body<2, false, true, false, RELU, !X3, X3>(H, b, u.act);
+        act_fused_body<2, false, true, BF16, RELU, !X3 && !BF16, X3>(H, b, u.act);
         return;
     }
     b -= C.n_act;
     const int k = b / C.per, bx = b - k * C.per, job = C.order[k];
-    if (job < 16) fwd_l2_body<kNT, RELU, false, false, 1>(FA, NoSample{}, bx, job, u.a, C.sync);
-    else fwd_l2_body<BNT, RELU, false, false, 2>(FB, NoSample{}, bx, job - 16, u.b, C.sync);
+    if (job < 16) fwd_l2_body<kNT, RELU, false, BF16, 1>(FA, NoSample{}, bx, job, u.a, C.sync);
+    else fwd_l2_body<BNT, RELU, false, BF16, 2>(FB, NoSample{}, bx, job - 16, u.b, C.sync);
 }
 
 }  // namespace
 
 namespace hxu {
 
-int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, const uint16_t* w2b, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
                  const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward, uint8_t* done, int8_t* success,
                  const HxStepOpts& o, const FwdArgs& FA, const FwdArgs& FB, const HxFront& front, hipStream_t st) {
-    HX_REQUIRE(actor && (w2f || w2x) && ((reinterpret_cast<uintptr_t>(w2f) | reinterpret_cast<uintptr_t>(w2x)) & 15u) == 0,
-               "hx_hirl_front: the actor and a 16-byte aligned image of its W2 (HxNets.actor_w2_x9 or actor_w2_f32i)");
+    HX_REQUIRE(actor && (w2f || w2x || w2b) && ((reinterpret_cast<uintptr_t>(w2f) | reinterpret_cast<uintptr_t>(w2x) | reinterpret_cast<uintptr_t>(w2b)) & 15u) == 0,
+               "hx_hirl_front: the actor and a 16-byte aligned image of its W2 (HxNets.actor_w2_x9, actor_w2_f32i or actor_w2_bf16)");
+    HX_REQUIRE(!w2b == !FA.images && FA.images == FB.images, "hx_hirl_front: the bf16 acting image goes with the bf16 update path (HxNets.w2_bf16_all), and only with it");
     const Mlp mA{13, 4, (noise_mode & 16) ? 1 : 0};  // + 16: layerNorm = False (as hx_actor_act_step)
     noise_mode &= 15;
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_hirl_front: bad noise mode");
@@ -77,12 +80,12 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, floa
     HX_REQUIRE(!FA.sample && FA.njobs >= 3 && FB.njobs >= 2, "hx_hirl_front: launch A reads finished minibatch tiles");
     ActFusedArgs H{actor, mA, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
                    noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
-                   o.cap > 0 ? 1.0 / (double)o.cap : 0.0, w2x, w2x ? nullptr : w2f, w2x ? 1 : 0};
+                   o.cap > 0 ? 1.0 / (double)o.cap : 0.0, w2b ? w2b : w2x, (w2x || w2b) ? nullptr : w2f, w2x ? 1 : 0};
     FwdArgsC CA{}, CB{};
     for (int j = 0; j < FA.njobs; ++j) { CA.job[j] = pack_fwd(FA.job[j]); CA.job[j].slope = FA.slope; }
     for (int j = 0; j < FB.njobs; ++j) { CB.job[j] = pack_fwd(FB.job[j]); CB.job[j].slope = FB.slope; }
-    CA.slope = FA.slope; CA.zero_nf = FA.zero_nf; CA.zero_f = FA.zero_f; CA.zero_i = FA.zero_i; CA.images = nullptr; CA.rowmap = 1;
-    CB.slope = FB.slope; CB.zero_nf = FB.zero_nf; CB.zero_f = FB.zero_f; CB.zero_i = FB.zero_i; CB.images = nullptr; CB.rowmap = 1;
+    CA.slope = FA.slope; CA.zero_nf = FA.zero_nf; CA.zero_f = FA.zero_f; CA.zero_i = FA.zero_i; CA.images = FA.images; CA.rowmap = 1;
+    CB.slope = FB.slope; CB.zero_nf = FB.zero_nf; CB.zero_f = FB.zero_f; CB.zero_i = FB.zero_i; CB.images = FB.images; CB.rowmap = 1;
     const int rows = FA.job[0].rows, tiles = (rows + RT - 1) / RT;
     HX_REQUIRE(tiles * FB.njobs < 128 && FA.njobs + FB.njobs <= 8, "hx_hirl_front: minibatches of at most 256 rows, at most 8 forward jobs");
     FrontCtl C{};
@@ -115,11 +118,12 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, floa
     HX_REQUIRE(tiles <= 16, "hx_hirl_front: at most 16 row tiles (HxFront.flags)");
     const dim3 grid((unsigned)(C.n_act + C.per * (FA.njobs + FB.njobs)));
     const bool relu = slope == 0.0f;
-#define HX_FRONT(RELU_, X3_) do { \
-        if (o.ev_start && o.ev_stop) hipExtLaunchKernelGGL((act_front_kernel<RELU_, X3_>), grid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C); \
-        else hipLaunchKernelGGL((act_front_kernel<RELU_, X3_>), grid, dim3(kWide), 0, st, H, CA, CB, C); } while (0)
-    if (relu) { if (w2x) HX_FRONT(true, true); else HX_FRONT(true, false); }
-    else { if (w2x) HX_FRONT(false, true); else HX_FRONT(false, false); }
+#define HX_FRONT(RELU_, X3_, BF16_) do { \
+        if (o.ev_start && o.ev_stop) hipExtLaunchKernelGGL((act_front_kernel<RELU_, X3_, BF16_>), grid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C); \
+        else hipLaunchKernelGGL((act_front_kernel<RELU_, X3_, BF16_>), grid, dim3(kWide), 0, st, H, CA, CB, C); } while (0)
+    if (w2b) { if (relu) HX_FRONT(true, false, true); else HX_FRONT(false, false, true); }
+    else if (relu) { if (w2x) HX_FRONT(true, true, false); else HX_FRONT(true, false, false); }
+    else { if (w2x) HX_FRONT(false, true, false); else HX_FRONT(false, false, false); }
 #undef HX_FRONT
     HX_CHECK_LAUNCH("hx_hirl_front");
     return 0;

@@ -357,22 +357,24 @@ int hx_hirl_front(float* state, int64_t n, int64_t stride, float* obs_io, float*
     HX_REQUIRE(N && Bt && Hy && front && opts && Bt->batch > 0 && Bt->batch % 16 == 0 && Bt->batch <= kFusedBatchMax && Bt->rows && Bt->noise,
                "hx_hirl_front: the minibatch tiles (a positive multiple of 16 rows, at most 256) and noise[4] must be there");
     HX_REQUIRE(front->flags && front->status && front->epoch >= 1, "hx_hirl_front: flags, status and a 1-based epoch are required");
-    HX_REQUIRE(!N->w2_bf16_all && !N->actor_w2_bf16 && (N->actor_w2_f32i || N->actor_w2_x9),
-               "hx_hirl_front: fp32 networks with HxNets.actor_w2_f32i or actor_w2_x9 (the bf16 paths run their launches one by one)");
+    const bool bf16 = N->w2_bf16_all != nullptr;  // the bf16 update path: then the acting image is the bf16 one too (bf16 acting beside an fp32 update: separate launches)
+    HX_REQUIRE(bf16 ? N->actor_w2_bf16 != nullptr : (!N->actor_w2_bf16 && (N->actor_w2_f32i || N->actor_w2_x9)),
+               "hx_hirl_front: fp32 networks with HxNets.actor_w2_f32i / actor_w2_x9, or the bf16 update path (w2_bf16_all) with actor_w2_bf16");
     const int actor_fwd = actor_phase ? (w_kind == 1 ? 2 : 1) : 0;
     FwdArgs FA, FB;
     make_launch_a(N, Bt, Hy, actor_fwd, FA);
     make_launch_b(N, Bt, Hy, actor_fwd, FB);
-    const bool x9 = (noise_mode & 32) != 0;  // + 32: the exact-split acting format (HxNets.actor_w2_x9), else fp32 MFMA from HxNets.actor_w2_f32i
-    HX_REQUIRE(x9 ? N->actor_w2_x9 != nullptr : N->actor_w2_f32i != nullptr, "hx_hirl_front: the image of the chosen acting format is missing from HxNets");
+    const bool x9 = !bf16 && (noise_mode & 32) != 0;  // + 32: the exact-split acting format (HxNets.actor_w2_x9), else fp32 MFMA from HxNets.actor_w2_f32i
+    HX_REQUIRE(bf16 || (x9 ? N->actor_w2_x9 != nullptr : N->actor_w2_f32i != nullptr), "hx_hirl_front: the image of the chosen acting format is missing from HxNets");
     noise_mode &= ~32;
-    return launch_front(N->actor, x9 ? nullptr : N->actor_w2_f32i, x9 ? N->actor_w2_x9 : nullptr, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed,
+    return launch_front(N->actor, (x9 || bf16) ? nullptr : N->actor_w2_f32i, x9 ? N->actor_w2_x9 : nullptr, bf16 ? N->actor_w2_bf16 : nullptr, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed,
                         row0, call, Hy->slope, reward, done, success, *opts, FA, FB, *front, (hipStream_t)stream);
 }
 // the predraw of hx_hirl_learn_back / hx_hirl_critic_grads_back as a device-side description (nothing is launched here)
 static int make_predraw(const HxNets* N, const HxBatch* Bt, const HxSample* next, const HxBatch* next_tiles, void* stream, SampleDev* SD) {
-    HX_REQUIRE(next_tiles && next_tiles->batch == Bt->batch && next_tiles->rows && next_tiles->noise && next_tiles->rows != Bt->rows && next_tiles->noise != Bt->noise &&
-               !N->w2_bf16_all, "hx_hirl_learn_back: the next minibatch needs tiles of its own (this call still reads the current ones); fp32 update path");
+    HX_REQUIRE(next_tiles && next_tiles->batch == Bt->batch && next_tiles->rows && next_tiles->noise && next_tiles->rows != Bt->rows && next_tiles->noise != Bt->noise,
+               "hx_hirl_learn_back: the next minibatch needs tiles of its own (this call still reads the current ones)");
+    (void)N;
     bool fused = false;
     if (int rc = prepare_draw(next, Bt->batch, const_cast<float*>(next_tiles->rows), const_cast<float*>(next_tiles->bc_rows), const_cast<float*>(next_tiles->noise),
                               stream, SD, &fused, /*launch_now=*/false)) return rc;

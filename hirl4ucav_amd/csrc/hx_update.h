@@ -739,7 +739,7 @@ void launch_fwd(const FwdArgs& F, hipStream_t st);                          // h
 void set_fwd_nt(int nt, int skip, int count);                                                  // hx_fwdbwd.hip (hx_debug_set_fwd_nt)
 void launch_bwd(int grp, const BwdArgs& G, hipStream_t st);                 // hx_fwdbwd.hip: grp = bwd_l2_kernel's GRP (0..3)
 // hx_front.hip: the act + env + insert workgroups of hx_actor_act_step_f32i (32 rows each) and the workgroups of launches A and B as ONE launch
-int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
+int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, const uint16_t* w2b, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
                  const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward, uint8_t* done, int8_t* success,
                  const HxStepOpts& o, const FwdArgs& FA, const FwdArgs& FB, const HxFront& front, hipStream_t st);
 void launch_wg(const WgArgs& W, bool adam, hipStream_t st);                 // hx_wgrad.hip: adam = the optimizer step rides in the launch

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kWide) void wgrad_kernel(WgArgsC AC) {
     float* rinfo = lds + kWgRowChunk * XP;    // [chunk][<=12] per-row scalars
     float* red = rinfo + kWgRowChunk * 12;    // [16][64][kRedP]  cross-row-group reduction
 
-    if constexpr (!BF16) {
+    {
         static_assert(sizeof(lds) >= (4 * kFusedSlots + 2 * kFusedBatchMax) * 4, "predraw_wg's tables fit");
         if (AC.has_pre && blockIdx.x >= kWgPerJob) {  // (eight columns beyond the jobs' own: the XCD of every other workgroup stays what it was)
             if (blockIdx.x == kWgPerJob && blockIdx.y == 0) predraw_wg(AC.pre, AC.pre_batch, lds);
@@ -687,7 +687,7 @@ namespace hxu {
 void launch_wg(const WgArgs& W, bool adam, hipStream_t st) {
     WgArgsC C{};
     for (int j = 0; j < W.njobs; ++j) C.job[j] = pack_wg(W.job[j], W);
-    const bool pre = W.predraw && !W.bf16;
+    const bool pre = W.predraw != nullptr;
     C.has_pre = pre ? 1 : 0;
     if (pre) { C.pre = *W.predraw; C.pre_batch = W.predraw_batch; }
     const dim3 grid(kWgPerJob + (pre ? 8 : 0), W.njobs);

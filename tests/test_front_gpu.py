@@ -51,6 +51,8 @@ def make_pair(eng_mod, n, cap, use_bc, slope, seed, act="f32", staged=False):
         e.x9_rows, e.front_x9 = None, False  # "f32" = fp32 MFMA in the front launch too, so that act_step (16-row workgroups, fp32 MFMA below x9_rows) is its reference
         e.staged = staged  # the sharded rank's launch sequence (one rank: the exchanges are no-ops)
         e.load_params(params["actor"], params["critic"], params["bc_actor"] if use_bc else None)
+        if act == "bf16":  # the bf16 update path with the bf16 acting format
+            e.set_update_dtype("bf16")
         if act != "f32":
             e.set_act_dtype(act)
         rep = DeviceReplay(cap)
@@ -80,7 +82,8 @@ def sorted_rows(rep):
 
 @pytest.mark.parametrize("use_bc,slope,n,cap,act,staged", [(True, 0.0, 1024, 2600, "f32", False), (False, 0.01, 576, 1400, "f32", False), (True, 0.0, 4096, 10000, "f32", False),
                                                            (True, 0.0, 4096, 10000, "f32x9", False), (False, 0.01, 1000, 2400, "f32x9", False),
-                                                           (True, 0.0, 1024, 2600, "f32", True), (False, 0.0, 2048, 5000, "f32x9", True)])
+                                                           (True, 0.0, 1024, 2600, "f32", True), (False, 0.0, 2048, 5000, "f32x9", True),
+                                                           (True, 0.0, 4096, 10000, "bf16", False), (False, 0.01, 1000, 2400, "bf16", True)])
 def test_front_launch_equals_act_step_then_guarded_learn(eng_mod, use_bc, slope, n, cap, act, staged):
     from hirl4ucav_amd import _lib
     L = _lib.load()

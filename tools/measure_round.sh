@@ -20,6 +20,7 @@ while read -r cfg; do
 done <<'CFGS'
 --no-front
 --dtype bf16
+--no-front --dtype bf16
 --dtype bf16_policy
 --dtype f32x9
 --no-front --dtype f32x9

@@ -12,7 +12,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 fn = T.test_front_launch_equals_act_step_then_guarded_learn.__wrapped__ if hasattr(T.test_front_launch_equals_act_step_then_guarded_learn, "__wrapped__") else T.test_front_launch_equals_act_step_then_guarded_learn
 k = 0
 for r in range(rounds):
-    for n, act, staged, use_bc in itertools.product((96, 500, 1000, 2048, 4096, 8192), ("f32", "f32x9"), (False, True), (True, False)):
+    for n, act, staged, use_bc in itertools.product((96, 500, 1000, 2048, 4096, 8192), ("f32", "f32x9", "bf16"), (False, True), (True, False)):
         cap = max(2 * n + 37 + 100 * r, 512)
         try:
             fn(engine, use_bc, 0.0 if use_bc else 0.01, n, cap, act, staged)
