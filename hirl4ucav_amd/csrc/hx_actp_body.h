@@ -1,0 +1,260 @@
+// hx_actp_body.h — the persistent bf16 acting workgroup (act_persist_bf16_kernel of hx_actp.hip) as a device function over an explicit LDS block and an
+// explicit workgroup index / count, + the helpers both persistent kernels share; hx_front.hip runs the same workgroups beside learn()'s first launches.
+#pragma once
+#include "hx_act.h"
+#include "hx_env_block.h"
+
+namespace hxact {
+using namespace hxnn;
+using namespace hxu;
+
+// -DHX_PX=mask builds a timing experiment (tools/ubench/actp_variants.sh; wrong results): 1 no head, 2 no LayerNorm 1, 4 no product MFMAs,
+// 8 no layer 1, 16 no z2 stores, 32 no noise draw
+#ifndef HX_PX
+#define HX_PX 0
+#endif
+constexpr int kEnvPass = 512;  // envs per pass of the tail: pair layout = 1,024 lanes = the workgroup
+
+// Layer 1 of NRT row tiles on the fp32 matrix cores: the products and the k order of act_fused_kernel's layer 1, with the two MFMA operands
+// SWAPPED — A = W1 (wave w: hidden units 16 w .. + 15), B = the observation rows — so that lane (lr, lg) ends up with FOUR CONSECUTIVE units
+// 16 w + 4 lg .. + 3 of row lr: one 16-byte LDS store per row tile instead of four conflicting dword stores.  The W1 fragments (w1f) and
+// the biases of the lane's four units (b1f) are loop invariants held in registers.
+template <int NRT>
+__device__ __forceinline__ void layer1_tiles(const float* xs, const float (&w1f)[4], v4f b1f, int wave, int lr, int lg, float* h1s) {
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {
+        v4f acc = b1f;
+        const float* xrow = xs + (t * RT + lr) * XP + lg;  // (columns 13.. of xs are zero, and so are the W1 fragments there)
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) acc = mfma16(w1f[mm], xrow[4 * mm], acc);  // K = 16 covers the 13 inputs
+        *reinterpret_cast<v4f*>(h1s + (t * RT + lr) * LDA1 + wave * 16 + 4 * lg) = acc;
+    }
+}
+
+// the four standard-normal draws of a row, two per lane: lane (row, pair p) -> components 2 p (cos) and 2 p + 1 (sin) of philox_normal's
+// Box-Muller pairs — one Philox evaluation, logarithm and root per PAIR instead of per component, the same bits
+__device__ __forceinline__ void philox_normal_pair(uint32_t row, uint32_t call, uint32_t tag, uint64_t seed, int p, float& n_cos, float& n_sin) {
+    uint32_t u[4];
+    philox4x32_10(row, call, tag, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), u);
+    const float ua = u01(p ? u[2] : u[0]), ub = u01(p ? u[3] : u[1]);
+    const float rad = sqrtf(-2.0f * logf(ua)), ang = 6.28318530717958647692f * ub;
+    n_cos = rad * cosf(ang);
+    n_sin = rad * sinf(ang);
+}
+
+// The env step of rows [row_begin, row_end) — whose actions this workgroup has written — kEnvPass at a time (HarfangEnv.step,
+// train_all.py:345).  It reads the launch description from the kernel-argument SEGMENT (uniform scalar loads, here, after the tile loop)
+// instead of from the kernel's parameter: as a parameter the env step's ~30 argument words stayed live in SGPRs across the tile loop, next to
+// the loop's own ~60, spilled into VGPR lanes, and pushed the loop's vector registers (64 of them resident weights) into scratch.
+typedef const __attribute__((address_space(4))) ActFusedArgs* KernArgs;
+__device__ __forceinline__ void env_tail(KernArgs Ap, int row_begin, int row_end, float* elds, unsigned* s_slot0, int* s_wcount, int bid, int nwg) {
+    using namespace hxenv;
+    StepArgs S;
+    S.state = Ap->state; S.n = (int64_t)Ap->rows; S.stride = Ap->stride; S.actions = Ap->actions; S.obs_io = Ap->obs; S.reward = Ap->reward;
+    S.done = Ap->done; S.success = Ap->success; S.inv_cap = Ap->inv_cap;
+    S.o.max_step = Ap->o.max_step; S.o.auto_reset = Ap->o.auto_reset; S.o.randomize = Ap->o.randomize; S.o.env_id0 = Ap->o.env_id0; S.o.seed = Ap->o.seed;
+    S.o.episode_ctr = Ap->o.episode_ctr; S.o.ring = Ap->o.ring; S.o.ring_success = Ap->o.ring_success; S.o.cap = Ap->o.cap; S.o.total = Ap->o.total;
+    S.o.stats = Ap->o.stats; S.o.ev_start = nullptr; S.o.ev_stop = nullptr; S.o.layout = 0;
+    unsigned way = (unsigned)bid;
+    for (int i0 = row_begin; i0 < row_end; i0 += kEnvPass, way += (unsigned)nwg) {
+        // (behind opaque copies of the base pointers nothing of a pass is invariant across passes: hoisted out of this loop, the 37 state
+        //  words' 64-bit addresses alone are 74 VGPRs and the pass spills ~170 bytes per lane)
+        asm volatile("" : "+s"(S.state), "+s"(S.obs_io), "+s"(S.actions), "+s"(S.stride));
+        env_block_step<true, true, kEnvPass>(S, i0, row_end, elds, *s_slot0, s_wcount, way);  // (launches without a replay ring take two launches)
+        __syncthreads();  // the pass's LDS tiles and slot words are free again
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16, weight-stationary (BASELINE.json configs[4]: bf16 actor, fp32 dynamics)
+// ---------------------------------------------------------------------------------------------------------------
+// the workgroup's LDS as one object (hx_front.hip overlays it with the forward workgroups' block)
+template <bool ENV>
+struct ActpLds {
+    static constexpr int NRT = 2, TR = NRT * RT;
+    typedef HeadImage<4> Img;
+    static constexpr int kLoop = TR * LDA1 + TR * LDA2 + TR * LDB1 / 2;  // h1s (fp32 pre-activations), z2s, h1b (bf16)
+    static constexpr int kTail = ENV ? hxenv::kEnvBlockLds<true, kEnvPass> : 0;
+    static constexpr int kUnion = kLoop > kTail ? kLoop : kTail;
+    __attribute__((aligned(16))) float lds[Img::kStride + TR * XP + 3 * H1 + H2 + kWide * 4 + 2 * TR * 4 + kUnion];
+    unsigned s_slot0;
+    int s_wcount[kWide / 64];
+};
+// bid / nwg: this workgroup's index among the acting workgroups and their number (the kernel's grid, or the acting role's share of a front launch)
+template <bool ENV, bool RELU>
+__device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, const int tiles_per_wg, const int bid, const int nwg, ActpLds<ENV>& SL) {
+    constexpr int NRT = 2, TR = NRT * RT;
+    typedef HeadImage<4> Img;
+    float* const lds = SL.lds;
+    unsigned& s_slot0 = SL.s_slot0;
+    int* const s_wcount = SL.s_wcount;
+    float* hps = lds;
+    float* xs = hps + Img::kStride;
+    float* g1s = xs + TR * XP;          // LayerNorm 1 weight | bias, read four columns at a time
+    float* b1s = g1s + 2 * H1;          // full1.bias
+    float* b2s = b1s + H1;              // full2.bias
+    float* w1t = b2s + H2;              // [1024][4]: every lane's four layer-1 A fragments of W1 (zero beyond the 13 inputs): one 16-byte read per tile
+    float* s_noise = w1t + kWide * 4;   // [2][TR][4]: the draws of tile t live in half t & 1
+    float* h1s = s_noise + 2 * TR * 4;
+    float* z2s = h1s + TR * LDA1;
+    __bf16* h1b = reinterpret_cast<__bf16*>(z2s + TR * LDA2);
+    const int tid0 = threadIdx.x;
+    const int row_begin = bid * tiles_per_wg * TR;
+    if (row_begin >= A.rows) return;
+    const int row_end = min(A.rows, row_begin + tiles_per_wg * TR);
+    const int ntile = (row_end - row_begin + TR - 1) / TR;
+    const float* net = A.net;
+    const Mlp m = A.m;
+    const float slope = A.slope;
+    STAMP_DECL;
+    STAMP();
+    // ---- once per workgroup: the small operands first, then this wave's share of the W2 image --------------------------------------
+    auto obs_of = [&](int tile, int tid) -> float {  // element `tid` of the tile's [TR][13] observation block (0 beyond the rows)
+        const int r0 = row_begin + tile * TR;
+        return (tile < ntile && tid < TR * 13 && r0 + tid / 13 < row_end) ? A.obs[(size_t)r0 * 13 + tid] : 0.0f;
+    };
+    float xv;
+    uint4 bq[2][8];  // B fragments of this wave's two column tiles, all of K: resident for every tile
+    {
+        const int tid = tid0, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+        xv = obs_of(0, tid);
+        float w1f[4];  // layer 1: this lane's A fragments of W1 (unit 16 wave + lr, inputs 4 mm + lg)
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) w1f[mm] = net[m.W1() + (wave * 16 + lr) * 13 + min(4 * mm + lg, 12)];
+        const float b1v = tid < H1 ? net[m.b1() + tid] : 0.0f;
+        const float gb = tid < 2 * H1 ? net[m.g1() + tid] : 0.0f;  // g1 | be1 are adjacent in the parameter block
+        const float b2v = tid < H2 ? net[m.b2() + tid] : 0.0f;
+        Img himg;
+        himg.fetch(net, m, tid);
+        // which 32 columns this wave owns rotates with the workgroup: the workgroups of a launch do not all ask L2 for the same lines at once
+        const int cw = (wave + bid) & 15;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint16_t* blk = A.w2b + (size_t)((t * 16 + cw) * 8) * 512 + lane * 8;  // (lane = 16 g + r: w2_image_index's block order)
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) bq[t][sl] = *reinterpret_cast<const uint4*>(blk + sl * 512);
+        }
+        *reinterpret_cast<float4*>(w1t + tid * 4) = make_float4(w1f[0], w1f[1], w1f[2], 12 + lg < 13 ? w1f[3] : 0.0f);  // (only 4 mm + lg = 13..15 are beyond)
+        if (tid < H1) b1s[tid] = b1v;
+        if (tid < 2 * H1) g1s[tid] = gb;
+        if (tid < H2) b2s[tid] = b2v;
+        if (tid < TR * XP) xs[tid] = 0.0f;
+        himg.store(hps, net, m, tid);
+        __syncthreads();
+        if (tid < TR * 13) xs[(tid / 13) * XP + tid % 13] = xv;
+        xv = obs_of(1, tid);
+        __syncthreads();
+    }
+    const bool draw_noise = !A.noise && A.sigma > 0.0f;
+    STAMP();
+    // ---- the tile loop: iteration i runs tile i's layer 1 / LayerNorm 1 and tile i - 1's product and head, two barriers per tile ------
+    for (int i = 0; i <= ntile; ++i) {
+        // The lane's LDS addresses are loop invariants, and with 64 registers of weights resident the allocator spills them; behind this
+        // opaque copy of the thread id they are recomputed per tile (a few VALU instructions) instead of living across the loop.
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int lr = lane & 15, lg = lane >> 4;
+        const int r0p = row_begin + (i - 1) * TR;  // first row of tile i - 1
+        const int cw = (wave + bid) & 15;
+        // P1: z2(i - 1) = h1(i - 1) W2^T (bf16 matrix cores, weights from registers) | layer 1 of tile i (fp32 matrix cores).
+        // Both products run with the MFMA operands swapped (weights as A, rows as B): the same products in the same k order, but lane
+        // (lr, lg) then holds FOUR CONSECUTIVE columns of row lr — 16-byte LDS stores instead of four conflicting dword stores each.
+        if (i >= 1) {
+            v4f acc[NRT][2];
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) acc[t][0] = acc[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
+            // K = 256 in 8 slabs of 32: lane (r, g) holds h1[row r][32 sl + 8 g ..+7] and W2[col r][32 sl + 8 g ..+7].  (One register set for
+            // the h1 fragments: the other three waves of the SIMD cover a wave's LDS round trip, and a second set costs spills of the weights.)
+            const __bf16* ap = h1b + lr * LDB1 + 8 * lg;
+            // layer 1 of tile i rides BETWEEN the slabs: its eight dependent fp32 MFMAs (two chains of four) and their LDS operands would
+            // otherwise open the phase on every wave at once with the bf16 matrix work waiting behind them
+            const bool l1 = i < ntile && !(HX_PX & 8);
+            float xf[NRT][4];
+            v4f acc1[NRT];
+            const v4f w1f = *reinterpret_cast<const v4f*>(w1t + tid * 4), b1f = *reinterpret_cast<const v4f*>(b1s + wave * 16 + 4 * lg);
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) {
+                acc1[t] = b1f;
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) xf[t][mm] = xs[(t * RT + lr) * XP + lg + 4 * mm];  // (read whether or not l1: a few dwords)
+            }
+#pragma unroll
+            for (int sl = 0; sl < ((HX_PX & 4) ? 0 : 8); ++sl) {
+                uint4 aq[NRT];
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) aq[t] = *reinterpret_cast<const uint4*>(ap + t * RT * LDB1 + 32 * ((HX_PX & 128) ? 0 : sl));
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) {
+                    acc[t][0] = mfma16_bf16(bq[0][sl], aq[t], acc[t][0]);
+                    acc[t][1] = mfma16_bf16(bq[1][sl], aq[t], acc[t][1]);
+                }
+                acc1[sl & 1] = mfma16(w1f[sl >> 1], xf[sl & 1][sl >> 1], acc1[sl & 1]);  // tile sl & 1, inputs 4 (sl >> 1) ..: k ascending per tile
+                if (!(HX_PX & 256)) __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise gathers the eight fp32 MFMAs at the head of the phase)
+            }
+            if (l1) {
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) *reinterpret_cast<v4f*>(h1s + (t * RT + lr) * LDA1 + wave * 16 + 4 * lg) = acc1[t];
+            }
+            const v4f bb0 = *reinterpret_cast<const v4f*>(b2s + cw * 16 + 4 * lg), bb1 = *reinterpret_cast<const v4f*>(b2s + 256 + cw * 16 + 4 * lg);
+#pragma unroll
+            for (int t = 0; t < ((HX_PX & 16) ? 0 : NRT); ++t) {
+                *reinterpret_cast<v4f*>(z2s + (t * RT + lr) * LDA2 + cw * 16 + 4 * lg) = acc[t][0] + bb0;
+                *reinterpret_cast<v4f*>(z2s + (t * RT + lr) * LDA2 + 256 + cw * 16 + 4 * lg) = acc[t][1] + bb1;
+            }
+        } else if (!(HX_PX & 8)) {
+            const v4f w1v = *reinterpret_cast<const v4f*>(w1t + tid * 4);
+            const float w1f[4] = {w1v[0], w1v[1], w1v[2], w1v[3]};
+            layer1_tiles<NRT>(xs, w1f, *reinterpret_cast<const v4f*>(b1s + wave * 16 + 4 * lg), wave, lr, lg, h1s);
+        }
+        __syncthreads();  // A: z2 of tile i - 1 and the pre-activations of tile i are in LDS; xs and h1b are free
+        // P2 (16 lanes per row, hx_act.h): waves 0-7 the head of tile i - 1, waves 8-15 LayerNorm 1 + activation of tile i -> bf16 h1;
+        // a wave's four rows are eight apart (pitch = 8 mod 64 dwords: their 16-byte reads fall on disjoint banks)
+        const int gq = lane >> 4, gc = lane & 15;
+        if (wave < 8) {
+            const int lrow = wave + 8 * gq;
+            if (i >= 1 && r0p + lrow < row_end && !(HX_PX & 1)) {
+                float o[4];
+                head16<4, 4, RELU, !(HX_PX & 64)>(z2s + lrow * LDA2, hps, gc, slope, m.no_ln, o);
+                if (gc < 4) A.actions[(size_t)(r0p + lrow) * 4 + gc] = action_of<false>(A, o, gc, r0p + lrow, s_noise + ((i - 1) & 1) * TR * 4 + lrow * 4);
+            }
+        } else {
+            if (i < ntile && !(HX_PX & 2)) {
+                const int row = wave - 8 + 8 * gq;
+                float v[16];
+                load_row16<H1>(h1s + row * LDA1, gc, v);
+                float mean, rstd;
+                row_stats16<16>(v, H1, mean, rstd);
+                if (m.no_ln) { mean = 0.0f; rstd = 1.0f; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const v4f g = *reinterpret_cast<const v4f*>(g1s + 64 * k + 4 * gc);
+                    const v4f be = *reinterpret_cast<const v4f*>(g1s + H1 + 64 * k + 4 * gc);
+                    typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+                    v4bf hb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hb[e] = (__bf16)ln_act<RELU>(v[4 * k + e], mean, rstd, g[e], be[e], slope);  // round to nearest even
+                    *reinterpret_cast<v4bf*>(h1b + row * LDB1 + 64 * k + 4 * gc) = hb;
+                }
+                // the exploration noise of tile i (its head runs in the next iteration): one wave, a lane per (row, Box-Muller pair)
+                if (draw_noise && wave == kWide / 64 - 1 && !(HX_PX & 32)) {
+                    float nc, ns;
+                    philox_normal_pair(A.row0 + (uint32_t)(row_begin + i * TR + (lane >> 1)), A.call, 0x61637421u, A.seed, lane & 1, nc, ns);
+                    *reinterpret_cast<float2*>(s_noise + (i & 1) * TR * 4 + lane * 2) = make_float2(nc, ns);
+                }
+            }
+        }
+        if (i + 1 < ntile) {
+            if (tid < TR * 13) xs[(tid / 13) * XP + tid % 13] = xv;
+            xv = obs_of(i + 2, tid);
+        }
+        __syncthreads();  // B: h1 of tile i (bf16) and the next observation tile are in LDS; every read of z2 is done
+    }
+    STAMP();
+    if (ENV) env_tail((KernArgs)__builtin_amdgcn_kernarg_segment_ptr(), row_begin, row_end, h1s, &s_slot0, s_wcount, bid, nwg);  // (barrier B: every action of the block is written; the launch description is the kernel's FIRST argument)
+    STAMP();
+    STAMP_FLUSH(0, (bid == 0 || bid == 200) && tid0 == 0);
+    SPAN_LOG(HX_SPAN_ACT);
+}
+
+}  // namespace hxact

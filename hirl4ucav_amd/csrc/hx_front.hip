@@ -14,6 +14,7 @@
 #include <hip/hip_ext.h>
 
 #include "hx_act_body.h"
+#include "hx_actp_body.h"
 #include "hx_fwd_body.h"
 
 using namespace hxnn;
@@ -62,6 +63,28 @@ __global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArg
     else fwd_l2_body<BNT, RELU, false, BF16, 2>(FB, NoSample{}, bx, job - 16, u.b, C.sync);
 }
 
+// Beyond 8,192 envs (bf16): the acting role is the PERSISTENT weight-stationary kernel of hx_actp.hip on fewer workgroups than CUs — 16,384 envs on 171
+// workgroups of three 32-row tiles take 28.4 us against 25.5 on 256 workgroups of two (tools/ubench/actp_time.py with HX_ACT_PERSIST_WGS) — and the
+// update's workgroups run on the CUs that leaves free.  tiles: row tiles per acting workgroup.
+template <bool RELU>
+__global__ __launch_bounds__(kWide) void actp_front_kernel(ActFusedArgs H, FwdArgsC FA, FwdArgsC FB, FrontCtl C, int tiles) {
+    typedef ActpLds<true> LdsAct;
+    typedef FwdLds<kNT, false, true> LdsF;
+    __shared__ union {
+        LdsAct act;
+        LdsF f;
+    } u;
+    int b = (int)blockIdx.x;
+    if (b < C.n_act) {
+        act_persist_bf16_body<true, RELU>(H, tiles, b, C.n_act, u.act);
+        return;
+    }
+    b -= C.n_act;
+    const int k = b / C.per, bx = b - k * C.per, job = C.order[k];
+    if (job < 16) fwd_l2_body<kNT, RELU, false, true, 1>(FA, NoSample{}, bx, job, u.f, C.sync);
+    else fwd_l2_body<kNT, RELU, false, true, 2>(FB, NoSample{}, bx, job - 16, u.f, C.sync);
+}
+
 }  // namespace
 
 namespace hxu {
@@ -76,7 +99,9 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
     noise_mode &= 15;
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_hirl_front: bad noise mode");
     if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_hirl_front")) return rc;
-    HX_REQUIRE(n <= kFuseEnvMax, "hx_hirl_front: at most 8,192 envs (one round of 32-row acting workgroups)");
+    const bool persistent = n > kFuseEnvMax;
+    HX_REQUIRE(!persistent || (w2b && n <= 32768 && o.ring), "hx_hirl_front: at most 8,192 envs per launch (one round of 32-row acting workgroups); bf16 with a replay "
+                                                              "ring: 32,768 (persistent acting workgroups)");
     HX_REQUIRE(!FA.sample && FA.njobs >= 3 && FB.njobs >= 2, "hx_hirl_front: launch A reads finished minibatch tiles");
     ActFusedArgs H{actor, mA, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
                    noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
@@ -116,8 +141,22 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
         C.sync = FrontSync{front.flags, (front.epoch - 1u) * per + (per - 1u), front.epoch * per, front.status, FB.job[0].noise, FB.job[0].noise_clamp};
     }
     HX_REQUIRE(tiles <= 16, "hx_hirl_front: at most 16 row tiles (HxFront.flags)");
-    const dim3 grid((unsigned)(C.n_act + C.per * (FA.njobs + FB.njobs)));
     const bool relu = slope == 0.0f;
+    if (persistent) {  // two thirds of the CUs act (ceil(tiles / 176) row tiles per workgroup), the rest serve the update
+        const int ntiles = (int)((n + 2 * RT - 1) / (2 * RT)), tiles_per_wg = (ntiles + 175) / 176;
+        C.n_act = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
+        const dim3 pgrid((unsigned)(C.n_act + C.per * (FA.njobs + FB.njobs)));
+        if (o.ev_start && o.ev_stop) {
+            if (relu) hipExtLaunchKernelGGL((actp_front_kernel<true>), pgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, tiles_per_wg);
+            else hipExtLaunchKernelGGL((actp_front_kernel<false>), pgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, tiles_per_wg);
+        } else {
+            if (relu) hipLaunchKernelGGL((actp_front_kernel<true>), pgrid, dim3(kWide), 0, st, H, CA, CB, C, tiles_per_wg);
+            else hipLaunchKernelGGL((actp_front_kernel<false>), pgrid, dim3(kWide), 0, st, H, CA, CB, C, tiles_per_wg);
+        }
+        HX_CHECK_LAUNCH("hx_hirl_front");
+        return 0;
+    }
+    const dim3 grid((unsigned)(C.n_act + C.per * (FA.njobs + FB.njobs)));
 #define HX_FRONT(RELU_, X3_, BF16_) do { \
         if (o.ev_start && o.ev_stop) hipExtLaunchKernelGGL((act_front_kernel<RELU_, X3_, BF16_>), grid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C); \
         else hipLaunchKernelGGL((act_front_kernel<RELU_, X3_, BF16_>), grid, dim3(kWide), 0, st, H, CA, CB, C); } while (0)
