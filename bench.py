@@ -971,7 +971,7 @@ def run_rank(args):
         front_name = None
         if loop.front:  # + the forward passes of launches A (3.5 nets on average) and B (3 on average) over the minibatch
             front_name = ("act_front_kernel<RELU, X3, BF16> (hx_front.hip): the acting workgroups (32 rows each: policy inference + env step + fused replay insert) on half "
-                          "of the CUs, launches A and B of learn() (target actor, critics; target critics) on the other half") if args.envs <= 8192 else \
+                          "of the CUs, launches A and B of learn() (target actor, critics; target critics) on the other half") if args.envs <= (4096 if args.dtype == "bf16" else 8192) else \
                          ("actp_front_kernel<RELU> (hx_front.hip): persistent weight-stationary acting workgroups (policy inference + env step + fused replay insert) on two "
                           "thirds of the CUs, launches A and B of learn() on the rest")
         plain_name = (("act_persist_*_kernel<..., ENV = true> (hx_actp.hip): persistent workgroups (one per CU) looping over their row tiles, env step + "

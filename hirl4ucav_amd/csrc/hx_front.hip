@@ -99,7 +99,10 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
     noise_mode &= 15;
     HX_REQUIRE(noise_mode >= 0 && noise_mode <= 3 && (noise || (noise_mode != 1 && noise_mode != 2)), "hx_hirl_front: bad noise mode");
     if (int rc = check_step_args(state, n, stride, obs_io, actions, reward, done, success, o, "hx_hirl_front")) return rc;
-    const bool persistent = n > kFuseEnvMax;
+    // bf16: beyond how many envs the acting role is the persistent kernel (tuning knob).  Measured, us per step with the per-tile / the persistent acting role:
+    // 4,096 envs 44.0 / 46.8; 8,192 envs 56.2 / 50.7 (there the per-tile role is 256 workgroups — no CU left for the update — the persistent one 128 of two tiles)
+    static const int64_t persist_rows = getenv("HX_FRONT_PERSIST_ROWS") ? atoll(getenv("HX_FRONT_PERSIST_ROWS")) : 4096;
+    const bool persistent = n > kFuseEnvMax || (w2b && o.ring && n > persist_rows);
     HX_REQUIRE(!persistent || (w2b && n <= 32768 && o.ring), "hx_hirl_front: at most 8,192 envs per launch (one round of 32-row acting workgroups); bf16 with a replay "
                                                               "ring: 32,768 (persistent acting workgroups)");
     HX_REQUIRE(!FA.sample && FA.njobs >= 3 && FB.njobs >= 2, "hx_hirl_front: launch A reads finished minibatch tiles");
