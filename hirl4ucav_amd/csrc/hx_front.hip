@@ -85,6 +85,27 @@ __global__ __launch_bounds__(kWide) void actp_front_kernel(ActFusedArgs H, FwdAr
     else fwd_l2_body<kNT, RELU, false, true, 2>(FB, NoSample{}, bx, job - 16, u.f, C.sync);
 }
 
+// fp32 in the exact-split format, 8,192 .. 12,288 envs: the acting role is the STREAMING persistent kernel of hx_actp.hip, one 64-row pass per workgroup — 128 to
+// 192 workgroups (37.6 us for a pass) and the rest of the CUs for the update; the per-tile role at 8,192 envs is 256 workgroups with no CU to spare (41.1 us)
+template <bool RELU>
+__global__ __launch_bounds__(kWide) void actps_front_kernel(ActFusedArgs H, FwdArgsC FA, FwdArgsC FB, FrontCtl C, int tiles) {
+    typedef ActpsLds<1, false, true> LdsAct;
+    typedef FwdLds<kNT, false, false> LdsF;
+    __shared__ union {
+        LdsAct act;
+        LdsF f;
+    } u;
+    int b = (int)blockIdx.x;
+    if (b < C.n_act) {
+        act_persist_stream_body<1, false, true, RELU>(H, tiles, b, C.n_act, u.act);
+        return;
+    }
+    b -= C.n_act;
+    const int k = b / C.per, bx = b - k * C.per, job = C.order[k];
+    if (job < 16) fwd_l2_body<kNT, RELU, false, false, 1>(FA, NoSample{}, bx, job, u.f, C.sync);
+    else fwd_l2_body<kNT, RELU, false, false, 2>(FB, NoSample{}, bx, job - 16, u.f, C.sync);
+}
+
 }  // namespace
 
 namespace hxu {
@@ -102,9 +123,12 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
     // bf16: beyond how many envs the acting role is the persistent kernel (tuning knob).  Measured, us per step with the per-tile / the persistent acting role:
     // 4,096 envs 44.0 / 46.8; 8,192 envs 56.2 / 50.7 (there the per-tile role is 256 workgroups — no CU left for the update — the persistent one 128 of two tiles)
     static const int64_t persist_rows = getenv("HX_FRONT_PERSIST_ROWS") ? atoll(getenv("HX_FRONT_PERSIST_ROWS")) : 4096;
-    const bool persistent = n > kFuseEnvMax || (w2b && o.ring && n > persist_rows);
-    HX_REQUIRE(!persistent || (w2b && n <= 32768 && o.ring), "hx_hirl_front: at most 8,192 envs per launch (one round of 32-row acting workgroups); bf16 with a replay "
-                                                              "ring: 32,768 (persistent acting workgroups)");
+    // fp32, exact split: from how many envs on the acting role is the streaming persistent kernel, one 64-row pass per workgroup (tuning knob)
+    static const int64_t stream_rows = getenv("HX_FRONT_STREAM_ROWS") ? atoll(getenv("HX_FRONT_STREAM_ROWS")) : 8192;
+    const bool stream = w2x && o.ring && n >= stream_rows && n <= 12288;
+    const bool persistent = !stream && (n > kFuseEnvMax || (w2b && o.ring && n > persist_rows));
+    HX_REQUIRE(!persistent || (w2b && n <= 32768 && o.ring), "hx_hirl_front: at most 8,192 envs per launch (one round of 32-row acting workgroups); with a replay ring "
+                                                              "12,288 in the exact-split format and 32,768 in bf16 (persistent acting workgroups)");
     HX_REQUIRE(!FA.sample && FA.njobs >= 3 && FB.njobs >= 2, "hx_hirl_front: launch A reads finished minibatch tiles");
     ActFusedArgs H{actor, mA, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
                    noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
@@ -145,6 +169,19 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
     }
     HX_REQUIRE(tiles <= 16, "hx_hirl_front: at most 16 row tiles (HxFront.flags)");
     const bool relu = slope == 0.0f;
+    if (stream) {  // one 64-row pass per acting workgroup
+        C.n_act = (int)((n + 4 * RT - 1) / (4 * RT));
+        const dim3 sgrid((unsigned)(C.n_act + C.per * (FA.njobs + FB.njobs)));
+        if (o.ev_start && o.ev_stop) {
+            if (relu) hipExtLaunchKernelGGL((actps_front_kernel<true>), sgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, 1);
+            else hipExtLaunchKernelGGL((actps_front_kernel<false>), sgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, 1);
+        } else {
+            if (relu) hipLaunchKernelGGL((actps_front_kernel<true>), sgrid, dim3(kWide), 0, st, H, CA, CB, C, 1);
+            else hipLaunchKernelGGL((actps_front_kernel<false>), sgrid, dim3(kWide), 0, st, H, CA, CB, C, 1);
+        }
+        HX_CHECK_LAUNCH("hx_hirl_front");
+        return 0;
+    }
     if (persistent) {  // two thirds of the CUs act (ceil(tiles / 176) row tiles per workgroup), the rest serve the update
         const int ntiles = (int)((n + 2 * RT - 1) / (2 * RT)), tiles_per_wg = (ntiles + 175) / 176;
         C.n_act = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
