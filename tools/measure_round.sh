@@ -27,6 +27,7 @@ done <<'CFGS'
 --agent sac --envs 16384 --scenario serpentine
 --envs 16384 --scenario mixed
 --envs 16384 --scenario mixed --dtype bf16
+--envs 16384 --scenario mixed --dtype bf16 --no-front
 --envs 8192 --scenario circular --type linear --bc_weight 0.5
 --envs 65536 --scenario circular --type linear --bc_weight 0.5
 --envs 131072 --scenario mixed --dtype bf16
@@ -55,6 +56,7 @@ if [ -z "$QUICK" ]; then
   stats circ65536_f32 --envs 65536 --scenario circular --type linear --bc_weight 0.5
   stats mixed131072_bf16 --envs 131072 --scenario mixed --dtype bf16
   stats mixed16k_bf16 --envs 16384 --scenario mixed --dtype bf16
+  stats circ8192_f32 --envs 8192 --scenario circular --type linear --bc_weight 0.5
   stats mixed16k_f32 --envs 16384 --scenario mixed
   STEPS=4000
 fi
