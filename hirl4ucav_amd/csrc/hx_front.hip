@@ -9,7 +9,10 @@
 // for them IN the launch, per row tile (FrontSync, hx_fwd_body.h) — off the critical path here, because A is through long before the acting
 // workgroups are.  Workgroups are dispatched in index order: acting first (the longest), then the update's jobs in FrontCtl::order.
 // CU time is what runs out in the shadow (tools/ubench/front_spans.py), so the minibatch is NOT drawn here: the previous hx_hirl_learn_back left its
-// tiles behind (predraw_wg in its first launch), and launch B runs in 64-column workgroups whatever its job count.
+// tiles behind (predraw_wg, one more workgroup of its wgrad launch), launch B runs in 64-column workgroups whatever its job count, and the target actor's
+// head is evaluated once per row tile (FRONT == 1 in hx_fwd_body.h) instead of in every target-critic workgroup.
+// Beyond one round of 32-row acting workgroups the acting role is a PERSISTENT kernel on part of the CUs (actp_front_kernel: bf16, weight-stationary;
+// actps_front_kernel: fp32 in the exact-split format, one 64-row pass per workgroup).
 // The draw's meaning changes (it cannot see this step's inserts and must not read the slots they overwrite): include/hirl4ucav.h hx_hirl_front.
 #include <hip/hip_ext.h>
 
@@ -37,7 +40,7 @@ struct FrontCtl {
 // tools/ubench/front_spans.py).  The K-split of a column tile differs between the two tilings (4 against 8 partial sums), hence the last bits of the
 // target critics' z2: hx_debug_set_fwd_nt(64) gives the separate launches the same tiling (tests/test_front_gpu.py).
 // X3: the acting workgroups multiply in the exact 9-term bf16 split (the engine's "f32x9" acting format, H.w2b = the hi | mid | lo images) instead of
-// fp32 MFMA from the fp32 image: 22.2 against 26.8 us for the 128 workgroups of 4,096 envs (tools/ubench/x9_32row.sh) — a shorter shadow, but the
+// fp32 MFMA from the fp32 image: 21.7 against 26.8 us for the 128 workgroups of 4,096 envs (tools/ubench/x9_32row.sh) — a shorter shadow, but the
 // acting workgroups are the launch's longest
 // BF16: the bf16 update path (HxNets.w2_bf16_all) with the bf16 acting kernel — both on v_mfma_f32_16x16x32_bf16, as their launches of their own
 template <bool RELU, bool X3, bool BF16 = false>
