@@ -130,8 +130,8 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
     static const int64_t stream_rows = getenv("HX_FRONT_STREAM_ROWS") ? atoll(getenv("HX_FRONT_STREAM_ROWS")) : 8192;
     const bool stream = w2x && o.ring && n >= stream_rows && n <= 12288;
     const bool persistent = !stream && (n > kFuseEnvMax || (w2b && o.ring && n > persist_rows));
-    HX_REQUIRE(!persistent || (w2b && n <= 32768 && o.ring), "hx_hirl_front: at most 8,192 envs per launch (one round of 32-row acting workgroups); with a replay ring "
-                                                              "12,288 in the exact-split format and 32,768 in bf16 (persistent acting workgroups)");
+    HX_REQUIRE(!persistent || (w2b && o.ring), "hx_hirl_front: at most 8,192 envs per launch (one round of 32-row acting workgroups); with a replay ring "
+                                               "12,288 in the exact-split format and any number in bf16 (persistent acting workgroups)");
     HX_REQUIRE(!FA.sample && FA.njobs >= 3 && FB.njobs >= 2, "hx_hirl_front: launch A reads finished minibatch tiles");
     ActFusedArgs H{actor, mA, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
                    noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
@@ -185,8 +185,12 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
         HX_CHECK_LAUNCH("hx_hirl_front");
         return 0;
     }
-    if (persistent) {  // two thirds of the CUs act (ceil(tiles / 176) row tiles per workgroup), the rest serve the update
-        const int ntiles = (int)((n + 2 * RT - 1) / (2 * RT)), tiles_per_wg = (ntiles + 175) / 176;
+    if (persistent) {
+        // up to 32,768 envs two thirds of the CUs act (ceil(tiles / 176) row tiles per workgroup) and the rest serve the update beside them; beyond, the acting
+        // workgroups take every CU (the update is a small share there) and the update's workgroups start as the first of them leave: two boundaries less
+        static const int wide_wgs = getenv("HX_FRONT_PERSIST_WIDE_WGS") ? atoi(getenv("HX_FRONT_PERSIST_WIDE_WGS")) : 256;  // tuning knob
+        const int want = n <= 32768 ? 176 : wide_wgs;
+        const int ntiles = (int)((n + 2 * RT - 1) / (2 * RT)), tiles_per_wg = (ntiles + want - 1) / want;
         C.n_act = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
         const dim3 pgrid((unsigned)(C.n_act + C.per * (FA.njobs + FB.njobs)));
         if (o.ev_start && o.ev_stop) {

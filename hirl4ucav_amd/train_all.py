@@ -353,7 +353,7 @@ def main(config):
     # step and the first two launches of learn() as ONE launch (HirlEngine.step_learn) — the minibatch is then drawn from the ring as it stood before
     # this step's insert.  --loop reference: the reference's order on every step (act -> env step -> insert -> draw -> learn)
     front = (config.loop == "front" and not sac and not config.separate_launches and config.updates_per_step == 1 and batch <= 256
-             and getattr(config, "dtype", "f32") in ("f32", "f32x9", "bf16") and n <= (32768 if getattr(config, "dtype", "f32") == "bf16" else 12288))
+             and getattr(config, "dtype", "f32") in ("f32", "f32x9", "bf16") and (getattr(config, "dtype", "f32") == "bf16" or n <= 12288))
     if rank == 0:
         print(f"vector loop: {'front launch (env step + first launches of learn() in one launch; draw before the insert)' if front else 'reference order'}", flush=True)
     for episode in range(episode0, config.episodes):
