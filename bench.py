@@ -79,7 +79,7 @@ def parse(argv=None):
                         "GPU it does not pay (every cross-stream event hand-off costs ~10 us on this runtime), so the default, at any N, is "
                         "the reference's strict act -> step -> sample -> learn order on one stream")
     p.add_argument("--front", dest="front", action="store_true", default=None,
-                   help="(default where it applies: HIRL in fp32 or --dtype bf16 with the policy's actions in one launch, <= 12,288 envs per GPU — bf16: any number —, batch <= 256) the FRONT launch "
+                   help="(default where it applies: HIRL in fp32 or --dtype bf16 with the policy's actions in one launch, batch <= 256) the FRONT launch "
                         "(HirlEngine.step_learn, include/hirl4ucav.h hx_hirl_front): env step + the first two launches of learn() as ONE launch; the minibatch is "
                         "then drawn from the ring as it stood before this step's insert, without the slots it may overwrite")
     p.add_argument("--front-acting", dest="front_acting", default="x9", choices=["x9", "mfma"],
@@ -251,9 +251,9 @@ class Loop:
         self.fused = not (self.uniform or self.separate)
         if not self.sac and getattr(args, "front_acting", "x9") == "mfma":
             self.eng.front_x9 = False
-        front_ok = not (self.sac or self.uniform or self.separate or args.overlap or args.sample_launch or args.dtype not in ("f32", "f32x9", "bf16") or n > ((1 << 30) if args.dtype == "bf16" else (12288 if getattr(args, "front_acting", "x9") == "x9" else 8192)) or args.batch > 256)
+        front_ok = not (self.sac or self.uniform or self.separate or args.overlap or args.sample_launch or args.dtype not in ("f32", "f32x9", "bf16") or n > ((1 << 30) if (args.dtype == "bf16" or getattr(args, "front_acting", "x9") == "x9") else 8192) or args.batch > 256)
         if getattr(args, "front", None) and not front_ok:
-            raise SystemExit("--front: HIRL in fp32 or bf16 (actor and critic), policy actions in one launch, one stream, at most 8,192 envs per GPU (exact-split acting: 12,288; bf16: any) and batch 256")
+            raise SystemExit("--front: HIRL in fp32 or bf16 (actor and critic), policy actions in one launch, one stream, at most 8,192 envs per GPU with fp32-MFMA acting (exact-split acting and bf16: any number) and batch 256")
         self.front = front_ok if getattr(args, "front", None) is None else bool(args.front)
 
     # ---- the hot path ------------------------------------------------------------------------------------------------

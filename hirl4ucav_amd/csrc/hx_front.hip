@@ -128,10 +128,10 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
     static const int64_t persist_rows = getenv("HX_FRONT_PERSIST_ROWS") ? atoll(getenv("HX_FRONT_PERSIST_ROWS")) : 4096;
     // fp32, exact split: from how many envs on the acting role is the streaming persistent kernel, one 64-row pass per workgroup (tuning knob)
     static const int64_t stream_rows = getenv("HX_FRONT_STREAM_ROWS") ? atoll(getenv("HX_FRONT_STREAM_ROWS")) : 8192;
-    const bool stream = w2x && o.ring && n >= stream_rows && n <= 12288;
+    const bool stream = w2x && o.ring && n >= stream_rows;
     const bool persistent = !stream && (n > kFuseEnvMax || (w2b && o.ring && n > persist_rows));
     HX_REQUIRE(!persistent || (w2b && o.ring), "hx_hirl_front: at most 8,192 envs per launch (one round of 32-row acting workgroups); with a replay ring "
-                                               "12,288 in the exact-split format and any number in bf16 (persistent acting workgroups)");
+                                               "any number in the exact-split format and in bf16 (persistent acting workgroups)");
     HX_REQUIRE(!FA.sample && FA.njobs >= 3 && FB.njobs >= 2, "hx_hirl_front: launch A reads finished minibatch tiles");
     ActFusedArgs H{actor, mA, obs_io, (int)n, slope, actions, (noise_mode == 1 || noise_mode == 2) ? noise : nullptr,
                    noise_mode == 2, noise_mode == 3 ? sigma : 0.0f, 0, seed, row0, call, state, stride, reward, done, success, o,
@@ -172,15 +172,17 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
     }
     HX_REQUIRE(tiles <= 16, "hx_hirl_front: at most 16 row tiles (HxFront.flags)");
     const bool relu = slope == 0.0f;
-    if (stream) {  // one 64-row pass per acting workgroup
-        C.n_act = (int)((n + 4 * RT - 1) / (4 * RT));
+    if (stream) {  // up to 16,384 envs one 64-row pass per acting workgroup (the CUs they leave serve the update beside them); beyond, passes over every CU and the
+                   // update's workgroups behind them (two boundaries less)
+        const int npass = (int)((n + 4 * RT - 1) / (4 * RT)), per_wg = (npass + 255) / 256;
+        C.n_act = (npass + per_wg - 1) / per_wg;
         const dim3 sgrid((unsigned)(C.n_act + C.per * (FA.njobs + FB.njobs)));
         if (o.ev_start && o.ev_stop) {
-            if (relu) hipExtLaunchKernelGGL((actps_front_kernel<true>), sgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, 1);
-            else hipExtLaunchKernelGGL((actps_front_kernel<false>), sgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, 1);
+            if (relu) hipExtLaunchKernelGGL((actps_front_kernel<true>), sgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, per_wg);
+            else hipExtLaunchKernelGGL((actps_front_kernel<false>), sgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, per_wg);
         } else {
-            if (relu) hipLaunchKernelGGL((actps_front_kernel<true>), sgrid, dim3(kWide), 0, st, H, CA, CB, C, 1);
-            else hipLaunchKernelGGL((actps_front_kernel<false>), sgrid, dim3(kWide), 0, st, H, CA, CB, C, 1);
+            if (relu) hipLaunchKernelGGL((actps_front_kernel<true>), sgrid, dim3(kWide), 0, st, H, CA, CB, C, per_wg);
+            else hipLaunchKernelGGL((actps_front_kernel<false>), sgrid, dim3(kWide), 0, st, H, CA, CB, C, per_wg);
         }
         HX_CHECK_LAUNCH("hx_hirl_front");
         return 0;

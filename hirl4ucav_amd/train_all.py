@@ -349,11 +349,11 @@ def main(config):
     log_rate = 300  # train_all.py:208
     ret = torch.zeros(n, device=device) if config.log_rewards else None
     last_stats = env.stats_dict()
-    # --loop front (default where it applies: the fp32 HIRL / TD3 agents, <= 8,192 envs per GPU, batch <= 256, one update per step): the env
+    # --loop front (default where it applies: HIRL / TD3 in fp32 or bf16 actor + critic, batch <= 256, one update per step): the env
     # step and the first two launches of learn() as ONE launch (HirlEngine.step_learn) — the minibatch is then drawn from the ring as it stood before
     # this step's insert.  --loop reference: the reference's order on every step (act -> env step -> insert -> draw -> learn)
     front = (config.loop == "front" and not sac and not config.separate_launches and config.updates_per_step == 1 and batch <= 256
-             and getattr(config, "dtype", "f32") in ("f32", "f32x9", "bf16") and (getattr(config, "dtype", "f32") == "bf16" or n <= 12288))
+             and getattr(config, "dtype", "f32") in ("f32", "f32x9", "bf16"))
     if rank == 0:
         print(f"vector loop: {'front launch (env step + first launches of learn() in one launch; draw before the insert)' if front else 'reference order'}", flush=True)
     for episode in range(episode0, config.episodes):
@@ -476,7 +476,7 @@ def parser():
     p.add_argument("--checkpoint_rate", type=int, default=25, help="episodes between validations (train_all.py:206)")
     p.add_argument("--bc_validate_from", type=int, default=1000, help="BC: first episode with validation (train_all.py:259)")
     p.add_argument("--loop", type=str, default="front", choices=["front", "reference"],
-                   help="front (default where it applies: fp32 HIRL / TD3, <= 8,192 envs per GPU, batch <= 256, one update per step): env step + the first two "
+                   help="front (default where it applies: HIRL / TD3 in fp32 or bf16 actor + critic, batch <= 256, one update per step): env step + the first two "
                         "launches of learn() as one launch; the minibatch is drawn from the ring as it stood before the step's insert, without the slots it may "
                         "overwrite.  reference: act -> env step -> insert -> draw -> learn on every step (the minibatch sees this step's transitions)")
     p.add_argument("--separate_launches", action="store_true",

@@ -347,7 +347,7 @@ int hx_hirl_learn_sampled(const HxNets* nets, const HxBatch* batch, const HxHype
 
 /* The FRONT launch (opt-in; fp32 networks — noise_mode + 32: the policy's W2 from HxNets.actor_w2_x9, the exact 9-term bf16 split, as
  * hx_actor_act_step_x9, else from HxNets.actor_w2_f32i — or the bf16 update path, HxNets.w2_bf16_all, with the bf16 acting image
- * HxNets.actor_w2_bf16; n <= 8,192 — with a replay ring 12,288 in the exact-split format and any number in bf16): hx_actor_act_step_f32i / _x9 / _bf16 for n envs (chooseAction + HarfangEnv.step + replay insert,
+ * HxNets.actor_w2_bf16; n <= 8,192 — with a replay ring any number in the exact-split format and in bf16): hx_actor_act_step_f32i / _x9 / _bf16 for n envs (chooseAction + HarfangEnv.step + replay insert,
  * train_all.py:343-345) AND the first two launches of the learn() call that follows it (targetActor(s'), Q1/Q2(s, a) [+ the actor call's forwards];
  * then targetCritic Q1/Q2 — HIRL.py:259-272) as workgroups of ONE launch: the acting workgroups take 32 rows each and so leave half of the CUs to
  * the update's workgroups, which would otherwise wait for the env step to finish although they depend on nothing it computes EXCEPT the ring it

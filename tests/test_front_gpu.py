@@ -87,7 +87,8 @@ def sorted_rows(rep):
                                                            (True, 0.0, 16384, 40000, "bf16", False), (False, 0.01, 12000, 30000, "bf16", True),
                                                            (True, 0.0, 8192, 20000, "bf16", False), (True, 0.0, 5000, 12000, "bf16", False),  # bf16 beyond 4,096 envs: persistent acting workgroups
                                                            (True, 0.0, 40000, 90000, "bf16", False),  # ... beyond 32,768: on every CU, the update's workgroups behind them
-                                                           (True, 0.0, 8192, 20000, "f32x9", False), (False, 0.01, 12288, 30000, "f32x9", True), (True, 0.0, 10000, 24000, "f32x9", False)])  # exact split, 8,192 .. 12,288 envs: one 64-row pass per acting workgroup
+                                                           (True, 0.0, 8192, 20000, "f32x9", False), (False, 0.01, 12288, 30000, "f32x9", True), (True, 0.0, 10000, 24000, "f32x9", False),  # exact split from 8,192 envs on: one 64-row pass per acting workgroup ...
+                                                           (True, 0.0, 20000, 44000, "f32x9", False)])  # ... beyond 16,384: passes over every CU, the update's workgroups behind them
 def test_front_launch_equals_act_step_then_guarded_learn(eng_mod, use_bc, slope, n, cap, act, staged):
     from hirl4ucav_amd import _lib
     L = _lib.load()
