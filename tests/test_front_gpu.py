@@ -5,8 +5,10 @@ Parity statement: one step_learn == act_step, then learn() on a minibatch drawn 
 HxSample.guard = n (the slots the step may overwrite left out), launch B in the front launch's tiling (hx_debug_set_fwd_nt) — bit for bit in everything both leave behind: actions, env state words,
 observations, rewards, episode counters, the replay rows (as a multiset: ring slots are handed out by an atomic), drawn indices, smoothing noise,
 row tiles, networks, Adam moments; loss sums to 1e-6 (they are accumulated with atomics).  Checked step by step from shared states over rings that
-fill up and wrap, HIRL (soft / fixed weights, BC minibatch, expert rows) and TD3, ReLU and leaky networks.  The draw rule itself is checked against
-a restatement on the host (allowed slots, no replacement)."""
+fill up and wrap, HIRL (soft / fixed weights, BC minibatch, expert rows) and TD3, ReLU and leaky networks, every acting role of the launch: per-tile 32-row
+workgroups (fp32 MFMA, exact split, bf16), the persistent weight-stationary bf16 kernel (beyond 4,096 envs; on every CU beyond 32,768) and the streaming
+exact-split kernel (from 8,192 envs on), one-call and sharded (staged) update sequences.  The draw rule itself is checked against a restatement on the host
+(allowed slots, no replacement), the loop against the env and update oracles directly."""
 import numpy as np
 import pytest
 
