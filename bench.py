@@ -251,7 +251,8 @@ class Loop:
         self.fused = not (self.uniform or self.separate)
         if not self.sac and getattr(args, "front_acting", "x9") == "mfma":
             self.eng.front_x9 = False
-        front_ok = not (self.sac or self.uniform or self.separate or args.overlap or args.sample_launch or args.dtype not in ("f32", "f32x9", "bf16") or n > ((1 << 30) if (args.dtype == "bf16" or getattr(args, "front_acting", "x9") == "x9") else 8192) or args.batch > 256)
+        sac_front_ok = self.sac and n > 8192 and self.world == 1 and not (self.uniform or self.separate or args.overlap or args.sample_launch) and args.batch <= 256
+        front_ok = sac_front_ok or not (self.sac or self.uniform or self.separate or args.overlap or args.sample_launch or args.dtype not in ("f32", "f32x9", "bf16") or n > ((1 << 30) if (args.dtype == "bf16" or getattr(args, "front_acting", "x9") == "x9") else 8192) or args.batch > 256)
         if getattr(args, "front", None) and not front_ok:
             raise SystemExit("--front: HIRL in fp32 or bf16 (actor and critic), policy actions in one launch, one stream, at most 8,192 envs per GPU with fp32-MFMA acting (exact-split acting and bf16: any number) and batch 256")
         self.front = front_ok if getattr(args, "front", None) is None else bool(args.front)
@@ -313,6 +314,9 @@ class Loop:
     def _front_step(self):
         """act + env step + replay insert AND launches A, B of learn() in one launch, then the rest of learn() (HirlEngine.step_learn)"""
         e = self.eng
+        if self.sac:  # explore + env step + insert AND the first forward launch of learn() in one launch, then the rest of learn() (SacEngine.step_learn)
+            e.step_learn(self.env, act_seed=1, out=self.actions, sample_seed=2 + self.rank)
+            return
         e.step_learn(self.env, self.expert, self.bc_table, n_main=e.batch - self.expert_num, act_sigma=0.1, act_seed=1, out=self.actions,
                      sample_seed=2 + self.rank, bc_weight_now=self._bc_weight(), bc_warm_up_weight=0.0)
 
@@ -853,7 +857,7 @@ def run_rank(args):
     for k in range(m_steps):
         loop.step_measured(split=(k % 4 == 3), pool=pool, kpool=kpool)
     barrier()
-    if loop.front:
+    if loop.front and hasattr(loop.eng, "front_check"):
         loop.eng.front_check()  # an in-launch wait that gave up leaves a minibatch half read: fail loudly instead of printing a number
     if exchanging:
         loop.eng._allreduce = inner
@@ -922,11 +926,12 @@ def run_rank(args):
                                   "repetitions": {"count": len(ref_reps), "statistic": "median", "ms_per_step": [round(t / args.steps * 1e3, 5) for t in ref_reps]}}
         del ref_loop
     res["config"]["loop"] = "front" if loop.front else "reference order"
-    if loop.front and args.dtype == "f32" and loop.eng.front_x9:
+    if loop.front and args.agent == "hirl" and args.dtype == "f32" and loop.eng.front_x9:
         res["config"]["acting_product"] = ("fp32 operands, the 256 -> 512 product as the exact 9-term bf16 split on bf16 MFMA with fp32 accumulation (the engine's fp32 acting "
                                            "format wherever it is the faster one: from 16,384 rows on, and in the front launch); max error vs fp64 4.0e-7 against 5.4e-7 for fp32 MFMA")
     if loop.front:
-        res["config"]["act_env"] = "FRONT launch (hx_hirl_front): act + env step + replay insert + launches A and B of learn() in one launch"
+        res["config"]["act_env"] = ("FRONT launch (hx_sac_front): explore + env step + replay insert + the first forward launch of learn() in one launch" if args.agent == "sac" else
+                                    "FRONT launch (hx_hirl_front): act + env step + replay insert + launches A and B of learn() in one launch")
         res["config"]["draw"] = ("uniform without replacement over the transitions that are in the ring before AND after this step's insert (drawn from the ring as it stood "
                                  "before the step, without the n slots the step may overwrite: HxSample.guard); --no-front draws after the insert, like the reference")
         res["stage_us"]["front launch + rest of learn() (3 of every 4 steps; the front launch stamped: + ~25 us of instruments)"] = None if med["front+back"] is None else round(med["front+back"], 2)
@@ -957,7 +962,7 @@ def run_rank(args):
             flop, peak = fp32_equiv, FP32_MATRIX_PEAK_TFLOPS
         else:
             flop, peak = fp32_equiv, BF16_MATRIX_PEAK_TFLOPS
-        if loop.front:  # + the forward passes of launches A and B over the minibatch: 3 + 2 nets on a critic-only call, 4 + 4 on an actor call (every 2nd)
+        if loop.front and args.agent != "sac":  # + the forward passes of launches A and B over the minibatch: 3 + 2 nets on a critic-only call, 4 + 4 on an actor call (every 2nd)
             flop += int(6.5 * args.batch * ACTOR_FLOP)
         tf, gb = flop / us / 1e6, ENV_BYTES_FUSED * args.envs / us / 1e3
         mf, hf = tf / peak, gb / HBM_PEAK_GBPS
@@ -969,7 +974,10 @@ def run_rank(args):
         first, second = (mfma, hbm) if mf >= hf else (hbm, mfma)
         persistent = args.envs > 8192
         front_name = None
-        if loop.front:  # + the forward passes of launches A (3.5 nets on average) and B (3 on average) over the minibatch
+        if loop.front and args.agent == "sac":
+            front_name = ("actps_sac_front_kernel<MODE> (hx_front.hip): the persistent streaming acting workgroups (Gaussian policy + env step + fused replay insert) with the "
+                          "first forward launch of learn() (policy(s'), policy(s), Q1/Q2(s, a)) behind them")
+        elif loop.front:  # + the forward passes of launches A (3.5 nets on average) and B (3 on average) over the minibatch
             front_name = ("act_front_kernel<RELU, X3, BF16> (hx_front.hip): the acting workgroups (32 rows each: policy inference + env step + fused replay insert) on half "
                           "of the CUs, launches A and B of learn() (target actor, critics; target critics) on the other half") if args.envs <= (4096 if args.dtype == "bf16" else 8192) else \
                          ("actp_front_kernel<RELU> / actps_front_kernel<RELU> (hx_front.hip): persistent acting workgroups (bf16: weight-stationary, two thirds of the CUs; exact split: "

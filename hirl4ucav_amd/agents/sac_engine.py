@@ -35,6 +35,9 @@ _lib.register("hx_sac_act_step_x9", [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.
 _lib.register("hx_sac_critic_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _i32, _vp])
 _lib.register("hx_sac_critic_grads_sampled", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _P(E.HxSample), _i32, _vp])
 _lib.register("hx_sac_critic_step", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _P(E.HxSample), _i32, _i32, _vp])
+_lib.register("hx_sac_front", [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, _vp,
+                                _P(_lib.HxStepOpts), _P(HxSacNets), _P(HxSacBatch), _vp])
+_lib.register("hx_sac_learn_back", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _i32, _i32, ctypes.c_float, _P(E.HxSample), _vp, _vp])
 _lib.register("hx_sac_learn", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _P(E.HxSample), _i32, _i32, ctypes.c_float, _vp])
 _lib.register("hx_sac_policy_grads", [_P(HxSacNets), _P(HxSacBatch), _P(E.HxHyper), _vp])
 _lib.register("hx_sac_adam", [_P(HxSacNets), _P(E.HxHyper), _i32, _i32, _f32, _f32, _vp])
@@ -273,6 +276,54 @@ class SacEngine:
             self._allreduce(self.losses)
             self.losses.mul_(gs)
         _lib.call("hx_sac_adam", nets, hyper, 1, self.learning_steps, gs, self.target_entropy, st)
+
+    def step_learn(self, env, expert=None, n_main=None, explore=True, act_seed=0, out=None, sample_seed=0):
+        """One iteration of the vector loop — act_step(env) then sample(env.replay, ..., defer=True) then learn() — in FRONT form (include/hirl4ucav.h
+        hx_sac_front): the env step and the first forward launch of learn() are ONE launch, the minibatch pre-drawn by the previous call.  As in
+        HirlEngine.step_learn the minibatch is drawn from the ring as it stood BEFORE this env step, without the env.n slots the step may overwrite.
+        More than 8,192 envs (the persistent acting kernel), one GPU, the one-call learn(), Philox draws.  -> (actions, obs, reward, done, success)."""
+        replay, n, B = env.replay, env.n, self.batch
+        if self.world > 1 or replay is None or n <= 8192 or getattr(self, "separate_critic_adam", False) or getattr(self, "staged_policy", False):
+            raise _lib.HxError("SacEngine.step_learn: one GPU, the one-call learn(), more than 8,192 envs with a replay ring attached")
+        if getattr(self, "_pending", None) is not None:
+            raise _lib.HxError("step_learn draws its own minibatch: a sample(defer=True) is still pending")
+        if getattr(self, "_front_tiles", None) is None:
+            second = torch.zeros(B * 32 + B, dtype=torch.float32, device=self.device)
+            self._front_tiles = [(self.rows, self._idx), (second[:B * 32], second[B * 32:].view(torch.int32))]
+            self._front_drawn = None
+        cur, nxt = self._front_tiles
+        n_main = B if (n_main is None or expert is None) else int(n_main)
+        self.sample_calls += 1
+        self._seed = int(sample_seed)
+
+        def draw(tiles, call):
+            return E.HxSample(replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(), expert.ring.data_ptr() if expert is not None else None,
+                              E.len_of(expert), None, 0, n_main, int(sample_seed), call, 0.0, tiles[1].data_ptr(), None, n)
+
+        want = (env, env.steps_issued, replay, expert, n_main, int(sample_seed), self.sample_calls, n)
+        if self._front_drawn != want:  # no tile in waiting for THIS draw: draw now, as a launch of its own
+            _lib.call("hx_sample_batch_guarded", replay.total.data_ptr(), replay.capacity, replay.ring.data_ptr(), expert.ring.data_ptr() if expert is not None else None,
+                      E.len_of(expert), None, 0, B, n_main, 1, int(sample_seed), self.sample_calls, 0.0, cur[1].data_ptr(), None, self._noise.data_ptr(),
+                      cur[0].data_ptr(), None, n, _lib.stream_ptr())
+        if out is None:
+            out = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        self.act_calls += 1
+        self.learning_steps += 1
+        batch = HxSacBatch(cur[0].data_ptr(), B, None, None, int(sample_seed), self.learning_steps)
+        nets, hyper, st = ctypes.byref(self.nets), ctypes.byref(self.hyper), _lib.stream_ptr()
+        x9 = self._x9_for(n)
+        _lib.call("hx_sac_front", self.policy.data_ptr(), self.w2_x9.data_ptr() if x9 else None, self.w2_f32i.data_ptr(), env.state.data_ptr(), n, env.pitch,
+                  env.obs.data_ptr(), out.data_ptr(), 2 if explore else 0, None, int(act_seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(),
+                  env.done.data_ptr(), env.success.data_ptr(), ctypes.byref(env._opts), nets, ctypes.byref(batch), st)
+        env.steps_issued += 1
+        nxt_draw = draw(nxt, self.sample_calls + 1)
+        polyak_first = int(self.learning_steps % self.interval == 0)
+        _lib.call("hx_sac_learn_back", nets, ctypes.byref(batch), hyper, polyak_first, self.learning_steps, self.target_entropy, ctypes.byref(nxt_draw),
+                  nxt[0].data_ptr(), st)
+        self._front_drawn = (env, env.steps_issued, replay, expert, n_main, int(sample_seed), self.sample_calls + 1, n)
+        self._front_tiles = [nxt, cur]
+        self.rows, self._idx = cur
+        return out, env.obs, env.reward, env.done, env.success
 
     def losses_host(self):
         """(q1_loss, q2_loss, policy_loss, entropy_loss, mean entropy, alpha)"""

@@ -212,3 +212,8 @@ inline int check_step_args(const float* state, int64_t n, int64_t stride, const 
 }
 
 }  // namespace hxact
+
+namespace hxu {
+// hx_front.hip: the SAC policy's act + env + insert launch (persistent streaming kernel) with the first forward launch of learn() behind it
+int launch_front_sac(const hxact::ActFusedArgs& H, const FwdArgs& FA, hipStream_t st);
+}  // namespace hxu

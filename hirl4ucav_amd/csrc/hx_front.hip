@@ -109,9 +109,54 @@ __global__ __launch_bounds__(kWide) void actps_front_kernel(ActFusedArgs H, FwdA
     else fwd_l2_body<kNT, RELU, false, false, 2>(FB, NoSample{}, bx, job - 16, u.f, C.sync);
 }
 
+// SAC (explore + env step + insert, then SacAgent.learn): the policy's acting launch beyond 8,192 envs is the streaming persistent kernel on every CU (one
+// 64-row pass each at 16,384 envs); the FIRST forward launch of learn() — policy(s'), policy(s), Q1/Q2(s, a): no dependency inside — rides behind it as further
+// workgroups that start as the acting ones leave: one boundary less and no draw in its workgroups (the tiles were pre-drawn).  MODE as act_persist_stream_kernel.
+template <int MODE>
+__global__ __launch_bounds__(kWide) void actps_sac_front_kernel(ActFusedArgs H, FwdArgsC FA, FrontCtl C, int tiles) {
+    typedef ActpsLds<MODE, true, true> LdsAct;
+    typedef FwdLds<kNT, false, false> LdsF;
+    __shared__ union {
+        LdsAct act;
+        LdsF f;
+    } u;
+    int b = (int)blockIdx.x;
+    if (b < C.n_act) {
+        act_persist_stream_body<MODE, true, true, true>(H, tiles, b, C.n_act, u.act);
+        return;
+    }
+    b -= C.n_act;
+    const int k = b / C.per, bx = b - k * C.per;
+    fwd_l2_body<kNT, true, false, false, 0>(FA, NoSample{}, bx, (int)C.order[k], u.f, FrontSync{});
+}
+
 }  // namespace
 
 namespace hxu {
+
+int launch_front_sac(const ActFusedArgs& H, const FwdArgs& FA, hipStream_t st) {
+    HX_REQUIRE(H.state && H.o.ring && H.rows > kFuseEnvMax && (H.w2f || (H.w2b && H.x9)), "hx_sac_front: more than 8,192 envs with a replay ring, the policy's W2 from an image");
+    HX_REQUIRE(!FA.sample && FA.njobs >= 3 && FA.njobs <= 8 && FA.slope == 0.0f, "hx_sac_front: the first forward launch of learn() on finished minibatch tiles");
+    FwdArgsC CA{};
+    for (int j = 0; j < FA.njobs; ++j) { CA.job[j] = pack_fwd(FA.job[j]); CA.job[j].slope = FA.slope; }
+    CA.slope = FA.slope; CA.zero_nf = FA.zero_nf; CA.zero_f = FA.zero_f; CA.zero_i = FA.zero_i; CA.images = nullptr; CA.rowmap = 1;
+    const int rows = FA.job[0].rows, tiles = (rows + RT - 1) / RT;
+    HX_REQUIRE(tiles * FA.njobs < 128, "hx_sac_front: minibatches of at most 256 rows");
+    FrontCtl C{};
+    C.per = tiles * (H2 / kNT);
+    for (int j = 0; j < FA.njobs; ++j) C.order[j] = (unsigned char)j;
+    const int npass = (H.rows + 4 * RT - 1) / (4 * RT), per_wg = (npass + 255) / 256;
+    C.n_act = (npass + per_wg - 1) / per_wg;
+    const dim3 grid((unsigned)(C.n_act + C.per * FA.njobs));
+    const bool x9 = H.w2b && H.x9;
+#define HX_SACF(MODE_) do { \
+        if (H.o.ev_start && H.o.ev_stop) hipExtLaunchKernelGGL((actps_sac_front_kernel<MODE_>), grid, dim3(kWide), 0, st, (hipEvent_t)H.o.ev_start, (hipEvent_t)H.o.ev_stop, 0, H, CA, C, per_wg); \
+        else hipLaunchKernelGGL((actps_sac_front_kernel<MODE_>), grid, dim3(kWide), 0, st, H, CA, C, per_wg); } while (0)
+    if (x9) HX_SACF(1); else HX_SACF(0);
+#undef HX_SACF
+    HX_CHECK_LAUNCH("hx_sac_front");
+    return 0;
+}
 
 int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, const uint16_t* w2b, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
                  const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward, uint8_t* done, int8_t* success,

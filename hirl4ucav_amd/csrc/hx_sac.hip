@@ -2,7 +2,7 @@
 // wgrad machinery, plus the small per-row kernels around it (gfx950).
 #include <cmath>
 
-#include "hx_update.h"
+#include "hx_act.h"
 
 using namespace hxnn;
 using namespace hxu;
@@ -216,8 +216,24 @@ static void sac_slots(const HxSacNets* N, int B, Slot* s) {
  * grad_critic.  Also evaluates policy(s) for the policy half.  Follow with hx_sac_adam(which = 0). */
 // one_call (hx_sac_learn): the Polyak step rides behind the Gaussian heads' workgroups instead of in a launch of its own, and policy.sample(s)
 // of the policy half is evaluated beside policy.sample(s') — the same arithmetic on the same values, two launches less
+// launch 1 of SacAgent.learn: policy(s'), policy(s), Q1/Q2(s, a)
+static void sac_launch_1(const HxSacNets* N, const HxSacBatch* Bt, FwdArgs& F) {
+    const int B = Bt->batch;
+    Slot s[S_COUNT];
+    sac_slots(N, B, s);
+    const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
+    const float* q1 = N->critic; const float* q2 = N->critic + kQs.padded();
+    F = FwdArgs{};
+    F.njobs = 4; F.slope = 0.0f;
+    F.zero_f = N->losses; F.zero_nf = 5;
+    F.job[0] = FwdJob{N->policy, kPolicy, src, 17, 0, Head{}, nullptr, 0.f, s[SS_PN], B, 0};
+    F.job[1] = FwdJob{N->policy, kPolicy, src, 0, 0, Head{}, nullptr, 0.f, s[SS_PC], B, 1};
+    F.job[2] = FwdJob{q1, kQs, src, 0, 0, Head{}, nullptr, 0.f, s[SS_Q1], B, 1};
+    F.job[3] = FwdJob{q2, kQs, src, 0, 0, Head{}, nullptr, 0.f, s[SS_Q2], B, 1};
+}
+// skip_first: launch 1 has run already (as workgroups of hx_sac_front's launch)
 static int sac_critic_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, const HxSample* S, int32_t polyak_first, void* stream,
-                                 int adam_step = 0, bool one_call = false) {
+                                 int adam_step = 0, bool one_call = false, bool skip_first = false) {
     HX_REQUIRE(N && Bt && Hy && Bt->rows && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_sac_critic_grads: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int B = Bt->batch;
@@ -236,14 +252,9 @@ static int sac_critic_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const
         launch_polyak(N->target_critic, N->critic, nq, Hy->tau, nullptr, nullptr, 0, st);
     const float* q1 = N->critic; const float* q2 = N->critic + kQs.padded();
     const float* t1 = N->target_critic; const float* t2 = N->target_critic + kQs.padded();
-    {   // policy(s'), policy(s), Q1/Q2(s, a)
-        FwdArgs F{};
-        F.njobs = 4; F.slope = 0.0f;
-        F.zero_f = N->losses; F.zero_nf = 5;
-        F.job[0] = FwdJob{N->policy, kPolicy, src, 17, 0, Head{}, nullptr, 0.f, s[SS_PN], B, 0};
-        F.job[1] = FwdJob{N->policy, kPolicy, src, 0, 0, Head{}, nullptr, 0.f, s[SS_PC], B, 1};
-        F.job[2] = FwdJob{q1, kQs, src, 0, 0, Head{}, nullptr, 0.f, s[SS_Q1], B, 1};
-        F.job[3] = FwdJob{q2, kQs, src, 0, 0, Head{}, nullptr, 0.f, s[SS_Q2], B, 1};
+    if (!skip_first) {   // policy(s'), policy(s), Q1/Q2(s, a)
+        FwdArgs F;
+        sac_launch_1(N, Bt, F);
         F.sample = fused ? &SD : nullptr;
         launch_fwd(F, st);
     }
@@ -324,7 +335,8 @@ int hx_sac_critic_step(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* 
 }
 // adam_step > 0 (hx_sac_learn): policy.sample(s) was evaluated in the critic half's launch, and policy_optim.step() + the log-alpha step ride in
 // the policy's weight-gradient launch (the thread that produced a gradient steps it; thread 0 of the launch steps log_alpha)
-static int sac_policy_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, void* stream, int adam_step, float target_entropy) {
+static int sac_policy_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, void* stream, int adam_step, float target_entropy,
+                                 const SampleDev* predraw = nullptr) {
     HX_REQUIRE(N && Bt && Hy && Bt->rows && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_sac_policy_grads: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int B = Bt->batch;
@@ -385,6 +397,7 @@ static int sac_policy_grads_impl(const HxSacNets* N, const HxSacBatch* Bt, const
         WgJob& J = W.job[0];
         J = WgJob{};
         J.net = N->policy; J.grad = N->grad_policy; J.m = kPolicy; J.ws[0] = s[SS_PC]; J.rows[0] = B; J.nslots = 1; J.wmode[0] = 0;
+        W.predraw = predraw; W.predraw_batch = B;  // hx_sac_learn_back: one more workgroup assembles the next front launch's minibatch (112 workgroups: CUs to spare)
         if (adam_step > 0) {
             const double b1 = 0.9, b2 = 0.999;
             const double bc1 = 1.0 - pow(b1, adam_step), bc2 = 1.0 - pow(b2, adam_step);
@@ -417,6 +430,34 @@ int hx_sac_learn(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, co
     HX_REQUIRE(step >= 1, "hx_sac_learn: step is 1-based");
     if (int rc = sac_critic_grads_impl(N, Bt, Hy, S, polyak_first, stream, step, true)) return rc;
     return sac_policy_grads_impl(N, Bt, Hy, stream, step, target_entropy);
+}
+
+/* hx_sac_learn in two parts around an env step (include/hirl4ucav.h "SAC front launch"): hx_sac_front = hx_sac_act_step_x9 / _f32i for n > 8,192 envs AND the first
+ * forward launch of the learn() call behind it as workgroups of ONE launch, on the minibatch tiles a predraw left in `batch`; hx_sac_learn_back = the rest. */
+int hx_sac_front(const float* policy, const uint16_t* w2_x9, const float* w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t mode,
+                 const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success, const HxStepOpts* opts,
+                 const HxSacNets* N, const HxSacBatch* Bt, void* stream) {
+    HX_REQUIRE(policy && (w2_x9 || w2_f32i) && opts && N && Bt && Bt->rows && Bt->batch > 0 && Bt->batch % 16 == 0 && Bt->batch <= kFusedBatchMax && mode >= 0 && mode <= 2 &&
+               (mode != 1 || eps), "hx_sac_front: bad arguments");
+    if (int rc = hxact::check_step_args(state, n, stride, obs_io, actions, reward, done, success, *opts, "hx_sac_front")) return rc;
+    hxact::ActFusedArgs H{policy, kPolicy, obs_io, (int)n, 0.0f, actions, mode == 1 ? eps : nullptr, 1, 0.0f, mode, seed, row0, call,
+                          state, stride, reward, done, success, *opts, opts->cap > 0 ? 1.0 / (double)opts->cap : 0.0, w2_x9, w2_x9 ? nullptr : w2_f32i, w2_x9 ? 1 : 0};
+    FwdArgs F;
+    sac_launch_1(N, Bt, F);
+    return launch_front_sac(H, F, (hipStream_t)stream);
+}
+int hx_sac_learn_back(const HxSacNets* N, const HxSacBatch* Bt, const HxHyper* Hy, int32_t polyak_first, int32_t step, float target_entropy, const HxSample* next,
+                      float* next_rows, void* stream) {
+    HX_REQUIRE(step >= 1 && N && Bt && Hy, "hx_sac_learn_back: step is 1-based");
+    SampleDev SD{};
+    if (next) {
+        HX_REQUIRE(next_rows && next_rows != Bt->rows && !next->bc_table && !next->idx_bc, "hx_sac_learn_back: the next minibatch needs a tile of its own; SAC has no BC minibatch");
+        bool fused = false;
+        if (int rc = prepare_draw(next, Bt->batch, next_rows, nullptr, nullptr, stream, &SD, &fused, /*launch_now=*/false)) return rc;
+        HX_REQUIRE(fused, "hx_sac_learn_back: the predraw covers minibatches of at most 256 rows");
+    }
+    if (int rc = sac_critic_grads_impl(N, Bt, Hy, nullptr, polyak_first, stream, step, true, /*skip_first=*/true)) return rc;
+    return sac_policy_grads_impl(N, Bt, Hy, stream, step, target_entropy, next ? &SD : nullptr);
 }
 
 }  // extern "C"

@@ -354,8 +354,9 @@ def main(config):
     # this step's insert.  --loop reference: the reference's order on every step (act -> env step -> insert -> draw -> learn)
     front = (config.loop == "front" and not sac and not config.separate_launches and config.updates_per_step == 1 and batch <= 256
              and getattr(config, "dtype", "f32") in ("f32", "f32x9", "bf16"))
+    front_sac = (config.loop == "front" and sac and world == 1 and not config.separate_launches and config.updates_per_step == 1 and batch <= 256 and n > 8192)
     if rank == 0:
-        print(f"vector loop: {'front launch (env step + first launches of learn() in one launch; draw before the insert)' if front else 'reference order'}", flush=True)
+        print(f"vector loop: {'front launch (env step + first launches of learn() in one launch; draw before the insert)' if (front or front_sac) else 'reference order'}", flush=True)
     for episode in range(episode0, config.episodes):
         w_now, warm = bc_weight_schedule(config.type, episode, config.bc_weight) if hirl else (0.0, 0.0)
         for step in range(max_step):
@@ -370,6 +371,12 @@ def main(config):
                     c_, a_, b_, r__, f_, _w = eng.losses_host()
                     for tag, v in (("Loss/Critic_Loss", c_), ("Loss/Actor_Loss", a_), ("Loss/BC_Loss", b_), ("Loss/RL_Loss", r__), ("Loss/BC_Fire_Loss", f_)):
                         writer.add_scalar(tag, v, step + episode * max_step)
+                continue
+            if front_sac and step < max_step - 1:  # SAC / E-SAC: explore + env step + the first forward launch of learn() in one launch (SacEngine.step_learn)
+                expert_num = expert_num_after(expert_num, step, warm_up_rate)
+                eng.step_learn(env, expert if esac else None, n_main=batch - expert_num, act_seed=seed + 1, out=actions, sample_seed=seed + 2 + rank)
+                if ret is not None:
+                    ret += env.reward
                 continue
             if config.separate_launches:  # chooseAction, then env.step: two launches
                 eng.act(env.obs, seed=seed + 1, row0=env.env_id0, out=actions) if sac else eng.act(env.obs, sigma=0.1, seed=seed + 1, row0=env.env_id0, out=actions)
@@ -476,7 +483,7 @@ def parser():
     p.add_argument("--checkpoint_rate", type=int, default=25, help="episodes between validations (train_all.py:206)")
     p.add_argument("--bc_validate_from", type=int, default=1000, help="BC: first episode with validation (train_all.py:259)")
     p.add_argument("--loop", type=str, default="front", choices=["front", "reference"],
-                   help="front (default where it applies: HIRL / TD3 in fp32 or bf16 actor + critic, batch <= 256, one update per step): env step + the first two "
+                   help="front (default where it applies: HIRL / TD3 in fp32 or bf16 actor + critic, SAC / E-SAC beyond 8,192 envs on one GPU; batch <= 256, one update per step): env step + the first "
                         "launches of learn() as one launch; the minibatch is drawn from the ring as it stood before the step's insert, without the slots it may "
                         "overwrite.  reference: act -> env step -> insert -> draw -> learn on every step (the minibatch sees this step's transitions)")
     p.add_argument("--separate_launches", action="store_true",

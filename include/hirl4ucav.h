@@ -452,6 +452,18 @@ int hx_sac_policy_grads(const HxSacNets* nets, const HxSacBatch* batch, const Hx
  * hx_sac_policy_grads + hx_sac_adam(which = 1); sample may be NULL (minibatch already assembled); step is 1-based. */
 int hx_sac_learn(const HxSacNets* nets, const HxSacBatch* batch, const HxHyper* hyper, const HxSample* sample, int32_t polyak_first, int32_t step,
                  float target_entropy, void* stream);
+/* The SAC front launch (n > 8,192 envs with a replay ring): hx_sac_act_step_x9 (w2_x9 != NULL) / hx_sac_act_step_f32i — explore / exploit + HarfangEnv.step +
+ * replay insert (train_sac.py:238-241) — AND the first forward launch of the SacAgent.learn call that follows it (policy(s'), policy(s), Q1/Q2(s, a): SAC/agent.py:
+ * 198-210, 276-290) as workgroups of ONE launch that start as the acting ones leave, on the minibatch `batch->rows` holds already.  As for hx_hirl_front the
+ * minibatch is drawn from the ring as it stood BEFORE this env step without the n slots the step may overwrite (HxSample.guard = n): by the previous
+ * hx_sac_learn_back (its `next`: one more workgroup of the policy's gradient launch draws and gathers into next_rows) or by hx_sample_batch_guarded.
+ * Bit-identical to hx_sac_act_step_* followed by hx_sac_learn with HxSample.total read before the step and HxSample.guard = n.
+ * hx_sac_learn_back = the rest of hx_sac_learn (8 launches). */
+int hx_sac_front(const float* policy, const uint16_t* w2_x9, const float* w2_f32i, float* state, int64_t n, int64_t stride, float* obs_io, float* actions,
+                 int32_t mode, const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,
+                 const HxStepOpts* opts, const HxSacNets* nets, const HxSacBatch* batch, void* stream);
+int hx_sac_learn_back(const HxSacNets* nets, const HxSacBatch* batch, const HxHyper* hyper, int32_t polyak_first, int32_t step, float target_entropy,
+                      const HxSample* next, float* next_rows, void* stream);
 int hx_sac_adam(const HxSacNets* nets, const HxHyper* hyper, int32_t which, int32_t step, float grad_scale, float target_entropy,
                 void* stream);
 

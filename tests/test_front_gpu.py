@@ -268,3 +268,64 @@ def test_front_loop_against_the_oracles(eng_mod, n):
         if n <= 32:
             check_params(e, o, eng_mod, f"front step {k}", was_actor_call=was_actor)
     e.front_check()
+
+
+@pytest.mark.parametrize("n,cap,esac", [(16384, 40000, False), (9000, 20000, True)])
+def test_sac_front_launch_equals_act_step_then_guarded_learn(n, cap, esac):
+    """The SAC front launch (hx_sac_front + hx_sac_learn_back, SacEngine.step_learn): explore + env step + insert and the first forward launch of
+    SacAgent.learn in ONE launch (the persistent acting kernel beyond 8,192 envs: exact split from 16,384 rows on, fp32 MFMA below), the minibatch pre-drawn
+    by the previous call == act_step, then learn() on a minibatch drawn with HxSample.total read before the step and guard = n — bit for bit, step by step
+    from shared states over a ring that fills and wraps; SAC and E-SAC (expert rows mixed in)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from hirl4ucav_amd.agents import sac_engine as SE
+    from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+    from tests.test_oracle_sac import sac_params
+
+    p = sac_params()
+    rng = np.random.default_rng(n)
+    exp = None
+    if esac:
+        exp = DeviceReplay(64)
+        exp.store_rows(torch.from_numpy(rng.normal(size=(40, 32)).astype(np.float32)))
+    scen = (np.arange(n) % 3).astype(np.int32)
+    side = []
+    for _ in range(2):
+        e = SE.SacEngine(batch=128)
+        e.load_params(p["policy"], p["q1"], p["q2"])
+        rep = DeviceReplay(cap)
+        env = BatchedHarfangEnv(n, scenario=scen, seed=5, max_step=6, auto_reset=True, random_reset=True, replay=rep)
+        env.reset()
+        side.append((e, env, rep))
+    (a, env_a, rep_a), (b, env_b, rep_b) = side
+    a.act_step(env_a, seed=3)
+    snap = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for k in range(8):
+        b.arena.copy_(a.arena)
+        for name in ("learning_steps", "sample_calls", "act_calls"):
+            setattr(b, name, getattr(a, name))
+        env_b._state_store.copy_(env_a._state_store)
+        for name in ("obs", "reward", "done", "success", "episode_ctr"):
+            getattr(env_b, name).copy_(getattr(env_a, name))
+        rep_b.ring.copy_(rep_a.ring); rep_b.success.copy_(rep_a.success); rep_b.total.copy_(rep_a.total)
+        tot0 = int(rep_a.total.item())
+        out_a = a.step_learn(env_a, exp, n_main=96, act_seed=3, sample_seed=11)
+        snap.copy_(rep_b.total)
+        out_b = b.act_step(env_b, seed=3)
+        b.sample(rep_b, exp, n_main=96, seed=11, defer=True)
+        b._pending[0].total, b._pending[0].guard = snap.data_ptr(), n
+        b.learn()
+        for x, y, name in zip(out_a, out_b, ("actions", "obs", "reward", "done", "success")):
+            assert torch.equal(x, y), (k, name)
+        assert torch.equal(env_a._state_store, env_b._state_store) and torch.equal(rep_a.total, rep_b.total), k
+        np.testing.assert_array_equal(sorted_rows(rep_a), sorted_rows(rep_b), err_msg=f"step {k}: replay rows")
+        assert torch.equal(a._idx, b._idx) and torch.equal(a.rows, b.rows), k
+        np.testing.assert_allclose(a.losses_host(), b.losses_host(), rtol=1e-6, atol=1e-7, err_msg=f"step {k}")
+        for name in ("policy", "critic", "target_critic", "m_policy", "v_policy", "m_critic", "v_critic", "alpha_state"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (k, name)
+        i = a._idx.cpu().numpy()
+        m = 96 if esac else 128
+        assert len(set(i[:m])) == m and np.isin(i[:m], allowed_slots(tot0, cap, n)).all(), (k, tot0)
+    assert int(rep_a.total.item()) > cap
+
