@@ -25,6 +25,7 @@ done <<'CFGS'
 --dtype f32x9
 --no-front --dtype f32x9
 --agent sac --envs 16384 --scenario serpentine
+--agent sac --envs 16384 --scenario serpentine --no-front
 --envs 16384 --scenario mixed
 --envs 16384 --scenario mixed --dtype bf16
 --envs 16384 --scenario mixed --dtype bf16 --no-front
