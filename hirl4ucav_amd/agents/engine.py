@@ -309,7 +309,7 @@ class HirlEngine:
         self.soft_count = self.soft_count[:1]
         self.sample_calls = 0
         self._pending = None  # a draw sample(defer=True) recorded for the next learn()
-        # step_learn: hand-off words (flags int32[16], status int32[1]) + the epoch counter; two sets of minibatch tiles (the rest of learn() k still
+        # step_learn: hand-off words (flags int32[64], status int32[1]) + the epoch counter; two sets of minibatch tiles (the rest of learn() k still
         # reads set k while its first launch fills set k + 1 for the next front launch) and what the set in waiting was drawn for
         self._front = None
         self._front_epoch = 0
@@ -720,8 +720,8 @@ class HirlEngine:
         if self._pending is not None:
             raise _lib.HxError("step_learn draws its own minibatch: a sample(defer=True) is still pending")
         if self._front is None:
-            buf = torch.zeros(32, dtype=torch.int32, device=self.device)
-            self._front = (buf[0:16], buf[16:17])
+            buf = torch.zeros(96, dtype=torch.int32, device=self.device)
+            self._front = (buf[0:64], buf[64:65])
             second = torch.zeros(2 * B * 32 + 2 * B + 64, dtype=torch.float32, device=self.device)
             t2 = (second[:B * 32], second[B * 32:2 * B * 32], second[2 * B * 32:2 * B * 32 + B].view(torch.int32),
                   second[2 * B * 32 + B:2 * B * 32 + 2 * B].view(torch.int32), second[2 * B * 32 + 2 * B:2 * B * 32 + 2 * B + 4])
@@ -753,7 +753,7 @@ class HirlEngine:
         elif act_sigma > 0:
             mode = 3
         self.act_calls += 1
-        if self._front_epoch >= 400_000_000:  # the tiles' counters advance by 9 per launch: start over long before 32 bits run out (stream-ordered reset)
+        if self._front_epoch >= 200_000_000:  # the tiles' counters advance by up to 16 per launch: start over long before 32 bits run out (stream-ordered reset)
             flags.zero_()
             self._front_epoch = 0
         self._front_epoch += 1

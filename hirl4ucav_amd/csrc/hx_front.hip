@@ -18,7 +18,7 @@
 
 #include "hx_act_body.h"
 #include "hx_actp_body.h"
-#include "hx_fwd_body.h"
+#include "hx_bwd_body.h"
 
 using namespace hxnn;
 using namespace hxu;
@@ -33,6 +33,9 @@ struct FrontCtl {
     // them round by round (two jobs per round at B = 128); the launches' own order (A's jobs, then B's) is as good as any (tools/ubench/front_order.sh)
     unsigned char order[8];
     FrontSync sync;
+    // launch C (the critics' backward: bwd_l2_body<0, ..., 3>) as the LAST workgroups of the launch — n_fwd = per x (jobs of A and B) forward workgroups in
+    // front of them, c_per per TD job (0: launch C stays a launch of its own).  They wait in-launch for what they read (hx_bwd_body.h)
+    int n_fwd, c_per;
 };
 
 // Launch B runs in 64-column workgroups whatever its job count (a launch of its own takes 32-column workgroups for two nets: twice the workgroups,
@@ -44,7 +47,7 @@ struct FrontCtl {
 // acting workgroups are the launch's longest
 // BF16: the bf16 update path (HxNets.w2_bf16_all) with the bf16 acting kernel — both on v_mfma_f32_16x16x32_bf16, as their launches of their own
 template <bool RELU, bool X3, bool BF16 = false>
-__global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArgsC FA, FwdArgsC FB, FrontCtl C) {
+__global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArgsC FA, FwdArgsC FB, FrontCtl C, BwdArgsC GC) {
     static_assert(!(X3 && BF16), "one acting format");
     constexpr int BNT = kNT;
     typedef ActLds<2, true, BF16, !X3 && !BF16, X3> LdsAct;
@@ -54,6 +57,7 @@ __global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArg
         LdsAct act;
         LdsA a;
         LdsB b;
+        BwdLds<0, BF16> c;
     } u;
     int b = (int)blockIdx.x;
     if (b < C.n_act) {
@@ -61,6 +65,12 @@ __global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArg
         return;
     }
     b -= C.n_act;
+    if (b >= C.n_fwd) {
+        b -= C.n_fwd;
+        const int cj = b / C.c_per;
+        bwd_l2_body<0, RELU, BF16, 3>(GC, b - cj * C.c_per, cj, u.c, C.sync);
+        return;
+    }
     const int k = b / C.per, bx = b - k * C.per, job = C.order[k];
     if (job < 16) fwd_l2_body<kNT, RELU, false, BF16, 1>(FA, NoSample{}, bx, job, u.a, C.sync);
     else fwd_l2_body<BNT, RELU, false, BF16, 2>(FB, NoSample{}, bx, job - 16, u.b, C.sync);
@@ -70,12 +80,13 @@ __global__ __launch_bounds__(kWide) void act_front_kernel(ActFusedArgs H, FwdArg
 // workgroups of three 32-row tiles take 28.4 us against 25.5 on 256 workgroups of two (tools/ubench/actp_time.py with HX_ACT_PERSIST_WGS) — and the
 // update's workgroups run on the CUs that leaves free.  tiles: row tiles per acting workgroup.
 template <bool RELU>
-__global__ __launch_bounds__(kWide) void actp_front_kernel(ActFusedArgs H, FwdArgsC FA, FwdArgsC FB, FrontCtl C, int tiles) {
+__global__ __launch_bounds__(kWide) void actp_front_kernel(ActFusedArgs H, FwdArgsC FA, FwdArgsC FB, FrontCtl C, int tiles, BwdArgsC GC) {
     typedef ActpLds<true> LdsAct;
     typedef FwdLds<kNT, false, true> LdsF;
     __shared__ union {
         LdsAct act;
         LdsF f;
+        BwdLds<0, true> c;
     } u;
     int b = (int)blockIdx.x;
     if (b < C.n_act) {
@@ -83,6 +94,12 @@ __global__ __launch_bounds__(kWide) void actp_front_kernel(ActFusedArgs H, FwdAr
         return;
     }
     b -= C.n_act;
+    if (b >= C.n_fwd) {
+        b -= C.n_fwd;
+        const int cj = b / C.c_per;
+        bwd_l2_body<0, RELU, true, 3>(GC, b - cj * C.c_per, cj, u.c, C.sync);
+        return;
+    }
     const int k = b / C.per, bx = b - k * C.per, job = C.order[k];
     if (job < 16) fwd_l2_body<kNT, RELU, false, true, 1>(FA, NoSample{}, bx, job, u.f, C.sync);
     else fwd_l2_body<kNT, RELU, false, true, 2>(FB, NoSample{}, bx, job - 16, u.f, C.sync);
@@ -91,12 +108,13 @@ __global__ __launch_bounds__(kWide) void actp_front_kernel(ActFusedArgs H, FwdAr
 // fp32 in the exact-split format, 8,192 .. 12,288 envs: the acting role is the STREAMING persistent kernel of hx_actp.hip, one 64-row pass per workgroup — 128 to
 // 192 workgroups (37.6 us for a pass) and the rest of the CUs for the update; the per-tile role at 8,192 envs is 256 workgroups with no CU to spare (41.1 us)
 template <bool RELU>
-__global__ __launch_bounds__(kWide) void actps_front_kernel(ActFusedArgs H, FwdArgsC FA, FwdArgsC FB, FrontCtl C, int tiles) {
+__global__ __launch_bounds__(kWide) void actps_front_kernel(ActFusedArgs H, FwdArgsC FA, FwdArgsC FB, FrontCtl C, int tiles, BwdArgsC GC) {
     typedef ActpsLds<1, false, true> LdsAct;
     typedef FwdLds<kNT, false, false> LdsF;
     __shared__ union {
         LdsAct act;
         LdsF f;
+        BwdLds<0, false> c;
     } u;
     int b = (int)blockIdx.x;
     if (b < C.n_act) {
@@ -104,6 +122,12 @@ __global__ __launch_bounds__(kWide) void actps_front_kernel(ActFusedArgs H, FwdA
         return;
     }
     b -= C.n_act;
+    if (b >= C.n_fwd) {
+        b -= C.n_fwd;
+        const int cj = b / C.c_per;
+        bwd_l2_body<0, RELU, false, 3>(GC, b - cj * C.c_per, cj, u.c, C.sync);
+        return;
+    }
     const int k = b / C.per, bx = b - k * C.per, job = C.order[k];
     if (job < 16) fwd_l2_body<kNT, RELU, false, false, 1>(FA, NoSample{}, bx, job, u.f, C.sync);
     else fwd_l2_body<kNT, RELU, false, false, 2>(FB, NoSample{}, bx, job - 16, u.f, C.sync);
@@ -160,7 +184,7 @@ int launch_front_sac(const ActFusedArgs& H, const FwdArgs& FA, hipStream_t st) {
 
 int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, const uint16_t* w2b, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
                  const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward, uint8_t* done, int8_t* success,
-                 const HxStepOpts& o, const FwdArgs& FA, const FwdArgs& FB, const HxFront& front, hipStream_t st) {
+                 const HxStepOpts& o, const FwdArgs& FA, const FwdArgs& FB, const BwdArgs* GC, const HxFront& front, hipStream_t st) {
     HX_REQUIRE(actor && (w2f || w2x || w2b) && ((reinterpret_cast<uintptr_t>(w2f) | reinterpret_cast<uintptr_t>(w2x) | reinterpret_cast<uintptr_t>(w2b)) & 15u) == 0,
                "hx_hirl_front: the actor and a 16-byte aligned image of its W2 (HxNets.actor_w2_x9, actor_w2_f32i or actor_w2_bf16)");
     HX_REQUIRE(!w2b == !FA.images && FA.images == FB.images, "hx_hirl_front: the bf16 acting image goes with the bf16 update path (HxNets.w2_bf16_all), and only with it");
@@ -213,21 +237,33 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
     {   // a row tile's counter advances by (column workgroups of the target actor's job) + 1 per front launch
         const uint32_t per = (uint32_t)(H2 / kNT) + 1u;
         HX_REQUIRE(FB.job[0].act_mode == 1 && FB.job[0].prev.net == FA.job[0].net, "hx_hirl_front: launch B's first job feeds on launch A's first");
-        C.sync = FrontSync{front.flags, (front.epoch - 1u) * per + (per - 1u), front.epoch * per, front.status, FB.job[0].noise, FB.job[0].noise_clamp};
+        C.sync = FrontSync{front.flags, (front.epoch - 1u) * per + (per - 1u), front.epoch * per, front.status, FB.job[0].noise, FB.job[0].noise_clamp, 0u, 0u, 0u};
     }
     HX_REQUIRE(tiles <= 16, "hx_hirl_front: at most 16 row tiles (HxFront.flags)");
+    C.n_fwd = C.per * (FA.njobs + FB.njobs);
+    BwdArgsC CG{};
+    if (GC) {  // launch C rides too: its two TD jobs behind the forward workgroups, waiting for launch A's critic jobs (1, 2) and launch B's target critics (0, 1)
+        HX_REQUIRE(GC->njobs == 2 && GC->job[0].mode == BM_CRITIC_TD && GC->job[0].rows == rows && FA.job[1].ws.z2 == GC->job[0].ws.z2 && FA.job[2].ws.z2 == GC->job[1].ws.z2 &&
+                   FB.job[0].ws.z2 == GC->job[0].t1.ws.z2 && FB.job[1].ws.z2 == GC->job[0].t2.ws.z2, "hx_hirl_front: launch C's TD jobs read launch A's jobs 1, 2 and launch B's jobs 0, 1");
+        for (int j = 0; j < 2; ++j) CG.job[j] = pack_bwd(GC->job[j], *GC);
+        CG.images = GC->images; CG.rowmap = 1;
+        C.c_per = ((rows + RT / 2 - 1) / (RT / 2)) * kColWgB;
+        const uint32_t cw = (uint32_t)(H2 / kNT);
+        C.sync.with_c = 1u; C.sync.c_target = front.epoch * cw; C.sync.t_target = front.epoch * 2u * cw;
+    }
+    const unsigned n_c = GC ? 2u * (unsigned)C.c_per : 0u;
     const bool relu = slope == 0.0f;
     if (stream) {  // up to 16,384 envs one 64-row pass per acting workgroup (the CUs they leave serve the update beside them); beyond, passes over every CU and the
                    // update's workgroups behind them (two boundaries less)
         const int npass = (int)((n + 4 * RT - 1) / (4 * RT)), per_wg = (npass + 255) / 256;
         C.n_act = (npass + per_wg - 1) / per_wg;
-        const dim3 sgrid((unsigned)(C.n_act + C.per * (FA.njobs + FB.njobs)));
+        const dim3 sgrid((unsigned)(C.n_act + C.n_fwd) + n_c);
         if (o.ev_start && o.ev_stop) {
-            if (relu) hipExtLaunchKernelGGL((actps_front_kernel<true>), sgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, per_wg);
-            else hipExtLaunchKernelGGL((actps_front_kernel<false>), sgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, per_wg);
+            if (relu) hipExtLaunchKernelGGL((actps_front_kernel<true>), sgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, per_wg, CG);
+            else hipExtLaunchKernelGGL((actps_front_kernel<false>), sgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, per_wg, CG);
         } else {
-            if (relu) hipLaunchKernelGGL((actps_front_kernel<true>), sgrid, dim3(kWide), 0, st, H, CA, CB, C, per_wg);
-            else hipLaunchKernelGGL((actps_front_kernel<false>), sgrid, dim3(kWide), 0, st, H, CA, CB, C, per_wg);
+            if (relu) hipLaunchKernelGGL((actps_front_kernel<true>), sgrid, dim3(kWide), 0, st, H, CA, CB, C, per_wg, CG);
+            else hipLaunchKernelGGL((actps_front_kernel<false>), sgrid, dim3(kWide), 0, st, H, CA, CB, C, per_wg, CG);
         }
         HX_CHECK_LAUNCH("hx_hirl_front");
         return 0;
@@ -239,21 +275,21 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
         const int want = n <= 32768 ? 176 : wide_wgs;
         const int ntiles = (int)((n + 2 * RT - 1) / (2 * RT)), tiles_per_wg = (ntiles + want - 1) / want;
         C.n_act = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
-        const dim3 pgrid((unsigned)(C.n_act + C.per * (FA.njobs + FB.njobs)));
+        const dim3 pgrid((unsigned)(C.n_act + C.n_fwd) + n_c);
         if (o.ev_start && o.ev_stop) {
-            if (relu) hipExtLaunchKernelGGL((actp_front_kernel<true>), pgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, tiles_per_wg);
-            else hipExtLaunchKernelGGL((actp_front_kernel<false>), pgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, tiles_per_wg);
+            if (relu) hipExtLaunchKernelGGL((actp_front_kernel<true>), pgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, tiles_per_wg, CG);
+            else hipExtLaunchKernelGGL((actp_front_kernel<false>), pgrid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, tiles_per_wg, CG);
         } else {
-            if (relu) hipLaunchKernelGGL((actp_front_kernel<true>), pgrid, dim3(kWide), 0, st, H, CA, CB, C, tiles_per_wg);
-            else hipLaunchKernelGGL((actp_front_kernel<false>), pgrid, dim3(kWide), 0, st, H, CA, CB, C, tiles_per_wg);
+            if (relu) hipLaunchKernelGGL((actp_front_kernel<true>), pgrid, dim3(kWide), 0, st, H, CA, CB, C, tiles_per_wg, CG);
+            else hipLaunchKernelGGL((actp_front_kernel<false>), pgrid, dim3(kWide), 0, st, H, CA, CB, C, tiles_per_wg, CG);
         }
         HX_CHECK_LAUNCH("hx_hirl_front");
         return 0;
     }
-    const dim3 grid((unsigned)(C.n_act + C.per * (FA.njobs + FB.njobs)));
+    const dim3 grid((unsigned)(C.n_act + C.n_fwd) + n_c);
 #define HX_FRONT(RELU_, X3_, BF16_) do { \
-        if (o.ev_start && o.ev_stop) hipExtLaunchKernelGGL((act_front_kernel<RELU_, X3_, BF16_>), grid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C); \
-        else hipLaunchKernelGGL((act_front_kernel<RELU_, X3_, BF16_>), grid, dim3(kWide), 0, st, H, CA, CB, C); } while (0)
+        if (o.ev_start && o.ev_stop) hipExtLaunchKernelGGL((act_front_kernel<RELU_, X3_, BF16_>), grid, dim3(kWide), 0, st, (hipEvent_t)o.ev_start, (hipEvent_t)o.ev_stop, 0, H, CA, CB, C, CG); \
+        else hipLaunchKernelGGL((act_front_kernel<RELU_, X3_, BF16_>), grid, dim3(kWide), 0, st, H, CA, CB, C, CG); } while (0)
     if (w2b) { if (relu) HX_FRONT(true, false, true); else HX_FRONT(false, false, true); }
     else if (relu) { if (w2x) HX_FRONT(true, true, false); else HX_FRONT(true, false, false); }
     else { if (w2x) HX_FRONT(false, true, false); else HX_FRONT(false, false, false); }

@@ -86,6 +86,7 @@ struct FwdLds {
 //      workgroups then evaluates the net's head for the tile's 16 rows — tanh, smoothing noise, clamp: what every consumer workgroup of a launch of its own
 //      repeats for itself, 2.7 us of CU time each — writes the action rows and counts once more
 //   2  consumer: a job that feeds on the previous net's head waits (bounded) for the counter of its row tile and reads the action rows with agent-scope loads
+//   (3: hx_bwd_body.h — launch C's workgroups wait for the critic jobs of launch A and the target critics of launch B, which count themselves in too: with_c)
 struct FrontSync {
     unsigned* flags;   // [row tiles] monotonic counters: + 1 per column workgroup of the producer job, + 1 once the tile's action rows are written
     unsigned arrive;   // value a row tile's counter shows when the LAST column workgroup of the producer job has counted itself in
@@ -93,6 +94,10 @@ struct FrontSync {
     unsigned* status;  // sticky: bit 0 = a consumer gave up waiting
     const float* noise;  // [4] the call's target-smoothing draw (or null) and its clamp: applied by the producer's last column workgroup
     float noise_clamp;
+    // launch C (the critics' backward, hx_bwd_body.h) as further workgroups of the same launch: the critic jobs of launch A (jobs 1, 2) and the target
+    // critics of launch B (jobs 0, 1) then publish what C reads — z2 rows, z1, LN1 statistics — with agent-scope stores and count themselves in on
+    // flags[16 + 16 * (job - 1) + rt] / flags[48 + rt]; C's workgroups wait for c_target (one job's column workgroups) / t_target (both target jobs')
+    unsigned with_c, c_target, t_target;
 };
 template <int NT, bool RELU, bool SAMPLE, bool BF16, int FRONT, typename SAT>
 __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, const int bx, const int by, FwdLds<NT, SAMPLE, BF16>& SL, const FrontSync& X) {
@@ -273,13 +278,17 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
             if (BF16) h1b[row * LDB1 + u] = (__bf16)h;  // v_cvt_pk_bf16_f32: round to nearest even
             else h1s[row * LDA1 + u] = h;
             if (save && row < nrow) {
-                J.ws.z1[(size_t)(r0 + row) * H1 + u] = z1[r];
+                if (FRONT != 0 && X.with_c) st_agent(&J.ws.z1[(size_t)(r0 + row) * H1 + u], z1[r]);  // (launch C of the same launch reads z1 and st1)
+                else J.ws.z1[(size_t)(r0 + row) * H1 + u] = z1[r];
                 J.ws.h1[(size_t)(r0 + row) * H1 + u] = h;
             }
         }
         if (save) {
             if (tid < nrow * XP) J.ws.x[(size_t)r0 * XP + tid] = xs[tid];
-            if (tid < nrow * 2) J.ws.st1[(size_t)r0 * 2 + tid] = sts[tid];
+            if (tid < nrow * 2) {
+                if (FRONT != 0 && X.with_c) st_agent(&J.ws.st1[(size_t)r0 * 2 + tid], sts[tid]);
+                else J.ws.st1[(size_t)r0 * 2 + tid] = sts[tid];
+            }
         }
         if (!WIDE && !BF16) {
 #pragma unroll
@@ -343,7 +352,7 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
                     for (int k = 0; k < KS; k += 2 * w) part[k] += part[k + w];
                 const int row = 4 * g + q;
                 if (row < nrow) {
-                    if (FRONT == 1 && by == 0) st_agent(&J.ws.z2[(size_t)(r0 + row) * H2 + n0 + r], part[0] + bias);
+                    if ((FRONT == 1 && by == 0) || (FRONT != 0 && X.with_c)) st_agent(&J.ws.z2[(size_t)(r0 + row) * H2 + n0 + r], part[0] + bias);
                     else J.ws.z2[(size_t)(r0 + row) * H2 + n0 + r] = part[0] + bias;
                 }
             }
@@ -371,6 +380,19 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
                 }
                 if (tid < 4 && SA.noise) SA.noise[tid] = smoothing_noise(SA, tid);  // the (4,) target-smoothing draw, HIRL.py:265
             }
+        }
+    }
+    if constexpr (FRONT == 1) {
+        if (bx == 0 && by == 0) {  // the accumulators launch C adds to are cleared BEFORE this workgroup counts itself in (C waits for row tile 0's counter too)
+            if ((int)threadIdx.x < A.zero_nf) st_agent(&A.zero_f[threadIdx.x], 0.0f);
+            if (threadIdx.x == 0 && A.zero_i) *A.zero_i = 0;
+        }
+    }
+    if constexpr (FRONT == 1 || FRONT == 2) {
+        if (X.with_c && ((FRONT == 1 && (by == 1 || by == 2)) || (FRONT == 2 && by < 2))) {  // read by launch C of this launch: count in once the rows have left the CU
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(&X.flags[(FRONT == 1 ? 16 * by : 48) + rt], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if constexpr (FRONT == 1) {
@@ -407,7 +429,7 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
         }
     }
     // accumulators of LATER launches are cleared here, at the end: their kernel-argument words are off every workgroup's critical path
-    if (bx == 0 && by == 0) {
+    if (FRONT != 1 && bx == 0 && by == 0) {
         if ((int)threadIdx.x < A.zero_nf) A.zero_f[threadIdx.x] = 0.0f;
         if (threadIdx.x == 0 && A.zero_i) *A.zero_i = 0;
     }

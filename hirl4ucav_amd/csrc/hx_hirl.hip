@@ -102,10 +102,8 @@ static void make_launch_b(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy,
     }
     F.images = N->w2_bf16_all;
 }
-// launches C and D: y, loss, dq, LN2 backward, dh1 for both heads; all critic parameter gradients.
-// adam_step > 0: the critic's optimizer step (and, with polyak, the soft_update of its target) rides in the wgrad launch
-static int critic_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, void* stream, int adam_step, bool polyak, const SampleDev* predraw = nullptr) {
-    hipStream_t st = (hipStream_t)stream;
+// launch C: y, loss, dq, LN2 backward, dh1 for both heads
+static void make_launch_c(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, BwdArgs& G) {
     const Mlp mQ{17, 1, Hy->no_layernorm ? 1 : 0};
     const int B = Bt->batch;
     Slot s[S_COUNT];
@@ -113,17 +111,38 @@ static int critic_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, vo
     const RowSrc src{Bt->rows, nullptr, nullptr, 0, 32};
     const float* tc1 = N->target_critic;
     const float* tc2 = N->target_critic + mQ.padded();
-    {   // launch C: y, loss, dq, LN2 backward, dh1 for both heads
-        BwdArgs G{};
-        G.njobs = 2; G.slope = Hy->slope; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = N->soft_count;
-        for (int h = 0; h < 2; ++h) {
-            BwdJob& J = G.job[h];
-            J = BwdJob{};
-            J.net = N->critic + h * mQ.padded(); J.m = mQ; J.ws = s[S_C1 + h]; J.rows = B; J.mode = BM_CRITIC_TD;
-            J.t1 = Head{tc1, mQ, s[S_TC1]}; J.t2 = Head{tc2, mQ, s[S_TC2]}; J.src = src; J.gamma = Hy->gamma;
-            J.img_t = IM_C1_T + h;
-        }
-        G.images = N->w2_bf16_all;
+    G = BwdArgs{};
+    G.njobs = 2; G.slope = Hy->slope; G.inv_batch = 1.0f / B; G.losses = N->losses; G.soft_count = N->soft_count;
+    for (int h = 0; h < 2; ++h) {
+        BwdJob& J = G.job[h];
+        J = BwdJob{};
+        J.net = N->critic + h * mQ.padded(); J.m = mQ; J.ws = s[S_C1 + h]; J.rows = B; J.mode = BM_CRITIC_TD;
+        J.t1 = Head{tc1, mQ, s[S_TC1]}; J.t2 = Head{tc2, mQ, s[S_TC2]}; J.src = src; J.gamma = Hy->gamma;
+        J.img_t = IM_C1_T + h;
+    }
+    G.images = N->w2_bf16_all;
+}
+// HX_FRONT_C=1 (tuning knob, read once; hx_hirl_front and the calls behind it read it alike): the front launch carries launch C too, its workgroups
+// waiting in-launch for launches A and B (hx_bwd_body.h).  Bit-identical (tests/test_front_gpu.py) and measured (tools/ubench/front_c_ab.sh,
+// profiles/r04c_front_c_ab.txt): a gain only where the acting workgroups leave the other CUs slack — 8,192 envs fp32, streaming acting role: 67.0 -> 64.7 us
+// per step; 4,096 envs fp32 54.1 -> 56.6, bf16 45.6 -> 49.8, 131,072 envs bf16 133.1 -> 136.4 — the workgroups of C cost 7.6 us instead of 5.9 (their
+// rows are asked for behind the wait, not at entry) and the CUs of the shadow have no time to spare.  Off by default.
+static bool front_has_c() {
+    static const bool on = getenv("HX_FRONT_C") && atoi(getenv("HX_FRONT_C")) != 0;
+    return on;
+}
+// launches C and D: y, loss, dq, LN2 backward, dh1 for both heads; all critic parameter gradients.
+// adam_step > 0: the critic's optimizer step (and, with polyak, the soft_update of its target) rides in the wgrad launch
+// skip_c: launch C ran inside the front launch
+static int critic_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, void* stream, int adam_step, bool polyak, const SampleDev* predraw = nullptr, bool skip_c = false) {
+    hipStream_t st = (hipStream_t)stream;
+    const Mlp mQ{17, 1, Hy->no_layernorm ? 1 : 0};
+    const int B = Bt->batch;
+    Slot s[S_COUNT];
+    make_slots(N, B, s);
+    if (!skip_c) {
+        BwdArgs G;
+        make_launch_c(N, Bt, Hy, G);
         launch_bwd(0, G, st);
     }
     {   // launch D: all critic parameter gradients
@@ -367,8 +386,10 @@ int hx_hirl_front(float* state, int64_t n, int64_t stride, float* obs_io, float*
     const bool x9 = !bf16 && (noise_mode & 32) != 0;  // + 32: the exact-split acting format (HxNets.actor_w2_x9), else fp32 MFMA from HxNets.actor_w2_f32i
     HX_REQUIRE(bf16 || (x9 ? N->actor_w2_x9 != nullptr : N->actor_w2_f32i != nullptr), "hx_hirl_front: the image of the chosen acting format is missing from HxNets");
     noise_mode &= ~32;
+    BwdArgs GC;
+    if (front_has_c()) make_launch_c(N, Bt, Hy, GC);
     return launch_front(N->actor, (x9 || bf16) ? nullptr : N->actor_w2_f32i, x9 ? N->actor_w2_x9 : nullptr, bf16 ? N->actor_w2_bf16 : nullptr, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed,
-                        row0, call, Hy->slope, reward, done, success, *opts, FA, FB, *front, (hipStream_t)stream);
+                        row0, call, Hy->slope, reward, done, success, *opts, FA, FB, front_has_c() ? &GC : nullptr, *front, (hipStream_t)stream);
 }
 // the predraw of hx_hirl_learn_back / hx_hirl_critic_grads_back as a device-side description (nothing is launched here)
 static int make_predraw(const HxNets* N, const HxBatch* Bt, const HxSample* next, const HxBatch* next_tiles, void* stream, SampleDev* SD) {
@@ -386,7 +407,7 @@ int hx_hirl_critic_grads_back(const HxNets* N, const HxBatch* Bt, const HxHyper*
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_critic_grads_back: batch must be a positive multiple of 16");
     SampleDev SD{};
     if (next) if (int rc = make_predraw(N, Bt, next, next_tiles, stream, &SD)) return rc;
-    return critic_back(N, Bt, Hy, stream, 0, false, next ? &SD : nullptr);
+    return critic_back(N, Bt, Hy, stream, 0, false, next ? &SD : nullptr, front_has_c());
 }
 int hx_hirl_learn_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t critic_step, int32_t actor_phase, int32_t actor_step, int32_t do_polyak,
                        int32_t w_kind, float w_given, float warm, const HxSample* next, const HxBatch* next_tiles, void* stream) {
@@ -394,7 +415,7 @@ int hx_hirl_learn_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, in
     HX_REQUIRE(critic_step >= 1 && (!actor_phase || actor_step >= 1), "hx_hirl_learn_back: Adam steps are 1-based");
     SampleDev SD{};
     if (next) if (int rc = make_predraw(N, Bt, next, next_tiles, stream, &SD)) return rc;
-    int rc = critic_back(N, Bt, Hy, stream, critic_step, do_polyak != 0, next ? &SD : nullptr);
+    int rc = critic_back(N, Bt, Hy, stream, critic_step, do_polyak != 0, next ? &SD : nullptr, front_has_c());
     if (rc || !actor_phase) return rc;
     if ((rc = hx_hirl_actor_backward(N, Bt, Hy, w_kind == 1, 1, stream))) return rc;
     return actor_wgrad_impl(N, Hy, Bt->batch, Bt->batch, w_kind, w_given, warm, stream, actor_step, do_polyak != 0);

@@ -741,7 +741,7 @@ void launch_bwd(int grp, const BwdArgs& G, hipStream_t st);                 // h
 // hx_front.hip: the act + env + insert workgroups of hx_actor_act_step_f32i (32 rows each) and the workgroups of launches A and B as ONE launch
 int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, const uint16_t* w2b, float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
                  const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float slope, float* reward, uint8_t* done, int8_t* success,
-                 const HxStepOpts& o, const FwdArgs& FA, const FwdArgs& FB, const HxFront& front, hipStream_t st);
+                 const HxStepOpts& o, const FwdArgs& FA, const FwdArgs& FB, const BwdArgs* GC, const HxFront& front, hipStream_t st);
 void launch_wg(const WgArgs& W, bool adam, hipStream_t st);                 // hx_wgrad.hip: adam = the optimizer step rides in the launch
 void launch_adam(const AdamArgs& A, hipStream_t st);                        // hx_wgrad.hip
 void launch_polyak(float* target, const float* source, int n, float tau, float* target2, const float* source2, int n2, hipStream_t st,

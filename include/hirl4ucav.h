@@ -72,7 +72,7 @@ const char* hx_last_error(void);
 /* HX_ABI_VERSION of the library that is loaded.  The structs below are part of the ABI: a caller built against another header version must
  * not call in (round 3 widened HxStepOpts.stats from 9 to HX_STAT_WAYS * HX_STAT_PITCH words and appended fields to HxNets / HxHyper without
  * bumping this: a 9-word stats buffer then took atomics up to word 504).  110: round 4 (hx_abi_sizes, hx_rccl_*, hx_allreduce_twostage). */
-#define HX_ABI_VERSION 111
+#define HX_ABI_VERSION 112
 int hx_version(void);
 /* sizes[0..7] (host) <- sizeof HxStepOpts, HxNets, HxHyper, HxBatch, HxSample, HxSacNets, HxSacBatch, and the words of a statistics buffer
  * (HX_STAT_WAYS * HX_STAT_PITCH): a binding checks these against its own declarations at load time (hirl4ucav_amd/_lib.py does). */
@@ -364,7 +364,7 @@ int hx_hirl_learn_sampled(const HxNets* nets, const HxBatch* batch, const HxHype
  * (or NULL): the draw of the NEXT front launch (guard = its n; *next->total is read inside this call's second launch, i.e. after this step's
  * inserts and before the next step's) into tiles of their own. */
 typedef struct HxFront {
-    uint32_t* flags;       /* [16] device words, zero before the first use */
+    uint32_t* flags;       /* [64] device words, zero before the first use (and whenever epoch starts over at 1) */
     uint32_t* status;      /* device word, sticky */
     uint32_t epoch;        /* 1, 2, 3, ... : one per front launch on these flags */
 } HxFront;

@@ -329,3 +329,26 @@ def test_sac_front_launch_equals_act_step_then_guarded_learn(n, cap, esac):
         assert len(set(i[:m])) == m and np.isin(i[:m], allowed_slots(tot0, cap, n)).all(), (k, tot0)
     assert int(rep_a.total.item()) > cap
 
+
+
+@pytest.mark.gpu
+def test_launch_c_inside_the_front_launch_is_bit_identical():
+    """HX_FRONT_C=1 (tuning knob, read once per process: hence the child): launch C — the critics' backward — rides in the front launch, its workgroups
+    waiting in-launch for launches A and B (hx_bwd_body.h, FRONT == 3).  The same parity statement must hold for every acting role, one-call and staged."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from hirl4ucav_amd.agents import engine\n"
+            "from tests import test_front_gpu as T\n"
+            "fn = T.test_front_launch_equals_act_step_then_guarded_learn\n"
+            "for case in [(True, 0.0, 4096, 10000, 'f32x9', False), (False, 0.01, 576, 1400, 'f32', False), (True, 0.0, 1024, 2600, 'f32', True),\n"
+            "             (True, 0.0, 4096, 10000, 'bf16', False), (False, 0.01, 12000, 30000, 'bf16', True), (True, 0.0, 8192, 20000, 'f32x9', False),\n"
+            "             (True, 0.0, 40000, 90000, 'bf16', False)]:\n"
+            "    fn(engine, *case)\n"
+            "print('front-c ok')\n") % root
+    env = dict(os.environ, HX_FRONT_C="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "front-c ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
