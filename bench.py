@@ -956,11 +956,9 @@ def run_rank(args):
             fused_pmc = profile_traffic(f"front_{args.envs}") if args.dtype == "f32" else None
         fp32_equiv = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
         # which matrix-core instruction the 256 -> 512 product runs on: fp32 MFMA; bf16 MFMA; or — the fp32 HIRL policy from 16,384 rows on, and
-        # --dtype f32x9 at every size — NINE bf16 MFMAs per fp32 product (the exact hi | mid | lo split): priced as executed bf16 FLOPs against the bf16 peak
+        # --dtype f32x9 at every size — NINE bf16 MFMAs per fp32 product (the exact hi | mid | lo split): `roofline.executed` prices those against the bf16 peak
         x9 = args.agent == "hirl" and (args.dtype == "f32x9" or (args.dtype == "f32" and (args.envs >= 16384 or (loop.front and loop.eng.front_x9))))
-        if x9:
-            flop, peak = fp32_equiv + 8 * 2 * 256 * 512 * args.envs, BF16_MATRIX_PEAK_TFLOPS
-        elif args.dtype in ("f32", "f32x9") or args.agent == "sac":
+        if args.dtype in ("f32", "f32x9") or args.agent == "sac":  # ALGORITHMIC FLOPs against the dense matrix peak of the dtype the path computes in
             flop, peak = fp32_equiv, FP32_MATRIX_PEAK_TFLOPS
         else:
             flop, peak = fp32_equiv, BF16_MATRIX_PEAK_TFLOPS
@@ -970,9 +968,13 @@ def run_rank(args):
         mf, hf = tf / peak, gb / HBM_PEAK_GBPS
         hbm = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hf, 4), "bytes_per_launch": ENV_BYTES_FUSED * args.envs}
         mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(mf, 4), "flop_per_launch": flop}
-        if x9:
-            mfma["note"] = ("executed FLOPs: the fp32 product as 9 bf16 MFMAs per 32 k (exact split, fp32 accumulate); fp32-equivalent "
-                            f"{round(fp32_equiv / us / 1e6, 2)} TFLOP/s = {round(fp32_equiv / us / 1e6 / FP32_MATRIX_PEAK_TFLOPS, 3)} of the fp32-MFMA peak")
+        if x9:  # the fp32 product runs as 9 bf16 MFMAs per 32 k (exact split, fp32 accumulate): what the matrix cores EXECUTE, against their bf16 peak
+            ex = flop + 8 * 2 * 256 * 512 * args.envs
+            mfma["executed"] = {"what": "the acting workgroups' 256 -> 512 product as NINE bf16 MFMAs per fp32 product (exact hi | mid | lo split): executed FLOPs against the bf16 "
+                                        "dense peak — the matrix cores' utilisation; `achieved` above is the fp32 arithmetic the launch delivers, which the split lets exceed "
+                                        "what v_mfma_f32_16x16x4_f32 could (peak 157.3)",
+                                "flop_per_launch": ex, "achieved": round(ex / us / 1e6, 2), "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(ex / us / 1e6 / BF16_MATRIX_PEAK_TFLOPS, 4)}
         first, second = (mfma, hbm) if mf >= hf else (hbm, mfma)
         persistent = args.envs > 8192
         front_name = None
