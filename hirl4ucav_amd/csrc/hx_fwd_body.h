@@ -150,6 +150,8 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
     const float4 wv0 = tid < n4 ? W1v[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 wv1 = tid + kWide < n4 ? W1v[tid + kWide] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float bias1 = J.net[J.m.b1() + u], g1v = J.net[J.m.g1() + u], be1v = J.net[J.m.be1() + u];
+    // b2 of this wave's column of the z2 tile: asked for HERE — behind the MFMA phase's barrier the load stood alone in front of the tile's stores
+    const float bias2 = J.net[J.m.b2() + nt * NTW + (WIDE ? wave * 16 : (wave % CT) * 16) + (lane & 15)];
     // 1. input tile xs[16][XP]: thread -> (row, column); columns 13..16 carry the action of a 17-wide net, the rest is zero
     const int xr = tid / XP, xc = tid % XP;
     const bool head_mode = in == 17 && J.act_mode != 0 && J.act_mode != 3;
@@ -308,7 +310,7 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
         } else {
             acc = tile_a_lds_bt_global<H1>(h1s, LDA1, J.net + J.m.W2() + (size_t)(n0 + r) * H1, acc);
         }
-        const float bias = J.net[J.m.b2() + n0 + r];
+        const float bias = bias2;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = 4 * g + q;
@@ -339,7 +341,7 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
         if (kq) *reinterpret_cast<float4*>(kred + (((kq - 1) * CT + ct) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         __syncthreads();
         if (kq == 0) {
-            const float bias = J.net[J.m.b2() + n0 + r];
+            const float bias = bias2;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float part[KS];  // fixed-order tree over the K-parts
