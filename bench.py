@@ -377,7 +377,9 @@ def host_cpu():
 
 
 def best_torch_threads(step, cores):
-    """torch's intra-op thread count that makes `step()` (one actor forward for all envs + one learn at B = 128) fastest on this host: the
+    """torch's intra-op thread count that makes `step()` (ONE WHOLE vector step of the loop: actor forward for all envs, the env step on its worker
+    threads, one learn at B = 128 — calibrated on the torch part alone, a box once chose 64 threads that then ran the loop 5x slower beside the 16 env
+    threads) fastest on this host: the
     default (one thread per physical core: 128 on the GPU boxes) is thread-oversubscribed for a 128-row MLP and reads 3-10x too slow — the CPU
     figure is reported at its best, not at its worst.  -> (threads, {threads: seconds per step})"""
     import torch
@@ -387,9 +389,9 @@ def best_torch_threads(step, cores):
         torch.set_num_threads(t)
         step()  # warm
         t0 = time.perf_counter()
-        step()
-        step()
-        tried[t] = round((time.perf_counter() - t0) / 2, 5)
+        for _ in range(4):
+            step()
+        tried[t] = round((time.perf_counter() - t0) / 4, 5)
     best = min(tried, key=tried.get)
     torch.set_num_threads(best)
     return best, tried
@@ -424,23 +426,24 @@ def baseline_port(args, seconds):
         ox.step_batch(envs[lo:hi], a[lo:hi], obs[lo:hi], max_step=1500, auto_reset=1, randomize=1, seed=0, env_id0=lo, episode_ctr=epi[lo:hi],
                       ring=rings[k], total=totals[k])
 
-    def torch_part():  # what runs on torch's threads in one vector step (the env step runs on the worker threads)
-        o.choose_action(obs, rng.normal(0, 0.1, (n, 4)).astype(np.float32))
-        rows = rings[0][rng.integers(0, 1, args.batch)]
-        ibc = rng.integers(0, es.shape[0], args.batch)
-        o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), (es[ibc], ea[ibc]), rng.normal(0, 0.2, 4).astype(np.float32), 0.5, 0.0)
+    count = [0]
 
-    torch_threads, tried = best_torch_threads(torch_part, cores)
-    steps, t0 = 0, time.perf_counter()
-    while True:
+    def loop_step():
+        k = count[0]
         a = o.choose_action(obs, rng.normal(0, 0.1, (n, 4)).astype(np.float32))
-        list(pool.map(lambda k: work(k, a), range(len(chunks))))
-        ring = rings[steps % len(rings)]
-        m = max(min(int(totals[steps % len(rings)][0]), cap), 1)
+        list(pool.map(lambda j: work(j, a), range(len(chunks))))
+        ring = rings[k % len(rings)]
+        m = max(min(int(totals[k % len(rings)][0]), cap), 1)
         rows = ring[rng.integers(0, m, args.batch)]
         ibc = rng.integers(0, es.shape[0], args.batch)
         o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), (es[ibc], ea[ibc]),
-                rng.normal(0, 0.2, 4).astype(np.float32), 100 if steps == 0 else o.bc_weight, 0.0)
+                rng.normal(0, 0.2, 4).astype(np.float32), 100 if k == 0 else o.bc_weight, 0.0)
+        count[0] = k + 1
+
+    torch_threads, tried = best_torch_threads(loop_step, cores)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        loop_step()
         steps += 1
         dt = time.perf_counter() - t0
         if dt > seconds or steps >= 2000:
@@ -448,7 +451,7 @@ def baseline_port(args, seconds):
     pool.shutdown()
     return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": cores, "kind": "port",
             "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s: oracle C env step on {len(chunks)} threads + torch-CPU actor forward and "
-                      f"HIRL learn on {torch_threads} threads (the fastest of {sorted(tried)}: seconds per torch part {tried})",
+                      f"HIRL learn on {torch_threads} threads (the fastest of {sorted(tried)}: seconds per vector step {tried})",
             "threads": {"env_step": len(chunks), "torch": torch_threads, "torch_tried_s_per_step": tried, "logical_cores": cores},
             "update_steps_per_s": round(steps / dt, 2)}
 
@@ -481,22 +484,23 @@ def baseline_port_sac(args, seconds):
         ox.step_batch(envs[lo:hi], a[lo:hi], obs[lo:hi], max_step=1500, auto_reset=1, randomize=1, seed=0, env_id0=lo, episode_ctr=epi[lo:hi],
                       ring=rings[k], total=totals[k])
 
-    def torch_part():
-        o.explore(obs, rng.normal(0, 1, (n, 4)).astype(np.float32))
-        rows = rings[0][rng.integers(0, 1, args.batch)]
-        o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 30], rows[:, 17:30], rows[:, 31]), rng.normal(0, 1, (args.batch, 4)).astype(np.float32),
-                rng.normal(0, 1, (args.batch, 4)).astype(np.float32))
+    count = [0]
 
-    torch_threads, tried = best_torch_threads(torch_part, cores)
-    steps, t0 = 0, time.perf_counter()
-    while True:
+    def loop_step():
+        k = count[0]
         a = o.explore(obs, rng.normal(0, 1, (n, 4)).astype(np.float32)).astype(np.float32)
-        list(pool.map(lambda k: work(k, a), range(len(chunks))))
-        ring = rings[steps % len(rings)]
-        m = max(min(int(totals[steps % len(rings)][0]), cap), 1)
+        list(pool.map(lambda j: work(j, a), range(len(chunks))))
+        ring = rings[k % len(rings)]
+        m = max(min(int(totals[k % len(rings)][0]), cap), 1)
         rows = ring[rng.integers(0, m, args.batch)]
         o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 30], rows[:, 17:30], rows[:, 31]), rng.normal(0, 1, (args.batch, 4)).astype(np.float32),
                 rng.normal(0, 1, (args.batch, 4)).astype(np.float32))
+        count[0] = k + 1
+
+    torch_threads, tried = best_torch_threads(loop_step, cores)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        loop_step()
         steps += 1
         dt = time.perf_counter() - t0
         if dt > seconds or steps >= 2000:
@@ -504,7 +508,7 @@ def baseline_port_sac(args, seconds):
     pool.shutdown()
     return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": cores, "kind": "port",
             "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s: oracle C env step on {len(chunks)} threads + torch-CPU SAC explore and "
-                      f"learn on {torch_threads} threads (the fastest of {sorted(tried)}: seconds per torch part {tried})",
+                      f"learn on {torch_threads} threads (the fastest of {sorted(tried)}: seconds per vector step {tried})",
             "threads": {"env_step": len(chunks), "torch": torch_threads, "torch_tried_s_per_step": tried, "logical_cores": cores},
             "update_steps_per_s": round(steps / dt, 2)}
 
