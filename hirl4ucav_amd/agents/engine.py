@@ -32,7 +32,7 @@ class HxSample(ctypes.Structure):
 
 class HxFront(ctypes.Structure):
     """in-launch hand-off state of the front launch (include/hirl4ucav.h HxFront)"""
-    _fields_ = [("flags", _vp), ("status", _vp), ("epoch", ctypes.c_uint32)]
+    _fields_ = [("flags", _vp), ("status", _vp), ("epoch", ctypes.c_uint32), ("with_c", ctypes.c_uint32)]
 
 
 class HxNets(ctypes.Structure):
@@ -220,8 +220,8 @@ _lib.register("hx_hirl_learn", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32
 _lib.register("hx_hirl_learn_sampled", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp])
 _lib.register("hx_hirl_front", [_vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i32, _vp, _f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, _vp,
                                  _P(_lib.HxStepOpts), _P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _P(HxFront), _vp])
-_lib.register("hx_hirl_learn_back", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _P(HxSample), _P(HxBatch), _vp])
-_lib.register("hx_hirl_critic_grads_back", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _P(HxBatch), _vp])
+_lib.register("hx_hirl_learn_back", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _P(HxSample), _P(HxBatch), _i32, _vp])
+_lib.register("hx_hirl_critic_grads_back", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _P(HxBatch), _i32, _vp])
 _lib.register("hx_sample_batch_guarded", [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _i32, _i32, _i32, ctypes.c_uint64,
                                            ctypes.c_uint32, _f32, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint32, _vp])
 _lib.register("hx_hirl_critic_grads_sampled", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _i32, _vp])
@@ -311,8 +311,10 @@ class HirlEngine:
         self._pending = None  # a draw sample(defer=True) recorded for the next learn()
         # step_learn: hand-off words (flags int32[64], status int32[1]) + the epoch counter; two sets of minibatch tiles (the rest of learn() k still
         # reads set k while its first launch fills set k + 1 for the next front launch) and what the set in waiting was drawn for
+        self.front_c = "auto"  # launch C inside the front launch: front_c_for()
         self._front = None
         self._front_epoch = 0
+        self._front_c_epoch = 0  # front launches that carried launch C (their counters advance only then)
         self._front_tiles = None
         self._front_drawn = None
         self.nets = HxNets(*(t.data_ptr() for t in (self.actor, self.critic, self.target_actor, self.target_critic, self.bc_actor,
@@ -755,9 +757,8 @@ class HirlEngine:
         self.act_calls += 1
         if self._front_epoch >= 200_000_000:  # the tiles' counters advance by up to 16 per launch: start over long before 32 bits run out (stream-ordered reset)
             flags.zero_()
-            self._front_epoch = 0
+            self._front_epoch = self._front_c_epoch = 0
         self._front_epoch += 1
-        front = HxFront(flags.data_ptr(), status.data_ptr(), self._front_epoch)
         batch, nets, hyper, st = tiles_of(cur), ctypes.byref(self.nets), ctypes.byref(self.hyper), _lib.stream_ptr()
         if bc_weight_now is None:
             w_kind, w_given = 2, 0.0
@@ -771,6 +772,12 @@ class HirlEngine:
             self.actor_step += 1
             self.update_count += 1
         do_polyak = actor_phase and self.update_count % self.target_update_freq == 0  # HIRL.py:327-330
+        with_c = int(self.front_c_for(n, actor_phase, w_kind, bf16))
+        knob = os.environ.get("HX_FRONT_C")  # (the library's A/B knob overrides the caller both ways; forced in, launch C needs its count as well)
+        carries_c = knob == "1" or (bool(with_c) and knob != "0")
+        if carries_c:
+            self._front_c_epoch += 1  # the counters of launch C's producers advance only in launches that carry it
+        front = HxFront(flags.data_ptr(), status.data_ptr(), self._front_epoch, self._front_c_epoch if carries_c else 0)
         _lib.call("hx_hirl_front", env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(), out.data_ptr(), mode | self._mode_bits | (32 if (not bf16 and self._x9_for(n, front=True)) else 0),
                   _lib.ptr(act_noise), float(act_sigma), int(act_seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(), env.done.data_ptr(),
                   env.success.data_ptr(), ctypes.byref(env._opts), nets, ctypes.byref(batch), hyper, int(actor_phase), w_kind, ctypes.byref(front), st)
@@ -778,15 +785,32 @@ class HirlEngine:
         nxt_draw, nxt_tiles = draw(nxt, self.sample_calls + 1), tiles_of(nxt)
         if not self.staged:
             _lib.call("hx_hirl_learn_back", nets, ctypes.byref(batch), hyper, self.critic_step, int(actor_phase), self.actor_step, int(do_polyak), w_kind, w_given,
-                      float(bc_warm_up_weight), ctypes.byref(nxt_draw), ctypes.byref(nxt_tiles), st)
+                      float(bc_warm_up_weight), ctypes.byref(nxt_draw), ctypes.byref(nxt_tiles), with_c, st)
         else:  # a sharded rank: the same front launch (every rank draws from its own ring), then the stages with the exchanges in between
-            self._learn_staged(lambda: _lib.call("hx_hirl_critic_grads_back", nets, ctypes.byref(batch), hyper, ctypes.byref(nxt_draw), ctypes.byref(nxt_tiles), st),
+            self._learn_staged(lambda: _lib.call("hx_hirl_critic_grads_back", nets, ctypes.byref(batch), hyper, ctypes.byref(nxt_draw), ctypes.byref(nxt_tiles), with_c, st),
                                batch, actor_phase, do_polyak, w_kind, w_given, bc_warm_up_weight)
         self._front_drawn = (env, env.steps_issued, replay, expert, bc_table, n_main, int(sample_seed), float(smooth_sigma), self.sample_calls + 1, n)
         self._front_tiles = [nxt, cur]
         self.rows, self.bc_rows, self._idx, self._idx_bc, self._noise = cur  # what this call's learn() read (the attribute names sample() / learn() use)
         self.actor_trainable = not self.actor_trainable  # HIRL.py:332
         return out, env.obs, env.reward, env.done, env.success
+
+    def front_c_for(self, n, actor_phase, w_kind, bf16):
+        """Does launch C (the critics' backward) ride in the front launch of this call too (HxFront.with_c)?  `front_c`: True / False, or "auto" (default):
+        only where the acting workgroups leave the other CUs more time than the update's workgroups need — CU time bounds the front launch
+        (profiles/r04c_front_c_ab.txt).  That is the STREAMING acting role (fp32 in the exact-split format, 8,192 .. 16,384 envs: one 64-row pass of ~37 us
+        per acting workgroup) with few enough acting workgroups: forward workgroups cost ~6 us of a CU each, launch C's 7.6 (their rows are asked for
+        behind the in-launch wait).  Around 8,192 envs: 67.1 -> 62.2 us per step; everywhere else it is slower (4,096 envs 54.1 -> 56.6 us), hence off."""
+        if self.front_c != "auto":
+            return bool(self.front_c)
+        if bf16 or not self._x9_for(n, front=True) or n < 8192 or n > 16384:
+            return False
+        acting = (n + 63) // 64
+        # (the job count of an ACTOR call whatever this call is: on for critic-only calls alone it was measured neutral, 8,704 .. 11,264 envs)
+        jobs = (3 + 2) + (1 + (0 if not self.use_bc else (2 if w_kind == 1 else 1)))
+        tiles = (self.batch + 15) // 16
+        need = jobs * tiles * 8 * 6.0 + 2 * ((self.batch + 7) // 8) * 8 * 7.6
+        return (256 - acting) * 37.0 >= need
 
     def front_check(self):
         """Raise if a workgroup of a front launch ever gave up waiting for its producers (synchronises)."""

@@ -249,7 +249,8 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
         CG.images = GC->images; CG.rowmap = 1;
         C.c_per = ((rows + RT / 2 - 1) / (RT / 2)) * kColWgB;
         const uint32_t cw = (uint32_t)(H2 / kNT);
-        C.sync.with_c = 1u; C.sync.c_target = front.epoch * cw; C.sync.t_target = front.epoch * 2u * cw;
+        HX_REQUIRE(front.with_c >= 1u, "hx_hirl_front: HxFront.with_c counts the front launches that carry launch C (1, 2, ...)");
+        C.sync.with_c = 1u; C.sync.c_target = front.with_c * cw; C.sync.t_target = front.with_c * 2u * cw;  // (their counters advance only in launches with C)
     }
     const unsigned n_c = GC ? 2u * (unsigned)C.c_per : 0u;
     const bool relu = slope == 0.0f;

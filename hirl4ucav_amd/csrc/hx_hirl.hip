@@ -122,14 +122,14 @@ static void make_launch_c(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy,
     }
     G.images = N->w2_bf16_all;
 }
-// HX_FRONT_C=1 (tuning knob, read once; hx_hirl_front and the calls behind it read it alike): the front launch carries launch C too, its workgroups
-// waiting in-launch for launches A and B (hx_bwd_body.h).  Bit-identical (tests/test_front_gpu.py) and measured (tools/ubench/front_c_ab.sh,
-// profiles/r04c_front_c_ab.txt): a gain only where the acting workgroups leave the other CUs slack — 8,192 envs fp32, streaming acting role: 67.0 -> 64.7 us
-// per step; 4,096 envs fp32 54.1 -> 56.6, bf16 45.6 -> 49.8, 131,072 envs bf16 133.1 -> 136.4 — the workgroups of C cost 7.6 us instead of 5.9 (their
-// rows are asked for behind the wait, not at entry) and the CUs of the shadow have no time to spare.  Off by default.
-static bool front_has_c() {
-    static const bool on = getenv("HX_FRONT_C") && atoi(getenv("HX_FRONT_C")) != 0;
-    return on;
+// Launch C inside the front launch (HxFront.with_c; its workgroups wait in-launch for launches A and B: hx_bwd_body.h) — the CALLER's choice, told to the
+// calls behind it as c_in_front.  Bit-identical either way (tests/test_front_gpu.py); it pays only where the acting workgroups leave the other CUs more
+// time than launches A, B AND C need (CU time bounds the front launch): the streaming acting role around 8,192 envs — 67.1 -> 62.2 us per step there,
+// 54.1 -> 56.6 at 4,096 envs fp32, 45.6 -> 49.8 bf16, 133.1 -> 136.4 at 131,072 bf16 (tools/ubench/front_c_ab.sh, profiles/r04c_front_c_ab.txt):
+// HirlEngine.front_c_for() holds the rule.  HX_FRONT_C = 0 / 1 (A/B knob, read once) overrides the caller in BOTH calls.
+static bool front_has_c(bool asked) {
+    static const int force = getenv("HX_FRONT_C") ? atoi(getenv("HX_FRONT_C")) : -1;
+    return force < 0 ? asked : force != 0;
 }
 // launches C and D: y, loss, dq, LN2 backward, dh1 for both heads; all critic parameter gradients.
 // adam_step > 0: the critic's optimizer step (and, with polyak, the soft_update of its target) rides in the wgrad launch
@@ -387,9 +387,11 @@ int hx_hirl_front(float* state, int64_t n, int64_t stride, float* obs_io, float*
     HX_REQUIRE(bf16 || (x9 ? N->actor_w2_x9 != nullptr : N->actor_w2_f32i != nullptr), "hx_hirl_front: the image of the chosen acting format is missing from HxNets");
     noise_mode &= ~32;
     BwdArgs GC;
-    if (front_has_c()) make_launch_c(N, Bt, Hy, GC);
+    const bool with_c = front_has_c(front->with_c != 0);
+    HX_REQUIRE(!with_c || front->with_c != 0, "hx_hirl_front: HX_FRONT_C=1 needs a caller that counts its launches with launch C (HxFront.with_c = 1, 2, ...)");
+    if (with_c) make_launch_c(N, Bt, Hy, GC);
     return launch_front(N->actor, (x9 || bf16) ? nullptr : N->actor_w2_f32i, x9 ? N->actor_w2_x9 : nullptr, bf16 ? N->actor_w2_bf16 : nullptr, state, n, stride, obs_io, actions, noise_mode, noise, sigma, seed,
-                        row0, call, Hy->slope, reward, done, success, *opts, FA, FB, front_has_c() ? &GC : nullptr, *front, (hipStream_t)stream);
+                        row0, call, Hy->slope, reward, done, success, *opts, FA, FB, with_c ? &GC : nullptr, *front, (hipStream_t)stream);
 }
 // the predraw of hx_hirl_learn_back / hx_hirl_critic_grads_back as a device-side description (nothing is launched here)
 static int make_predraw(const HxNets* N, const HxBatch* Bt, const HxSample* next, const HxBatch* next_tiles, void* stream, SampleDev* SD) {
@@ -403,19 +405,20 @@ static int make_predraw(const HxNets* N, const HxBatch* Bt, const HxSample* next
     return 0;
 }
 /* The sharded rank's form (as hx_hirl_critic_grads after a front launch): launches C and D without the optimizer step; grad_critic is ready for the exchange. */
-int hx_hirl_critic_grads_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, const HxSample* next, const HxBatch* next_tiles, void* stream) {
+int hx_hirl_critic_grads_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, const HxSample* next, const HxBatch* next_tiles, int32_t c_in_front,
+                              void* stream) {
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_critic_grads_back: batch must be a positive multiple of 16");
     SampleDev SD{};
     if (next) if (int rc = make_predraw(N, Bt, next, next_tiles, stream, &SD)) return rc;
-    return critic_back(N, Bt, Hy, stream, 0, false, next ? &SD : nullptr, front_has_c());
+    return critic_back(N, Bt, Hy, stream, 0, false, next ? &SD : nullptr, front_has_c(c_in_front != 0));
 }
 int hx_hirl_learn_back(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy, int32_t critic_step, int32_t actor_phase, int32_t actor_step, int32_t do_polyak,
-                       int32_t w_kind, float w_given, float warm, const HxSample* next, const HxBatch* next_tiles, void* stream) {
+                       int32_t w_kind, float w_given, float warm, const HxSample* next, const HxBatch* next_tiles, int32_t c_in_front, void* stream) {
     HX_REQUIRE(N && Bt && Hy && Bt->batch > 0 && Bt->batch % 16 == 0, "hx_hirl_learn_back: batch must be a positive multiple of 16");
     HX_REQUIRE(critic_step >= 1 && (!actor_phase || actor_step >= 1), "hx_hirl_learn_back: Adam steps are 1-based");
     SampleDev SD{};
     if (next) if (int rc = make_predraw(N, Bt, next, next_tiles, stream, &SD)) return rc;
-    int rc = critic_back(N, Bt, Hy, stream, critic_step, do_polyak != 0, next ? &SD : nullptr, front_has_c());
+    int rc = critic_back(N, Bt, Hy, stream, critic_step, do_polyak != 0, next ? &SD : nullptr, front_has_c(c_in_front != 0));
     if (rc || !actor_phase) return rc;
     if ((rc = hx_hirl_actor_backward(N, Bt, Hy, w_kind == 1, 1, stream))) return rc;
     return actor_wgrad_impl(N, Hy, Bt->batch, Bt->batch, w_kind, w_given, warm, stream, actor_step, do_polyak != 0);

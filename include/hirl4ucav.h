@@ -367,15 +367,20 @@ typedef struct HxFront {
     uint32_t* flags;       /* [64] device words, zero before the first use (and whenever epoch starts over at 1) */
     uint32_t* status;      /* device word, sticky */
     uint32_t epoch;        /* 1, 2, 3, ... : one per front launch on these flags */
+    uint32_t with_c;       /* 0, or 1, 2, 3, ... = this is the k-th front launch on these flags WITH launch C: the critics' backward launch (y, loss, dq, dh1: HIRL.py:270-286) rides in this launch too, waiting in-launch for the forward
+                            * workgroups it reads; then pass c_in_front = 1 to hx_hirl_learn_back / hx_hirl_critic_grads_back.  Same bits; it pays only where the
+                            * acting workgroups leave the other CUs time to spare (around 8,192 envs in the exact-split format: HirlEngine.front_c_for) */
 } HxFront;
 int hx_hirl_front(float* state, int64_t n, int64_t stride, float* obs_io, float* actions, int32_t noise_mode,
                   const float* noise, float sigma, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done, int8_t* success,
                   const HxStepOpts* opts, const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, int32_t actor_phase, int32_t w_kind,
                   const HxFront* front, void* stream);
 int hx_hirl_learn_back(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, int32_t critic_step, int32_t actor_phase, int32_t actor_step,
-                       int32_t do_polyak, int32_t w_kind, float w_given, float warm, const HxSample* next, const HxBatch* next_tiles, void* stream);
+                       int32_t do_polyak, int32_t w_kind, float w_given, float warm, const HxSample* next, const HxBatch* next_tiles, int32_t c_in_front,
+                       void* stream);
 /* A sharded rank's form: what hx_hirl_critic_grads leaves behind (grad_critic, ready for the exchange; no optimizer step) after a front launch, + the predraw. */
-int hx_hirl_critic_grads_back(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, const HxSample* next, const HxBatch* next_tiles, void* stream);
+int hx_hirl_critic_grads_back(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, const HxSample* next, const HxBatch* next_tiles, int32_t c_in_front,
+                              void* stream);
 
 
 /* ------------------------------------------------------------------------------------------------------------
