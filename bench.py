@@ -331,7 +331,7 @@ class Loop:
         self.t += 1
 
     # ---- the same step with instruments (second pass only) -----------------------------------------------------------------
-    def step_measured(self, split, pool, kpool):
+    def step_measured(self, split, pool, kpool, stamp_front=True):
         torch = self.torch
 
         def timed(name, fn):
@@ -342,7 +342,7 @@ class Loop:
             self.rec[name].append((a, b))
 
         stamp = None
-        if not self.uniform and len(kpool) >= 2 and (split or not self.separate):
+        if not self.uniform and len(kpool) >= 2 and (split or not self.separate) and (split or stamp_front or not self.front):
             stamp = (kpool.pop(), kpool.pop())  # split: the env launch, else the fused act + env launch (filed by _act_env when it runs)
         if self.front and not split:  # the front launch stamped with its own begin / end; the whole step under one pair of stream events
             if stamp is not None:
@@ -836,7 +836,7 @@ def run_rank(args):
         reps.append(dt)
     dt = float(np.median(reps))
 
-    # ---- second pass: stage events; the act + env launch stamped; a quarter of the steps (every 4th; front loop: the last quarter) act and env step as two launches, the env launch stamped ----
+    # ---- second pass: stage events; the act + env launch stamped; every 4th step act and env step as two launches, the env launch stamped ----
     ar_events = []
     m_steps = max(int(args.measure_steps), 16)
     pool = [torch.cuda.Event(enable_timing=True) for _ in range(12 * (m_steps + 1))]
@@ -859,9 +859,9 @@ def run_rank(args):
             return t if out is None else out
         loop.eng._allreduce = timed_allreduce
     for k in range(m_steps):
-        # front loop: the split steps as ONE trailing block (a front launch that follows a foreign step has no pre-drawn minibatch and draws
-        # in a launch of its own: interleaved, a third of the stamped front launches would be that slower first one)
-        loop.step_measured(split=(k >= m_steps - m_steps // 4) if loop.front else (k % 4 == 3), pool=pool, kpool=kpool)
+        # front loop: the front launch right behind a split step is not stamped (it follows a foreign env step: no pre-drawn minibatch, a draw launch
+        # of its own in front of it, colder caches — a third of the stamped launches would be that slower first one)
+        loop.step_measured(split=(k % 4 == 3), pool=pool, kpool=kpool, stamp_front=(k % 4 != 0))
     barrier()
     if loop.front and hasattr(loop.eng, "front_check"):
         loop.eng.front_check()  # an in-launch wait that gave up leaves a minibatch half read: fail loudly instead of printing a number
@@ -905,8 +905,8 @@ def run_rank(args):
         "timed_region": "R x [K x step() between two barrier + synchronize pairs]; no events, no stamped or split launches inside (those are the second pass)",
         "stage_us": {"pass": f"second pass, {m_steps} steps after the timed region (events add a few us per step)",
                      "act+env_step(1 kernel)": None if med["act+env"] is None else round(med["act+env"], 2),
-                     "act(own launch, a quarter of the steps)": None if act_us is None else round(act_us, 2),
-                     "env_step(own launch, a quarter of the steps)": None if med["env"] is None else round(med["env"], 2),
+                     "act(own launch, every 4th step)": None if act_us is None else round(act_us, 2),
+                     "env_step(own launch, every 4th step)": None if med["env"] is None else round(med["env"], 2),
                      "sample+learn": None if learn_us is None else round(learn_us, 2)},
     }
     if loop.front and world == 1 and not pg:
@@ -940,7 +940,7 @@ def run_rank(args):
                                     "FRONT launch (hx_hirl_front): act + env step + replay insert + launches A and B of learn() in one launch")
         res["config"]["draw"] = ("uniform without replacement over the transitions that are in the ring before AND after this step's insert (drawn from the ring as it stood "
                                  "before the step, without the n slots the step may overwrite: HxSample.guard); --no-front draws after the insert, like the reference")
-        res["stage_us"]["front launch + rest of learn() (the first three quarters of the second pass; the front launch stamped: + ~25 us of instruments)"] = None if med["front+back"] is None else round(med["front+back"], 2)
+        res["stage_us"]["front launch + rest of learn() (3 of every 4 steps of the second pass; the front launch stamped: + ~25 us of instruments)"] = None if med["front+back"] is None else round(med["front+back"], 2)
 
     env_roof = {"kernel": "env_step_kernel<PAIR, INSERT, EPB> (hx_env.hip)", "bound": "hbm",
                 "achieved": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -996,7 +996,7 @@ def run_rank(args):
         res["roofline"] = {"kernel": ((front_name + "; FLOPs: the policy's over the envs + the 6.5 forward passes (average) of launches A and B over the minibatch") if front_name else plain_name) + ", the dominant kernel of the timed loop", **first, "traffic": (fused_pmc or {}).get("bytes"), "other_roof": second,
                            "us_per_launch": round(us, 2), "launches_timed": len(fused),
                            "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the fused launches "
-                                     "of the second pass (" + ("its first three quarters; the last quarter issues act, env step and learn() as separate launches" if loop.front else "3 of every 4 steps") + ")",
+                                     "of the second pass (" + ("2 of every 4 steps: every 4th issues act, env step and learn() as separate launches, and the front launch behind it is not stamped" if loop.front else "3 of every 4 steps") + ")",
                            "note": ("bound by CU time: 128 acting workgroups of 32 rows beside 320-448 update workgroups on the other 128 CUs; neither roof is near (DESIGN.md section 4 K5)" if loop.front else
                                     "vector-issue / LDS bound tile loop (LayerNorm + head per row), DESIGN.md section 4" if persistent else
                                     "latency-bound at this size: 256 workgroups, one round; neither roof is near (DESIGN.md section 4)"),
@@ -1016,7 +1016,7 @@ def run_rank(args):
     if act_us and not loop.uniform:  # (with --actions uniform the 'act' stage is a torch uniform_ fill, not the policy)
         peak = FP32_MATRIX_PEAK_TFLOPS if (args.dtype in ("f32", "f32x9") or args.agent == "sac") else BF16_MATRIX_PEAK_TFLOPS
         flop = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
-        res["roofline_act"] = {"kernels": "the acting kernel (ENV = false) as its own launch (a quarter of the steps of the second pass); fp32-equivalent FLOPs", "bound": "mfma", "unit": "TFLOP/s",
+        res["roofline_act"] = {"kernels": "the acting kernel (ENV = false) as its own launch (every 4th step of the second pass); fp32-equivalent FLOPs", "bound": "mfma", "unit": "TFLOP/s",
                                "achieved": round(flop / act_us / 1e6, 3), "peak": peak,
                                "frac": round(flop / act_us / 1e6 / peak, 5), "us": round(act_us, 2), "timing": "torch events (median)"}
     if pg:
