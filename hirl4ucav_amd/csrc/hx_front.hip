@@ -13,6 +13,8 @@
 // head is evaluated once per row tile (FRONT == 1 in hx_fwd_body.h) instead of in every target-critic workgroup.
 // Beyond one round of 32-row acting workgroups the acting role is a PERSISTENT kernel on part of the CUs (actp_front_kernel: bf16, weight-stationary;
 // actps_front_kernel: fp32 in the exact-split format, one 64-row pass per workgroup).
+// Launch C (the critics' backward) can ride too (HxFront.with_c: bwd_l2_body<0, ..., FRONT = 3>, hx_bwd_body.h, waiting in-launch for the jobs of A and B it
+// reads): worth it only where the acting workgroups leave the other CUs time for 256 more workgroups — the streaming role at 8,192 envs (hx_hirl.hip).
 // The draw's meaning changes (it cannot see this step's inserts and must not read the slots they overwrite): include/hirl4ucav.h hx_hirl_front.
 #include <hip/hip_ext.h>
 
