@@ -200,6 +200,23 @@ def test_front_launch_default_acting_format_is_the_exact_split(eng_mod):
     assert float((outs[0] - outs[2]).abs().max()) < 2e-6 and not torch.equal(outs[0], outs[2])
 
 
+def test_launch_c_rides_only_where_the_cus_have_time_for_it(eng_mod):
+    """HirlEngine.front_c_for ("auto"): launch C inside the front launch only in the streaming acting role around 8,192 envs (fp32, exact split) — measured
+    slower everywhere else (profiles/r04c_front_c_ab.txt); front_c = True / False overrides.  (That the results do not depend on it: the parity test above
+    runs 8,192 envs with it, and test_launch_c_inside_the_front_launch_is_bit_identical forces it for every acting role.)"""
+    e = eng_mod.HirlEngine(batch=128, use_bc=True)
+    assert e.front_c == "auto"
+    for actor_phase in (False, True):
+        assert e.front_c_for(8192, actor_phase, 0, False) and e.front_c_for(8256, actor_phase, 0, False)
+        for n in (32, 4096, 6144, 8704, 12288, 16384, 65536):
+            assert not e.front_c_for(n, actor_phase, 0, False), n
+        assert not e.front_c_for(8192, actor_phase, 0, True)  # the bf16 update path: persistent bf16 acting role
+    e.front_c = True
+    assert e.front_c_for(4096, False, 0, False)
+    e.front_c = False
+    assert not e.front_c_for(8192, True, 0, False)
+
+
 def test_front_loop_free_running(eng_mod):
     """40 free-running steps of the front loop (no re-synchronisation, every minibatch but the first drawn by the previous call's learn() part): finite
     losses, every Adam step counted, the ring wrapped, the hand-off status word clear."""
