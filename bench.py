@@ -957,7 +957,7 @@ def run_rank(args):
         fused_pmc = (profile_traffic(f"fused_{args.envs}") if args.dtype == "f32" else profile_traffic(f"fused_bf16_{args.envs}") if args.dtype == "bf16" else None) \
             if args.agent == "hirl" else None
         if loop.front:  # (the front launch has PMC passes of its own)
-            fused_pmc = profile_traffic(f"front_{args.envs}") if args.dtype == "f32" else None
+            fused_pmc = profile_traffic(f"front_{args.envs}") if args.dtype == "f32" else profile_traffic(f"front_bf16_{args.envs}") if args.dtype == "bf16" else None
         fp32_equiv = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
         # which matrix-core instruction the 256 -> 512 product runs on: fp32 MFMA; bf16 MFMA; or — the fp32 HIRL policy from 16,384 rows on, and
         # --dtype f32x9 at every size — NINE bf16 MFMAs per fp32 product (the exact hi | mid | lo split): `roofline.executed` prices those against the bf16 peak

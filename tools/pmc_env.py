@@ -36,6 +36,9 @@ if os.environ.get("HX_PMC_FRONT"):  # bench.py's default loop where it applies: 
     from hirl4ucav_amd.agents.engine import HirlEngine
     from tests import _hirl_data as D
     eng = HirlEngine(batch=128)
+    if os.environ.get("HX_PMC_DTYPE", "f32") == "bf16":  # the bf16 update path with the bf16 acting format (persistent acting role beyond 4,096 envs)
+        eng.set_update_dtype("bf16")
+        eng.set_act_dtype("bf16")
     pp = D.make_params(1)
     eng.load_params(pp["actor"], pp["critic"], pp["bc_actor"])
     rng = np.random.default_rng(0)

@@ -7,7 +7,7 @@ O="$R/gpurun_out/${1:-r04_pmc}"
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 # envs per launch : fused act + env launches too (0 / 1) : policy format of the fused launches
-for CFG in 4096:2:f32 65536:1:f32 1048576:0:f32 16384:1:bf16 131072:1:bf16; do
+for CFG in 4096:2:f32 8192:2:f32 65536:1:f32 1048576:0:f32 16384:2:bf16 131072:1:bf16; do
   IFS=: read -r N FUSED DT <<< "$CFG"
   for C in FETCH_SIZE WRITE_SIZE; do
     export HX_PMC_ENVS=$N HX_PMC_DTYPE=$DT

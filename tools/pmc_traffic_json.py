@@ -11,12 +11,12 @@ import re
 import sys
 
 d, commit = sys.argv[1], sys.argv[2]
-ALGO = {"env_step_kernel": 550, "act_fused_kernel": 550, "act_persist": 550, "act_front_kernel": 550}  # algorithmic bytes per env-step with the fused insert
+ALGO = {"env_step_kernel": 550, "act_fused_kernel": 550, "act_persist": 550, "act_front_kernel": 550, "actps_front_kernel": 550, "actp_front_kernel": 550}  # algorithmic bytes per env-step with the fused insert
 
 
 # the front launch also reads the five networks of launches A and B once (target actor, critic x 2, target critic x 2) beside the acting policy's:
 # 4 B x (138,756 + 4 x 138,244) = 2.77 MB; the counter sees every XCD's L2 pull its own copy of all of them
-extra = {"act_front_kernel": 4 * (138756 + 4 * 138244)}
+extra = {k: 4 * (138756 + 4 * 138244) for k in ("act_front_kernel", "actps_front_kernel", "actp_front_kernel")}  # (actps_ / actp_: the streaming / persistent acting roles)
 
 
 def rows(path):
@@ -40,7 +40,8 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_FETCH_SIZE_env_*.csv"))):
     cal_w = [float(r["Counter_Value"]) for r in wr if "calib_copy_dword" in r["Kernel_Name"]]
     kib = 128 * 1024 * 1024 * 4 / 1024  # the copy reads and writes 512 MiB
     ff, wf = kib / (sum(cal_f) / len(cal_f)), kib / (sum(cal_w) / len(cal_w))
-    for kern, key in (("env_step_kernel", str(n)), ("act_fused_kernel", f"fused{dt}_{n}"), ("act_persist", f"fused{dt}_{n}"), ("act_front_kernel", f"front{dt}_{n}")):
+    for kern, key in (("env_step_kernel", str(n)), ("act_fused_kernel", f"fused{dt}_{n}"), ("act_persist", f"fused{dt}_{n}"), ("act_front_kernel", f"front{dt}_{n}"),
+                      ("actps_front_kernel", f"front{dt}_{n}"), ("actp_front_kernel", f"front{dt}_{n}")):
         if kern == "env_step_kernel" and (dt or str(n) in out):
             continue
         fv = [float(r["Counter_Value"]) for r in fr if kern in r["Kernel_Name"]]
