@@ -69,152 +69,9 @@ _lib.register("hx_adam", [_P(HxNets), _P(HxHyper), _i32, _i32, _f32, _i32, _f32,
 _lib.register("hx_polyak", [_P(HxNets), _P(HxHyper), _vp])
 _lib.register("hx_hirl_actor_wgrad_split", [_P(HxNets), _P(HxHyper), _i32, _vp, _vp])
 _lib.register("hx_adam_mixed", [_P(HxNets), _P(HxHyper), _i32, _i32, _f32, _i32, _f32, _f32, _i32, _vp, _vp])
-_lib.register("hx_ipc_alloc", [ctypes.c_int64, _i32, _P(_vp)])
-_lib.register("hx_ipc_free", [_vp])
-_lib.register("hx_ipc_export", [_vp, _vp])
-_lib.register("hx_ipc_import", [_vp, _P(_vp)])
-_lib.register("hx_ipc_close", [_vp])
-_lib.register("hx_allreduce_oneshot", [_vp, _P(_vp), _P(_vp), _vp, _i32, _i32, ctypes.c_int64, ctypes.c_uint32, _i32, _vp])
-_lib.register("hx_allreduce_twostage", [_vp, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _vp, _i32, _i32, ctypes.c_int64, ctypes.c_uint32, _i32, _i32, _vp])
-_lib.register("hx_rccl_unique_id", [_vp])
-_lib.register("hx_rccl_init", [_vp, _i32, _i32, _P(_vp)])
-_lib.register("hx_rccl_allreduce", [_vp, _vp, ctypes.c_int64, _i32, _vp])
-_lib.register("hx_rccl_destroy", [_vp])
+from .exchange import OneShotExchange, RcclDirect, _DeviceWords, negotiate_rccl_direct  # noqa: E402,F401  (the transports of the sharded update)
 
 
-class RcclDirect:
-    """RCCL without torch.distributed in the loop (include/hirl4ucav.h hx_rccl_*): ncclAllReduce enqueued on the engine's stream by the
-    library.  The communicator's 128-byte id is made on rank 0 and travels once, at construction, through the existing process group
-    (torch.distributed.broadcast_object_list: the launcher's TCP store / gloo / nccl — any backend); one GPU per rank."""
-
-    def __init__(self, group=None):
-        dist = torch.distributed
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        box = [None]
-        if self.rank == 0:
-            raw = ctypes.create_string_buffer(128)
-            _lib.call("hx_rccl_unique_id", raw)
-            box[0] = raw.raw
-        dist.broadcast_object_list(box, src=0, group=group)
-        comm = _vp()
-        _lib.call("hx_rccl_init", ctypes.create_string_buffer(box[0], 128), self.world, self.rank, ctypes.byref(comm))
-        self.comm = comm
-
-    def allreduce(self, t):
-        """t <- sum over the ranks of t (fp32), in place, on the current stream"""
-        _lib.call("hx_rccl_allreduce", self.comm, t.data_ptr(), t.numel(), 0, _lib.stream_ptr())
-        return t
-
-    def close(self):
-        if self.comm is not None:
-            torch.cuda.synchronize()
-            c, self.comm = self.comm, None
-            _lib.call("hx_rccl_destroy", c)
-
-
-class _DeviceWords:
-    """raw device memory as a torch tensor (no copy): the __cuda_array_interface__ protocol"""
-
-    def __init__(self, ptr, nfloats):
-        self.__cuda_array_interface__ = {"shape": (int(nfloats),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
-
-
-class OneShotExchange:
-    """The exchange step over hipIpc peer mappings (include/hirl4ucav.h hx_allreduce_oneshot): every rank owns, per message kind, two
-    message buffers (epoch parity) that the peers map, and one fine-grained flag word.  Handles travel once, at construction, through
-    torch.distributed.all_gather_object (any backend)."""
-
-    def __init__(self, sizes, device, group=None, timeout_ms=5000, two_stage=False, bf16=False):
-        """two_stage: reduce-scatter + all-gather (hx_allreduce_twostage: 2 (world - 1) / world x n floats per rank over xGMI instead of
-        world x n); bf16 (two_stage only): the reduced slices travel as bf16"""
-        dist = torch.distributed
-        self.two_stage, self.bf16 = bool(two_stage), bool(bf16) and bool(two_stage)
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        self.device, self.timeout_ms = device, int(timeout_ms)
-        self.kinds = list(sizes)
-        self.n = {k: (int(v) + 3) & ~3 for k, v in sizes.items()}
-        total = sum((3 if self.two_stage else 2) * self.n[k] for k in self.kinds)  # two message buffers (epoch parity) [+ the reduced slices]
-        msg, flag = _vp(), _vp()
-        _lib.call("hx_ipc_alloc", total * 4, 0, ctypes.byref(msg))
-        _lib.call("hx_ipc_alloc", 256, 1, ctypes.byref(flag))  # word k: flag of kind k; word 32: status
-        self._own = (msg.value, flag.value)
-        hm, hf = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
-        _lib.call("hx_ipc_export", msg, hm)
-        _lib.call("hx_ipc_export", flag, hf)
-        every = [None] * self.world
-        uuid = str(getattr(torch.cuda.get_device_properties(device), "uuid", "")) or f"{os.uname().nodename}:{torch.cuda.current_device()}"
-        dist.all_gather_object(every, (hm.raw, hf.raw, uuid), group=group)
-        uuids = [e[2] for e in every]
-        every = [e[:2] for e in every]
-        # Ranks that SHARE a GPU (functional tests on a one-GPU box): a rank's wait kernel spinning on every CU keeps the peer's 1024-thread
-        # workgroups from being placed for seconds at a time.  A few workgroups leave the chip to the peer (3 s instead of minutes for a short
-        # run); ranks with a GPU each keep the 256 workgroups whose loads cover the xGMI round trip.  (Read once, at the first exchange.)
-        self.shared_device = len(set(uuids)) < len(uuids)
-        if self.shared_device:
-            os.environ.setdefault("HX_ONESHOT_BLOCKS", "16")
-        self._peers = []
-        bases, flags = [], []
-        for r, (m_h, f_h) in enumerate(every):
-            if r == self.rank:
-                bases.append(msg.value)
-                flags.append(flag.value)
-                continue
-            pm, pf = _vp(), _vp()
-            _lib.call("hx_ipc_import", ctypes.create_string_buffer(m_h, 64), ctypes.byref(pm))
-            _lib.call("hx_ipc_import", ctypes.create_string_buffer(f_h, 64), ctypes.byref(pf))
-            self._peers += [pm.value, pf.value]
-            bases.append(pm.value)
-            flags.append(pf.value)
-        self.status_ptr = flag.value + 32 * 4
-        self.epoch = {k: 0 for k in self.kinds}
-        self.own, self.bufs, self.flags, self.reduced, self.reds, self.flags2 = {}, {}, {}, {}, {}, {}
-        off = 0
-        arr = _vp * self.world
-        for ki, k in enumerate(self.kinds):
-            for par in (0, 1):
-                self.own[k, par] = torch.as_tensor(_DeviceWords(msg.value + off * 4, self.n[k]), device=device)
-                self.bufs[k, par] = arr(*[b + off * 4 for b in bases])
-                off += self.n[k]
-            if self.two_stage:
-                self.reds[k] = arr(*[b + off * 4 for b in bases])
-                off += self.n[k]
-            self.flags[k] = arr(*[f + ki * 4 for f in flags])
-            self.flags2[k] = arr(*[f + (8 + ki) * 4 for f in flags])  # words 8..: the second stage's flags
-            self.reduced[k] = torch.zeros(self.n[k], dtype=torch.float32, device=device)
-        dist.barrier(group=group)  # every mapping exists before the first exchange
-
-    def write_buffer(self, kind):
-        """where this rank's NEXT message of `kind` must be written (the parity of the epoch its exchange will carry)"""
-        return self.own[kind, (self.epoch[kind] + 1) & 1]
-
-    def allreduce(self, kind):
-        """sum of every rank's message written into write_buffer(kind) -> a local tensor (the same bits on every rank)"""
-        self.epoch[kind] += 1
-        e = self.epoch[kind]
-        if self.two_stage:
-            _lib.call("hx_allreduce_twostage", self.reduced[kind].data_ptr(), self.bufs[kind, e & 1], self.reds[kind], self.flags[kind], self.flags2[kind],
-                      self.status_ptr, self.world, self.rank, self.n[kind], e & 0xFFFFFFFF, self.timeout_ms, int(self.bf16), _lib.stream_ptr())
-        else:
-            _lib.call("hx_allreduce_oneshot", self.reduced[kind].data_ptr(), self.bufs[kind, e & 1], self.flags[kind], self.status_ptr, self.world,
-                      self.rank, self.n[kind], e & 0xFFFFFFFF, self.timeout_ms, _lib.stream_ptr())
-        return self.reduced[kind]
-
-    def check(self):
-        """raises if a wait timed out since the last check (synchronises)"""
-        torch.cuda.synchronize()
-        st = torch.as_tensor(_DeviceWords(self.status_ptr, 1), device=self.device).view(torch.int32)
-        code = int(st.item())
-        if code != 0:
-            raise _lib.HxError("one-shot exchange failed (sticky, every rank stops stepping): " +
-                               ("a peer did not arrive within the timeout" if code == 1 else "a peer reported failure"))
-
-    def close(self):
-        for p in self._peers:
-            _lib.call("hx_ipc_close", p)
-        self._peers = []
-        for p in self._own:
-            _lib.call("hx_ipc_free", p)
-        self._own = ()
 _lib.register("hx_bc_train_actor", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _vp])
 _lib.register("hx_hirl_learn", [_P(HxNets), _P(HxBatch), _P(HxHyper), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp])
 _lib.register("hx_hirl_learn_sampled", [_P(HxNets), _P(HxBatch), _P(HxHyper), _P(HxSample), _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp])
@@ -552,33 +409,23 @@ class HirlEngine:
         """Exchange gradients with ncclAllReduce enqueued by the library on the engine's stream (hx_rccl_allreduce) instead of
         torch.distributed.all_reduce: no host-side collective call inside learn().  Needs an initialised process group (for the id) and one
         GPU per rank (RCCL refuses two ranks on one device); works at world size 1 (the sharded rank's sequence, bench.py --staged).
-        The communicator is checked with one all-reduce of ones before it is used, and EVERY rank takes the same decision: if any rank could
+        The communicator is checked with one all-reduce of ones before it is used, and EVERY rank takes the same decision
+        (exchange.negotiate_rccl_direct: no rank is left alone in a collective, whichever step failed where): if any rank could
         not build or verify it (a second RCCL instance in the process, a launcher without device binding, ...) all ranks keep
         torch.distributed.all_reduce and say so on stderr — `exchange_name` (bench.py: `rccl_ranks.backend`) tells which transport runs."""
         dist = torch.distributed
         if not (dist.is_available() and dist.is_initialized()):
             raise _lib.HxError("use_rccl_direct needs an initialised torch.distributed process group (it carries the communicator id)")
         import sys
-        ok, why, r = 1, "", None
-        try:
-            r = RcclDirect(self.group)
-            probe = torch.ones(64, dtype=torch.float32, device=self.device)
-            r.allreduce(probe)
-            torch.cuda.synchronize()
-            if not bool((probe == float(r.world)).all()):
-                ok, why = 0, f"the probe all-reduce returned {float(probe[0])} instead of {r.world}"
-        except Exception as e:  # noqa: BLE001 — any failure here means "use the other transport", on every rank
-            ok, why = 0, repr(e)
-        flag = torch.tensor([ok], dtype=torch.int32, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        if int(flag.item()) != 1:
-            if r is not None:
-                try:
-                    r.close()
-                except Exception:  # noqa: BLE001
-                    pass
-            print(f"hirl4ucav_amd: RCCL direct not available on rank {dist.get_rank(self.group)} ({why or 'another rank failed'}): "
-                  f"the gradient exchange stays on torch.distributed.all_reduce", file=sys.stderr, flush=True)
+
+        def connect(uid, world, rank):
+            r = RcclDirect(uid, world, rank)
+            r.probe(self.device)
+            return r
+
+        r, _why = negotiate_rccl_direct(self.group, self.device if dist.get_backend(self.group) == "nccl" else "cpu", connect=connect,
+                                        log=lambda m: print(m, file=sys.stderr, flush=True))
+        if r is None:
             return False
         self.rccl = r
         self.exchange_name = "rccl-direct"
@@ -731,6 +578,20 @@ class HirlEngine:
         flags, status = self._front
         cur, nxt = self._front_tiles
         n_main = B if n_main is None else int(n_main)
+        # the host's counters run ahead of the library calls below; if one of them refuses (HX_REQUIRE: ring smaller than 2n, too many row tiles, a missing
+        # image) they are put back and the hand-off words start over — a caller that catches the error must not be left with a host epoch ahead of the device's
+        held = (self._front_epoch, self._front_c_epoch, self.critic_step, self.actor_step, self.update_count, self.sample_calls, self.act_calls, env.steps_issued)
+        try:
+            return self._step_learn(env, expert, bc_table, n_main, act_noise, act_sigma, act_seed, out, sample_seed, smooth_sigma, bc_weight_now,
+                                    bc_warm_up_weight, bf16, flags, status, cur, nxt)
+        except _lib.HxError:
+            (self._front_epoch, self._front_c_epoch, self.critic_step, self.actor_step, self.update_count, self.sample_calls, self.act_calls, env.steps_issued) = held
+            self.front_reset()
+            raise
+
+    def _step_learn(self, env, expert, bc_table, n_main, act_noise, act_sigma, act_seed, out, sample_seed, smooth_sigma, bc_weight_now, bc_warm_up_weight,
+                    bf16, flags, status, cur, nxt):
+        replay, n, B = env.replay, env.n, self.batch
         self.sample_calls += 1
 
         def draw(tiles, call):
@@ -812,10 +673,30 @@ class HirlEngine:
         need = jobs * tiles * 8 * 6.0 + 2 * ((self.batch + 7) // 8) * 8 * 7.6
         return (256 - acting) * 37.0 >= need
 
+    def front_reset(self):
+        """The hand-off words of the front launch start over (stream-ordered): counters and status to zero, the host's epochs with them, no tiles in waiting
+        (the next step_learn draws its minibatch with a launch of its own)."""
+        if self._front is not None:
+            self._front[0].zero_()
+            self._front[1].zero_()
+        self._front_epoch = self._front_c_epoch = 0
+        self._front_drawn = None
+
+    def front_status(self):
+        """The front launch's sticky status word (synchronises).  0: every in-launch wait was answered.  Bit 0: a launch-B workgroup gave up waiting for the
+        target actor's rows of its row tile (launch A); bit 1: a launch-C workgroup gave up waiting for the jobs of A / B it reads.  The waits assume that
+        the workgroups of one launch START in index order (producers have lower indices) — observed on gfx950, promised by nobody (include/hirl4ucav.h
+        hx_hirl_front): a set bit means a minibatch may have been read half-written, and every update since is suspect."""
+        return 0 if self._front is None else int(self._front[1].item())
+
     def front_check(self):
-        """Raise if a workgroup of a front launch ever gave up waiting for its producers (synchronises)."""
-        if self._front is not None and int(self._front[1].item()) != 0:
-            raise _lib.HxError("front launch: an in-launch wait for the target actor's rows timed out (status word set)")
+        """Raise if a workgroup of a front launch ever gave up waiting for its producers (synchronises).  `train_all --loop reference` /
+        `bench.py --no-front` run the same update without in-launch waits."""
+        code = self.front_status()
+        if code != 0:
+            which = [w for bit, w in ((1, "launch B for the target actor's rows (launch A)"), (2, "launch C for the rows of launches A / B")) if code & bit]
+            raise _lib.HxError(f"front launch: an in-launch wait timed out (status word {code}: " + "; ".join(which) + ") - the minibatches read since are "
+                               "suspect; the reference-order loop (train_all --loop reference) has no in-launch waits")
 
     def bc_train_actor(self):
         """BC.Agent.train_actor (BC.py:160-185) on the BC minibatch last assembled: mse, backward, Adam on the actor."""

@@ -67,6 +67,13 @@ Api* api() {
 
 extern "C" {
 
+/* 0 when librccl.so and the entry points this file needs can be bound in this process; nothing collective, nothing allocated.  The all-rank
+ * negotiation (hirl4ucav_amd/agents/exchange.py negotiate_rccl_direct) asks this on every rank BEFORE anyone enters ncclCommInitRank. */
+int hx_rccl_available(void) {
+    HX_REQUIRE(api(), "hx_rccl_available: librccl.so (ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy) not found "
+                      "(HX_RCCL_LIBRARY names another path)");
+    return 0;
+}
 /* 128 bytes that identify a new communicator: call on ONE rank, hand the bytes to every rank (any byte channel: the launcher's TCP store). */
 int hx_rccl_unique_id(uint8_t* id128) {
     HX_REQUIRE(id128, "hx_rccl_unique_id: null");

@@ -298,13 +298,13 @@ def main(config):
     dtype = getattr(config, "dtype", "f32")
     # the run's arithmetic is part of its state: a snapshot taken under one --dtype does not continue under another (the same flag changed
     # meaning once already: round 2's "bf16" was policy inference only, since round 3 it is the policy AND learn()'s 256 <-> 512 products)
-    snap_dtype = snap["driver"].get("dtype") if snap is not None else None
-    if snap_dtype is not None and snap_dtype != dtype:
-        raise SystemExit(f"train_all: --resume {config.resume} was run with --dtype {snap_dtype}, --dtype {dtype} given")
-    if sac and dtype != "f32":
+    if sac and dtype != "f32":  # (before the snapshot comparison: a SAC run started with --dtype bf16 stored "f32", and resumes with the same command line)
         if rank == 0:
             print(f"WARNING: --dtype {dtype} has no effect on the SAC / E-SAC agents (their kernels are fp32): running fp32", flush=True)
         dtype = "f32"
+    snap_dtype = snap["driver"].get("dtype") if snap is not None else None
+    if snap_dtype is not None and snap_dtype != dtype:
+        raise SystemExit(f"train_all: --resume {config.resume} was run with --dtype {snap_dtype}, --dtype {dtype} given")
     if world > 1 and os.environ.get("HX_DIST_BACKEND", "nccl") == "nccl" and hasattr(eng, "use_rccl_direct"):
         eng.use_rccl_direct()  # ncclAllReduce enqueued by the library on the engine's stream (hx_rccl_*): no torch.distributed call inside learn()
     if dtype == "f32x9" and not sac:  # fp32, the acting kernel's 256 -> 512 product as the exact 9-term bf16 split (engine.set_act_dtype)
@@ -357,9 +357,34 @@ def main(config):
     front_sac = (config.loop == "front" and sac and world == 1 and not config.separate_launches and config.updates_per_step == 1 and batch <= 256 and n > 8192)
     if rank == 0:
         print(f"vector loop: {'front launch (env step + first launches of learn() in one launch; draw before the insert)' if (front or front_sac) else 'reference order'}", flush=True)
-    for episode in range(episode0, config.episodes):
+    # The front launch's in-launch waits (launch B for launch A's rows, launch C for both) assume that the workgroups of ONE launch start in index order —
+    # observed on gfx950, promised by nobody.  A wait that gives up sets a sticky status word: it is read every --status_check_every vector steps (one host
+    # sync; every rank takes the same decision), and on a trip every rank goes back to the newest snapshot and continues in the reference's order INSIDE this
+    # process (--on_front_trip fallback, the default), or the run exits with code 3 (no snapshot yet, or --on_front_trip exit).
+    check_every = max(int(config.status_check_every), 0)
+    snap_path = os.path.join(config.resume, f"state_rank{rank}.pt") if config.resume else None  # the newest whole-run snapshot this process can go back to
+    steps_since_check = 0
+
+    def front_tripped():
+        code = eng.front_status()
+        if world > 1:
+            t = torch.tensor([code], dtype=torch.int32, device=device if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            code = int(t.item())
+        return code
+
+    episode = episode0
+    while episode < config.episodes:
         w_now, warm = bc_weight_schedule(config.type, episode, config.bc_weight) if hirl else (0.0, 0.0)
+        tripped = 0
         for step in range(max_step):
+            if front and check_every:
+                steps_since_check += 1
+                if steps_since_check >= check_every:
+                    steps_since_check = 0
+                    tripped = front_tripped()
+                    if tripped:
+                        break
             if front and step < max_step - 1:  # (the last step of an episode has no learn() behind it, train_all.py:346-347)
                 expert_num = expert_num_after(expert_num, step, warm_up_rate)
                 eng.step_learn(env, expert, bc_table, n_main=batch - expert_num, act_sigma=0.1, act_seed=seed + 1, out=actions, sample_seed=seed + 2 + rank,
@@ -402,8 +427,26 @@ def main(config):
                 c_, a_, b_, r__, f_, _w = eng.losses_host()
                 for tag, v in (("Loss/Critic_Loss", c_), ("Loss/Actor_Loss", a_), ("Loss/BC_Loss", b_), ("Loss/RL_Loss", r__), ("Loss/BC_Fire_Loss", f_)):
                     writer.add_scalar(tag, v, step + episode * max_step)
-        if front:
-            eng.front_check()  # a front launch whose in-launch wait gave up read a half-written minibatch: stop here, not at the next validation
+        if front and not tripped:
+            tripped = front_tripped()  # ... and at every episode's end: nothing of a tripped episode reaches a validation, a checkpoint or a snapshot
+        if tripped:
+            why = (f"front launch: an in-launch wait gave up (status word {tripped}: " + " and ".join(w for b_, w in ((1, "launch B waiting for launch A's rows"),
+                   (2, "launch C waiting for launches A / B")) if tripped & b_) + f") in episode {episode + 1} — the minibatches read since the last check are suspect")
+            if config.on_front_trip != "fallback" or snap_path is None or not os.path.exists(snap_path):
+                if rank == 0:
+                    print(why + "; " + ("--on_front_trip exit" if config.on_front_trip != "fallback" else "no snapshot to go back to (--snapshot_every)") +
+                          ": stopping.  `--loop reference` runs the same update without in-launch waits", flush=True)
+                raise SystemExit(3)
+            run = CK.load_run(snap_path, eng, env, replay)  # every rank its own shard; all shards of a snapshot come from the same episode
+            eng.front_reset()
+            expert_num, high_score, success_rate, arttir = run["expert_num"], run["high_score"], run["success_rate"], run["arttir"]
+            episode = episode0 = run["episode"]
+            t0, last_stats, front = time.time(), env.stats_dict(), False
+            if ret is not None:
+                ret.zero_()
+            if rank == 0:
+                print(why + f": back to the snapshot of episode {episode} ({snap_path}), continuing in the REFERENCE's order (no in-launch waits)", flush=True)
+            continue
         if rank == 0:
             c, a, b, r_, f, w = eng.losses_host()
             st = env.stats_dict()
@@ -452,6 +495,8 @@ def main(config):
                          "seed": seed, "dtype": dtype})
             if world > 1:
                 torch.distributed.barrier()  # ... and nobody runs ahead while a shard is still being written
+            snap_path = os.path.join(log_dir, f"state_rank{rank}.pt")
+        episode += 1
     if writer is not None:
         writer.close()
     if world > 1:
@@ -501,6 +546,11 @@ def parser():
     p.add_argument("--load_dir", type=str, default=None, help="--load_model: directory of the checkpoint files (default: this run's model dir)")
     p.add_argument("--load_tag", type=str, default="Agent20_successRate0.64", help="--load_model: checkpoint tag (train_all.py:240 hard-codes this one)")
     p.add_argument("--log_rewards", action="store_true", help="also log Training/Episode Reward (one more small launch per vector step)")
+    p.add_argument("--status_check_every", type=int, default=256,
+                   help="front loop: vector steps between reads of the front launch's status word (one host sync each; 0: only at every episode's end)")
+    p.add_argument("--on_front_trip", type=str, default="fallback", choices=["fallback", "exit"],
+                   help="a front launch's in-launch wait gave up: fallback = reload the newest snapshot and continue with --loop reference inside this process "
+                        "(exit code 3 when there is no snapshot yet); exit = always exit with code 3")
     p.add_argument("--replica_check_every", type=int, default=5, help="sharded runs: episodes between replica checksum comparisons (0: only at validation)")
     return p
 

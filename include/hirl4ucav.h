@@ -71,8 +71,9 @@ enum { HX_STAT_EPISODES = 0, HX_STAT_KILLS, HX_STAT_FIRE_SUCCESS_EPISODES, HX_ST
 const char* hx_last_error(void);
 /* HX_ABI_VERSION of the library that is loaded.  The structs below are part of the ABI: a caller built against another header version must
  * not call in (round 3 widened HxStepOpts.stats from 9 to HX_STAT_WAYS * HX_STAT_PITCH words and appended fields to HxNets / HxHyper without
- * bumping this: a 9-word stats buffer then took atomics up to word 504).  110: round 4 (hx_abi_sizes, hx_rccl_*, hx_allreduce_twostage). */
-#define HX_ABI_VERSION 112
+ * bumping this: a 9-word stats buffer then took atomics up to word 504).  110: round 4 (hx_abi_sizes, hx_rccl_*, hx_allreduce_twostage).
+ * 113: round 5. */
+#define HX_ABI_VERSION 113
 int hx_version(void);
 /* sizes[0..7] (host) <- sizeof HxStepOpts, HxNets, HxHyper, HxBatch, HxSample, HxSacNets, HxSacBatch, and the words of a statistics buffer
  * (HX_STAT_WAYS * HX_STAT_PITCH): a binding checks these against its own declarations at load time (hirl4ucav_amd/_lib.py does). */
@@ -503,6 +504,7 @@ int hx_allreduce_twostage(float* dst, const float* const* bufs, void* const* red
  * any channel, hx_rccl_init on every rank (collective; one GPU per rank), then hx_rccl_allreduce per message: buf <- sum over ranks, in place
  * (dtype 0 fp32, 1 bf16), the same bits on every rank.  SURVEY.md 8e: the flat critic gradient and the merged actor message.
  * ------------------------------------------------------------------------------------------------------------ */
+int hx_rccl_available(void); /* 0: the library and its entry points bind in this process (local, no collective) — ask on every rank before hx_rccl_init */
 int hx_rccl_unique_id(uint8_t* id128 /* host, out */);
 int hx_rccl_init(const uint8_t* id128 /* host */, int32_t world, int32_t rank, void** comm /* host, out */);
 int hx_rccl_allreduce(void* comm, void* buf, int64_t n, int32_t dtype, void* stream);

@@ -126,3 +126,73 @@ def test_env_shards_are_disjoint_streams_of_one_global_env_set():
     whole, _ = ox.reset_batch(128, 0, 1, seed=5, env_id0=0)
     np.testing.assert_array_equal(pos, whole[:, 0:3])  # two shards of 64 == one set of 128: no collective on the data path
     assert steps == 1280.0 and t == 2.0
+
+
+class _FakeConn:
+    """stands in for RcclDirect over gloo: counts close() calls"""
+
+    def __init__(self, uid, world, rank):
+        self.uid, self.world, self.rank, self.closed = uid, world, rank, 0
+
+    def close(self):
+        self.closed += 1
+
+
+def _negotiate(rank, world, port, case, out):
+    """exchange.negotiate_rccl_direct (what HirlEngine.use_rccl_direct runs) with one step failing on ONE rank: every rank must come back,
+    with the same decision, and a communicator built by the healthy ranks must be closed again (rank 0 failing before the id
+    broadcast left the other ranks waiting in it)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=30))  # a hang fails the test, not the suite
+    from hirl4ucav_amd.agents.exchange import negotiate_rccl_direct
+
+    step, bad = case
+    made = []
+
+    def boom(what):
+        raise RuntimeError(f"{what} fails on rank {rank}")
+
+    def available():
+        if step == "available" and rank == bad:
+            boom("available")
+
+    def make_id():
+        if step == "make_id":
+            boom("make_id")
+        return b"\x07" * 128
+
+    def connect(uid, w, r):
+        assert uid == b"\x07" * 128 and w == world and r == rank
+        c = _FakeConn(uid, w, r)
+        made.append(c)
+        if step == "connect" and rank == bad:
+            boom("connect")
+        return c
+
+    log = []
+    conn, why = negotiate_rccl_direct(None, "cpu", available=available, make_id=make_id, connect=connect, log=log.append)
+    out[rank] = (conn is not None, why, len(made), sum(c.closed for c in made), len(log))
+    dist.barrier()  # the process group is still usable: nobody is stuck in a collective the others left
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [("none", -1), ("make_id", 0), ("available", 0), ("available", 2), ("connect", 1)])
+def test_rccl_direct_negotiation_takes_one_decision_and_never_hangs(case):
+    world, port = 3, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_negotiate, args=(world, port, case, out), nprocs=world, join=True)
+        res = dict(out)
+    step, bad = case
+    assert len(res) == world
+    if step == "none":
+        assert all(r == (True, "", 1, 0, 0) for r in res.values())
+        return
+    assert all(not ok and why and logged == 1 for ok, why, _, _, logged in res.values())  # everyone falls back, everyone says why
+    if step == "connect":  # the healthy ranks built a communicator and gave it back
+        assert all(res[r][2] == 1 for r in range(world)) and all(res[r][3] == 1 for r in range(world) if r != bad)
+    else:                  # nobody entered the collective init
+        assert all(res[r][2] == 0 for r in range(world))
+    assert f"rank {bad}" in res[bad][1]

@@ -364,3 +364,73 @@ def test_validation_latches_success_at_the_first_done():
     assert all(int(f[i]) & _lib.F_EPISODE_SUCCESS for i in (0, 1, 2))  # the late kills DID happen in the simulator ...
     assert succ == 1 and fire == 1                                      # ... but only env 2's counts
     assert eng.act_calls == calls                                       # validation leaves the exploration-noise counter alone
+
+
+def test_front_trip_falls_back_to_the_reference_order_from_the_last_snapshot(tmp_path, capsys, monkeypatch):
+    """The front launch's in-launch waits lean on an undocumented dispatch order (include/hirl4ucav.h hx_hirl_front), so a wait that gives up must be cheap
+    to see and survivable: the driver reads the status word every --status_check_every vector steps, and on a trip reloads the newest snapshot and
+    continues in the reference's order (hirl/train_all.py:343-361: store, then sample) inside the same process — or exits with code 3 when there is
+    nothing to go back to.  The trip is injected at the host's read of the word (the kernels never produced one: tools/soak_front_roles.sh)."""
+    from hirl4ucav_amd import train_all as T
+    from hirl4ucav_amd.agents.engine import HirlEngine
+
+    common = ["--agent", "HIRL", "--type", "soft", "--env", "straight_line", "--random", "--seed", "3", "--num_envs", "256", "--buffer_size", "32768",
+              "--checkpoint_rate", "100", "--synthetic_expert", "--status_check_every", "16"]
+    reads = {"n": 0, "trip_at": 8}  # 48 steps per episode, a read every 16 steps + one at each episode's end: read 8 is the second read of episode 3
+
+    def status(self):
+        reads["n"] += 1
+        return 2 if reads["n"] == reads["trip_at"] else 0
+
+    monkeypatch.setattr(HirlEngine, "front_status", status)
+    T.MAX_STEP["straight_line"] = 48
+    try:
+        d = T.main(T.parser().parse_args(common + ["--episodes", "4", "--snapshot_every", "1", "--result_dir", str(tmp_path / "a")]))
+        out = capsys.readouterr().out
+        assert "status word 2: launch C waiting for launches A / B" in out and "back to the snapshot of episode 2" in out and "REFERENCE's order" in out
+        assert out.count("Episode 3:") == 1 and "Episode 4:" in out  # the tripped episode printed nothing; the run finished
+        snap = torch.load(os.path.join(d, "state_rank0.pt"), weights_only=False)
+        assert snap["driver"]["episode"] == 4
+        reads["n"] = 0  # ... and with nothing to go back to, or when told so: exit code 3
+        with pytest.raises(SystemExit) as e:
+            T.main(T.parser().parse_args(common + ["--episodes", "4", "--snapshot_every", "0", "--result_dir", str(tmp_path / "b")]))
+        assert e.value.code == 3 and "no snapshot to go back to" in capsys.readouterr().out
+        reads["n"] = 0
+        with pytest.raises(SystemExit) as e:
+            T.main(T.parser().parse_args(common + ["--episodes", "4", "--snapshot_every", "1", "--on_front_trip", "exit", "--result_dir", str(tmp_path / "c")]))
+        assert e.value.code == 3
+    finally:
+        T.MAX_STEP["straight_line"] = 1500
+
+
+def test_step_learn_that_is_refused_leaves_the_engine_as_it_was():
+    """step_learn advanced the host's counters before hx_hirl_front could refuse (here: a ring smaller than 2 n) — a caller that catches the
+    error was left with a host epoch ahead of the device's hand-off counters.  Counters are put back and the hand-off words start over."""
+    from hirl4ucav_amd import _lib
+    from hirl4ucav_amd.agents import engine as E
+    from hirl4ucav_amd.agents.HIRL import init_actor_state_dict, init_critic_state_dict
+    from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    n = 512
+    eng = E.HirlEngine(batch=128, use_bc=False, slope=0.01)
+    eng.load_params(init_actor_state_dict(), init_critic_state_dict())
+    small, big = DeviceReplay(768), DeviceReplay(1 << 14)
+    env = BatchedHarfangEnv(n, scenario="straight_line", seed=1, replay=big)
+    env.reset()
+    for _ in range(2):
+        env.step(torch.rand((n, 4), device="cuda") * 2 - 1)
+    eng.step_learn(env, None, None, act_sigma=0.1, sample_seed=5)
+    before = (eng._front_epoch, eng.critic_step, eng.actor_step, eng.update_count, eng.sample_calls, eng.act_calls, env.steps_issued, eng.actor_trainable)
+    env2 = BatchedHarfangEnv(n, scenario="straight_line", seed=1, replay=small)
+    env2.reset()
+    env2.step(torch.rand((n, 4), device="cuda") * 2 - 1)
+    issued2 = env2.steps_issued
+    with pytest.raises(_lib.HxError):
+        eng.step_learn(env2, None, None, act_sigma=0.1, sample_seed=5)
+    assert (0, eng.critic_step, eng.actor_step, eng.update_count, eng.sample_calls, eng.act_calls, env.steps_issued, eng.actor_trainable) == (eng._front_epoch,) + before[1:]
+    assert env2.steps_issued == issued2 and int(eng._front[0].abs().sum()) == 0 and eng.front_status() == 0
+    for _ in range(3):  # ... and the loop goes on (the first call draws with a launch of its own)
+        eng.step_learn(env, None, None, act_sigma=0.1, sample_seed=5)
+    eng.front_check()
+    assert np.isfinite(eng.losses_host()[0])
