@@ -165,6 +165,105 @@ __device__ __forceinline__ void head16(const float* zrow, const float* hp, int c
 #pragma unroll
     for (int j = 0; j < OUT; ++j) o[j] = sum16u(acc[j].x + acc[j].y) + hp[(2 + IMG) * H2 + j];
 }
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// [r5] LayerNorm 2 + final layer STRAIGHT FROM THE ACCUMULATORS of the 256 -> 512 product (the bf16 acting kernels: act_fused_body<.., BF16>,
+// act_persist_bf16_body).  Actor.forward hirl/agents/HIRL.py:132-140.
+// Until round 4 the z2 tile went to LDS (64 KB per 32 rows) and a 16-lane group per row read it three times (sum, centred squares, projection) beside
+// the whole head image (g2, be2, four W3 rows: 12 KB per ROW) — 650 KB of LDS reads per 32-row tile, an LDS pipe 62 % busy, and a ~2 us dependent chain
+// per head phase (tools/pmc_actp_passes.sh, profiles/r05_pmc_sq_actp_per_wave.txt).  Now, with the product's operands swapped (weights as A), lane
+// (lr, lg) of the wave that owns column group cw holds EIGHT values of row lr — columns 16 cw + 4 lg .. + 3 and 256 + 16 cw + 4 lg .. + 3 — and:
+//   1. the wave's 32 columns of a row give a PARTIAL (mean_w, M2_w = sum of squares about mean_w): 8 values per lane, then lanes l, l ^ 16, l ^ 32,
+//      l ^ 48 (v_permlane16_swap / v_permlane32_swap: two instructions per sum); one float2 per (row, column group) to LDS — 4 KB per 32 rows;
+//   2. behind ONE barrier the 16 partials of a row combine (Chan et al.'s pairwise update for equal counts: mean = sum mean_w / 16,
+//      M2 = sum M2_w + 32 sum (mean_w - mean)^2) IN COLUMN-GROUP ORDER — the statistics do not depend on which wave owned which group;
+//   3. h2 = act(LN2(z2)) of the lane's eight values, rounded to bf16, IS the B operand of one more v_mfma_f32_16x16x32_bf16 (K = the wave's 32
+//      columns; A = W3's four rows at those columns, bf16, twelve zero rows): its fp32 result, in the lg = 0 lanes, is the wave's share of the
+//      four pre-tanh outputs of row lr; 16 shares per row meet in LDS (16 bytes each) and are summed in column-group order + b3.
+// Numerics: the statistics agree with the two-pass form to fp32 rounding (M2 is a sum of centred squares at every level — no E[z^2] - mean^2
+// cancellation); the final layer's operands are bf16 like the 256 -> 512 product's (products exact in fp32, fp32 accumulation) — tests/test_bf16_gpu.py
+// states the rounded-operand reference accordingly.  Every kernel that uses these functions produces the same bits for a row.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// sum over lanes l, l ^ 16, l ^ 32, l ^ 48 (the four 16-lane rows of the wave), the same bits in all four: (row 0 + row 1) + (row 2 + row 3)
+__device__ __forceinline__ float sum_rows4(float v) {
+    // v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second: with both = v, the first comes back holding
+    // rows (0, 0, 2, 2) and the second rows (1, 1, 3, 3); v_permlane32_swap likewise for the wave's halves
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+constexpr int kPartPitch = 32;  // floats per row of the partial-statistics tile: 16 column groups x (mean_w, M2_w)
+// step 1 for one row tile: z0 / z1 = the lane's four values of column tile cw / 16 + cw (bias added).  Lanes lg == 0 store the pair.
+__device__ __forceinline__ void row_partial32(const v4f& z0, const v4f& z1, int lg, float* prow_cw) {
+    const float s = sum_rows4(((z0[0] + z0[1]) + (z0[2] + z0[3])) + ((z1[0] + z1[1]) + (z1[2] + z1[3])));
+    const float mw = s * (1.0f / 32.0f);
+    float q = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float d = z0[e] - mw;
+        q = __builtin_fmaf(d, d, q);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float d = z1[e] - mw;
+        q = __builtin_fmaf(d, d, q);
+    }
+    q = sum_rows4(q);
+    if (lg == 0) *reinterpret_cast<v2f*>(prow_cw) = v2f{mw, q};
+}
+// step 2: lane (lr, lg) reads the partials of column groups 4 lg .. 4 lg + 3 of its row (32 bytes); the four lanes of the row end with the same bits
+__device__ __forceinline__ void row_combine16(const float* prow, int lg, int no_ln, float& mean, float& rstd) {
+    const v4f p0 = *reinterpret_cast<const v4f*>(prow + 8 * lg), p1 = *reinterpret_cast<const v4f*>(prow + 8 * lg + 4);  // (m, M2, m, M2) x 2
+    mean = sum_rows4((p0[0] + p0[2]) + (p1[0] + p1[2])) * (1.0f / 16.0f);
+    const float e0 = p0[0] - mean, e1 = p0[2] - mean, e2 = p1[0] - mean, e3 = p1[2] - mean;
+    const float de = __builtin_fmaf(e3, e3, __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0)));
+    const float m2 = sum_rows4(__builtin_fmaf(32.0f, de, (p0[1] + p0[3]) + (p1[1] + p1[3])));
+    rstd = __builtin_amdgcn_rsqf(m2 * (1.0f / (float)H2) + LN_EPS);  // nn.LayerNorm: biased variance, eps inside the root (v_rsq_f32, as row_stats16)
+    if (no_ln) { mean = 0.0f; rstd = 1.0f; }
+}
+// step 3, the operand: h2 of the lane's eight values -> bf16 (round to nearest even) in the order of the final MFMA's k = 8 lg + e:
+// e < 4 column 16 cw + 4 lg + e, e >= 4 column 256 + 16 cw + 4 lg + e - 4.  hp: the LDS head image (g2 | be2 | ...), col0 = 16 cw + 4 lg
+template <bool RELU>
+__device__ __forceinline__ uint4 ln2_operand(const v4f& z0, const v4f& z1, float mean, float rstd, const float* hp, int col0, float slope) {
+    const v4f g0 = *reinterpret_cast<const v4f*>(hp + col0), g1 = *reinterpret_cast<const v4f*>(hp + 256 + col0);
+    const v4f b0 = *reinterpret_cast<const v4f*>(hp + H2 + col0), b1 = *reinterpret_cast<const v4f*>(hp + H2 + 256 + col0);
+    float h[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = ln_act<RELU>(z0[e], mean, rstd, g0[e], b0[e], slope);
+        h[4 + e] = ln_act<RELU>(z1[e], mean, rstd, g1[e], b1[e], slope);
+    }
+    return pack8_bf16(h);
+}
+// ... and the other operand: W3's rows at the same columns, for lane (i = lane & 15, g = lane >> 4) of the wave that owns column group cw —
+// output i < OUT, k = 8 g + e; zero rows beyond OUT (the MFMA tile is 16 wide).  Loaded once per workgroup from the fp32 parameters.
+__device__ __forceinline__ uint4 w3_fragment(const float* __restrict__ net, const Mlp& m, int cw, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = 0.0f;
+    if (i < m.out) {
+        const float* row = net + m.W3() + (size_t)i * H2 + 16 * cw + 4 * g;
+        const v4f a = *reinterpret_cast<const v4f*>(row), b = *reinterpret_cast<const v4f*>(row + 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            w[e] = a[e];
+            w[4 + e] = b[e];
+        }
+    }
+    return pack8_bf16(w);
+}
+// the last step for (row, component c): the 16 column groups' shares in group order + b3.  outp: [16 groups][rows][4]
+__device__ __forceinline__ float head_sum16(const float* outp, int rows, int row, int c, float b3) {
+    float p[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p[k] = outp[((size_t)k * rows + row) * 4 + c];
+#pragma unroll
+    for (int w = 1; w < 16; w *= 2)
+#pragma unroll
+        for (int k = 0; k < 16; k += 2 * w) p[k] += p[k + w];
+    return p[0] + b3;
+}
 #pragma clang fp contract(fast)
 
 // What follows the head for the row of lane (q, c), c < 4 = the action component: tanh, exploration noise, clamp (chooseAction*,
@@ -189,6 +288,14 @@ __device__ __forceinline__ float action_of(const ActFusedArgs& A, const float (&
         }
         return tanhf(a);
     }
+}
+
+// the same for ONE pre-tanh output o of component c (deterministic head; the [r5] bf16 kernels hold one output per lane)
+__device__ __forceinline__ float action_of1(const ActFusedArgs& A, float o, int c, int r, const float* s_noise) {
+    float a = fast_tanh(o);
+    if (A.noise) a = fminf(fmaxf(a + A.noise[(A.noise_per_row ? (size_t)r * 4 : 0) + c], -1.0f), 1.0f);
+    else if (A.sigma > 0.0f) a = fminf(fmaxf(a + A.sigma * s_noise[c], -1.0f), 1.0f);
+    return a;
 }
 
 // Rows beyond which the persistent kernel takes over (hx_actp.hip).  Up to here ONE round of 16- / 32-row workgroups covers the rows and

@@ -72,7 +72,7 @@ static void launch_act(const ActFusedArgs& H, hipStream_t st) {
         return;
     }
     if (GAUSS || H.slope == 0.0f) {
-        if (H.w2b) launch_act_t<GAUSS, true, true>(H, st);
+        if (!GAUSS && H.w2b) launch_act_t<false, true, true>(H, st);  // (no entry point hands a Gaussian policy a plain bf16 image: its bf16-core format is the exact split above)
         else if (H.w2f) launch_act_t<GAUSS, false, true, true>(H, st);
         else launch_act_t<GAUSS, false, true>(H, st);
     } else {

@@ -145,6 +145,8 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
     // BF16: which 32 columns this wave owns rotates with the workgroup, so that the 256 workgroups of a launch do not all ask L2 for
     // the same lines of the W2 image at the same moment
     const int cw = (BF16 || X3) ? ((wave + bid) & 15) : wave;
+    uint4 w3q = {0u, 0u, 0u, 0u};  // BF16: this lane's A fragment of the final layer (hx_act.h w3_fragment)
+    if constexpr (BF16) w3q = w3_fragment(net, m, cw, lane);
     if constexpr (BF16) {
         // requested only now, behind the prologue's own operands: every workgroup pulls the whole 256 KB image through L2 (64 MB per
         // launch at 4,096 rows, ~6 us of L2 service); issued at kernel entry those requests queue up in front of OTHER workgroups'
@@ -226,6 +228,19 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
     }
     __syncthreads();
     STAMP();
+    // ENV: the env lanes (wave 0, two lanes per env: hx_env_dev.h "Pair") request their state words and the current observation while the
+    // policy's last phases run
+    hxenv::Stepper<true> envT;
+    float envPrev[HX_OBS_DIM];
+    const int env_e = lane >> 1;            // env of this lane inside the workgroup's rows
+    const bool env_opp = (lane & 1) != 0;   // this lane owns the opponent aircraft
+    auto env_load = [&]() {
+        if (ENV && wave == 0 && env_e < nrow) {
+            envT.load(A.state, A.stride, r0, (uint32_t)env_e, env_opp);
+#pragma unroll
+            for (int j = 0; j < HX_OBS_DIM; ++j) envPrev[j] = (A.o.ring && env_opp) ? A.obs[((size_t)r0 + env_e) * HX_OBS_DIM + j] : 0.0f;
+        }
+    };
     {   // z2 tiles: columns 16*wave .. and 256 + 16*wave .. of every row tile; k ascending, chunk by chunk
         const int r = lane & 15, g = lane >> 4;
         v4f acc[NRT][2];
@@ -237,10 +252,11 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
             for (int sl = 0; sl < 8; ++sl) {
 #pragma unroll
                 for (int t = 0; t < NRT; ++t) {
+                    // [r5] operands swapped (weights as A, rows as B) as in act_persist_bf16_body: the same products in the same k order, and lane
+                    // (r, g) holds FOUR CONSECUTIVE columns 4 g .. + 3 of row r — what hx_act.h's "straight from the accumulators" steps take
                     const uint4 aq = *reinterpret_cast<const uint4*>(h1b + (t * RT + r) * LDB1 + 32 * sl + 8 * g);
-                    const v8bf a8 = __builtin_bit_cast(v8bf, aq);
-                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(v8bf, bq[0][sl]), acc[t][0], 0, 0, 0);
-                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(v8bf, bq[1][sl]), acc[t][1], 0, 0, 0);
+                    acc[t][0] = mfma16_bf16(bq[0][sl], aq, acc[t][0]);
+                    acc[t][1] = mfma16_bf16(bq[1][sl], aq, acc[t][1]);
                 }
             }
         }
@@ -366,6 +382,29 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
 #undef ACT_MUL
 #undef ACT_LOAD
 #undef ACT_STORE
+        if constexpr (BF16) {
+            // [r5] no z2 tile: bias, then the wave's partial LayerNorm-2 statistics of its 32 columns of rows r / 16 + r (hx_act.h, step 1) -> part
+            const v4f bb0 = *reinterpret_cast<const v4f*>(net + m.b2() + cw * 16 + 4 * g), bb1 = *reinterpret_cast<const v4f*>(net + m.b2() + 256 + cw * 16 + 4 * g);
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) {
+                acc[t][0] = acc[t][0] + bb0;
+                acc[t][1] = acc[t][1] + bb1;
+                row_partial32(acc[t][0], acc[t][1], g, z2s + (t * RT + r) * kPartPitch + 2 * cw);
+            }
+            himg.store(hps, net, m, tid);
+            env_load();
+            __syncthreads();
+            // steps 2, 3: LayerNorm 2 + activation from the accumulators, the final layer's share on the bf16 matrix cores -> outp[16 groups][ROWS][4]
+            float* const outp = z2s + ROWS * kPartPitch;
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) {
+                float mean, rstd;
+                row_combine16(z2s + (t * RT + r) * kPartPitch, g, m.no_ln, mean, rstd);
+                const uint4 hq = ln2_operand<RELU>(acc[t][0], acc[t][1], mean, rstd, hps, cw * 16 + 4 * g, slope);
+                const v4f o = mfma16_bf16(w3q, hq, v4f{0.f, 0.f, 0.f, 0.f});  // outputs 0..3 of row r in the g = 0 lanes
+                if (g == 0) *reinterpret_cast<v4f*>(outp + ((size_t)cw * ROWS + t * RT + r) * 4) = o;
+            }
+        } else {
         const float bb0 = net[m.b2() + cw * 16 + r], bb1 = net[m.b2() + 256 + cw * 16 + r];
 #pragma unroll
         for (int t = 0; t < NRT; ++t)
@@ -375,22 +414,25 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
                 z2s[(t * RT + 4 * g + q) * LDA2 + 256 + cw * 16 + r] = acc[t][1][q] + bb1;
             }
         himg.store(hps, net, m, tid);  // ... and h1 / x / W1 are dead: their LDS takes the head image
+        }
     }
     __syncthreads();
     STAMP();
-    // ENV: the env lanes (wave 0, two lanes per env: hx_env_dev.h "Pair") request their state words and the current observation
-    // now — the head phase hides the round trip
-    hxenv::Stepper<true> envT;
-    float envPrev[HX_OBS_DIM];
-    const int env_e = lane >> 1;            // env of this lane inside the workgroup's rows
-    const bool env_opp = (lane & 1) != 0;   // this lane owns the opponent aircraft
-    if (ENV && wave == 0 && env_e < nrow) {
-        envT.load(A.state, A.stride, r0, (uint32_t)env_e, env_opp);
-#pragma unroll
-        for (int j = 0; j < HX_OBS_DIM; ++j) envPrev[j] = (A.o.ring && env_opp) ? A.obs[((size_t)r0 + env_e) * HX_OBS_DIM + j] : 0.0f;
-    }
+    if (!BF16) env_load();  // (BF16: requested in front of the LayerNorm-2 steps above — the short last step would not hide the round trip)
     // head, 16 lanes per row (hx_act.h): waves 0 .. 4 NRT - 1, four rows each, the same rows as in the LN1 statistics
-    if (wave < kRowWaves) {
+    if constexpr (BF16) {
+        // [r5] the last step: waves 0 .. NRT - 1, a lane per (row, component) — the 16 column groups' shares in group order + b3, tanh, noise, clamp
+        static_assert(!(BF16 && GAUSS), "the bf16 acting format is the deterministic head's");
+        if (wave < NRT) {
+            const int lrow = wave * RT + (lane >> 2), c = lane & 3;
+            if (lrow < nrow) {
+                const float o = head_sum16(z2s + ROWS * kPartPitch, ROWS, lrow, c, hps[(2 + 4) * H2 + c]);
+                const float a = action_of1(A, o, c, r0 + lrow, s_noise + lrow * 4);
+                A.actions[(size_t)(r0 + lrow) * 4 + c] = a;
+                if (ENV) s_act[lrow * 4 + c] = a;
+            }
+        }
+    } else if (wave < kRowWaves) {
         const int lrow = wave + kRowWaves * gq;
         if (lrow < nrow) {
             const int r = r0 + lrow;

@@ -73,10 +73,12 @@ template <bool ENV>
 struct ActpLds {
     static constexpr int NRT = 2, TR = NRT * RT;
     typedef HeadImage<4> Img;
-    static constexpr int kLoop = TR * LDA1 + TR * LDA2 + TR * LDB1 / 2;  // h1s (fp32 pre-activations), z2s, h1b (bf16)
+    // the loop's tiles: h1s (fp32 pre-activations of layer 1), h1b (bf16 h1), the partial LayerNorm-2 statistics [TR][16 groups][2] and the column
+    // groups' shares of the outputs [2 tile parities][16 groups][TR][4] ([r5]: no z2 tile — hx_act.h "straight from the accumulators")
+    static constexpr int kLoop = TR * LDA1 + TR * LDB1 / 2 + TR * kPartPitch + 2 * 16 * TR * 4;
     static constexpr int kTail = ENV ? hxenv::kEnvBlockLds<true, kEnvPass> : 0;
     static constexpr int kUnion = kLoop > kTail ? kLoop : kTail;
-    __attribute__((aligned(16))) float lds[Img::kStride + TR * XP + 3 * H1 + H2 + kWide * 4 + 2 * TR * 4 + kUnion];
+    __attribute__((aligned(16))) float lds[Img::kStride + TR * XP + 3 * H1 + H2 + 2 * kWide * 4 + 2 * TR * 4 + kUnion];
     unsigned s_slot0;
     int s_wcount[kWide / 64];
 };
@@ -88,16 +90,18 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
     float* const lds = SL.lds;
     unsigned& s_slot0 = SL.s_slot0;
     int* const s_wcount = SL.s_wcount;
-    float* hps = lds;
+    float* hps = lds;                   // g2 | be2 | (W3 rows: unused here, the final layer's operand lives in w3t) | b3
     float* xs = hps + Img::kStride;
     float* g1s = xs + TR * XP;          // LayerNorm 1 weight | bias, read four columns at a time
     float* b1s = g1s + 2 * H1;          // full1.bias
     float* b2s = b1s + H1;              // full2.bias
     float* w1t = b2s + H2;              // [1024][4]: every lane's four layer-1 A fragments of W1 (zero beyond the 13 inputs): one 16-byte read per tile
-    float* s_noise = w1t + kWide * 4;   // [2][TR][4]: the draws of tile t live in half t & 1
+    float* w3t = w1t + kWide * 4;       // [1024][4]: every lane's A fragment of the final layer (bf16 x 8: W3 at the wave's 32 columns, hx_act.h w3_fragment)
+    float* s_noise = w3t + kWide * 4;   // [2][TR][4]: the draws of tile t live in half t & 1
     float* h1s = s_noise + 2 * TR * 4;
-    float* z2s = h1s + TR * LDA1;
-    __bf16* h1b = reinterpret_cast<__bf16*>(z2s + TR * LDA2);
+    __bf16* h1b = reinterpret_cast<__bf16*>(h1s + TR * LDA1);
+    float* part = h1s + TR * LDA1 + TR * LDB1 / 2;  // [TR][16][2]
+    float* outp = part + TR * kPartPitch;           // [2][16][TR][4]
     const int tid0 = threadIdx.x;
     const int row_begin = bid * tiles_per_wg * TR;
     if (row_begin >= A.rows) return;
@@ -128,6 +132,7 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
         himg.fetch(net, m, tid);
         // which 32 columns this wave owns rotates with the workgroup: the workgroups of a launch do not all ask L2 for the same lines at once
         const int cw = (wave + bid) & 15;
+        const uint4 w3q = w3_fragment(net, m, cw, lane);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const uint16_t* blk = A.w2b + (size_t)((t * 16 + cw) * 8) * 512 + lane * 8;  // (lane = 16 g + r: w2_image_index's block order)
@@ -135,6 +140,7 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
             for (int sl = 0; sl < 8; ++sl) bq[t][sl] = *reinterpret_cast<const uint4*>(blk + sl * 512);
         }
         *reinterpret_cast<float4*>(w1t + tid * 4) = make_float4(w1f[0], w1f[1], w1f[2], 12 + lg < 13 ? w1f[3] : 0.0f);  // (only 4 mm + lg = 13..15 are beyond)
+        *reinterpret_cast<uint4*>(w3t + tid * 4) = w3q;
         if (tid < H1) b1s[tid] = b1v;
         if (tid < 2 * H1) g1s[tid] = gb;
         if (tid < H2) b2s[tid] = b2v;
@@ -147,21 +153,24 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
     }
     const bool draw_noise = !A.noise && A.sigma > 0.0f;
     STAMP();
-    // ---- the tile loop: iteration i runs tile i's layer 1 / LayerNorm 1 and tile i - 1's product and head, two barriers per tile ------
-    for (int i = 0; i <= ntile; ++i) {
+    // ---- the tile loop, two barriers per tile, three tiles in flight: iteration i runs layer 1 / LayerNorm 1 of tile i, the product, LayerNorm 2 and
+    //      the final layer's shares of tile i - 1, and the last sum + tanh + noise of tile i - 2 -----------------------------------------
+    v4f acc[NRT][2];  // z2 of tile i - 1: this lane's 4 + 4 columns of rows lr and 16 + lr — alive from the product (P1) across barrier A into P2
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) acc[t][0] = acc[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i <= ntile + 1; ++i) {
         // The lane's LDS addresses are loop invariants, and with 64 registers of weights resident the allocator spills them; behind this
         // opaque copy of the thread id they are recomputed per tile (a few VALU instructions) instead of living across the loop.
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         const int lr = lane & 15, lg = lane >> 4;
-        const int r0p = row_begin + (i - 1) * TR;  // first row of tile i - 1
         const int cw = (wave + bid) & 15;
+        const bool mid = i >= 1 && i <= ntile;  // tile i - 1 exists
         // P1: z2(i - 1) = h1(i - 1) W2^T (bf16 matrix cores, weights from registers) | layer 1 of tile i (fp32 matrix cores).
         // Both products run with the MFMA operands swapped (weights as A, rows as B): the same products in the same k order, but lane
-        // (lr, lg) then holds FOUR CONSECUTIVE columns of row lr — 16-byte LDS stores instead of four conflicting dword stores each.
-        if (i >= 1) {
-            v4f acc[NRT][2];
+        // (lr, lg) then holds FOUR CONSECUTIVE columns of row lr.
+        if (mid) {
 #pragma unroll
             for (int t = 0; t < NRT; ++t) acc[t][0] = acc[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
             // K = 256 in 8 slabs of 32: lane (r, g) holds h1[row r][32 sl + 8 g ..+7] and W2[col r][32 sl + 8 g ..+7].  (One register set for
@@ -196,29 +205,45 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
 #pragma unroll
                 for (int t = 0; t < NRT; ++t) *reinterpret_cast<v4f*>(h1s + (t * RT + lr) * LDA1 + wave * 16 + 4 * lg) = acc1[t];
             }
+            // bias, then the wave's partial LayerNorm-2 statistics of its 32 columns of rows lr / 16 + lr (hx_act.h: step 1)
             const v4f bb0 = *reinterpret_cast<const v4f*>(b2s + cw * 16 + 4 * lg), bb1 = *reinterpret_cast<const v4f*>(b2s + 256 + cw * 16 + 4 * lg);
 #pragma unroll
-            for (int t = 0; t < ((HX_PX & 16) ? 0 : NRT); ++t) {
-                *reinterpret_cast<v4f*>(z2s + (t * RT + lr) * LDA2 + cw * 16 + 4 * lg) = acc[t][0] + bb0;
-                *reinterpret_cast<v4f*>(z2s + (t * RT + lr) * LDA2 + 256 + cw * 16 + 4 * lg) = acc[t][1] + bb1;
+            for (int t = 0; t < NRT; ++t) {
+                acc[t][0] = acc[t][0] + bb0;
+                acc[t][1] = acc[t][1] + bb1;
+                if (!(HX_PX & 1)) row_partial32(acc[t][0], acc[t][1], lg, part + (t * RT + lr) * kPartPitch + 2 * cw);
             }
-        } else if (!(HX_PX & 8)) {
+        } else if (i == 0 && !(HX_PX & 8)) {
             const v4f w1v = *reinterpret_cast<const v4f*>(w1t + tid * 4);
             const float w1f[4] = {w1v[0], w1v[1], w1v[2], w1v[3]};
             layer1_tiles<NRT>(xs, w1f, *reinterpret_cast<const v4f*>(b1s + wave * 16 + 4 * lg), wave, lr, lg, h1s);
         }
-        __syncthreads();  // A: z2 of tile i - 1 and the pre-activations of tile i are in LDS; xs and h1b are free
-        // P2 (16 lanes per row, hx_act.h): waves 0-7 the head of tile i - 1, waves 8-15 LayerNorm 1 + activation of tile i -> bf16 h1;
-        // a wave's four rows are eight apart (pitch = 8 mod 64 dwords: their 16-byte reads fall on disjoint banks)
-        const int gq = lane >> 4, gc = lane & 15;
-        if (wave < 8) {
-            const int lrow = wave + 8 * gq;
-            if (i >= 1 && r0p + lrow < row_end && !(HX_PX & 1)) {
-                float o[4];
-                head16<4, 4, RELU, !(HX_PX & 64)>(z2s + lrow * LDA2, hps, gc, slope, m.no_ln, o);
-                if (gc < 4) A.actions[(size_t)(r0p + lrow) * 4 + gc] = action_of<false>(A, o, gc, r0p + lrow, s_noise + ((i - 1) & 1) * TR * 4 + lrow * 4);
+        __syncthreads();  // A: the partial statistics of tile i - 1 and the pre-activations of tile i are in LDS; xs and h1b are free
+        // P2, every wave: LayerNorm 2 + activation of its 32 columns of tile i - 1 from the accumulators, the final layer's share on the bf16 matrix
+        // cores (hx_act.h: steps 2, 3) -> outp[(i - 1) & 1]
+        if (mid && !(HX_PX & 1)) {
+            const uint4 w3q = *reinterpret_cast<const uint4*>(w3t + tid * 4);
+            float* const op = outp + (size_t)(((i - 1) & 1) * 16 + cw) * TR * 4;
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) {
+                float mean, rstd;
+                row_combine16(part + (t * RT + lr) * kPartPitch, lg, m.no_ln, mean, rstd);
+                const uint4 hq = ln2_operand<RELU>(acc[t][0], acc[t][1], mean, rstd, hps, cw * 16 + 4 * lg, slope);
+                const v4f o = mfma16_bf16(w3q, hq, v4f{0.f, 0.f, 0.f, 0.f});  // D[i = 4 lg + q][j = lr]: outputs 0..3 of row lr in the lg = 0 lanes
+                if (lg == 0) *reinterpret_cast<v4f*>(op + (t * RT + lr) * 4) = o;
             }
-        } else {
+        }
+        // waves 0, 1: the last step of tile i - 2 — its 16 shares per output in column-group order + b3, tanh, exploration noise, clamp (a lane per
+        // (row, component): 256 contiguous bytes of actions per wave); waves 8-15: LayerNorm 1 + activation of tile i -> bf16 h1 (16 lanes per
+        // row, hx_act.h; a wave's four rows are eight apart: pitch = 8 mod 64 dwords, their 16-byte reads fall on disjoint banks)
+        const int gq = lane >> 4, gc = lane & 15;
+        if (wave < 2) {
+            const int lrow = wave * 16 + (lane >> 2), c = lane & 3, r = row_begin + (i - 2) * TR + lrow;
+            if (i >= 2 && r < row_end && !(HX_PX & 1)) {
+                const float o = head_sum16(outp + (size_t)((i & 1) * 16) * TR * 4, TR, lrow, c, hps[(2 + 4) * H2 + c]);
+                A.actions[(size_t)r * 4 + c] = action_of1(A, o, c, r, s_noise + (i & 1) * TR * 4 + lrow * 4);
+            }
+        } else if (wave >= 8) {
             if (i < ntile && !(HX_PX & 2)) {
                 const int row = wave - 8 + 8 * gq;
                 float v[16];
@@ -236,19 +261,19 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
                     for (int e = 0; e < 4; ++e) hb[e] = (__bf16)ln_act<RELU>(v[4 * k + e], mean, rstd, g[e], be[e], slope);  // round to nearest even
                     *reinterpret_cast<v4bf*>(h1b + row * LDB1 + 64 * k + 4 * gc) = hb;
                 }
-                // the exploration noise of tile i (its head runs in the next iteration): one wave, a lane per (row, Box-Muller pair)
-                if (draw_noise && wave == kWide / 64 - 1 && !(HX_PX & 32)) {
-                    float nc, ns;
-                    philox_normal_pair(A.row0 + (uint32_t)(row_begin + i * TR + (lane >> 1)), A.call, 0x61637421u, A.seed, lane & 1, nc, ns);
-                    *reinterpret_cast<float2*>(s_noise + (i & 1) * TR * 4 + lane * 2) = make_float2(nc, ns);
-                }
+            }
+            // the exploration noise of tile i - 1 (its last step runs in the next iteration, reading the other half): one wave, a lane per (row, Box-Muller pair)
+            if (draw_noise && mid && wave == kWide / 64 - 1 && !(HX_PX & 32)) {
+                float nc, ns;
+                philox_normal_pair(A.row0 + (uint32_t)(row_begin + (i - 1) * TR + (lane >> 1)), A.call, 0x61637421u, A.seed, lane & 1, nc, ns);
+                *reinterpret_cast<float2*>(s_noise + ((i - 1) & 1) * TR * 4 + lane * 2) = make_float2(nc, ns);
             }
         }
         if (i + 1 < ntile) {
             if (tid < TR * 13) xs[(tid / 13) * XP + tid % 13] = xv;
             xv = obs_of(i + 2, tid);
         }
-        __syncthreads();  // B: h1 of tile i (bf16) and the next observation tile are in LDS; every read of z2 is done
+        __syncthreads();  // B: h1 of tile i (bf16), the next observation tile and the output shares of tile i - 1 are in LDS; the partial statistics are free
     }
     STAMP();
     if (ENV) env_tail((KernArgs)__builtin_amdgcn_kernarg_segment_ptr(), row_begin, row_end, h1s, &s_slot0, s_wcount, bid, nwg);  // (barrier B: every action of the block is written; the launch description is the kernel's FIRST argument)

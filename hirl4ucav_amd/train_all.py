@@ -256,7 +256,7 @@ def main(config):
     if rank == 0:
         print(f"seed {seed}" + (" (from the snapshot)" if snap_seed is not None else "" if config.seed is not None else " (drawn: no --seed given)"), flush=True)
     env_type, n = config.env, config.num_envs
-    max_step = MAX_STEP[env_type] * (8 if config.render else 1)
+    max_step = (int(config.max_step) if getattr(config, "max_step", None) else MAX_STEP[env_type]) * (8 if config.render else 1)
     if config.agent == "BC":
         return train_bc(config, device, seed, max_step)
     hirl = config.agent == "HIRL"
@@ -546,6 +546,7 @@ def parser():
     p.add_argument("--load_dir", type=str, default=None, help="--load_model: directory of the checkpoint files (default: this run's model dir)")
     p.add_argument("--load_tag", type=str, default="Agent20_successRate0.64", help="--load_model: checkpoint tag (train_all.py:240 hard-codes this one)")
     p.add_argument("--log_rewards", action="store_true", help="also log Training/Episode Reward (one more small launch per vector step)")
+    p.add_argument("--max_step", type=int, default=None, help="steps per episode (default: the scenario's, train_all.py:159-183: 1500 / 1500 / 1900); short rehearsal runs")
     p.add_argument("--status_check_every", type=int, default=256,
                    help="front loop: vector steps between reads of the front launch's status word (one host sync each; 0: only at every episode's end)")
     p.add_argument("--on_front_trip", type=str, default="fallback", choices=["fallback", "exit"],

@@ -1,6 +1,6 @@
-"""Run under `python -m torch.distributed.run --nproc-per-node 2 ... tests/_sharded_check.py {rccl|oneshot|twostage|twostage-bf16}` (gloo, both ranks on the one GPU
-of the box): K sharded learn() calls of the PRODUCT engine — each rank its own minibatch of 128, ONE exchange per phase — against a
-single engine of batch 256 fed the two minibatches concatenated (the same global batch).  Rank 0 prints SHARDED_OK."""
+"""Run under `python -m torch.distributed.run --nproc-per-node W ... tests/_sharded_check.py {rccl|oneshot|twostage|twostage-bf16}` (gloo, all W ranks on the one GPU
+of the box; W = 2, 3, 8): K sharded learn() calls of the PRODUCT engine — each rank its own minibatch of 128, ONE exchange per phase — against a
+single engine of batch 128 W fed the minibatches concatenated (the same global batch).  Rank 0 prints SHARDED_OK."""
 import os
 import sys
 
@@ -43,7 +43,7 @@ def main(exchange):
     out = {k: getattr(e, k).cpu().numpy() for k in ("actor", "critic", "target_actor", "target_critic")}
     out["losses"] = np.asarray(e.losses_host())
     if rank == 0:
-        np.savez(os.environ["SHARDED_OUT"], **out, exchange=np.asarray(e.exchange_name))
+        np.savez(os.environ["SHARDED_OUT"], **out, exchange=np.asarray(e.exchange_name), world=np.asarray(world))
         print("SHARDED_OK", e.exchange_name, flush=True)
     if e.xchg is not None:
         torch.distributed.barrier()

@@ -224,3 +224,43 @@ def test_driver_two_ranks(agent, tmp_path):
     assert p.returncode == 0, p.stderr[-3000:]
     assert "Episode 2:" in p.stdout and "Validation 1:" in p.stdout and "diverged" not in p.stderr
     assert p.stdout.count("Episode 2:") == 1  # rank 0 reports
+
+
+# ---- the 8-rank forms (BASELINE.json configs[3] / configs[4]: 8 x MI355X), rehearsed with all ranks on the box's one GPU ---------------------------------
+# No 8-GPU node is available to this suite; what CAN run before the first scaling measurement is everything except the wire: the launcher at 8, eight
+# env shards with their own rings, kMaxWorld flag / red arrays and seven hipIpc mappings per rank, the 8-way slices of the two-stage exchange, the
+# replica check over eight checksums.  rccl_ranks.distinct_gpus says 1 — that is the point of recording it.
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.parametrize("extra", [[], TWOSTAGE])
+def test_bench_eight_ranks_on_one_gpu(extra):
+    """`python bench.py --gpus 8` with no launcher environment: the bench starts its eight ranks itself (gloo for the RCCL-shaped path / the two-stage
+    peer-read kernels over hipIpc); the JSON line is kept under gpurun_out/ for profiles/."""
+    peer = bool(extra)
+    steps, warm = ("12", "2") if peer else ("60", "10")
+    d = run([sys.executable, "bench.py", "--gpus", "8", "--steps", steps, "--warmup", warm, "--no-sweep", "--no-cpu-baseline", "--settle-s", "0" if peer else "0.2"] + extra,
+            env={"HX_BENCH_BACKEND": "gloo"})
+    check(d, 8, int(steps), int(warm))
+    rr = d["rccl_ranks"]
+    assert rr["world_size"] == 8 and rr["distinct_gpus"] == 1 and rr["exchange"] == ("twostage" if peer else "rccl")
+    assert d["replicas_identical"] is True and len(d["allreduce"]) == 2 and d["env_stats"]["env_steps"] > 0
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"r05_bench_8ranks_one_gpu_{'twostage' if peer else 'gloo'}.json"), "w") as f:
+        json.dump(d, f)
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_driver_eight_ranks_started_by_the_driver(tmp_path):
+    """`python -m hirl4ucav_amd.train_all --gpus 8 ...` without a launcher environment: the driver starts its eight ranks as a child (launch_ranks), each
+    with its env shard (env ids [r n, (r + 1) n)) and ring; 10 short episodes of configs[3]'s agent (HIRL-linear, circular) with the replica check every 5."""
+    p = subprocess.run([sys.executable, "-m", "hirl4ucav_amd.train_all", "--gpus", "8", "--agent", "HIRL", "--type", "linear", "--env", "circular", "--seed", "1",
+                        "--num_envs", "512", "--episodes", "10", "--max_step", "24", "--checkpoint_rate", "10", "--snapshot_every", "5", "--synthetic_expert",
+                        "--buffer_size", "65536", "--result_dir", str(tmp_path)],
+                       cwd=ROOT, env={**os.environ, "HX_DIST_BACKEND": "gloo"}, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    assert p.stdout.count("Episode 10:") == 1 and "Validation 1:" in p.stdout and "diverged" not in p.stderr
+    run_dir = [os.path.join(dp, d) for dp, ds, _ in os.walk(tmp_path) for d in ds if d == "model"]
+    assert len(run_dir) == 1  # ONE run directory for all ranks ...
+    shards = sorted(f for f in os.listdir(os.path.dirname(run_dir[0])) if f.startswith("state_rank"))
+    assert shards == [f"state_rank{r}.pt" for r in range(8)]  # ... holding every rank's shard of the snapshot

@@ -2,8 +2,10 @@
 (hx_actor_act_bf16 / hx_actor_act_step_bf16 / hx_pack_w2_bf16).
 
 Tolerances, stated separately from the fp32 path's 1e-5 (SURVEY.md 7 "bf16 config"):
-  * against an fp32 evaluation of the SAME rounded operands (W2 and h1 rounded to bf16, everything else fp32): 99 % of the outputs
-    within 1e-4 (only the accumulation order of the 256-long dot products differs) and all within 2e-3 (an h1 element whose fp32
+  * against an fp32 evaluation of the SAME rounded operands — both MATRIX PRODUCTS of the policy beyond its 13-wide input layer take bf16 operands
+    since round 5: W2 and h1 (256 -> 512), and W3 and h2 = act(LN2(z2)) (512 -> 4: the final layer rides on the bf16 matrix cores straight from the
+    accumulators, hirl4ucav_amd/csrc/hx_act.h "[r5]"); layer 1, both LayerNorms, biases, tanh stay fp32: 99 % of the outputs
+    within 1e-4 (only the accumulation order of the dot products differs) and all within 2e-3 (an h1 / h2 element whose fp32
     value sits within an ulp of a bf16 rounding boundary may round the other way in the kernel than in torch: one 2^-9 step);
   * against the full-fp32 policy: |da| <= 2e-2 on the tanh outputs, mean |da| <= 2e-3 (8 significant bits on two operands).
 Dynamics, masks, rewards stay exactly what the env step computes from the actions it is given: checked bit for bit."""
@@ -40,14 +42,16 @@ def mods():
 
 
 def rounded_operand_policy(p, x):
-    """Actor.forward (HIRL.py:126-140) in fp32 with the two operands of the 256 -> 512 product rounded to bf16 first."""
+    """Actor.forward (HIRL.py:126-140) in fp32 with the operands of the 256 -> 512 and of the 512 -> 4 product rounded to bf16 first."""
     p = {k: torch.as_tensor(v) for k, v in p.items()}
     h = F.relu(F.layer_norm(F.linear(x, p["full1.weight"], p["full1.bias"]), (256,), p["layernorm1.weight"], p["layernorm1.bias"], 1e-5))
     hb = h.to(torch.bfloat16).to(torch.float32)
     w2 = p["full2.weight"].to(torch.bfloat16).to(torch.float32)
     z2 = F.linear(hb.double(), w2.double(), p["full2.bias"].double()).float()  # exact products, fp64 sums: the reference value
     h2 = F.relu(F.layer_norm(z2, (512,), p["layernorm2.weight"], p["layernorm2.bias"], 1e-5))
-    return torch.tanh(F.linear(h2, p["final.weight"], p["final.bias"]))
+    h2b = h2.to(torch.bfloat16).to(torch.float32)
+    w3 = p["final.weight"].to(torch.bfloat16).to(torch.float32)
+    return torch.tanh(F.linear(h2b.double(), w3.double(), p["final.bias"].double()).float())
 
 
 def close_to_rounded_operands(a, ref):

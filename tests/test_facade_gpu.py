@@ -376,7 +376,7 @@ def test_front_trip_falls_back_to_the_reference_order_from_the_last_snapshot(tmp
 
     common = ["--agent", "HIRL", "--type", "soft", "--env", "straight_line", "--random", "--seed", "3", "--num_envs", "256", "--buffer_size", "32768",
               "--checkpoint_rate", "100", "--synthetic_expert", "--status_check_every", "16"]
-    reads = {"n": 0, "trip_at": 8}  # 48 steps per episode, a read every 16 steps + one at each episode's end: read 8 is the second read of episode 3
+    reads = {"n": 0, "trip_at": 10}  # 48 steps per episode, a read every 16 steps + one at each episode's end = 4 per episode: read 10 is the second of episode 3
 
     def status(self):
         reads["n"] += 1

@@ -235,12 +235,14 @@ def test_front_loop_free_running(eng_mod):
     assert int(rep_a.total.item()) > 8192
 
 
-@pytest.mark.parametrize("n", [32, 768])
+@pytest.mark.parametrize("n", [32, 768, 4096])
 def test_front_loop_against_the_oracles(eng_mod, n):
     """The front loop checked against the CHECKERS directly, step by step (not only against the separate launches): its env step == the C env oracle
     stepped with the actions the launch chose (done / success flags exact, observations and rewards 1e-5); its learn() == the update oracle (pinned to
     the reference's Agent.learn) on the minibatch the loop drew, from synchronised states: losses 2e-5 and — with 32 envs, ONE acting workgroup, where the
-    order of the replay rows and with it the whole run is reproducible — every parameter within check_params' bars.  (With several acting workgroups the
+    order of the replay rows and with it the whole run is reproducible — every parameter within check_params' bars.  n = 4096 is the HEADLINE's shape
+    (BASELINE.json configs[1]: 128 acting workgroups of 32 rows in the exact-split format, launches A and B beside them): it meets both oracles in one hop,
+    not only through the bit-identity with the separate launches.  (With several acting workgroups the
     ring slots are handed out by an atomic, every run draws other minibatches, and one in ~500 of them holds a parameter whose gradient sits on a ReLU kink:
     tools/ubench/front_oracle_stress.py shows the separate launches missing the bar on exactly the same entries, bit for bit.)"""
     from oracle import hirl_oracle as H
@@ -258,7 +260,7 @@ def test_front_loop_against_the_oracles(eng_mod, n):
     bc_t = torch.from_numpy(bc).cuda()
     exp = DeviceReplay(D.N_EXPERT)
     exp.store_rows(torch.from_numpy(data["expert_rows"]))
-    rep = DeviceReplay(4096)
+    rep = DeviceReplay(max(4096, 4 * n))
     env = BatchedHarfangEnv(n, scenario="straight_line", seed=1, auto_reset=False, replay=rep)
     env.reset()
     envs, oobs = ox.reset_batch(n, 0, 1, seed=1)

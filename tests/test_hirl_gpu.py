@@ -390,6 +390,48 @@ def test_learn_ragged_batches_and_outlier_rows(eng_mod):
             check_params(e, o, eng_mod, f"B={B} call {k} params", was_actor_call)
 
 
+@pytest.mark.parametrize("guard,tot", [(0, 700), (0, 431), (150, 3 * 700 + 620), (150, 400)])
+def test_device_draw_is_uniform(eng_mod, guard, tot):
+    """UniformMemory.sample is random.sample(population, batchSize) (hirl/utils/buffer.py:45): every slot of the population equally likely, no duplicates
+    inside a minibatch.  test_device_sampler / test_guarded_draw_covers_its_population prove support and distinctness; this is the FREQUENCY: 4,000 draws
+    of 128 from a 700-slot ring (full / part full; unguarded, and the front loop's guarded draw that leaves out the 150 slots behind the ring head).
+    A slot's count over K draws is Binomial(K, 128/P) and the counts are exchangeable with sum 128 K, so (P-1)/P * sum (c - K p)^2 / (K p (1-p)) is
+    chi-square with P - 1 degrees of freedom; the Philox streams are keyed by (seed, call), so the statistic is the same on every run — no flake.
+    Position r of the minibatch must not prefer slots either (the LDS hash set resolves collisions by re-drawing): first and last position checked alone."""
+    from scipy import stats
+
+    from hirl4ucav_amd import _lib
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    cap, B, K = 700, 128, 4000
+    rep = DeviceReplay(cap)
+    rep.total.fill_(tot)
+    e = eng_mod.HirlEngine(batch=B, use_bc=False)
+    live = np.arange(min(tot, cap))
+    pop = np.setdiff1d(live, (tot + np.arange(guard)) % cap)
+    P = len(pop)
+    counts = torch.zeros(cap, dtype=torch.int64, device="cuda")
+    first, last = torch.zeros_like(counts), torch.zeros_like(counts)
+    for call in range(1, K + 1):
+        _lib.call("hx_sample_batch_guarded", rep.total.data_ptr(), cap, rep.ring.data_ptr(), None, 0, None, 0, B, B, 1, 12345, call, 0.2,
+                  e._idx.data_ptr(), None, e._noise.data_ptr(), e.rows.data_ptr(), None, guard, _lib.stream_ptr())
+        i = e._idx.to(torch.int64)
+        counts += torch.bincount(i, minlength=cap)
+        first[i[0]] += 1
+        last[i[B - 1]] += 1
+    c = counts.cpu().numpy()
+    assert c.sum() == K * B and c[np.setdiff1d(np.arange(cap), pop)].sum() == 0  # nothing outside the population
+    p = B / P
+    chi = (P - 1) / P * (((c[pop] - K * p) ** 2).sum() / (K * p * (1 - p)))
+    pv = stats.chi2.sf(chi, P - 1)
+    assert 1e-3 < pv < 1 - 1e-3, (guard, tot, P, chi, pv)  # not too uneven — and not too even either (a permutation walk would be)
+    for name, v in (("first", first), ("last", last)):
+        f = v.cpu().numpy()[pop]
+        chi1 = ((f - K / P) ** 2).sum() / (K / P)
+        pv1 = stats.chi2.sf(chi1, P - 1)
+        assert 1e-3 < pv1 < 1 - 1e-3, (name, guard, tot, chi1, pv1)
+
+
 def test_device_sampler(eng_mod):
     """hx_sample_batch: indices inside the live part of each table, no duplicates inside a group (random.sample /
     np.random.choice(replace=False) semantics), deterministic per (seed, call), ring length read on the device, and the
