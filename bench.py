@@ -968,9 +968,13 @@ def run_rank(args):
             flop, peak = fp32_equiv, BF16_MATRIX_PEAK_TFLOPS
         if loop.front and args.agent != "sac":  # + the forward passes of launches A and B over the minibatch: 3 + 2 nets on a critic-only call, 4 + 4 on an actor call (every 2nd)
             flop += int(6.5 * args.batch * ACTOR_FLOP)
-        tf, gb = flop / us / 1e6, ENV_BYTES_FUSED * args.envs / us / 1e3
+        # algorithmic bytes of the launch: 550 B per env step — and, for the front launch, the five networks of launches A and B read once
+        # (target actor, critic x 2, target critic x 2: the figure tools/pmc_traffic_json.py sets the counter passes against; VERDICT r4: the flop side
+        # already counted A and B, the byte side did not)
+        nbytes = ENV_BYTES_FUSED * args.envs + (4 * (138756 + 4 * 138244) if (loop.front and args.agent != "sac") else 0)
+        tf, gb = flop / us / 1e6, nbytes / us / 1e3
         mf, hf = tf / peak, gb / HBM_PEAK_GBPS
-        hbm = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hf, 4), "bytes_per_launch": ENV_BYTES_FUSED * args.envs}
+        hbm = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hf, 4), "bytes_per_launch": nbytes}
         mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(mf, 4), "flop_per_launch": flop}
         if x9:  # the fp32 product runs as 9 bf16 MFMAs per 32 k (exact split, fp32 accumulate): what the matrix cores EXECUTE, against their bf16 peak
             ex = flop + 8 * 2 * 256 * 512 * args.envs

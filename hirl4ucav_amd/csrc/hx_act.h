@@ -225,13 +225,17 @@ __device__ __forceinline__ void row_combine16(const float* prow, int lg, int no_
 // e < 4 column 16 cw + 4 lg + e, e >= 4 column 256 + 16 cw + 4 lg + e - 4.  hp: the LDS head image (g2 | be2 | ...), col0 = 16 cw + 4 lg
 template <bool RELU>
 __device__ __forceinline__ uint4 ln2_operand(const v4f& z0, const v4f& z1, float mean, float rstd, const float* hp, int col0, float slope) {
-    const v4f g0 = *reinterpret_cast<const v4f*>(hp + col0), g1 = *reinterpret_cast<const v4f*>(hp + 256 + col0);
-    const v4f b0 = *reinterpret_cast<const v4f*>(hp + H2 + col0), b1 = *reinterpret_cast<const v4f*>(hp + H2 + 256 + col0);
     float h[8];
+    {
+        const v4f g0 = *reinterpret_cast<const v4f*>(hp + col0), b0 = *reinterpret_cast<const v4f*>(hp + H2 + col0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        h[e] = ln_act<RELU>(z0[e], mean, rstd, g0[e], b0[e], slope);
-        h[4 + e] = ln_act<RELU>(z1[e], mean, rstd, g1[e], b1[e], slope);
+        for (int e = 0; e < 4; ++e) h[e] = ln_act<RELU>(z0[e], mean, rstd, g0[e], b0[e], slope);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (one column tile's eight LayerNorm parameters at a time: with all sixteen requested up front the persistent kernel spills)
+    {
+        const v4f g1 = *reinterpret_cast<const v4f*>(hp + 256 + col0), b1 = *reinterpret_cast<const v4f*>(hp + H2 + 256 + col0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[4 + e] = ln_act<RELU>(z1[e], mean, rstd, g1[e], b1[e], slope);
     }
     return pack8_bf16(h);
 }

@@ -73,9 +73,10 @@ template <bool ENV>
 struct ActpLds {
     static constexpr int NRT = 2, TR = NRT * RT;
     typedef HeadImage<4> Img;
-    // the loop's tiles: h1s (fp32 pre-activations of layer 1), h1b (bf16 h1), the partial LayerNorm-2 statistics [TR][16 groups][2] and the column
-    // groups' shares of the outputs [2 tile parities][16 groups][TR][4] ([r5]: no z2 tile — hx_act.h "straight from the accumulators")
-    static constexpr int kLoop = TR * LDA1 + TR * LDB1 / 2 + TR * kPartPitch + 2 * 16 * TR * 4;
+    // the loop's tiles: h1s (fp32 pre-activations of layer 1), h1b (bf16 h1, TWO tiles: the product of tile i - 1 reads one while LayerNorm 1 of tile i
+    // fills the other), the partial LayerNorm-2 statistics [TR][16 groups][2] and the column groups' shares of the outputs [2 tile parities][16 groups][TR][4]
+    // ([r5]: no z2 tile — hx_act.h "straight from the accumulators")
+    static constexpr int kLoop = TR * LDA1 + 2 * (TR * LDB1 / 2) + TR * kPartPitch + 2 * 16 * TR * 4;
     static constexpr int kTail = ENV ? hxenv::kEnvBlockLds<true, kEnvPass> : 0;
     static constexpr int kUnion = kLoop > kTail ? kLoop : kTail;
     __attribute__((aligned(16))) float lds[Img::kStride + TR * XP + 3 * H1 + H2 + 2 * kWide * 4 + 2 * TR * 4 + kUnion];
@@ -99,8 +100,8 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
     float* w3t = w1t + kWide * 4;       // [1024][4]: every lane's A fragment of the final layer (bf16 x 8: W3 at the wave's 32 columns, hx_act.h w3_fragment)
     float* s_noise = w3t + kWide * 4;   // [2][TR][4]: the draws of tile t live in half t & 1
     float* h1s = s_noise + 2 * TR * 4;
-    __bf16* h1b = reinterpret_cast<__bf16*>(h1s + TR * LDA1);
-    float* part = h1s + TR * LDA1 + TR * LDB1 / 2;  // [TR][16][2]
+    __bf16* h1b = reinterpret_cast<__bf16*>(h1s + TR * LDA1);  // [2][TR][LDB1]
+    float* part = h1s + TR * LDA1 + 2 * (TR * LDB1 / 2);  // [TR][16][2]
     float* outp = part + TR * kPartPitch;           // [2][16][TR][4]
     const int tid0 = threadIdx.x;
     const int row_begin = bid * tiles_per_wg * TR;
@@ -153,9 +154,22 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
     }
     const bool draw_noise = !A.noise && A.sigma > 0.0f;
     STAMP();
-    // ---- the tile loop, two barriers per tile, three tiles in flight: iteration i runs layer 1 / LayerNorm 1 of tile i, the product, LayerNorm 2 and
-    //      the final layer's shares of tile i - 1, and the last sum + tanh + noise of tile i - 2 -----------------------------------------
-    v4f acc[NRT][2];  // z2 of tile i - 1: this lane's 4 + 4 columns of rows lr and 16 + lr — alive from the product (P1) across barrier A into P2
+    // ---- the tile loop, two barriers per tile, four tiles in flight.  Each phase pairs MATRIX work of one tile with VECTOR work of another, so that neither
+    //      pipe idles while the other runs (rounds 3-4 alternated an MFMA-only phase with a VALU-only one: 27 % matrix cores, 43 % VALU busy):
+    //        X(i):  product of tile i - 1 (bf16 matrix cores) -> accumulators, bias, partial LayerNorm-2 statistics
+    //               | waves 8-15: LayerNorm 1 + activation of tile i -> bf16 h1 | wave 0: the exploration noise of tile i - 1 | the observation tile i + 1 -> LDS
+    //        Y(i):  LayerNorm 2 + activation of tile i - 1 from the accumulators, the final layer's shares (hx_act.h) | layer 1 of tile i + 1 (fp32 matrix cores)
+    //               | waves 0, 1: the last sum + tanh + noise + clamp of tile i - 2
+    {   // layer 1 of tile 0 (the loop computes tile i + 1's in Y(i))
+        const int tid = tid0, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+        if (!(HX_PX & 8)) {
+            const v4f w1v = *reinterpret_cast<const v4f*>(w1t + tid * 4);
+            const float w1f[4] = {w1v[0], w1v[1], w1v[2], w1v[3]};
+            layer1_tiles<NRT>(xs, w1f, *reinterpret_cast<const v4f*>(b1s + wave * 16 + 4 * lg), wave, lr, lg, h1s);
+        }
+        __syncthreads();
+    }
+    v4f acc[NRT][2];  // z2 of tile i - 1: this lane's 4 + 4 columns of rows lr and 16 + lr — alive from the product (X) across barrier A into Y
 #pragma unroll
     for (int t = 0; t < NRT; ++t) acc[t][0] = acc[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i <= ntile + 1; ++i) {
@@ -167,27 +181,50 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
         const int lr = lane & 15, lg = lane >> 4;
         const int cw = (wave + bid) & 15;
         const bool mid = i >= 1 && i <= ntile;  // tile i - 1 exists
-        // P1: z2(i - 1) = h1(i - 1) W2^T (bf16 matrix cores, weights from registers) | layer 1 of tile i (fp32 matrix cores).
-        // Both products run with the MFMA operands swapped (weights as A, rows as B): the same products in the same k order, but lane
-        // (lr, lg) then holds FOUR CONSECUTIVE columns of row lr.
+        const int gq = lane >> 4, gc = lane & 15;
+        // ---- X: vector work first (its waves' matrix work follows while the other waves' runs) ----
+        if (wave >= 8) {
+            // LayerNorm 1 + activation of tile i -> bf16 h1 (16 lanes per row, hx_act.h; a wave's four rows are eight apart: pitch = 8 mod 64 dwords, their
+            // 16-byte reads fall on disjoint banks)
+            if (i < ntile && !(HX_PX & 2)) {
+                const int row = wave - 8 + 8 * gq;
+                __bf16* const hb_tile = h1b + (i & 1) * TR * LDB1;
+                float v[16];
+                load_row16<H1>(h1s + row * LDA1, gc, v);
+                float mean, rstd;
+                row_stats16<16>(v, H1, mean, rstd);
+                if (m.no_ln) { mean = 0.0f; rstd = 1.0f; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const v4f g = *reinterpret_cast<const v4f*>(g1s + 64 * k + 4 * gc);
+                    const v4f be = *reinterpret_cast<const v4f*>(g1s + H1 + 64 * k + 4 * gc);
+                    typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+                    v4bf hb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hb[e] = (__bf16)ln_act<RELU>(v[4 * k + e], mean, rstd, g[e], be[e], slope);  // round to nearest even
+                    *reinterpret_cast<v4bf*>(hb_tile + row * LDB1 + 64 * k + 4 * gc) = hb;
+                }
+            }
+        } else if (wave == 0) {
+            // the exploration noise of tile i - 1 (its last step runs in Y(i + 1), reading the other half): a lane per (row, Box-Muller pair)
+            if (draw_noise && mid && !(HX_PX & 32)) {
+                float nc, ns;
+                philox_normal_pair(A.row0 + (uint32_t)(row_begin + (i - 1) * TR + (lane >> 1)), A.call, 0x61637421u, A.seed, lane & 1, nc, ns);
+                *reinterpret_cast<float2*>(s_noise + ((i - 1) & 1) * TR * 4 + lane * 2) = make_float2(nc, ns);
+            }
+        }
+        if (i + 1 < ntile) {  // (layer 1 of tile i read xs in Y(i - 1))
+            if (tid < TR * 13) xs[(tid / 13) * XP + tid % 13] = xv;
+            xv = obs_of(i + 2, tid);
+        }
+        // z2(i - 1) = h1(i - 1) W2^T (weights from registers).  The MFMA operands are swapped (weights as A, rows as B): the same products in the same
+        // k order, but lane (lr, lg) then holds FOUR CONSECUTIVE columns of row lr.
         if (mid) {
 #pragma unroll
             for (int t = 0; t < NRT; ++t) acc[t][0] = acc[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
             // K = 256 in 8 slabs of 32: lane (r, g) holds h1[row r][32 sl + 8 g ..+7] and W2[col r][32 sl + 8 g ..+7].  (One register set for
             // the h1 fragments: the other three waves of the SIMD cover a wave's LDS round trip, and a second set costs spills of the weights.)
-            const __bf16* ap = h1b + lr * LDB1 + 8 * lg;
-            // layer 1 of tile i rides BETWEEN the slabs: its eight dependent fp32 MFMAs (two chains of four) and their LDS operands would
-            // otherwise open the phase on every wave at once with the bf16 matrix work waiting behind them
-            const bool l1 = i < ntile && !(HX_PX & 8);
-            float xf[NRT][4];
-            v4f acc1[NRT];
-            const v4f w1f = *reinterpret_cast<const v4f*>(w1t + tid * 4), b1f = *reinterpret_cast<const v4f*>(b1s + wave * 16 + 4 * lg);
-#pragma unroll
-            for (int t = 0; t < NRT; ++t) {
-                acc1[t] = b1f;
-#pragma unroll
-                for (int mm = 0; mm < 4; ++mm) xf[t][mm] = xs[(t * RT + lr) * XP + lg + 4 * mm];  // (read whether or not l1: a few dwords)
-            }
+            const __bf16* ap = h1b + ((i - 1) & 1) * TR * LDB1 + lr * LDB1 + 8 * lg;
 #pragma unroll
             for (int sl = 0; sl < ((HX_PX & 4) ? 0 : 8); ++sl) {
                 uint4 aq[NRT];
@@ -198,12 +235,6 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
                     acc[t][0] = mfma16_bf16(bq[0][sl], aq[t], acc[t][0]);
                     acc[t][1] = mfma16_bf16(bq[1][sl], aq[t], acc[t][1]);
                 }
-                acc1[sl & 1] = mfma16(w1f[sl >> 1], xf[sl & 1][sl >> 1], acc1[sl & 1]);  // tile sl & 1, inputs 4 (sl >> 1) ..: k ascending per tile
-                if (!(HX_PX & 256)) __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise gathers the eight fp32 MFMAs at the head of the phase)
-            }
-            if (l1) {
-#pragma unroll
-                for (int t = 0; t < NRT; ++t) *reinterpret_cast<v4f*>(h1s + (t * RT + lr) * LDA1 + wave * 16 + 4 * lg) = acc1[t];
             }
             // bias, then the wave's partial LayerNorm-2 statistics of its 32 columns of rows lr / 16 + lr (hx_act.h: step 1)
             const v4f bb0 = *reinterpret_cast<const v4f*>(b2s + cw * 16 + 4 * lg), bb1 = *reinterpret_cast<const v4f*>(b2s + 256 + cw * 16 + 4 * lg);
@@ -213,13 +244,22 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
                 acc[t][1] = acc[t][1] + bb1;
                 if (!(HX_PX & 1)) row_partial32(acc[t][0], acc[t][1], lg, part + (t * RT + lr) * kPartPitch + 2 * cw);
             }
-        } else if (i == 0 && !(HX_PX & 8)) {
-            const v4f w1v = *reinterpret_cast<const v4f*>(w1t + tid * 4);
-            const float w1f[4] = {w1v[0], w1v[1], w1v[2], w1v[3]};
-            layer1_tiles<NRT>(xs, w1f, *reinterpret_cast<const v4f*>(b1s + wave * 16 + 4 * lg), wave, lr, lg, h1s);
         }
-        __syncthreads();  // A: the partial statistics of tile i - 1 and the pre-activations of tile i are in LDS; xs and h1b are free
-        // P2, every wave: LayerNorm 2 + activation of its 32 columns of tile i - 1 from the accumulators, the final layer's share on the bf16 matrix
+        __syncthreads();  // A: the partial statistics of tile i - 1, h1 of tile i (bf16) and the observation tile i + 1 are in LDS; the pre-activations are free
+        // ---- Y: layer 1 of tile i + 1 on the fp32 matrix cores (issued first: it runs while the vector work below issues) ----
+        v4f acc1[NRT];
+        const bool l1 = i + 1 < ntile && !(HX_PX & 8);
+        if (l1) {
+            const v4f w1f = *reinterpret_cast<const v4f*>(w1t + tid * 4), b1f = *reinterpret_cast<const v4f*>(b1s + wave * 16 + 4 * lg);
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) {
+                acc1[t] = b1f;
+                const float* xrow = xs + (t * RT + lr) * XP + lg;  // (columns 13.. of xs are zero, and so are the W1 fragments there)
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) acc1[t] = mfma16(w1f[mm], xrow[4 * mm], acc1[t]);  // K = 16 covers the 13 inputs; k ascending
+            }
+        }
+        // every wave: LayerNorm 2 + activation of its 32 columns of tile i - 1 from the accumulators, the final layer's share on the bf16 matrix
         // cores (hx_act.h: steps 2, 3) -> outp[(i - 1) & 1]
         if (mid && !(HX_PX & 1)) {
             const uint4 w3q = *reinterpret_cast<const uint4*>(w3t + tid * 4);
@@ -234,46 +274,19 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
             }
         }
         // waves 0, 1: the last step of tile i - 2 — its 16 shares per output in column-group order + b3, tanh, exploration noise, clamp (a lane per
-        // (row, component): 256 contiguous bytes of actions per wave); waves 8-15: LayerNorm 1 + activation of tile i -> bf16 h1 (16 lanes per
-        // row, hx_act.h; a wave's four rows are eight apart: pitch = 8 mod 64 dwords, their 16-byte reads fall on disjoint banks)
-        const int gq = lane >> 4, gc = lane & 15;
+        // (row, component): 256 contiguous bytes of actions per wave)
         if (wave < 2) {
             const int lrow = wave * 16 + (lane >> 2), c = lane & 3, r = row_begin + (i - 2) * TR + lrow;
             if (i >= 2 && r < row_end && !(HX_PX & 1)) {
                 const float o = head_sum16(outp + (size_t)((i & 1) * 16) * TR * 4, TR, lrow, c, hps[(2 + 4) * H2 + c]);
                 A.actions[(size_t)r * 4 + c] = action_of1(A, o, c, r, s_noise + (i & 1) * TR * 4 + lrow * 4);
             }
-        } else if (wave >= 8) {
-            if (i < ntile && !(HX_PX & 2)) {
-                const int row = wave - 8 + 8 * gq;
-                float v[16];
-                load_row16<H1>(h1s + row * LDA1, gc, v);
-                float mean, rstd;
-                row_stats16<16>(v, H1, mean, rstd);
-                if (m.no_ln) { mean = 0.0f; rstd = 1.0f; }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const v4f g = *reinterpret_cast<const v4f*>(g1s + 64 * k + 4 * gc);
-                    const v4f be = *reinterpret_cast<const v4f*>(g1s + H1 + 64 * k + 4 * gc);
-                    typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
-                    v4bf hb;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) hb[e] = (__bf16)ln_act<RELU>(v[4 * k + e], mean, rstd, g[e], be[e], slope);  // round to nearest even
-                    *reinterpret_cast<v4bf*>(h1b + row * LDB1 + 64 * k + 4 * gc) = hb;
-                }
-            }
-            // the exploration noise of tile i - 1 (its last step runs in the next iteration, reading the other half): one wave, a lane per (row, Box-Muller pair)
-            if (draw_noise && mid && wave == kWide / 64 - 1 && !(HX_PX & 32)) {
-                float nc, ns;
-                philox_normal_pair(A.row0 + (uint32_t)(row_begin + (i - 1) * TR + (lane >> 1)), A.call, 0x61637421u, A.seed, lane & 1, nc, ns);
-                *reinterpret_cast<float2*>(s_noise + ((i - 1) & 1) * TR * 4 + lane * 2) = make_float2(nc, ns);
-            }
         }
-        if (i + 1 < ntile) {
-            if (tid < TR * 13) xs[(tid / 13) * XP + tid % 13] = xv;
-            xv = obs_of(i + 2, tid);
+        if (l1) {
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) *reinterpret_cast<v4f*>(h1s + (t * RT + lr) * LDA1 + wave * 16 + 4 * lg) = acc1[t];
         }
-        __syncthreads();  // B: h1 of tile i (bf16), the next observation tile and the output shares of tile i - 1 are in LDS; the partial statistics are free
+        __syncthreads();  // B: the pre-activations of tile i + 1 and the output shares of tile i - 1 are in LDS; the partial statistics and xs are free
     }
     STAMP();
     if (ENV) env_tail((KernArgs)__builtin_amdgcn_kernarg_segment_ptr(), row_begin, row_end, h1s, &s_slot0, s_wcount, bid, nwg);  // (barrier B: every action of the block is written; the launch description is the kernel's FIRST argument)

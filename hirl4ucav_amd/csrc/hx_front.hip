@@ -210,8 +210,13 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
     FwdArgsC CA{}, CB{};
     for (int j = 0; j < FA.njobs; ++j) { CA.job[j] = pack_fwd(FA.job[j]); CA.job[j].slope = FA.slope; }
     for (int j = 0; j < FB.njobs; ++j) { CB.job[j] = pack_fwd(FB.job[j]); CB.job[j].slope = FB.slope; }
-    CA.slope = FA.slope; CA.zero_nf = FA.zero_nf; CA.zero_f = FA.zero_f; CA.zero_i = FA.zero_i; CA.images = FA.images; CA.rowmap = 1;
-    CB.slope = FB.slope; CB.zero_nf = FB.zero_nf; CB.zero_f = FB.zero_f; CB.zero_i = FB.zero_i; CB.images = FB.images; CB.rowmap = 1;
+    // Which of the update's workgroups share an XCD (blocks b and b + 8 do, under the round-robin placement observed on gfx950: speed only, never
+    // correctness).  1 (default): a ROW TILE's workgroups — the launches behind this one find its rows in their own L2, but every XCD pulls every network
+    // of launches A and B through its L2 (36 MB of fetches per launch against 5 MB algorithmic, profiles/pmc_env_traffic.json front_4096).  0
+    // (HX_FRONT_ROWMAP=0, tools/ubench/front_rowmap_ab.sh): a 64-COLUMN slice's workgroups — each W2 slice enters ONE L2 — measured, see docs/LEVERS.md
+    static const int front_rowmap = getenv("HX_FRONT_ROWMAP") ? atoi(getenv("HX_FRONT_ROWMAP")) : 1;
+    CA.slope = FA.slope; CA.zero_nf = FA.zero_nf; CA.zero_f = FA.zero_f; CA.zero_i = FA.zero_i; CA.images = FA.images; CA.rowmap = front_rowmap & 1;
+    CB.slope = FB.slope; CB.zero_nf = FB.zero_nf; CB.zero_f = FB.zero_f; CB.zero_i = FB.zero_i; CB.images = FB.images; CB.rowmap = front_rowmap & 1;
     const int rows = FA.job[0].rows, tiles = (rows + RT - 1) / RT;
     HX_REQUIRE(tiles * FB.njobs < 128 && FA.njobs + FB.njobs <= 8, "hx_hirl_front: minibatches of at most 256 rows, at most 8 forward jobs");
     FrontCtl C{};

@@ -359,8 +359,15 @@ int hx_hirl_learn_sampled(const HxNets* nets, const HxBatch* batch, const HxHype
  * one more workgroup of the critics' gradient launch draws and gathers, on a CU that launch leaves idle), or hx_sample_batch_guarded as a launch of its own.
  * Bit-identical to hx_actor_act_step_f32i / _x9 followed by hx_hirl_learn_sampled with HxSample.total read before the step and HxSample.guard = n
  * (and launch B in 64-column workgroups: hx_debug_set_fwd_nt).  The target critics wait IN the launch for the target actor's rows (per-row-tile
- * counters `flags`, agent-scope relaxed accesses, bounded wait: bit 0 of *status is set if a wait gives up — workgroups are dispatched in
- * index order and the producers come first, so that is a fault, not a schedule).
+ * counters `flags`, agent-scope relaxed accesses, bounded wait ~1 s: bit 0 of *status is set if a launch-B workgroup gives up, bit 1 if a launch-C
+ * workgroup does (HxFront.with_c)).
+ * THE ASSUMPTION BEHIND THE WAITS: the workgroups of one launch START in index order (producers have the lower indices), so a waiting workgroup's
+ * producers are running or done.  That is what gfx950 / ROCm 7.2 does (1.9 M free-running launches over every acting role: profiles/r04c_front_soak_*.json);
+ * HIP promises no dispatch order.  Under another order a wait still ends as soon as the producers get a CU (the acting workgroups never wait and leave
+ * after ~20 us); only if EVERY resident workgroup were a waiting consumer could a wait run into its bound — then the status word says so, the minibatch
+ * of that launch may have been read half-written, and the caller must not go on: read *status at least every few hundred launches (hirl4ucav_amd/
+ * train_all.py --status_check_every, default 256: on a trip it reloads its last snapshot and continues in the reference's order in the same process, or
+ * exits with code 3) and fall back to hx_actor_act_step_* + hx_hirl_learn_sampled (no in-launch waits; `train_all --loop reference`, `bench.py --no-front`).
  * hx_hirl_learn_back = the rest of the call (critic backward + gradients + Adam [+ the delayed actor step]) on the same `batch`; next / next_tiles
  * (or NULL): the draw of the NEXT front launch (guard = its n; *next->total is read inside this call's second launch, i.e. after this step's
  * inserts and before the next step's) into tiles of their own. */

@@ -260,7 +260,7 @@ def test_driver_eight_ranks_started_by_the_driver(tmp_path):
                        cwd=ROOT, env={**os.environ, "HX_DIST_BACKEND": "gloo"}, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     assert p.stdout.count("Episode 10:") == 1 and "Validation 1:" in p.stdout and "diverged" not in p.stderr
-    run_dir = [os.path.join(dp, d) for dp, ds, _ in os.walk(tmp_path) for d in ds if d == "model"]
+    run_dir = [dp for dp, _, fs in os.walk(tmp_path) if "log1.txt" in fs]
     assert len(run_dir) == 1  # ONE run directory for all ranks ...
-    shards = sorted(f for f in os.listdir(os.path.dirname(run_dir[0])) if f.startswith("state_rank"))
+    shards = sorted(f for f in os.listdir(run_dir[0]) if f.startswith("state_rank"))
     assert shards == [f"state_rank{r}.pt" for r in range(8)]  # ... holding every rank's shard of the snapshot
