@@ -192,7 +192,9 @@ __device__ __forceinline__ float sum_rows4(float v) {
     const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
-constexpr int kPartPitch = 32;  // floats per row of the partial-statistics tile: 16 column groups x (mean_w, M2_w)
+// floats per row of the partial-statistics tile: 16 column groups x (mean_w, M2_w) + 4 of padding — with a pitch of 32 the sixteen float2 stores of a wave fell on
+// ONE bank pair (16-way) and the 16-byte reads of step 2 on two (4-way); 36 puts the stores on 16 different pairs and the reads on disjoint quads
+constexpr int kPartPitch = 36;
 // step 1 for one row tile: z0 / z1 = the lane's four values of column tile cw / 16 + cw (bias added).  Lanes lg == 0 store the pair.
 __device__ __forceinline__ void row_partial32(const v4f& z0, const v4f& z1, int lg, float* prow_cw) {
     const float s = sum_rows4(((z0[0] + z0[1]) + (z0[2] + z0[3])) + ((z1[0] + z1[1]) + (z1[2] + z1[3])));
