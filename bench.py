@@ -61,7 +61,7 @@ def parse(argv=None):
     p.add_argument("--bc_weight", type=float, default=0.5, help="linear / fixed: the weight (configs[3]: linear, 0.5)")
     p.add_argument("--agent", default="hirl", choices=["hirl", "sac"], help="sac: BASELINE.json configs[2] (use --envs 16384 --scenario serpentine)")
     p.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16_policy", "f32x9"],
-                   help="f32x9: fp32 everywhere, the policy's 256->512 product of the ACTING kernel as the exact 9-term bf16 split on the bf16 matrix cores "
+                   help="f32x9: fp32 everywhere, the policy's 256->512 product of the ACTING kernel through the exact three-way bf16 split of both operands on the bf16 matrix cores "
                         "(fp32 operands, exact partial products, fp32 accumulation: fp32 results up to summation order; NOT the default); "
                         "bf16: actor AND critic — policy inference and the three 256<->512 products of every network in learn() on bf16 MFMA, fp32 "
                         "accumulation, fp32 master weights / Adam / LayerNorm / dynamics (BASELINE.json configs[4]); bf16_policy: policy inference only")
@@ -83,7 +83,7 @@ def parse(argv=None):
                         "(HirlEngine.step_learn, include/hirl4ucav.h hx_hirl_front): env step + the first two launches of learn() as ONE launch; the minibatch is "
                         "then drawn from the ring as it stood before this step's insert, without the slots it may overwrite")
     p.add_argument("--front-acting", dest="front_acting", default="x9", choices=["x9", "mfma"],
-                   help="--dtype f32 in the front loop: x9 (default, engine.front_x9) = the acting workgroups' 256 -> 512 product as the exact 9-term bf16 split; mfma = fp32 MFMA")
+                   help="--dtype f32 in the front loop: x9 (default, engine.front_x9) = the acting workgroups' 256 -> 512 product through the exact three-way bf16 split of both operands; mfma = fp32 MFMA")
     p.add_argument("--no-front", dest="front", action="store_false",
                    help="the reference's order on every step: act -> env step -> insert -> draw -> learn, each launch after the other (the minibatch sees this step's transitions)")
     p.add_argument("--serial", action="store_true", help="(default) one stream")
@@ -755,7 +755,7 @@ def workload_label(args):
         return what + tag
     dt = {"f32": "fp32", "bf16": "bf16 actor/critic (fp32 accumulate, fp32 master weights / Adam / LayerNorm) + fp32 dynamics",
           "bf16_policy": "bf16 policy inference (fp32 accumulate) + fp32 dynamics / update",
-          "f32x9": "fp32 (acting kernel: the 256->512 product as the exact 9-term bf16 split on bf16 MFMA, fp32 accumulate)"}[args.dtype]
+          "f32x9": "fp32 (acting kernel: the 256->512 product through the exact three-way bf16 split of both operands on bf16 MFMA, fp32 accumulate)"}[args.dtype]
     kind = f"HIRL-{args.type}" + (f" (bc_weight {args.bc_weight})" if args.type != "soft" else "")
     what = f"{args.envs} parallel {args.scenario} envs per GPU, {kind} {dt}, 1 learn(B={args.batch}) per vector step"
     tag = ""
@@ -933,8 +933,8 @@ def run_rank(args):
         del ref_loop
     res["config"]["loop"] = "front" if loop.front else "reference order"
     if loop.front and args.agent == "hirl" and args.dtype == "f32" and loop.eng.front_x9:
-        res["config"]["acting_product"] = ("fp32 operands, the 256 -> 512 product as the exact 9-term bf16 split on bf16 MFMA with fp32 accumulation (the engine's fp32 acting "
-                                           "format wherever it is the faster one: from 16,384 rows on, and in the front launch); max error vs fp64 4.0e-7 against 5.4e-7 for fp32 MFMA")
+        res["config"]["acting_product"] = ("fp32 operands, the 256 -> 512 product through the exact three-way bf16 split of both operands (hi | mid | lo), six of the nine partial products — the three below fp32 resolution are not formed — on bf16 MFMA with fp32 accumulation (the engine's fp32 acting "
+                                           "format wherever it is the faster one: from 4,096 rows on, and in the front launch); max error vs fp64 2.7e-7 against 3.8e-7 for fp32 MFMA (16,384 rows, profiles/r05_x9_terms_ab.txt)")
     if loop.front:
         res["config"]["act_env"] = ("FRONT launch (hx_sac_front): explore + env step + replay insert + the first forward launch of learn() in one launch" if args.agent == "sac" else
                                     "FRONT launch (hx_hirl_front): act + env step + replay insert + launches A and B of learn() in one launch")
@@ -960,8 +960,8 @@ def run_rank(args):
             fused_pmc = profile_traffic(f"front_{args.envs}") if args.dtype == "f32" else profile_traffic(f"front_bf16_{args.envs}") if args.dtype == "bf16" else None
         fp32_equiv = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
         # which matrix-core instruction the 256 -> 512 product runs on: fp32 MFMA; bf16 MFMA; or — the fp32 HIRL policy from 16,384 rows on, and
-        # --dtype f32x9 at every size — NINE bf16 MFMAs per fp32 product (the exact hi | mid | lo split): `roofline.executed` prices those against the bf16 peak
-        x9 = args.agent == "hirl" and (args.dtype == "f32x9" or (args.dtype == "f32" and (args.envs >= 16384 or (loop.front and loop.eng.front_x9))))
+        # --dtype f32x9 at every size — SIX bf16 MFMAs per fp32 product (the exact hi | mid | lo split of both operands, its partial products above fp32 resolution): `roofline.executed` prices those against the bf16 peak
+        x9 = args.agent == "hirl" and (args.dtype == "f32x9" or (args.dtype == "f32" and (args.envs >= 4096 or (loop.front and loop.eng.front_x9))))
         if args.dtype in ("f32", "f32x9") or args.agent == "sac":  # ALGORITHMIC FLOPs against the dense matrix peak of the dtype the path computes in
             flop, peak = fp32_equiv, FP32_MATRIX_PEAK_TFLOPS
         else:
@@ -977,8 +977,8 @@ def run_rank(args):
         hbm = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hf, 4), "bytes_per_launch": nbytes}
         mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(mf, 4), "flop_per_launch": flop}
         if x9:  # the fp32 product runs as 9 bf16 MFMAs per 32 k (exact split, fp32 accumulate): what the matrix cores EXECUTE, against their bf16 peak
-            ex = flop + 8 * 2 * 256 * 512 * args.envs
-            mfma["executed"] = {"what": "the acting workgroups' 256 -> 512 product as NINE bf16 MFMAs per fp32 product (exact hi | mid | lo split): executed FLOPs against the bf16 "
+            ex = flop + 5 * 2 * 256 * 512 * args.envs
+            mfma["executed"] = {"what": "the acting workgroups' 256 -> 512 product as SIX bf16 MFMAs per fp32 product (exact hi | mid | lo split of both operands; the three partial products below fp32 resolution are not formed): executed FLOPs against the bf16 "
                                         "dense peak — the matrix cores' utilisation; `achieved` above is the fp32 arithmetic the launch delivers, which the split lets exceed "
                                         "what v_mfma_f32_16x16x4_f32 could (peak 157.3)",
                                 "flop_per_launch": ex, "achieved": round(ex / us / 1e6, 2), "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",

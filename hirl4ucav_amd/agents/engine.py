@@ -178,12 +178,13 @@ class HirlEngine:
                                                      self.grad_actor, self.grad_critic, self.m_actor, self.v_actor, self.m_critic,
                                                      self.v_critic, self.losses, self.soft_count, self.wstate, self.ws)), None, None, None, None, None)
         self.act_dtype, self.w2_bf16, self.w2_x9, self._x9_live = "f32", None, None, False
-        # act_dtype "f32" and at least this many rows: the 256 -> 512 product of the ACTING kernel runs as the exact 9-term bf16 split on the
+        # act_dtype "f32" and at least this many rows: the 256 -> 512 product of the ACTING kernel runs through the exact three-way bf16 split of both operands on the
         # bf16 matrix cores (hx_actor_act_x9: fp32 operands, every partial product exact, fp32 accumulation — an fp32 result up to summation
         # order, 1e-5 parity like the fp32-MFMA path) instead of fp32 MFMA: 121 against 163 us at 65,536 rows, 34 against 48 at 16,384
         # (tools/ubench/actp_time.py).  None: never (fp32 MFMA at every size).  The three images are built at the first such call and kept
         # current by the actor's Adam steps from then on.
-        self.x9_rows = 16384
+        # [r5] from 4,096 rows on (round 4: 16,384): in the reference-order loop at 4,096 envs 68.2 -> 66.8 us per step (tools/ubench/nofront_levers.sh)
+        self.x9_rows = 4096
         # ... and in the FRONT launch (step_learn) at every size: there the acting workgroups take 32 rows each on half of the CUs and are the launch's
         # longest — 21.7 against 26.8 us for 4,096 envs (tools/ubench/x9_32row.sh), 52.5 against 56.9 us per step.  False: fp32 MFMA there too.
         self.front_x9 = True
@@ -228,7 +229,7 @@ class HirlEngine:
     def set_act_dtype(self, dtype):
         """"f32": policy inference on fp32 MFMA (parity 1e-5).  "bf16": its 256 -> 512 layer on bf16 MFMA from a bf16 image of W2 that
         every actor Adam step keeps current (BASELINE.json configs[4]); what learn() computes in is set_update_dtype's business.
-        "f32x9": fp32 policy inference with the 256 -> 512 product as the EXACT 9-term bf16 split on the bf16 matrix cores (hx_actor_act_x9:
+        "f32x9": fp32 policy inference with the 256 -> 512 product through the EXACT three-way bf16 split of both operands on the bf16 matrix cores (six of the nine partial products — the three below fp32 resolution are not formed; hx_actor_act_x9:
         fp32 operands, every partial product exact, fp32 accumulation — fp32 results up to summation order); fp32 update only."""
         if dtype not in ("f32", "bf16", "f32x9"):
             raise ValueError(dtype)

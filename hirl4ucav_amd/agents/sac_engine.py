@@ -113,7 +113,7 @@ class SacEngine:
         # fp32 image of the policy's W2 in the acting kernel's operand order (hx_pack_w2_f32i): kept current by hx_sac_adam(which = 1)
         self.w2_f32i = torch.zeros(512 * 256, dtype=torch.float32, device=self.device)
         self.nets.policy_w2_f32i = self.w2_f32i.data_ptr()
-        # From this many rows on the policy's fp32 256 -> 512 product runs as the exact 9-term bf16 split on the bf16 matrix cores
+        # From this many rows on the policy's fp32 256 -> 512 product runs through the exact three-way bf16 split of both operands on the bf16 matrix cores
         # (hx_sac_act*_x9: every partial product exact, fp32 accumulation; 34 against 45 us at 16,384 rows, tools/ubench/actp_time.py);
         # None: fp32 MFMA at every size.  The hi | mid | lo images are built at the first such call, the policy's optimizer step keeps them current.
         self.x9_rows, self.w2_x9 = 16384, None

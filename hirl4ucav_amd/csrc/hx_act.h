@@ -5,6 +5,15 @@
 #pragma once
 #include "hx_update.h"
 
+// The "x9" acting format: both operands of the fp32 256 -> 512 product as EXACT three-way bf16 splits (x = hi + mid + lo, 3 x 8 significand bits = 24: nothing
+// is lost), their partial products — each exact in fp32 — accumulated in fp32 on the bf16 matrix cores.  [r5] SIX of the nine partial products are formed:
+// lo x lo, lo x mid and mid x lo are at most 2^-24 of the product they belong to — below the fp32 resolution of the sum they would join — and cost a third of
+// the matrix-core work.  Measured (tools/ubench/x9_terms_ab.sh, profiles/r05_x9_terms_ab.txt): error against an fp64 evaluation over 16,384 rows 2.68e-7 max /
+// 4.59e-8 mean with six terms, 2.72e-7 / 4.60e-8 with nine, 3.78e-7 / 7.30e-8 for the fp32-MFMA kernel; 65,536 circular envs 384 -> 439 M env steps/s, SAC at
+// 16,384 envs 165 -> 174 M, the headline's front launch 24.4 -> 23.0 us.  -DHX_X9_TERMS=9 builds the nine-term form (the A/B's other side).
+#ifndef HX_X9_TERMS
+#define HX_X9_TERMS 6
+#endif
 namespace hxact {
 using namespace hxnn;
 using namespace hxu;
@@ -88,6 +97,28 @@ __device__ __forceinline__ void row_stats16(const float (&v)[PER], int n, float&
         q2 = fma2(d, d, q2);
     }
     rstd = __builtin_amdgcn_rsqf(sum16u(q2.x + q2.y) / (float)n + LN_EPS);  // v_rsq_f32, as row_stats
+}
+// [r5] The same statistics with THIRTY-TWO lanes per row, two rows per wave (the bf16 acting kernels' LayerNorm 1: every one of the 16 waves takes two of a
+// 32-row tile's rows — with 16 lanes per row eight waves carried the whole phase while the other eight waited, profiles/r05_actp_bf16_wave_stamps_v2.txt).
+// Lane (h = lane >> 5, c = lane & 31) holds 8 elements of row h: columns 4 c .. + 3 and 128 + 4 c .. + 3.  The butterfly leaves the same bits in all 32 lanes.
+__device__ __forceinline__ float sum32u(float v) {
+    v = sum16u(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);  // rows (0, 0, 2, 2) | (1, 1, 3, 3): see sum_rows4
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ void row_stats32(const v4f& x0, const v4f& x1, int n, float& mean, float& rstd) {
+    const v2f s2 = (v2f{x0[0], x0[1]} + v2f{x0[2], x0[3]}) + (v2f{x1[0], x1[1]} + v2f{x1[2], x1[3]});
+    mean = sum32u(s2.x + s2.y) / (float)n;
+    const v2f m2 = {mean, mean};
+    v2f d = v2f{x0[0], x0[1]} - m2;
+    v2f q2 = d * d;
+    d = v2f{x0[2], x0[3]} - m2;
+    q2 = fma2(d, d, q2);
+    d = v2f{x1[0], x1[1]} - m2;
+    q2 = fma2(d, d, q2);
+    d = v2f{x1[2], x1[3]} - m2;
+    q2 = fma2(d, d, q2);
+    rstd = __builtin_amdgcn_rsqf(sum32u(q2.x + q2.y) / (float)n + LN_EPS);
 }
 // this lane's 16 (N = 256) or 32 (N = 512) elements of the LDS row `row`
 template <int N>
@@ -196,48 +227,54 @@ __device__ __forceinline__ float sum_rows4(float v) {
 // ONE bank pair (16-way) and the 16-byte reads of step 2 on two (4-way); 36 puts the stores on 16 different pairs and the reads on disjoint quads
 constexpr int kPartPitch = 36;
 // step 1 for one row tile: z0 / z1 = the lane's four values of column tile cw / 16 + cw (bias added).  Lanes lg == 0 store the pair.
+// (Packed fp32 throughout — the vector units are what bounds the tile loop, tools/ubench/actp_variants.sh: every running sum is an (even, odd) pair of
+// columns, as in row_stats16.)
 __device__ __forceinline__ void row_partial32(const v4f& z0, const v4f& z1, int lg, float* prow_cw) {
-    const float s = sum_rows4(((z0[0] + z0[1]) + (z0[2] + z0[3])) + ((z1[0] + z1[1]) + (z1[2] + z1[3])));
-    const float mw = s * (1.0f / 32.0f);
-    float q = 0.0f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float d = z0[e] - mw;
-        q = __builtin_fmaf(d, d, q);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float d = z1[e] - mw;
-        q = __builtin_fmaf(d, d, q);
-    }
-    q = sum_rows4(q);
+    const v2f a = (v2f{z0[0], z0[1]} + v2f{z0[2], z0[3]}) + (v2f{z1[0], z1[1]} + v2f{z1[2], z1[3]});
+    const float mw = sum_rows4(a.x + a.y) * (1.0f / 32.0f);
+    const v2f m2 = {mw, mw};
+    v2f d = v2f{z0[0], z0[1]} - m2;
+    v2f q2 = d * d;
+    d = v2f{z0[2], z0[3]} - m2;
+    q2 = fma2(d, d, q2);
+    d = v2f{z1[0], z1[1]} - m2;
+    q2 = fma2(d, d, q2);
+    d = v2f{z1[2], z1[3]} - m2;
+    q2 = fma2(d, d, q2);
+    const float q = sum_rows4(q2.x + q2.y);
     if (lg == 0) *reinterpret_cast<v2f*>(prow_cw) = v2f{mw, q};
 }
 // step 2: lane (lr, lg) reads the partials of column groups 4 lg .. 4 lg + 3 of its row (32 bytes); the four lanes of the row end with the same bits
 __device__ __forceinline__ void row_combine16(const float* prow, int lg, int no_ln, float& mean, float& rstd) {
     const v4f p0 = *reinterpret_cast<const v4f*>(prow + 8 * lg), p1 = *reinterpret_cast<const v4f*>(prow + 8 * lg + 4);  // (m, M2, m, M2) x 2
-    mean = sum_rows4((p0[0] + p0[2]) + (p1[0] + p1[2])) * (1.0f / 16.0f);
-    const float e0 = p0[0] - mean, e1 = p0[2] - mean, e2 = p1[0] - mean, e3 = p1[2] - mean;
-    const float de = __builtin_fmaf(e3, e3, __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0)));
-    const float m2 = sum_rows4(__builtin_fmaf(32.0f, de, (p0[1] + p0[3]) + (p1[1] + p1[3])));
+    const v2f t = (v2f{p0[0], p0[1]} + v2f{p0[2], p0[3]}) + (v2f{p1[0], p1[1]} + v2f{p1[2], p1[3]});  // (sum of the four means, sum of the four M2)
+    mean = sum_rows4(t.x) * (1.0f / 16.0f);
+    const v2f mm = {mean, mean};
+    const v2f e01 = v2f{p0[0], p0[2]} - mm, e23 = v2f{p1[0], p1[2]} - mm;
+    const v2f de = fma2(e23, e23, e01 * e01);
+    const float m2 = sum_rows4(__builtin_fmaf(32.0f, de.x + de.y, t.y));
     rstd = __builtin_amdgcn_rsqf(m2 * (1.0f / (float)H2) + LN_EPS);  // nn.LayerNorm: biased variance, eps inside the root (v_rsq_f32, as row_stats16)
     if (no_ln) { mean = 0.0f; rstd = 1.0f; }
 }
 // step 3, the operand: h2 of the lane's eight values -> bf16 (round to nearest even) in the order of the final MFMA's k = 8 lg + e:
-// e < 4 column 16 cw + 4 lg + e, e >= 4 column 256 + 16 cw + 4 lg + e - 4.  hp: the LDS head image (g2 | be2 | ...), col0 = 16 cw + 4 lg
+// e < 4 column 16 cw + 4 lg + e, e >= 4 column 256 + 16 cw + 4 lg + e - 4.  hp: the LDS head image (g2 | be2 | ...), col0 = 16 cw + 4 lg.
+// Elementwise ln_act2 (the same bits as ln_act per element).
 template <bool RELU>
 __device__ __forceinline__ uint4 ln2_operand(const v4f& z0, const v4f& z1, float mean, float rstd, const float* hp, int col0, float slope) {
+    const v2f m2 = {mean, mean}, r2 = {rstd, rstd};
     float h[8];
     {
         const v4f g0 = *reinterpret_cast<const v4f*>(hp + col0), b0 = *reinterpret_cast<const v4f*>(hp + H2 + col0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = ln_act<RELU>(z0[e], mean, rstd, g0[e], b0[e], slope);
+        const v2f a = ln_act2<RELU>(v2f{z0[0], z0[1]}, m2, r2, v2f{g0[0], g0[1]}, v2f{b0[0], b0[1]}, slope);
+        const v2f b = ln_act2<RELU>(v2f{z0[2], z0[3]}, m2, r2, v2f{g0[2], g0[3]}, v2f{b0[2], b0[3]}, slope);
+        h[0] = a.x; h[1] = a.y; h[2] = b.x; h[3] = b.y;
     }
     __builtin_amdgcn_sched_barrier(0);  // (one column tile's eight LayerNorm parameters at a time: with all sixteen requested up front the persistent kernel spills)
     {
         const v4f g1 = *reinterpret_cast<const v4f*>(hp + 256 + col0), b1 = *reinterpret_cast<const v4f*>(hp + H2 + 256 + col0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[4 + e] = ln_act<RELU>(z1[e], mean, rstd, g1[e], b1[e], slope);
+        const v2f a = ln_act2<RELU>(v2f{z1[0], z1[1]}, m2, r2, v2f{g1[0], g1[1]}, v2f{b1[0], b1[1]}, slope);
+        const v2f b = ln_act2<RELU>(v2f{z1[2], z1[3]}, m2, r2, v2f{g1[2], g1[3]}, v2f{b1[2], b1[3]}, slope);
+        h[4] = a.x; h[5] = a.y; h[6] = b.x; h[7] = b.y;
     }
     return pack8_bf16(h);
 }
@@ -308,7 +345,7 @@ __device__ __forceinline__ float action_of1(const ActFusedArgs& A, float o, int 
 // the env step rides in wave 0 of each; beyond, every further round of workgroups would fetch the whole W2 image again.
 constexpr int64_t kFuseEnvMax = 8192;
 
-// hx_actp.hip.  mode: 0 fp32 from the fp32 image (H.w2f), 1 bf16 (H.w2b), 2 the exact 9-term bf16 split (H.w2b = hi | mid | lo, H.x9).
+// hx_actp.hip.  mode: 0 fp32 from the fp32 image (H.w2f), 1 bf16 (H.w2b), 2 the exact three-way bf16 split, six partial products (H.w2b = hi | mid | lo, H.x9).
 // Returns false when no persistent instantiation covers the request (the caller falls back to act_fused_kernel).
 bool launch_act_persist(const ActFusedArgs& H, bool gauss, hipStream_t st);
 

@@ -213,7 +213,7 @@ int hx_actor_act_step_bf16(const float* actor, const uint16_t* w2_bf16, float* s
                                success, opts, stream);
 }
 
-/* The fp32 policy with the 256 -> 512 product as the exact 9-term bf16 split on the bf16 matrix cores (see the header). */
+/* The fp32 policy with the 256 -> 512 product through the exact three-way bf16 split of both operands on the bf16 matrix cores (see the header; hx_act.h HX_X9_TERMS). */
 int hx_pack_w2_x9(const float* net, int32_t in_dim, uint16_t* w2_x9, void* stream) {
     HX_REQUIRE(net && w2_x9 && (in_dim == 13 || in_dim == 17) && (reinterpret_cast<uintptr_t>(w2_x9) & 15u) == 0, "hx_pack_w2_x9: bad arguments");
     const Mlp m{in_dim, 1, 0};

@@ -32,7 +32,7 @@ constexpr int ACT_NCH = H1 / ACT_KC;  // 16 chunks
 //         workgroup) go from L2 straight into registers at kernel entry — no LDS staging, no chunk barriers; the 16 (32) rows
 //         of h1 are the only shared operand.
 // X3   = fp32 policy, the 256 -> 512 product on v_mfma_f32_16x16x32_bf16 EXACTLY: h1 and W2 as hi + mid + lo bf16 parts (split3_bf16: nothing
-//         is lost), all 9 partial products (each exact in fp32) accumulated in fp32 — the 8 small ones in their own accumulator, joined with
+//         is lost), the partial products (each exact in fp32; [r5] six of the nine: hx_act.h HX_X9_TERMS) accumulated in fp32 — the small ones in their own accumulator, joined with
 //         hi x hi at the end.  144 matrix-core cycles per 32 k and column tile against 256 for fp32 MFMA; the B fragments stream from the three
 //         images (768 KB per workgroup) one slab ahead of the multiply.
 // The workgroup's LDS as ONE object: the kernel declares it (hx_act.hip), hx_front.hip overlays it with the forward workgroups' block in a union.
@@ -192,7 +192,20 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
     // apart at NRT = 2: the pitch is 8 mod 64 dwords, so the four rows of a wave's 16-byte reads fall on disjoint banks)
     constexpr int kRowWaves = 4 * NRT;
     const int gq = lane >> 4, gc = lane & 15;
-    if (wave < kRowWaves) {
+    if constexpr (BF16) {
+        // [r5] 32 lanes per row, two rows per wave (hx_act.h row_stats32): the statistics act_persist_bf16_body computes on all of its 16 waves — same bits
+        if (wave < ROWS / 2) {
+            const int row = 2 * wave + (lane >> 5), c = lane & 31;
+            const v4f x0 = *reinterpret_cast<const v4f*>(h1s + row * LDA1 + 4 * c), x1 = *reinterpret_cast<const v4f*>(h1s + row * LDA1 + 128 + 4 * c);
+            float mean, rstd;
+            row_stats32(x0, x1, H1, mean, rstd);
+            if (m.no_ln) { mean = 0.0f; rstd = 1.0f; }
+            if (c == 0) {
+                sts[row * 2] = mean;
+                sts[row * 2 + 1] = rstd;
+            }
+        }
+    } else if (wave < kRowWaves) {
         const int row = wave + kRowWaves * gq;
         float v[16];
         load_row16<H1>(h1s + row * LDA1, gc, v);
@@ -288,12 +301,14 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
                     for (int sx = 0; sx < 3; ++sx) a3[sx] = *reinterpret_cast<const uint4*>(h1x + ((sx * ROWS) + t * RT + r) * LDB1 + 32 * sl + 8 * g);
                     const uint4(&b)[3][2] = bb[sl & 1];
                     // smallest first: lo lo, lo mid, mid lo | lo hi, hi lo, mid mid | mid hi, hi mid -> rest; hi hi -> acc
+                    if (HX_X9_TERMS == 9) {
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[2], b[2][ct], rest[t][ct]);
+                        for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[2], b[2][ct], rest[t][ct]);
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[2], b[1][ct], rest[t][ct]);
+                        for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[2], b[1][ct], rest[t][ct]);
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[1], b[2][ct], rest[t][ct]);
+                        for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[1], b[2][ct], rest[t][ct]);
+                    }
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) rest[t][ct] = mfma16_bf16(a3[2], b[0][ct], rest[t][ct]);
 #pragma unroll

@@ -13,6 +13,12 @@ using namespace hxu;
 #ifndef HX_PX
 #define HX_PX 0
 #endif
+// per-wave stamps of ONE steady-state iteration of the bf16 tile loop (diagnostic build only: tools/ubench/stamps_actp_waves.py)
+#ifdef HX_STAMPS
+#define WSTAMP(k) do { if (i == 4) ws_[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WSTAMP(k)
+#endif
 constexpr int kEnvPass = 512;  // envs per pass of the tail: pair layout = 1,024 lanes = the workgroup
 
 // Layer 1 of NRT row tiles on the fp32 matrix cores: the products and the k order of act_fused_kernel's layer 1, with the two MFMA operands
@@ -71,54 +77,42 @@ __device__ __forceinline__ void env_tail(KernArgs Ap, int row_begin, int row_end
 // the workgroup's LDS as one object (hx_front.hip overlays it with the forward workgroups' block)
 template <bool ENV>
 struct ActpLds {
-    static constexpr int TR = RT;      // [r5] 16-row tiles, five of them in flight (see act_persist_bf16_body)
-    static constexpr int kHost = 2 * RT;  // the host counts a workgroup's share in 32-row units (hx_actp.hip, hx_front.hip)
+    static constexpr int NRT = 2, TR = NRT * RT;
     typedef HeadImage<4> Img;
-    // the loop's tiles, TWO of each (a stage fills one while the next stage reads the other): h1s (fp32 pre-activations of layer 1), h1b (bf16 h1), the
-    // partial LayerNorm-2 statistics [TR][kPartPitch] and the column groups' shares of the outputs [16 groups][TR][4] (no z2 tile: hx_act.h "[r5]")
-    static constexpr int kLoop = 2 * TR * LDA1 + 2 * (TR * LDB1 / 2) + 2 * TR * kPartPitch + 2 * 16 * TR * 4;
+    // the loop's tiles: h1s (fp32 pre-activations of layer 1), h1b (bf16 h1, TWO tiles: the product of tile i - 1 reads one while LayerNorm 1 of tile i
+    // fills the other), the partial LayerNorm-2 statistics [TR][16 groups][2] and the column groups' shares of the outputs [2 tile parities][16 groups][TR][4]
+    // ([r5]: no z2 tile — hx_act.h "straight from the accumulators")
+    static constexpr int kLoop = TR * LDA1 + 2 * (TR * LDB1 / 2) + TR * kPartPitch + 2 * 16 * TR * 4;
     static constexpr int kTail = ENV ? hxenv::kEnvBlockLds<true, kEnvPass> : 0;
     static constexpr int kUnion = kLoop > kTail ? kLoop : kTail;
-    __attribute__((aligned(16))) float lds[Img::kStride + 2 * TR * XP + 3 * H1 + H2 + 2 * kWide * 4 + 8 * TR * 4 + kUnion];
+    __attribute__((aligned(16))) float lds[Img::kStride + TR * XP + 3 * H1 + H2 + 2 * kWide * 4 + 2 * TR * 4 + kUnion];
     unsigned s_slot0;
     int s_wcount[kWide / 64];
 };
-// bid / nwg: this workgroup's index among the acting workgroups and their number (the kernel's grid, or the acting role's share of a front launch);
-// tiles_per_wg: its share of the rows in 32-row units.
-//
-// [r5] ONE phase per 16-row tile, ONE barrier, five tiles in flight.  Rounds 3-4 alternated an MFMA-only phase (product + layer 1) with a VALU-only one
-// (head + LayerNorm 1): tools/ubench/actp_variants.sh prices the pieces at 131,072 rows as skeleton 9 us | layer 1 5-8 | product 18 | LayerNorm 1 8 |
-// LayerNorm 2 + final layer 33 — and their SUM is the launch (profiles/r05_actp_bf16_phase_removal.txt): nothing overlapped, because a row tile's LayerNorm 2
-// needs every wave's columns of the product (a barrier) and a wave held ONE set of accumulators.  With 16-row tiles a wave holds TWO sets in the registers
-// one 32-row set took: iteration `it` runs, dealt slab by slab into one instruction stream per wave,
-//     layer 1 of tile it (fp32 matrix cores) | the product of tile it - 2 (bf16 matrix cores) -> accumulators, bias, partial LayerNorm-2 statistics
-//   | LayerNorm 2 + activation + the final layer's share of tile it - 3 from the OTHER accumulator set (vector, hx_act.h)
-//   | waves 12-15: LayerNorm 1 + activation of tile it - 1 -> bf16 h1 | wave 0: last sum + tanh + noise + clamp of tile it - 4 | wave 1: noise draws
-// so the matrix cores run the product while the vector units run the previous tile's LayerNorm 2.  The row arithmetic is hx_act.h's, per 16-row tile: the
-// same bits as act_fused_body<.., BF16> (tests/test_actp_gpu.py).
+// bid / nwg: this workgroup's index among the acting workgroups and their number (the kernel's grid, or the acting role's share of a front launch)
 template <bool ENV, bool RELU>
 __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, const int tiles_per_wg, const int bid, const int nwg, ActpLds<ENV>& SL) {
-    constexpr int TR = RT;
+    constexpr int NRT = 2, TR = NRT * RT;
     typedef HeadImage<4> Img;
     float* const lds = SL.lds;
     unsigned& s_slot0 = SL.s_slot0;
     int* const s_wcount = SL.s_wcount;
     float* hps = lds;                   // g2 | be2 | (W3 rows: unused here, the final layer's operand lives in w3t) | b3
-    float* xs = hps + Img::kStride;     // [2][TR][XP]
-    float* g1s = xs + 2 * TR * XP;      // LayerNorm 1 weight | bias, read four columns at a time
+    float* xs = hps + Img::kStride;
+    float* g1s = xs + TR * XP;          // LayerNorm 1 weight | bias, read four columns at a time
     float* b1s = g1s + 2 * H1;          // full1.bias
     float* b2s = b1s + H1;              // full2.bias
     float* w1t = b2s + H2;              // [1024][4]: every lane's four layer-1 A fragments of W1 (zero beyond the 13 inputs): one 16-byte read per tile
     float* w3t = w1t + kWide * 4;       // [1024][4]: every lane's A fragment of the final layer (bf16 x 8: W3 at the wave's 32 columns, hx_act.h w3_fragment)
-    float* s_noise = w3t + kWide * 4;   // [8][TR][4]: the draws of tile t live in slot t & 7 (drawn up to four iterations before their use, two tiles at a time)
-    float* h1s = s_noise + 8 * TR * 4;  // [2][TR][LDA1]
-    __bf16* h1b = reinterpret_cast<__bf16*>(h1s + 2 * TR * LDA1);  // [2][TR][LDB1]
-    float* part = h1s + 2 * TR * LDA1 + 2 * (TR * LDB1 / 2);       // [2][TR][kPartPitch]
-    float* outp = part + 2 * TR * kPartPitch;                      // [2][16][TR][4]
+    float* s_noise = w3t + kWide * 4;   // [2][TR][4]: the draws of tile t live in half t & 1
+    float* h1s = s_noise + 2 * TR * 4;
+    __bf16* h1b = reinterpret_cast<__bf16*>(h1s + TR * LDA1);  // [2][TR][LDB1]
+    float* part = h1s + TR * LDA1 + 2 * (TR * LDB1 / 2);  // [TR][16][2]
+    float* outp = part + TR * kPartPitch;           // [2][16][TR][4]
     const int tid0 = threadIdx.x;
-    const int row_begin = bid * tiles_per_wg * ActpLds<ENV>::kHost;
+    const int row_begin = bid * tiles_per_wg * TR;
     if (row_begin >= A.rows) return;
-    const int row_end = min(A.rows, row_begin + tiles_per_wg * ActpLds<ENV>::kHost);
+    const int row_end = min(A.rows, row_begin + tiles_per_wg * TR);
     const int ntile = (row_end - row_begin + TR - 1) / TR;
     const float* net = A.net;
     const Mlp m = A.m;
@@ -157,19 +151,38 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
         if (tid < H1) b1s[tid] = b1v;
         if (tid < 2 * H1) g1s[tid] = gb;
         if (tid < H2) b2s[tid] = b2v;
-        if (tid < 2 * TR * XP) xs[tid] = 0.0f;
+        if (tid < TR * XP) xs[tid] = 0.0f;
         himg.store(hps, net, m, tid);
         __syncthreads();
-        if (tid < TR * 13) xs[(tid / 13) * XP + tid % 13] = xv;  // tile 0 -> xs[0]
+        if (tid < TR * 13) xs[(tid / 13) * XP + tid % 13] = xv;
         xv = obs_of(1, tid);
         __syncthreads();
     }
     const bool draw_noise = !A.noise && A.sigma > 0.0f;
     STAMP();
-    v4f accp[2], accq[2];  // z2 of the tile whose product runs (accp) and of the tile before it, whose LayerNorm 2 runs beside it (accq): 4 + 4 columns of row lr
+    // ---- the tile loop, two barriers per tile, four tiles in flight.  Each phase pairs MATRIX work of one tile with VECTOR work of another, so that neither
+    //      pipe idles while the other runs (rounds 3-4 alternated an MFMA-only phase with a VALU-only one: 27 % matrix cores, 43 % VALU busy):
+    //        X(i):  every wave: LayerNorm 1 + activation of two rows of tile i -> bf16 h1, then the product of tile i - 1 (bf16 matrix cores) -> accumulators,
+    //               bias, partial LayerNorm-2 statistics | wave 0: the exploration noise of tile i - 1 | waves 2, 3: the last sum + tanh + noise + clamp of
+    //               tile i - 2 | the observation tile i + 1 -> LDS
+    //        Y(i):  LayerNorm 2 + activation of tile i - 1 from the accumulators, the final layer's shares (hx_act.h), with layer 1 of tile i + 1 (fp32 matrix
+    //               cores) dealt between its steps
+    {   // layer 1 of tile 0 (the loop computes tile i + 1's in Y(i))
+        const int tid = tid0, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+        if (!(HX_PX & 8)) {
+            const v4f w1v = *reinterpret_cast<const v4f*>(w1t + tid * 4);
+            const float w1f[4] = {w1v[0], w1v[1], w1v[2], w1v[3]};
+            layer1_tiles<NRT>(xs, w1f, *reinterpret_cast<const v4f*>(b1s + wave * 16 + 4 * lg), wave, lr, lg, h1s);
+        }
+        __syncthreads();
+    }
+    v4f acc[NRT][2];  // z2 of tile i - 1: this lane's 4 + 4 columns of rows lr and 16 + lr — alive from the product (X) across barrier A into Y
 #pragma unroll
-    for (int c = 0; c < 2; ++c) accp[c] = accq[c] = v4f{0.f, 0.f, 0.f, 0.f};
-    for (int it = 0; it < ntile + 4; ++it) {
+    for (int t = 0; t < NRT; ++t) acc[t][0] = acc[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
+#ifdef HX_STAMPS
+    unsigned long long ws_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    for (int i = 0; i <= ntile + 1; ++i) {
         // The lane's LDS addresses are loop invariants, and with 64 registers of weights resident the allocator spills them; behind this
         // opaque copy of the thread id they are recomputed per tile (a few VALU instructions) instead of living across the loop.
         int tid = tid0;
@@ -177,107 +190,151 @@ __device__ __forceinline__ void act_persist_bf16_body(const ActFusedArgs& A, con
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         const int lr = lane & 15, lg = lane >> 4;
         const int cw = (wave + bid) & 15;
-        const int gq = lane >> 4, gc = lane & 15;
-        const bool do_l1 = it < ntile && !(HX_PX & 8);                     // layer 1 of tile it
-        const bool do_ln1 = it >= 1 && it - 1 < ntile && !(HX_PX & 2);     // LayerNorm 1 of tile it - 1
-        const bool do_prod = it >= 2 && it - 2 < ntile;                    // product of tile it - 2
-        const bool do_ln2 = it >= 3 && it - 3 < ntile && !(HX_PX & 1);     // LayerNorm 2 + final layer's shares of tile it - 3
-        const bool do_fin = it >= 4 && !(HX_PX & 1);                       // last step of tile it - 4
-        // ---- the vector-only roles first: their waves' matrix work follows while the other waves' runs ----
-        if (wave >= 12) {
-            // LayerNorm 1 + activation of tile it - 1 -> bf16 h1 (16 lanes per row, hx_act.h; wave w rows w - 12, + 4, + 8, + 12)
-            if (do_ln1) {
-                const int row = wave - 12 + 4 * gq;
-                const float* pre = h1s + ((it - 1) & 1) * TR * LDA1;
-                __bf16* const hb_tile = h1b + ((it - 1) & 1) * TR * LDB1;
-                float v[16];
-                load_row16<H1>(pre + row * LDA1, gc, v);
+        const bool mid = i >= 1 && i <= ntile;  // tile i - 1 exists
+        WSTAMP(0);
+        // ---- X: vector work first (its waves' matrix work follows while the other waves' runs) ----
+        {
+            // LayerNorm 1 + activation of tile i -> bf16 h1: EVERY wave takes two rows, 32 lanes per row (hx_act.h row_stats32; lane (h, c): row 2 wave + h,
+            // columns 4 c .. + 3 and 128 + 4 c .. + 3).  With 16 lanes per row on waves 8-15 this was the phase's long pole: 1.3-1.8 us of its 2.9
+            // (profiles/r05_actp_bf16_wave_stamps_v2.txt)
+            if (i < ntile && !(HX_PX & 2)) {
+                const int row = 2 * wave + (lane >> 5), c = lane & 31;
+                __bf16* const hb_row = h1b + (i & 1) * TR * LDB1 + row * LDB1;
+                const v4f x0 = *reinterpret_cast<const v4f*>(h1s + row * LDA1 + 4 * c), x1 = *reinterpret_cast<const v4f*>(h1s + row * LDA1 + 128 + 4 * c);
                 float mean, rstd;
-                row_stats16<16>(v, H1, mean, rstd);
+                row_stats32(x0, x1, H1, mean, rstd);
                 if (m.no_ln) { mean = 0.0f; rstd = 1.0f; }
+                typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const v4f g = *reinterpret_cast<const v4f*>(g1s + 64 * k + 4 * gc);
-                    const v4f be = *reinterpret_cast<const v4f*>(g1s + H1 + 64 * k + 4 * gc);
-                    typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+                for (int k = 0; k < 2; ++k) {
+                    const v4f x = k ? x1 : x0;
+                    const v4f g = *reinterpret_cast<const v4f*>(g1s + 128 * k + 4 * c);
+                    const v4f be = *reinterpret_cast<const v4f*>(g1s + H1 + 128 * k + 4 * c);
                     v4bf hb;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) hb[e] = (__bf16)ln_act<RELU>(v[4 * k + e], mean, rstd, g[e], be[e], slope);  // round to nearest even
-                    *reinterpret_cast<v4bf*>(hb_tile + row * LDB1 + 64 * k + 4 * gc) = hb;
+                    for (int e = 0; e < 4; ++e) hb[e] = (__bf16)ln_act<RELU>(x[e], mean, rstd, g[e], be[e], slope);  // round to nearest even
+                    *reinterpret_cast<v4bf*>(hb_row + 128 * k + 4 * c) = hb;
                 }
             }
-        } else if (wave == 0) {
-            // the last step of tile it - 4: its 16 shares per output in column-group order + b3, tanh, exploration noise, clamp (a lane per (row, component))
-            const int lrow = lane >> 2, c = lane & 3, r = row_begin + (it - 4) * TR + lrow;
-            if (do_fin && r < row_end) {
-                const float o = head_sum16(outp + (size_t)((it & 1) * 16) * TR * 4, TR, lrow, c, hps[(2 + 4) * H2 + c]);
-                A.actions[(size_t)r * 4 + c] = action_of1(A, o, c, r, s_noise + ((it - 4) & 7) * TR * 4 + lrow * 4);
-            }
-        } else if (wave == 1) {
-            // the exploration noise of tiles it - 1 and it (their last steps run three and four iterations on), every second iteration: a lane per (row,
-            // Box-Muller pair) of the two tiles — 64 lanes for the price of 32
-            if (draw_noise && (it & 1) && it - 1 < ntile && !(HX_PX & 32)) {
+        }
+        if (wave == 0) {
+            // the exploration noise of tile i - 1 (its last step runs in X(i + 1), reading the other half): a lane per (row, Box-Muller pair)
+            if (draw_noise && mid && !(HX_PX & 32)) {
                 float nc, ns;
-                philox_normal_pair(A.row0 + (uint32_t)(row_begin + (it - 1) * TR + (lane >> 1)), A.call, 0x61637421u, A.seed, lane & 1, nc, ns);
-                *reinterpret_cast<float2*>(s_noise + (((it - 1) & 7) * TR + (lane >> 1)) * 4 + (lane & 1) * 2) = make_float2(nc, ns);  // (slots it - 1 and it are adjacent: it is odd)
+                philox_normal_pair(A.row0 + (uint32_t)(row_begin + (i - 1) * TR + (lane >> 1)), A.call, 0x61637421u, A.seed, lane & 1, nc, ns);
+                *reinterpret_cast<float2*>(s_noise + ((i - 1) & 1) * TR * 4 + lane * 2) = make_float2(nc, ns);
+            }
+        } else if (wave == 2 || wave == 3) {
+            // the last step of tile i - 2 — its 16 shares per output in column-group order + b3, tanh, exploration noise, clamp (a lane per (row, component):
+            // 256 contiguous bytes of actions per wave); the shares were written in Y(i - 1)
+            const int lrow = (wave - 2) * 16 + (lane >> 2), c = lane & 3, r = row_begin + (i - 2) * TR + lrow;
+            if (i >= 2 && r < row_end && !(HX_PX & 1)) {
+                const float o = head_sum16(outp + (size_t)((i & 1) * 16) * TR * 4, TR, lrow, c, hps[(2 + 4) * H2 + c]);
+                A.actions[(size_t)r * 4 + c] = action_of1(A, o, c, r, s_noise + (i & 1) * TR * 4 + lrow * 4);
             }
         }
-        if (it + 1 < ntile) {  // the observation tile it + 1 -> xs[(it + 1) & 1] (layer 1 of tile it reads the other)
-            if (tid < TR * 13) xs[((it + 1) & 1) * TR * XP + (tid / 13) * XP + tid % 13] = xv;
-            xv = obs_of(it + 2, tid);
+        if (i + 1 < ntile) {  // (layer 1 of tile i read xs in Y(i - 1))
+            if (tid < TR * 13) xs[(tid / 13) * XP + tid % 13] = xv;
+            xv = obs_of(i + 2, tid);
         }
-        // ---- LayerNorm 2 of tile it - 3 (from accq) dealt between the slabs of the product of tile it - 2 (into accp) and layer 1 of tile it ----
-        v4f acc1 = *reinterpret_cast<const v4f*>(b1s + wave * 16 + 4 * lg);
-        const v4f w1f = *reinterpret_cast<const v4f*>(w1t + tid * 4);
-        const float* xrow = xs + (it & 1) * TR * XP + lr * XP + lg;  // (columns 13.. of xs are zero, and so are the W1 fragments there)
-        const __bf16* ap = h1b + (it & 1) * TR * LDB1 + lr * LDB1 + 8 * lg;  // h1 of tile it - 2
-        const float* prow = part + (((it - 3) & 1) * TR + lr) * kPartPitch;
-        float mean = 0.0f, rstd = 1.0f;
-        uint4 hq = {0u, 0u, 0u, 0u};
-        if (do_prod) accp[0] = accp[1] = v4f{0.f, 0.f, 0.f, 0.f};
+        WSTAMP(1);
+        // z2(i - 1) = h1(i - 1) W2^T (weights from registers).  The MFMA operands are swapped (weights as A, rows as B): the same products in the same
+        // k order, but lane (lr, lg) then holds FOUR CONSECUTIVE columns of row lr.
+        if (mid) {
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl) {
-            if (do_prod && !(HX_PX & 4)) {
-                // K = 256 in 8 slabs of 32: lane (r, g) holds h1[row r][32 sl + 8 g ..+7] and W2[col r][32 sl + 8 g ..+7]; operands swapped (weights as A): lane
-                // (lr, lg) ends with FOUR CONSECUTIVE columns of row lr
-                const uint4 aq = *reinterpret_cast<const uint4*>(ap + 32 * ((HX_PX & 128) ? 0 : sl));
-                accp[0] = mfma16_bf16(bq[0][sl], aq, accp[0]);
-                accp[1] = mfma16_bf16(bq[1][sl], aq, accp[1]);
-            }
-            if (do_l1 && sl < 4) acc1 = mfma16(w1f[sl], xrow[4 * sl], acc1);  // K = 16 covers the 13 inputs; k ascending
-            if (do_ln2) {
-                if (sl == 1) row_combine16(prow, lg, m.no_ln, mean, rstd);
-                if (sl == 3) hq = ln2_operand<RELU>(accq[0], accq[1], mean, rstd, hps, cw * 16 + 4 * lg, slope);
-                if (sl == 5) {
-                    const uint4 w3q = *reinterpret_cast<const uint4*>(w3t + tid * 4);
-                    const v4f o = mfma16_bf16(w3q, hq, v4f{0.f, 0.f, 0.f, 0.f});  // D[i = 4 lg + q][j = lr]: outputs 0..3 of row lr in the lg = 0 lanes
-                    if (lg == 0) *reinterpret_cast<v4f*>(outp + ((size_t)(((it - 3) & 1) * 16 + cw) * TR + lr) * 4) = o;
+            for (int t = 0; t < NRT; ++t) acc[t][0] = acc[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
+            // K = 256 in 8 slabs of 32: lane (r, g) holds h1[row r][32 sl + 8 g ..+7] and W2[col r][32 sl + 8 g ..+7].  (One register set for
+            // the h1 fragments: the other three waves of the SIMD cover a wave's LDS round trip, and a second set costs spills of the weights.)
+            const __bf16* ap = h1b + ((i - 1) & 1) * TR * LDB1 + lr * LDB1 + 8 * lg;
+#pragma unroll
+            for (int sl = 0; sl < ((HX_PX & 4) ? 0 : 8); ++sl) {
+                uint4 aq[NRT];
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) aq[t] = *reinterpret_cast<const uint4*>(ap + t * RT * LDB1 + 32 * ((HX_PX & 128) ? 0 : sl));
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) {
+                    acc[t][0] = mfma16_bf16(bq[0][sl], aq[t], acc[t][0]);
+                    acc[t][1] = mfma16_bf16(bq[1][sl], aq[t], acc[t][1]);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);  // (the deal stays as written: the scheduler otherwise gathers the matrix instructions at the head of the phase)
+            WSTAMP(2);
+            // bias, then the wave's partial LayerNorm-2 statistics of its 32 columns of rows lr / 16 + lr (hx_act.h: step 1)
+            const v4f bb0 = *reinterpret_cast<const v4f*>(b2s + cw * 16 + 4 * lg), bb1 = *reinterpret_cast<const v4f*>(b2s + 256 + cw * 16 + 4 * lg);
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) {
+                acc[t][0] = acc[t][0] + bb0;
+                acc[t][1] = acc[t][1] + bb1;
+                if (!(HX_PX & 1)) row_partial32(acc[t][0], acc[t][1], lg, part + (t * RT + lr) * kPartPitch + 2 * cw);
+            }
         }
-        if (do_l1) *reinterpret_cast<v4f*>(h1s + (it & 1) * TR * LDA1 + lr * LDA1 + wave * 16 + 4 * lg) = acc1;
-        if (do_prod) {
-            // bias, then the wave's partial LayerNorm-2 statistics of its 32 columns of row lr (hx_act.h: step 1); the accumulators change hands
-            accq[0] = accp[0] + *reinterpret_cast<const v4f*>(b2s + cw * 16 + 4 * lg);
-            accq[1] = accp[1] + *reinterpret_cast<const v4f*>(b2s + 256 + cw * 16 + 4 * lg);
-            if (!(HX_PX & 1)) row_partial32(accq[0], accq[1], lg, part + (((it - 2) & 1) * TR + lr) * kPartPitch + 2 * cw);
+        WSTAMP(3);
+        __syncthreads();  // A: the partial statistics of tile i - 1, h1 of tile i (bf16) and the observation tile i + 1 are in LDS; the pre-activations are free
+        WSTAMP(4);
+        // ---- Y: layer 1 of tile i + 1 on the fp32 matrix cores, its eight instructions (two dependent chains of four) DEALT between the steps of LayerNorm 2 +
+        //      activation of tile i - 1 from the accumulators and the final layer's shares (hx_act.h: steps 2, 3 -> outp[(i - 1) & 1]): a wave that issues
+        //      its chain in one go waits at every link for the link before, with its vector work queued behind ----
+        v4f acc1[NRT];
+        const bool l1 = i + 1 < ntile && !(HX_PX & 8);
+        const bool ln2 = mid && !(HX_PX & 1);
+        const v4f w1f = *reinterpret_cast<const v4f*>(w1t + tid * 4);
+        float mean = 0.0f, rstd = 1.0f;
+        uint4 hq[NRT];
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) {
+            acc1[t] = *reinterpret_cast<const v4f*>(b1s + wave * 16 + 4 * lg);
+            hq[t] = uint4{0u, 0u, 0u, 0u};
         }
-        __syncthreads();  // every stage's tile is in LDS for the next stage
+        WSTAMP(5);
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            if (l1) {
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) acc1[t] = mfma16(w1f[mm], xs[(t * RT + lr) * XP + lg + 4 * mm], acc1[t]);  // K = 16 covers the 13 inputs; k ascending
+            }
+            if (ln2) {  // row tile mm >> 1: statistics, then the operand
+                if (!(mm & 1)) row_combine16(part + ((mm >> 1) * RT + lr) * kPartPitch, lg, m.no_ln, mean, rstd);
+                else hq[mm >> 1] = ln2_operand<RELU>(acc[mm >> 1][0], acc[mm >> 1][1], mean, rstd, hps, cw * 16 + 4 * lg, slope);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (the deal stays as written)
+        }
+        if (ln2) {
+            const uint4 w3q = *reinterpret_cast<const uint4*>(w3t + tid * 4);
+            float* const op = outp + (size_t)(((i - 1) & 1) * 16 + cw) * TR * 4;
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) {
+                const v4f o = mfma16_bf16(w3q, hq[t], v4f{0.f, 0.f, 0.f, 0.f});  // D[i = 4 lg + q][j = lr]: outputs 0..3 of row lr in the lg = 0 lanes
+                if (lg == 0) *reinterpret_cast<v4f*>(op + (t * RT + lr) * 4) = o;
+            }
+        }
+        WSTAMP(6);
+        if (l1) {
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) *reinterpret_cast<v4f*>(h1s + (t * RT + lr) * LDA1 + wave * 16 + 4 * lg) = acc1[t];
+        }
+        WSTAMP(7);
+        __syncthreads();  // B: the pre-activations of tile i + 1 and the output shares of tile i - 1 are in LDS; the partial statistics and xs are free
+        WSTAMP(8);
     }
+#ifdef HX_STAMPS
+    {   // waves 0, 5, 9, 15 of workgroup 3: eight phase lengths each -> hx_dbg[16 + 8 slot ..]
+        const int wv = tid0 >> 6, slot = wv == 0 ? 0 : wv == 5 ? 1 : wv == 9 ? 2 : wv == 15 ? 3 : -1;
+        if (bid == 3 && (tid0 & 63) == 0 && slot >= 0)
+            for (int k = 0; k < 8; ++k) hx_dbg[16 + 8 * slot + k] = (float)(ws_[k + 1] - ws_[k]);
+    }
+#endif
     STAMP();
-    if (ENV) env_tail((KernArgs)__builtin_amdgcn_kernarg_segment_ptr(), row_begin, row_end, h1s, &s_slot0, s_wcount, bid, nwg);  // (the barrier: every action of the block is written; the launch description is the kernel's FIRST argument)
+    if (ENV) env_tail((KernArgs)__builtin_amdgcn_kernarg_segment_ptr(), row_begin, row_end, h1s, &s_slot0, s_wcount, bid, nwg);  // (barrier B: every action of the block is written; the launch description is the kernel's FIRST argument)
     STAMP();
     STAMP_FLUSH(0, (bid == 0 || bid == 200) && tid0 == 0);
     SPAN_LOG(HX_SPAN_ACT);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// fp32 (MODE 0: the fp32 image, fp32 MFMA) and fp32 through the exact 9-term bf16 split (MODE 1: hi | mid | lo images, bf16 MFMA): W2 does
+// fp32 (MODE 0: the fp32 image, fp32 MFMA) and fp32 through the exact three-way bf16 split (MODE 1: hi | mid | lo images, bf16 MFMA; six partial products, hx_act.h HX_X9_TERMS): W2 does
 // not fit the register file (512 / 768 KB), so each wave STREAMS its column slices from L2 once per pass over 64 rows — four row tiles per B
 // fragment, a quarter of act_fused_kernel<2>'s L2 traffic per row — and z2 leaves the accumulators in two halves of 32 rows through the
 // LDS that held h1.  Per pass: layer 1 | LayerNorm 1 (16 lanes per row, every wave four rows) | the product | 2 x { z2 half -> LDS, head }.
-// The k order of every accumulator, and with MODE 1 the order of the nine partial products, are act_fused_kernel's: the same bits.
+// The k order of every accumulator, and with MODE 1 the order of the partial products, are act_fused_kernel's: the same bits.
 // ---------------------------------------------------------------------------------------------------------------
 template <int MODE, bool GAUSS, bool ENV>
 struct ActpsLds {
@@ -438,9 +495,11 @@ __device__ __forceinline__ void act_persist_stream_body(const ActFusedArgs& A, c
                     for (int sx = 0; sx < 3; ++sx) a3[sx] = *reinterpret_cast<const uint4*>(h1x + ((sx * TR) + t * RT + lr) * LDB1 + 32 * sl + 8 * lg);
                     // smallest first, as act_fused_kernel: lo lo, lo mid, mid lo | lo hi, hi lo, mid mid | mid hi, hi mid -> rest; hi hi -> acc
                     v4f r = rest[t][ct];
-                    r = mfma16_bf16(b[2], a3[2], r);
-                    r = mfma16_bf16(b[1], a3[2], r);
-                    r = mfma16_bf16(b[2], a3[1], r);
+                    if (HX_X9_TERMS == 9) {
+                        r = mfma16_bf16(b[2], a3[2], r);
+                        r = mfma16_bf16(b[1], a3[2], r);
+                        r = mfma16_bf16(b[2], a3[1], r);
+                    }
                     r = mfma16_bf16(b[0], a3[2], r);
                     r = mfma16_bf16(b[2], a3[0], r);
                     r = mfma16_bf16(b[1], a3[1], r);

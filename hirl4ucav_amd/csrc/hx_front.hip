@@ -44,7 +44,7 @@ struct FrontCtl {
 // each with half the MFMA work — right for an empty chip, wrong in the shadow of the acting workgroups, where CU time is what runs out:
 // tools/ubench/front_spans.py).  The K-split of a column tile differs between the two tilings (4 against 8 partial sums), hence the last bits of the
 // target critics' z2: hx_debug_set_fwd_nt(64) gives the separate launches the same tiling (tests/test_front_gpu.py).
-// X3: the acting workgroups multiply in the exact 9-term bf16 split (the engine's "f32x9" acting format, H.w2b = the hi | mid | lo images) instead of
+// X3: the acting workgroups multiply through the exact three-way bf16 split (six partial products, hx_act.h HX_X9_TERMS) (the engine's "f32x9" acting format, H.w2b = the hi | mid | lo images) instead of
 // fp32 MFMA from the fp32 image: 21.7 against 26.8 us for the 128 workgroups of 4,096 envs (tools/ubench/x9_32row.sh) — a shorter shadow, but the
 // acting workgroups are the launch's longest
 // BF16: the bf16 update path (HxNets.w2_bf16_all) with the bf16 acting kernel — both on v_mfma_f32_16x16x32_bf16, as their launches of their own

@@ -61,7 +61,10 @@ static int g_force_fwd_nt = 0, g_force_skip = 0, g_force_count = 0;
 void set_fwd_nt(int nt, int skip, int count) { g_force_fwd_nt = nt; g_force_skip = skip; g_force_count = count; }
 
 void launch_fwd(const FwdArgs& F, hipStream_t st) {
-    bool force64 = false;
+    // HX_FWD_NT64=1 (tuning knob, tools/ubench/nofront_levers.sh): every latency-mode forward launch in 64-column workgroups — the tiling launch B takes inside
+    // the front launch, where CU time is what runs out; on an empty chip 128 workgroups of 7.5 us against 256 of 6
+    static const bool env64 = getenv("HX_FWD_NT64") && atoi(getenv("HX_FWD_NT64")) != 0;
+    bool force64 = env64;
     if (g_force_fwd_nt == kNT) {  // (tests only) the launches [skip, skip + count) after the setter
         if (g_force_skip > 0) --g_force_skip;
         else if (g_force_count > 0) { --g_force_count; force64 = true; }

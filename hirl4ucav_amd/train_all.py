@@ -307,7 +307,7 @@ def main(config):
         raise SystemExit(f"train_all: --resume {config.resume} was run with --dtype {snap_dtype}, --dtype {dtype} given")
     if world > 1 and os.environ.get("HX_DIST_BACKEND", "nccl") == "nccl" and hasattr(eng, "use_rccl_direct"):
         eng.use_rccl_direct()  # ncclAllReduce enqueued by the library on the engine's stream (hx_rccl_*): no torch.distributed call inside learn()
-    if dtype == "f32x9" and not sac:  # fp32, the acting kernel's 256 -> 512 product as the exact 9-term bf16 split (engine.set_act_dtype)
+    if dtype == "f32x9" and not sac:  # fp32, the acting kernel's 256 -> 512 product through the exact three-way bf16 split of both operands (engine.set_act_dtype)
         eng.set_act_dtype("f32x9")
     elif dtype != "f32" and not sac:  # bf16: actor AND critic (BASELINE.json configs[4]); bf16_policy: policy inference only
         eng.set_act_dtype("bf16")
@@ -538,8 +538,8 @@ def parser():
     p.add_argument("--resume", type=str, default=None, help="run directory holding state_rank<r>.pt to continue from")
     p.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; without a launcher environment the driver starts them itself")
     p.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "bf16_policy", "f32x9"],
-                   help="f32 (default): fp32 everywhere — from 16,384 envs per GPU on, the ACTING kernel forms its fp32 256->512 product as the exact "
-                        "9-term bf16 split on the bf16 matrix cores (engine.x9_rows); f32x9: that format at every size; bf16: policy inference AND the "
+                   help="f32 (default): fp32 everywhere — from 4,096 envs per GPU on, the ACTING kernel forms its fp32 256->512 product as the exact "
+                        "three-way bf16 split of both operands on the bf16 matrix cores (engine.x9_rows); f32x9: that format at every size; bf16: policy inference AND the "
                         "256<->512 products of learn() on bf16 MFMA (fp32 accumulate, fp32 master weights / Adam / LayerNorm / dynamics); bf16_policy: "
                         "policy inference only.  HIRL / TD3 only: the SAC agents run fp32.  Stored in the snapshot: --resume refuses another value")
     p.add_argument("--synthetic_expert", action="store_true", help="uniform-random stand-in for the expert CSV (throughput runs and tests ONLY)")

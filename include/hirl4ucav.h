@@ -346,7 +346,7 @@ int hx_hirl_critic_grads_sampled(const HxNets* nets, const HxBatch* batch, const
 int hx_hirl_learn_sampled(const HxNets* nets, const HxBatch* batch, const HxHyper* hyper, const HxSample* sample, int32_t critic_step,
                           int32_t actor_phase, int32_t actor_step, int32_t do_polyak, int32_t w_kind, float w_given, float warm, void* stream);
 
-/* The FRONT launch (opt-in; fp32 networks — noise_mode + 32: the policy's W2 from HxNets.actor_w2_x9, the exact 9-term bf16 split, as
+/* The FRONT launch (opt-in; fp32 networks — noise_mode + 32: the policy's W2 from HxNets.actor_w2_x9, the exact three-way bf16 split, as
  * hx_actor_act_step_x9, else from HxNets.actor_w2_f32i — or the bf16 update path, HxNets.w2_bf16_all, with the bf16 acting image
  * HxNets.actor_w2_bf16; n <= 8,192 — with a replay ring any number in the exact-split format and in bf16): hx_actor_act_step_f32i / _x9 / _bf16 for n envs (chooseAction + HarfangEnv.step + replay insert,
  * train_all.py:343-345) AND the first two launches of the learn() call that follows it (targetActor(s'), Q1/Q2(s, a) [+ the actor call's forwards];
@@ -432,7 +432,7 @@ int hx_sac_act_step_f32i(const float* policy, const float* w2_f32i, float* state
                          int32_t mode, const float* eps, uint64_t seed, uint32_t row0, uint32_t call, float* reward, uint8_t* done,
                          int8_t* success, const HxStepOpts* opts /* host, may be NULL */, void* stream);
 /* SacAgent.explore / exploit + HarfangEnv.step in one launch (train_sac.py:238-241). */
-/* The same from the exact 9-term bf16 split of the 256 -> 512 product (hx_actor_act_x9's format; w2_x9 = hx_pack_w2_x9(policy, 13, ...)):
+/* The same from the exact three-way bf16 split of the 256 -> 512 product's operands (hx_actor_act_x9's format; w2_x9 = hx_pack_w2_x9(policy, 13, ...)):
  * the large-population format of the fp32 policy — beyond 8,192 rows the persistent kernel streams the three images; up to 8,192 rows these
  * entry points fall back to the fp32 image, which must then be given as well (w2_f32i). */
 int hx_sac_act_x9(const float* policy, const uint16_t* w2_x9, const float* w2_f32i, const float* obs, int64_t rows, float* actions, int32_t mode,

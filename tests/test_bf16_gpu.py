@@ -133,6 +133,7 @@ def test_f32_image_path_is_bit_identical_and_follows_adam(mods, staged, n):
     params, data = D.make_params(5), D.make_data(6)
     e = E.HirlEngine(batch=128)
     e.staged = staged
+    e.x9_rows = None  # the fp32-MFMA family at every size (from 4,096 rows on the engine's default is the exact-split format: tests/test_x9_gpu.py)
     e.load_params(params["actor"], params["critic"], params["bc_actor"])
     ring = torch.from_numpy(data["replay"]).cuda()
     bc = np.zeros((D.N_EXPERT, 32), np.float32)

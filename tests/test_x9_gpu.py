@@ -1,6 +1,6 @@
-"""fp32 policy inference with the 256 -> 512 product as the EXACT 9-term bf16 split on the bf16 matrix cores (hx_actor_act_x9 /
+"""fp32 policy inference with the 256 -> 512 product through the EXACT three-way bf16 split of both operands on the bf16 matrix cores (hx_actor_act_x9 /
 hx_actor_act_step_x9, HxNets.actor_w2_x9; Actor.forward HIRL.py:126-140, chooseAction HIRL.py:192-212).  Every fp32 operand is split into
-three bf16 parts without loss, all nine partial products are exact in fp32 and are accumulated in fp32: the arithmetic of the fp32 kernels
+three bf16 parts without loss, the partial products are exact in fp32 and are accumulated in fp32 (six of the nine since round 5: lo x lo, lo x mid, mid x lo lie below the fp32 resolution of the sum — hx_act.h HX_X9_TERMS): the arithmetic of the fp32 kernels
 up to the order of the sums.  Bars: the SAME 1e-5 / 1e-6 as the fp32 acting kernel against the oracle and the reference's recorded
 actions; its error against an fp64 evaluation no larger than 1.25 x the fp32-MFMA kernel's; the three images reproduce every weight
 bit for bit and follow every Adam step of the actor; act + env in one launch == act, then env step."""
