@@ -42,7 +42,9 @@ def check_roof(r):
     assert r["peak"] in (8000.0, 157.3, 2500.0) and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
 
 
-def check(d, n_gpus, steps, warmup, envs=4096, dtype="f32", fused=True):
+def check(d, n_gpus, steps, warmup, envs=4096, dtype="f32", fused=True, shared_gpu=False):
+    """shared_gpu: several ranks on ONE GPU (the 8-rank rehearsal) — launches of different ranks interleave on the chip, so relations between the stamped
+    durations of two kernels say nothing there"""
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -58,7 +60,7 @@ def check(d, n_gpus, steps, warmup, envs=4096, dtype="f32", fused=True):
     front = d["config"].get("loop") == "front"
     if front:  # the default loop where it applies: fp32 HIRL, <= 8,192 envs per GPU — env step + launches A and B of learn() in ONE launch
         assert fused and "_front_kernel" in r["kernel"] and "draw" in d["config"]
-        assert [v for k, v in d["stage_us"].items() if k.startswith("front launch + rest of learn()")][0] >= r["us_per_launch"]
+        assert shared_gpu or [v for k, v in d["stage_us"].items() if k.startswith("front launch + rest of learn()")][0] >= r["us_per_launch"]
         if n_gpus == 1 and "rccl_ranks" not in d:  # the same workload in the reference's order, timed in the same process
             ro = d["reference_order"]
             assert ro["value"] > 0 and abs(ro["value"] - envs * 1e3 / ro["ms_per_step"]) < 1e-3 * ro["value"] and ro["repetitions"]["count"] == 3
@@ -66,13 +68,13 @@ def check(d, n_gpus, steps, warmup, envs=4096, dtype="f32", fused=True):
         assert front or (("act_persist_" if envs > 8192 else "act_fused_kernel") in r["kernel"] and "ENV" in r["kernel"])
         # ... and it is the DOMINANT kernel of the step: no other stage's launch outlasts it
         st = d["stage_us"]
-        assert all(v is None or r["us_per_launch"] >= 0.8 * v for k, v in st.items() if k.startswith(("act(", "env_step(")))
+        assert shared_gpu or all(v is None or r["us_per_launch"] >= 0.8 * v for k, v in st.items() if k.startswith(("act(", "env_step(")))
         check_roof(r["other_roof"])
         assert {r["bound"], r["other_roof"]["bound"]} == {"hbm", "mfma"} and r["frac"] >= r["other_roof"]["frac"]
         e = d["roofline_env_kernel"]
         assert e["bound"] == "hbm" and "env_step_kernel" in e["kernel"] and 0 < e["frac"] < 1 and "traffic_from_profiles" in e
-        assert r["us_per_launch"] > e["us_per_launch"] * 0.8  # the fused launch contains the env step
-        assert front or d["stage_us"]["act+env_step(1 kernel)"] >= r["us_per_launch"] * 0.8  # events around the launch >= the kernel's own stamps
+        assert shared_gpu or r["us_per_launch"] > e["us_per_launch"] * 0.8  # the fused launch contains the env step
+        assert front or shared_gpu or d["stage_us"]["act+env_step(1 kernel)"] >= r["us_per_launch"] * 0.8  # events around the launch >= the kernel's own stamps
     else:
         assert r["bound"] == "hbm" and "env_step_kernel" in r["kernel"] and "roofline_env_kernel" not in d
     assert "settle_s" in d and "timed_region" in d and d["stage_us"]["sample+learn"] > 0
@@ -117,7 +119,7 @@ def test_bench_labels_follow_the_arguments():
     assert d["roofline_update"]["peak"] == 2500.0 and d["roofline_act"]["peak"] == 2500.0
     d = run([sys.executable, "bench.py", "--dtype", "f32x9", "--no-cpu-baseline"] + common)  # opt-in: never labelled as the configs[1] line
     check(d, 1, 60, 10, dtype="f32 (policy product: exact bf16 x 9 split)")
-    assert "configs[" not in d["config"]["workload"] and "9-term bf16 split" in d["config"]["workload"] and d["roofline"]["peak"] == 157.3  # (algorithmic fp32 FLOPs against the fp32 matrix peak ...)
+    assert "configs[" not in d["config"]["workload"] and "three-way bf16 split" in d["config"]["workload"] and d["roofline"]["peak"] == 157.3  # (algorithmic fp32 FLOPs against the fp32 matrix peak ...)
     ex = d["roofline"]["executed"]  # (... and the nine bf16 MFMAs per fp32 product it executes against the bf16 peak)
     assert ex["peak"] == 2500.0 and ex["flop_per_launch"] > 5 * d["roofline"]["flop_per_launch"] and abs(ex["frac"] - ex["achieved"] / 2500.0) < 1e-3
     assert d["roofline"]["traffic"] is None  # (the committed PMC passes are of the fp32-MFMA kernel)
@@ -241,7 +243,7 @@ def test_bench_eight_ranks_on_one_gpu(extra):
     steps, warm = ("12", "2") if peer else ("60", "10")
     d = run([sys.executable, "bench.py", "--gpus", "8", "--steps", steps, "--warmup", warm, "--no-sweep", "--no-cpu-baseline", "--settle-s", "0" if peer else "0.2"] + extra,
             env={"HX_BENCH_BACKEND": "gloo"})
-    check(d, 8, int(steps), int(warm))
+    check(d, 8, int(steps), int(warm), shared_gpu=True)
     rr = d["rccl_ranks"]
     assert rr["world_size"] == 8 and rr["distinct_gpus"] == 1 and rr["exchange"] == ("twostage" if peer else "rccl")
     assert d["replicas_identical"] is True and len(d["allreduce"]) == 2 and d["env_stats"]["env_steps"] > 0

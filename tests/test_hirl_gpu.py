@@ -164,6 +164,7 @@ def test_act_row_tilings_agree_bit_for_bit(eng_mod):
     tiles): the per-row arithmetic is the same, so the outputs must be identical, ragged tail included."""
     params = D.make_params(D.PARAM_SEED)
     e = eng_mod.HirlEngine(batch=128)
+    e.x9_rows = None  # the fp32-MFMA family at every size (the engine's default takes the exact-split format from 4,096 rows on: tests/test_x9_gpu.py, test_actp_gpu.py)
     e.load_params(params["actor"], params["critic"], params["bc_actor"])
     rng = np.random.default_rng(5)
     n = 8192 + 37

@@ -1,5 +1,5 @@
 #!/bin/bash
-# [r5] The fp32 acting product as a 6-term bf16 split (-DHX_X9_TERMS=6: without lo x lo, lo x mid, mid x lo) against the exact 9-term split: accuracy against an fp64
+# [r5] The fp32 acting product as a 6-term bf16 split (-DHX_X9_TERMS=9: without lo x lo, lo x mid, mid x lo) against the exact 9-term split: accuracy against an fp64
 # evaluation and step times, alternated on one box.  Build first:  tools/ubench/x9_terms_ab.sh build ;  on the GPU box: tools/ubench/x9_terms_ab.sh run [tag]
 set -uo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)}
@@ -11,19 +11,19 @@ if [ "${1:-run}" = build ]; then
     b=$(basename "$f" .hip)
     if grep -q "HX_X9_TERMS\|hx_act.h\|hx_act_body.h\|hx_actp_body.h" "$f" || [ "$b" = hx_act ] || [ "$b" = hx_actp ] || [ "$b" = hx_front ]; then
       FL=""; [ "$b" = hx_env ] && FL="-ffp-contract=off"
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DHX_X9_TERMS=6 $FL -c "$f" -o "/tmp/x6_$b.o"
-      OBJS="$OBJS /tmp/x6_$b.o"
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DHX_X9_TERMS=9 $FL -c "$f" -o "/tmp/x9f_$b.o"
+      OBJS="$OBJS /tmp/x9f_$b.o"
     else
       OBJS="$OBJS $C/$b.o"
     fi
   done
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o hirl4ucav_amd/libhx_x6.so $OBJS -ldl
-  ls -la hirl4ucav_amd/libhx_x6.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o hirl4ucav_amd/libhx_x9full.so $OBJS -ldl
+  ls -la hirl4ucav_amd/libhx_x9full.so
   exit 0
 fi
 TAG=${2:-r05_x9_terms_ab}; O="$R/gpurun_out/$TAG"; mkdir -p "$O"
 {
-  for L in hirl4ucav_amd/libhx_mi355.so hirl4ucav_amd/libhx_x6.so; do
+  for L in hirl4ucav_amd/libhx_mi355.so hirl4ucav_amd/libhx_x9full.so; do
     echo "== $L: error of the acting kernel against an fp64 evaluation, 16,384 rows (max / mean), beside the fp32-MFMA kernel's"
     HX_LIBRARY="$R/$L" python3 - <<'PY'
 import numpy as np, torch, sys
@@ -53,7 +53,7 @@ PY
   done
   for cfg in "" "--steps 20 --warmup 5" "--envs 65536 --scenario circular --type linear --bc_weight 0.5" "--agent sac --envs 16384 --scenario serpentine" "--envs 8192 --scenario circular --type linear --bc_weight 0.5" "--no-front --dtype f32x9"; do
     for rep in 1 2; do
-      for L in hirl4ucav_amd/libhx_mi355.so hirl4ucav_amd/libhx_x6.so; do
+      for L in hirl4ucav_amd/libhx_mi355.so hirl4ucav_amd/libhx_x9full.so; do
         # shellcheck disable=SC2086
         HX_LIBRARY="$R/$L" python3 bench.py $cfg --no-cpu-baseline --no-sweep 2>/dev/null | tail -1 | python3 -c "
 import json, sys
