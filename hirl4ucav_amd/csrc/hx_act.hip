@@ -36,12 +36,15 @@ static void launch_act_k(K kernel, dim3 grid, const ActFusedArgs& H, hipStream_t
 template <bool GAUSS, bool BF16, bool RELU, bool F32I = false, bool X3 = false>
 static void launch_act_t(const ActFusedArgs& H, hipStream_t st) {
     const bool env = H.state != nullptr;
-    // 32 rows per workgroup: from 8,192 rows on (fp32: below that, 16-row workgroups fill the chip and the fp32 MFMA work per workgroup
-    // is the longer pole); bf16: the same switch point by default (HX_ACT_BF16_NRT2_ROWS moves it: there the launch is bound by every workgroup pulling
-    // W2 through L2, not by MFMA)
-    static const int nrt2_bf16 = getenv("HX_ACT_BF16_NRT2_ROWS") ? atoi(getenv("HX_ACT_BF16_NRT2_ROWS")) : 8192;  // tuning knob
+    // 32 rows per workgroup: fp32 MFMA from 8,192 rows on (below that, 16-row workgroups fill the chip and the fp32 MFMA work per workgroup
+    // is the longer pole); bf16 and the exact-split format [r5]: as soon as 16-row workgroups would need a second round (4,097 rows: there the launch is
+    // bound by every workgroup pulling its images through L2, not by MFMA)
+    static const int nrt2_bf16 = getenv("HX_ACT_BF16_NRT2_ROWS") ? atoi(getenv("HX_ACT_BF16_NRT2_ROWS")) : 4097;  // tuning knob; [r5] 4,097 (was 8,192): 5,120 rows 22.6 -> 14.3 us (profiles/r05_act_x9_tiling_time.txt)
     static const int nrt2_f32 = getenv("HX_ACT_F32_NRT2_ROWS") ? atoi(getenv("HX_ACT_F32_NRT2_ROWS")) : 8192;     // tuning knob (tools/ubench/merge_probe.sh)
-    static const int nrt2_x9 = getenv("HX_ACT_X9_NRT2_ROWS") ? atoi(getenv("HX_ACT_X9_NRT2_ROWS")) : (1 << 30);  // tuning knob; default: 16-row workgroups (256 of them fill the chip up to 4,096 rows; beyond 8,192 the persistent kernel runs)
+    // tuning knob; default [r5]: 32-row workgroups as soon as 16-row ones would need a second round (4,097 .. 8,192 rows: 5,120 rows 30.5 -> 19.2 us, 8,192 rows
+    // 31.7 -> 21.5 us act + env + insert, tools/ubench/act_x9_tiling_time.py, profiles/r05_act_x9_tiling_time.txt; fp32 MFMA from the fp32 image 35.0 / 27.9);
+    // up to 4,096 rows 256 16-row workgroups fill the chip; beyond 8,192 the persistent kernel runs
+    static const int nrt2_x9 = getenv("HX_ACT_X9_NRT2_ROWS") ? atoi(getenv("HX_ACT_X9_NRT2_ROWS")) : 4097;
     {
         if (H.rows >= (X3 ? nrt2_x9 : BF16 ? nrt2_bf16 : nrt2_f32)) {
             const dim3 grid((unsigned)((H.rows + 2 * RT - 1) / (2 * RT)));

@@ -121,7 +121,7 @@ def test_bench_labels_follow_the_arguments():
     check(d, 1, 60, 10, dtype="f32 (policy product: exact bf16 x 9 split)")
     assert "configs[" not in d["config"]["workload"] and "three-way bf16 split" in d["config"]["workload"] and d["roofline"]["peak"] == 157.3  # (algorithmic fp32 FLOPs against the fp32 matrix peak ...)
     ex = d["roofline"]["executed"]  # (... and the nine bf16 MFMAs per fp32 product it executes against the bf16 peak)
-    assert ex["peak"] == 2500.0 and ex["flop_per_launch"] > 5 * d["roofline"]["flop_per_launch"] and abs(ex["frac"] - ex["achieved"] / 2500.0) < 1e-3
+    assert ex["peak"] == 2500.0 and ex["flop_per_launch"] > 4 * d["roofline"]["flop_per_launch"] and abs(ex["frac"] - ex["achieved"] / 2500.0) < 1e-3
     assert d["roofline"]["traffic"] is None  # (the committed PMC passes are of the fp32-MFMA kernel)
     d = run([sys.executable, "bench.py", "--agent", "sac", "--envs", "16384", "--scenario", "serpentine", "--cpu-seconds", "4"] + common)
     check(d, 1, 60, 10, envs=16384)

@@ -6,7 +6,7 @@
 # rank's launch sequence over RCCL at world size 1 (program directly after `--`: python3 <script>).
 set -uo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}
-TAG=${1:-r04}; QUICK=${2:-}
+TAG=${1:-r05}; QUICK=${2:-}
 O="$R/gpurun_out/$TAG"
 mkdir -p "$O"
 cd "$R"

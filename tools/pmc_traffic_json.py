@@ -30,7 +30,7 @@ out = {"_comment": "HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / --p
                    "the persistent act_persist_*_kernel<..., ENV> beyond), 'fused_bf16_<n>' the same with the bf16 policy, 'front_<n>' the front launch (act_front_kernel: the same "
                    "plus launches A and B of learn() on the minibatch; algorithmic bytes = the env step's only); their reads include the policy's W2 per "
                    "workgroup out of L2, which the counter does not see.",
-       "kernel_build": "round 4: persistent acting kernels beyond 8,192 envs (hx_actp.hip); env kernel as in round 3", "measured_at_commit": commit}
+       "kernel_build": "round 5: fp32 acting in the exact-split format from 4,096 rows on (six partial products), bf16 acting kernels with LayerNorm 2 + final layer from the accumulators; env kernel as in round 3", "measured_at_commit": commit}
 for f in sorted(glob.glob(os.path.join(d, "pmc_FETCH_SIZE_env_*.csv"))):
     mt = re.search(r"env_(\d+)(_bf16)?\.csv", f)
     n, dt = int(mt.group(1)), (mt.group(2) or "")
