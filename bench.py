@@ -18,7 +18,7 @@ episodes (random_reset, Philox), synthetic 20,000-row expert set, seeded-init ne
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
 Shape of a run: [settle: untimed steps for --settle-s seconds, so that clocks and caches are where a long run keeps them] ->
-W warm-up steps -> R = --reps (3) repetitions of { barrier + synchronize -> EXACTLY K steps with nothing but the hot path on the stream
+W warm-up steps -> [--dry-regions (1) untimed region of the same shape, declared] -> R = --reps (3) repetitions of { barrier + synchronize -> EXACTLY K steps with nothing but the hot path on the stream
 -> synchronize + barrier (max over ranks) }; `value` / `ms_per_step` are the MEDIAN repetition, all R are listed.
 Everything that needs events or stamped launches (stage times, the act + env launch's own duration for the roofline, the stand-alone env
 kernel, all-reduce times) runs in a SECOND pass after the clock has been read.
@@ -66,6 +66,8 @@ def parse(argv=None):
                         "bf16: actor AND critic — policy inference and the three 256<->512 products of every network in learn() on bf16 MFMA, fp32 "
                         "accumulation, fp32 master weights / Adam / LayerNorm / dynamics (BASELINE.json configs[4]); bf16_policy: policy inference only")
     p.add_argument("--reps", type=int, default=3, help="timed repetitions of K steps; value = the median repetition (SURVEY.md 8d)")
+    p.add_argument("--dry-regions", dest="dry_regions", type=int, default=1,
+                   help="untimed barrier-to-barrier regions of K steps between the warm-up and the timed repetitions (declared in the JSON line)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="total budget of the CPU baseline legs")
     p.add_argument("--no-sweep", action="store_true", help="skip the env-step kernel sweep over 4k..4M envs per launch (< 1 s)")
@@ -449,7 +451,8 @@ def baseline_port(args, seconds):
         if dt > seconds or steps >= 2000:
             break
     pool.shutdown()
-    return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": cores, "kind": "port",
+    # `cores` = the threads this baseline actually USED at once (the env phase and the torch phase alternate: the larger of the two), not the box's 256
+    return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": max(len(chunks), int(torch_threads)), "kind": "port",
             "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s: oracle C env step on {len(chunks)} threads + torch-CPU actor forward and "
                       f"HIRL learn on {torch_threads} threads (the fastest of {sorted(tried)}: seconds per vector step {tried})",
             "threads": {"env_step": len(chunks), "torch": torch_threads, "torch_tried_s_per_step": tried, "logical_cores": cores},
@@ -506,7 +509,7 @@ def baseline_port_sac(args, seconds):
         if dt > seconds or steps >= 2000:
             break
     pool.shutdown()
-    return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": cores, "kind": "port",
+    return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": max(len(chunks), int(torch_threads)), "kind": "port",
             "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s: oracle C env step on {len(chunks)} threads + torch-CPU SAC explore and "
                       f"learn on {torch_threads} threads (the fastest of {sorted(tried)}: seconds per vector step {tried})",
             "threads": {"env_step": len(chunks), "torch": torch_threads, "torch_tried_s_per_step": tried, "logical_cores": cores},
@@ -820,6 +823,13 @@ def run_rank(args):
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         loop.step()
+    # one UNTIMED dry region of the same shape (declared: `dry_regions`): the first barrier-to-barrier region behind the settle phase reads 2-15 us per step
+    # high in the 20-step form (69.4 / 56.8 / 54.5 and 61.4 / 53.3 / 54.1 us in two round-5 runs: the median of three then lands on the second-worst)
+    for _ in range(max(int(args.dry_regions), 0)):
+        barrier()
+        for _ in range(args.steps):
+            loop.step()
+        barrier()
     # ---- the timed region: R repetitions of K steps, nothing else on the stream ----
     reps = []
     for _ in range(max(int(args.reps), 1)):
@@ -890,7 +900,7 @@ def run_rank(args):
     value = n_total * args.steps / dt
     res = {
         "metric": "env steps/sec (whole node) + HIRL update steps/sec at 4096 envs/GPU", "value": round(value, 1),
-        "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_s": args.settle_s, "settle_steps": settle_steps,
+        "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_s": args.settle_s, "settle_steps": settle_steps, "dry_regions": max(int(args.dry_regions), 0),
         "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32", "bf16": "bf16", "bf16_policy": "bf16 policy / f32 update", "f32x9": "f32 (policy product: exact bf16 x 9 split)"}[args.dtype], "data": "synthetic",
         "repetitions": {"count": len(reps), "statistic": "median", "ms_per_step": [round(t / args.steps * 1e3, 5) for t in reps],
@@ -902,7 +912,7 @@ def run_rank(args):
                    "parallelism": f"dp{world}: env shards + replicated nets, {'peer-read ' + args.exchange if (world > 1 and args.exchange in ('oneshot', 'twostage', 'twostage-bf16')) else 'RCCL'} "
                                   f"all-reduce of the flat gradients; effective batch = {args.batch} x {world}"},
         "update_steps_per_s": round(args.steps / dt, 1),
-        "timed_region": "R x [K x step() between two barrier + synchronize pairs]; no events, no stamped or split launches inside (those are the second pass)",
+        "timed_region": "R x [K x step() between two barrier + synchronize pairs]; no events, no stamped or split launches inside (those are the second pass); `dry_regions` untimed regions of the same shape run before the first timed one",
         "stage_us": {"pass": f"second pass, {m_steps} steps after the timed region (events add a few us per step)",
                      "act+env_step(1 kernel)": None if med["act+env"] is None else round(med["act+env"], 2),
                      "act(own launch, every 4th step)": None if act_us is None else round(act_us, 2),
@@ -918,6 +928,11 @@ def run_rank(args):
         ref_loop = Loop(ref_args, rank, world, device)
         for _ in range(max(args.warmup, 64)):
             ref_loop.step()
+        for _ in range(max(int(args.dry_regions), 0)):  # (the same untimed dry region as the line's own loop)
+            barrier()
+            for _ in range(args.steps):
+                ref_loop.step()
+            barrier()
         ref_reps = []
         for _ in range(max(int(args.reps), 1)):
             barrier()

@@ -77,7 +77,7 @@ def check(d, n_gpus, steps, warmup, envs=4096, dtype="f32", fused=True, shared_g
         assert front or shared_gpu or d["stage_us"]["act+env_step(1 kernel)"] >= r["us_per_launch"] * 0.8  # events around the launch >= the kernel's own stamps
     else:
         assert r["bound"] == "hbm" and "env_step_kernel" in r["kernel"] and "roofline_env_kernel" not in d
-    assert "settle_s" in d and "timed_region" in d and d["stage_us"]["sample+learn"] > 0
+    assert "settle_s" in d and "dry_regions" in d and "timed_region" in d and d["stage_us"]["sample+learn"] > 0
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")

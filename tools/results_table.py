@@ -1,0 +1,71 @@
+"""Markdown tables of a round's measurement set (tools/measure_round.sh <tag> -> gpurun_out/<tag>/ or profiles/<tag>_*): the lines DESIGN.md section 8 quotes.
+    python tools/results_table.py profiles/r05_            (a file-name prefix: <prefix>bench_default_line_with_sweep_and_cpu.json, ...)"""
+import csv
+import json
+import os
+import sys
+
+pre = sys.argv[1]
+
+
+def load(name):
+    p = pre + name
+    return json.load(open(p)) if os.path.exists(p) else None
+
+
+def line(d):
+    return f"{d['value'] / 1e6:.1f} M env steps/s, {d['ms_per_step'] * 1e3:.2f} µs, {d.get('update_steps_per_s', 0):,.0f} `learn()`/s"
+
+
+d = load("bench_default_line_with_sweep_and_cpu.json")
+dd = load("bench_driver_form_steps20_warmup5.json")
+print("| workload (one GPU, one `learn(B=128)` per vector step) | reference order | **front loop** |")
+print("|---|---|---|")
+if d:
+    print(f"| **configs[1]** 4,096 straight_line, HIRL-soft fp32 — default run (3 × 20,000 steps) | {line(d['reference_order'])} | **{line(d)}** |")
+if dd:
+    print(f"| … the driver's form `--steps 20 --warmup 5` (3 × 20 steps; repetitions {', '.join('%.1f' % (x * 1e3) for x in dd['repetitions']['ms_per_step'])} µs) | {line(dd['reference_order'])} | **{line(dd)}** |")
+rows = {}
+p = pre + "bench_other_configs.jsonl"
+if os.path.exists(p):
+    for ln in open(p):
+        try:
+            x = json.loads(ln)
+        except Exception:
+            continue
+        c = x["config"]
+        key = c["workload"].split(", 1 learn")[0]
+        if "rccl_ranks" in x or "staged" in json.dumps(c):
+            key += " [sharded rank's sequence]"
+        if c.get("actions") == "uniform" or "uniform" in c["workload"]:
+            key += " [uniform actions]"
+        rows.setdefault(key, {})[c.get("loop")] = x
+for k, v in rows.items():
+    f, r = v.get("front"), v.get("reference order")
+    print(f"| {k} | {line(r) if r else '—'} | {('**' + line(f) + '**') if f else '—'} |")
+print()
+print("| configuration | dominant launch (rocprofv3 average, µs) | share of GPU time | the other launches (average µs × calls) |")
+print("|---|---|---|---|")
+for tag in ("f32", "f32_reference_order", "bf16", "staged_f32", "sac16k_serpentine", "circ8192_f32", "mixed16k_f32", "mixed16k_bf16", "circ65536_f32", "mixed131072_bf16"):
+    p = pre + f"bench_{tag}_kernel_stats.csv"
+    if not os.path.exists(p):
+        continue
+    rs = [r for r in csv.DictReader(open(p)) if "hx" in r["Name"] or "act_" in r["Name"] or "_l2" in r["Name"] or "wgrad" in r["Name"] or "kernel" in r["Name"]]
+    rs = [r for r in rs if "elementwise" not in r["Name"] and "rocclr" not in r["Name"]]
+    tot = sum(float(r["TotalDurationNs"]) for r in rs)
+    rs.sort(key=lambda r: -float(r["TotalDurationNs"]))
+
+    def nm(r):
+        return r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:44]
+    top = rs[0]
+    rest = "; ".join(f"`{nm(r)}` {float(r['AverageNs']) / 1e3:.2f} × {int(r['Calls'])}" for r in rs[1:7])
+    print(f"| {tag} | `{nm(top)}` **{float(top['AverageNs']) / 1e3:.2f}** × {int(top['Calls'])} | {float(top['TotalDurationNs']) / tot:.0%} | {rest} |")
+if d:
+    print()
+    r = d["roofline"]
+    print(f"roofline (default run): {r['bound']} {r['achieved']} / {r['peak']} {r['unit']} = {r['frac']}; {r['us_per_launch']} µs per launch (live stamp); traffic {r['traffic']}; other roof {r['other_roof']['achieved']} GB/s = {r['other_roof']['frac']}")
+    if "executed" in r:
+        print(f"executed: {r['executed']['achieved']} TFLOP/s = {r['executed']['frac']} of the bf16 peak")
+    print("env sweep:", " | ".join(f"{x['envs_per_launch']:,}: {x['us']} µs = {x['frac']}" for x in d["roofline_env_sweep"]))
+    c = d["cpu_baseline"]
+    print(f"cpu baseline: {c['value']:,.0f} env steps/s on {c['cores']} cores ({c.get('sample', '')[:120]}); B0 {c['b0_reference_plumbing']['value']}, B1 {c['b1_batched_cpu']['value']:,.0f}, B2 {c['b2_eager_rocm_learn']['value']}")
