@@ -280,7 +280,8 @@ int launch_front(const float* actor, const float* w2f, const uint16_t* w2x, cons
         // up to 32,768 envs two thirds of the CUs act (ceil(tiles / 176) row tiles per workgroup) and the rest serve the update beside them; beyond, the acting
         // workgroups take every CU (the update is a small share there) and the update's workgroups start as the first of them leave: two boundaries less
         static const int wide_wgs = getenv("HX_FRONT_PERSIST_WIDE_WGS") ? atoi(getenv("HX_FRONT_PERSIST_WIDE_WGS")) : 256;  // tuning knob
-        const int want = n <= 32768 ? 176 : wide_wgs;
+        static const int part_wgs = getenv("HX_FRONT_PERSIST_WGS") ? atoi(getenv("HX_FRONT_PERSIST_WGS")) : 176;  // tuning knob (tools/ubench/front_persist_wgs.sh)
+        const int want = n <= 32768 ? part_wgs : wide_wgs;
         const int ntiles = (int)((n + 2 * RT - 1) / (2 * RT)), tiles_per_wg = (ntiles + want - 1) / want;
         C.n_act = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
         const dim3 pgrid((unsigned)(C.n_act + C.n_fwd) + n_c);

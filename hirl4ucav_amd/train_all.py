@@ -373,6 +373,15 @@ def main(config):
             code = int(t.item())
         return code
 
+    if front and check_every and config.on_front_trip == "fallback" and config.snapshot_every and snap_path is None:
+        # a trip before the first periodic snapshot would leave nothing to go back to: take one of the starting state (every rank its shard)
+        if world > 1:
+            torch.distributed.barrier()
+        snap_path = os.path.join(log_dir, f"state_rank{rank}.pt")
+        CK.save_run(snap_path, eng, env, replay, {"episode": episode0, "expert_num": expert_num, "high_score": high_score, "success_rate": success_rate,
+                                                  "arttir": arttir, "seed": seed, "dtype": dtype})
+        if world > 1:
+            torch.distributed.barrier()
     episode = episode0
     while episode < config.episodes:
         w_now, warm = bc_weight_schedule(config.type, episode, config.bc_weight) if hirl else (0.0, 0.0)
