@@ -8,8 +8,8 @@ namespace hxact {
 using namespace hxnn;
 using namespace hxu;
 
-// -DHX_PX=mask builds a timing experiment (tools/ubench/actp_variants.sh; wrong results): 1 no head, 2 no LayerNorm 1, 4 no product MFMAs,
-// 8 no layer 1, 16 no z2 stores, 32 no noise draw
+// -DHX_PX=mask builds a timing experiment (tools/ubench/actp_variants.sh; wrong results): 1 no LayerNorm 2 / final layer / last step (the product then
+// is dead code and goes too), 2 no LayerNorm 1, 4 no product MFMAs, 8 no layer 1, 32 no noise draw, 128 every h1 fragment from slab 0
 #ifndef HX_PX
 #define HX_PX 0
 #endif
