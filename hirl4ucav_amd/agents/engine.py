@@ -168,7 +168,10 @@ class HirlEngine:
         self._pending = None  # a draw sample(defer=True) recorded for the next learn()
         # step_learn: hand-off words (flags int32[64], status int32[1]) + the epoch counter; two sets of minibatch tiles (the rest of learn() k still
         # reads set k while its first launch fills set k + 1 for the next front launch) and what the set in waiting was drawn for
-        self.front_c = "auto"  # launch C inside the front launch: front_c_for()
+        # launch C inside the front launch (front_c_for()).  [r5] OFF by default: with the six-term acting format the one size class where it paid (8,192 envs
+        # fp32: 67.2 -> 62.6 us per step in round 4) reads 62.1 -> 61.4 us — 1 % does not earn a third in-launch dependency (profiles/r05_front_c_8192.txt).  "auto"
+        # turns round 4's rule back on, True / False force it; HX_FRONT_C overrides both ways
+        self.front_c = False
         self._front = None
         self._front_epoch = 0
         self._front_c_epoch = 0  # front launches that carried launch C (their counters advance only then)

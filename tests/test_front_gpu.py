@@ -201,11 +201,13 @@ def test_front_launch_default_acting_format_is_the_exact_split(eng_mod):
 
 
 def test_launch_c_rides_only_where_the_cus_have_time_for_it(eng_mod):
-    """HirlEngine.front_c_for ("auto"): launch C inside the front launch only in the streaming acting role around 8,192 envs (fp32, exact split) — measured
-    slower everywhere else (profiles/r04c_front_c_ab.txt); front_c = True / False overrides.  (That the results do not depend on it: the parity test above
-    runs 8,192 envs with it, and test_launch_c_inside_the_front_launch_is_bit_identical forces it for every acting role.)"""
+    """HirlEngine.front_c_for: OFF by default since round 5 (the one size class where launch C inside the front launch paid — 8,192 envs fp32 — reads 62.1 -> 61.4 us
+    with the six-term acting format, profiles/r05_front_c_8192.txt); "auto" = round 4's rule: only in the streaming acting role around 8,192 envs (fp32, exact
+    split) — measured slower everywhere else (profiles/r04c_front_c_ab.txt); True / False force it.  (That the results do not depend on it:
+    test_launch_c_inside_the_front_launch_is_bit_identical forces it for every acting role.)"""
     e = eng_mod.HirlEngine(batch=128, use_bc=True)
-    assert e.front_c == "auto"
+    assert e.front_c is False and not e.front_c_for(8192, True, 0, False)
+    e.front_c = "auto"
     for actor_phase in (False, True):
         assert e.front_c_for(8192, actor_phase, 0, False) and e.front_c_for(8256, actor_phase, 0, False)
         for n in (32, 4096, 6144, 8704, 12288, 16384, 65536):
