@@ -3,7 +3,6 @@ hirl/agents/HIRL.py:52, and has no counterpart): RCCL direct (hx_rccl_*), the pe
 hx_allreduce_twostage), and the all-rank negotiation that decides whether RCCL direct is used.  HirlEngine (engine.py) drives them."""
 import ctypes
 import os
-import sys
 
 import torch
 
