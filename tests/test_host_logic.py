@@ -246,3 +246,22 @@ def test_env_snapshot_with_single_way_statistics_still_loads():
     env.stats.random_(0, 1000)
     ck.load_env_state(env2, ck.env_state(env))  # the current format round-trips way by way
     assert torch.equal(env.stats, env2.stats)
+
+
+def test_front_vs_reference_summaries_follow_from_the_committed_logs():
+    """The learning-outcome evidence for the front loop is reproducible from the logs beside it: tools/demo_front_summary.py over
+    profiles/r05_demo_front_vs_reference[_final]/ gives the committed summary.md, every run is there (3 scenarios x 3 seeds x {BC, HIRL-soft, TD3} x loop), each
+    log says which loop it ran, and front minus reference lies inside the seed-to-seed spread in every row."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tag in ("r05_demo_front_vs_reference", "r05_demo_front_vs_reference_final"):
+        d = os.path.join(root, "profiles", tag)
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "demo_front_summary.py"), d], capture_output=True, text=True, check=True).stdout
+        assert out.strip() == open(os.path.join(d, "summary.md")).read().strip(), tag
+        rows = [ln for ln in out.splitlines() if ln.startswith("| ") and "| front |" in ln or "| reference |" in ln]
+        per_run = [ln for ln in rows if ln.count("|") == 11]
+        assert len(per_run) == 3 * 3 * 2 * 2 and "LOG SAYS" not in out, (tag, len(per_run))
+        verdicts = [ln.split("|")[-2].strip() for ln in out.splitlines() if ln.startswith("| ") and ln.rstrip().endswith(("yes |", "NO |"))]
+        assert len(verdicts) == 6 and all(v == "yes" for v in verdicts), (tag, verdicts)
