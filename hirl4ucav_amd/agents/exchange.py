@@ -78,10 +78,16 @@ def negotiate_rccl_direct(group=None, flag_device="cpu", available=None, make_id
       4. connect(id, world, rank)  ncclCommInitRank + one probe all-reduce — only when step 3 agreed
       5. MIN all-reduce of `ok`    after the probe
     -> (the connected object, "") on every rank, or (None, why) on every rank (a communicator built by some ranks is closed again).
-    `available` / `make_id` / `connect` default to RcclDirect's; tests inject failing ones over gloo on the CPU."""
+    `available` / `make_id` default to RcclDirect's, `connect` to RcclDirect(id, world, rank) + probe on the current GPU; tests inject failing
+    ones over gloo on the CPU."""
     dist = torch.distributed
     available = RcclDirect.available if available is None else available
     make_id = RcclDirect.make_id if make_id is None else make_id
+    if connect is None:
+        def connect(uid, world, rank):
+            r = RcclDirect(uid, world, rank)
+            r.probe(torch.device("cuda", torch.cuda.current_device()))
+            return r
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     ok, why, conn = 1, "", None
 
