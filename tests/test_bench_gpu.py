@@ -201,7 +201,7 @@ def test_bench_two_ranks_launch_form(extra):
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
              "bench.py", "--gpus", "2", "--steps", steps, "--warmup", warm, "--no-cpu-baseline", "--no-sweep", "--settle-s", "0" if peer else "0.2"] + extra,
             env={"HX_BENCH_BACKEND": "gloo"})
-    check(d, 2, int(steps), int(warm))
+    check(d, 2, int(steps), int(warm), shared_gpu=True)  # both ranks on the box's one GPU: their launches interleave, durations of two kernels do not compare
     assert d["allreduce"] and all(a["median_us"] > 0 for a in d["allreduce"])
     assert d["env_stats"]["env_steps"] > 0
     assert d["replicas_identical"] is True  # 70 sharded updates later every rank holds the same networks and Adam moments, bit for bit
