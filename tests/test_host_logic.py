@@ -248,20 +248,38 @@ def test_env_snapshot_with_single_way_statistics_still_loads():
     assert torch.equal(env.stats, env2.stats)
 
 
-def test_front_vs_reference_summaries_follow_from_the_committed_logs():
+def test_front_vs_reference_summaries_follow_from_the_committed_logs(tmp_path):
     """The learning-outcome evidence for the front loop is reproducible from the logs beside it: tools/demo_front_summary.py over
-    profiles/r05_demo_front_vs_reference[_final]/ gives the committed summary.md, every run is there (3 scenarios x 3 seeds x {BC, HIRL-soft, TD3} x loop), each
-    log says which loop it ran, and front minus reference lies inside the seed-to-seed spread in every row."""
+    profiles/r05_demo_front_vs_reference[_final | _seeds3to8]/ gives the committed summary.md, every run is there (3 scenarios x 3 or 6 seeds x {BC, HIRL-soft,
+    TD3} x loop), each log says which loop it ran, and front minus reference lies inside the seed-to-seed spread in every row; the nine seeds run on the
+    round's final binaries (_final + _seeds3to8), pooled and PAIRED by (scenario, seed), show no difference between the loops."""
+    import shutil
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for tag in ("r05_demo_front_vs_reference", "r05_demo_front_vs_reference_final"):
+
+    def summary(d):
+        return subprocess.run([sys.executable, os.path.join(root, "tools", "demo_front_summary.py"), str(d)], capture_output=True, text=True, check=True).stdout
+
+    def verdicts(out):
+        return [ln.split("|")[-2].strip() for ln in out.splitlines() if ln.startswith("| ") and ln.rstrip().endswith(("yes |", "NO |"))]
+
+    for tag, seeds in (("r05_demo_front_vs_reference", 3), ("r05_demo_front_vs_reference_final", 3), ("r05_demo_front_vs_reference_seeds3to8", 6)):
         d = os.path.join(root, "profiles", tag)
-        out = subprocess.run([sys.executable, os.path.join(root, "tools", "demo_front_summary.py"), d], capture_output=True, text=True, check=True).stdout
+        out = summary(d)
         assert out.strip() == open(os.path.join(d, "summary.md")).read().strip(), tag
         rows = [ln for ln in out.splitlines() if ln.startswith("| ") and "| front |" in ln or "| reference |" in ln]
         per_run = [ln for ln in rows if ln.count("|") == 11]
-        assert len(per_run) == 3 * 3 * 2 * 2 and "LOG SAYS" not in out, (tag, len(per_run))
-        verdicts = [ln.split("|")[-2].strip() for ln in out.splitlines() if ln.startswith("| ") and ln.rstrip().endswith(("yes |", "NO |"))]
-        assert len(verdicts) == 6 and all(v == "yes" for v in verdicts), (tag, verdicts)
+        assert len(per_run) == 3 * seeds * 2 * 2 and "LOG SAYS" not in out, (tag, len(per_run))
+        assert len(verdicts(out)) == 6 and all(v == "yes" for v in verdicts(out)), (tag, verdicts(out))
+    for env in ("straight_line", "serpentine", "circular"):
+        for tag in ("r05_demo_front_vs_reference_final", "r05_demo_front_vs_reference_seeds3to8"):
+            for sd in os.listdir(os.path.join(root, "profiles", tag, env)):
+                if sd.startswith("seed"):
+                    shutil.copytree(os.path.join(root, "profiles", tag, env, sd), tmp_path / env / sd)
+    out = summary(tmp_path)
+    assert out.strip() == open(os.path.join(root, "profiles", "r05_demo_front_vs_reference_9seeds_summary.md")).read().strip()
+    assert all(v == "yes" for v in verdicts(out))
+    paired = [ln for ln in out.splitlines() if ln.startswith(("| HIRL-soft | 27 |", "| TD3 | 27 |"))]
+    assert len(paired) == 2 and all(ln.rstrip().endswith("| no |") for ln in paired), paired

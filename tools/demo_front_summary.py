@@ -27,7 +27,7 @@ def read(p):
 print("| scenario | seed | agent | loop | validations | last: success / fire success / reward | best success | mean success over validations | "
       "training kill rate, last quarter | env steps/s |")
 print("|---|---|---|---|---|---|---|---|---|---|")
-agg = {}
+agg, runs = {}, {}
 for env in ("straight_line", "serpentine", "circular"):
     for sd in sorted(glob.glob(os.path.join(root, env, "seed*"))):
         seed = os.path.basename(sd)[4:]
@@ -47,6 +47,7 @@ for env in ("straight_line", "serpentine", "circular"):
                 print(f"| {env} | {seed} | {agent} | {loop} | {len(v)} | {last[1]:.2f} / {last[2]:.2f} / {last[0]:.1f} | {best:.2f} | {mean:.2f} | "
                       f"{'-' if kr is None else f'{kr:.3f}'} | {rate} |")
                 agg.setdefault((env, agent, loop), []).append((last[1], best, mean, kr if kr is not None else float('nan'), last[0]))
+                runs[(env, seed, agent, loop)] = (mean, kr if kr is not None else float('nan'))
 
 
 def col(xs, i):
@@ -78,3 +79,22 @@ for (env, agent, loop), xs in agg.items():
         row += [f"{d:+.3f}", f"{spread:.3f}"]
         ok = ok and abs(d) <= spread + 0.02
     print(f"| {env} | {agent} | {row[0]} | {row[1]} | {row[2]} | {row[3]} | {'yes' if ok else 'NO'} |")
+
+# the same comparison PAIRED: front and reference runs of one (scenario, seed) share the expert set, the BC checkpoint and every seed
+print()
+print("Paired by (scenario, seed): front minus reference, mean over the pairs +- its standard error (sd / sqrt(pairs)); |mean| <= 2 standard errors = no difference shown:")
+print()
+print("| agent | pairs | d(mean validation success) | d(training kill rate) | difference shown? |")
+print("|---|---|---|---|---|")
+for agent in ("HIRL-soft", "TD3"):
+    pairs = [(runs[k], runs[(k[0], k[1], agent, "reference")]) for k in runs if k[2] == agent and k[3] == "front" and (k[0], k[1], agent, "reference") in runs]
+    if len(pairs) < 2:
+        continue
+    cells, shown = [], False
+    for i in (0, 1):
+        d = [a[i] - b[i] for a, b in pairs if a[i] == a[i] and b[i] == b[i]]
+        m = sum(d) / len(d)
+        se = (sum((x - m) ** 2 for x in d) / (len(d) - 1)) ** 0.5 / len(d) ** 0.5
+        cells.append(f"{m:+.3f} +- {se:.3f}")
+        shown = shown or abs(m) > 2 * se + 1e-12
+    print(f"| {agent} | {len(pairs)} | {cells[0]} | {cells[1]} | {'YES' if shown else 'no'} |")
