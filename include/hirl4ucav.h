@@ -368,6 +368,7 @@ int hx_hirl_learn_sampled(const HxNets* nets, const HxBatch* batch, const HxHype
  * of that launch may have been read half-written, and the caller must not go on: read *status at least every few hundred launches (hirl4ucav_amd/
  * train_all.py --status_check_every, default 256: on a trip it reloads its last snapshot and continues in the reference's order in the same process, or
  * exits with code 3) and fall back to hx_actor_act_step_* + hx_hirl_learn_sampled (no in-launch waits; `train_all --loop reference`, `bench.py --no-front`).
+ * (Roles taken in START order from a ticket would need no such assumption; measured, that costs 2.8 us of a 51.4 us step: docs/LEVERS.md, Round 5.)
  * hx_hirl_learn_back = the rest of the call (critic backward + gradients + Adam [+ the delayed actor step]) on the same `batch`; next / next_tiles
  * (or NULL): the draw of the NEXT front launch (guard = its n; *next->total is read inside this call's second launch, i.e. after this step's
  * inserts and before the next step's) into tiles of their own. */
