@@ -660,6 +660,18 @@ class HirlEngine:
         self.actor_trainable = not self.actor_trainable  # HIRL.py:332
         return out, env.obs, env.reward, env.done, env.success
 
+    @staticmethod
+    def front_waiting_workgroups(batch, with_c=False):
+        """How many workgroups of ONE front launch wait in-launch for others: launch B's two target-critic jobs (a 64-column workgroup per 16-row tile and
+        column slice: 8 per tile) and, with launch C riding, its two TD jobs (8 column workgroups per 8 rows).  Every workgroup of the launch is a whole CU
+        (1,024 threads, up to 128 VGPRs), the acting workgroups and launch A's never wait and leave within ~20 us — so while this count stays BELOW the
+        number of CUs (256 on MI355X), pending producers always find a CU under ANY dispatch order that places pending workgroups on free CUs, and every
+        wait ends long before its ~1 s bound.  Default shape (B = 128, launch C on its own): 128 of 256.  At B = 256 (256) or with launch C riding
+        (128 + 256) the count reaches the chip, and the waits lean on the dispatch order observed on gfx950: producers (lower indices) start first
+        (include/hirl4ucav.h hx_hirl_front; bounded waits + sticky status word + train_all's fallback cover that case)."""
+        tiles = (int(batch) + 15) // 16
+        return 2 * tiles * 8 + (2 * ((int(batch) + 7) // 8) * 8 if with_c else 0)
+
     def front_c_for(self, n, actor_phase, w_kind, bf16):
         """Does launch C (the critics' backward) ride in the front launch of this call too (HxFront.with_c)?  `front_c`: True / False, or "auto" (default):
         only where the acting workgroups leave the other CUs more time than the update's workgroups need — CU time bounds the front launch
@@ -688,9 +700,10 @@ class HirlEngine:
 
     def front_status(self):
         """The front launch's sticky status word (synchronises).  0: every in-launch wait was answered.  Bit 0: a launch-B workgroup gave up waiting for the
-        target actor's rows of its row tile (launch A); bit 1: a launch-C workgroup gave up waiting for the jobs of A / B it reads.  The waits assume that
-        the workgroups of one launch START in index order (producers have lower indices) — observed on gfx950, promised by nobody (include/hirl4ucav.h
-        hx_hirl_front): a set bit means a minibatch may have been read half-written, and every update since is suspect."""
+        target actor's rows of its row tile (launch A); bit 1: a launch-C workgroup gave up waiting for the jobs of A / B it reads.  In the default shape (B = 128, launch C on its own) the waiting
+        workgroups are half a chip's worth and the waits end under any dispatch order (front_waiting_workgroups); where they can fill the chip (B = 256, launch C riding) the waits
+        assume that the workgroups of one launch START in index order (producers have lower indices) — observed on gfx950, promised by nobody (include/hirl4ucav.h
+        hx_hirl_front).  A set bit means a minibatch may have been read half-written, and every update since is suspect."""
         return 0 if self._front is None else int(self._front[1].item())
 
     def front_check(self):

@@ -361,8 +361,13 @@ int hx_hirl_learn_sampled(const HxNets* nets, const HxBatch* batch, const HxHype
  * (and launch B in 64-column workgroups: hx_debug_set_fwd_nt).  The target critics wait IN the launch for the target actor's rows (per-row-tile
  * counters `flags`, agent-scope relaxed accesses, bounded wait ~1 s: bit 0 of *status is set if a launch-B workgroup gives up, bit 1 if a launch-C
  * workgroup does (HxFront.with_c)).
- * THE ASSUMPTION BEHIND THE WAITS: the workgroups of one launch START in index order (producers have the lower indices), so a waiting workgroup's
- * producers are running or done.  That is what gfx950 / ROCm 7.2 does (1.9 M free-running launches over every acting role: profiles/r04c_front_soak_*.json);
+ * WHY THE WAITS END.  Every workgroup of the launch is a whole CU; the acting workgroups and launch A's never wait and leave within ~20 us; the waiting
+ * ones are launch B's two target-critic jobs (16 per 16-row tile: 128 at B = 128) and, with launch C riding, its TD jobs (256 more).  While the waiting
+ * workgroups are FEWER than the CUs (256) — the default shape: B = 128, launch C on its own — a pending producer always finds a CU under ANY dispatch
+ * order that places pending workgroups on free CUs, and a wait ends within the acting workgroups' ~20 us (HirlEngine.front_waiting_workgroups).
+ * At B = 256 or with launch C riding the waiting workgroups can fill the chip, and there THE ASSUMPTION BEHIND THE WAITS is needed: the workgroups of one
+ * launch START in index order (producers have the lower indices), so a waiting workgroup's producers are running or done.  That is what gfx950 /
+ * ROCm 7.2 does (free-running soaks of every acting role, launch C riding included: profiles/r04c_front_soak_*.json, profiles/r05_soak_front_roles.jsonl);
  * HIP promises no dispatch order.  Under another order a wait still ends as soon as the producers get a CU (the acting workgroups never wait and leave
  * after ~20 us); only if EVERY resident workgroup were a waiting consumer could a wait run into its bound — then the status word says so, the minibatch
  * of that launch may have been read half-written, and the caller must not go on: read *status at least every few hundred launches (hirl4ucav_amd/

@@ -283,3 +283,14 @@ def test_front_vs_reference_summaries_follow_from_the_committed_logs(tmp_path):
     assert all(v == "yes" for v in verdicts(out))
     paired = [ln for ln in out.splitlines() if ln.startswith(("| HIRL-soft | 27 |", "| TD3 | 27 |"))]
     assert len(paired) == 2 and all(ln.rstrip().endswith("| no |") for ln in paired), paired
+
+def test_front_launch_waiters_stay_below_the_chip_in_the_default_shape():
+    """Why the front launch's in-launch waits end under any dispatch order in the default shape (include/hirl4ucav.h hx_hirl_front "WHY THE WAITS END"):
+    every workgroup is a whole CU, only launch B's target-critic jobs (and launch C's, when it rides) wait, and at B = 128 without launch C they are 128 of
+    the 256 CUs' worth; the shapes where they can fill the chip are the opt-in ones."""
+    from hirl4ucav_amd.agents.engine import HirlEngine
+
+    w = HirlEngine.front_waiting_workgroups
+    assert w(128) == 128 and w(64) == 64 and w(100) == 7 * 16  # two jobs x 8 column workgroups per 16-row tile
+    assert w(256) == 256 and w(128, with_c=True) == 128 + 256   # B = 256, or launch C riding: the count reaches the 256 CUs
+    assert w(128) < 256
