@@ -170,7 +170,8 @@ class HirlEngine:
         # reads set k while its first launch fills set k + 1 for the next front launch) and what the set in waiting was drawn for
         # launch C inside the front launch (front_c_for()).  [r5] OFF by default: with the six-term acting format the one size class where it paid (8,192 envs
         # fp32: 67.2 -> 62.6 us per step in round 4) reads 62.1 -> 61.4 us — 1 % does not earn a third in-launch dependency (profiles/r05_front_c_8192.txt).  "auto"
-        # turns round 4's rule back on, True / False force it; HX_FRONT_C overrides both ways
+        # turns round 4's rule back on, True / False force it; HX_FRONT_C overrides both ways.  One process per GPU only: with launch C riding the waiting workgroups
+        # outnumber the CUs, and beside two more processes on the same GPU its waits ran into their bound (profiles/r05_soak_front_shared_gpu.txt)
         self.front_c = False
         self._front = None
         self._front_epoch = 0

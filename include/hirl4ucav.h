@@ -365,6 +365,9 @@ int hx_hirl_learn_sampled(const HxNets* nets, const HxBatch* batch, const HxHype
  * ones are launch B's two target-critic jobs (16 per 16-row tile: 128 at B = 128) and, with launch C riding, its TD jobs (256 more).  While the waiting
  * workgroups are FEWER than the CUs (256) — the default shape: B = 128, launch C on its own — a pending producer always finds a CU under ANY dispatch
  * order that places pending workgroups on free CUs, and a wait ends within the acting workgroups' ~20 us (HirlEngine.front_waiting_workgroups).
+ * (One process per GPU: processes that share a GPU share its CUs, and their waiters add up.  Three processes free-running the default shapes on one GPU
+ * still never tripped, 100,000 steps each in every acting role; with launch C riding the third process made the waits time out — the status word caught
+ * it: profiles/r05_soak_front_shared_gpu.txt.)
  * At B = 256 or with launch C riding the waiting workgroups can fill the chip, and there THE ASSUMPTION BEHIND THE WAITS is needed: the workgroups of one
  * launch START in index order (producers have the lower indices), so a waiting workgroup's producers are running or done.  That is what gfx950 /
  * ROCm 7.2 does (free-running soaks of every acting role, launch C riding included: profiles/r04c_front_soak_*.json, profiles/r05_soak_front_roles.jsonl);
