@@ -434,3 +434,90 @@ def test_step_learn_that_is_refused_leaves_the_engine_as_it_was():
         eng.step_learn(env, None, None, act_sigma=0.1, sample_seed=5)
     eng.front_check()
     assert np.isfinite(eng.losses_host()[0])
+
+
+class _ScriptedFire:
+    """an engine whose policy is the loaded actor's, with the launch decision scripted (fire on the steps listed): a random-init actor never locks, and the
+    counters of the infinite env only move when missiles leave the rail"""
+
+    def __init__(self, eng, fire_steps):
+        self.eng, self.fire_steps, self.t, self.act_calls = eng, set(fire_steps), 0, 0
+
+    def act(self, obs):
+        a = self.eng.act(obs).clone()
+        a[:, 3] = 1.0 if self.t in self.fire_steps else -1.0
+        self.t += 1
+        return a
+
+
+@pytest.mark.parametrize("infinite", [False, True])
+def test_validate_all_round_is_the_references_loop_episode_by_episode(infinite):
+    """hirl4ucav_amd.validate_all.validate_round (one batch) against validate() of hirl/validate_all.py:25-77 restated over the single-env classes, one fresh env per
+    episode: scores, fire successes and — with --infinite — the launch counters of HarfangSerpentineInfiniteEnv (re-arm before every 60th call, :484-486)."""
+    import hirl4ucav_amd.environments.HarfangEnv_GYM as G
+    from hirl4ucav_amd import validate_all as V
+    from hirl4ucav_amd.agents import engine as E
+    from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
+
+    params = D.make_params(D.PARAM_SEED)
+    eng = E.HirlEngine(batch=128)
+    eng.load_params(params["actor"], params["critic"], params["bc_actor"])
+    episodes, steps, seed, dev = 5, 260, 11, torch.device("cuda")
+    fire_steps = (3, 61, 70, 125, 190, 241)  # 3: the first missile; 61 / 125 / 190 / 241: behind a re-arm; 70: nothing on the rail
+    benv = BatchedHarfangEnv(episodes, scenario="serpentine", seed=seed, auto_reset=False, random_reset=True, collect_stats=False)
+    benv.episode_ctr += 1  # (the single-env classes count the episode before they reset: the same Philox counter on both sides)
+    benv.reset()
+    got = V.validate_round(_ScriptedFire(eng, fire_steps), episodes, steps, True, seed, dev, infinite=infinite, env=benv)
+    # the reference's loop (validate_all.py:25-77), one env per episode so that every episode's call counter starts at 0 (the module's documented deviation)
+    scores, fire_success, launches, locked = [], 0, 0, 0
+    for e in range(episodes):
+        env = (G.HarfangSerpentineInfiniteEnv if infinite else G.HarfangSerpentineEnv)()
+        env._env = BatchedHarfangEnv(1, scenario="serpentine", seed=seed, auto_reset=False, random_reset=True, env_id0=e, collect_stats=False)
+        agent = _ScriptedFire(eng, fire_steps)
+        state = env.random_reset()
+        total, done = 0.0, False
+        for step in range(steps):
+            if not done:
+                action = agent.act(torch.from_numpy(np.asarray(state, np.float32)[None]).cuda())[0].cpu().numpy()
+                state, reward, done, _, *_rest = env.step_test(action)
+                total += reward
+                if step == steps - 1:
+                    break
+            else:
+                fire_success += int(env.fire_success)
+                break
+        scores.append(total)
+        if infinite:
+            launches += env.infinite_total_fire
+            locked += env.infinite_total_success
+    assert abs(got[0] - np.mean(scores)) <= 1e-4 * max(1.0, abs(np.mean(scores))), (got[0], np.mean(scores))
+    assert got[1] == fire_success / episodes
+    if infinite:
+        assert launches >= 3 * episodes - 2 and got[2] == (locked / launches if launches else 0.0), (got, launches, locked)  # re-armed missiles DID leave the rail
+    else:
+        assert got[2] == 0.0
+
+
+def test_validate_all_driver_loads_a_checkpoint_and_prints_the_references_lines(tmp_path, capsys):
+    """python -m hirl4ucav_amd.validate_all: the checkpoint files are the reference's (Agent.saveCheckpoints, HIRL.py:336-342), the output the two lines of
+    validate_all.py:202-204 (or the one of :200 with --infinite)."""
+    from hirl4ucav_amd import validate_all as V
+    from hirl4ucav_amd.agents import engine as E
+
+    params = D.make_params(D.PARAM_SEED)
+    torch.save({k: torch.as_tensor(v) for k, v in params["actor"].items()}, os.path.join(tmp_path, "Agent7_100_5_Actor_Harfang_GYM"))
+    common = ["--model_dir", str(tmp_path), "--model_name", "Agent7_100_5_", "--random", "--seed", "3", "--episodes", "8", "--validation_step", "200"]
+    r, s, f = V.main(V.parser().parse_args(["--agent", "HIRL"] + common))
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(r) == 2 and len(s) == 2 and f == [0.0, 0.0]
+    assert [float(x) for x in out[-2].split()] == pytest.approx([np.mean(r), np.std(r, ddof=1)]) and [float(x) for x in out[-1].split()] == pytest.approx([np.mean(s), np.std(s, ddof=1)])
+    r2, _, _ = V.main(V.parser().parse_args(["--agent", "HIRL"] + common))
+    assert r2 == r  # same seed, same rounds
+    rt, _, _ = V.main(V.parser().parse_args(["--agent", "TD3"] + common))
+    assert rt != r  # the same file read as a LeakyReLU network (TD3.py) is another policy
+    _, _, fi = V.main(V.parser().parse_args(["--agent", "HIRL", "--infinite"] + common))
+    last = capsys.readouterr().out.strip().splitlines()[-1].split()
+    assert len(last) == 2 and float(last[0]) == pytest.approx(np.mean(fi))
+    with pytest.raises(FileNotFoundError):
+        V.main(V.parser().parse_args(["--agent", "HIRL", "--model_dir", str(tmp_path), "--model_name", "missing_"]))
+    del E

@@ -294,3 +294,16 @@ def test_front_launch_waiters_stay_below_the_chip_in_the_default_shape():
     assert w(128) == 128 and w(64) == 64 and w(100) == 7 * 16  # two jobs x 8 column workgroups per 16-row tile
     assert w(256) == 256 and w(128, with_c=True) == 128 + 256   # B = 256, or launch C riding: the count reaches the 256 CUs
     assert w(128) < 256
+
+
+def test_validate_all_flags_are_the_references():
+    """hirl4ucav_amd.validate_all accepts every flag of hirl/validate_all.py:214-227 with the reference's defaults (and names the checkpoint, which the
+    reference hard-codes, through two required extras)."""
+    from hirl4ucav_amd import validate_all as V
+
+    a = V.parser().parse_args(["--model_dir", "d", "--model_name", "Agent1_50_0_"])
+    assert (a.agent, a.port, a.type, a.bc_weight, a.load_model, a.render, a.plot, a.seed, a.env, a.random, a.infinite) == \
+        ("HIRL", None, "linear", 1, False, False, False, None, "straight_line", False, False)
+    assert (a.nums, a.episodes, a.validation_step, a.scenario) == (2, 50, 1200, None)  # validate_all.py:192, :123, :187-190; serpentine whatever --env says
+    with pytest.raises(SystemExit):
+        V.parser().parse_args([])  # no checkpoint named
