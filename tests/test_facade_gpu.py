@@ -236,6 +236,13 @@ def test_sac_agent_facade_and_driver(tmp_path, capsys):
     agent.eng.policy.zero_(); agent.eng.critic.zero_(); agent.eng.target_critic.zero_()
     agent.eng.load_models(agent.model_dir, "Agent1_0_-5_")
     assert torch.equal(agent.eng.policy, before[:agent.eng.policy.numel()]) and float(agent.eng.critic.abs().sum()) > 0
+    # validate_sac.py on those files: python -m hirl4ucav_amd.validate_all --agent SAC (exploit = tanh(mean), SAC/agent.py:191-196)
+    from hirl4ucav_amd import validate_all as V
+
+    vr, vs, _ = V.main(V.parser().parse_args(["--agent", "SAC", "--model_dir", agent.model_dir, "--model_name", "Agent1_0_-5_", "--random", "--seed", "5",
+                                              "--episodes", "6", "--validation_step", "120"]))
+    assert len(vr) == 2 and all(np.isfinite(vr)) and all(0.0 <= x <= 1.0 for x in vs)
+    capsys.readouterr()
     T.MAX_STEP["serpentine"] = 30
     try:
         T.main(T.parser().parse_args(["--agent", "SAC", "--env", "serpentine", "--random", "--seed", "2", "--num_envs", "256", "--episodes", "2",
