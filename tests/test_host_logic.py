@@ -307,3 +307,14 @@ def test_validate_all_flags_are_the_references():
     assert (a.nums, a.episodes, a.validation_step, a.scenario) == (2, 50, 1200, None)  # validate_all.py:192, :123, :187-190; serpentine whatever --env says
     with pytest.raises(SystemExit):
         V.parser().parse_args([])  # no checkpoint named
+
+
+def test_sac_entry_points_keep_the_references_defaults():
+    """python -m hirl4ucav_amd.train_sac / validate_sac: the command lines of hirl/train_sac.py:441-457 and hirl/validate_sac.py:191-201 on the shared drivers."""
+    from hirl4ucav_amd import train_sac, validate_sac
+
+    a = train_sac.parser().parse_args(["--env", "serpentine", "--random"])
+    assert (a.agent, a.type, a.env, a.random, a.port, a.render, a.plot, a.seed) == ("SAC", "ESAC", "serpentine", True, None, False, False, None)
+    assert train_sac.parser().parse_args(["--type", "SAC"]).type == "SAC"
+    v = validate_sac.parser().parse_args(["--model_dir", "d", "--model_name", "t", "--infinite"])
+    assert (v.agent, v.type, v.infinite, v.env) == ("SAC", "ESAC", True, "straight_line")
