@@ -1,4 +1,4 @@
-import sys, ctypes, torch, numpy as np
+import sys, torch
 sys.path.insert(0, ".")
 from hirl4ucav_amd import _lib
 from hirl4ucav_amd.agents import sac_engine as SE

@@ -1,7 +1,7 @@
 import sys, os
 sys.path.insert(0, "/root/repo")
 os.chdir("/root/repo")
-import numpy as np, torch
+import torch  # noqa: F401 (CUDA context for the imports below)
 from tests import test_bf16_update_gpu as T
 from hirl4ucav_amd.agents import engine as E
 gd = os.path.join("tests", "golden")

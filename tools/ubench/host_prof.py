@@ -1,4 +1,4 @@
-import os, sys, time, collections
+import sys, time, collections
 import torch
 sys.path.insert(0, ".")
 import bench

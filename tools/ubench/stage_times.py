@@ -1,7 +1,7 @@
 """Back-to-back timing of each C-ABI stage (HIP events on the launch stream), to separate kernel time from
 profiler/launch artefacts.  Run on the GPU box: python tools/ubench/stage_times.py"""
 import sys, time
-import numpy as np, torch
+import torch
 sys.path.insert(0, ".")
 import bench as B
 from hirl4ucav_amd import _lib
