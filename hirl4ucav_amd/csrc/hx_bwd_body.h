@@ -261,7 +261,7 @@ __device__ __forceinline__ void bwd_l2_body(const BwdArgsC& AC, const int bx, co
             while ((int)(__hip_atomic_load(fo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - X.c_target) < 0 ||
                    (int)(__hip_atomic_load(ft2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - X.t_target) < 0 ||
                    (int)(__hip_atomic_load(X.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - X.arrive) < 0) {
-                if (++spins > 4000000) { atomicOr(X.status, 2u); break; }  // (the producers have lower workgroup ids and were dispatched first)
+                if (++spins > 4000000) { atomicOr(X.status, 2u); break; }  // (launch C riding: the waiters can outnumber the CUs — include/hirl4ucav.h hx_hirl_front; opt-in, one process per GPU)
                 __builtin_amdgcn_s_sleep(1);
             }
         }

@@ -198,7 +198,7 @@ __device__ __forceinline__ void fwd_l2_body(const FwdArgsC& A, const SAT& SA, co
             if (tid == 0) {
                 int spins = 0;
                 while ((int)(__hip_atomic_load(&X.flags[rt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - X.target) < 0) {
-                    if (++spins > 4000000) { atomicOr(X.status, 1u); break; }  // (~1 s: the producers have lower workgroup ids and were dispatched first)
+                    if (++spins > 4000000) { atomicOr(X.status, 1u); break; }  // (~1 s, never seen: include/hirl4ucav.h hx_hirl_front, WHY THE WAITS END)
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
