@@ -17,13 +17,21 @@ episodes (random_reset, Philox), synthetic 20,000-row expert set, seeded-init ne
                                           # a GPU) and relays rank 0's line; fails if fewer than N GPUs are visible
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
-Shape of a run: [settle: untimed steps for --settle-s seconds, so that clocks and caches are where a long run keeps them] ->
-W warm-up steps -> [--dry-regions (1) untimed region of the same shape, declared] -> R = --reps (3) repetitions of { barrier + synchronize -> EXACTLY K steps with nothing but the hot path on the stream
--> synchronize + barrier (max over ranks) }; `value` / `ms_per_step` are the MEDIAN repetition, all R are listed.
+Shape of a run: [settle: untimed steps for --settle-s seconds] -> W warm-up steps -> [--dry-regions (1) untimed region of the same shape,
+declared] -> R = --reps (3) repetitions of { barrier + synchronize -> EXACTLY K steps with nothing but the hot path on the stream ->
+synchronize + barrier (max over ranks) }; `value` / `ms_per_step` are the MEDIAN repetition, all R are listed.
 Everything that needs events or stamped launches (stage times, the act + env launch's own duration for the roofline, the stand-alone env
 kernel, all-reduce times) runs in a SECOND pass after the clock has been read.
+
+Which loop: the FRONT loop (env step + the first two launches of learn() in one launch, HirlEngine.step_learn) where it
+applies AND every rank has a GPU of its own; the reference's order otherwise (`config.loop`, `config.loop_reason`).  The front launch waits inside the
+launch; if such a wait ever gives up (sticky status word) the run is repeated in the reference's order IN THIS PROCESS and the line says so
+(`config.loop = "reference order (front tripped)"`, `front_status`): a valid line and exit code 0, never a crash and never a number from a tripped loop.
+
+The pieces: tools/bench_inputs.py (synthetic inputs), tools/bench_roofline.py (roofline records and their rule), tools/bench_baselines.py (CPU legs).
 """
 import argparse
+import copy
 import ctypes
 import json
 import os
@@ -31,19 +39,19 @@ import socket
 import subprocess
 import sys
 import time
+import traceback
 
 import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-FP32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak, same guide
-BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, same guide
-ENV_BYTES_FUSED = 550            # algorithmic bytes per env-step with the fused replay insert
-ENV_BYTES_PLAIN = 370
-ACTOR_FLOP = 272896              # forward FLOPs per sample (2 * MAC, GEMMs only), SURVEY.md 8d
-LEARN_FLOP_PER_SAMPLE = 3810816  # HIRL-soft learn(), averaged over the actor-every-2nd alternation, SURVEY.md 8d
+from tools.bench_baselines import (baseline_batched_cpu, baseline_eager_rocm_learn, baseline_port, baseline_port_sac,  # noqa: E402,F401
+                                   baseline_reference_plumbing, cpu_baselines)
+from tools.bench_inputs import init_params, synthetic_expert  # noqa: E402
+from tools import bench_roofline as RL  # noqa: E402
+
+CRITIC_MESSAGE_FLOATS = 276488  # the flat critic gradient: the larger of the two messages of a sharded update
 
 
 def parse(argv=None):
@@ -54,15 +62,15 @@ def parse(argv=None):
     p.add_argument("--settle-s", dest="settle_s", type=float, default=1.5,
                    help="untimed steps of the same loop for this many seconds BEFORE the warm-up (clocks, caches, allocator); 0 = off")
     p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    p.add_argument("--batch", type=int, default=128)
+    p.add_argument("--batch", type=int, default=128, help="rows of the minibatch of one learn(); up to 1,024 (beyond 256: the reference's order)")
     p.add_argument("--scenario", default="straight_line", choices=["straight_line", "serpentine", "circular", "mixed"],
                    help="mixed: scenario id = env id mod 3, sorted so that each third of the shard is one scenario (BASELINE.json configs[4])")
     p.add_argument("--type", default="soft", choices=["soft", "linear", "fixed"], help="HIRL BC-weight schedule (train_all.py:328-339)")
     p.add_argument("--bc_weight", type=float, default=0.5, help="linear / fixed: the weight (configs[3]: linear, 0.5)")
     p.add_argument("--agent", default="hirl", choices=["hirl", "sac"], help="sac: BASELINE.json configs[2] (use --envs 16384 --scenario serpentine)")
     p.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16_policy", "f32x9"],
-                   help="f32x9: fp32 everywhere, the policy's 256->512 product of the ACTING kernel through the exact three-way bf16 split of both operands on the bf16 matrix cores "
-                        "(fp32 operands, exact partial products, fp32 accumulation: fp32 results up to summation order; NOT the default); "
+                   help="f32x9: fp32 everywhere, the policy's 256->512 product of the ACTING kernel through the exact three-way bf16 split of both "
+                        "operands on the bf16 matrix cores at every size (fp32 results up to summation order; f32 takes it from 4,096 rows on); "
                         "bf16: actor AND critic — policy inference and the three 256<->512 products of every network in learn() on bf16 MFMA, fp32 "
                         "accumulation, fp32 master weights / Adam / LayerNorm / dynamics (BASELINE.json configs[4]); bf16_policy: policy inference only")
     p.add_argument("--reps", type=int, default=3, help="timed repetitions of K steps; value = the median repetition (SURVEY.md 8d)")
@@ -81,24 +89,32 @@ def parse(argv=None):
                         "GPU it does not pay (every cross-stream event hand-off costs ~10 us on this runtime), so the default, at any N, is "
                         "the reference's strict act -> step -> sample -> learn order on one stream")
     p.add_argument("--front", dest="front", action="store_true", default=None,
-                   help="(default where it applies: HIRL in fp32 or --dtype bf16 with the policy's actions in one launch, batch <= 256) the FRONT launch "
-                        "(HirlEngine.step_learn, include/hirl4ucav.h hx_hirl_front): env step + the first two launches of learn() as ONE launch; the minibatch is "
-                        "then drawn from the ring as it stood before this step's insert, without the slots it may overwrite")
+                   help="(default where it applies and every rank has a GPU of its own: HIRL in fp32 or --dtype bf16 with the policy's actions in one "
+                        "launch, batch <= 256) the FRONT launch (HirlEngine.step_learn, include/hirl4ucav.h hx_hirl_front): env step + the first two "
+                        "launches of learn() as ONE launch; the minibatch is then drawn from the ring as it stood before this step's insert, without "
+                        "the slots it may overwrite.  Given explicitly it is also taken by ranks that share a GPU (soak tests)")
     p.add_argument("--front-acting", dest="front_acting", default="x9", choices=["x9", "mfma"],
-                   help="--dtype f32 in the front loop: x9 (default, engine.front_x9) = the acting workgroups' 256 -> 512 product through the exact three-way bf16 split of both operands; mfma = fp32 MFMA")
+                   help="--dtype f32 in the front loop: x9 (default, engine.front_x9) = the acting workgroups' 256 -> 512 product through the exact "
+                        "three-way bf16 split of both operands; mfma = fp32 MFMA")
     p.add_argument("--no-front", dest="front", action="store_false",
-                   help="the reference's order on every step: act -> env step -> insert -> draw -> learn, each launch after the other (the minibatch sees this step's transitions)")
+                   help="the reference's order on every step: act -> env step -> insert -> draw -> learn, each launch after the other (the minibatch "
+                        "sees this step's transitions)")
     p.add_argument("--serial", action="store_true", help="(default) one stream")
     p.add_argument("--separate-launches", dest="separate_launches", action="store_true",
                    help="act and env step as two launches on every step (default: one fused launch, hx_actor_act_step)")
     p.add_argument("--staged", action="store_true",
                    help="run EXACTLY the launch sequence of a sharded rank on one rank too (stage entry points, split actor message, hx_adam_mixed, "
                         "both exchange calls — through torch.distributed when launched by torch.distributed.run): the cost of the N > 1 step")
-    p.add_argument("--exchange", default="rccl", choices=["rccl", "rccl-torch", "oneshot", "twostage", "twostage-bf16"],
+    p.add_argument("--exchange", default="rccl", choices=["rccl", "rccl-torch", "rccl-bf16", "oneshot", "twostage", "twostage-bf16", "auto"],
                    help="gradient exchange of the sharded step: rccl = ncclAllReduce enqueued by the library on the engine's stream (hx_rccl_allreduce; "
-                        "with the gloo test backend it falls back to torch.distributed); rccl-torch = torch.distributed.all_reduce; EXPERIMENTAL, never "
-                        "run on two physical GPUs: oneshot (every rank reads every peer's message over hipIpc mappings), twostage (reduce-scatter + "
-                        "all-gather over the same mappings), twostage-bf16 (its reduced slices as bf16)")
+                        "with the gloo test backend it falls back to torch.distributed); rccl-torch = torch.distributed.all_reduce; rccl-bf16 = the same "
+                        "direct path with the messages cast to bf16 (half the wire bytes, bf16 sums); EXPERIMENTAL, never run on two physical GPUs: "
+                        "oneshot (every rank reads every peer's message over hipIpc mappings), twostage (reduce-scatter + all-gather over the same "
+                        "mappings), twostage-bf16 (its reduced slices as bf16); auto = whichever of rccl / twostage the probe (below) found faster")
+    p.add_argument("--no-exchange-probe", dest="exchange_probe", action="store_false",
+                   help="N > 1: skip the probe that times --probe-messages all-reduces of the critic's 1.1 MB message through rccl AND twostage on the "
+                        "run's own process group before the timed loop (`exchange_probe` in the JSON line)")
+    p.add_argument("--probe-messages", dest="probe_messages", type=int, default=200)
     p.add_argument("--b0-episodes", dest="b0_episodes", type=int, default=0,
                    help="B0 (reference plumbing) in SURVEY.md 8(d)'s form: this many episodes of 1,500 steps (3 = ~4 minutes on the GPU box's host); "
                         "0 (default): a few-second sample, so that the default run stays within minutes")
@@ -106,6 +122,9 @@ def parse(argv=None):
                    help="one-shot exchange: how long a rank waits for a peer's message before it raises (ranks that SHARE a GPU - tests - "
                         "only make progress through pre-emption and need far longer than ranks with a GPU each)")
     p.add_argument("--measure-steps", dest="measure_steps", type=int, default=256, help="steps of the instrumented second pass")
+    p.add_argument("--inject-front-trip", dest="inject_front_trip", action="store_true",
+                   help="tests: the LAST rank sets its front launch's status word after the timed region, as a wait that gave up would — every rank "
+                        "must then repeat the run in the reference's order and rank 0 print a valid line")
     return p.parse_args(argv)
 
 
@@ -139,39 +158,48 @@ def launch_ranks(args, argv):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# synthetic inputs
+# which loop
 # ---------------------------------------------------------------------------------------------------------------------
-def synthetic_expert(rng, n=20000):
-    """states U(-1,1)^13 with cols 7,8 in {+-1}, col 12 in [0, 0.2]; actions U(-1,1)^3 ++ fire +-1, P(+1) = 1e-3."""
-    s = rng.uniform(-1, 1, (n, 13)).astype(np.float32)
-    s[:, 7] = np.where(rng.random(n) < 0.5, 1, -1)
-    s[:, 8] = np.where(rng.random(n) < 0.5, 1, -1)
-    s[:, 12] = rng.uniform(0, 0.2, n)
-    a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
-    a[:, 3] = np.where(rng.random(n) < 1e-3, 1, -1)
-    return s, a
+SHARED_GPU = "ranks share a GPU"
 
 
-def init_params(rng):
-    """Seeded-init networks with the reference's bounds (HIRL.py:26-37,111-121)."""
-    import math
-
-    def U(b, shape):
-        return rng.uniform(-b, b, shape).astype(np.float32)
-
-    def block(in_dim, out_dim, names):
-        fa, la, fb, lb, fin = names
-        return {fa + ".weight": U(math.sqrt(6 / in_dim), (256, in_dim)), fa + ".bias": U(1 / math.sqrt(in_dim), (256,)),
-                la + ".weight": np.ones(256, np.float32), la + ".bias": np.zeros(256, np.float32),
-                fb + ".weight": U(math.sqrt(6 / 256), (512, 256)), fb + ".bias": U(1 / 16, (512,)),
-                lb + ".weight": np.ones(512, np.float32), lb + ".bias": np.zeros(512, np.float32),
-                fin + ".weight": U(1 / math.sqrt(512), (out_dim, 512)), fin + ".bias": U(1 / math.sqrt(512), (out_dim,))}
-
-    actor = block(13, 4, ("full1", "layernorm1", "full2", "layernorm2", "final"))
-    bc = block(13, 4, ("full1", "layernorm1", "full2", "layernorm2", "final"))
-    critic = block(17, 1, ("full1", "layernorm1", "full2", "layernorm2", "final1"))
-    critic.update(block(17, 1, ("full3", "layernorm3", "full4", "layernorm4", "final2")))
-    return actor, critic, bc
+def loop_choice(args, world, shared_device):
+    """-> (front, reason).  The front launch (HirlEngine.step_learn / SacEngine.step_learn) where it applies; never by default when ranks share
+    a device: its in-launch waits are argued for ONE process per GPU (include/hirl4ucav.h hx_hirl_front — the waiters of several processes add up;
+    GPUTEST_r05: eight front-loop ranks on one GPU tripped and took the suite with them)."""
+    sac = args.agent == "sac"
+    why = []
+    if args.actions == "uniform":
+        why.append("uniform actions: no policy launch to fuse")
+    if args.separate_launches:
+        why.append("--separate-launches")
+    if args.overlap:
+        why.append("--overlap (two streams)")
+    if args.sample_launch:
+        why.append("--sample-launch (the draw as a launch of its own)")
+    if args.batch > 256:
+        why.append("batch > 256 (the front launch holds at most 16 row tiles of the minibatch)")
+    if sac:
+        if args.envs <= 8192:
+            why.append("the SAC front launch exists beyond 8,192 envs")
+        if world > 1:
+            why.append("the SAC front launch is single-GPU")
+    else:
+        if args.dtype not in ("f32", "f32x9", "bf16"):
+            why.append(f"--dtype {args.dtype}: the front launch takes fp32 networks or the bf16 actor + critic path")
+        if args.dtype in ("f32", "f32x9") and args.front_acting == "mfma" and args.envs > 8192:
+            why.append("fp32-MFMA acting in the front launch: at most 8,192 envs per GPU")
+    if args.front is True:
+        if why:
+            raise SystemExit("bench.py --front: " + "; ".join(why))
+        return True, "--front given" + (f" ({SHARED_GPU}: beyond the shape the in-launch waits are argued for; a trip falls back)" if shared_device else "")
+    if args.front is False:
+        return False, "--no-front given"
+    if shared_device:
+        why.append(f"{world} {SHARED_GPU}: the front launch's in-launch waits are for one process per GPU")
+    if why:
+        return False, "; ".join(why)
+    return True, "default where it applies (one process per GPU, policy actions in one launch, batch <= 256)"
 
 
 class Loop:
@@ -179,7 +207,7 @@ class Loop:
     else; step_measured() is the same step with events around the stages and, on request, act / env step as two launches with the
     env launch stamped — it is used only AFTER the timed region."""
 
-    def __init__(self, args, rank, world, device):
+    def __init__(self, args, rank, world, device, shared_device=False, forced_reason=None):
         import torch
 
         from hirl4ucav_amd import _lib
@@ -221,10 +249,13 @@ class Loop:
                 self.eng.sharded_sequence = True
             self.eng.set_act_dtype({"f32": "f32", "f32x9": "f32x9"}.get(args.dtype, "bf16"))
             self.eng.set_update_dtype("bf16" if args.dtype == "bf16" else "f32")
+            exchanging = world > 1 or args.staged
             if world > 1 and args.exchange in ("oneshot", "twostage", "twostage-bf16"):
-                self.eng.use_oneshot_exchange(timeout_ms=args.exchange_timeout_ms, two_stage=args.exchange != "oneshot", bf16=args.exchange == "twostage-bf16")
-            elif args.exchange == "rccl" and getattr(args, "pg_backend", None) == "nccl" and (world > 1 or args.staged):
-                self.eng.use_rccl_direct()  # (one GPU per rank: RCCL refuses ranks that share a device — the gloo test backend keeps torch.distributed)
+                self.eng.use_oneshot_exchange(timeout_ms=args.exchange_timeout_ms, two_stage=args.exchange != "oneshot",
+                                              bf16=args.exchange == "twostage-bf16")
+            elif args.exchange in ("rccl", "rccl-bf16") and getattr(args, "pg_backend", None) == "nccl" and exchanging:
+                # (one GPU per rank: RCCL refuses ranks that share a device — the gloo test backend keeps torch.distributed)
+                self.eng.use_rccl_direct(bf16=args.exchange == "rccl-bf16")
         es, ea = synthetic_expert(rng)
         # BC table rows (s, a) and the expert replay ring labelled on the GPU (train_all.py:289-306)
         bc_rows = np.zeros((es.shape[0], 32), np.float32)
@@ -251,13 +282,16 @@ class Loop:
         # act + env step + replay insert as ONE launch at every size (hx_actor_act_step / hx_sac_act_step: up to 8,192 envs one 16- / 32-row
         # workgroup per row tile with the env step on its first wave, beyond that the persistent kernel of csrc/hx_actp.hip)
         self.fused = not (self.uniform or self.separate)
-        if not self.sac and getattr(args, "front_acting", "x9") == "mfma":
+        if not self.sac and args.front_acting == "mfma":
             self.eng.front_x9 = False
-        sac_front_ok = self.sac and n > 8192 and self.world == 1 and not (self.uniform or self.separate or args.overlap or args.sample_launch) and args.batch <= 256
-        front_ok = sac_front_ok or not (self.sac or self.uniform or self.separate or args.overlap or args.sample_launch or args.dtype not in ("f32", "f32x9", "bf16") or n > ((1 << 30) if (args.dtype == "bf16" or getattr(args, "front_acting", "x9") == "x9") else 8192) or args.batch > 256)
-        if getattr(args, "front", None) and not front_ok:
-            raise SystemExit("--front: HIRL in fp32 or bf16 (actor and critic), policy actions in one launch, one stream, at most 8,192 envs per GPU with fp32-MFMA acting (exact-split acting and bf16: any number) and batch 256")
-        self.front = front_ok if getattr(args, "front", None) is None else bool(args.front)
+        if forced_reason is not None:  # the in-process repeat after a tripped front loop
+            self.front, self.loop_reason = False, forced_reason
+        else:
+            self.front, self.loop_reason = loop_choice(args, world, shared_device)
+
+    def close(self):
+        if hasattr(self.eng, "close"):
+            self.eng.close()
 
     # ---- the hot path ------------------------------------------------------------------------------------------------
     def _act_env(self, timed=None, split=False, stamp=None):
@@ -289,12 +323,13 @@ class Loop:
 
     def _learn(self, act_env):
         e = self.eng
+        defer = not (self.args.sample_launch or self.args.overlap)  # --overlap: the next env step may run beside learn(): draw first
         if self.sac:  # train_sac.py:401-403
-            e.sample(self.replay, seed=2 + self.rank, defer=not (self.args.sample_launch or self.args.overlap))
+            e.sample(self.replay, seed=2 + self.rank, defer=defer)
             e.learn()
             return
         # the draw and the gather ride in the first launch of learn() (hx_hirl_learn_sampled): same minibatch, one launch less
-        e.sample(self.replay, self.expert, self.bc_table, n_main=e.batch - self.expert_num, seed=2 + self.rank, defer=not (self.args.sample_launch or self.args.overlap))  # --overlap: the next env step may run beside learn(): draw first
+        e.sample(self.replay, self.expert, self.bc_table, n_main=e.batch - self.expert_num, seed=2 + self.rank, defer=defer)
         # a critic-only learn() leaves the acting network alone: the next act + env.step go out on the side stream now
         self.pipe.arm(act_env, acting_net_untouched=not e.actor_trainable, engine=e)
         w = self._bc_weight()
@@ -316,7 +351,7 @@ class Loop:
     def _front_step(self):
         """act + env step + replay insert AND launches A, B of learn() in one launch, then the rest of learn() (HirlEngine.step_learn)"""
         e = self.eng
-        if self.sac:  # explore + env step + insert AND the first forward launch of learn() in one launch, then the rest of learn() (SacEngine.step_learn)
+        if self.sac:  # explore + env step + insert AND the first forward launch of learn() in one launch, then the rest (SacEngine.step_learn)
             e.step_learn(self.env, act_seed=1, out=self.actions, sample_seed=2 + self.rank)
             return
         e.step_learn(self.env, self.expert, self.bc_table, n_main=e.batch - self.expert_num, act_sigma=0.1, act_seed=1, out=self.actions,
@@ -334,8 +369,6 @@ class Loop:
 
     # ---- the same step with instruments (second pass only) -----------------------------------------------------------------
     def step_measured(self, split, pool, kpool, stamp_front=True):
-        torch = self.torch
-
         def timed(name, fn):
             a, b = pool.pop(), pool.pop()
             a.record()
@@ -359,406 +392,22 @@ class Loop:
         timed("learn", lambda: self._learn(act_env))
         self.pipe.join()
         self.t += 1
-        del torch
 
-
-# ---------------------------------------------------------------------------------------------------------------------
-# CPU baselines (BASELINE.md 3 / SURVEY.md 8d): reported beside the GPU number, never a target.  The oracle may serve this leg.
-# ---------------------------------------------------------------------------------------------------------------------
-def host_cpu():
-    model = ""
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
-    return model, os.cpu_count() or 1
-
-
-def best_torch_threads(step, cores):
-    """torch's intra-op thread count that makes `step()` (ONE WHOLE vector step of the loop: actor forward for all envs, the env step on its worker
-    threads, one learn at B = 128 — calibrated on the torch part alone, a box once chose 64 threads that then ran the loop 5x slower beside the 16 env
-    threads) fastest on this host: the
-    default (one thread per physical core: 128 on the GPU boxes) is thread-oversubscribed for a 128-row MLP and reads 3-10x too slow — the CPU
-    figure is reported at its best, not at its worst.  -> (threads, {threads: seconds per step})"""
-    import torch
-
-    tried = {}
-    for t in [c for c in (1, 2, 4, 8, 16, 32, 64) if c <= cores] or [1]:
-        torch.set_num_threads(t)
-        step()  # warm
-        t0 = time.perf_counter()
-        for _ in range(4):
-            step()
-        tried[t] = round((time.perf_counter() - t0) / 4, 5)
-    best = min(tried, key=tried.get)
-    torch.set_num_threads(best)
-    return best, tried
-
-
-def baseline_port(args, seconds):
-    """The oracle timed on a BOUNDED sample of the same workload: the same loop (actor forward for all envs, env step for all
-    envs with insert — the envs split over host threads, >= 256 envs each —, one HIRL learn at B = 128) for as many vector steps as fit."""
-    import torch
-    from concurrent.futures import ThreadPoolExecutor
-
-    from oracle import hirl_oracle as H
-    from tests import _oracle as ox
-
-    n = args.envs
-    cores = os.cpu_count() or 1
-    rng = np.random.default_rng(0)
-    actor, critic, bc = init_params(rng)
-    es, ea = synthetic_expert(rng)
-    o = H.HirlOracle(actor, critic, bc)
-    envs, obs = ox.reset_batch(n, 0, 1, seed=0)
-    workers = max(1, min(cores, n // 256))
-    chunks = [(k * n // workers, (k + 1) * n // workers) for k in range(workers)]
-    cap = 1 << 14
-    rings = [np.zeros((cap, 32), np.float32) for _ in chunks]   # one private ring segment per worker (no shared head on the CPU side)
-    totals = [np.zeros(1, np.uint64) for _ in chunks]
-    epi = np.zeros(n, np.uint32)
-    pool = ThreadPoolExecutor(len(chunks))  # ctypes releases the GIL inside ox_env_step_batch
-
-    def work(k, a):
-        lo, hi = chunks[k]
-        ox.step_batch(envs[lo:hi], a[lo:hi], obs[lo:hi], max_step=1500, auto_reset=1, randomize=1, seed=0, env_id0=lo, episode_ctr=epi[lo:hi],
-                      ring=rings[k], total=totals[k])
-
-    count = [0]
-
-    def loop_step():
-        k = count[0]
-        a = o.choose_action(obs, rng.normal(0, 0.1, (n, 4)).astype(np.float32))
-        list(pool.map(lambda j: work(j, a), range(len(chunks))))
-        ring = rings[k % len(rings)]
-        m = max(min(int(totals[k % len(rings)][0]), cap), 1)
-        rows = ring[rng.integers(0, m, args.batch)]
-        ibc = rng.integers(0, es.shape[0], args.batch)
-        o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), (es[ibc], ea[ibc]),
-                rng.normal(0, 0.2, 4).astype(np.float32), 100 if k == 0 else o.bc_weight, 0.0)
-        count[0] = k + 1
-
-    torch_threads, tried = best_torch_threads(loop_step, cores)
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        loop_step()
-        steps += 1
-        dt = time.perf_counter() - t0
-        if dt > seconds or steps >= 2000:
-            break
-    pool.shutdown()
-    # `cores` = the threads this baseline actually USED at once (the env phase and the torch phase alternate: the larger of the two), not the box's 256
-    return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": max(len(chunks), int(torch_threads)), "kind": "port",
-            "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s: oracle C env step on {len(chunks)} threads + torch-CPU actor forward and "
-                      f"HIRL learn on {torch_threads} threads (the fastest of {sorted(tried)}: seconds per vector step {tried})",
-            "threads": {"env_step": len(chunks), "torch": torch_threads, "torch_tried_s_per_step": tried, "logical_cores": cores},
-            "update_steps_per_s": round(steps / dt, 2)}
-
-
-def baseline_port_sac(args, seconds):
-    """The SAC loop (train_sac.py:238-241,401-403) on the oracle: SacOracle.explore for all envs, the oracle's C env step with insert on host
-    threads, one SacOracle.learn at B = 128 per vector step — a BOUNDED sample of the same workload."""
-    import torch
-    from concurrent.futures import ThreadPoolExecutor
-
-    from oracle import sac_oracle as S
-    from tests import _oracle as ox
-
-    n = args.envs
-    cores = os.cpu_count() or 1
-    rng = np.random.default_rng(0)
-    o = S.SacOracle(S.init_mlp(rng, 13, 8), S.init_mlp(rng, 17, 1), S.init_mlp(rng, 17, 1))
-    scen = {"straight_line": 0, "serpentine": 1, "circular": 2}.get(args.scenario, 0)
-    envs, obs = ox.reset_batch(n, scen, 1, seed=0)
-    workers = max(1, min(cores, n // 256))
-    chunks = [(k * n // workers, (k + 1) * n // workers) for k in range(workers)]
-    cap = 1 << 14
-    rings = [np.zeros((cap, 32), np.float32) for _ in chunks]
-    totals = [np.zeros(1, np.uint64) for _ in chunks]
-    epi = np.zeros(n, np.uint32)
-    pool = ThreadPoolExecutor(len(chunks))
-
-    def work(k, a):
-        lo, hi = chunks[k]
-        ox.step_batch(envs[lo:hi], a[lo:hi], obs[lo:hi], max_step=1500, auto_reset=1, randomize=1, seed=0, env_id0=lo, episode_ctr=epi[lo:hi],
-                      ring=rings[k], total=totals[k])
-
-    count = [0]
-
-    def loop_step():
-        k = count[0]
-        a = o.explore(obs, rng.normal(0, 1, (n, 4)).astype(np.float32)).astype(np.float32)
-        list(pool.map(lambda j: work(j, a), range(len(chunks))))
-        ring = rings[k % len(rings)]
-        m = max(min(int(totals[k % len(rings)][0]), cap), 1)
-        rows = ring[rng.integers(0, m, args.batch)]
-        o.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 30], rows[:, 17:30], rows[:, 31]), rng.normal(0, 1, (args.batch, 4)).astype(np.float32),
-                rng.normal(0, 1, (args.batch, 4)).astype(np.float32))
-        count[0] = k + 1
-
-    torch_threads, tried = best_torch_threads(loop_step, cores)
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        loop_step()
-        steps += 1
-        dt = time.perf_counter() - t0
-        if dt > seconds or steps >= 2000:
-            break
-    pool.shutdown()
-    return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": max(len(chunks), int(torch_threads)), "kind": "port",
-            "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s: oracle C env step on {len(chunks)} threads + torch-CPU SAC explore and "
-                      f"learn on {torch_threads} threads (the fastest of {sorted(tried)}: seconds per vector step {tried})",
-            "threads": {"env_step": len(chunks), "torch": torch_threads, "torch_tried_s_per_step": tried, "logical_cores": cores},
-            "update_steps_per_s": round(steps / dt, 2)}
-
-
-def baseline_batched_cpu(seconds):
-    """B1: the batched CPU integrator alone on ALL host cores — the oracle's C env step (no policy, no update), one thread per logical
-    core, 1,024 envs per thread, uniform random actions: the fairest CPU line for the env half of the metric."""
-    from concurrent.futures import ThreadPoolExecutor
-
-    from tests import _oracle as ox
-
-    cores = os.cpu_count() or 1
-    per = 1024
-    n = cores * per
-    envs, obs = ox.reset_batch(n, 0, 1, seed=0)
-    rng = np.random.default_rng(1)
-    a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
-    epi = np.zeros(n, np.uint32)
-    pool = ThreadPoolExecutor(cores)
-
-    def work(k):
-        lo, hi = k * per, (k + 1) * per
-        for _ in range(8):  # 8 steps per dispatch: the Python hand-off stays below 1 % of the thread's time
-            ox.step_batch(envs[lo:hi], a[lo:hi], obs[lo:hi], max_step=1500, auto_reset=1, randomize=1, seed=0, env_id0=lo, episode_ctr=epi[lo:hi])
-
-    list(pool.map(work, range(cores)))  # warm
-    steps, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        list(pool.map(work, range(cores)))
-        steps += 8
-    dt = time.perf_counter() - t0
-    pool.shutdown()
-    return {"value": round(n * steps / dt, 1), "unit": "env steps/s", "cores": cores, "kind": "port",
-            "what": "the oracle's batched env step alone (scalar C, -O2, one thread per logical core, no policy / update)",
-            "sample": f"{steps} vector steps of {n} envs in {dt:.1f} s"}
-
-
-def baseline_reference_plumbing(seconds, episodes=0, episode_steps=1500):
-    """episodes > 0: SURVEY.md 8(d)'s form of B0 — that many episodes of `episode_steps` steps (straight_line's maxStep), each opened with
-    random_reset's message sequence (HarfangEnv_GYM.py:51-81), however long it takes (--b0-episodes: minutes; the default run takes a few-second sample).
-    B0 (configs[0]): ONE env behind the reference's loopback framing — 4-byte big-endian length + JSON (socket_lib.py:86-143), the
-    wrapper's message sequence per step (HarfangEnv_GYM.py:139-158: 6 level setters [+ FIRE_MISSILE] + UPDATE_SCENE; :193-251: 4
-    request/reply read-backs), no TCP_NODELAY on the client (the reference sets none) — with the oracle simulator as the server and
-    the oracle's eager CPU HIRL agent doing chooseAction + learn every step, as train_all.py:341-361 does."""
-    import torch
-
-    from hirl4ucav_amd.environments.wire import ALLY, OPPO, WireServer
-    from oracle import hirl_oracle as H
-    from tests._wire_backend import OracleSimBackend
-
-    rng = np.random.default_rng(0)
-    actor, critic, bc = init_params(rng)
-    es, ea = synthetic_expert(rng)
-    agent = H.HirlOracle(actor, critic, bc)
-    srv = WireServer(OracleSimBackend(), "127.0.0.1", 0).start()
-    sock = socket.create_connection(("127.0.0.1", srv.port))
-    sent = [0]
-
-    def send(command, **a):
-        body = json.dumps({"command": command, "args": a}).encode()
-        sock.sendall(len(body).to_bytes(4, "big") + body)
-        sent[0] += 1
-
-    def exact(k):
-        buf = b""
-        while len(buf) < k:
-            buf += sock.recv(k - len(buf))
-        return buf
-
-    def ask(command, **a):
-        send(command, **a)
-        return json.loads(exact(int.from_bytes(exact(4), "big")).decode())
-
-    def observe():
-        pa, po = ask("GET_PLANE_STATE", plane_id=ALLY), ask("GET_PLANE_STATE", plane_id=OPPO)
-        h = ask("GET_HEALTH", machine_id=OPPO)["health_level"]
-        slot = ask("GET_MISSILESDEVICE_SLOTS_STATE", machine_id=ALLY)["missiles_slots"][0]
-        d = (np.asarray(pa["position"]) - np.asarray(po["position"])) / 10000.0
-        return np.concatenate([d, np.asarray(pa["Euler_angles"]) / np.pi, [pa["target_angle"] / 180.0, 1.0 if pa["target_locked"] else -1.0,
-                               1.0 if slot else -1.0], np.asarray(po["Euler_angles"]) / np.pi, [h]]), float(np.linalg.norm(d) * 10000.0)
-
-    def random_reset():  # _random_reset_machine + _reset_missile + the first observation (HarfangEnv_GYM.py:51-81, :171-188)
-        send("RESET_MACHINE", machine_id=ALLY)
-        send("RESET_MACHINE", machine_id=OPPO)
-        send("SET_HEALTH", machine_id=OPPO, health_level=0.2)
-        send("RESET_MACHINE_MATRIX", machine_id=OPPO, position=[0, 4200, 0], rotation=[0, 0, 0])
-        send("RESET_MACHINE_MATRIX", machine_id=ALLY, position=[int(rng.integers(-100, 101)), 3500 + int(rng.integers(-100, 101)), -4000 + int(rng.integers(-100, 101))],
-             rotation=[0, 0, 0])
-        send("SET_PLANE_THRUST", plane_id=ALLY, thrust_level=1.0)
-        send("SET_PLANE_THRUST", plane_id=OPPO, thrust_level=0.6)
-        send("SET_PLANE_LINEAR_SPEED", plane_id=ALLY, linear_speed=300.0)
-        send("SET_PLANE_LINEAR_SPEED", plane_id=OPPO, linear_speed=200.0)
-        send("REARM_MACHINE", machine_id=ALLY)
-        return observe()[0]
-
-    obs, _ = observe()
-    # the replay memory starts with 128 rows, as after the reference's exploration episodes (train_all.py:266-282): learn() runs from step 1
-    mem = [rng.uniform(-1, 1, 32).astype(np.float32) for _ in range(128)]
-    steps, t0 = 0, time.perf_counter()
-    limit = episodes * episode_steps if episodes > 0 else 5000
-    while True:
-        if episodes > 0 and steps % episode_steps == 0:
-            obs = random_reset()
-        a = agent.choose_action(obs.astype(np.float32)[None], rng.normal(0, 0.1, 4).astype(np.float32))[0]
-        send("SET_PLANE_PITCH", plane_id=ALLY, pitch_level=float(a[0]))
-        send("SET_PLANE_ROLL", plane_id=ALLY, roll_level=float(a[1]))
-        send("SET_PLANE_YAW", plane_id=ALLY, yaw_level=float(a[2]))
-        send("SET_PLANE_PITCH", plane_id=OPPO, pitch_level=0.0)
-        send("SET_PLANE_ROLL", plane_id=OPPO, roll_level=0.0)
-        send("SET_PLANE_YAW", plane_id=OPPO, yaw_level=0.0)
-        if a[3] > 0:
-            send("FIRE_MISSILE", machine_id=ALLY, slot_id=0)
-        send("UPDATE_SCENE")
-        nobs, dist = observe()
-        r = -1e-4 * dist - 10.0 * nobs[6] - (8.0 if a[3] > 0 else 0.0)
-        mem.append(np.concatenate([obs, a, nobs, [r, 0.0]]).astype(np.float32))
-        obs = nobs
-        if len(mem) >= 128:
-            rows = np.stack([mem[i] for i in rng.choice(len(mem), 128, replace=False)])
-            ibc = rng.choice(es.shape[0], 128, replace=False)
-            agent.learn((rows[:, 0:13], rows[:, 13:17], rows[:, 17:30], rows[:, 30], rows[:, 31]), (es[ibc], ea[ibc]),
-                        rng.normal(0, 0.2, 4).astype(np.float32), 100 if len(mem) == 128 else agent.bc_weight, 0.0)
-        steps += 1
-        dt = time.perf_counter() - t0
-        if (episodes <= 0 and dt > seconds) or steps >= limit:
-            break
-        if len(mem) > 20000:  # (the sample is uniform over the memory: keep the full form's host memory bounded)
-            del mem[:10000]
-    sock.close()
-    srv.close()
-    return {"value": round(steps / dt, 2), "unit": "env steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "what": "configs[0]: 1 env behind the reference's socket framing (loopback TCP + JSON), eager CPU HIRL chooseAction + learn per step",
-            "sample": (f"{episodes} episodes x {episode_steps} steps = " if episodes > 0 else "") +
-                      f"{steps} env steps in {dt:.1f} s, {sent[0] / max(steps, 1):.1f} messages per step, one learn(B=128) per step"}
-
-
-def baseline_eager_rocm_learn(args, seconds, device):
-    """B2: the same HIRL learn() as stock eager PyTorch-ROCm ops on the GPU (the oracle's functional restatement with its tensors
-    on the device) — what the reference's agent costs when only its device string changes."""
-    import torch
-
-    from oracle import hirl_oracle as H
-
-    rng = np.random.default_rng(0)
-    actor, critic, bc = init_params(rng)
-    es, ea = synthetic_expert(rng)
-    o = H.HirlOracle(actor, critic, bc, device=device)
-    rows = torch.from_numpy(rng.uniform(-1, 1, (4096, 32)).astype(np.float32)).to(device)
-    est, eat = torch.from_numpy(es).to(device), torch.from_numpy(ea).to(device)
-    noise = torch.from_numpy(rng.normal(0, 0.2, 4).astype(np.float32)).to(device)
-
-    def one(k):
-        idx = torch.randint(0, rows.shape[0], (args.batch,), device=device)
-        ib = torch.randint(0, est.shape[0], (args.batch,), device=device)
-        b = rows[idx]
-        o.learn((b[:, 0:13], b[:, 13:17], b[:, 17:30], b[:, 30], (b[:, 31] > 0.9).float()), (est[ib], eat[ib]), noise, 100 if k == 0 else o.bc_weight, 0.0)
-
-    for k in range(4):
-        one(k)
-    torch.cuda.synchronize()
-    steps, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds and steps < 4000:
-        one(steps + 4)
-        steps += 1
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"value": round(steps / dt, 1), "unit": "learn() calls/s", "kind": "port",
-            "what": "HIRL learn(B=128) as eager PyTorch-ROCm ops on the same GPU (autograd + hand-written Adam/Polyak of the oracle)",
-            "sample": f"{steps} calls in {dt:.1f} s"}
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-def stamped_env_us(env, actions, launches):
-    """The env-step kernel's OWN duration (begin/end stamps of hipExtLaunchKernelGGL, what rocprofv3 reports) over `launches` launches."""
-    import torch
-
-    from hirl4ucav_amd import _lib
-
-    L = _lib.load()
-    evs = [(ctypes.c_void_p(L.hx_event_create()), ctypes.c_void_p(L.hx_event_create())) for _ in range(launches)]
-    for s, e in evs:
-        env.time_next_steps(s, e)
-        env.step(actions)
-    env.time_next_steps(None, None)
-    torch.cuda.synchronize()
-    us = []
-    for s, e in evs:
-        v = ctypes.c_float()
-        _lib.call("hx_event_elapsed_us", s, e, ctypes.byref(v))
-        us.append(v.value)
-        L.hx_event_destroy(s)
-        L.hx_event_destroy(e)
-    return us
-
-
-def env_sweep(device):
-    """The env-step kernel with the fused insert over 4k..4M envs per launch: the kernel's own duration, algorithmic 550 B per env-step."""
-    import torch
-
-    from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
-    from hirl4ucav_amd.utils.buffer import DeviceReplay
-
-    out = []
-    for n in (4096, 65536, 1 << 20, 1 << 22):
-        rep = DeviceReplay(max(2 * n, 1 << 20), device)
-        env = BatchedHarfangEnv(n, scenario="straight_line", device=device, seed=0, max_step=1500, replay=rep)
-        env.reset()
-        a = torch.rand(n, 4, device=device) * 2 - 1
-        for _ in range(3):
-            env.step(a)
-        us = float(np.median(stamped_env_us(env, a, 16)))
-        out.append({"envs_per_launch": n, "us": round(us, 2), "GBps": round(ENV_BYTES_FUSED * n / us / 1e3, 1),
-                    "frac": round(ENV_BYTES_FUSED * n / us / 1e3 / HBM_PEAK_GBPS, 4)})
-        del env, rep
-        torch.cuda.empty_cache()
-    return out
-
-
-def profile_traffic(envs):
-    """HBM bytes per launch of the env-step kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per
-    pass, gfx950 FETCH x2 calibration: tools/pmc_env.py).  Not measured by this run: reported under its own key with the file it came from."""
-    f = os.path.join(REPO, "profiles", "pmc_env_traffic.json")
-    if not os.path.exists(f):
-        return None
-    with open(f) as fh:
-        doc = json.load(fh)
-    pmc = doc.get(str(envs))
-    if not pmc:
-        return None
-    return {"bytes": pmc["traffic_bytes"], "fetch_bytes": pmc["fetch_bytes"], "write_bytes": pmc["write_bytes"], "ratio_to_algorithmic": pmc["ratio"],
-            "source": "profiles/pmc_env_traffic.json", "kernel_build": doc.get("kernel_build"), "measured_at_commit": doc.get("measured_at_commit"),
-            "note": "separate rocprofv3 --pmc passes of tools/pmc_env.py at this size; a profile artefact, not a measurement of this run"}
-
-
-POLICY_FLOP_SAC = 2 * (13 * 256 + 256 * 512 + 512 * 8)  # GaussianPolicy forward, GEMMs only
+    def front_status(self):
+        """the front launch's sticky status word (HIRL engine; the SAC front launch has no in-launch wait); synchronises"""
+        return int(self.eng.front_status()) if (self.front and hasattr(self.eng, "front_status")) else 0
 
 
 def workload_label(args):
     """what THIS run computes, from its arguments; a BASELINE.json configs[] index only where the arguments match that config"""
     if args.agent == "sac":
         what = f"{args.envs} parallel {args.scenario} envs per GPU, SAC fp32, 1 learn(B={args.batch}) per vector step"
-        cfg = 2 if (args.envs == 16384 and args.scenario == "serpentine") else None
-        tag = " (BASELINE.json configs[2])" if cfg == 2 else ""
+        tag = " (BASELINE.json configs[2])" if (args.envs == 16384 and args.scenario == "serpentine" and args.batch == 128) else ""
         return what + tag
     dt = {"f32": "fp32", "bf16": "bf16 actor/critic (fp32 accumulate, fp32 master weights / Adam / LayerNorm) + fp32 dynamics",
           "bf16_policy": "bf16 policy inference (fp32 accumulate) + fp32 dynamics / update",
-          "f32x9": "fp32 (acting kernel: the 256->512 product through the exact three-way bf16 split of both operands on bf16 MFMA, fp32 accumulate)"}[args.dtype]
+          "f32x9": "fp32 (acting kernel: the 256->512 product through the exact three-way bf16 split of both operands on bf16 MFMA at every size, "
+                   "fp32 accumulate)"}[args.dtype]
     kind = f"HIRL-{args.type}" + (f" (bc_weight {args.bc_weight})" if args.type != "soft" else "")
     what = f"{args.envs} parallel {args.scenario} envs per GPU, {kind} {dt}, 1 learn(B={args.batch}) per vector step"
     tag = ""
@@ -770,6 +419,243 @@ def workload_label(args):
         elif args.envs == 16384 and args.scenario == "mixed" and args.dtype == "bf16":
             tag = " (one GPU's shard of BASELINE.json configs[4])"
     return what + tag
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the run of one rank
+# ---------------------------------------------------------------------------------------------------------------------
+class Ctx:
+    """what every phase of a rank's run needs"""
+
+    def __init__(self, args, rank, world, device, pg, backend, shared_device):
+        self.args, self.rank, self.world, self.device, self.pg, self.backend, self.shared_device = args, rank, world, device, pg, backend, shared_device
+
+    def barrier(self):
+        import torch
+
+        if self.world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, v, op="MAX"):
+        import torch
+
+        if self.world <= 1:
+            return v
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
+        torch.distributed.all_reduce(t, op=getattr(torch.distributed.ReduceOp, op))
+        return float(t.item())
+
+
+def settle(ctx, loop):
+    """untimed steps of the same loop for --settle-s seconds; every rank leaves after the SAME number of collective calls"""
+    import torch
+
+    args, steps = ctx.args, 0
+    if args.settle_s <= 0:
+        return 0
+    t_end = time.perf_counter() + args.settle_s
+    while True:
+        for _ in range(32):
+            loop.step()
+        steps += 32
+        if ctx.world > 1:
+            # the all-reduced flag alone decides (a rank-local clock test here could let one rank fall out of the loop while its peers enqueue
+            # 32 more steps and one more flag exchange: mismatched collective sequences)
+            flag = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], device=ctx.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if float(flag.item()) == 0.0:
+                break
+        elif time.perf_counter() >= t_end:
+            break
+    torch.cuda.synchronize()
+    return steps
+
+
+def timed_regions(ctx, loop):
+    """[--dry-regions untimed regions] + R repetitions of { barrier + synchronize -> EXACTLY K x step() -> synchronize + barrier }, max over ranks.
+    The first barrier-to-barrier region behind the settle phase reads 2-15 us per step high in the 20-step form (69.4 / 56.8 / 54.5 us in a round-5
+    run: the median of three then lands on the second-worst): hence the declared dry region."""
+    args = ctx.args
+    for _ in range(max(int(args.dry_regions), 0)):
+        ctx.barrier()
+        for _ in range(args.steps):
+            loop.step()
+        ctx.barrier()
+    reps = []
+    for _ in range(max(int(args.reps), 1)):
+        ctx.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loop.step()
+        ctx.barrier()
+        reps.append(ctx.max_over_ranks(time.perf_counter() - t0))
+    return reps
+
+
+def second_pass(ctx, loop):
+    """stage events; the act + env (or front) launch stamped; every 4th step act and env step as two launches, the env launch stamped; events around
+    every gradient exchange.  -> dict of medians and lists in us"""
+    import torch
+
+    args = ctx.args
+    m_steps = max(int(args.measure_steps), 16)
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(12 * (m_steps + 1))]
+    L = loop.lib.load()
+    kpool = [ctypes.c_void_p(L.hx_event_create()) for _ in range(2 * (m_steps + 2))]
+    ar_events = []
+    exchanging = ctx.world > 1 or (args.staged and ctx.pg and args.agent == "hirl")
+    inner = getattr(loop.eng, "_allreduce", None)
+    if exchanging:  # events around every gradient exchange (on the stream it is enqueued on)
+        def timed_allreduce(t, kind=None):
+            call = (lambda: inner(t, kind)) if kind is not None else (lambda: inner(t))
+            if len(pool) >= 2:
+                a, b = pool.pop(), pool.pop()
+                a.record()
+                out = call()
+                b.record()
+                ar_events.append((t.numel() * 4, a, b))
+            else:
+                out = call()
+            return t if out is None else out
+        loop.eng._allreduce = timed_allreduce
+    for k in range(m_steps):
+        # front loop: the front launch right behind a split step is not stamped (it follows a foreign env step: no pre-drawn minibatch, a draw
+        # launch of its own in front of it, colder caches — a third of the stamped launches would be that slower first one)
+        loop.step_measured(split=(k % 4 == 3), pool=pool, kpool=kpool, stamp_front=(k % 4 != 0))
+    ctx.barrier()
+    if exchanging:
+        loop.eng._allreduce = inner
+        if getattr(loop.eng, "xchg", None) is not None:
+            loop.eng.xchg.check()  # a timed-out wait leaves garbage behind: fail loudly instead of printing a number
+    out = {"m_steps": m_steps, "exchanging": exchanging,
+           "med": {k: (float(np.median([a.elapsed_time(b) * 1e3 for a, b in v])) if v else None) for k, v in loop.rec.items()}}
+    kern = RL.stamped_us(loop.lib, loop.krec)
+    if not kern:  # uniform actions: the loop has no act launch to split off; stamp plain env steps
+        kern = RL.stamped_env_us(loop.env, loop.actions, 32)
+    out["env_kernel_us"] = kern
+    out["fused_us"] = RL.stamped_us(loop.lib, loop.krec_fused) if loop.fused else []
+    by = {}
+    for nbytes, a, b in ar_events:
+        by.setdefault(nbytes, []).append(a.elapsed_time(b) * 1e3)
+    out["allreduce"] = by
+    return out
+
+
+def measure(ctx, loop):
+    m = {"settle_steps": settle(ctx, loop)}
+    for _ in range(ctx.args.warmup):
+        loop.step()
+    m["reps"] = timed_regions(ctx, loop)
+    if ctx.args.inject_front_trip and loop.front and ctx.rank == ctx.world - 1 and getattr(loop.eng, "_front", None) is not None:
+        loop.eng._front[1].fill_(1)  # as a launch-B workgroup that gave up would leave it
+    m.update(second_pass(ctx, loop))
+    m["front_status"] = int(ctx.max_over_ranks(loop.front_status()))  # ONE decision for all ranks
+    return m
+
+
+def reference_order_leg(ctx, args):
+    """the SAME workload with every launch in the reference's order (act -> env step -> insert -> draw -> learn), timed the same way in the same
+    process: what the front launch buys, and the figure to quote if the draw must see the current step's transitions"""
+    ref_args = copy.copy(args)
+    ref_args.front = False
+    ref_loop = Loop(ref_args, ctx.rank, ctx.world, ctx.device)
+    for _ in range(max(args.warmup, 64)):
+        ref_loop.step()
+    reps = timed_regions(ctx, ref_loop)
+    dt = float(np.median(reps))
+    n_total = args.envs * ctx.world
+    return {"loop": "reference order (--no-front): the minibatch is drawn after this step's insert", "value": round(n_total * args.steps / dt, 1),
+            "unit": "env steps/s", "ms_per_step": round(dt / args.steps * 1e3, 5), "update_steps_per_s": round(args.steps / dt, 1),
+            "repetitions": {"count": len(reps), "statistic": "median", "ms_per_step": [round(t / args.steps * 1e3, 5) for t in reps]}}
+
+
+def probe_exchanges(ctx, loop):
+    """N > 1, before the timed loop: --probe-messages all-reduces of the critic's message (276,488 floats = 1.1 MB, the larger message of a sharded
+    update) through BOTH transports — `rccl` in this process, as the run uses it (direct, or torch.distributed with the gloo test backend), with events
+    on the stream it is enqueued on; the two-stage peer-read kernel over hipIpc mappings in CHILD processes (tools/exchange_probe.py, one per rank, a
+    process group of their own): that kernel has never met two physical GPUs, and whatever its first contact with real xGMI does — a refused mapping,
+    a wait that times out, a fault that aborts the process — must cost this run nothing but the probe's entry.  Every step ends with ONE all-rank
+    agreement, so no rank is left alone in a collective.  -> the `exchange_probe` record (rank 0's view; every rank returns the same `fastest`)"""
+    import torch
+
+    args, dev = ctx.args, ctx.device
+    count = max(int(args.probe_messages), 4) if not ctx.shared_device else min(max(int(args.probe_messages), 4), 24)
+    rec = {"message_bytes": 4 * CRITIC_MESSAGE_FLOATS, "messages": count, "transports": []}
+
+    def agree(ok):
+        return ctx.max_over_ranks(0.0 if ok else 1.0) == 0.0
+
+    # ---- rccl, as the run uses it ----
+    msg = torch.ones(CRITIC_MESSAGE_FLOATS, dtype=torch.float32, device=dev)
+    direct = getattr(loop.eng, "rccl", None)
+    entry = {"transport": getattr(loop.eng, "exchange_name", "rccl") if direct is not None else f"torch.distributed ({ctx.backend})"}
+
+    def rccl_one():
+        if direct is not None:
+            direct.allreduce(msg)
+        else:
+            torch.distributed.all_reduce(msg)
+
+    ok, why = True, ""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(count)]
+    try:
+        for _ in range(4):
+            msg.fill_(1.0)
+            rccl_one()
+        ctx.barrier()
+        for a, b in evs:
+            msg.fill_(1.0)  # (outside the timed pair; keeps the values bounded over hundreds of sums)
+            a.record()
+            rccl_one()
+            b.record()
+        torch.cuda.synchronize()
+        ok = bool((msg == float(ctx.world)).all())
+        why = "" if ok else "the sum of ones is not the world size"
+    except Exception as e:  # noqa: BLE001
+        ok, why = False, f"{type(e).__name__}: {e}"
+    if agree(ok):
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+        med = ctx.max_over_ranks(us[len(us) // 2])
+        entry.update({"ok": True, "median_us": round(med, 2), "p10_us": round(us[len(us) // 10], 2), "p90_us": round(us[(9 * len(us)) // 10], 2),
+                      "busbw_GBps": round(2 * (ctx.world - 1) / ctx.world * rec["message_bytes"] / med / 1e3, 2),
+                      "statistic": "the slowest rank's median (p10 / p90: rank 0's)"})
+    else:
+        entry.update({"ok": False, "error": why or "another rank failed"})
+    rec["transports"].append(entry)
+
+    # ---- twostage, in child processes ----
+    box = [free_port() if ctx.rank == 0 else None]
+    torch.distributed.broadcast_object_list(box, src=0)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}  # (the children rendezvous on a store of their OWN)
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(box[0]), "RANK": str(ctx.rank), "WORLD_SIZE": str(ctx.world),
+                "LOCAL_RANK": str(ctx.device.index), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    cmd = [sys.executable, os.path.join(REPO, "tools", "exchange_probe.py"), "--floats", str(CRITIC_MESSAGE_FLOATS), "--messages", str(count),
+           "--kind", "twostage", "--timeout-ms", str(args.exchange_timeout_ms)]
+    entry, out, err, rc = {"transport": "twostage", "where": "child processes (tools/exchange_probe.py)"}, "", "", None
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)  # a CHILD: nothing here replaces this process
+    try:
+        out, err = child.communicate(timeout=300)
+        rc = child.returncode
+    except subprocess.TimeoutExpired:
+        child.kill()
+        out, err = child.communicate()
+        rc = "timeout"
+    if agree(rc == 0):
+        line = [ln for ln in out.splitlines() if ln.startswith("{")]
+        got = json.loads(line[-1]) if line else {}  # (rank 0's child prints the record; the other ranks only learn that it worked)
+        keys = ("ok", "median_us", "p10_us", "p90_us", "busbw_GBps", "per_rank_median_us", "distinct_gpus", "statistic")
+        entry.update({k: got.get(k) for k in keys} if got else {"ok": True})
+    else:
+        tail = " | ".join(err.strip().splitlines()[-3:])[-600:]
+        entry.update({"ok": False, "error": f"rank {ctx.rank}: child exit {rc}" + (f": {tail}" if rc != 0 else " (another rank's child failed)")})
+    rec["transports"].append(entry)
+    # every rank must pick the same transport: rank 0 holds the children's figure, so rank 0 decides and broadcasts
+    good = [t for t in rec["transports"] if t.get("ok") and t.get("median_us")]
+    box = [min(good, key=lambda t: t["median_us"])["transport"] if (ctx.rank == 0 and good) else None]
+    torch.distributed.broadcast_object_list(box, src=0)
+    rec["fastest"] = box[0]
+    return rec
 
 
 def run_rank(args):
@@ -792,298 +678,146 @@ def run_rank(args):
     # Under a launcher the process group exists at ANY world size (RCCL = backend "nccl" on ROCm): with --staged a single rank then sends
     # its two messages per actor call through the collective library too.
     pg = world > 1 or launched
-    if pg:
+    own_pg = False
+    if pg and not torch.distributed.is_initialized():  # (tools/bench_many.py runs several argument sets on ONE process group)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+        own_pg = True
     args.pg_backend = backend if pg else None
-    loop = Loop(args, rank, world, device)
+    ctx = Ctx(args, rank, world, device, pg, backend, shared_device=world > ngpu)
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+    probe = None
+    if world > 1 and args.agent == "hirl" and (args.exchange == "auto" or (args.exchange == "rccl" and args.exchange_probe and not ctx.shared_device)):
+        # (ranks that share a GPU — the gloo rehearsals — probe only on request: --exchange auto)
+        # the probe needs the run's rccl transport: build the loop the run would use with `rccl`, probe, then pick
+        chosen = args.exchange
+        args.exchange = "rccl"
+        loop = Loop(args, rank, world, device, shared_device=ctx.shared_device)
+        probe = probe_exchanges(ctx, loop)
+        if chosen == "auto" and probe["fastest"] == "twostage":
+            loop.close()
+            args.exchange = "twostage"
+            loop = Loop(args, rank, world, device, shared_device=ctx.shared_device)
+        probe["requested"], probe["chosen"] = chosen, args.exchange
+    else:
+        loop = Loop(args, rank, world, device, shared_device=ctx.shared_device)
 
-    # ---- settle (declared, untimed), warm-up ----
-    settle_steps = 0
-    if args.settle_s > 0:
-        t_end = time.perf_counter() + args.settle_s
-        while True:
-            for _ in range(32):
-                loop.step()
-            settle_steps += 32
-            if world > 1:
-                # every rank leaves the phase after the SAME number of collective calls: the all-reduced flag alone decides (a rank-local
-                # clock test here could let one rank fall out of the loop while its peers enqueue 32 more steps and one more flag exchange)
-                flag = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], device=device)
-                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-                if float(flag.item()) == 0.0:
-                    break
-            elif time.perf_counter() >= t_end:
-                break
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        loop.step()
-    # one UNTIMED dry region of the same shape (declared: `dry_regions`): the first barrier-to-barrier region behind the settle phase reads 2-15 us per step
-    # high in the 20-step form (69.4 / 56.8 / 54.5 and 61.4 / 53.3 / 54.1 us in two round-5 runs: the median of three then lands on the second-worst)
-    for _ in range(max(int(args.dry_regions), 0)):
-        barrier()
-        for _ in range(args.steps):
-            loop.step()
-        barrier()
-    # ---- the timed region: R repetitions of K steps, nothing else on the stream ----
-    reps = []
-    for _ in range(max(int(args.reps), 1)):
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loop.step()
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt], device=device)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            dt = float(tt.item())
-        reps.append(dt)
+    m = measure(ctx, loop)
+    tripped = m["front_status"] if loop.front else 0
+    if tripped:
+        # an in-launch wait gave up somewhere: the minibatches read since are suspect and so is the number.  Repeat the run in the reference's order
+        # (no in-launch waits) in THIS process — never a re-exec: this process has touched the GPU — and say so in the line.
+        sys.stderr.write(f"bench.py rank {rank}: front launch tripped (status word {tripped}); repeating the run in the reference's order\n")
+        loop.close()
+        ref_args = copy.copy(args)
+        ref_args.front, ref_args.inject_front_trip = False, False
+        why = f"the front loop tripped (status word {tripped}: an in-launch wait gave up) and the run was repeated in the reference's order"
+        loop = Loop(ref_args, rank, world, device, shared_device=ctx.shared_device, forced_reason=why)
+        m = measure(ctx, loop)
+
+    res = record(ctx, loop, m, tripped, probe)
+    if rank == 0:
+        if not args.no_sweep:
+            res["roofline_env_sweep"] = RL.env_sweep(device)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baselines(args, device)
+    loop.close()
+    if pg and own_pg:
+        torch.distributed.destroy_process_group()
+        # RCCL writes a version banner through C stdio, which a redirected stdout holds back until exit: let it out first, so that the
+        ctypes.CDLL(None).fflush(None)  # record is the LAST line of stdout
+    return res if rank == 0 else None
+
+
+def record(ctx, loop, m, tripped, probe):
+    """the JSON line of this run (every rank takes part in the collectives; rank 0 prints)"""
+    import torch
+
+    args, world, rank, device = ctx.args, ctx.world, ctx.rank, ctx.device
+    reps, med = m["reps"], m["med"]
     dt = float(np.median(reps))
-
-    # ---- second pass: stage events; the act + env launch stamped; every 4th step act and env step as two launches, the env launch stamped ----
-    ar_events = []
-    m_steps = max(int(args.measure_steps), 16)
-    pool = [torch.cuda.Event(enable_timing=True) for _ in range(12 * (m_steps + 1))]
-    L = loop.lib.load()
-    kpool = [ctypes.c_void_p(L.hx_event_create()) for _ in range(2 * (m_steps + 2))]
-    exchanging = world > 1 or (args.staged and pg and args.agent == "hirl")
-    if exchanging:  # exchange step: events around every gradient exchange (on the stream it is enqueued on)
-        inner = loop.eng._allreduce
-
-        def timed_allreduce(t, kind=None):
-            call = (lambda: inner(t, kind)) if kind is not None else (lambda: inner(t))
-            if len(pool) >= 2:
-                a, b = pool.pop(), pool.pop()
-                a.record()
-                out = call()
-                b.record()
-                ar_events.append((t.numel() * 4, a, b))
-            else:
-                out = call()
-            return t if out is None else out
-        loop.eng._allreduce = timed_allreduce
-    for k in range(m_steps):
-        # front loop: the front launch right behind a split step is not stamped (it follows a foreign env step: no pre-drawn minibatch, a draw launch
-        # of its own in front of it, colder caches — a third of the stamped launches would be that slower first one)
-        loop.step_measured(split=(k % 4 == 3), pool=pool, kpool=kpool, stamp_front=(k % 4 != 0))
-    barrier()
-    if loop.front and hasattr(loop.eng, "front_check"):
-        loop.eng.front_check()  # an in-launch wait that gave up leaves a minibatch half read: fail loudly instead of printing a number
-    if exchanging:
-        loop.eng._allreduce = inner
-        if getattr(loop.eng, "xchg", None) is not None:
-            loop.eng.xchg.check()  # a timed-out wait leaves garbage behind: fail loudly instead of printing a number
-    med = {k: (float(np.median([a.elapsed_time(b) * 1e3 for a, b in v])) if v else None) for k, v in loop.rec.items()}
-
-    def stamped_us(pairs):
-        out = []
-        for a, b in pairs:
-            us = ctypes.c_float()
-            loop.lib.call("hx_event_elapsed_us", a, b, ctypes.byref(us))
-            out.append(us.value)
-        return out
-
-    kern = stamped_us(loop.krec)
-    if not kern:  # uniform actions: the loop has no act launch to split off; stamp plain env steps
-        kern = stamped_env_us(loop.env, loop.actions, 32)
-    env_kernel_us = float(np.mean(kern))  # mean, like the rocprofv3 --stats average it must agree with
-    fused = stamped_us(loop.krec_fused) if loop.fused else []
-    act_us, learn_us = med["act"], med["learn"]
-
     n_total = args.envs * world
-    value = n_total * args.steps / dt
+    act_us, learn_us = med["act"], med["learn"]
+    dtype_label = {"f32": "f32", "bf16": "bf16", "bf16_policy": "bf16 policy / f32 update",
+                   "f32x9": "f32 (policy product: exact three-way bf16 split, six partial products)"}[args.dtype]
+    peer = world > 1 and args.exchange in ("oneshot", "twostage", "twostage-bf16")
     res = {
-        "metric": "env steps/sec (whole node) + HIRL update steps/sec at 4096 envs/GPU", "value": round(value, 1),
-        "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_s": args.settle_s, "settle_steps": settle_steps, "dry_regions": max(int(args.dry_regions), 0),
+        "metric": "env steps/sec (whole node) + HIRL update steps/sec at 4096 envs/GPU", "value": round(n_total * args.steps / dt, 1),
+        "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_s": args.settle_s,
+        "settle_steps": m["settle_steps"], "dry_regions": max(int(args.dry_regions), 0),
         "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"f32": "f32", "bf16": "bf16", "bf16_policy": "bf16 policy / f32 update", "f32x9": "f32 (policy product: exact bf16 x 9 split)"}[args.dtype], "data": "synthetic",
+        "dtype": dtype_label, "data": "synthetic",
         "repetitions": {"count": len(reps), "statistic": "median", "ms_per_step": [round(t / args.steps * 1e3, 5) for t in reps],
                         "value": [round(n_total * args.steps / t, 1) for t in reps]},
-        "config": {"workload": workload_label(args), "envs_per_gpu": args.envs, "batch": args.batch,
-                   "actions": args.actions, "act_env": "one launch (hx_actor_act_step / hx_sac_act_step)" if loop.fused else "two launches",
+        "config": {"workload": workload_label(args), "envs_per_gpu": args.envs, "batch": args.batch, "actions": args.actions,
+                   "act_env": "one launch (hx_actor_act_step / hx_sac_act_step)" if loop.fused else "two launches",
                    "issue_order": "two streams" if loop.pipe.overlap else "serial",
                    "update_path": "staged (the sharded rank's launch sequence)" if (args.staged or world > 1) and args.agent == "hirl" else "one-call",
-                   "parallelism": f"dp{world}: env shards + replicated nets, {'peer-read ' + args.exchange if (world > 1 and args.exchange in ('oneshot', 'twostage', 'twostage-bf16')) else 'RCCL'} "
+                   "parallelism": f"dp{world}: env shards + replicated nets, {'peer-read ' + args.exchange if peer else 'RCCL'} "
                                   f"all-reduce of the flat gradients; effective batch = {args.batch} x {world}"},
-        "update_steps_per_s": round(args.steps / dt, 1),
-        "timed_region": "R x [K x step() between two barrier + synchronize pairs]; no events, no stamped or split launches inside (those are the second pass); `dry_regions` untimed regions of the same shape run before the first timed one",
-        "stage_us": {"pass": f"second pass, {m_steps} steps after the timed region (events add a few us per step)",
+        "update_steps_per_s": round(args.steps / dt, 1), "update_samples_per_s": round(args.batch * args.steps / dt, 1),
+        "timed_region": "R x [K x step() between two barrier + synchronize pairs]; no events, no stamped or split launches inside (those are the "
+                        "second pass); `dry_regions` untimed regions of the same shape run before the first timed one",
+        "stage_us": {"pass": f"second pass, {m['m_steps']} steps after the timed region (events add a few us per step)",
                      "act+env_step(1 kernel)": None if med["act+env"] is None else round(med["act+env"], 2),
                      "act(own launch, every 4th step)": None if act_us is None else round(act_us, 2),
                      "env_step(own launch, every 4th step)": None if med["env"] is None else round(med["env"], 2),
                      "sample+learn": None if learn_us is None else round(learn_us, 2)},
     }
-    if loop.front and world == 1 and not pg:
-        # the SAME workload with every launch in the reference's order (act -> env step -> insert -> draw -> learn), timed the same way in the same process:
-        # what the front launch buys, and the figure to quote if the draw must see the current step's transitions
-        import copy
-        ref_args = copy.copy(args)
-        ref_args.front = False
-        ref_loop = Loop(ref_args, rank, world, device)
-        for _ in range(max(args.warmup, 64)):
-            ref_loop.step()
-        for _ in range(max(int(args.dry_regions), 0)):  # (the same untimed dry region as the line's own loop)
-            barrier()
-            for _ in range(args.steps):
-                ref_loop.step()
-            barrier()
-        ref_reps = []
-        for _ in range(max(int(args.reps), 1)):
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                ref_loop.step()
-            barrier()
-            ref_reps.append(time.perf_counter() - t0)
-        ref_dt = float(np.median(ref_reps))
-        res["reference_order"] = {"loop": "reference order (--no-front): the minibatch is drawn after this step's insert", "value": round(n_total * args.steps / ref_dt, 1),
-                                  "unit": "env steps/s", "ms_per_step": round(ref_dt / args.steps * 1e3, 5), "update_steps_per_s": round(args.steps / ref_dt, 1),
-                                  "repetitions": {"count": len(ref_reps), "statistic": "median", "ms_per_step": [round(t / args.steps * 1e3, 5) for t in ref_reps]}}
-        del ref_loop
-    res["config"]["loop"] = "front" if loop.front else "reference order"
+    cfg = res["config"]
+    cfg["loop"] = "front" if loop.front else ("reference order (front tripped)" if tripped else "reference order")
+    cfg["loop_reason"] = loop.loop_reason
+    res["front_status"] = int(tripped)
+    if loop.front and world == 1 and not ctx.pg:
+        res["reference_order"] = reference_order_leg(ctx, args)
     if loop.front and args.agent == "hirl" and args.dtype == "f32" and loop.eng.front_x9:
-        res["config"]["acting_product"] = ("fp32 operands, the 256 -> 512 product through the exact three-way bf16 split of both operands (hi | mid | lo), six of the nine partial products — the three below fp32 resolution are not formed — on bf16 MFMA with fp32 accumulation (the engine's fp32 acting "
-                                           "format wherever it is the faster one: from 4,096 rows on, and in the front launch); max error vs fp64 2.7e-7 against 3.8e-7 for fp32 MFMA (16,384 rows, profiles/r05_x9_terms_ab.txt)")
+        cfg["acting_product"] = ("fp32 operands, the 256 -> 512 product through the exact three-way bf16 split of both operands (hi | mid | lo), six of "
+                                 "the nine partial products — the three below fp32 resolution are not formed — on bf16 MFMA with fp32 accumulation (the "
+                                 "engine's fp32 acting format wherever it is the faster one: from 4,096 rows on, and in the front launch); max error vs "
+                                 "fp64 2.7e-7 against 3.8e-7 for fp32 MFMA (16,384 rows, profiles/r05_x9_terms_ab.txt)")
     if loop.front:
-        res["config"]["act_env"] = ("FRONT launch (hx_sac_front): explore + env step + replay insert + the first forward launch of learn() in one launch" if args.agent == "sac" else
-                                    "FRONT launch (hx_hirl_front): act + env step + replay insert + launches A and B of learn() in one launch")
-        res["config"]["draw"] = ("uniform without replacement over the transitions that are in the ring before AND after this step's insert (drawn from the ring as it stood "
-                                 "before the step, without the n slots the step may overwrite: HxSample.guard); --no-front draws after the insert, like the reference")
-        res["stage_us"]["front launch + rest of learn() (3 of every 4 steps of the second pass; the front launch stamped: + ~25 us of instruments)"] = None if med["front+back"] is None else round(med["front+back"], 2)
+        cfg["act_env"] = ("FRONT launch (hx_sac_front): explore + env step + replay insert + the first forward launch of learn() in one launch"
+                          if args.agent == "sac" else
+                          "FRONT launch (hx_hirl_front): act + env step + replay insert + launches A and B of learn() in one launch")
+        cfg["draw"] = ("uniform without replacement over the transitions that are in the ring before AND after this step's insert (drawn from the ring "
+                       "as it stood before the step, without the n slots the step may overwrite: HxSample.guard); --no-front draws after the insert, "
+                       "like the reference")
+        res["stage_us"]["front launch + rest of learn() (3 of every 4 steps of the second pass; the front launch stamped: + ~25 us of instruments)"] = \
+            None if med["front+back"] is None else round(med["front+back"], 2)
 
-    env_roof = {"kernel": "env_step_kernel<PAIR, INSERT, EPB> (hx_env.hip)", "bound": "hbm",
-                "achieved": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ENV_BYTES_FUSED * args.envs / env_kernel_us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": (profile_traffic(args.envs) or {}).get("bytes"),
-                "bytes_per_launch": ENV_BYTES_FUSED * args.envs, "us_per_launch": round(env_kernel_us, 2), "launches_timed": len(kern),
-                "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the launches of "
-                          "the second pass in which act and env step are issued as two launches",
-                "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes of this kernel at this size (not collectable inside this "
-                                "process): see traffic_from_profiles; null when no pass exists for the size",
-                "traffic_from_profiles": profile_traffic(args.envs)}
-    if fused:
-        # the kernel the timed loop RUNS: policy inference + env step + replay insert in one launch.  Both roofs are quoted; `bound` names the nearer.
-        us = float(np.mean(fused))
-        fused_pmc = (profile_traffic(f"fused_{args.envs}") if args.dtype == "f32" else profile_traffic(f"fused_bf16_{args.envs}") if args.dtype == "bf16" else None) \
-            if args.agent == "hirl" else None
-        if loop.front:  # (the front launch has PMC passes of its own)
-            fused_pmc = profile_traffic(f"front_{args.envs}") if args.dtype == "f32" else profile_traffic(f"front_bf16_{args.envs}") if args.dtype == "bf16" else None
-        fp32_equiv = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
-        # which matrix-core instruction the 256 -> 512 product runs on: fp32 MFMA; bf16 MFMA; or — the fp32 HIRL policy from 16,384 rows on, and
-        # --dtype f32x9 at every size — SIX bf16 MFMAs per fp32 product (the exact hi | mid | lo split of both operands, its partial products above fp32 resolution): `roofline.executed` prices those against the bf16 peak
-        x9 = args.agent == "hirl" and (args.dtype == "f32x9" or (args.dtype == "f32" and (args.envs >= 4096 or (loop.front and loop.eng.front_x9))))
-        if args.dtype in ("f32", "f32x9") or args.agent == "sac":  # ALGORITHMIC FLOPs against the dense matrix peak of the dtype the path computes in
-            flop, peak = fp32_equiv, FP32_MATRIX_PEAK_TFLOPS
-        else:
-            flop, peak = fp32_equiv, BF16_MATRIX_PEAK_TFLOPS
-        if loop.front and args.agent != "sac":  # + the forward passes of launches A and B over the minibatch: 3 + 2 nets on a critic-only call, 4 + 4 on an actor call (every 2nd)
-            flop += int(6.5 * args.batch * ACTOR_FLOP)
-        # algorithmic bytes of the launch: 550 B per env step — and, for the front launch, the five networks of launches A and B read once
-        # (target actor, critic x 2, target critic x 2: the figure tools/pmc_traffic_json.py sets the counter passes against; VERDICT r4: the flop side
-        # already counted A and B, the byte side did not)
-        nbytes = ENV_BYTES_FUSED * args.envs + (4 * (138756 + 4 * 138244) if (loop.front and args.agent != "sac") else 0)
-        tf, gb = flop / us / 1e6, nbytes / us / 1e3
-        mf, hf = tf / peak, gb / HBM_PEAK_GBPS
-        hbm = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hf, 4), "bytes_per_launch": nbytes}
-        mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(mf, 4), "flop_per_launch": flop}
-        if x9:  # the fp32 product runs as 9 bf16 MFMAs per 32 k (exact split, fp32 accumulate): what the matrix cores EXECUTE, against their bf16 peak
-            ex = flop + 5 * 2 * 256 * 512 * args.envs
-            mfma["executed"] = {"what": "the acting workgroups' 256 -> 512 product as SIX bf16 MFMAs per fp32 product (exact hi | mid | lo split of both operands; the three partial products below fp32 resolution are not formed): executed FLOPs against the bf16 "
-                                        "dense peak — the matrix cores' utilisation; `achieved` above is the fp32 arithmetic the launch delivers, which the split lets exceed "
-                                        "what v_mfma_f32_16x16x4_f32 could (peak 157.3)",
-                                "flop_per_launch": ex, "achieved": round(ex / us / 1e6, 2), "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(ex / us / 1e6 / BF16_MATRIX_PEAK_TFLOPS, 4)}
-        first, second = (mfma, hbm) if mf >= hf else (hbm, mfma)
-        persistent = args.envs > 8192
-        front_name = None
-        if loop.front and args.agent == "sac":
-            front_name = ("actps_sac_front_kernel<MODE> (hx_front.hip): the persistent streaming acting workgroups (Gaussian policy + env step + fused replay insert) with the "
-                          "first forward launch of learn() (policy(s'), policy(s), Q1/Q2(s, a)) behind them")
-        elif loop.front:  # + the forward passes of launches A (3.5 nets on average) and B (3 on average) over the minibatch
-            front_name = ("act_front_kernel<RELU, X3, BF16> (hx_front.hip): the acting workgroups (32 rows each: policy inference + env step + fused replay insert) on half "
-                          "of the CUs, launches A and B of learn() (target actor, critics; target critics) on the other half") if args.envs <= (4096 if args.dtype == "bf16" else 8192) else \
-                         ("actp_front_kernel<RELU> / actps_front_kernel<RELU> (hx_front.hip): persistent acting workgroups (bf16: weight-stationary, two thirds of the CUs; exact split: "
-                          "one 64-row pass each) with the env step + fused replay insert in their tail, launches A and B of learn() on the CUs they leave")
-        plain_name = (("act_persist_*_kernel<..., ENV = true> (hx_actp.hip): persistent workgroups (one per CU) looping over their row tiles, env step + "
-                       "fused replay insert in the launch's tail") if persistent else
-                      "act_fused_kernel<NRT, GAUSS, ENV = true, ...> (hx_act.hip): policy inference + env step + fused replay insert")
-        res["roofline"] = {"kernel": ((front_name + "; FLOPs: the policy's over the envs + the 6.5 forward passes (average) of launches A and B over the minibatch") if front_name else plain_name) + ", the dominant kernel of the timed loop", **first, "traffic": (fused_pmc or {}).get("bytes"), "other_roof": second,
-                           "us_per_launch": round(us, 2), "launches_timed": len(fused),
-                           "timing": "the kernel's own begin/end stamps (hipExtLaunchKernelGGL events) on the launch stream, mean over the fused launches "
-                                     "of the second pass (" + ("2 of every 4 steps: every 4th issues act, env step and learn() as separate launches, and the front launch behind it is not stamped" if loop.front else "3 of every 4 steps") + ")",
-                           "note": ("bound by CU time: 128 acting workgroups of 32 rows beside 320-448 update workgroups on the other 128 CUs; neither roof is near (DESIGN.md section 4 K5)" if loop.front else
-                                    "vector-issue / LDS bound tile loop (LayerNorm + head per row), DESIGN.md section 4" if persistent else
-                                    "latency-bound at this size: 256 workgroups, one round; neither roof is near (DESIGN.md section 4)"),
-                           "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes of this launch (HIRL, this policy format, this size; FETCH_SIZE "
-                                           "calibrated x2, WRITE_SIZE: tools/pmc_env_passes.sh); each of the 8 XCDs pulls the policy's weights into its own L2 once "
-                                           "per launch, hence a few x the env's 550 B/env-step at small sizes; null where no pass exists",
-                           "traffic_from_profiles": fused_pmc}
+    env_roof = RL.env_kernel_roof(args.envs, m["env_kernel_us"])
+    if m["fused_us"]:
+        res["roofline"] = RL.launch_roofline(args, loop, m["fused_us"])
         res["roofline_env_kernel"] = env_roof
     else:
         res["roofline"] = env_roof
     if learn_us:
-        peak_u = BF16_MATRIX_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MATRIX_PEAK_TFLOPS
-        res["roofline_update"] = {"kernels": "fwd_l2/bwd_l2/wgrad(+adam) (one learn, minibatch draw included)", "bound": "mfma", "unit": "TFLOP/s",
-                                  "achieved": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6, 3), "peak": peak_u,
-                                  "frac": round(LEARN_FLOP_PER_SAMPLE * args.batch / learn_us / 1e6 / peak_u, 5),
-                                  "us_per_learn": round(learn_us, 2), "timing": "torch events around learn() in the second pass (median)"}
+        res["roofline_update"] = RL.update_roof(args, learn_us)
     if act_us and not loop.uniform:  # (with --actions uniform the 'act' stage is a torch uniform_ fill, not the policy)
-        peak = FP32_MATRIX_PEAK_TFLOPS if (args.dtype in ("f32", "f32x9") or args.agent == "sac") else BF16_MATRIX_PEAK_TFLOPS
-        flop = (POLICY_FLOP_SAC if args.agent == "sac" else ACTOR_FLOP) * args.envs
-        res["roofline_act"] = {"kernels": "the acting kernel (ENV = false) as its own launch (every 4th step of the second pass); fp32-equivalent FLOPs", "bound": "mfma", "unit": "TFLOP/s",
-                               "achieved": round(flop / act_us / 1e6, 3), "peak": peak,
-                               "frac": round(flop / act_us / 1e6 / peak, 5), "us": round(act_us, 2), "timing": "torch events (median)"}
-    if pg:
+        res["roofline_act"] = RL.act_roof(args, loop, act_us)
+    if ctx.pg:
         ids = [None] * world
-        torch.distributed.all_gather_object(ids, (socket.gethostname(), str(getattr(torch.cuda.get_device_properties(local), "uuid", local))))
-        direct = getattr(loop.eng, "exchange_name", "") == "rccl-direct"
-        res["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(), "backend": "rccl-direct" if direct else backend, "process_group_backend": backend,
-                             "distinct_gpus": len(set(ids)),
-                             "exchange": getattr(loop.eng, "exchange_name", "rccl"),
-                             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}
+        torch.distributed.all_gather_object(ids, (socket.gethostname(), str(getattr(torch.cuda.get_device_properties(device.index), "uuid", device.index))))
+        name = getattr(loop.eng, "exchange_name", "rccl")
+        res["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(), "backend": name if name.startswith("rccl-direct") else ctx.backend,
+                             "process_group_backend": ctx.backend, "distinct_gpus": len(set(ids)), "exchange": name,
+                             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if ctx.backend == "nccl" else None}
+    if probe is not None:
+        res["exchange_probe"] = probe
     if world > 1:  # the replicas must still be bit-identical after every sharded update so far (SURVEY.md 8e)
         mine = torch.tensor([loop.eng.replica_checksum()], dtype=torch.int64, device=device)
         every = [torch.zeros_like(mine) for _ in range(world)]
         torch.distributed.all_gather(every, mine)
         res["replicas_identical"] = bool(all(int(c.item()) == int(mine.item()) for c in every))
-    if ar_events:  # SURVEY.md 8d "collective bytes": per message size, median us and bus bandwidth 2 (n-1)/n * bytes / t
-        by = {}
-        for nbytes, a, b in ar_events:
-            by.setdefault(nbytes, []).append(a.elapsed_time(b) * 1e3)
+    if m["allreduce"]:  # SURVEY.md 8d "collective bytes": per message size, median us and bus bandwidth 2 (n-1)/n * bytes / t
         res["allreduce"] = [{"bytes": k, "calls": len(v), "median_us": round(float(np.median(v)), 2),
-                             "busbw_GBps": round(2 * (world - 1) / world * k / float(np.median(v)) / 1e3, 2)} for k, v in sorted(by.items())]
+                             "busbw_GBps": round(2 * (world - 1) / world * k / float(np.median(v)) / 1e3, 2)} for k, v in sorted(m["allreduce"].items())]
         if world == 1:
-            res["allreduce_note"] = ("world size 1: the collective library short-circuits an in-place all-reduce of one rank (no kernel is launched); the "
-                                     "figure is the host-side call on the stream, NOT an exchange time — the N > 1 term stays unmeasured on this box")
+            res["allreduce_note"] = ("world size 1: the collective library short-circuits an in-place all-reduce of one rank (no kernel is launched); "
+                                     "the figure is the host-side call on the stream, NOT an exchange time — the N > 1 term stays unmeasured on this box")
     res["env_stats"] = loop.env.stats_dict()
-    if rank == 0:
-        if not args.no_sweep:
-            res["roofline_env_sweep"] = env_sweep(device)
-        if world == 1 and not args.no_cpu_baseline:
-            model, cores = host_cpu()
-            budget = max(args.cpu_seconds, 1.0)
-            if args.agent == "hirl":
-                res["cpu_baseline"] = baseline_port(args, 0.4 * budget)
-                res["cpu_baseline"]["host"] = f"{model}, {cores} logical cores"
-                res["cpu_baseline"]["b0_reference_plumbing"] = baseline_reference_plumbing(0.3 * budget, episodes=args.b0_episodes)
-                res["cpu_baseline"]["b1_batched_cpu"] = baseline_batched_cpu(0.15 * budget)
-                res["cpu_baseline"]["b2_eager_rocm_learn"] = baseline_eager_rocm_learn(args, 0.15 * budget, device)
-            else:
-                res["cpu_baseline"] = baseline_port_sac(args, 0.7 * budget)
-                res["cpu_baseline"]["host"] = f"{model}, {cores} logical cores"
-                res["cpu_baseline"]["b1_batched_cpu"] = baseline_batched_cpu(0.3 * budget)
-    if pg:
-        torch.distributed.destroy_process_group()
-        # RCCL writes a version banner through C stdio, which a redirected stdout holds back until exit: let it out first, so that the
-        ctypes.CDLL(None).fflush(None)  # record is the LAST line of stdout
-    if rank == 0:
-        print(json.dumps(res), flush=True)
-    return 0
+    del rank
+    return res
 
 
 def main(argv=None):
@@ -1092,7 +826,21 @@ def main(argv=None):
     launched = "WORLD_SIZE" in os.environ or "RANK" in os.environ
     if args.gpus > 1 and not launched:
         return launch_ranks(args, argv)
-    return run_rank(args)
+    rank = os.environ.get("RANK", "0")
+    try:
+        res = run_rank(args)
+    except SystemExit as e:
+        if isinstance(e.code, str):  # ONE greppable line per failing rank (torchrun's failure table drowns a traceback: GPUTEST_r05)
+            sys.stderr.write(f"bench.py rank {rank}: SystemExit: {' '.join(e.code.split())}\n")
+        raise
+    except BaseException as e:  # noqa: BLE001
+        traceback.print_exc()
+        sys.stderr.write(f"bench.py rank {rank}: {type(e).__name__}: {' '.join(str(e).split())[:1500]}\n")
+        sys.stderr.flush()
+        return 1
+    if res is not None:
+        print(json.dumps(res), flush=True)
+    return 0
 
 
 if __name__ == "__main__":

@@ -46,7 +46,7 @@ _SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 113  # HX_ABI_VERSION of include/hirl4ucav.h
+ABI_VERSION = 114  # HX_ABI_VERSION of include/hirl4ucav.h
 _ABI_STRUCTS = {}  # name -> (index in hx_abi_sizes, ctypes class): filled by the binding modules (check_struct)
 
 

@@ -174,6 +174,8 @@ class HirlEngine:
         # outnumber the CUs, and beside two more processes on the same GPU its waits ran into their bound (profiles/r05_soak_front_shared_gpu.txt)
         self.front_c = False
         self._front = None
+        self._front_enqueued = False
+        self.needs_reload = False  # set when a call failed after its front launch was enqueued (step_learn); cleared by a snapshot load
         self._front_epoch = 0
         self._front_c_epoch = 0  # front launches that carried launch C (their counters advance only then)
         self._front_tiles = None
@@ -314,6 +316,12 @@ class HirlEngine:
 
     refresh_images = refresh_bf16
 
+    def acting_format(self):
+        """What decides the ACTING arithmetic of this engine beyond its dtype flags — stored in whole-run snapshots [ADVICE r5: the default `x9_rows`
+        went from 16,384 to 4,096 and the split from nine to six partial products between rounds 4 and 5; a run resumed across that change continued
+        under other acting arithmetic without a word]."""
+        return {"act_dtype": self.act_dtype, "update_dtype": self.update_dtype, "x9_rows": self.x9_rows, "front_x9": bool(self.front_x9), "x9_terms": 6}
+
     def replica_checksum(self):
         """int64 sum of the bit patterns of every network and Adam moment: equal on all ranks of a sharded run, or the replicas have
         diverged (Adam and Polyak see identical inputs on every rank).  Synchronises."""
@@ -410,8 +418,9 @@ class HirlEngine:
         self.nets.xchg_status = self.xchg.status_ptr  # a failed exchange freezes the optimizer steps (fail-stop), check() raises
         self.exchange_name = "oneshot" if not two_stage else ("twostage-bf16" if bf16 else "twostage")
 
-    def use_rccl_direct(self):
-        """Exchange gradients with ncclAllReduce enqueued by the library on the engine's stream (hx_rccl_allreduce) instead of
+    def use_rccl_direct(self, bf16=False):
+        """bf16: the two messages travel and are summed as bf16 (RcclDirect(bf16=True): half the wire bytes; replicas still bit-identical).
+        Exchange gradients with ncclAllReduce enqueued by the library on the engine's stream (hx_rccl_allreduce) instead of
         torch.distributed.all_reduce: no host-side collective call inside learn().  Needs an initialised process group (for the id) and one
         GPU per rank (RCCL refuses two ranks on one device); works at world size 1 (the sharded rank's sequence, bench.py --staged).
         The communicator is checked with one all-reduce of ones before it is used, and EVERY rank takes the same decision
@@ -424,7 +433,7 @@ class HirlEngine:
         import sys
 
         def connect(uid, world, rank):
-            r = RcclDirect(uid, world, rank)
+            r = RcclDirect(uid, world, rank, bf16=bf16)
             r.probe(self.device)
             return r
 
@@ -433,7 +442,7 @@ class HirlEngine:
         if r is None:
             return False
         self.rccl = r
-        self.exchange_name = "rccl-direct"
+        self.exchange_name = "rccl-direct-bf16" if bf16 else "rccl-direct"
         return True
 
     def _allreduce(self, t, kind=None):
@@ -487,6 +496,8 @@ class HirlEngine:
         results with losses_host().  before_exchange: called once, right before the first gradient all-reduce of the sharded path
         (utils/pipeline.py releases its side stream there)."""
         B = self.batch
+        if self.needs_reload:
+            raise _lib.HxError("this engine failed after a front launch had been enqueued: load a snapshot before learn()")
         st = _lib.stream_ptr()
         pending, self._pending = self._pending, None
         pipe = getattr(before_exchange, "__self__", None) if before_exchange is not None else None
@@ -583,13 +594,24 @@ class HirlEngine:
         flags, status = self._front
         cur, nxt = self._front_tiles
         n_main = B if n_main is None else int(n_main)
-        # the host's counters run ahead of the library calls below; if one of them refuses (HX_REQUIRE: ring smaller than 2n, too many row tiles, a missing
-        # image) they are put back and the hand-off words start over — a caller that catches the error must not be left with a host epoch ahead of the device's
+        # the host's counters run ahead of the library calls below; if one of them refuses BEFORE the front launch is enqueued (HX_REQUIRE: ring smaller than
+        # 2n, too many row tiles, a missing image) they are put back and the hand-off words start over — a caller that catches the error must not be left
+        # with a host epoch ahead of the device's.  A failure AFTER hx_hirl_front has returned (the rest of learn(), a staged exchange) is another matter
+        # [ADVICE r5]: the device HAS stepped the envs, inserted into the ring and maybe applied part of the update — putting the host's counters back would
+        # replay the same Philox noise and sample calls against a device that has moved on.  The counters stay advanced and the engine is marked:
+        # `needs_reload` refuses every further step_learn / learn until a snapshot has been loaded (utils/checkpoint.load_engine_state clears it).
+        if self.needs_reload:
+            raise _lib.HxError("this engine failed after a front launch had been enqueued (host and device state may disagree): load a snapshot "
+                               "(utils/checkpoint.load_run) before stepping it again")
         held = (self._front_epoch, self._front_c_epoch, self.critic_step, self.actor_step, self.update_count, self.sample_calls, self.act_calls, env.steps_issued)
+        self._front_enqueued = False
         try:
             return self._step_learn(env, expert, bc_table, n_main, act_noise, act_sigma, act_seed, out, sample_seed, smooth_sigma, bc_weight_now,
                                     bc_warm_up_weight, bf16, flags, status, cur, nxt)
         except _lib.HxError:
+            if self._front_enqueued:
+                self.needs_reload = True
+                raise
             (self._front_epoch, self._front_c_epoch, self.critic_step, self.actor_step, self.update_count, self.sample_calls, self.act_calls, env.steps_issued) = held
             self.front_reset()
             raise
@@ -647,6 +669,7 @@ class HirlEngine:
         _lib.call("hx_hirl_front", env.state.data_ptr(), n, env.pitch, env.obs.data_ptr(), out.data_ptr(), mode | self._mode_bits | (32 if (not bf16 and self._x9_for(n, front=True)) else 0),
                   _lib.ptr(act_noise), float(act_sigma), int(act_seed), int(env.env_id0), self.act_calls, env.reward.data_ptr(), env.done.data_ptr(),
                   env.success.data_ptr(), ctypes.byref(env._opts), nets, ctypes.byref(batch), hyper, int(actor_phase), w_kind, ctypes.byref(front), st)
+        self._front_enqueued = True  # from here on a failure leaves the device AHEAD of any rollback (step_learn)
         env.steps_issued += 1
         nxt_draw, nxt_tiles = draw(nxt, self.sample_calls + 1), tiles_of(nxt)
         if not self.staged:

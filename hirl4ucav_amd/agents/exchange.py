@@ -20,6 +20,7 @@ _lib.register("hx_allreduce_twostage", [_vp, _P(_vp), _P(_vp), _P(_vp), _P(_vp),
 _lib.register("hx_rccl_unique_id", [_vp])
 _lib.register("hx_rccl_init", [_vp, _i32, _i32, _P(_vp)])
 _lib.register("hx_rccl_allreduce", [_vp, _vp, ctypes.c_int64, _i32, _vp])
+_lib.register("hx_rccl_allreduce_bf16", [_vp, _vp, _vp, ctypes.c_int64, _vp])
 _lib.register("hx_rccl_destroy", [_vp])
 
 
@@ -42,21 +43,30 @@ class RcclDirect:
         _lib.call("hx_rccl_unique_id", raw)
         return raw.raw
 
-    def __init__(self, uid, world, rank):
-        self.world, self.rank = int(world), int(rank)
+    def __init__(self, uid, world, rank, bf16=False):
+        """bf16: the messages travel (and are summed) as bf16 — hx_rccl_allreduce_bf16: half the wire bytes; every rank still receives the same
+        bits, so the replicas stay identical (opt-in: bench.py --exchange rccl-bf16)"""
+        self.world, self.rank, self.bf16 = int(world), int(rank), bool(bf16)
+        self._scratch = None
         comm = _vp()
         _lib.call("hx_rccl_init", ctypes.create_string_buffer(uid, 128), self.world, self.rank, ctypes.byref(comm))
         self.comm = comm
 
     def allreduce(self, t):
         """t <- sum over the ranks of t (fp32), in place, on the current stream"""
-        _lib.call("hx_rccl_allreduce", self.comm, t.data_ptr(), t.numel(), 0, _lib.stream_ptr())
+        n = t.numel()
+        if self.bf16 and n % 4 == 0:
+            if self._scratch is None or self._scratch.numel() < n:
+                self._scratch = torch.empty(n, dtype=torch.bfloat16, device=t.device)
+            _lib.call("hx_rccl_allreduce_bf16", self.comm, t.data_ptr(), self._scratch.data_ptr(), n, _lib.stream_ptr())
+            return t
+        _lib.call("hx_rccl_allreduce", self.comm, t.data_ptr(), n, 0, _lib.stream_ptr())
         return t
 
     def probe(self, device):
         """one all-reduce of ones through the new communicator; raises when the sum is not the world size (synchronises)"""
         ones = torch.ones(64, dtype=torch.float32, device=device)
-        self.allreduce(ones)
+        self.allreduce(ones)  # (world sizes are exact in bf16 too)
         torch.cuda.synchronize()
         if not bool((ones == float(self.world)).all()):
             raise _lib.HxError(f"the probe all-reduce returned {float(ones[0])} instead of {self.world}")

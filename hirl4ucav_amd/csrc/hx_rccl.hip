@@ -63,6 +63,21 @@ Api* api() {
         if (rc_ != 0) return ::hx::fail(HX_ERR_HIP, "%s: RCCL error %d (%s)", what, rc_, R->error_string ? R->error_string(rc_) : "?"); \
     } while (0)
 
+// the bf16 wire format of hx_rccl_allreduce_bf16: four values per thread, round to nearest even (the compiler's __bf16 conversion)
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = src[i];
+    dst[i] = make_uint2(__builtin_bit_cast(unsigned, v2bf{(__bf16)v.x, (__bf16)v.y}), __builtin_bit_cast(unsigned, v2bf{(__bf16)v.z, (__bf16)v.w}));
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const uint2* __restrict__ src, float4* __restrict__ dst, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const uint2 q = src[i];
+    dst[i] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xFFFF0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xFFFF0000u));
+}
+
 }  // namespace
 
 extern "C" {
@@ -102,6 +117,19 @@ int hx_rccl_allreduce(void* comm, void* buf, int64_t n, int32_t dtype, void* str
     Api* R = api();
     HX_REQUIRE(R, "hx_rccl_allreduce: librccl.so not loaded");
     HX_RCCL(R->all_reduce(buf, buf, (size_t)n, dtype == 0 ? 7 : 9, 0, (Comm)comm, (hipStream_t)stream), "hx_rccl_allreduce");
+    return 0;
+}
+int hx_rccl_allreduce_bf16(void* comm, float* buf, uint16_t* scratch, int64_t n, void* stream) {
+    HX_REQUIRE(comm && buf && scratch && n > 0 && (n & 3) == 0, "hx_rccl_allreduce_bf16: bad arguments (n must be a multiple of 4)");
+    Api* R = api();
+    HX_REQUIRE(R, "hx_rccl_allreduce_bf16: librccl.so not loaded");
+    const long long n4 = n / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, grid, block, 0, (hipStream_t)stream, reinterpret_cast<const float4*>(buf), reinterpret_cast<uint2*>(scratch), n4);
+    HX_CHECK_LAUNCH("hx_rccl_allreduce_bf16 (cast)");
+    HX_RCCL(R->all_reduce(scratch, scratch, (size_t)n, 9, 0, (Comm)comm, (hipStream_t)stream), "hx_rccl_allreduce_bf16");
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, grid, block, 0, (hipStream_t)stream, reinterpret_cast<const uint2*>(scratch), reinterpret_cast<float4*>(buf), n4);
+    HX_CHECK_LAUNCH("hx_rccl_allreduce_bf16 (uncast)");
     return 0;
 }
 int hx_rccl_destroy(void* comm) {

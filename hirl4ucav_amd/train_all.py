@@ -352,11 +352,17 @@ def main(config):
     # --loop front (default where it applies: HIRL / TD3 in fp32 or bf16 actor + critic, batch <= 256, one update per step): the env
     # step and the first two launches of learn() as ONE launch (HirlEngine.step_learn) — the minibatch is then drawn from the ring as it stood before
     # this step's insert.  --loop reference: the reference's order on every step (act -> env step -> insert -> draw -> learn)
+    # ... and only with ONE process per GPU: the in-launch waits of the front launch are argued for a chip of its own (include/hirl4ucav.h hx_hirl_front —
+    # the waiting workgroups of processes that share a GPU add up; eight front-loop ranks on one GPU tripped in round 5).  HX_FRONT_SHARED_GPU=1 takes it
+    # anyway (soak tests); the status word + fallback below stay armed either way.
+    shared_gpu = world > torch.cuda.device_count() and not os.environ.get("HX_FRONT_SHARED_GPU")
     front = (config.loop == "front" and not sac and not config.separate_launches and config.updates_per_step == 1 and batch <= 256
-             and getattr(config, "dtype", "f32") in ("f32", "f32x9", "bf16"))
+             and getattr(config, "dtype", "f32") in ("f32", "f32x9", "bf16") and not shared_gpu)
     front_sac = (config.loop == "front" and sac and world == 1 and not config.separate_launches and config.updates_per_step == 1 and batch <= 256 and n > 8192)
     if rank == 0:
-        print(f"vector loop: {'front launch (env step + first launches of learn() in one launch; draw before the insert)' if (front or front_sac) else 'reference order'}", flush=True)
+        which = "front launch (env step + first launches of learn() in one launch; draw before the insert)" if (front or front_sac) else "reference order"
+        print(f"vector loop: {which}" + (f" ({world} ranks share a GPU: the front launch is for one process per GPU)" if (shared_gpu and config.loop == "front") else ""),
+              flush=True)
     # The front launch's in-launch waits (launch B for launch A's rows, launch C for both) assume that the workgroups of ONE launch start in index order —
     # observed on gfx950, promised by nobody.  A wait that gives up sets a sticky status word: it is read every --status_check_every vector steps (one host
     # sync; every rank takes the same decision), and on a trip every rank goes back to the newest snapshot and continues in the reference's order INSIDE this
@@ -455,6 +461,12 @@ def main(config):
                 ret.zero_()
             if rank == 0:
                 print(why + f": back to the snapshot of episode {episode} ({snap_path}), continuing in the REFERENCE's order (no in-launch waits)", flush=True)
+                if dtype == "f32" and eng.front_x9 and (eng.x9_rows is None or n < eng.x9_rows):  # [ADVICE r5] say what else changes with the loop
+                    print(f"note: the front launch acted in the exact-split format at every size; in the reference's order {n} envs act on fp32 MFMA "
+                          f"(the split applies from {eng.x9_rows} rows on): fp32 results up to summation order from here on", flush=True)
+                print(f"note: scalars and checkpoints written for episodes {episode + 1}.. before the trip are written again from here", flush=True)
+                if writer is not None:
+                    writer.add_scalar("Others/Front_trip_rollback_to_episode", episode, episode)
             continue
         if rank == 0:
             c, a, b, r_, f, w = eng.losses_host()

@@ -16,14 +16,27 @@ ENGINE_COUNTERS = ("critic_step", "actor_step", "update_count", "actor_trainable
 
 
 def engine_state(eng):
-    return {"arena": eng.arena.detach().cpu().clone(),
-            "counters": {k: getattr(eng, k) for k in ENGINE_COUNTERS if hasattr(eng, k)}}
+    st = {"arena": eng.arena.detach().cpu().clone(), "counters": {k: getattr(eng, k) for k in ENGINE_COUNTERS if hasattr(eng, k)}}
+    if hasattr(eng, "acting_format"):
+        st["acting_format"] = eng.acting_format()  # the run's arithmetic is part of its state (train_all.py: --dtype; here: what the flag does not say)
+    return st
 
 
 def load_engine_state(eng, st):
     if st["arena"].numel() != eng.arena.numel():
         raise ValueError(f"snapshot arena has {st['arena'].numel()} words, this engine {eng.arena.numel()} (different agent or batch size)")
+    was, now = st.get("acting_format"), (eng.acting_format() if hasattr(eng, "acting_format") else None)
+    if now is not None and was != now:
+        import warnings
+
+        # (a snapshot from before round 6 carries no format: round 5's default, or round 4's x9_rows = 16,384 with nine terms — it cannot tell)
+        warnings.warn(f"snapshot was written under acting format {was if was is not None else 'unrecorded (a round <= 5 snapshot)'}, this engine "
+                      f"acts under {now}: the run continues under other acting arithmetic (fp32 results up to summation order)", stacklevel=2)
     eng.arena.copy_(st["arena"])
+    if hasattr(eng, "needs_reload"):
+        eng.needs_reload = False  # host counters and device state agree again from here
+    if hasattr(eng, "front_reset"):
+        eng.front_reset()
     if hasattr(eng, "refresh_bf16"):
         eng.refresh_bf16()  # the bf16 image of the actor's W2 follows the restored fp32 parameters
     for k, v in st["counters"].items():

@@ -72,8 +72,8 @@ const char* hx_last_error(void);
 /* HX_ABI_VERSION of the library that is loaded.  The structs below are part of the ABI: a caller built against another header version must
  * not call in (round 3 widened HxStepOpts.stats from 9 to HX_STAT_WAYS * HX_STAT_PITCH words and appended fields to HxNets / HxHyper without
  * bumping this: a 9-word stats buffer then took atomics up to word 504).  110: round 4 (hx_abi_sizes, hx_rccl_*, hx_allreduce_twostage).
- * 113: round 5. */
-#define HX_ABI_VERSION 113
+ * 113: round 5.  114: round 6 (hx_rccl_allreduce_bf16). */
+#define HX_ABI_VERSION 114
 int hx_version(void);
 /* sizes[0..7] (host) <- sizeof HxStepOpts, HxNets, HxHyper, HxBatch, HxSample, HxSacNets, HxSacBatch, and the words of a statistics buffer
  * (HX_STAT_WAYS * HX_STAT_PITCH): a binding checks these against its own declarations at load time (hirl4ucav_amd/_lib.py does). */
@@ -524,6 +524,10 @@ int hx_rccl_available(void); /* 0: the library and its entry points bind in this
 int hx_rccl_unique_id(uint8_t* id128 /* host, out */);
 int hx_rccl_init(const uint8_t* id128 /* host */, int32_t world, int32_t rank, void** comm /* host, out */);
 int hx_rccl_allreduce(void* comm, void* buf, int64_t n, int32_t dtype, void* stream);
+/* The same exchange with the message on the wire as bf16 (half the bytes; RCCL sums in bf16): buf[i] (fp32) -> scratch[i] (bf16, round to nearest even) ->
+ * ncclAllReduce(bf16) -> buf[i] (fp32), three enqueues on `stream`.  Every rank receives the same bits (replicas stay identical); opt-in
+ * (`--exchange rccl-bf16`), n a multiple of 4, scratch: n bf16 device words. */
+int hx_rccl_allreduce_bf16(void* comm, float* buf, uint16_t* scratch, int64_t n, void* stream);
 int hx_rccl_destroy(void* comm);
 
 #ifdef __cplusplus

@@ -1,6 +1,8 @@
-"""Run under `python -m torch.distributed.run --nproc-per-node W ... tests/_sharded_check.py {rccl|oneshot|twostage|twostage-bf16}` (gloo, all W ranks on the one GPU
-of the box; W = 2, 3, 8): K sharded learn() calls of the PRODUCT engine — each rank its own minibatch of 128, ONE exchange per phase — against a
-single engine of batch 128 W fed the minibatches concatenated (the same global batch).  Rank 0 prints SHARDED_OK."""
+"""Run under `python -m torch.distributed.run --nproc-per-node W ... tests/_sharded_check.py rccl,oneshot,twostage,twostage-bf16` (gloo, all W ranks on the
+one GPU of the box; W = 2, 3, 8): for every exchange of the comma-separated list, on ONE process group (a cold `import torch` per process is what a
+fresh box charges for: one launch per world size, not one per case), K sharded learn() calls of the PRODUCT engine — each rank its own minibatch of 128,
+ONE exchange per phase — to be compared with a single engine of batch 128 W fed the minibatches concatenated (the same global batch).  Rank 0 writes
+$SHARDED_OUT.<exchange>.npz and prints SHARDED_OK <exchange> per case."""
 import os
 import sys
 
@@ -12,10 +14,17 @@ from hirl4ucav_amd.agents import engine as E  # noqa: E402
 from tests import _hirl_data as D  # noqa: E402
 
 
-def main(exchange):
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+def main(exchanges):
     torch.cuda.set_device(0)
     torch.distributed.init_process_group("gloo")
+    for exchange in exchanges.split(","):
+        one(exchange)
+        torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def one(exchange):
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     params, data = D.make_params(31), D.make_data(32)
     ring = torch.from_numpy(data["replay"]).cuda().contiguous()
     bc = np.zeros((D.N_EXPERT, 32), np.float32)
@@ -43,12 +52,11 @@ def main(exchange):
     out = {k: getattr(e, k).cpu().numpy() for k in ("actor", "critic", "target_actor", "target_critic")}
     out["losses"] = np.asarray(e.losses_host())
     if rank == 0:
-        np.savez(os.environ["SHARDED_OUT"], **out, exchange=np.asarray(e.exchange_name), world=np.asarray(world))
+        np.savez(os.environ["SHARDED_OUT"] + "." + exchange + ".npz", **out, exchange=np.asarray(e.exchange_name), world=np.asarray(world))
         print("SHARDED_OK", e.exchange_name, flush=True)
     if e.xchg is not None:
         torch.distributed.barrier()
         e.close()  # checks the status word once more, then releases the peer mappings
-    torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

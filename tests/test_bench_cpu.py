@@ -44,3 +44,46 @@ def test_workload_label_names_a_baseline_config_only_when_the_arguments_match():
     assert "configs[4]" in bench.workload_label(bench.parse(["--envs", "16384", "--scenario", "mixed", "--dtype", "bf16"]))
     assert "configs[4]" not in bench.workload_label(bench.parse(["--envs", "16384", "--scenario", "mixed", "--dtype", "bf16_policy"]))
     assert "configs[2]" in bench.workload_label(bench.parse(["--agent", "sac", "--envs", "16384", "--scenario", "serpentine"]))
+
+
+def test_loop_choice_never_takes_in_launch_waits_on_a_shared_gpu():
+    """ranks that share a device run the reference's order unless --front asks for the other; every refusal names its reason."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    front, why = bench.loop_choice(bench.parse([]), 1, False)
+    assert front and "default" in why
+    front, why = bench.loop_choice(bench.parse(["--gpus", "8"]), 8, True)
+    assert not front and "8 ranks share a GPU" in why
+    front, why = bench.loop_choice(bench.parse(["--gpus", "8"]), 8, False)  # a GPU each: the front loop, sharded
+    assert front
+    front, why = bench.loop_choice(bench.parse(["--gpus", "2", "--front"]), 2, True)  # asked for explicitly (soak tests)
+    assert front and "--front given" in why and "ranks share a GPU" in why
+    assert bench.loop_choice(bench.parse(["--no-front"]), 1, False) == (False, "--no-front given")
+    for argv, word in ((["--batch", "512"], "batch > 256"), (["--actions", "uniform"], "uniform actions"), (["--dtype", "bf16_policy"], "bf16_policy"),
+                       (["--agent", "sac"], "beyond 8,192 envs"), (["--overlap"], "--overlap"), (["--sample-launch"], "--sample-launch"),
+                       (["--envs", "16384", "--front-acting", "mfma"], "at most 8,192 envs")):
+        front, why = bench.loop_choice(bench.parse(argv), 1, False)
+        assert not front and word in why, (argv, why)
+    assert bench.loop_choice(bench.parse(["--agent", "sac", "--envs", "16384"]), 1, False)[0]
+    assert not bench.loop_choice(bench.parse(["--agent", "sac", "--envs", "16384", "--gpus", "2"]), 2, False)[0]
+    import pytest
+
+    with pytest.raises(SystemExit, match="batch > 256"):
+        bench.loop_choice(bench.parse(["--front", "--batch", "512"]), 1, False)
+
+
+def test_roofline_fractions_stay_inside_the_roof_they_name():
+    """the exact-split launches are priced by the bf16 FLOPs they execute; round 5's 131,072-env fp32 line (117.9 us at 65,536 envs,
+    242 us at 131,072) read `frac` 0.93 / 1.04 against the fp32 matrix peak."""
+    sys.path.insert(0, ROOT)
+    from tools import bench_roofline as RL
+
+    for envs, us in ((4096, 21.6), (65536, 117.86), (131072, 228.0)):
+        flop = RL.ACTOR_FLOP * envs
+        r = RL.matrix_roof(flop, envs, us, "x9")
+        assert r["peak"] == 2500.0 and 0 < r["frac"] < 1 and r["flop_per_launch"] == flop + 5 * RL.PRODUCT_FLOP * envs
+        eq = r["fp32_equivalent"]
+        assert eq["peak"] == 157.3 and abs(eq["ratio_to_peak"] - flop / us / 1e6 / 157.3) < 1e-3 and "frac" not in eq
+    assert RL.matrix_roof(RL.ACTOR_FLOP * 131072, 131072, 228.0, "x9")["fp32_equivalent"]["ratio_to_peak"] > 0.99  # what used to be printed as frac
+    assert RL.matrix_roof(RL.ACTOR_FLOP * 4096, 4096, 19.2, "f32")["peak"] == 157.3 and RL.matrix_roof(1e9, 4096, 19.2, "bf16")["peak"] == 2500.0
