@@ -88,6 +88,11 @@ def negotiate_rccl_direct(group=None, flag_device="cpu", available=None, make_id
       4. connect(id, world, rank)  ncclCommInitRank + one probe all-reduce — only when step 3 agreed
       5. MIN all-reduce of `ok`    after the probe
     -> (the connected object, "") on every rank, or (None, why) on every rank (a communicator built by some ranks is closed again).
+    LIMIT of the promise [ADVICE r5]: it covers steps 1-3 and the agreement around step 4, not step 4's inside.  connect() is itself collective and
+    unbounded — ncclCommInitRank, then a probe all-reduce + torch.cuda.synchronize(): if ONE rank's init raises locally while the others are already inside
+    theirs, those block in RCCL until the launcher's own timeout ends the job (close() synchronises too).  Step 3 exists to make that rare (a rank that
+    cannot even bind the library never lets the others enter), it cannot exclude it; a deadline would need RCCL's non-blocking init
+    (ncclCommInitRankConfig + ncclCommGetAsyncError), which this header-free binding does not restate.  The CPU tests inject a NON-collective connect().
     `available` / `make_id` default to RcclDirect's, `connect` to RcclDirect(id, world, rank) + probe on the current GPU; tests inject failing
     ones over gloo on the CPU."""
     dist = torch.distributed

@@ -443,6 +443,81 @@ def test_step_learn_that_is_refused_leaves_the_engine_as_it_was():
     assert np.isfinite(eng.losses_host()[0])
 
 
+def test_step_learn_that_fails_behind_the_front_launch_is_not_rolled_back(tmp_path, monkeypatch):
+    """the rollback above is right only while nothing has been enqueued.  A failure AFTER hx_hirl_front has returned (here: the rest
+    of learn() refuses) finds a device that has stepped the envs and inserted into the ring: putting the host's counters back would replay the same Philox
+    noise and sample calls against it.  The counters stay advanced, the engine refuses further steps (`needs_reload`) until a snapshot is loaded, and a
+    snapshot load puts host and device back in step."""
+    from hirl4ucav_amd import _lib
+    from hirl4ucav_amd.agents import engine as E
+    from hirl4ucav_amd.agents.HIRL import init_actor_state_dict, init_critic_state_dict
+    from hirl4ucav_amd.environments.batched import BatchedHarfangEnv
+    from hirl4ucav_amd.utils import checkpoint as CK
+    from hirl4ucav_amd.utils.buffer import DeviceReplay
+
+    n = 512
+    eng = E.HirlEngine(batch=128, use_bc=False, slope=0.01)
+    eng.load_params(init_actor_state_dict(), init_critic_state_dict())
+    rep = DeviceReplay(1 << 14)
+    env = BatchedHarfangEnv(n, scenario="straight_line", seed=1, replay=rep)
+    env.reset()
+    for _ in range(2):
+        env.step(torch.rand((n, 4), device="cuda") * 2 - 1)
+    eng.step_learn(env, None, None, act_sigma=0.1, sample_seed=5)
+    snap = str(tmp_path / "state.pt")
+    CK.save_run(snap, eng, env, rep, {"episode": 0})
+    held = (eng.critic_step, eng.sample_calls, eng.act_calls, env.steps_issued, eng._front_epoch)
+    real = _lib.call
+
+    def failing(name, *a):
+        if name == "hx_hirl_learn_back":
+            raise _lib.HxError("hx_hirl_learn_back failed (-2): injected")
+        return real(name, *a)
+
+    monkeypatch.setattr(_lib, "call", failing)
+    with pytest.raises(_lib.HxError, match="injected"):
+        eng.step_learn(env, None, None, act_sigma=0.1, sample_seed=5)
+    monkeypatch.setattr(_lib, "call", real)
+    # the front launch WAS enqueued: nothing is put back, and the engine says so
+    assert eng.needs_reload and (eng.critic_step, eng.sample_calls, eng.act_calls, eng._front_epoch) == (held[0] + 1, held[1] + 1, held[2] + 1, held[4] + 1)
+    with pytest.raises(_lib.HxError, match="load a snapshot"):
+        eng.step_learn(env, None, None, act_sigma=0.1, sample_seed=5)
+    with pytest.raises(_lib.HxError, match="load a snapshot"):
+        eng.learn()
+    CK.load_run(snap, eng, env, rep)  # back to a state where host and device agree
+    assert not eng.needs_reload and (eng.critic_step, eng.sample_calls, eng.act_calls) == held[:3] and eng._front_epoch == 0
+    for _ in range(3):
+        eng.step_learn(env, None, None, act_sigma=0.1, sample_seed=5)
+    eng.front_check()
+    assert np.isfinite(eng.losses_host()[0])
+
+
+def test_snapshot_records_the_acting_format(tmp_path):
+    """what decides the acting arithmetic beyond --dtype (the row count from which the exact split applies, the number of partial products,
+    the front launch's format) is part of a whole-run snapshot; loading it into an engine that acts otherwise warns instead of continuing silently."""
+    import warnings
+
+    from hirl4ucav_amd.agents import engine as E
+    from hirl4ucav_amd.agents.HIRL import init_actor_state_dict, init_critic_state_dict
+    from hirl4ucav_amd.utils import checkpoint as CK
+
+    eng = E.HirlEngine(batch=128, use_bc=False, slope=0.01)
+    eng.load_params(init_actor_state_dict(), init_critic_state_dict())
+    st = CK.engine_state(eng)
+    assert st["acting_format"] == {"act_dtype": "f32", "update_dtype": "f32", "x9_rows": 4096, "front_x9": True, "x9_terms": 6}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        CK.load_engine_state(eng, st)  # the same format: silent
+    other = E.HirlEngine(batch=128, use_bc=False, slope=0.01)
+    other.load_params(init_actor_state_dict(), init_critic_state_dict())
+    other.x9_rows = 16384  # round 4's rule
+    with pytest.warns(UserWarning, match="other acting arithmetic"):
+        CK.load_engine_state(other, st)
+    old = {k: v for k, v in st.items() if k != "acting_format"}  # a snapshot from before round 6
+    with pytest.warns(UserWarning, match="unrecorded"):
+        CK.load_engine_state(eng, old)
+
+
 class _ScriptedFire:
     """an engine whose policy is the loaded actor's, with the launch decision scripted (fire on the steps listed): a random-init actor never locks, and the
     counters of the infinite env only move when missiles leave the rail"""
