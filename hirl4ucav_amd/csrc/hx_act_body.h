@@ -145,6 +145,16 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
     // BF16: which 32 columns this wave owns rotates with the workgroup, so that the 256 workgroups of a launch do not all ask L2 for
     // the same lines of the W2 image at the same moment
     const int cw = (BF16 || X3) ? ((wave + bid) & 15) : wave;
+#ifdef HX_DBG_ACT_HOT
+    // TIMING EXPERIMENT ONLY (tools/ubench/act_l2_stream_ab.sh builds a second library with it; wrong results by construction): the exact-split product's
+    // B fragments all come from the FIRST k-slab's addresses (level 1: 6 KB per wave, L2-hot) or from ONE wave's first slab (level 2: 6 KB per workgroup,
+    // L1-hot) — the same load instructions and bytes per lane, none of the 768 KB image stream: what the product phase costs when the stream costs nothing
+    const int cwi = HX_DBG_ACT_HOT >= 2 ? 0 : cw;
+    constexpr int kHotSlab = 0;
+#else
+    const int cwi = cw;
+    constexpr int kHotSlab = 1;
+#endif
     uint4 w3q = {0u, 0u, 0u, 0u};  // BF16: this lane's A fragment of the final layer (hx_act.h w3_fragment)
     if constexpr (BF16) w3q = w3_fragment(net, m, cw, lane);
     if constexpr (BF16) {
@@ -162,7 +172,7 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
     // the product loop (where its L2 round trip was the loop's first wait)
     uint4 bb0[X3 ? 3 : 1][2];
     if constexpr (X3) {
-        const uint16_t* img = A.w2b + (size_t)(cw * 8) * 512 + lane * 8;
+        const uint16_t* img = A.w2b + (size_t)(cwi * 8) * 512 + lane * 8;
 #pragma unroll
         for (int sx = 0; sx < 3; ++sx)
 #pragma unroll
@@ -278,7 +288,7 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
             v4f rest[NRT][2];
 #pragma unroll
             for (int t = 0; t < NRT; ++t) rest[t][0] = rest[t][1] = v4f{0.f, 0.f, 0.f, 0.f};
-            const uint16_t* img = A.w2b + (size_t)(cw * 8) * 512 + lane * 8;  // image s at + s kImgElems, column tile 16 + cw at + 16 * 8 * 512
+            const uint16_t* img = A.w2b + (size_t)(cwi * 8) * 512 + lane * 8;  // image s at + s kImgElems, column tile 16 + cw at + 16 * 8 * 512
             uint4 bb[2][3][2];
 #pragma unroll
             for (int sx = 0; sx < 3; ++sx)
@@ -291,7 +301,7 @@ __device__ __forceinline__ void act_fused_body(const ActFusedArgs& A, const int 
                     for (int sx = 0; sx < 3; ++sx)
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct)
-                            bb[(sl + 1) & 1][sx][ct] = *reinterpret_cast<const uint4*>(img + (size_t)sx * kImgElems + (size_t)ct * (16 * 8 * 512) + (sl + 1) * 512);
+                            bb[(sl + 1) & 1][sx][ct] = *reinterpret_cast<const uint4*>(img + (size_t)sx * kImgElems + (size_t)ct * (16 * 8 * 512) + kHotSlab * (sl + 1) * 512);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the multiply (see the F32I loop)
 #pragma unroll

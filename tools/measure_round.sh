@@ -6,7 +6,7 @@
 # rank's launch sequence over RCCL at world size 1 (program directly after `--`: python3 <script>).
 set -uo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}
-TAG=${1:-r05}; QUICK=${2:-}
+TAG=${1:-r06}; QUICK=${2:-}
 O="$R/gpurun_out/$TAG"
 mkdir -p "$O"
 cd "$R"
@@ -37,6 +37,11 @@ done <<'CFGS'
 --actions uniform
 --staged
 --staged --no-front
+--batch 256
+--batch 256 --no-front
+--batch 512
+--batch 1024
+--batch 1024 --dtype bf16
 CFGS
 STEPS=4000
 stats() {  # stats <name> <bench flags...>: per-kernel stats of a $STEPS-step run under rocprofv3

@@ -35,6 +35,8 @@ if os.path.exists(p):
             continue
         c = x["config"]
         key = c["workload"].split(", 1 learn")[0]
+        if c.get("batch", 128) != 128:
+            key += f" [learn(B = {c['batch']})]"
         if "rccl_ranks" in x or "staged" in json.dumps(c):
             key += " [sharded rank's sequence]"
         if c.get("actions") == "uniform" or "uniform" in c["workload"]:
@@ -64,8 +66,17 @@ if d:
     print()
     r = d["roofline"]
     print(f"roofline (default run): {r['bound']} {r['achieved']} / {r['peak']} {r['unit']} = {r['frac']}; {r['us_per_launch']} µs per launch (live stamp); traffic {r['traffic']}; other roof {r['other_roof']['achieved']} GB/s = {r['other_roof']['frac']}")
-    if "executed" in r:
-        print(f"executed: {r['executed']['achieved']} TFLOP/s = {r['executed']['frac']} of the bf16 peak")
+    if "fp32_equivalent" in r:  # [r6] frac = executed bf16 FLOPs / bf16 peak; the fp32 arithmetic delivered is a RATIO beside it
+        q = r["fp32_equivalent"]
+        print(f"fp32-equivalent: {q['achieved']} TFLOP/s = {q['ratio_to_peak']} x the fp32 matrix peak (a ratio, not a roofline fraction)")
+    print("every line of the set: roofline.frac / other_roof.frac / roofline_act.frac / roofline_update.frac")
+    every = [("default", d)] + ([("driver form", dd)] if dd else []) + [(k + " / " + lp, x) for k, v in rows.items() for lp, x in v.items()]
+    worst = 0.0
+    for name, x in every:
+        fr = [x["roofline"]["frac"], x["roofline"].get("other_roof", {}).get("frac"), x.get("roofline_act", {}).get("frac"), x.get("roofline_update", {}).get("frac")]
+        worst = max([worst] + [f for f in fr if f is not None])
+        print(f"  {name[:90]:90s} " + " / ".join("-" if f is None else f"{f:.4f}" for f in fr))
+    print(f"largest frac of the set: {worst:.4f} (must be < 1)")
     print("env sweep:", " | ".join(f"{x['envs_per_launch']:,}: {x['us']} µs = {x['frac']}" for x in d["roofline_env_sweep"]))
     c = d["cpu_baseline"]
     print(f"cpu baseline: {c['value']:,.0f} env steps/s on {c['cores']} cores ({c.get('sample', '')[:120]}); B0 {c['b0_reference_plumbing']['value']}, B1 {c['b1_batched_cpu']['value']:,.0f}, B2 {c['b2_eager_rocm_learn']['value']}")
