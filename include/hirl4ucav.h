@@ -365,9 +365,12 @@ int hx_hirl_learn_sampled(const HxNets* nets, const HxBatch* batch, const HxHype
  * ones are launch B's two target-critic jobs (16 per 16-row tile: 128 at B = 128) and, with launch C riding, its TD jobs (256 more).  While the waiting
  * workgroups are FEWER than the CUs (256) — the default shape: B = 128, launch C on its own — a pending producer always finds a CU under ANY dispatch
  * order that places pending workgroups on free CUs, and a wait ends within the acting workgroups' ~20 us (HirlEngine.front_waiting_workgroups).
- * (One process per GPU: processes that share a GPU share its CUs, and their waiters add up.  Three processes free-running the default shapes on one GPU
- * still never tripped, 100,000 steps each in every acting role; with launch C riding the third process made the waits time out — the status word caught
- * it: profiles/r05_soak_front_shared_gpu.txt.)
+ * ONE PROCESS PER GPU: processes that share a GPU share its CUs, and their waiters add up — the argument above is void there.  Three processes
+ * free-running the default shapes on one GPU never tripped (100,000 steps each in every acting role; with launch C riding the third process made the
+ * waits time out and the status word caught it: profiles/r05_soak_front_shared_gpu.txt); EIGHT did, on a fresh box, and took round 5's test run with
+ * them (GPUTEST_r05: 1,024 waiters on 256 CUs).  So the callers decide by design, not by soak [r6]: bench.py and train_all take this entry point only
+ * when every rank has a device of its own (world <= visible devices) and run the reference's order otherwise; asked for explicitly on a shared device
+ * (bench.py --front, HX_FRONT_SHARED_GPU=1) the status word + fallback below are what stands between a trip and a wrong number.
  * At B = 256 or with launch C riding the waiting workgroups can fill the chip, and there THE ASSUMPTION BEHIND THE WAITS is needed: the workgroups of one
  * launch START in index order (producers have the lower indices), so a waiting workgroup's producers are running or done.  That is what gfx950 /
  * ROCm 7.2 does (free-running soaks of every acting role, launch C riding included: profiles/r04c_front_soak_*.json, profiles/r05_soak_front_roles.jsonl);
@@ -375,7 +378,9 @@ int hx_hirl_learn_sampled(const HxNets* nets, const HxBatch* batch, const HxHype
  * after ~20 us); only if EVERY resident workgroup were a waiting consumer could a wait run into its bound — then the status word says so, the minibatch
  * of that launch may have been read half-written, and the caller must not go on: read *status at least every few hundred launches (hirl4ucav_amd/
  * train_all.py --status_check_every, default 256: on a trip it reloads its last snapshot and continues in the reference's order in the same process, or
- * exits with code 3) and fall back to hx_actor_act_step_* + hx_hirl_learn_sampled (no in-launch waits; `train_all --loop reference`, `bench.py --no-front`).
+ * exits with code 3; bench.py reads it after the timed region and the second pass — one decision for all ranks — and on a trip repeats the whole run in
+ * the reference's order in the same process and labels the line `reference order (front tripped)`) and fall back to hx_actor_act_step_* +
+ * hx_hirl_learn_sampled (no in-launch waits; `train_all --loop reference`, `bench.py --no-front`).
  * (Roles taken in START order from a ticket would need no such assumption; measured, that costs 2.8 us of a 51.4 us step: docs/LEVERS.md, Round 5.)
  * hx_hirl_learn_back = the rest of the call (critic backward + gradients + Adam [+ the delayed actor step]) on the same `batch`; next / next_tiles
  * (or NULL): the draw of the NEXT front launch (guard = its n; *next->total is read inside this call's second launch, i.e. after this step's
