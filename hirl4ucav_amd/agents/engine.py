@@ -699,7 +699,7 @@ class HirlEngine:
     def front_c_for(self, n, actor_phase, w_kind, bf16):
         """Does launch C (the critics' backward) ride in the front launch of this call too (HxFront.with_c)?  `front_c`: True / False, or "auto" (default):
         only where the acting workgroups leave the other CUs more time than the update's workgroups need — CU time bounds the front launch
-        (profiles/r04c_front_c_ab.txt).  That is the STREAMING acting role (fp32 in the exact-split format, 8,192 .. 16,384 envs: one 64-row pass of ~37 us
+        (profiles/archive/r04c_front_c_ab.txt).  That is the STREAMING acting role (fp32 in the exact-split format, 8,192 .. 16,384 envs: one 64-row pass of ~37 us
         per acting workgroup) with few enough acting workgroups: forward workgroups cost ~6 us of a CU each, launch C's 7.6 (their rows are asked for
         behind the in-launch wait).  Around 8,192 envs: 67.1 -> 62.2 us per step; everywhere else it is slower (4,096 envs 54.1 -> 56.6 us), hence off."""
         if self.front_c != "auto":

@@ -125,7 +125,7 @@ static void make_launch_c(const HxNets* N, const HxBatch* Bt, const HxHyper* Hy,
 // Launch C inside the front launch (HxFront.with_c; its workgroups wait in-launch for launches A and B: hx_bwd_body.h) — the CALLER's choice, told to the
 // calls behind it as c_in_front.  Bit-identical either way (tests/test_front_gpu.py); it pays only where the acting workgroups leave the other CUs more
 // time than launches A, B AND C need (CU time bounds the front launch): the streaming acting role around 8,192 envs — 67.1 -> 62.2 us per step there,
-// 54.1 -> 56.6 at 4,096 envs fp32, 45.6 -> 49.8 bf16, 133.1 -> 136.4 at 131,072 bf16 (tools/ubench/front_c_ab.sh, profiles/r04c_front_c_ab.txt):
+// 54.1 -> 56.6 at 4,096 envs fp32, 45.6 -> 49.8 bf16, 133.1 -> 136.4 at 131,072 bf16 (tools/ubench/front_c_ab.sh, profiles/archive/r04c_front_c_ab.txt):
 // HirlEngine.front_c_for() holds the rule.  HX_FRONT_C = 0 / 1 (A/B knob, read once) overrides the caller in BOTH calls.
 static bool front_has_c(bool asked) {
     static const int force = getenv("HX_FRONT_C") ? atoi(getenv("HX_FRONT_C")) : -1;

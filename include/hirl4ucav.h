@@ -373,7 +373,7 @@ int hx_hirl_learn_sampled(const HxNets* nets, const HxBatch* batch, const HxHype
  * (bench.py --front, HX_FRONT_SHARED_GPU=1) the status word + fallback below are what stands between a trip and a wrong number.
  * At B = 256 or with launch C riding the waiting workgroups can fill the chip, and there THE ASSUMPTION BEHIND THE WAITS is needed: the workgroups of one
  * launch START in index order (producers have the lower indices), so a waiting workgroup's producers are running or done.  That is what gfx950 /
- * ROCm 7.2 does (free-running soaks of every acting role, launch C riding included: profiles/r04c_front_soak_*.json, profiles/r05_soak_front_roles.jsonl);
+ * ROCm 7.2 does (free-running soaks of every acting role, launch C riding included: profiles/archive/r04c_front_soak_*.json, profiles/r05_soak_front_roles.jsonl);
  * HIP promises no dispatch order.  Under another order a wait still ends as soon as the producers get a CU (the acting workgroups never wait and leave
  * after ~20 us); only if EVERY resident workgroup were a waiting consumer could a wait run into its bound — then the status word says so, the minibatch
  * of that launch may have been read half-written, and the caller must not go on: read *status at least every few hundred launches (hirl4ucav_amd/

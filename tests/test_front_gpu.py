@@ -203,7 +203,7 @@ def test_front_launch_default_acting_format_is_the_exact_split(eng_mod):
 def test_launch_c_rides_only_where_the_cus_have_time_for_it(eng_mod):
     """HirlEngine.front_c_for: OFF by default since round 5 (the one size class where launch C inside the front launch paid — 8,192 envs fp32 — reads 62.1 -> 61.4 us
     with the six-term acting format, profiles/r05_front_c_8192.txt); "auto" = round 4's rule: only in the streaming acting role around 8,192 envs (fp32, exact
-    split) — measured slower everywhere else (profiles/r04c_front_c_ab.txt); True / False force it.  (That the results do not depend on it:
+    split) — measured slower everywhere else (profiles/archive/r04c_front_c_ab.txt); True / False force it.  (That the results do not depend on it:
     test_launch_c_inside_the_front_launch_is_bit_identical forces it for every acting role.)"""
     e = eng_mod.HirlEngine(batch=128, use_bc=True)
     assert e.front_c is False and not e.front_c_for(8192, True, 0, False)
