@@ -635,7 +635,7 @@ def probe_exchanges(ctx, loop):
     entry, out, err, rc = {"transport": "twostage", "where": "child processes (tools/exchange_probe.py)"}, "", "", None
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)  # a CHILD: nothing here replaces this process
     try:
-        out, err = child.communicate(timeout=120)
+        out, err = child.communicate(timeout=90)
         rc = child.returncode
     except subprocess.TimeoutExpired:
         child.kill()
