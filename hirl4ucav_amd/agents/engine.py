@@ -235,7 +235,8 @@ class HirlEngine:
     def set_act_dtype(self, dtype):
         """"f32": policy inference on fp32 MFMA (parity 1e-5).  "bf16": its 256 -> 512 layer on bf16 MFMA from a bf16 image of W2 that
         every actor Adam step keeps current (BASELINE.json configs[4]); what learn() computes in is set_update_dtype's business.
-        "f32x9": fp32 policy inference with the 256 -> 512 product through the EXACT three-way bf16 split of both operands on the bf16 matrix cores (six of the nine partial products — the three below fp32 resolution are not formed; hx_actor_act_x9:
+        "f32x9": fp32 policy inference with the 256 -> 512 product through the EXACT three-way bf16 split of both operands on the bf16 matrix cores (six of
+        the nine partial products — the three below fp32 resolution are not formed; hx_actor_act_x9:
         fp32 operands, every partial product exact, fp32 accumulation — fp32 results up to summation order); fp32 update only."""
         if dtype not in ("f32", "bf16", "f32x9"):
             raise ValueError(dtype)

@@ -502,7 +502,9 @@ def main(config):
             print(f"Validation {arttir}: avg reward {mean:.2f} (std {std:.2f}) success {succ / 50:.2f} fire success {fire / 50:.2f}", flush=True)
             log_validation(writer, episode, mean, std, succ / 50, fire / 50)
             arttir += 1
-        if world > 1 and ((episode + 1) % checkpoint_rate == 0 or (config.replica_check_every and (episode + 1) % config.replica_check_every == 0)):  # sharded run: the replicas must not have drifted apart
+        # sharded run: the replicas must not have drifted apart
+        check_due = (episode + 1) % checkpoint_rate == 0 or (config.replica_check_every and (episode + 1) % config.replica_check_every == 0)
+        if world > 1 and check_due:
             mine = torch.tensor([eng.replica_checksum()], dtype=torch.int64, device=device)
             every = [torch.zeros_like(mine) for _ in range(world)]
             torch.distributed.all_gather(every, mine)
@@ -549,7 +551,8 @@ def parser():
     p.add_argument("--checkpoint_rate", type=int, default=25, help="episodes between validations (train_all.py:206)")
     p.add_argument("--bc_validate_from", type=int, default=1000, help="BC: first episode with validation (train_all.py:259)")
     p.add_argument("--loop", type=str, default="front", choices=["front", "reference"],
-                   help="front (default where it applies: HIRL / TD3 in fp32 or bf16 actor + critic, SAC / E-SAC beyond 8,192 envs on one GPU; batch <= 256, one update per step): env step + the first "
+                   help="front (default where it applies AND every rank has a GPU of its own: HIRL / TD3 in fp32 or bf16 actor + critic, SAC / E-SAC beyond 8,192 envs on "
+                        "one GPU; batch <= 256, one update per step; ranks that share a GPU run the reference's order): env step + the first "
                         "launches of learn() as one launch; the minibatch is drawn from the ring as it stood before the step's insert, without the slots it may "
                         "overwrite.  reference: act -> env step -> insert -> draw -> learn on every step (the minibatch sees this step's transitions)")
     p.add_argument("--separate_launches", action="store_true",
