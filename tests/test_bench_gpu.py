@@ -349,6 +349,7 @@ def test_bench_eight_ranks_two_stage_exchange():
     """the same eight ranks through the peer-read kernels (seven hipIpc mappings per rank, the 8-way slices of hx_allreduce_twostage)"""
     d, = run_many([PEER + ["--gpus", "8", "--exchange", "twostage"]], nproc=8, env=GLOO, timeout=900)
     check_two_ranks(d, 12, 2, "twostage", world=8)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "r06_bench_8ranks_one_gpu_twostage.json"), "w") as f:
         json.dump(d, f)
 
